@@ -1,0 +1,228 @@
+/* macx.h -- C ABI of libmacx.so: the MI355X-native MAC reasoning cell.
+ *
+ * The reference (stanfordnlp/mac-network) has no FFI: its hot path is the Python class
+ * MACCell (mac_cell.py:30-592) driven by MACnet.MACnetwork (model.py:428-489), and all
+ * arithmetic lives in the TensorFlow-1.x runtime.  This header is the boundary a maintainer
+ * would bind to replace that class's arithmetic (ctypes stub in INTEGRATION.md).  Every entry
+ * point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all tensors fp32, row-major, contiguous, 16-byte aligned;
+ *     question lengths int32.  All pointers are DEVICE pointers unless marked host.
+ *   - ownership: the caller owns every buffer (parameters, inputs, `saved`, `ws`, gradients).
+ *     The library never allocates, frees or retains device memory.
+ *   - asynchronous: work is enqueued on `stream`; nothing synchronises the device.
+ *   - errors: 0 on success, a negative MACX_E* code for a rejected call, or the positive
+ *     hipError_t of a failed launch.  No exceptions, no abort().
+ *   - determinism: no floating-point atomics anywhere; weight gradients use fixed-order
+ *     slab reductions, so two runs on the same inputs are bit-identical.
+ */
+#ifndef MACX_H
+#define MACX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MACX_ABI_VERSION 1
+
+enum {
+  MACX_OK = 0,
+  MACX_EINVAL = -1,      /* malformed shapes / null pointer / misaligned pointer            */
+  MACX_EUNSUPPORTED = -2,/* legal reference option combination without a HIP path yet       */
+  MACX_EREJECTED = -3,   /* option value that raises in the reference   */
+  MACX_ESMALL = -4       /* `saved` or `ws` smaller than macx_saved_floats / macx_ws_floats */
+};
+
+/* activation codes (ops.py:181-187; "RELU" resolves through config.relu, ops.py:161-179) */
+enum { MACX_ACT_NON = 0, MACX_ACT_TANH = 1, MACX_ACT_SIGMOID = 2, MACX_ACT_ELU = 3, MACX_ACT_RELU = 4 };
+/* state initialisation (mac_cell.py:496-505) */
+enum { MACX_INIT_PRM = 0, MACX_INIT_ZERO = 1, MACX_INIT_Q = 2 };
+/* write-unit inputs (mac_cell.py:333-340) */
+enum { MACX_WRITE_MEM = 0, MACX_WRITE_INFO = 1, MACX_WRITE_SUM = 2, MACX_WRITE_BOTH = 3 };
+
+/* Frozen option surface: the subset of config.py flags (config.py:194-223, 292-387) the cell
+ * branches on, resolved to integers by the host (mac-network_amd/options.py). */
+typedef struct macx_opts {
+  int32_t abi_version;              /* MACX_ABI_VERSION                                        */
+  int32_t init_ctrl, init_mem;      /* --initCtrl / --initMem                                  */
+  int32_t control_input_unshared;   /* --controlInputUnshared     (mac_cell.py:430-432)        */
+  int32_t control_input_act;        /* --controlInputAct          (mac_cell.py:445)            */
+  int32_t control_feed_prev;        /* --controlFeedPrev          (mac_cell.py:142)            */
+  int32_t control_feed_prev_att;    /* --controlFeedPrevAtt       (mac_cell.py:143)            */
+  int32_t control_feed_inputs;      /* --controlFeedInputs        (mac_cell.py:144-146)        */
+  int32_t control_cont_act;         /* --controlContAct           (mac_cell.py:149-150)        */
+  int32_t read_mem_act;             /* --readMemAct resolved      (mac_cell.py:237)            */
+  int32_t read_ctrl_act;            /* --readCtrlAct resolved     (mac_cell.py:262)            */
+  int32_t write_inputs;             /* --writeInputs              (mac_cell.py:333-340)        */
+  int32_t write_self_att;           /* --writeSelfAtt             (mac_cell.py:316-330)        */
+  int32_t write_self_att_cont;      /* --writeSelfAttMod == CONT  (mac_cell.py:318-319)        */
+  int32_t write_mem_act;            /* --writeMemAct resolved     (mac_cell.py:355)            */
+  int32_t write_gate;               /* --writeGate                (mac_cell.py:358-367)        */
+  int32_t write_gate_shared;        /* --writeGateShared          (mac_cell.py:360-361)        */
+  float   write_gate_bias;          /* --writeGateBias            (mac_cell.py:363)            */
+  int32_t memory_variational_dropout; /* --memoryVariationalDropout (mac_cell.py:214-217)      */
+} macx_opts;
+
+typedef struct macx_shapes {
+  int32_t B;     /* questions in this (shard of the) batch                                     */
+  int32_t S;     /* padded question length                                                     */
+  int32_t N;     /* knowledge-base cells per question (H*W, model.py:202)                      */
+  int32_t d;     /* memDim == ctrlDim == attDim (config.py:294-296); multiple of 128           */
+  int32_t p;     /* netLength (config.py:292)                                                  */
+  int32_t b0;    /* global index of question 0: data-parallel shard offset (model.py:139-149)  */
+} macx_shapes;
+
+/* Dropout of one cell run.  keep == 1 (evaluation, model.py:118-125) is the exact identity. */
+typedef struct macx_dropout {
+  float keep_memory, keep_read, keep_write;   /* config.py:213-215                              */
+  uint32_t seed;                              /* stateless mask stream, see macx_dropout_mask  */
+} macx_dropout;
+
+/* Parameters, keyed by the reference's variable names under macModel/MACnetwork/ (SURVEY 8b).
+ * Matrices are [in, out] row-major exactly as tf.get_variable stores them. */
+typedef struct macx_params {
+  const float* initMem;        /* initMem [d]                         (mac_cell.py:498)         */
+  const float* initCtrl;       /* initCtrl [d]           (PRM only)                             */
+  const float* qInput_W;       /* MACCell/linearLayerqInput/weights/weight [d,d]                */
+  const float* qInput_b;       /*                       .../biases/bias [d]                     */
+  const float* qInputU_W;      /* linearLayerqInput{i} stacked [p,d,d] (or [1,d,d] if shared)   */
+  const float* qInputU_b;      /* [p,d] / [1,d]                                                 */
+  const float* ctrlLogits_w;   /* control/inter2logits/linearLayerlogits/weights/weight [d]     */
+  const float* ctrlLogits_b;   /* .../biases/bias []                                            */
+  const float* contControl_W;  /* control/linearLayercontControl [d or 2d, d]   (args1)         */
+  const float* contControl_b;
+  const float* contControl2_W; /* .../linearLayercontControl_2 [d,d]   (controlContAct != NON)  */
+  const float* contControl2_b;
+  const float* projX_W;        /* read/mulmemInter/linearLayerprojX [d,d]                       */
+  const float* projX_b;
+  const float* projY_W;        /* read/mulmemInter/linearLayerprojY [d,d]                       */
+  const float* projY_b;
+  const float* memKbProj_W;    /* read/linearLayermemKbProj [2d,d]: rows [0,d) x*y, [d,2d) x    */
+  const float* memKbProj_b;
+  const float* memKbProj2_W;   /* read/linearLayermemKbProj/linearLayermemKbProj_2 [d,d]        */
+  const float* memKbProj2_b;
+  const float* kbLogits_w;     /* read/inter2att/inter2logits/linearLayerlogits [d]             */
+  const float* kbLogits_b;
+  const float* newMemory_W;    /* write/linearLayernewMemory [2d or 3d, d]                      */
+  const float* newMemory_b;
+  const float* selfCtrl_W;     /* write/linearLayerctrlProj [d,d]               (args3)         */
+  const float* selfCtrl_b;
+  const float* selfLogits_w;   /* write/inter2attselfAttention/.../linearLayerlogits [d]        */
+  const float* selfLogits_b;
+  const float* gate_W;         /* write/linearLayergate [d, d or 1]             (args4)         */
+  const float* gate_b;
+} macx_params;
+
+/* Gradients: same fields, written (not accumulated) by macx_cell_backward. */
+typedef struct macx_param_grads {
+  float* initMem; float* initCtrl;
+  float* qInput_W; float* qInput_b; float* qInputU_W; float* qInputU_b;
+  float* ctrlLogits_w; float* ctrlLogits_b;
+  float* contControl_W; float* contControl_b; float* contControl2_W; float* contControl2_b;
+  float* projX_W; float* projX_b; float* projY_W; float* projY_b;
+  float* memKbProj_W; float* memKbProj_b; float* memKbProj2_W; float* memKbProj2_b;
+  float* kbLogits_w; float* kbLogits_b;
+  float* newMemory_W; float* newMemory_b;
+  float* selfCtrl_W; float* selfCtrl_b; float* selfLogits_w; float* selfLogits_b;
+  float* gate_W; float* gate_b;
+} macx_param_grads;
+
+/* Cell inputs: the tensors MACCell.__init__ stores (mac_cell.py:59-79). */
+typedef struct macx_inputs {
+  const float* vecQuestions;     /* [B,d]                                                        */
+  const float* words;            /* [B,S,d]  questionCntxWords or questionWords (mac_cell.py:570) */
+  const int32_t* questionLengths;/* [B]                                                          */
+  const float* knowledgeBase;    /* [B,N,d]  stem output (model.py:202)                          */
+} macx_inputs;
+
+typedef struct macx_input_grads {
+  float* vecQuestions;           /* [B,d]                                                        */
+  float* words;                  /* [B,S,d]                                                      */
+  float* knowledgeBase;          /* [B,N,d]                                                      */
+} macx_input_grads;
+
+/* Segments of the `saved` buffer that the host may view (offsets in floats). */
+enum {
+  MACX_SEG_CONTROLS = 0,   /* [p+1,B,d]  controls history, entry 0 = initial (mac_cell.py:549,472) */
+  MACX_SEG_MEMORIES = 1,   /* [p+1,B,d]  memories history                     (mac_cell.py:550,473) */
+  MACX_SEG_INFOS = 2,      /* [p,B,d]    retrieved information per step       (mac_cell.py:474)     */
+  MACX_SEG_ATT_QUESTION = 3,/* [p,B,S]   attentions["question"]               (mac_cell.py:176)     */
+  MACX_SEG_ATT_KB = 4,     /* [p,B,N]    attentions["kb"]                     (mac_cell.py:268)     */
+  MACX_SEG_ATT_SELF = 5,   /* [p,B,p]    attentions["self"], row i uses i+1   (mac_cell.py:329)     */
+  MACX_SEG_ATT_GATE = 6,   /* [p,B,d|1]  attentions["gate"]                   (mac_cell.py:365)     */
+  MACX_SEG_COUNT = 7
+};
+
+/* ---- sizing -------------------------------------------------------------------------------- */
+/* floats the caller must provide in `saved` (kept from forward to backward) and `ws` (scratch).
+ * keep_activations = 1 keeps the per-step [B,N,d] read-unit activations needed by backward. */
+size_t macx_saved_floats(const macx_opts*, const macx_shapes*, int keep_activations);
+size_t macx_ws_floats(const macx_opts*, const macx_shapes*, int for_backward);
+/* offset (floats) and element count of a viewable segment of `saved`; returns MACX_OK or error */
+int macx_saved_segment(const macx_opts*, const macx_shapes*, int keep_activations, int segment,
+                       size_t* offset, size_t* count);
+/* validates an option/shape combination exactly as macx_cell_begin would */
+int macx_check(const macx_opts*, const macx_shapes*);
+
+/* ---- the cell ------------------------------------------------------------------------------ */
+/* Replaces MACCell.zero_state (mac_cell.py:539-592): initial control/memory, histories, memory
+ * variational-dropout stream; additionally packs the weights for the MFMA kernels and, when the
+ * control is not recurrent (controlFeedPrev off), computes all p control states up front
+ * (mac_cell.py:442-451, :133-187). */
+int macx_cell_begin(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*,
+                    const macx_inputs*, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                    int keep_activations, void* stream);
+
+/* Replaces one MACCell.__call__ (mac_cell.py:420-480) for iteration `step`: control (if
+ * recurrent), read, write, history append.  Must be called with step = 0..p-1 in order. */
+int macx_cell_step(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*,
+                   const macx_inputs*, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                   int keep_activations, int step, void* stream);
+
+/* begin + p steps in one call (the loop of model.py:453-458). */
+int macx_cell_forward(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*,
+                      const macx_inputs*, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                      int keep_activations, void* stream);
+
+/* Gradient of the whole p-step run (what tf.gradients builds for model.py:453-458).
+ * d_memory / d_control: [B,d] gradients of the final state (either may be NULL = zero).
+ * Requires `saved` from a forward run with keep_activations = 1 and the same dropout struct. */
+int macx_cell_backward(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*,
+                       const macx_inputs*, const float* saved, size_t saved_floats,
+                       float* ws, size_t ws_floats,
+                       const float* d_memory, const float* d_control,
+                       const macx_param_grads*, const macx_input_grads*, void* stream);
+
+/* ---- unit-level entry points (the ops.py primitives; used by the parity tests) -------------- */
+/* out[r, :] = act(concat(x1[r], x2[r]) @ W + b + bias_const)     ops.linear (ops.py:298-333) */
+int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows,
+                const float* W, const float* b, float bias_const, int n_out, int act,
+                float* out, void* stream);
+/* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688).  `ws` >= d*d floats. */
+int macx_kb_project(const macx_shapes*, const macx_dropout*, int step, const float* kb,
+                    const float* W, const float* b, float* out, float* ws, void* stream);
+/* softmax(expMask(logits)) + att2Smry over the question words for one step
+ * (mac_cell.py:155-181; ops.py:114-150, 243-247).  cc: continuous control [B,d]. */
+int macx_control_attend(const macx_shapes*, const float* cc, const float* words, const int32_t* lengths,
+                        const float* w, const float* b, float* att, float* control, void* stream);
+/* Materialises the 0/1 keep mask of a dropout site for n elements starting at flat index
+ * `first` (test hook for the stateless stream; site numbers in macx_common.cuh). */
+int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
+                      size_t n, float* out, void* stream);
+/* weight-gradient contraction out[k][j] = sum_m A[m][k] G[m][j]  (fixed-order split reduction).
+ * `ws` >= nsplit*Kd*Jd floats where nsplit = macx_wgrad_splits(M, Kd, Jd). */
+int macx_wgrad_splits(int M, int Kd, int Jd);
+int macx_wgrad(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd,
+               float* out, float* ws, void* stream);
+
+const char* macx_strerror(int code);
+int macx_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MACX_H */

@@ -1,0 +1,10 @@
+"""mac-network_amd: an MI355X-native MAC reasoning cell (control / read / write units of
+stanfordnlp/mac-network's mac_cell.py and the ops.py primitives they call) behind the
+reference's own MACCell interface.  Import with `importlib.import_module("mac-network_amd")`
+or through the `macx` alias module at the repo root."""
+from . import _lib, build, options, params          # noqa: F401
+from .cell import MACCell, MACCellTuple             # noqa: F401
+from .options import UnsupportedOptions, freeze     # noqa: F401
+from .params import MACCellParams                   # noqa: F401
+
+__all__ = ["MACCell", "MACCellTuple", "MACCellParams", "UnsupportedOptions", "freeze"]

@@ -1,0 +1,125 @@
+"""ctypes binding of libmacx.so -- the C ABI declared in include/macx.h.
+
+The product path has NO CPU fallback: if the library is missing or does not export the ABI this
+module raises, and every op built on it fails loudly.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+ABI_VERSION = 1
+
+MACX_OK, MACX_EINVAL, MACX_EUNSUPPORTED, MACX_EREJECTED, MACX_ESMALL = 0, -1, -2, -3, -4
+ACT = {"NON": 0, "TANH": 1, "SIGMOID": 2, "ELU": 3, "RELU": 4}
+INIT = {"PRM": 0, "ZERO": 1, "Q": 2}
+WRITE_INPUTS = {"MEM": 0, "INFO": 1, "SUM": 2, "BOTH": 3}
+SEG = {"controls": 0, "memories": 1, "infos": 2, "att_question": 3, "att_kb": 4, "att_self": 5, "att_gate": 6}
+
+
+class MacxOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "init_ctrl", "init_mem", "control_input_unshared", "control_input_act", "control_feed_prev",
+        "control_feed_prev_att", "control_feed_inputs", "control_cont_act", "read_mem_act", "read_ctrl_act",
+        "write_inputs", "write_self_att", "write_self_att_cont", "write_mem_act", "write_gate", "write_gate_shared")]
+    _fields_ += [("write_gate_bias", C.c_float), ("memory_variational_dropout", C.c_int32)]
+
+
+class MacxShapes(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "S", "N", "d", "p", "b0")]
+
+
+class MacxDropout(C.Structure):
+    _fields_ = [("keep_memory", C.c_float), ("keep_read", C.c_float), ("keep_write", C.c_float), ("seed", C.c_uint32)]
+
+
+PARAM_FIELDS = (
+    "initMem", "initCtrl", "qInput_W", "qInput_b", "qInputU_W", "qInputU_b", "ctrlLogits_w", "ctrlLogits_b",
+    "contControl_W", "contControl_b", "contControl2_W", "contControl2_b", "projX_W", "projX_b", "projY_W", "projY_b",
+    "memKbProj_W", "memKbProj_b", "memKbProj2_W", "memKbProj2_b", "kbLogits_w", "kbLogits_b", "newMemory_W",
+    "newMemory_b", "selfCtrl_W", "selfCtrl_b", "selfLogits_w", "selfLogits_b", "gate_W", "gate_b")
+
+
+class MacxParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
+
+
+class MacxParamGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
+
+
+class MacxInputs(C.Structure):
+    _fields_ = [("vecQuestions", C.c_void_p), ("words", C.c_void_p), ("questionLengths", C.c_void_p),
+                ("knowledgeBase", C.c_void_p)]
+
+
+class MacxInputGrads(C.Structure):
+    _fields_ = [("vecQuestions", C.c_void_p), ("words", C.c_void_p), ("knowledgeBase", C.c_void_p)]
+
+
+EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats", "macx_ws_floats",
+           "macx_saved_segment", "macx_cell_begin", "macx_cell_step", "macx_cell_forward", "macx_cell_backward",
+           "macx_linear", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_wgrad_splits",
+           "macx_wgrad")
+
+_lib = None
+
+
+class MacxError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().macx_strerror(code).decode() if _lib is not None else str(code)
+        super().__init__("%s failed: %s (code %d)" % (where, msg, code))
+
+
+def lib():
+    """Load libmacx.so (building it if the sources are newer).  Raises if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path) or os.environ.get("MACX_REBUILD"):
+        path = _build.build()
+    L = C.CDLL(path)
+    missing = [n for n in EXPORTS if not hasattr(L, n)]
+    if missing:
+        raise ImportError("libmacx.so lacks symbols: %s" % missing)
+    L.macx_abi_version.restype = C.c_int
+    if L.macx_abi_version() != ABI_VERSION:
+        raise ImportError("libmacx.so ABI %d != binding ABI %d" % (L.macx_abi_version(), ABI_VERSION))
+    L.macx_strerror.restype = C.c_char_p
+    L.macx_strerror.argtypes = [C.c_int]
+    P = C.POINTER
+    L.macx_check.argtypes = [P(MacxOpts), P(MacxShapes)]
+    L.macx_saved_floats.restype = C.c_size_t
+    L.macx_saved_floats.argtypes = [P(MacxOpts), P(MacxShapes), C.c_int]
+    L.macx_ws_floats.restype = C.c_size_t
+    L.macx_ws_floats.argtypes = [P(MacxOpts), P(MacxShapes), C.c_int]
+    L.macx_saved_segment.argtypes = [P(MacxOpts), P(MacxShapes), C.c_int, C.c_int, P(C.c_size_t), P(C.c_size_t)]
+    common = [P(MacxOpts), P(MacxShapes), P(MacxDropout), P(MacxParams), P(MacxInputs), C.c_void_p, C.c_size_t,
+              C.c_void_p, C.c_size_t]
+    L.macx_cell_begin.argtypes = common + [C.c_int, C.c_void_p]
+    L.macx_cell_step.argtypes = common + [C.c_int, C.c_int, C.c_void_p]
+    L.macx_cell_forward.argtypes = common + [C.c_int, C.c_void_p]
+    L.macx_cell_backward.argtypes = common + [C.c_void_p, C.c_void_p, P(MacxParamGrads), P(MacxInputGrads), C.c_void_p]
+    L.macx_linear.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                              C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.macx_kb_project.argtypes = [P(MacxShapes), P(MacxDropout), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
+    L.macx_control_attend.argtypes = [P(MacxShapes)] + [C.c_void_p] * 8
+    L.macx_dropout_mask.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_void_p,
+                                    C.c_void_p]
+    L.macx_wgrad_splits.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.macx_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                             C.c_void_p]
+    for n in EXPORTS:
+        f = getattr(L, n)
+        if f.restype is C.c_int or n in ("macx_check",):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(code, where):
+    if code != 0:
+        raise MacxError(code, where)

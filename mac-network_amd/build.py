@@ -1,0 +1,59 @@
+"""Builds libmacx.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+No torch.utils.cpp_extension (it hipifies), no Triton, no BLAS: one translation unit, one
+`hipcc --offload-arch=gfx950 -shared -fPIC` command.  The .so is git-ignored but travels to the GPU
+box with the repo snapshot.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmacx.so")
+STAMP = LIB_PATH + ".stamp"
+SOURCES = ["macx_api.hip"]
+HEADERS = ["macx_common.cuh", "macx_gemm.cuh", "macx_gemm_tn.cuh", "macx_small.cuh", os.path.join(ROOT, "include", "macx.h")]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        p = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def hipcc_path():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    """Compile libmacx.so for gfx950 if sources changed.  Returns the library path."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    dig = _digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            if fh.read().strip() == dig:
+                return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-Wno-pass-failed", "-I", os.path.join(ROOT, "include")]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as fh:
+        fh.write(dig)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,287 @@
+"""MACCell -- the host-side mirror of the reference's recurrent cell (mac_cell.py:30-592) over
+libmacx.so.
+
+Same constructor arguments, `zero_state`, per-step `__call__`, `.iteration`, `.attentions`,
+`.controls/.memories/.infos` as the reference class, so the loop of model.py:453-458 runs
+unchanged:
+
+    cell = MACCell(vecQuestions=..., questionWords=..., questionCntxWords=..., questionLengths=...,
+                   knowledgeBase=..., memoryDropout=..., readDropout=..., writeDropout=...,
+                   batchSize=B, train=True, config=config, params=params)
+    state = cell.zero_state(B)
+    for i in range(config.netLength):
+        cell.iteration = i
+        _, state = cell(none, state)
+
+All arithmetic runs in hand-written HIP kernels behind the C ABI of include/macx.h; PyTorch only
+owns the device memory and the stream.  There is no CPU or eager fallback: without a loadable
+libmacx.so or without a HIP device every entry point raises.
+"""
+import collections
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .options import freeze, get
+from .params import MACCellParams
+
+MACCellTuple = collections.namedtuple("MACCellTuple", ("control", "memory"))   # mac_cell.py:8
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the HIP device: the MAC cell has no CPU path" % name)
+    return t.contiguous()
+
+
+class _Run:
+    """One cell run: shapes, frozen options, buffers, and the ctypes structs that describe them."""
+
+    def __init__(self, cell, keep_activations):
+        self.cell = cell
+        self.keep = int(bool(keep_activations))
+        self.L = _lib.lib()
+        self.opts = cell.opts
+        B, S, d = cell.words.shape
+        N = cell.knowledgeBase.shape[1]
+        self.shapes = _lib.MacxShapes(B=B, S=S, N=N, d=d, p=cell.netLength, b0=cell.b0)
+        _lib.check(self.L.macx_check(C.byref(self.opts), C.byref(self.shapes)), "macx_check")
+        self.drop = _lib.MacxDropout(keep_memory=cell.dropouts["memory"], keep_read=cell.dropouts["read"],
+                                     keep_write=cell.dropouts["write"], seed=cell.seed & 0xFFFFFFFF)
+        dev = cell.knowledgeBase.device
+        self.saved_floats = self.L.macx_saved_floats(C.byref(self.opts), C.byref(self.shapes), self.keep)
+        self.saved = torch.empty(self.saved_floats, dtype=torch.float32, device=dev)
+        self.ws_fwd = torch.empty(max(4, self.L.macx_ws_floats(C.byref(self.opts), C.byref(self.shapes), 0)),
+                                  dtype=torch.float32, device=dev)
+        self.params = cell.params
+        self.pstruct = _lib.MacxParams()
+        self._ptensors = {}
+        for f in _lib.PARAM_FIELDS:
+            t = getattr(self.params, f, None) if f in self.params.fields else None
+            if t is not None:
+                t = _f32c(t.detach(), f)
+                self._ptensors[f] = t
+            setattr(self.pstruct, f, t.data_ptr() if t is not None else None)
+        self.inputs = _lib.MacxInputs(vecQuestions=cell.vecQuestions.data_ptr(), words=cell.words.data_ptr(),
+                                      questionLengths=cell.questionLengths.data_ptr(),
+                                      knowledgeBase=cell.knowledgeBase.data_ptr())
+        self.stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def _common(self):
+        return (C.byref(self.opts), C.byref(self.shapes), C.byref(self.drop), C.byref(self.pstruct), C.byref(self.inputs),
+                _ptr(self.saved), C.c_size_t(self.saved_floats), _ptr(self.ws_fwd), C.c_size_t(self.ws_fwd.numel()))
+
+    def begin(self):
+        _lib.check(self.L.macx_cell_begin(*self._common(), self.keep, self.stream), "macx_cell_begin")
+
+    def step(self, i):
+        _lib.check(self.L.macx_cell_step(*self._common(), self.keep, int(i), self.stream), "macx_cell_step")
+
+    def forward(self):
+        _lib.check(self.L.macx_cell_forward(*self._common(), self.keep, self.stream), "macx_cell_forward")
+
+    def segment(self, name, shape):
+        off, cnt = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(self.L.macx_saved_segment(C.byref(self.opts), C.byref(self.shapes), self.keep, _lib.SEG[name],
+                                             C.byref(off), C.byref(cnt)), "macx_saved_segment")
+        n = 1
+        for x in shape:
+            n *= x
+        if n > cnt.value:
+            raise ValueError("segment %s holds %d floats, view wants %d" % (name, cnt.value, n))
+        return self.saved[off.value: off.value + n].view(*shape)
+
+    def backward(self, d_control, d_memory):
+        if not self.keep:
+            raise RuntimeError("this run did not keep its activations (train=False / no_grad)")
+        dev = self.saved.device
+        ws_floats = self.L.macx_ws_floats(C.byref(self.opts), C.byref(self.shapes), 1)
+        ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
+        gstruct = _lib.MacxParamGrads()
+        grads = {}
+        for f in _lib.PARAM_FIELDS:
+            if f in self._ptensors:
+                g = torch.zeros_like(self._ptensors[f])
+                grads[f] = g
+                setattr(gstruct, f, g.data_ptr())
+            else:
+                setattr(gstruct, f, None)
+        cell = self.cell
+        gi_vq = torch.empty_like(cell.vecQuestions)
+        gi_words = torch.empty_like(cell.words)
+        gi_kb = torch.empty_like(cell.knowledgeBase)
+        gistruct = _lib.MacxInputGrads(vecQuestions=gi_vq.data_ptr(), words=gi_words.data_ptr(),
+                                       knowledgeBase=gi_kb.data_ptr())
+        dm = _f32c(d_memory, "d_memory") if d_memory is not None else None
+        dc = _f32c(d_control, "d_control") if d_control is not None else None
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(self.L.macx_cell_backward(
+            C.byref(self.opts), C.byref(self.shapes), C.byref(self.drop), C.byref(self.pstruct), C.byref(self.inputs),
+            _ptr(self.saved), C.c_size_t(self.saved_floats), _ptr(ws), C.c_size_t(ws_floats), _ptr(dm), _ptr(dc),
+            C.byref(gstruct), C.byref(gistruct), stream), "macx_cell_backward")
+        return grads, gi_vq, gi_words, gi_kb
+
+
+class _CellFunction(torch.autograd.Function):
+    """Autograd node for one whole p-step run.  mode 'run' executes the forward here; mode 'adopt'
+    wraps a forward that the per-step API already executed."""
+
+    @staticmethod
+    def forward(ctx, run, mode, vecQ, words, kb, *params):
+        if mode == "run":
+            run.begin_and_forward()
+        ctx.run = run
+        p = run.shapes.p
+        controls = run.segment("controls", (p + 1, run.shapes.B, run.shapes.d))
+        memories = run.segment("memories", (p + 1, run.shapes.B, run.shapes.d))
+        return controls[p].clone(), memories[p].clone()
+
+    @staticmethod
+    def backward(ctx, d_control, d_memory):
+        run = ctx.run
+        grads, gvq, gwords, gkb = run.backward(d_control, d_memory)
+        pgrads = tuple(grads[f] for f in run.params.fields)
+        return (None, None, gvq, gwords, gkb) + pgrads
+
+
+def _begin_and_forward(self):
+    self.forward()
+
+
+_Run.begin_and_forward = _begin_and_forward
+
+
+class MACCell:
+    """Drop-in for mac_cell.MACCell.  Extra keyword arguments (all optional):
+    config   object with the reference's flag names (default: the reference defaults)
+    params   MACCellParams (default: freshly initialised like tf.get_variable would)
+    seed     dropout stream seed;  b0  global index of this shard's first question (data parallel)
+    """
+
+    def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
+                 memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
+                 netLength=None, seed=0, b0=0):
+        from types import SimpleNamespace
+        self.config = config if config is not None else SimpleNamespace()
+        self.opts = freeze(self.config)           # raises for rejected / unsupported option sets
+        self.netLength = int(netLength if netLength is not None else get(self.config, "netLength"))
+        self.vecQuestions = _f32c(vecQuestions, "vecQuestions")
+        self.questionWords = questionWords
+        self.questionCntxWords = questionCntxWords
+        # word source select, mac_cell.py:570
+        words = questionCntxWords if get(self.config, "controlContextual") else questionWords
+        self._words_src = words
+        self.words = _f32c(words, "question words")
+        if questionLengths.dtype != torch.int32:
+            questionLengths = questionLengths.to(torch.int32)
+        self.questionLengths = questionLengths.contiguous()
+        self._kb_src = knowledgeBase
+        self._vq_src = vecQuestions
+        self.knowledgeBase = _f32c(knowledgeBase, "knowledgeBase")
+        train = bool(train)
+        self.train = train
+        # evaluation feeds keep = 1.0 to every dropout placeholder (model.py:118-125)
+        self.dropouts = {"memory": float(memoryDropout) if train else 1.0,
+                         "read": float(readDropout) if train else 1.0,
+                         "write": float(writeDropout) if train else 1.0}
+        self.batchSize = int(batchSize)
+        self.reuse = reuse
+        self.seed = int(seed)
+        self.b0 = int(b0)
+        self.params = params if params is not None else MACCellParams(self.config, self.netLength, device=self.knowledgeBase.device)
+        self.none = torch.zeros((self.batchSize, 1), dtype=torch.float32, device=self.knowledgeBase.device)
+        self.iteration = 0
+        self._run = None
+
+    # mac_cell.py:84-93
+    @property
+    def state_size(self):
+        d = get(self.config, "memDim")
+        return MACCellTuple(d, d)
+
+    @property
+    def output_size(self):
+        return 1
+
+    def _needs_grad(self):
+        if not torch.is_grad_enabled():
+            return False
+        srcs = [self._vq_src, self._words_src, self._kb_src] + self.params.tensors()
+        return any(t.requires_grad for t in srcs)
+
+    def _views(self):
+        run, s = self._run, self._run.shapes
+        self._controls_all = run.segment("controls", (s.p + 1, s.B, s.d))
+        self._memories_all = run.segment("memories", (s.p + 1, s.B, s.d))
+        self._infos_all = run.segment("infos", (s.p, s.B, s.d))
+        self._att_q = run.segment("att_question", (s.p, s.B, s.S))
+        self._att_kb = run.segment("att_kb", (s.p, s.B, s.N))
+
+    # ---- zero_state (mac_cell.py:539-592)
+    def zero_state(self, batchSize=None, dtype=torch.float32):
+        self._run = _Run(self, keep_activations=self._needs_grad())
+        self._run.begin()
+        self._views()
+        self._steps_done = 0
+        self.attentions = {"kb": [], "question": [], "self": [], "gate": []}
+        return MACCellTuple(self._controls_all[0], self._memories_all[0])
+
+    def _publish_step(self, i):
+        self.attentions["question"].append(self._att_q[i])
+        self.attentions["kb"].append(self._att_kb[i])
+
+    # histories as the reference exposes them: [B, steps+1, d] (mac_cell.py:472-474)
+    @property
+    def controls(self):
+        return self._controls_all[: self._steps_done + 1].transpose(0, 1)
+
+    @property
+    def memories(self):
+        return self._memories_all[: self._steps_done + 1].transpose(0, 1)
+
+    @property
+    def infos(self):
+        # the reference seeds `infos` with the initial MEMORY (mac_cell.py:551)
+        return torch.cat([self._memories_all[:1], self._infos_all[: self._steps_done]], dim=0).transpose(0, 1)
+
+    # ---- one step (mac_cell.py:420-480)
+    def __call__(self, inputs, state, scope=None):
+        if self._run is None:
+            raise RuntimeError("call zero_state() first (model.py:447)")
+        i = int(self.iteration)
+        if i != self._steps_done:
+            raise RuntimeError("steps must run in order: expected iteration %d, got %d" % (self._steps_done, i))
+        self._run.step(i)
+        self._steps_done = i + 1
+        self._publish_step(i)
+        control, memory = self._controls_all[i + 1], self._memories_all[i + 1]
+        if i == self.netLength - 1 and self._run.keep:
+            # the final state carries the autograd edge of the whole run
+            control, memory = _CellFunction.apply(self._run, "adopt", self._vq_src, self._words_src, self._kb_src,
+                                                  *self.params.tensors())
+        return self.none, MACCellTuple(control, memory)
+
+    # ---- the whole loop of model.py:453-458 in one ABI call
+    def run(self):
+        self._run = _Run(self, keep_activations=self._needs_grad())
+        self.attentions = {"kb": [], "question": [], "self": [], "gate": []}
+        if self._run.keep:
+            control, memory = _CellFunction.apply(self._run, "run", self._vq_src, self._words_src, self._kb_src,
+                                                  *self.params.tensors())
+        else:
+            self._run.forward()
+            control = memory = None
+        self._views()
+        self._steps_done = self.netLength
+        for i in range(self.netLength):
+            self._publish_step(i)
+        if control is None:
+            control, memory = self._controls_all[self.netLength], self._memories_all[self.netLength]
+        return MACCellTuple(control, memory)

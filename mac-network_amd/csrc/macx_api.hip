@@ -1,0 +1,780 @@
+// macx_api.hip -- extern "C" entry points of libmacx.so (see include/macx.h) and the host-side
+// sequencing of one MAC-cell run: what MACnet.MACnetwork's loop (model.py:453-458) makes TF execute,
+// expressed as a fixed schedule of gfx950 kernels on one HIP stream.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "../../include/macx.h"
+#include "macx_common.cuh"
+#include "macx_gemm.cuh"
+#include "macx_gemm_tn.cuh"
+#include "macx_small.cuh"
+
+using namespace macx;
+
+#define CK(expr)                         \
+  do {                                   \
+    hipError_t _e = (expr);              \
+    if (_e != hipSuccess) return (int)_e;\
+  } while (0)
+#define CKI(expr)             \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != 0) return _r;   \
+  } while (0)
+
+namespace {
+
+inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+inline DropSpec make_drop(float keep, uint32_t seed, uint32_t site, uint32_t step) {
+  DropSpec s;
+  s.key = site_key(seed, site, step);
+  if (keep >= 1.0f) {
+    s.thr24 = 1u << 24;
+    s.inv_keep = 1.0f;
+  } else {
+    s.thr24 = (uint32_t)floor((double)keep * 16777216.0);
+    s.inv_keep = 1.0f / keep;
+  }
+  return s;
+}
+inline DropSpec no_drop() {
+  DropSpec s;
+  s.key = 0;
+  s.thr24 = 1u << 24;
+  s.inv_keep = 1.0f;
+  return s;
+}
+
+inline int write_in_dim(const macx_opts* o, int d) {
+  int dim = d;
+  if (o->write_inputs == MACX_WRITE_BOTH) dim = 2 * d;
+  if (o->write_self_att) dim += d;
+  return dim;
+}
+
+// ---- layout of `saved` ------------------------------------------------------------------------
+struct SavedLayout {
+  size_t seg[MACX_SEG_COUNT];
+  size_t seg_count[MACX_SEG_COUNT];
+  size_t wx_p, w1a_p, w1b_p, w2_p;  // packed forward weights
+  size_t ctrl_t;                    // [B,d]   act(qInput(vecQ))
+  size_t cI;                        // [p,B,d] controlInput per step (mac_cell.py:447)
+  size_t cc;                        // [p,B,d] continuous control (alias of cI unless controlFeedPrev)
+  size_t cc_h;                      // [p,B,d] hidden act(contControl) when controlContAct != NON
+  size_t md;                        // [p,B,d] dropped memory fed to projY
+  size_t y;                         // [p,B,d] projected memory
+  size_t info_raw;                  // [p,B,d] information before write dropout
+  size_t wlin;                      // [p,B,d] pre-activation output of linearLayernewMemory
+  size_t mnew;                      // [p,B,d] post-activation, pre-gate new memory (gate only)
+  size_t sc;                        // [p,B,d] projected control for self attention
+  size_t self_smry;                 // [p,B,d]
+  size_t logit_part;                // [d/128][B*N]
+  size_t X, H1, I2;                 // [pk][B,N,d], pk = p (keep) or 1
+  size_t act_stride;                // B*N*d if keep else 0
+  size_t total;
+};
+
+SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
+  SavedLayout L;
+  memset(&L, 0, sizeof(L));
+  const size_t B = s->B, S = s->S, N = s->N, d = s->d, p = s->p;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
+  const size_t gate_w = o->write_gate ? (o->write_gate_shared ? 1 : d) : 0;
+  const size_t counts[MACX_SEG_COUNT] = {(p + 1) * B * d, (p + 1) * B * d, p * B * d, p * B * S, p * B * N,
+                                         o->write_self_att ? p * B * p : 0, p * B * gate_w};
+  for (int i = 0; i < MACX_SEG_COUNT; ++i) {
+    L.seg_count[i] = counts[i];
+    L.seg[i] = take(counts[i]);
+  }
+  L.wx_p = take(d * d);
+  L.w1a_p = take(d * d);
+  L.w1b_p = take(d * d);
+  L.w2_p = take(d * d);
+  L.ctrl_t = take(B * d);
+  L.cI = take(p * B * d);
+  if (o->control_feed_prev) {
+    L.cc = take(p * B * d);
+    L.cc_h = take(p * B * d);
+  } else {
+    L.cc = L.cI;
+    L.cc_h = L.cI;
+  }
+  L.md = take(p * B * d);
+  L.y = take(p * B * d);
+  L.info_raw = take(p * B * d);
+  L.wlin = take(p * B * d);
+  L.mnew = o->write_gate ? take(p * B * d) : L.wlin;
+  if (o->write_self_att) {
+    L.sc = take(p * B * d);
+    L.self_smry = take(p * B * d);
+  }
+  L.logit_part = take((d / 128) * B * N);
+  const size_t pk = keep ? p : 1;
+  L.act_stride = keep ? B * N * d : 0;
+  L.X = take(pk * B * N * d);
+  L.H1 = take(pk * B * N * d);
+  L.I2 = take(pk * B * N * d);
+  L.total = off;
+  return L;
+}
+
+inline int nrb_of(int N) {
+  const int rt = kb_gemm_pick_rt(N);
+  return (N + rt * 32 - 1) / (rt * 32);
+}
+
+inline int wgrad_splits(int M, int Kd, int Jd) {
+  const int tiles = (Kd / T_TILE) * (Jd / T_TILE);
+  int ns = 256 / tiles;
+  if (ns < 1) ns = 1;
+  const int max_by_rows = (M + 63) / 64;   // at least 64 rows per split
+  if (ns > max_by_rows) ns = max_by_rows;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+inline int rows_per_split(int M, int ns) {
+  int r = (M + ns - 1) / ns;
+  return (r + 1) & ~1;
+}
+inline int sb_qpg(int B) {   // questions per workgroup group in the S_b kernel: 16 tiles x groups ~ 256
+  int qpg = (B + 15) / 16;
+  return qpg < 1 ? 1 : qpg;
+}
+
+// ---- layout of the backward workspace ---------------------------------------------------------
+struct BwdLayout {
+  size_t wxT_p, w1aT_p, w1bT_p, w2T_p;
+  size_t wyT, wmT, wqT, wqUT, wccT, wcc2T, wscT, wgT;
+  size_t dI2, dI1, dX, da;
+  size_t DM;        // [p+1,B,d]  dL/d memories
+  size_t DC;        // [p+1,B,d]  dL/d controls
+  size_t dcI;       // [p,B,d]    dL/d controlInput_i
+  size_t dcc;       // [p,B,d]    dL/d continuous control (alias dcI unless controlFeedPrev)
+  size_t dwlin;     // [p,B,d]    dL/d (newMemory linear output)
+  size_t dwin;      // [B, win]   dL/d write inputs of the current step
+  size_t dinfo;     // [B,d]
+  size_t dy_part;   // [2*d/128][B][d]
+  size_t DY;        // [p,B,d]
+  size_t dmd;       // [B,d]
+  size_t dt, du;    // [B,d]
+  size_t slab_w2, slab_wx, slab_w1a, slab_w1b;
+  size_t ns_big, ngroup;
+  size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part;
+  size_t tmpBd[4];  // [B,d] scratch
+  size_t small_slab;
+  size_t total;
+};
+
+BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
+  BwdLayout L;
+  memset(&L, 0, sizeof(L));
+  const size_t B = s->B, N = s->N, d = s->d, p = s->p;
+  const size_t win = write_in_dim(o, s->d);
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
+  L.wxT_p = take(d * d); L.w1aT_p = take(d * d); L.w1bT_p = take(d * d); L.w2T_p = take(d * d);
+  L.wyT = take(d * d);
+  L.wmT = take(win * d);
+  L.wqT = take(d * d);
+  L.wqUT = take((o->control_input_unshared ? p : 1) * d * d);
+  L.wccT = take(2 * d * d); L.wcc2T = take(d * d); L.wscT = take(d * d); L.wgT = take(d * d);
+  L.dI2 = take(B * N * d); L.dI1 = take(B * N * d); L.dX = take(B * N * d); L.da = take(B * N);
+  L.DM = take((p + 1) * B * d);
+  L.DC = take((p + 1) * B * d);
+  L.dcI = take(p * B * d);
+  L.dcc = o->control_feed_prev ? take(p * B * d) : L.dcI;
+  L.dwlin = take(p * B * d);
+  L.dwin = take(B * win);
+  L.dinfo = take(B * d);
+  L.dy_part = take((2 * d / 128) * B * d);
+  L.DY = take(p * B * d);
+  L.dmd = take(B * d);
+  L.dt = take(B * d); L.du = take(B * d);
+  L.ns_big = wgrad_splits((int)(B * N), (int)d, (int)d);
+  L.ngroup = (B + sb_qpg((int)B) - 1) / sb_qpg((int)B);
+  L.slab_w2 = take(p * L.ns_big * d * d);
+  L.slab_wx = take(p * L.ns_big * d * d);
+  L.slab_w1a = take(p * L.ngroup * d * d);
+  L.slab_w1b = take(p * L.ngroup * d * d);
+  const size_t nrb = nrb_of((int)N);
+  L.db2_part = take(p * B * d);
+  L.db1_part = take(p * B * nrb * d);
+  L.dbx_part = take(p * B * nrb * d);
+  L.dwk_part = take(p * B * d);
+  L.dbk_part = take(p * B);
+  L.dwc_part = take(B * d);
+  L.dbc_part = take(B);
+  for (int i = 0; i < 4; ++i) L.tmpBd[i] = take(B * d);
+  // scratch slabs for the small weight gradients (largest: write unit, rows p*B, [win x d])
+  size_t small = 0;
+  {
+    const int ns = wgrad_splits((int)(p * B), (int)d, (int)d);
+    small = (size_t)ns * d * d;
+  }
+  L.small_slab = take(small);
+  L.total = off;
+  return L;
+}
+
+int check_impl(const macx_opts* o, const macx_shapes* s) {
+  if (!o || !s) return MACX_EINVAL;
+  if (o->abi_version != MACX_ABI_VERSION) return MACX_EINVAL;
+  if (s->B < 1 || s->S < 1 || s->N < 1 || s->p < 1 || s->d < 128) return MACX_EINVAL;
+  if (s->d % 128 != 0 || s->d > 1024) return MACX_EINVAL;
+  if (s->S > C_MAXS || s->N > K_MAXN) return MACX_EINVAL;
+  if ((size_t)(s->b0 + s->B) * s->N * s->d >= (1ull << 32)) return MACX_EINVAL;  // 32-bit dropout index
+  if (o->write_inputs != MACX_WRITE_BOTH) return MACX_EUNSUPPORTED;
+  if (o->read_mem_act == MACX_ACT_NON) return MACX_EUNSUPPORTED;   // no memKbProj_2 layer then (ops.py:325)
+  if (o->control_feed_prev) return MACX_EUNSUPPORTED;
+  if (o->write_self_att) return MACX_EUNSUPPORTED;
+  if (o->write_gate) return MACX_EUNSUPPORTED;
+  return MACX_OK;
+}
+
+inline bool misaligned(const void* p) { return ((uintptr_t)p & 15) != 0; }
+
+hipError_t pack(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(256), dim3(256), 0, st, src, ld_k, ld_j, K, Nout, dst);
+  return hipGetLastError();
+}
+hipError_t transpose(const float* src, int R, int C, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, src, R, C, dst);
+  return hipGetLastError();
+}
+
+LinP lin_basic(const float* x, int ldx, int K, int rows, const float* W, int ldw, const float* bias, int n_out,
+               int act, float* out, int ldo) {
+  LinP p;
+  memset(&p, 0, sizeof(p));
+  p.seg[0] = LinSeg{x, ldx, K, 0};
+  p.seg[1] = LinSeg{nullptr, 0, 1 << 30, 0};
+  p.seg[2] = LinSeg{nullptr, 0, 1 << 30, 0};
+  p.Ktot = K;
+  p.rows = rows;
+  p.n_out = n_out;
+  p.W = W; p.ldw = ldw;
+  p.bias = bias;
+  p.act = act;
+  p.out = out; p.ldo = ldo;
+  p.d1 = no_drop(); p.d2 = no_drop();
+  return p;
+}
+
+hipError_t rowsum(const float* src, int rows, int n, size_t ld, float* dst, hipStream_t st) {
+  if (!dst) return hipSuccess;
+  hipLaunchKernelGGL(rowsum_kernel, dim3((n + 63) / 64), dim3(256), 0, st, src, rows, n, ld, dst);
+  return hipGetLastError();
+}
+hipError_t axpy(const float* x, size_t n, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(64), dim3(256), 0, st, x, n, y);
+  return hipGetLastError();
+}
+
+int wgrad_impl(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd, float* out, float* ws,
+               hipStream_t st) {
+  TnP t;
+  memset(&t, 0, sizeof(t));
+  t.M = M; t.Kd = Kd; t.Jd = Jd;
+  t.nsplit = wgrad_splits(M, Kd, Jd);
+  t.rows_per_split = rows_per_split(M, t.nsplit);
+  t.A = A; t.lda = lda; t.G = G; t.ldg = ldg;
+  t.a_drop = no_drop();
+  t.part = (t.nsplit == 1) ? out : ws;
+  CK(wgrad_tn_launch<A_PLAIN>(t, st));
+  if (t.nsplit > 1) CK(slab_reduce_launch(ws, t.nsplit, (size_t)Kd * Jd, out, 0, st));
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int macx_abi_version(void) { return MACX_ABI_VERSION; }
+
+const char* macx_strerror(int code) {
+  switch (code) {
+    case MACX_OK: return "ok";
+    case MACX_EINVAL: return "invalid shapes, null or misaligned pointer";
+    case MACX_EUNSUPPORTED: return "option combination has no HIP path yet";
+    case MACX_EREJECTED: return "option value that raises in the reference";
+    case MACX_ESMALL: return "saved/ws buffer too small";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown macx error";
+  }
+}
+
+int macx_check(const macx_opts* o, const macx_shapes* s) { return check_impl(o, s); }
+
+size_t macx_saved_floats(const macx_opts* o, const macx_shapes* s, int keep) {
+  if (check_impl(o, s) != MACX_OK) return 0;
+  return make_saved(o, s, keep).total;
+}
+
+size_t macx_ws_floats(const macx_opts* o, const macx_shapes* s, int for_backward) {
+  if (check_impl(o, s) != MACX_OK) return 0;
+  if (!for_backward) return 4;   // forward keeps everything in `saved`
+  return make_bwd(o, s).total;
+}
+
+int macx_saved_segment(const macx_opts* o, const macx_shapes* s, int keep, int segment, size_t* offset, size_t* count) {
+  CKI(check_impl(o, s));
+  if (segment < 0 || segment >= MACX_SEG_COUNT || !offset || !count) return MACX_EINVAL;
+  SavedLayout L = make_saved(o, s, keep);
+  *offset = L.seg[segment];
+  *count = L.seg_count[segment];
+  return MACX_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                    const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                    int keep, void* stream) {
+  CKI(check_impl(o, s));
+  if (!dp || !P || !in || !saved) return MACX_EINVAL;
+  if (misaligned(saved) || misaligned(in->knowledgeBase) || misaligned(in->words) || misaligned(in->vecQuestions))
+    return MACX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const SavedLayout L = make_saved(o, s, keep);
+  if (saved_floats < L.total) return MACX_ESMALL;
+  (void)ws; (void)ws_floats;
+  const int B = s->B, d = s->d, p = s->p;
+
+  // weights -> MFMA operand layout  (memKbProj rows [0,d) multiply x*y, rows [d,2d) multiply x: ops.py:718)
+  CK(pack(P->projX_W, d, 1, d, d, saved + L.wx_p, st));
+  CK(pack(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, st));
+  CK(pack(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, st));
+  CK(pack(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, st));
+
+  // initial state (mac_cell.py:546-553)
+  float* controls = saved + L.seg[MACX_SEG_CONTROLS];
+  float* memories = saved + L.seg[MACX_SEG_MEMORIES];
+  hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, st, o->init_ctrl, P->initCtrl, in->vecQuestions, B, d, controls);
+  hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, st, o->init_mem, P->initMem, in->vecQuestions, B, d, memories);
+  CK(hipGetLastError());
+
+  // control inputs (mac_cell.py:442-448).  qInput is step-invariant; qInput{i} is batched over steps.
+  {
+    LinP l = lin_basic(in->vecQuestions, d, d, B, P->qInput_W, d, P->qInput_b, d, o->control_input_act, saved + L.ctrl_t, d);
+    CK(small_linear_launch(l, 1, st));
+    LinP u = lin_basic(saved + L.ctrl_t, d, d, B, P->qInputU_W, d, P->qInputU_b, d, MACX_ACT_NON, saved + L.cI, d);
+    if (o->control_input_unshared) { u.zW = (size_t)d * d; u.zb = d; }
+    u.zout = (size_t)B * d;
+    CK(small_linear_launch(u, p, st));
+  }
+  if (!o->control_feed_prev) {
+    // control is not recurrent (mac_cell.py:141-151): all p word attentions in one launch
+    CtrlP c;
+    c.B = B; c.S = s->S; c.d = d;
+    c.cc = saved + L.cc; c.z_cc = (size_t)B * d;
+    c.words = in->words; c.lengths = in->questionLengths;
+    c.w = P->ctrlLogits_w; c.bias = P->ctrlLogits_b;
+    c.att = saved + L.seg[MACX_SEG_ATT_QUESTION]; c.z_att = (size_t)B * s->S;
+    c.control = controls + (size_t)B * d; c.z_ctl = (size_t)B * d;
+    hipLaunchKernelGGL(control_attend_kernel, dim3(B, p), dim3(256), 0, st, c);
+    CK(hipGetLastError());
+  }
+  return MACX_OK;
+}
+
+int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                   const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                   int keep, int step, void* stream) {
+  CKI(check_impl(o, s));
+  if (!dp || !P || !in || !saved) return MACX_EINVAL;
+  if (step < 0 || step >= s->p) return MACX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const SavedLayout L = make_saved(o, s, keep);
+  if (saved_floats < L.total) return MACX_ESMALL;
+  (void)ws; (void)ws_floats;
+  const int B = s->B, N = s->N, d = s->d;
+  const size_t Bd = (size_t)B * d;
+  const int i = step;
+
+  float* controls = saved + L.seg[MACX_SEG_CONTROLS];
+  float* memories = saved + L.seg[MACX_SEG_MEMORIES];
+  const float* c_i = controls + (size_t)(i + 1) * Bd;
+  const float* m_prev = memories + (size_t)i * Bd;
+  float* m_new = memories + (size_t)(i + 1) * Bd;
+  float* md = saved + L.md + (size_t)i * Bd;
+  float* y = saved + L.y + (size_t)i * Bd;
+  float* X = saved + L.X + (size_t)i * L.act_stride;
+  float* H1 = saved + L.H1 + (size_t)i * L.act_stride;
+  float* I2 = saved + L.I2 + (size_t)i * L.act_stride;
+  float* info_raw = saved + L.info_raw + (size_t)i * Bd;
+  float* info = saved + L.seg[MACX_SEG_INFOS] + (size_t)i * Bd;
+
+  // ---- read unit (mac_cell.py:209-277)
+  // memory dropout (mac_cell.py:214-217) then the read-dropout of ops.mul's y input (ops.py:679)
+  const DropSpec dm = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
+                                                    : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
+  const DropSpec dry = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i);
+  hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md);
+  CK(hipGetLastError());
+  {
+    LinP l = lin_basic(md, d, d, B, P->projY_W, d, P->projY_b, d, MACX_ACT_NON, y, d);
+    CK(small_linear_launch(l, 1, st));
+  }
+  GemmP g;
+  memset(&g, 0, sizeof(g));
+  g.B = B; g.N = N; g.K = d; g.Nout = d; g.b0 = s->b0;
+  g.a_drop = no_drop(); g.e_drop = no_drop();
+  // X = dropout(KB) Wx + bx  (ops.py:678,688)
+  g.A = in->knowledgeBase; g.lda = d;
+  g.a_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
+  g.Wp = saved + L.wx_p;
+  g.out = X; g.ldo = d; g.bias = P->projX_b; g.act = MACX_ACT_NON;
+  CK((kb_gemm_launch<A_DROP, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  // H1 = act( concat([X*y, X]) W1 + b1 ) = act( X (diag(y) W1a + W1b) + b1 )   (ops.py:703,718; mac_cell.py:237)
+  g.A = X; g.a_drop = no_drop();
+  g.Wp = saved + L.w1a_p; g.Wp2 = saved + L.w1b_p; g.y = y; g.ldy = d;
+  g.out = H1; g.bias = P->memKbProj_b; g.act = o->read_mem_act;
+  CK((kb_gemm_launch<A_PLAIN, B_YMIX_ROW, E_BIAS_ACT, false>(g, st)));
+  // I2 = H1 W2 + b2 ; logits = dropout(act(I2 * c)) . w_k   (ops.py:326; mac_cell.py:248,262,266)
+  g.A = H1; g.Wp = saved + L.w2_p; g.Wp2 = nullptr; g.y = nullptr;
+  g.out = I2; g.bias = P->memKbProj2_b; g.act = o->read_ctrl_act;
+  g.cvec = c_i; g.wvec = P->kbLogits_w;
+  g.logit_part = saved + L.logit_part;
+  g.e_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
+  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_I2_LOGIT, false>(g, st)));
+  // attention over the knowledge base + summary (mac_cell.py:266-275)
+  {
+    KbAttP a;
+    a.B = B; a.N = N; a.d = d; a.nparts = d / 128;
+    a.logit_part = saved + L.logit_part; a.bias = P->kbLogits_b;
+    a.kb = in->knowledgeBase;
+    a.att = saved + L.seg[MACX_SEG_ATT_KB] + (size_t)i * B * N;
+    a.info = info_raw;
+    hipLaunchKernelGGL(kb_attend_kernel, dim3(B, d / 128), dim3(256), 0, st, a);
+    CK(hipGetLastError());
+  }
+  // write dropout (mac_cell.py:461-463); self.infos keeps the dropped value (mac_cell.py:474)
+  {
+    const DropSpec dw = make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i);
+    hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, info_raw, B, d, (uint32_t)s->b0, dw, no_drop(), info);
+    CK(hipGetLastError());
+  }
+  // ---- write unit (mac_cell.py:305-375), writeInputs = BOTH: concat([memory, info]) W + b
+  {
+    float* wlin = saved + L.wlin + (size_t)i * Bd;
+    LinP l = lin_basic(m_prev, d, d, B, P->newMemory_W, d, P->newMemory_b, d, MACX_ACT_NON, wlin, d);
+    l.seg[1] = LinSeg{info, d, d, 0};
+    l.Ktot = 2 * d;
+    if (o->write_mem_act == MACX_ACT_NON) {
+      l.out = m_new;   // wlin == new memory; no separate pre-activation copy needed
+      CK(small_linear_launch(l, 1, st));
+    } else {
+      CK(small_linear_launch(l, 1, st));
+      LinP a = l;   // second pass just applies the activation into the history slot
+      a.act = o->write_mem_act;
+      a.out = m_new;
+      CK(small_linear_launch(a, 1, st));
+    }
+  }
+  return MACX_OK;
+}
+
+int macx_cell_forward(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                      const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                      int keep, void* stream) {
+  CKI(macx_cell_begin(o, s, dp, P, in, saved, saved_floats, ws, ws_floats, keep, stream));
+  for (int i = 0; i < s->p; ++i) CKI(macx_cell_step(o, s, dp, P, in, saved, saved_floats, ws, ws_floats, keep, i, stream));
+  return MACX_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                       const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                       const float* d_memory, const float* d_control, const macx_param_grads* GP,
+                       const macx_input_grads* GI, void* stream) {
+  CKI(check_impl(o, s));
+  if (!dp || !P || !in || !saved || !ws || !GP || !GI) return MACX_EINVAL;
+  if (!GI->knowledgeBase || !GI->words || !GI->vecQuestions) return MACX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const SavedLayout L = make_saved(o, s, 1);
+  const BwdLayout W = make_bwd(o, s);
+  if (saved_floats < L.total || ws_floats < W.total) return MACX_ESMALL;
+  const int B = s->B, N = s->N, d = s->d, p = s->p, S = s->S;
+  const size_t Bd = (size_t)B * d;
+  const size_t BNd = (size_t)B * N * d;
+  const size_t dd = (size_t)d * d;
+  const int win = write_in_dim(o, d);
+  const int nrb = nrb_of(N);
+
+  // ---- weights in the layouts the backward kernels read
+  CK(pack(P->projX_W, 1, d, d, d, ws + W.wxT_p, st));            // Wx^T
+  CK(pack(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, st));       // W1a^T
+  CK(pack(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, st));  // W1b^T
+  CK(pack(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, st));       // W2^T
+  CK(transpose(P->projY_W, d, d, ws + W.wyT, st));
+  CK(transpose(P->newMemory_W, win, d, ws + W.wmT, st));         // -> [d][win]
+  CK(transpose(P->qInput_W, d, d, ws + W.wqT, st));
+  const int nU = o->control_input_unshared ? p : 1;
+  for (int i = 0; i < nU; ++i) CK(transpose(P->qInputU_W + (size_t)i * dd, d, d, ws + W.wqUT + (size_t)i * dd, st));
+
+  float* DM = ws + W.DM;
+  float* DC = ws + W.DC;
+  CK(hipMemsetAsync(DM, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
+  CK(hipMemsetAsync(DC, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
+  if (d_memory) CK(hipMemcpyAsync(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (d_control) CK(hipMemcpyAsync(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(hipMemsetAsync(GI->words, 0, (size_t)B * S * d * sizeof(float), st));
+
+  const float* controls = saved + L.seg[MACX_SEG_CONTROLS];
+  const float* memories = saved + L.seg[MACX_SEG_MEMORIES];
+  const float* infos = saved + L.seg[MACX_SEG_INFOS];
+  const float* att_kb = saved + L.seg[MACX_SEG_ATT_KB];
+
+  for (int i = p - 1; i >= 0; --i) {
+    const float* c_i = controls + (size_t)(i + 1) * Bd;
+    const float* X = saved + L.X + (size_t)i * BNd;
+    const float* H1 = saved + L.H1 + (size_t)i * BNd;
+    const float* I2 = saved + L.I2 + (size_t)i * BNd;
+    const float* y = saved + L.y + (size_t)i * Bd;
+    const float* dm_i = DM + (size_t)(i + 1) * Bd;   // dL/d m_i, complete at this point
+    float* dm_prev = DM + (size_t)i * Bd;
+    float* dwlin = ws + W.dwlin + (size_t)i * Bd;
+    float* dwin = ws + W.dwin;
+    float* dinfo = ws + W.dinfo;
+
+    // ---- write unit backward: dwlin = dm * act'(m_i) ; [dm_prev part | dinfo] = dwlin Wm^T
+    hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, dm_i, memories + (size_t)(i + 1) * Bd,
+                       o->write_mem_act, Bd, dwlin);
+    CK(hipGetLastError());
+    {
+      LinP l = lin_basic(dwlin, d, d, B, ws + W.wmT, win, nullptr, win, MACX_ACT_NON, dwin, win);
+      CK(small_linear_launch(l, 1, st));
+    }
+    // d(info) through the write dropout (mac_cell.py:463)
+    hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)dwin, win, d, B, d, (uint32_t)s->b0,
+                       make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i), dinfo);
+    CK(hipGetLastError());
+
+    // ---- read unit backward
+    hipLaunchKernelGGL(kb_att_da_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, (const float*)dinfo, in->knowledgeBase, B, N, d,
+                       ws + W.da);
+    CK(hipGetLastError());
+    {
+      ReadAttBwdP r;
+      r.B = B; r.N = N; r.d = d; r.b0 = s->b0;
+      r.att = att_kb + (size_t)i * B * N; r.da = ws + W.da; r.I2 = I2; r.c = c_i; r.wk = P->kbLogits_w;
+      r.act = o->read_ctrl_act;
+      r.drop = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
+      r.dI2 = ws + W.dI2;
+      r.dc = ws + W.tmpBd[0];
+      r.dwk_part = ws + W.dwk_part + (size_t)i * Bd;
+      r.db2_part = ws + W.db2_part + (size_t)i * Bd;
+      r.dbk_part = ws + W.dbk_part + (size_t)i * B;
+      hipLaunchKernelGGL(read_att_bwd_kernel, dim3(B, d / 128), dim3(256), 0, st, r);
+      CK(hipGetLastError());
+      CK(axpy(ws + W.tmpBd[0], Bd, DC + (size_t)(i + 1) * Bd, st));   // dL/dc_i += read-unit part
+    }
+    GemmP g;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.N = N; g.K = d; g.Nout = d; g.b0 = s->b0;
+    g.a_drop = no_drop(); g.e_drop = no_drop();
+    // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
+    g.A = ws + W.dI2; g.lda = d; g.Wp = ws + W.w2T_p;
+    g.out = ws + W.dI1; g.ldo = d; g.aux = H1; g.act = o->read_mem_act;
+    g.colsum_part = ws + W.db1_part + (size_t)i * B * nrb * d;
+    CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_MUL_DACT, true>(g, st)));
+    // dW2 slabs = H1^T dI2
+    {
+      TnP t;
+      memset(&t, 0, sizeof(t));
+      t.M = B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(B * N, t.nsplit);
+      t.A = H1; t.lda = d; t.G = ws + W.dI2; t.ldg = d; t.a_drop = no_drop();
+      t.part = ws + W.slab_w2 + (size_t)i * W.ns_big * dd;
+      CK(wgrad_tn_launch<A_PLAIN>(t, st));
+    }
+    // dX = dI1 (diag(y) W1a + W1b)^T ; dbx partials
+    g.A = ws + W.dI1; g.Wp = ws + W.w1aT_p; g.Wp2 = ws + W.w1bT_p; g.y = y; g.ldy = d;
+    g.out = ws + W.dX; g.aux = nullptr;
+    g.colsum_part = ws + W.dbx_part + (size_t)i * B * nrb * d;
+    CK((kb_gemm_launch<A_PLAIN, B_YMIX_COL, E_PLAIN, true>(g, st)));
+    // S_b = X_b^T dI1_b -> dW1a / dW1b slabs and dy partials
+    {
+      SbP q;
+      q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B);
+      q.X = X; q.dI1 = ws + W.dI1; q.y = y; q.W1a = P->memKbProj_W;
+      q.dW1a_part = ws + W.slab_w1a + (size_t)i * W.ngroup * dd;
+      q.dW1b_part = ws + W.slab_w1b + (size_t)i * W.ngroup * dd;
+      q.dy_part = ws + W.dy_part;
+      CK(sb_wgrad_launch(q, st));
+    }
+    // dKB (+)= (dX Wx^T) * kbmask + att * dinfo
+    g.A = ws + W.dX; g.Wp = ws + W.wxT_p; g.Wp2 = nullptr; g.y = nullptr;
+    g.out = GI->knowledgeBase; g.aux = dinfo; g.att = att_kb + (size_t)i * B * N;
+    g.e_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
+    g.accumulate = (i != p - 1);
+    g.colsum_part = nullptr;
+    CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_DKB, false>(g, st)));
+    // dWx slabs = dropout(KB)^T dX
+    {
+      TnP t;
+      memset(&t, 0, sizeof(t));
+      t.M = B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(B * N, t.nsplit);
+      t.A = in->knowledgeBase; t.lda = d; t.G = ws + W.dX; t.ldg = d;
+      t.a_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
+      t.row0_global = (uint32_t)s->b0 * (uint32_t)N;
+      t.part = ws + W.slab_wx + (size_t)i * W.ns_big * dd;
+      CK(wgrad_tn_launch<A_DROP>(t, st));
+    }
+    // dy -> d(md) -> dL/d m_{i-1} = dwin[:, :d] + (dy Wy^T) * memmask * readmask
+    float* DYi = ws + W.DY + (size_t)i * Bd;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dy_part), 2 * d / 128, Bd, DYi);
+    CK(hipGetLastError());
+    {
+      LinP l = lin_basic(DYi, d, d, B, ws + W.wyT, d, nullptr, d, MACX_ACT_NON, dm_prev, d);
+      l.use_drop = 1;
+      l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
+                                           : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
+      l.d2 = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i);
+      l.drop_row0 = (uint32_t)s->b0;
+      l.addend = dwin; l.ld_add = win;
+      CK(small_linear_launch(l, 1, st));
+    }
+  }
+
+  // ---- control unit backward.  Not recurrent: every control depends on the question only, so all
+  // p steps are handled by one launch (one workgroup per question, steps in fixed order).
+  {
+    CtrlBwdP c;
+    c.B = B; c.S = S; c.d = d; c.nz = p;
+    c.dcontrol = DC + Bd; c.z_dc = Bd;
+    c.cc = saved + L.cc; c.z_cc = Bd;
+    c.att = saved + L.seg[MACX_SEG_ATT_QUESTION]; c.z_att = (size_t)B * S;
+    c.words = in->words; c.w = P->ctrlLogits_w;
+    c.dcc = ws + W.dcc; c.z_dcc = Bd;
+    c.dwords = GI->words;
+    c.dw_part = ws + W.dwc_part; c.db_part = ws + W.dbc_part;
+    hipLaunchKernelGGL(control_attend_bwd_kernel, dim3(B), dim3(256), 0, st, c);
+    CK(hipGetLastError());
+    CK(rowsum(ws + W.dwc_part, B, d, d, GP->ctrlLogits_w, st));
+    CK(rowsum(ws + W.dbc_part, B, 1, 1, GP->ctrlLogits_b, st));
+  }
+  // ---- control inputs backward (mac_cell.py:442-448): dt = sum_i dcI_i WqU_i^T ; du = dt * act'(t)
+  const float* ctrl_t = saved + L.ctrl_t;
+  float* dcI_sum = ws + W.tmpBd[1];
+  if (o->control_input_unshared) {
+    for (int i = 0; i < p; ++i) {
+      LinP li = lin_basic(ws + W.dcI + (size_t)i * Bd, d, d, B, ws + W.wqUT + (size_t)i * dd, d, nullptr, d, MACX_ACT_NON,
+                          ws + W.dt, d);
+      if (i > 0) { li.addend = ws + W.dt; li.ld_add = d; }
+      CK(small_linear_launch(li, 1, st));
+      CKI(wgrad_impl(ctrl_t, d, ws + W.dcI + (size_t)i * Bd, d, B, d, d, GP->qInputU_W + (size_t)i * dd, ws + W.small_slab, st));
+      CK(rowsum(ws + W.dcI + (size_t)i * Bd, B, d, d, GP->qInputU_b + (size_t)i * d, st));
+    }
+  } else {
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dcI), p, Bd, dcI_sum);
+    CK(hipGetLastError());
+    LinP ls = lin_basic(dcI_sum, d, d, B, ws + W.wqUT, d, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
+    CK(small_linear_launch(ls, 1, st));
+    CKI(wgrad_impl(ctrl_t, d, dcI_sum, d, B, d, d, GP->qInputU_W, ws + W.small_slab, st));
+    CK(rowsum(dcI_sum, B, d, d, GP->qInputU_b, st));
+  }
+  hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dt), ctrl_t, o->control_input_act, Bd,
+                     ws + W.du);
+  CK(hipGetLastError());
+  {
+    LinP l = lin_basic(ws + W.du, d, d, B, ws + W.wqT, d, nullptr, d, MACX_ACT_NON, GI->vecQuestions, d);
+    CK(small_linear_launch(l, 1, st));
+  }
+  CKI(wgrad_impl(in->vecQuestions, d, ws + W.du, d, B, d, d, GP->qInput_W, ws + W.small_slab, st));
+  CK(rowsum(ws + W.du, B, d, d, GP->qInput_b, st));
+
+  // ---- initial state (mac_cell.py:496-505)
+  if (o->init_mem == MACX_INIT_PRM) CK(rowsum(DM, B, d, d, GP->initMem, st));
+  else if (o->init_mem == MACX_INIT_Q) CK(axpy(DM, Bd, GI->vecQuestions, st));
+  if (o->init_ctrl == MACX_INIT_PRM) CK(rowsum(DC, B, d, d, GP->initCtrl, st));
+  else if (o->init_ctrl == MACX_INIT_Q) CK(axpy(DC, Bd, GI->vecQuestions, st));
+
+  // ---- weight gradients of the [B,d] linears, one contraction over all p*B rows each
+  CKI(wgrad_impl(saved + L.md, d, ws + W.DY, d, p * B, d, d, GP->projY_W, ws + W.small_slab, st));
+  CK(rowsum(ws + W.DY, p * B, d, d, GP->projY_b, st));
+  CKI(wgrad_impl(memories, d, ws + W.dwlin, d, p * B, d, d, GP->newMemory_W, ws + W.small_slab, st));
+  CKI(wgrad_impl(infos, d, ws + W.dwlin, d, p * B, d, d, GP->newMemory_W + dd, ws + W.small_slab, st));
+  CK(rowsum(ws + W.dwlin, p * B, d, d, GP->newMemory_b, st));
+
+  // ---- read-unit weights: fixed-order reduction of the per-step slabs
+  CK(slab_reduce_launch(ws + W.slab_w2, (int)(p * W.ns_big), dd, GP->memKbProj2_W, 0, st));
+  CK(slab_reduce_launch(ws + W.slab_wx, (int)(p * W.ns_big), dd, GP->projX_W, 0, st));
+  CK(slab_reduce_launch(ws + W.slab_w1a, (int)(p * W.ngroup), dd, GP->memKbProj_W, 0, st));
+  CK(slab_reduce_launch(ws + W.slab_w1b, (int)(p * W.ngroup), dd, GP->memKbProj_W + dd, 0, st));
+  CK(rowsum(ws + W.db2_part, p * B, d, d, GP->memKbProj2_b, st));
+  CK(rowsum(ws + W.db1_part, p * B * nrb, d, d, GP->memKbProj_b, st));
+  CK(rowsum(ws + W.dbx_part, p * B * nrb, d, d, GP->projX_b, st));
+  CK(rowsum(ws + W.dwk_part, p * B, d, d, GP->kbLogits_w, st));
+  CK(rowsum(ws + W.dbk_part, p * B, 1, 1, GP->kbLogits_b, st));
+  return MACX_OK;
+}
+
+// =================================================================================================
+// unit-level entry points
+// =================================================================================================
+int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows, const float* Wt, const float* b, float bias_const,
+                int n_out, int act, float* out, void* stream) {
+  if (!x1 || !Wt || !out || rows < 1 || n_out < 1) return MACX_EINVAL;
+  if (k1 % 32 != 0 || k2 % 32 != 0 || k1 < 32 || (x2 == nullptr) != (k2 == 0)) return MACX_EINVAL;
+  if (misaligned(x1) || misaligned(x2)) return MACX_EINVAL;
+  LinP l = lin_basic(x1, k1, k1, rows, Wt, n_out, b, n_out, act, out, n_out);
+  if (x2) { l.seg[1] = LinSeg{x2, k2, k2, 0}; l.Ktot = k1 + k2; }
+  l.bias_const = bias_const;
+  CK(small_linear_launch(l, 1, (hipStream_t)stream));
+  return MACX_OK;
+}
+
+int macx_kb_project(const macx_shapes* s, const macx_dropout* dp, int step, const float* kb, const float* Wt, const float* b,
+                    float* out, float* ws, void* stream) {
+  if (!s || !dp || !kb || !Wt || !b || !out || !ws) return MACX_EINVAL;
+  if (s->d % 128 != 0 || s->N > K_MAXN) return MACX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int d = s->d;
+  CK(pack(Wt, d, 1, d, d, ws, st));
+  GemmP g;
+  memset(&g, 0, sizeof(g));
+  g.B = s->B; g.N = s->N; g.K = d; g.Nout = d; g.b0 = s->b0;
+  g.A = kb; g.lda = d;
+  g.a_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, step);
+  g.e_drop = no_drop();
+  g.Wp = ws; g.out = out; g.ldo = d; g.bias = b; g.act = MACX_ACT_NON;
+  CK((kb_gemm_launch<A_DROP, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  return MACX_OK;
+}
+
+int macx_control_attend(const macx_shapes* s, const float* cc, const float* words, const int32_t* lengths, const float* w,
+                        const float* b, float* att, float* control, void* stream) {
+  if (!s || !cc || !words || !lengths || !w || !b || !att || !control) return MACX_EINVAL;
+  if (s->S > C_MAXS || s->d % 4 != 0) return MACX_EINVAL;
+  CtrlP c;
+  c.B = s->B; c.S = s->S; c.d = s->d;
+  c.cc = cc; c.z_cc = 0; c.words = words; c.lengths = lengths; c.w = w; c.bias = b;
+  c.att = att; c.z_att = 0; c.control = control; c.z_ctl = 0;
+  hipLaunchKernelGGL(control_attend_kernel, dim3(s->B, 1), dim3(256), 0, (hipStream_t)stream, c);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
+int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first, size_t n, float* out, void* stream) {
+  if (!out) return MACX_EINVAL;
+  const DropSpec ds = make_drop(keep, seed, site, step);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, ds.key, ds.thr24, first, n, out);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
+int macx_wgrad_splits(int M, int Kd, int Jd) {
+  if (M < 1 || Kd < 128 || Jd < 128 || Kd % 128 || Jd % 128) return MACX_EINVAL;
+  return wgrad_splits(M, Kd, Jd);
+}
+
+int macx_wgrad(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd, float* out, float* ws, void* stream) {
+  if (!A || !G || !out || !ws) return MACX_EINVAL;
+  if (M < 1 || Kd < 128 || Jd < 128 || Kd % 128 || Jd % 128 || lda % 4 || ldg % 4) return MACX_EINVAL;
+  return wgrad_impl(A, lda, G, ldg, M, Kd, Jd, out, ws, (hipStream_t)stream);
+}
+
+}  // extern "C"

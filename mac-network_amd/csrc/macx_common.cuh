@@ -1,0 +1,116 @@
+// macx_common.cuh -- shared device helpers for the MI355X (gfx950) MAC-cell kernels.
+//
+// Everything here is wave64 / CDNA4 specific on purpose: no CUDA shims, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace macx {
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based dropout stream.
+//
+// The reference draws its masks from TF's stateful Philox stream (ops.py:312, :674-679,
+// :1054-1059, mac_cell.py:217,463), which is not reproducible across runs even in TF itself. The
+// product replaces it with a stateless hash of (site key, flat element index): the mask of a
+// given (seed, site, step, element) is a pure function, so forward and backward regenerate it
+// instead of storing [B,N,d] masks, and a data-parallel shard sees exactly the masks the
+// full-batch run would have used (the element index is built from the GLOBAL question index).
+//
+//   bits(idx, key) = fmix(idx ^ key);   keep  <=>  (bits >> 8) < thr24,   thr24 = floor(keep * 2^24)
+//
+// oracle/dropout_hash.py restates the same function in numpy; tests compare the two bit-exactly.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t hash_mix(uint32_t h) {
+  h *= 0x9E3779B1u;
+  h ^= h >> 15;
+  h *= 0x85EBCA77u;
+  h ^= h >> 13;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 16;
+  return h;
+}
+
+__host__ __device__ __forceinline__ uint32_t site_key(uint32_t seed, uint32_t site, uint32_t step) {
+  return hash_mix(hash_mix(seed ^ 0xA511E9B3u) ^ hash_mix(site * 0x632BE5ABu + step * 0x2545F491u + 0x1B873593u));
+}
+
+__host__ __device__ __forceinline__ bool keep_bit(uint32_t idx, uint32_t key, uint32_t thr24) {
+  return (hash_mix(idx ^ key) >> 8) < thr24;
+}
+
+// dropout sites inside the cell (the numbers are part of the mask definition)
+enum : uint32_t {
+  SITE_MEM_VAR = 1,   // ops.py:1054  variational memory mask, drawn once per batch in zero_state
+  SITE_MEM     = 2,   // mac_cell.py:217  plain memory dropout (memoryVariationalDropout off)
+  SITE_READ_KB = 3,   // ops.py:678   dropout(x) on the knowledge base inside ops.mul(proj=...)
+  SITE_READ_MEM = 4,  // ops.py:679   dropout(y) on the memory inside ops.mul(proj=...)
+  SITE_READ_ATT = 5,  // ops.py:312 via :142  dropout on the interactions before the d->1 logits
+  SITE_WRITE_INFO = 6 // mac_cell.py:463  dropout on the retrieved information
+};
+
+struct DropSpec {
+  uint32_t key;      // site_key(seed, site, step)
+  uint32_t thr24;    // floor(keep * 2^24); 1<<24 means keep everything
+  float inv_keep;    // 1/keep
+};
+
+__device__ __forceinline__ float drop_apply(float v, uint32_t idx, const DropSpec& d) {
+  return keep_bit(idx, d.key, d.thr24) ? v * d.inv_keep : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations (ops.py:161-187).  config.relu selects what "RELU" means; args.txt uses ELU.
+// ---------------------------------------------------------------------------------------------
+enum : int { ACT_NON = 0, ACT_TANH = 1, ACT_SIGMOID = 2, ACT_ELU = 3, ACT_RELU = 4 };
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : expm1f(x); }
+// derivative of ELU expressed through its OUTPUT h = elu(x): x>0 -> 1, else exp(x) = h + 1
+__device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }
+// derivative of ELU from its INPUT
+__device__ __forceinline__ float elu_grad_from_in(float x) { return x > 0.0f ? 1.0f : expf(x); }
+
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case ACT_TANH: return tanhf(x);
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case ACT_ELU: return elu_f(x);
+    case ACT_RELU: return fmaxf(x, 0.0f);
+    default: return x;
+  }
+}
+// d act / d x given the activation OUTPUT o
+__device__ __forceinline__ float act_grad_from_out(int act, float o) {
+  switch (act) {
+    case ACT_TANH: return 1.0f - o * o;
+    case ACT_SIGMOID: return o * (1.0f - o);
+    case ACT_ELU: return elu_grad_from_out(o);
+    case ACT_RELU: return o > 0.0f ? 1.0f : 0.0f;
+    default: return 1.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 32 lanes of one half-wave (lanes 0-31 and 32-63 reduce independently)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace macx

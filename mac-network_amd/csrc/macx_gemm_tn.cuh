@@ -1,0 +1,333 @@
+// macx_gemm_tn.cuh -- weight-gradient contractions of the read unit:  C[k][j] = sum_m A[m][k] * G[m][j]
+// reduced over the B*N knowledge-base rows (dW2 = H1^T dI2, dWx = KBd^T dX,
+// dW1 = [X*y, X]^T dI1).  Both operands are row-major over m, which is already the MFMA-friendly
+// layout for a TN product (fragments read along the contiguous dimension, conflict-free b32).
+//
+// Determinism: no float atomics.  Every workgroup owns one (split, 128x128 tile) slab of a partial
+// buffer; a fixed-order reduction kernel sums the slabs.
+#pragma once
+#include "macx_common.cuh"
+#include "macx_gemm.cuh"
+
+namespace macx {
+
+constexpr int T_BM = 32;            // reduction rows per stage
+constexpr int T_TILE = 128;         // output tile edge
+constexpr int T_STAGE = T_BM * T_TILE;
+
+struct TnP {
+  int M;                 // reduction rows (B*N)
+  int Kd, Jd;            // output dims (multiples of 128)
+  int nsplit;
+  int rows_per_split;    // multiple of 2
+  const float* A; int lda;
+  const float* G; int ldg;
+  DropSpec a_drop;       // A_DROP: mask indexed (row0_global + m)*lda + k
+  uint32_t row0_global;  // b0*N
+  float* part;           // [nsplit][Kd][Jd]
+};
+
+template <int AP>
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(TnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                  // [2][T_STAGE]
+  float* sG = smem + 2 * T_STAGE;    // [2][T_STAGE]
+
+  const int ntj = p.Jd / T_TILE;
+  const int ntk = p.Kd / T_TILE;
+  const int ntile = ntj * ntk;
+  // tiles of one split are neighbours in the virtual order -> same XCD after the remap, so the
+  // 16 tiles that re-read the same A/G rows share one L2.
+  const int nblk = gridDim.x;
+  int v = blockIdx.x;
+  if ((nblk & 7) == 0) v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int split = v / ntile;
+  const int tile = v % ntile;
+  const int tk = tile / ntj, tj = tile % ntj;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int nchunk = (m_end - m_begin + T_BM - 1) / T_BM;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+
+  f32x4 ra[4], rg[4];
+  auto load_stage = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int m = m_begin + ch * T_BM + (f >> 5);
+      const int c4 = (f & 31) * 4;
+      if (m < m_end) {
+        ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)m * p.lda + tk * T_TILE + c4);
+        rg[i] = *reinterpret_cast<const f32x4*>(p.G + (size_t)m * p.ldg + tj * T_TILE + c4);
+      } else {
+        ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto store_stage = [&](int buf, int ch) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      f32x4 val = ra[i];
+      if (AP == A_DROP) {
+        const int m = m_begin + ch * T_BM + (f >> 5);
+        const uint32_t idx = (uint32_t)(((size_t)p.row0_global + m) * p.lda + tk * T_TILE + (f & 31) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = drop_apply(val[e], idx + e, p.a_drop);
+      }
+      *reinterpret_cast<f32x4*>(sA + buf * T_STAGE + f * 4) = val;
+      *reinterpret_cast<f32x4*>(sG + buf * T_STAGE + f * 4) = rg[i];
+    }
+  };
+  auto compute = [&](int buf, int steps) {
+    const float* a = sA + buf * T_STAGE + (lane >> 5) * T_TILE + wr * 64 + (lane & 31);
+    const float* g = sG + buf * T_STAGE + (lane >> 5) * T_TILE + wc * 64 + (lane & 31);
+#pragma unroll 4
+    for (int s = 0; s < steps; ++s) {
+      const float a0 = a[s * 2 * T_TILE], a1 = a[s * 2 * T_TILE + 32];
+      const float g0 = g[s * 2 * T_TILE], g1 = g[s * 2 * T_TILE + 32];
+      acc[0][0] = mfma32(a0, g0, acc[0][0]);
+      acc[0][1] = mfma32(a0, g1, acc[0][1]);
+      acc[1][0] = mfma32(a1, g0, acc[1][0]);
+      acc[1][1] = mfma32(a1, g1, acc[1][1]);
+    }
+  };
+
+  if (nchunk > 0) {
+    load_stage(0);
+    store_stage(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int cur = ch & 1;
+      if (ch + 1 < nchunk) load_stage(ch + 1);
+      const int rows = min(T_BM, m_end - (m_begin + ch * T_BM));
+      compute(cur, (rows + 1) >> 1);
+      if (ch + 1 < nchunk) store_stage(cur ^ 1, ch + 1);
+      __syncthreads();
+    }
+  }
+
+  float* out = p.part + (size_t)split * p.Kd * p.Jd;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = tk * T_TILE + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int j = tj * T_TILE + wc * 64 + c * 32 + (lane & 31);
+        out[(size_t)k * p.Jd + j] = acc[a][c][e];
+      }
+}
+
+template <int AP>
+inline hipError_t wgrad_tn_launch(const TnP& p, hipStream_t st) {
+  auto kern = wgrad_tn_kernel<AP>;
+  constexpr size_t lds = 4 * T_STAGE * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = (p.Kd / T_TILE) * (p.Jd / T_TILE) * p.nsplit;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-question interaction gradient  S_b = X_b^T dI1_b  (one [d x d] matrix per question), consumed
+// in registers for the three quantities the folded weight  W_eff(b) = diag(y_b) W1a + W1b  needs:
+//     dW1a += diag(y_b) S_b        dW1b += S_b        dy[b][k] = sum_j W1a[k][j] S_b[k][j]
+// (SURVEY Appendix A "W1" + "mem-mul" rows, rewritten through S_b so that neither the [B,N,2d]
+// concat nor dP is ever formed.)  A workgroup owns one 128x128 tile and a group of questions.
+// ---------------------------------------------------------------------------------------------
+struct SbP {
+  int B, N, d;
+  int qpg;                 // questions per group
+  const float* X;          // [B][N][d]
+  const float* dI1;        // [B][N][d]
+  const float* y;          // [B][d]
+  const float* W1a;        // [d][d] row-major (k, j)
+  float* dW1a_part;        // [ngroup][d][d]
+  float* dW1b_part;        // [ngroup][d][d]
+  float* dy_part;          // [2*d/128][B][d]
+};
+
+__global__ __launch_bounds__(256) void sb_wgrad_kernel(SbP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;
+  float* sG = smem + 2 * T_STAGE;
+
+  const int nt = p.d / T_TILE;
+  const int ntile = nt * nt;
+  const int nblk = gridDim.x;
+  int v = blockIdx.x;
+  if ((nblk & 7) == 0) v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int group = v / ntile;
+  const int tile = v % ntile;
+  const int tk = tile / nt, tj = tile % nt;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int hh = lane >> 5;
+
+  f32x16 accS[2][2], accA[2][2], accB[2][2], w1a[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        accA[a][c][e] = 0.f;
+        accB[a][c][e] = 0.f;
+        const int k = tk * T_TILE + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int j = tj * T_TILE + wc * 64 + c * 32 + (lane & 31);
+        w1a[a][c][e] = p.W1a[(size_t)k * p.d + j];
+      }
+
+  const int nchunk = (p.N + T_BM - 1) / T_BM;
+  const int b_begin = group * p.qpg;
+  const int b_end = min(p.B, b_begin + p.qpg);
+
+  f32x4 ra[4], rg[4];
+  for (int b = b_begin; b < b_end; ++b) {
+    const float* Xb = p.X + (size_t)b * p.N * p.d;
+    const float* Gb = p.dI1 + (size_t)b * p.N * p.d;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accS[a][c][e] = 0.f;
+
+    auto load_stage = [&](int ch) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        const int n = ch * T_BM + (f >> 5);
+        const int c4 = (f & 31) * 4;
+        if (n < p.N) {
+          ra[i] = *reinterpret_cast<const f32x4*>(Xb + (size_t)n * p.d + tk * T_TILE + c4);
+          rg[i] = *reinterpret_cast<const f32x4*>(Gb + (size_t)n * p.d + tj * T_TILE + c4);
+        } else {
+          ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        *reinterpret_cast<f32x4*>(sA + buf * T_STAGE + f * 4) = ra[i];
+        *reinterpret_cast<f32x4*>(sG + buf * T_STAGE + f * 4) = rg[i];
+      }
+    };
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int cur = ch & 1;
+      if (ch + 1 < nchunk) load_stage(ch + 1);
+      const int rows = min(T_BM, p.N - ch * T_BM);
+      const int steps = (rows + 1) >> 1;
+      const float* a = sA + cur * T_STAGE + hh * T_TILE + wr * 64 + (lane & 31);
+      const float* g = sG + cur * T_STAGE + hh * T_TILE + wc * 64 + (lane & 31);
+#pragma unroll 4
+      for (int s = 0; s < steps; ++s) {
+        const float a0 = a[s * 2 * T_TILE], a1 = a[s * 2 * T_TILE + 32];
+        const float g0 = g[s * 2 * T_TILE], g1 = g[s * 2 * T_TILE + 32];
+        accS[0][0] = mfma32(a0, g0, accS[0][0]);
+        accS[0][1] = mfma32(a0, g1, accS[0][1]);
+        accS[1][0] = mfma32(a1, g0, accS[1][0]);
+        accS[1][1] = mfma32(a1, g1, accS[1][1]);
+      }
+      if (ch + 1 < nchunk) store_stage(cur ^ 1);
+      __syncthreads();
+    }
+
+    // consume S_b
+    const float* yb = p.y + (size_t)b * p.d;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = tk * T_TILE + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const float yk = yb[k];
+        const float s0 = accS[a][0][e], s1 = accS[a][1][e];
+        accB[a][0][e] += s0;
+        accB[a][1][e] += s1;
+        accA[a][0][e] = fmaf(yk, s0, accA[a][0][e]);
+        accA[a][1][e] = fmaf(yk, s1, accA[a][1][e]);
+        float dyp = half_sum(w1a[a][0][e] * s0 + w1a[a][1][e] * s1);
+        if ((lane & 31) == 0) p.dy_part[((size_t)(tj * 2 + wc) * p.B + b) * p.d + k] = dyp;
+      }
+    }
+  }
+
+  float* oa = p.dW1a_part + (size_t)group * p.d * p.d;
+  float* ob = p.dW1b_part + (size_t)group * p.d * p.d;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = tk * T_TILE + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int j = tj * T_TILE + wc * 64 + c * 32 + (lane & 31);
+        oa[(size_t)k * p.d + j] = accA[a][c][e];
+        ob[(size_t)k * p.d + j] = accB[a][c][e];
+      }
+}
+
+inline hipError_t sb_wgrad_launch(const SbP& p, hipStream_t st) {
+  constexpr size_t lds = 4 * T_STAGE * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sb_wgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int nt = p.d / T_TILE;
+  const int ngroup = (p.B + p.qpg - 1) / p.qpg;
+  hipLaunchKernelGGL(sb_wgrad_kernel, dim3(nt * nt * ngroup), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed-order reduction of partial slabs:  dst[i] (+)= sum_s part[s][i]
+// ---------------------------------------------------------------------------------------------
+__global__ void slab_reduce_kernel(const float* __restrict__ part, int nslab, size_t n4, float* dst, int accumulate) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
+    for (int k = 1; k < nslab; ++k) s += reinterpret_cast<const f32x4*>(part + (size_t)k * n4 * 4)[i];
+    if (accumulate) s += reinterpret_cast<const f32x4*>(dst)[i];
+    reinterpret_cast<f32x4*>(dst)[i] = s;
+  }
+}
+
+inline hipError_t slab_reduce_launch(const float* part, int nslab, size_t n, float* dst, int accumulate, hipStream_t st) {
+  const size_t n4 = n / 4;
+  int grid = (int)((n4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, st, part, nslab, n4, dst, accumulate);
+  return hipGetLastError();
+}
+
+}  // namespace macx

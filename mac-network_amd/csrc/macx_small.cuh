@@ -1,0 +1,552 @@
+// macx_small.cuh -- the [B,d]-sized and HBM-bound kernels of the cell: weight packing, the small
+// linears (ops.py:298-333 on [B,d] inputs), the control unit's word attention
+// (mac_cell.py:153-181), the read unit's softmax + summary over the knowledge base
+// (mac_cell.py:264-275; ops.py:140-150) and their backward twins.
+#pragma once
+#include "macx_common.cuh"
+
+namespace macx {
+
+// ---------------------------------------------------------------------------------------------
+// weight packing for kb_gemm:  dst[q][h][j][e] = src[(8q+4h+e)*ld_k + j*ld_j]
+//   (ld_k, ld_j) = (Nout, 1) packs W[K][Nout];  (1, K) packs W^T from W[Nout][K]
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int ld_j, int K, int Nout, float* dst) {
+  const size_t total = (size_t)K * Nout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = i & 3;
+    const size_t t = i >> 2;
+    const int j = t % Nout;
+    const size_t qh = t / Nout;
+    const int h = qh & 1;
+    const int q = qh >> 1;
+    const int k = 8 * q + 4 * h + e;
+    dst[i] = src[(size_t)k * ld_k + (size_t)j * ld_j];
+  }
+}
+
+// dst[c][r] = src[r][c]
+__global__ void transpose_kernel(const float* __restrict__ src, int R, int C, float* dst) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+  for (int i = ty; i < 32; i += 8) {
+    const int r = by + i, c = bx + tx;
+    tile[i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = bx + i, r = by + tx;
+    if (r < R && c < C) dst[(size_t)c * R + r] = tile[tx][i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small linear:  out[z][r][j] = epi( sum_k x(z,r,k) W[z][k][j] + bias[z][j] + bias_const )
+// x is the concatenation of up to 3 segments along k (ops.concat, ops.py:65-78, without
+// materialising it).  Rows are wave-uniform, so x is fetched through the scalar cache and the
+// vector memory pipe only streams W.  4 waves split K; fixed-order LDS combine.
+// ---------------------------------------------------------------------------------------------
+struct LinSeg { const float* x; int ld; int K; size_t zstride; };
+struct LinP {
+  LinSeg seg[3];
+  int Ktot, rows, n_out;
+  const float* W; int ldw; size_t zW;
+  const float* bias; size_t zb; float bias_const;
+  int act;
+  float* out; int ldo; size_t zout;
+  // optional epilogue pieces (applied in this order after bias/act)
+  const float* actgrad_src; int actgrad_act; int ld_ag; size_t zag;  // val *= act'(src)
+  int use_drop; DropSpec d1, d2; uint32_t drop_row0;                // val *= f1*f2, idx=(drop_row0+r)*n_out+j
+  const float* addend; int ld_add; size_t zadd;                      // val += addend
+};
+
+constexpr int L_ROWS = 16;
+
+__global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
+  __shared__ float red[4][L_ROWS][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * 64 + lane;
+  const int jc = min(j, p.n_out - 1);
+  const int r0 = blockIdx.y * L_ROWS;
+  const int z = blockIdx.z;
+
+  float acc[L_ROWS];
+#pragma unroll
+  for (int r = 0; r < L_ROWS; ++r) acc[r] = 0.f;
+
+  const float* __restrict__ Wz = p.W + (size_t)z * p.zW;
+  for (int kc = wave * 32; kc < p.Ktot; kc += 128) {
+    int s = 0, koff = kc;
+    while (koff >= p.seg[s].K) { koff -= p.seg[s].K; ++s; }
+    const float* __restrict__ xs = p.seg[s].x + (size_t)z * p.seg[s].zstride + koff;
+    const int ld = p.seg[s].ld;
+    const float* __restrict__ w = Wz + (size_t)kc * p.ldw + jc;
+#pragma unroll 2
+    for (int kk = 0; kk < 32; kk += 4) {
+      const float w0 = w[(size_t)(kk + 0) * p.ldw];
+      const float w1 = w[(size_t)(kk + 1) * p.ldw];
+      const float w2 = w[(size_t)(kk + 2) * p.ldw];
+      const float w3 = w[(size_t)(kk + 3) * p.ldw];
+#pragma unroll
+      for (int r = 0; r < L_ROWS; ++r) {
+        const int rr = min(r0 + r, p.rows - 1);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (size_t)rr * ld + kk);
+        acc[r] = fmaf(xv[0], w0, acc[r]);
+        acc[r] = fmaf(xv[1], w1, acc[r]);
+        acc[r] = fmaf(xv[2], w2, acc[r]);
+        acc[r] = fmaf(xv[3], w3, acc[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < L_ROWS; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  for (int o = threadIdx.x; o < L_ROWS * 64; o += 256) {
+    const int r = o >> 6, l = o & 63;
+    const int row = r0 + r, col = blockIdx.x * 64 + l;
+    if (row >= p.rows || col >= p.n_out) continue;
+    float val = ((red[0][r][l] + red[1][r][l]) + red[2][r][l]) + red[3][r][l];
+    if (p.bias) val += p.bias[(size_t)z * p.zb + col];
+    val += p.bias_const;
+    val = act_apply(p.act, val);
+    if (p.actgrad_src) val *= act_grad_from_out(p.actgrad_act, p.actgrad_src[(size_t)z * p.zag + (size_t)row * p.ld_ag + col]);
+    if (p.use_drop) {
+      const uint32_t idx = (p.drop_row0 + row) * (uint32_t)p.n_out + col;
+      float f = 1.f;
+      if (!keep_bit(idx, p.d1.key, p.d1.thr24)) f = 0.f; else f *= p.d1.inv_keep;
+      if (!keep_bit(idx, p.d2.key, p.d2.thr24)) f = 0.f; else f *= p.d2.inv_keep;
+      val *= f;
+    }
+    if (p.addend) val += p.addend[(size_t)z * p.zadd + (size_t)row * p.ld_add + col];
+    p.out[(size_t)z * p.zout + (size_t)row * p.ldo + col] = val;
+  }
+}
+
+inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
+  dim3 grid((p.n_out + 63) / 64, (p.rows + L_ROWS - 1) / L_ROWS, nz);
+  hipLaunchKernelGGL(small_linear_kernel, grid, dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise helpers on [B,d]
+// ---------------------------------------------------------------------------------------------
+// out = x * f1 * f2 with two dropout streams indexed (row0+r)*d + j   (mac_cell.py:214-217 then ops.py:679)
+__global__ void drop2_kernel(const float* __restrict__ x, int rows, int d, uint32_t row0, DropSpec d1, DropSpec d2, float* out) {
+  const int n = rows * d;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t idx = row0 * (uint32_t)d + i;
+    float v = x[i];
+    v = drop_apply(v, idx, d1);
+    v = drop_apply(v, idx, d2);
+    out[i] = v;
+  }
+}
+
+// initial state (mac_cell.py:496-505): PRM -> tile the [d] variable, ZERO, Q -> copy vecQuestions
+__global__ void init_state_kernel(int mode, const float* __restrict__ prm, const float* __restrict__ vecQ, int rows, int d, float* out) {
+  const int n = rows * d;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (mode == 0) v = prm[i % d];
+    else if (mode == 2) v = vecQ[i];
+    out[i] = v;
+  }
+}
+
+__global__ void dropout_mask_kernel(uint32_t key, uint32_t thr24, uint32_t first, size_t n, float* out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = keep_bit(first + (uint32_t)i, key, thr24) ? 1.f : 0.f;
+}
+
+// dst[i] = sum over `rows` rows of src[r*ld + i]   (bias gradients from per-question partials).
+// One workgroup per 64 columns; the 4 waves take interleaved rows, fixed-order LDS combine.
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ src, int rows, int n, size_t ld, float* dst) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < n) {
+    int r = wave;
+    for (; r + 4 < rows; r += 8) {
+      s0 += src[(size_t)r * ld + i];
+      s1 += src[(size_t)(r + 4) * ld + i];
+    }
+    if (r < rows) s0 += src[(size_t)r * ld + i];
+  }
+  red[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && i < n) dst[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// dst[r][j] = src[r*ld_src + col0 + j] * dropfactor((row0+r)*d + j)
+__global__ void copy_cols_drop_kernel(const float* __restrict__ src, int ld_src, int col0, int rows, int d, uint32_t row0,
+                                      DropSpec ds, float* dst) {
+  const int n = rows * d;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int r = i / d, j = i - r * d;
+    dst[i] = drop_apply(src[(size_t)r * ld_src + col0 + j], row0 * (uint32_t)d + i, ds);
+  }
+}
+
+// dst = g * act'(o) where o is the activation OUTPUT
+__global__ void mul_actgrad_kernel(const float* __restrict__ g, const float* __restrict__ o, int act, size_t n, float* dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = g[i] * act_grad_from_out(act, o[i]);
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, size_t n, float* y) {   // y += x
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += x[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// control unit, step 2 (mac_cell.py:153-181): one workgroup per (question, step)
+//   logits[s] = sum_d cc[d] words[s][d] w[d] + b ;  att = softmax(logits + (1-mask)*(-1e30))
+//   control[d] = sum_s att[s] words[s][d]
+// Requires d <= 1024 (2 x float2 per thread would be needed beyond 512; handled by a d-loop).
+// ---------------------------------------------------------------------------------------------
+struct CtrlP {
+  int B, S, d;
+  const float* cc; size_t z_cc;        // [z][B][d]
+  const float* words;                  // [B][S][d]
+  const int32_t* lengths;              // [B]
+  const float* w; const float* bias;   // [d], [1]
+  float* att; size_t z_att;            // [z][B][S]
+  float* control; size_t z_ctl;        // [z][B][d]
+};
+
+constexpr int C_MAXS = 256;   // max padded question length held in LDS
+
+__global__ __launch_bounds__(256) void control_attend_kernel(CtrlP p) {
+  __shared__ float s_logit[C_MAXS];
+  __shared__ float s_red[8];
+  const int b = blockIdx.x, z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* cc = p.cc + (size_t)z * p.z_cc + (size_t)b * p.d;
+  const float* words = p.words + (size_t)b * p.S * p.d;
+  const int L = p.lengths[b];
+
+  for (int s = wave; s < p.S; s += 4) {
+    float part = 0.f;
+    for (int k = lane * 4; k < p.d; k += 256) {
+      const f32x4 wd = *reinterpret_cast<const f32x4*>(words + (size_t)s * p.d + k);
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(cc + k);
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.w + k);
+      // (cc * words) * w, the order of mac_cell.py:155 then ops.py:317
+      part += (c4[0] * wd[0]) * w4[0] + (c4[1] * wd[1]) * w4[1] + (c4[2] * wd[2]) * w4[2] + (c4[3] * wd[3]) * w4[3];
+    }
+    part = wave_sum(part);
+    if (lane == 0) {
+      const float logit = part + p.bias[0];
+      // ops.expMask (ops.py:243-247): seq + (1 - mask) * (-1e30)
+      s_logit[s] = logit + (s < L ? 0.f : 1.0f) * (-1e30f);
+    }
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int s = tid; s < p.S; s += 256) m = fmaxf(m, s_logit[s]);
+  m = wave_max(m);
+  if (lane == 0) s_red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  float sum = 0.f;
+  for (int s = tid; s < p.S; s += 256) sum += expf(s_logit[s] - m);
+  sum = wave_sum(sum);
+  if (lane == 0) s_red[4 + wave] = sum;
+  __syncthreads();
+  sum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+  const float inv = 1.0f / sum;
+  __syncthreads();
+  for (int s = tid; s < p.S; s += 256) {
+    const float a = expf(s_logit[s] - m) * inv;
+    s_logit[s] = a;
+    p.att[(size_t)z * p.z_att + (size_t)b * p.S + s] = a;
+  }
+  __syncthreads();
+  for (int k = tid * 2; k < p.d; k += 512) {
+    float o0 = 0.f, o1 = 0.f;
+    for (int s = 0; s < p.S; ++s) {
+      const float a = s_logit[s];
+      const float2 wd = *reinterpret_cast<const float2*>(words + (size_t)s * p.d + k);
+      o0 = fmaf(a, wd.x, o0);
+      o1 = fmaf(a, wd.y, o1);
+    }
+    float* dst = p.control + (size_t)z * p.z_ctl + (size_t)b * p.d + k;
+    dst[0] = o0;
+    dst[1] = o1;
+  }
+}
+
+// backward of the above for steps z = 0..nz-1 of one question (one workgroup per question so that
+// d(words) accumulates over steps in a fixed order without atomics).
+struct CtrlBwdP {
+  int B, S, d, nz;
+  const float* dcontrol; size_t z_dc;   // [z][B][d]  gradient wrt the control of step z
+  const float* cc; size_t z_cc;         // [z][B][d]
+  const float* att; size_t z_att;       // [z][B][S]
+  const float* words;                   // [B][S][d]
+  const float* w;                       // [d]
+  float* dcc; size_t z_dcc;             // [z][B][d]   out
+  float* dwords;                        // [B][S][d]   out (+= over steps; zeroed by caller)
+  float* dw_part;                       // [B][d]      out (sum over steps)
+  float* db_part;                       // [B]         out
+};
+
+__global__ __launch_bounds__(256) void control_attend_bwd_kernel(CtrlBwdP p) {
+  __shared__ float s_dl[C_MAXS];
+  __shared__ float s_att[C_MAXS];
+  __shared__ float s_red[4];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* words = p.words + (size_t)b * p.S * p.d;
+  float* dwords = p.dwords + (size_t)b * p.S * p.d;
+  float dbsum = 0.f;
+  // per-thread partial of dw over steps, for the (up to 2) column pairs this thread owns
+  float dw0[2] = {0.f, 0.f}, dw1[2] = {0.f, 0.f};
+
+  for (int z = 0; z < p.nz; ++z) {
+    const float* dc = p.dcontrol + (size_t)z * p.z_dc + (size_t)b * p.d;
+    const float* cc = p.cc + (size_t)z * p.z_cc + (size_t)b * p.d;
+    const float* att = p.att + (size_t)z * p.z_att + (size_t)b * p.S;
+    // da[s] = dc . words[s]
+    for (int s = wave; s < p.S; s += 4) {
+      float part = 0.f;
+      for (int k = lane * 4; k < p.d; k += 256) {
+        const f32x4 wd = *reinterpret_cast<const f32x4*>(words + (size_t)s * p.d + k);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dc + k);
+        part += g[0] * wd[0] + g[1] * wd[1] + g[2] * wd[2] + g[3] * wd[3];
+      }
+      part = wave_sum(part);
+      if (lane == 0) { s_dl[s] = part; s_att[s] = att[s]; }
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int s = tid; s < p.S; s += 256) dot += s_att[s] * s_dl[s];
+    dot = wave_sum(dot);
+    if (lane == 0) s_red[wave] = dot;
+    __syncthreads();
+    dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    __syncthreads();
+    float dls = 0.f;
+    for (int s = tid; s < p.S; s += 256) {
+      const float dl = s_att[s] * (s_dl[s] - dot);   // masked words have att == 0 -> dl == 0
+      s_dl[s] = dl;
+      dls += dl;
+    }
+    dbsum += dls;
+    __syncthreads();
+    int slot = 0;
+    for (int k = tid * 2; k < p.d; k += 512, ++slot) {
+      const float2 c2 = *reinterpret_cast<const float2*>(cc + k);
+      const float2 w2 = *reinterpret_cast<const float2*>(p.w + k);
+      const float2 g2 = *reinterpret_cast<const float2*>(dc + k);
+      float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
+      for (int s = 0; s < p.S; ++s) {
+        const float dl = s_dl[s], a = s_att[s];
+        const float2 wd = *reinterpret_cast<const float2*>(words + (size_t)s * p.d + k);
+        a0 = fmaf(dl, wd.x, a0);            // sum_s dl[s] words[s]
+        a1 = fmaf(dl, wd.y, a1);
+        float2* dwp = reinterpret_cast<float2*>(dwords + (size_t)s * p.d + k);
+        float2 cur = *dwp;
+        cur.x += a * g2.x + dl * (c2.x * w2.x);
+        cur.y += a * g2.y + dl * (c2.y * w2.y);
+        *dwp = cur;
+      }
+      q0 = a0 * c2.x; q1 = a1 * c2.y;       // dw[d] += sum_s dl[s] cc[d] words[s][d]
+      if (slot < 2) { dw0[slot] += q0; dw1[slot] += q1; }
+      float* dst = p.dcc + (size_t)z * p.z_dcc + (size_t)b * p.d + k;
+      dst[0] = a0 * w2.x;                    // dcc[d] = sum_s dl[s] words[s][d] w[d]
+      dst[1] = a1 * w2.y;
+    }
+    __syncthreads();
+  }
+  int slot = 0;
+  for (int k = tid * 2; k < p.d; k += 512, ++slot) {
+    if (slot < 2) {
+      p.dw_part[(size_t)b * p.d + k] = dw0[slot];
+      p.dw_part[(size_t)b * p.d + k + 1] = dw1[slot];
+    }
+  }
+  dbsum = wave_sum(dbsum);
+  if (lane == 0) s_red[wave] = dbsum;
+  __syncthreads();
+  if (tid == 0) p.db_part[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// read unit, step 3 (mac_cell.py:264-275): softmax over the N knowledge-base cells of the logits
+// the memKbProj_2 epilogue left behind, then the attention-weighted KB summary.
+// One workgroup per (question, 128-column slab); 16-byte coalesced loads down the N axis.
+// ---------------------------------------------------------------------------------------------
+struct KbAttP {
+  int B, N, d, nparts;
+  const float* logit_part;   // [nparts][B*N]
+  const float* bias;         // [1]
+  const float* kb;           // [B][N][d]
+  float* att;                // [B][N]
+  float* info;               // [B][d]
+};
+constexpr int K_MAXN = 1024;
+
+__global__ __launch_bounds__(256) void kb_attend_kernel(KbAttP p) {
+  __shared__ float s_att[K_MAXN];
+  __shared__ float s_red[8];
+  __shared__ f32x4 s_acc[8][32];
+  const int b = blockIdx.x, slab = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -INFINITY;
+  for (int n = tid; n < p.N; n += 256) {
+    float l = p.bias[0];
+    for (int q = 0; q < p.nparts; ++q) l += p.logit_part[(size_t)q * p.B * p.N + (size_t)b * p.N + n];
+    s_att[n] = l;
+    m = fmaxf(m, l);
+  }
+  m = wave_max(m);
+  if (lane == 0) s_red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  float sum = 0.f;
+  for (int n = tid; n < p.N; n += 256) {
+    const float e = expf(s_att[n] - m);
+    s_att[n] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) s_red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+  for (int n = tid; n < p.N; n += 256) {
+    const float a = s_att[n] * inv;
+    s_att[n] = a;
+    if (slab == 0) p.att[(size_t)b * p.N + n] = a;
+  }
+  __syncthreads();
+  // summary: 8 row groups x 32 float4 columns
+  const int rg = tid >> 5, c4 = tid & 31;
+  const float* kb = p.kb + (size_t)b * p.N * p.d + slab * 128 + c4 * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int n = rg; n < p.N; n += 8) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(kb + (size_t)n * p.d);
+    const float a = s_att[n];
+    acc += v * a;
+  }
+  s_acc[rg][c4] = acc;
+  __syncthreads();
+  if (tid < 32) {
+    f32x4 t = s_acc[0][tid];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += s_acc[g][tid];
+    *reinterpret_cast<f32x4*>(p.info + (size_t)b * p.d + slab * 128 + tid * 4) = t;
+  }
+}
+
+// backward, part 1: da[b][n] = dr[b] . KB[b][n]   (one wave per knowledge-base cell)
+__global__ __launch_bounds__(256) void kb_att_da_kernel(const float* __restrict__ dr, const float* __restrict__ kb,
+                                                        int B, int N, int d, float* da) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * 4 + wave;
+  if (row >= (size_t)B * N) return;
+  const int b = row / N;
+  float part = 0.f;
+  for (int k = lane * 4; k < d; k += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(kb + row * d + k);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dr + (size_t)b * d + k);
+    part += v[0] * g[0] + v[1] * g[1] + v[2] * g[2] + v[3] * g[3];
+  }
+  part = wave_sum(part);
+  if (lane == 0) da[row] = part;
+}
+
+// backward, part 2: softmax backward + everything elementwise between the logits and I2
+// (SURVEY appendix A rows "softmax", "logit", "ctrl-mul").  One workgroup per (question, 128-column slab).
+struct ReadAttBwdP {
+  int B, N, d, b0;
+  const float* att;      // [B][N]
+  const float* da;       // [B][N]
+  const float* I2;       // [B][N][d]
+  const float* c;        // [B][d]   control of this step
+  const float* wk;       // [d]
+  int act;               // readCtrlAct
+  DropSpec drop;         // SITE_READ_ATT mask of this step
+  float* dI2;            // [B][N][d]
+  float* dc;             // [B][d]        (written)
+  float* dwk_part;       // [B][d]        (written)
+  float* db2_part;       // [B][d]        column sums of dI2 (written)
+  float* dbk_part;       // [B]           (written, by slab 0)
+};
+
+__global__ __launch_bounds__(256) void read_att_bwd_kernel(ReadAttBwdP p) {
+  __shared__ float s_dl[K_MAXN];
+  __shared__ float s_red[4];
+  __shared__ f32x4 s_acc[3][8][32];
+  const int b = blockIdx.x, slab = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float dot = 0.f;
+  for (int n = tid; n < p.N; n += 256) dot += p.att[(size_t)b * p.N + n] * p.da[(size_t)b * p.N + n];
+  dot = wave_sum(dot);
+  if (lane == 0) s_red[wave] = dot;
+  __syncthreads();
+  dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  __syncthreads();
+  float dls = 0.f;
+  for (int n = tid; n < p.N; n += 256) {
+    const float dl = p.att[(size_t)b * p.N + n] * (p.da[(size_t)b * p.N + n] - dot);
+    s_dl[n] = dl;
+    dls += dl;
+  }
+  dls = wave_sum(dls);
+  if (lane == 0) s_red[wave] = dls;
+  __syncthreads();
+  if (tid == 0 && slab == 0) p.dbk_part[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+
+  const int rg = tid >> 5, c4 = tid & 31;
+  const int col = slab * 128 + c4 * 4;
+  const f32x4 cv = *reinterpret_cast<const f32x4*>(p.c + (size_t)b * p.d + col);
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(p.wk + col);
+  f32x4 a_dc = {0.f, 0.f, 0.f, 0.f}, a_dw = {0.f, 0.f, 0.f, 0.f}, a_db = {0.f, 0.f, 0.f, 0.f};
+  for (int n = rg; n < p.N; n += 8) {
+    const size_t off = ((size_t)b * p.N + n) * p.d + col;
+    const f32x4 i2 = *reinterpret_cast<const f32x4*>(p.I2 + off);
+    const float dl = s_dl[n];
+    const uint32_t idx = (uint32_t)(((size_t)(p.b0 + b) * p.N + n) * p.d + col);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float zv = i2[e] * cv[e];
+      const float g = act_apply(p.act, zv);
+      const bool keep = keep_bit(idx + e, p.drop.key, p.drop.thr24);
+      const float f = keep ? p.drop.inv_keep : 0.f;
+      a_dw[e] = fmaf(dl, g * f, a_dw[e]);                 // dw_k += dl * dropped(G)
+      const float dz = (dl * wv[e]) * f * act_grad_from_out(p.act, g);
+      a_dc[e] = fmaf(dz, i2[e], a_dc[e]);                 // dc += dZ * I2
+      o[e] = dz * cv[e];                                  // dI2 = dZ * c
+      a_db[e] += o[e];
+    }
+    *reinterpret_cast<f32x4*>(p.dI2 + off) = o;
+  }
+  s_acc[0][rg][c4] = a_dc;
+  s_acc[1][rg][c4] = a_dw;
+  s_acc[2][rg][c4] = a_db;
+  __syncthreads();
+  if (tid < 96) {
+    const int which = tid >> 5, cc4 = tid & 31;
+    f32x4 t = s_acc[which][0][cc4];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += s_acc[which][g][cc4];
+    float* dst = (which == 0 ? p.dc : which == 1 ? p.dwk_part : p.db2_part) + (size_t)b * p.d + slab * 128 + cc4 * 4;
+    *reinterpret_cast<f32x4*>(dst) = t;
+  }
+}
+
+// dy[b][k] = sum over parts   (S_b kernel leaves 2*d/128 partials)
+__global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, size_t n, float* dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = part[i];
+    for (int q = 1; q < nparts; ++q) s += part[(size_t)q * n + i];
+    dst[i] = s;
+  }
+}
+
+}  // namespace macx

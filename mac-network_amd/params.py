@@ -1,0 +1,126 @@
+"""Parameters of the MAC cell, stored in the layouts the kernels read and exposed under the
+reference's TF variable names for checkpoint import/export."""
+import math
+
+import torch
+
+from . import _lib
+from .options import get
+
+SCOPE = "MACnetwork/MACCell/"
+_LIN = "linearLayer%s/weights/weight"
+_BIAS = "linearLayer%s/biases/bias"
+
+
+def reference_names(config, p):
+    """internal field -> list of (reference variable name, index into the stacked tensor or None)."""
+    names = {
+        "initMem": [("MACnetwork/initMem", None)],
+        "qInput_W": [(SCOPE + _LIN % "qInput", None)],
+        "qInput_b": [(SCOPE + _BIAS % "qInput", None)],
+        "ctrlLogits_w": [(SCOPE + "control/inter2logits/" + _LIN % "logits", None)],
+        "ctrlLogits_b": [(SCOPE + "control/inter2logits/" + _BIAS % "logits", None)],
+        "projX_W": [(SCOPE + "read/mulmemInter/" + _LIN % "projX", None)],
+        "projX_b": [(SCOPE + "read/mulmemInter/" + _BIAS % "projX", None)],
+        "projY_W": [(SCOPE + "read/mulmemInter/" + _LIN % "projY", None)],
+        "projY_b": [(SCOPE + "read/mulmemInter/" + _BIAS % "projY", None)],
+        "memKbProj_W": [(SCOPE + "read/" + _LIN % "memKbProj", None)],
+        "memKbProj_b": [(SCOPE + "read/" + _BIAS % "memKbProj", None)],
+        "memKbProj2_W": [(SCOPE + "read/linearLayermemKbProj/" + _LIN % "memKbProj_2", None)],
+        "memKbProj2_b": [(SCOPE + "read/linearLayermemKbProj/" + _BIAS % "memKbProj_2", None)],
+        "kbLogits_w": [(SCOPE + "read/inter2att/inter2logits/" + _LIN % "logits", None)],
+        "kbLogits_b": [(SCOPE + "read/inter2att/inter2logits/" + _BIAS % "logits", None)],
+        "newMemory_W": [(SCOPE + "write/" + _LIN % "newMemory", None)],
+        "newMemory_b": [(SCOPE + "write/" + _BIAS % "newMemory", None)],
+    }
+    if get(config, "controlInputUnshared"):
+        names["qInputU_W"] = [(SCOPE + _LIN % ("qInput%d" % i), i) for i in range(p)]
+        names["qInputU_b"] = [(SCOPE + _BIAS % ("qInput%d" % i), i) for i in range(p)]
+    else:
+        names["qInputU_W"] = [(SCOPE + _LIN % "qInputU", 0)]
+        names["qInputU_b"] = [(SCOPE + _BIAS % "qInputU", 0)]
+    if get(config, "initCtrl") == "PRM":
+        names["initCtrl"] = [("MACnetwork/initCtrl", None)]
+    if get(config, "writeSelfAtt"):
+        names["selfCtrl_W"] = [(SCOPE + "write/" + _LIN % "ctrlProj", None)]
+        names["selfCtrl_b"] = [(SCOPE + "write/" + _BIAS % "ctrlProj", None)]
+        names["selfLogits_w"] = [(SCOPE + "write/inter2attselfAttention/inter2logits/" + _LIN % "logits", None)]
+        names["selfLogits_b"] = [(SCOPE + "write/inter2attselfAttention/inter2logits/" + _BIAS % "logits", None)]
+    if get(config, "writeGate"):
+        names["gate_W"] = [(SCOPE + "write/" + _LIN % "gate", None)]
+        names["gate_b"] = [(SCOPE + "write/" + _BIAS % "gate", None)]
+    if get(config, "controlFeedPrev"):
+        names["contControl_W"] = [(SCOPE + "control/" + _LIN % "contControl", None)]
+        names["contControl_b"] = [(SCOPE + "control/" + _BIAS % "contControl", None)]
+        if get(config, "controlContAct") != "NON":
+            names["contControl2_W"] = [(SCOPE + "control/linearLayercontControl/" + _LIN % "contControl_2", None)]
+            names["contControl2_b"] = [(SCOPE + "control/linearLayercontControl/" + _BIAS % "contControl_2", None)]
+    return names
+
+
+def shapes(config, p):
+    d = get(config, "memDim")
+    nU = p if get(config, "controlInputUnshared") else 1
+    win = 2 * d + (d if get(config, "writeSelfAtt") else 0)
+    cin = d + (d if get(config, "controlFeedInputs") else 0)
+    sh = {
+        "initMem": (d,), "initCtrl": (d,), "qInput_W": (d, d), "qInput_b": (d,), "qInputU_W": (nU, d, d),
+        "qInputU_b": (nU, d), "ctrlLogits_w": (d,), "ctrlLogits_b": (1,), "projX_W": (d, d), "projX_b": (d,),
+        "projY_W": (d, d), "projY_b": (d,), "memKbProj_W": (2 * d, d), "memKbProj_b": (d,), "memKbProj2_W": (d, d),
+        "memKbProj2_b": (d,), "kbLogits_w": (d,), "kbLogits_b": (1,), "newMemory_W": (win, d), "newMemory_b": (d,),
+        "selfCtrl_W": (d, d), "selfCtrl_b": (d,), "selfLogits_w": (d,), "selfLogits_b": (1,), "gate_W": (d, d),
+        "gate_b": (d,), "contControl_W": (cin, d), "contControl_b": (d,), "contControl2_W": (d, d),
+        "contControl2_b": (d,),
+    }
+    return sh
+
+
+class MACCellParams(torch.nn.Module):
+    """Trainable parameters of the cell.  One tensor per macx_params field."""
+
+    def __init__(self, config, netLength=None, device=None, generator=None, dtype=torch.float32):
+        super().__init__()
+        self.p = int(netLength if netLength is not None else get(config, "netLength"))
+        self._names = reference_names(config, self.p)
+        sh = shapes(config, self.p)
+        self.fields = [f for f in _lib.PARAM_FIELDS if f in self._names]
+        gen = generator
+        for f in self.fields:
+            shape = sh[f]
+            if f in ("initMem", "initCtrl"):
+                t = torch.randn(shape, generator=gen, dtype=torch.float64)          # mac_cell.py:498-499
+            elif f.endswith("_b"):
+                t = torch.zeros(shape, dtype=torch.float64)                          # ops.py:40
+            else:
+                # xavier-uniform (ops.py:20): limit sqrt(6/(fan_in+fan_out)); 1-D weight: sqrt(3/n)
+                if f.endswith("_w"):
+                    lim = math.sqrt(3.0 / shape[0])
+                else:
+                    lim = math.sqrt(6.0 / (shape[-2] + shape[-1]))
+                t = (torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * lim
+            self.register_parameter(f, torch.nn.Parameter(t.to(dtype).to(device) if device else t.to(dtype)))
+
+    def tensors(self):
+        return [getattr(self, f) for f in self.fields]
+
+    def to_reference_dict(self):
+        """{TF variable name: tensor} with the reference's shapes (scalar biases are 0-d)."""
+        out = {}
+        for f in self.fields:
+            t = getattr(self, f).detach()
+            for name, idx in self._names[f]:
+                v = t if idx is None else t[idx]
+                if f in ("ctrlLogits_b", "kbLogits_b", "selfLogits_b"):
+                    v = v.reshape(())
+                out[name] = v.clone()
+        return out
+
+    @torch.no_grad()
+    def load_reference_dict(self, ref):
+        for f in self.fields:
+            t = getattr(self, f)
+            for name, idx in self._names[f]:
+                src = torch.as_tensor(ref[name]).to(t.dtype).to(t.device)
+                dst = t if idx is None else t[idx]
+                dst.copy_(src.reshape(dst.shape))
+        return self

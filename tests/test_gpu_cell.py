@@ -1,0 +1,134 @@
+"""-m gpu: whole-cell parity (forward, attentions, histories, gradients) of the HIP path against
+the oracle on identical parameters, inputs and dropout masks."""
+import pytest
+import torch
+
+from oracle import mac_oracle as mo
+from helpers import make_case, oracle_run, rel_err, max_abs
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 2e-5     # relative, per state tensor (fp32 kernels vs fp64 oracle)
+GRAD_TOL = 2e-4    # relative to the largest entry of each gradient tensor
+
+
+def build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=0, b0=0, requires_grad=False, gen_seed=5):
+    p = cfg.netLength
+    params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(gen_seed)).to(dev)
+    # non-zero biases so that bias paths are exercised
+    g = torch.Generator().manual_seed(gen_seed + 1)
+    with torch.no_grad():
+        for f in params.fields:
+            t = getattr(params, f)
+            if f.endswith("_b"):
+                t.copy_((torch.rand(t.shape, generator=g) - 0.5) * 0.2)
+    vqd, wd, kbd = [t.to(dev).requires_grad_(requires_grad) for t in (vq, words, kb)]
+    cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=lengths.to(dev),
+                        knowledgeBase=kbd, memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout,
+                        writeDropout=cfg.writeDropout, batchSize=vq.shape[0], train=train, config=cfg, params=params,
+                        seed=seed, b0=b0)
+    return cell, params, (vqd, wd, kbd)
+
+
+@pytest.mark.parametrize("name,B,S,N,d,p,train", [
+    ("args", 4, 9, 196, 128, 3, False),
+    ("args", 4, 9, 196, 128, 3, True),
+    ("args", 3, 50, 49, 256, 2, True),
+    ("args", 2, 7, 14, 128, 2, False),
+    ("args2", 5, 12, 100, 128, 2, True),
+])
+def test_forward_stepwise_matches_oracle(macx, dev, name, B, S, N, d, p, train):
+    cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
+    cell, params, _ = build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=77, b0=2)
+    with torch.no_grad():
+        state = cell.zero_state(B)
+        for i in range(p):
+            cell.iteration = i
+            _, state = cell(cell.none, state)
+    torch.cuda.synchronize()
+    ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=train, seed=77, b0=2)
+    rc = ref["cell"]
+    assert rel_err(state.memory, ref["memory"]) < FWD_TOL
+    assert rel_err(state.control, ref["control"]) < FWD_TOL
+    assert rel_err(cell.controls, rc.controls) < FWD_TOL
+    assert rel_err(cell.memories, rc.memories) < FWD_TOL
+    assert rel_err(cell.infos, rc.infos) < FWD_TOL
+    for i in range(p):
+        assert max_abs(cell.attentions["kb"][i], rc.attentions["kb"][i]) < 2e-6
+        assert max_abs(cell.attentions["question"][i], rc.attentions["question"][i]) < 2e-6
+        a = cell.attentions["kb"][i]
+        assert float(a.min()) >= 0 and max_abs(a.sum(-1), torch.ones(B)) < 1e-5
+
+
+@pytest.mark.parametrize("name,B,S,N,d,p,train", [
+    ("args", 3, 9, 196, 128, 2, False),
+    ("args", 3, 9, 196, 128, 3, True),
+    ("args", 2, 11, 49, 256, 2, True),
+])
+def test_backward_matches_oracle_autograd(macx, dev, name, B, S, N, d, p, train):
+    cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
+    cell, params, (vqd, wd, kbd) = build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=5, requires_grad=True)
+    g = torch.Generator().manual_seed(9)
+    dmem = torch.randn(B, d, generator=g) / B
+    dctl = torch.randn(B, d, generator=g) / B
+    state = cell.run()
+    loss = (state.memory * dmem.to(dev)).sum() + (state.control * dctl.to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=train, seed=5, need_grad=True,
+                     d_memory=dmem, d_control=dctl)
+    assert rel_err(state.memory, ref["memory"]) < FWD_TOL
+    rvq, rwords, rkb = ref["inputs"]
+    errs = {"vecQuestions": rel_err(vqd.grad, rvq.grad), "words": rel_err(wd.grad, rwords.grad),
+            "knowledgeBase": rel_err(kbd.grad, rkb.grad)}
+    names = macx.params.reference_names(cfg, p)
+    for f in params.fields:
+        gt = getattr(params, f).grad
+        assert gt is not None, f
+        for refname, idx in names[f]:
+            rg = ref["params"][refname].grad
+            got = gt if idx is None else gt[idx]
+            errs[refname] = rel_err(got.reshape(rg.shape), rg)
+    bad = {k: v for k, v in errs.items() if not (v < GRAD_TOL)}
+    assert not bad, bad
+
+
+def test_stepwise_final_state_carries_gradient(macx, dev):
+    """The model.py:453-458 loop, unchanged, trains: the last step's state has the autograd edge."""
+    cfg, vq, words, lengths, kb = make_case("args", 2, 6, 49, 128, 2)
+    cell, params, (vqd, wd, kbd) = build_cell(macx, dev, cfg, vq, words, lengths, kb, False, requires_grad=True)
+    state = cell.zero_state(2)
+    for i in range(cfg.netLength):
+        cell.iteration = i
+        _, state = cell(cell.none, state)
+    state.memory.sum().backward()
+    torch.cuda.synchronize()
+    cell2, params2, (vq2, w2, kb2) = build_cell(macx, dev, cfg, vq, words, lengths, kb, False, requires_grad=True)
+    s2 = cell2.run()
+    s2.memory.sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(state.memory, s2.memory)
+    assert torch.equal(kbd.grad, kb2.grad)
+    assert torch.equal(params.projX_W.grad, params2.projX_W.grad)
+
+
+def test_headline_shape_forward_backward(macx, dev):
+    """BASELINE configs[1] shape (B=64,S=50,N=196,d=512,p=4): parity vs the fp32 oracle + invariants."""
+    cfg, vq, words, lengths, kb = make_case("args", 64, 50, 196, 512, 4)
+    cell, params, (vqd, wd, kbd) = build_cell(macx, dev, cfg, vq, words, lengths, kb, True, seed=1234, requires_grad=True)
+    state = cell.run()
+    dmem = torch.randn(64, 512, generator=torch.Generator().manual_seed(1)) / 64
+    (state.memory * dmem.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=True, seed=1234, dtype=torch.float32,
+                     need_grad=True, d_memory=dmem)
+    assert rel_err(state.memory, ref["memory"]) < 1e-4
+    assert rel_err(kbd.grad, ref["inputs"][2].grad) < 1e-3
+    # determinism: a second identical run is bit-identical (no float atomics anywhere)
+    cell2, params2, (vq2, w2, kb2) = build_cell(macx, dev, cfg, vq, words, lengths, kb, True, seed=1234, requires_grad=True)
+    s2 = cell2.run()
+    (s2.memory * dmem.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(state.memory, s2.memory)
+    assert torch.equal(kbd.grad, kb2.grad)
+    assert torch.equal(params.memKbProj_W.grad, params2.memKbProj_W.grad)

@@ -1,0 +1,120 @@
+"""-m gpu: unit-level parity of the HIP kernels, called through the C ABI, against the oracle / torch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dropout_hash as dh
+from oracle import mac_oracle as mo
+from helpers import rel_err, max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def test_dropout_stream_matches_numpy(macx, dev):
+    L = macx._lib.lib()
+    n = 100003
+    for (seed, site, step, keep, first) in [(1234, 3, 0, 0.85, 0), (7, 5, 11, 0.5, 4000000000), (0, 1, 0, 1.0, 17)]:
+        out = torch.empty(n, device=dev)
+        macx._lib.check(L.macx_dropout_mask(seed, site, step, keep, first, n, _p(out), None), "mask")
+        torch.cuda.synchronize()
+        ref = dh.keep_mask(seed, site, step, keep, first, n)
+        assert np.array_equal(out.cpu().numpy(), ref)
+        if keep < 1:
+            assert abs(ref.mean() - keep) < 0.01
+
+
+@pytest.mark.parametrize("rows,k1,k2,nout,act", [(64, 512, 0, 512, "NON"), (64, 512, 512, 512, "TANH"),
+                                                  (5, 128, 0, 128, "ELU"), (37, 256, 128, 200, "SIGMOID"), (64, 512, 0, 512, "RELU")])
+def test_linear(macx, dev, rows, k1, k2, nout, act):
+    L = macx._lib.lib()
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.randn(rows, k1, generator=g)
+    x2 = torch.randn(rows, k2, generator=g) if k2 else None
+    W = torch.randn(k1 + k2, nout, generator=g) / (k1 + k2) ** 0.5
+    b = torch.randn(nout, generator=g)
+    xin = x1 if x2 is None else torch.cat([x1, x2], dim=1)
+    ref = xin.double() @ W.double() + b.double() + 0.25
+    ref = {"NON": lambda t: t, "TANH": torch.tanh, "ELU": torch.nn.functional.elu, "SIGMOID": torch.sigmoid,
+           "RELU": torch.relu}[act](ref)
+    out = torch.empty(rows, nout, device=dev)
+    x1d, Wd, bd = x1.to(dev), W.to(dev), b.to(dev)
+    x2d = x2.to(dev) if x2 is not None else None
+    macx._lib.check(L.macx_linear(_p(x1d), k1, _p(x2d) if x2d is not None else None, k2, rows, _p(Wd), _p(bd), 0.25, nout,
+                                  macx._lib.ACT[act], _p(out), None), "linear")
+    torch.cuda.synchronize()
+    assert max_abs(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,N,d,keep", [(4, 196, 128, 1.0), (3, 196, 256, 0.85), (5, 49, 128, 0.85), (2, 14, 128, 0.5),
+                                        (2, 100, 128, 0.85), (2, 300, 128, 1.0)])
+def test_kb_project(macx, dev, B, N, d, keep):
+    """X = dropout(KB) Wx + bx through the MFMA kernel vs fp64, asymmetric W (transpose-detecting)."""
+    L = macx._lib.lib()
+    g = torch.Generator().manual_seed(2)
+    kb = torch.randn(B, N, d, generator=g)
+    W = torch.randn(d, d, generator=g) / d ** 0.5
+    b = torch.randn(d, generator=g)
+    sh = macx._lib.MacxShapes(B=B, S=1, N=N, d=d, p=1, b0=3)
+    dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=keep, keep_write=1.0, seed=99)
+    out = torch.empty(B, N, d, device=dev)
+    ws = torch.empty(d * d, device=dev)
+    kbd, Wd, bd = kb.to(dev), W.to(dev), b.to(dev)
+    macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 5, _p(kbd), _p(Wd), _p(bd), _p(out), _p(ws), None), "kb_project")
+    torch.cuda.synchronize()
+    mask = torch.from_numpy(dh.mask_for(99, dh.SITE_READ_KB, 5, keep, (B, N, d), b0=3)).double()
+    ref = ((kb.double() / keep) * mask) @ W.double() + b.double()
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_control_attend(macx, dev):
+    L = macx._lib.lib()
+    B, S, d = 6, 13, 256
+    g = torch.Generator().manual_seed(3)
+    cc = torch.randn(B, d, generator=g)
+    words = torch.randn(B, S, d, generator=g)
+    lengths = torch.tensor([13, 1, 5, 7, 12, 3], dtype=torch.int32)
+    w = torch.randn(d, generator=g) / d ** 0.5
+    b = torch.tensor([0.3])
+    sh = macx._lib.MacxShapes(B=B, S=S, N=1, d=d, p=1, b0=0)
+    att = torch.empty(B, S, device=dev)
+    ctl = torch.empty(B, d, device=dev)
+    args = [t.to(dev) for t in (cc, words, lengths, w, b)]
+    macx._lib.check(L.macx_control_attend(C.byref(sh), *[_p(t) for t in args], _p(att), _p(ctl), None), "control_attend")
+    torch.cuda.synchronize()
+    inter = cc.double().unsqueeze(1) * words.double()
+    logits = (inter * w.double()).sum(-1) + 0.3
+    ref_att = torch.softmax(mo.Ops.expMask(logits, lengths), dim=-1)
+    ref_ctl = (ref_att.unsqueeze(-1) * words.double()).sum(1)
+    assert max_abs(att, ref_att) < 1e-6
+    assert max_abs(ctl, ref_ctl) < 1e-5
+    # padded words get exactly zero attention
+    for bi in range(B):
+        assert float(att[bi, lengths[bi]:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M,Kd,Jd", [(12544, 512, 512), (768, 512, 512), (64, 128, 256), (1001, 256, 128), (49, 128, 128)])
+def test_wgrad(macx, dev, M, Kd, Jd):
+    L = macx._lib.lib()
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn(M, Kd, generator=g)
+    G = torch.randn(M, Jd, generator=g)
+    ns = L.macx_wgrad_splits(M, Kd, Jd)
+    assert ns >= 1
+    out = torch.empty(Kd, Jd, device=dev)
+    ws = torch.empty(ns * Kd * Jd, device=dev)
+    Ad, Gd = A.to(dev), G.to(dev)
+    macx._lib.check(L.macx_wgrad(_p(Ad), Kd, _p(Gd), Jd, M, Kd, Jd, _p(out), _p(ws), None), "wgrad")
+    torch.cuda.synchronize()
+    ref = A.double().t() @ G.double()
+    assert rel_err(out, ref) < 3e-6
+    # deterministic: a second call is bit-identical
+    out2 = torch.empty_like(out)
+    macx._lib.check(L.macx_wgrad(_p(Ad), Kd, _p(Gd), Jd, M, Kd, Jd, _p(out2), _p(ws), None), "wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
