@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- questions/sec (fwd+bwd) of the MAC cell on MI355X, BASELINE.json's metric.
+
+A "step" is one pass of the hot path over one synthetic CLEVR-shaped batch: p = 12 applications of
+the MAC cell (control -> read -> write) forward in training mode (dropout keep .85/.85/1.0) plus the
+full backward (parameter, knowledge-base, question-word and question-vector gradients), through the
+C ABI of libmacx.so.  For N > 1 every rank runs the same per-GPU batch (weak scaling) on its own
+shard of a global batch of N*B questions and the flat gradient buffer is all-reduced over RCCL
+inside the timed step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (metric, value, roofline, cpu_baseline ...).  Inputs are resident in HBM
+before the timed region; nothing under /root/reference is read.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B, S, N, D, P = 64, 50, 196, 512, 12
+PEAK_FP32_MFMA = 157.3e12       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def flops_per_question_step(n=N, s=S, d=D):
+    """F = 2 d^2 (4N + 5) + 6 N d + 5 S d  (reference op count, forward, args.txt)."""
+    return 2 * d * d * (4 * n + 5) + 6 * n * d + 5 * s * d
+
+
+def cpu_baseline(seed, iters, sample_b):
+    """The op-for-op torch-CPU restatement of the reference graph (oracle/, kind = "port") timed on
+    this host's cores over a bounded sample of the same workload."""
+    from oracle import mac_oracle as mo
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = mo.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
+    vq, words, lengths, kb = mo.synthetic_inputs(sample_b, S, N, D, seed=seed)
+    vs = mo.VarStore(generator=torch.Generator().manual_seed(seed), requires_grad=True)
+    keeps = (cfg.memoryDropout, cfg.readDropout, cfg.writeDropout)
+    mask_fn = mo.hash_mask_fn(seed, keeps)
+    gm = torch.randn(sample_b, D, generator=torch.Generator().manual_seed(1)) / sample_b
+    times = []
+    for it in range(iters + 1):
+        kbr = kb.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        c, m, _ = mo.mac_network(cfg, vs, vq, words, words, lengths, kbr, train=True, mask_fn=mask_fn, keeps=keeps)
+        (m * gm).sum().backward()
+        dt = time.perf_counter() - t0
+        if it > 0:                      # first pass creates the variables / warms the allocator
+            times.append(dt)
+        for v in vs.params.values():
+            v.grad = None
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(sample_b / med, 3), "unit": "questions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d x (B=%d, S=%d, N=%d, d=%d, p=%d) fwd+bwd, torch-CPU fp32 op-for-op restatement of the TF1 graph "
+                      "(oracle/mac_oracle.py), median" % (iters, sample_b, S, N, D, P)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--p", type=int, default=P, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the MAC cell has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+
+    import macx
+    from oracle import mac_oracle as mo   # only for synthetic input shapes + the cpu_baseline leg
+    p = args.p
+    cfg = mo.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
+    seed = 1234
+    b0 = rank * B                                                   # tower rule, equal shards (model.py:139-149)
+    vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, D, seed=seed + rank)
+    params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(seed)).to(dev)
+    vqd, wd, kbd = [t.to(dev).requires_grad_(True) for t in (vq, words, kb)]
+    ld = lengths.to(dev)
+    gmem = (torch.randn(B, D, generator=torch.Generator().manual_seed(1)) / B).to(dev)
+    bucket = macx.dp.GradBucket(params.tensors())
+
+    def step(i):
+        cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=ld,
+                            knowledgeBase=kbd, memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout,
+                            writeDropout=cfg.writeDropout, batchSize=B, train=True, config=cfg, params=params,
+                            seed=seed + i, b0=b0)
+        state = cell.run()
+        for t in (vqd, wd, kbd):
+            t.grad = None
+        for t in params.tensors():
+            t.grad = None
+        torch.autograd.backward([state.memory], [gmem])
+        if world > 1:
+            bucket.allreduce_(B, B * world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    qps = B * world * args.steps / dt
+
+    out = None
+    if rank == 0:
+        F = flops_per_question_step()
+        # ---- roofline of the dominant kernel: the knowledge-base GEMM (kb_gemm_kernel, fp32 MFMA).
+        # algorithmic FLOPs per launch = 2 * (B*N) * d * d ; duration from HIP events on the stream the
+        # kernel is launched on (torch's current stream is handed to the C ABI).
+        L = macx._lib.lib()
+        sh = macx._lib.MacxShapes(B=B, S=S, N=N, d=D, p=p, b0=0)
+        dp = macx._lib.MacxDropout(keep_memory=0.85, keep_read=0.85, keep_write=1.0, seed=seed)
+        wp = torch.empty(D * D, device=dev)
+        xo = torch.empty(B, N, D, device=dev)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        macx._lib.check(L.macx_pack_weight(ptr(params.projX_W.detach()), D, D, 0, ptr(wp), st), "pack")
+        kbc = kbd.detach()
+        for _ in range(3):
+            L.macx_kb_project(C.byref(sh), C.byref(dp), 0, ptr(kbc), ptr(wp), ptr(params.projX_b.detach()), ptr(xo), st)
+        nrep = 30
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(nrep):
+            L.macx_kb_project(C.byref(sh), C.byref(dp), 0, ptr(kbc), ptr(wp), ptr(params.projX_b.detach()), ptr(xo), st)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / nrep
+        k_flops = 2.0 * B * N * D * D
+        achieved = k_flops / (k_ms * 1e-3)
+        roofline = {"bound": "mfma", "kernel": "kb_gemm_kernel<7,A_DROP,B_PLAIN,E_BIAS_ACT> (X = dropout(KB) Wx + bx)",
+                    "achieved": round(achieved / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
+                    "kernel_ms": round(k_ms, 4), "flops_per_launch": k_flops,
+                    "whole_step_frac": round(qps / world * 3 * p * F / PEAK_FP32_MFMA, 4)}
+        out = {"metric": "questions/sec fwd+bwd (B=64,d=512,p=12,KB=14x14x1024) at 1/2/4/8 MI355X",
+               "value": round(qps, 2), "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "MAC cell fwd+bwd, configs/args.txt options, train-mode dropout .85/.85/1.0, "
+                                      "per-GPU batch B=%d, S=%d, KB=[B,%d,%d] (stem output of 14x14x1024 features), d=%d, p=%d; "
+                                      "cell only (stem/encoder/classifier are SURVEY 8f 'next' rows)" % (B, S, N, D, D, p),
+                          "global_batch": B * world, "parallelism": "dp%d" % world,
+                          "flops_per_question_fwd_bwd": 3 * p * F},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seed, args.cpu_iters, B)
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -202,9 +202,14 @@ int macx_cell_backward(const macx_opts*, const macx_shapes*, const macx_dropout*
 int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows,
                 const float* W, const float* b, float bias_const, int n_out, int act,
                 float* out, void* stream);
-/* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688).  `ws` >= d*d floats. */
+/* Re-lays a [K, n_out] weight (transpose = 0) or the transpose of a [n_out, K] weight
+ * (transpose = 1) into the MFMA operand order the knowledge-base GEMM reads:
+ * out[q][h][j][e] = W[8q + 4h + e][j].  K % 32 == 0, n_out % 128 == 0; `out` holds K*n_out floats. */
+int macx_pack_weight(const float* W, int K, int n_out, int transpose, float* out, void* stream);
+/* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688) on fp32 MFMA.
+ * `W_packed` from macx_pack_weight(Wx, d, d, 0). */
 int macx_kb_project(const macx_shapes*, const macx_dropout*, int step, const float* kb,
-                    const float* W, const float* b, float* out, float* ws, void* stream);
+                    const float* W_packed, const float* b, float* out, void* stream);
 /* softmax(expMask(logits)) + att2Smry over the question words for one step
  * (mac_cell.py:155-181; ops.py:114-150, 243-247).  cc: continuous control [B,d]. */
 int macx_control_attend(const macx_shapes*, const float* cc, const float* words, const int32_t* lengths,

@@ -727,20 +727,26 @@ int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows, cons
   return MACX_OK;
 }
 
-int macx_kb_project(const macx_shapes* s, const macx_dropout* dp, int step, const float* kb, const float* Wt, const float* b,
-                    float* out, float* ws, void* stream) {
-  if (!s || !dp || !kb || !Wt || !b || !out || !ws) return MACX_EINVAL;
+int macx_pack_weight(const float* Wt, int K, int n_out, int transpose, float* out, void* stream) {
+  if (!Wt || !out || K < 32 || K % 32 || n_out < 128 || n_out % 128) return MACX_EINVAL;
+  if (transpose) CK(pack(Wt, 1, K, K, n_out, out, (hipStream_t)stream));
+  else CK(pack(Wt, n_out, 1, K, n_out, out, (hipStream_t)stream));
+  return MACX_OK;
+}
+
+int macx_kb_project(const macx_shapes* s, const macx_dropout* dp, int step, const float* kb, const float* Wp, const float* b,
+                    float* out, void* stream) {
+  if (!s || !dp || !kb || !Wp || !b || !out) return MACX_EINVAL;
   if (s->d % 128 != 0 || s->N > K_MAXN) return MACX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int d = s->d;
-  CK(pack(Wt, d, 1, d, d, ws, st));
   GemmP g;
   memset(&g, 0, sizeof(g));
   g.B = s->B; g.N = s->N; g.K = d; g.Nout = d; g.b0 = s->b0;
   g.A = kb; g.lda = d;
   g.a_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, step);
   g.e_drop = no_drop();
-  g.Wp = ws; g.out = out; g.ldo = d; g.bias = b; g.act = MACX_ACT_NON;
+  g.Wp = Wp; g.out = out; g.ldo = d; g.bias = b; g.act = MACX_ACT_NON;
   CK((kb_gemm_launch<A_DROP, B_PLAIN, E_BIAS_ACT, false>(g, st)));
   return MACX_OK;
 }

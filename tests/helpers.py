@@ -33,10 +33,12 @@ def oracle_run(cfg, ref_params, vq, words, lengths, kb, train=False, seed=0, b0=
     return out
 
 
-def rel_err(a, b):
+def rel_err(a, b, floor=1e-6):
+    """max |a-b| relative to the largest reference entry (floored: gradients that are analytically
+    zero, e.g. d/d(logit bias) of a softmax, are compared absolutely)."""
     a = a.detach().cpu().double()
     b = b.detach().cpu().double()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor))
 
 
 def max_abs(a, b):

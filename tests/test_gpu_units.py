@@ -63,9 +63,10 @@ def test_kb_project(macx, dev, B, N, d, keep):
     sh = macx._lib.MacxShapes(B=B, S=1, N=N, d=d, p=1, b0=3)
     dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=keep, keep_write=1.0, seed=99)
     out = torch.empty(B, N, d, device=dev)
-    ws = torch.empty(d * d, device=dev)
+    wp = torch.empty(d * d, device=dev)
     kbd, Wd, bd = kb.to(dev), W.to(dev), b.to(dev)
-    macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 5, _p(kbd), _p(Wd), _p(bd), _p(out), _p(ws), None), "kb_project")
+    macx._lib.check(L.macx_pack_weight(_p(Wd), d, d, 0, _p(wp), None), "pack")
+    macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 5, _p(kbd), _p(wp), _p(bd), _p(out), None), "kb_project")
     torch.cuda.synchronize()
     mask = torch.from_numpy(dh.mask_for(99, dh.SITE_READ_KB, 5, keep, (B, N, d), b0=3)).double()
     ref = ((kb.double() / keep) * mask) @ W.double() + b.double()

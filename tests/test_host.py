@@ -1,0 +1,101 @@
+"""CPU: host logic -- option freezing, parameter naming, the C-ABI library loads and exports every
+symbol include/macx.h declares (no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import mac_oracle as mo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_the_header(macx):
+    L = macx._lib.lib()
+    assert L.macx_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "macx.h")).read()
+    declared = set(re.findall(r"\b(macx_[a-z_0-9]+)\s*\(", header))
+    declared -= {"macx_opts", "macx_shapes"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), "libmacx.so does not export %s" % name
+    assert set(macx._lib.EXPORTS) == declared
+
+
+def test_struct_layouts_match_header(macx):
+    assert C.sizeof(macx._lib.MacxOpts) == 19 * 4
+    assert C.sizeof(macx._lib.MacxShapes) == 6 * 4
+    assert C.sizeof(macx._lib.MacxDropout) == 4 * 4
+    assert C.sizeof(macx._lib.MacxParams) == 30 * 8 == C.sizeof(macx._lib.MacxParamGrads)
+    header = open(os.path.join(ROOT, "include", "macx.h")).read()
+    body = header[header.index("typedef struct macx_params"): header.index("} macx_params;")]
+    fields = re.findall(r"const float\*\s+(\w+);", body)
+    assert tuple(fields) == macx._lib.PARAM_FIELDS
+
+
+def test_check_and_sizing_without_gpu(macx):
+    L = macx._lib.lib()
+    o = macx.freeze(mo.flag_file_config("args"))
+    s = macx._lib.MacxShapes(B=64, S=50, N=196, d=512, p=12, b0=0)
+    assert L.macx_check(C.byref(o), C.byref(s)) == 0
+    keep = L.macx_saved_floats(C.byref(o), C.byref(s), 1)
+    nokeep = L.macx_saved_floats(C.byref(o), C.byref(s), 0)
+    assert keep - nokeep == 3 * 11 * 64 * 196 * 512          # X, H1, I2 kept for 11 more steps
+    off, cnt = C.c_size_t(), C.c_size_t()
+    assert L.macx_saved_segment(C.byref(o), C.byref(s), 1, macx._lib.SEG["att_kb"], C.byref(off), C.byref(cnt)) == 0
+    assert cnt.value == 12 * 64 * 196
+    bad = macx._lib.MacxShapes(B=64, S=50, N=196, d=500, p=12, b0=0)
+    assert L.macx_check(C.byref(o), C.byref(bad)) == macx._lib.MACX_EINVAL
+    assert L.macx_saved_floats(C.byref(o), C.byref(bad), 1) == 0
+    assert b"invalid" in L.macx_strerror(-1)
+
+
+@pytest.mark.parametrize("name", ["args", "args2"])
+def test_supported_flag_files_freeze(macx, name):
+    o = macx.freeze(mo.flag_file_config(name))
+    assert o.control_input_unshared == 1 and o.init_ctrl == macx._lib.INIT["Q"] and o.init_mem == macx._lib.INIT["PRM"]
+    assert o.read_mem_act == macx._lib.ACT["ELU"] and o.memory_variational_dropout == 1
+
+
+@pytest.mark.parametrize("over,exc", [
+    (dict(readMemAttType="DIAG"), UnboundLocalError), (dict(initKBwithQ="MUL"), TypeError),
+    (dict(addNullWord=True), UnboundLocalError), (dict(relu="LKY"), AttributeError), (dict(relu="SELU"), UnboundLocalError),
+    (dict(readProjInputs=False), UnboundLocalError), (dict(writeGate=True, writeGateShared=True), ValueError),
+])
+def test_freeze_rejects_like_the_reference(macx, over, exc):
+    with pytest.raises(exc):
+        macx.freeze(mo.flag_file_config("args", **over))
+
+
+@pytest.mark.parametrize("over", [dict(unsharedCells=True), dict(controlProj=True), dict(writeInputs="SUM"),
+                                  dict(relu="PRM"), dict(readMemAct="NON"), dict(mulBias=0.5), dict(memoryBN=True)])
+def test_unsupported_combinations_fail_loudly(macx, over):
+    with pytest.raises(macx.UnsupportedOptions):
+        macx.freeze(mo.flag_file_config("args", **over))
+
+
+def test_parameter_names_are_the_reference_variable_names(macx):
+    cfg = mo.flag_file_config("args", netLength=3, memDim=128, ctrlDim=128, attDim=128)
+    prm = macx.MACCellParams(cfg, 3, generator=torch.Generator().manual_seed(0))
+    ref = prm.to_reference_dict()
+    vs = mo.VarStore(generator=torch.Generator().manual_seed(0))
+    vq, words, lengths, kb = mo.synthetic_inputs(2, 4, 5, 128)
+    mo.mac_network(cfg, vs, vq, words, words, lengths, kb)
+    assert set(ref) == set(vs.params)
+    for k in ref:
+        assert tuple(ref[k].shape) == tuple(vs.params[k].shape), k
+    prm2 = macx.MACCellParams(cfg, 3).load_reference_dict(vs.params)
+    assert torch.equal(prm2.qInputU_W[2], vs.params["MACnetwork/MACCell/linearLayerqInput2/weights/weight"])
+    # xavier limits (ops.py:20): sqrt(6/(in+out)); 1-D: sqrt(3/n)
+    assert float(prm.memKbProj_W.abs().max()) <= (6.0 / (256 + 128)) ** 0.5
+    assert float(prm.kbLogits_w.abs().max()) <= (3.0 / 128) ** 0.5
+
+
+def test_cell_refuses_cpu_tensors(macx):
+    cfg = mo.flag_file_config("args", netLength=1, memDim=128, ctrlDim=128, attDim=128)
+    vq, words, lengths, kb = mo.synthetic_inputs(2, 4, 5, 128)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        macx.MACCell(vq, words, words, lengths, kb, 0.85, 0.85, 1.0, 2, True, config=cfg,
+                     params=macx.MACCellParams(cfg, 1))
