@@ -106,7 +106,7 @@ def lib():
                               C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.macx_pack_weight.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.macx_kb_project.argtypes = [P(MacxShapes), P(MacxDropout), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p]
+                                  C.c_void_p, C.c_void_p]
     L.macx_control_attend.argtypes = [P(MacxShapes)] + [C.c_void_p] * 8
     L.macx_dropout_mask.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_void_p,
                                     C.c_void_p]

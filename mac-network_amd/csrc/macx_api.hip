@@ -59,7 +59,10 @@ inline int write_in_dim(const macx_opts* o, int d) {
 struct SavedLayout {
   size_t seg[MACX_SEG_COUNT];
   size_t seg_count[MACX_SEG_COUNT];
-  size_t wx_p, w1a_p, w1b_p, w2_p;  // packed forward weights
+  size_t wx_p, w1a_p, w1b_p, w2_p;  // packed forward weights (read unit)
+  size_t wy_p, wm_p, wq_p, wqU_p;   // packed forward weights of the [B,d] linears
+  size_t kb_bits, att_bits;         // [pk][B*N*d/32] keep bits of the two [B,N,d] dropout sites
+  size_t bits_stride;               // words per step (0 when activations are not kept)
   size_t ctrl_t;                    // [B,d]   act(qInput(vecQ))
   size_t cI;                        // [p,B,d] controlInput per step (mac_cell.py:447)
   size_t cc;                        // [p,B,d] continuous control (alias of cI unless controlFeedPrev)
@@ -94,6 +97,10 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.w1a_p = take(d * d);
   L.w1b_p = take(d * d);
   L.w2_p = take(d * d);
+  L.wy_p = take(d * d);
+  L.wm_p = take((size_t)write_in_dim(o, s->d) * d);
+  L.wq_p = take(d * d);
+  L.wqU_p = take((o->control_input_unshared ? p : 1) * d * d);
   L.ctrl_t = take(B * d);
   L.cI = take(p * B * d);
   if (o->control_feed_prev) {
@@ -118,13 +125,16 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.X = take(pk * B * N * d);
   L.H1 = take(pk * B * N * d);
   L.I2 = take(pk * B * N * d);
+  L.bits_stride = keep ? B * N * d / 32 : 0;
+  L.kb_bits = take(pk * B * N * d / 32);
+  L.att_bits = take(pk * B * N * d / 32);
   L.total = off;
   return L;
 }
 
 inline int nrb_of(int N) {
-  const int rt = kb_gemm_pick_rt(N);
-  return (N + rt * 32 - 1) / (rt * 32);
+  const int rows = kb_gemm_rows(N);
+  return (N + rows - 1) / rows;
 }
 
 inline int wgrad_splits(int M, int Kd, int Jd) {
@@ -246,7 +256,7 @@ hipError_t transpose(const float* src, int R, int C, float* dst, hipStream_t st)
   return hipGetLastError();
 }
 
-LinP lin_basic(const float* x, int ldx, int K, int rows, const float* W, int ldw, const float* bias, int n_out,
+LinP lin_basic(const float* x, int ldx, int K, int rows, const float* Wp, const float* bias, int n_out,
                int act, float* out, int ldo) {
   LinP p;
   memset(&p, 0, sizeof(p));
@@ -256,12 +266,21 @@ LinP lin_basic(const float* x, int ldx, int K, int rows, const float* W, int ldw
   p.Ktot = K;
   p.rows = rows;
   p.n_out = n_out;
-  p.W = W; p.ldw = ldw;
+  p.W = Wp;
   p.bias = bias;
   p.act = act;
   p.out = out; p.ldo = ldo;
   p.d1 = no_drop(); p.d2 = no_drop();
   return p;
+}
+
+hipError_t mask_bits(float keep, uint32_t seed, uint32_t site, uint32_t step, uint32_t first, size_t nwords, uint32_t* out,
+                     hipStream_t st) {
+  const DropSpec ds = make_drop(keep, seed, site, step);
+  int grid = (int)((nwords + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(mask_bits_kernel, dim3(grid), dim3(256), 0, st, ds.key, ds.thr24, first, nwords, out);
+  return hipGetLastError();
 }
 
 hipError_t rowsum(const float* src, int rows, int n, size_t ld, float* dst, hipStream_t st) {
@@ -282,7 +301,6 @@ int wgrad_impl(const float* A, int lda, const float* G, int ldg, int M, int Kd, 
   t.nsplit = wgrad_splits(M, Kd, Jd);
   t.rows_per_split = rows_per_split(M, t.nsplit);
   t.A = A; t.lda = lda; t.G = G; t.ldg = ldg;
-  t.a_drop = no_drop();
   t.part = (t.nsplit == 1) ? out : ws;
   CK(wgrad_tn_launch<A_PLAIN>(t, st));
   if (t.nsplit > 1) CK(slab_reduce_launch(ws, t.nsplit, (size_t)Kd * Jd, out, 0, st));
@@ -348,6 +366,11 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
   CK(pack(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, st));
   CK(pack(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, st));
   CK(pack(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, st));
+  CK(pack(P->projY_W, d, 1, d, d, saved + L.wy_p, st));
+  CK(pack(P->newMemory_W, d, 1, write_in_dim(o, d), d, saved + L.wm_p, st));
+  CK(pack(P->qInput_W, d, 1, d, d, saved + L.wq_p, st));
+  for (int i = 0; i < (o->control_input_unshared ? p : 1); ++i)
+    CK(pack(P->qInputU_W + (size_t)i * d * d, d, 1, d, d, saved + L.wqU_p + (size_t)i * d * d, st));
 
   // initial state (mac_cell.py:546-553)
   float* controls = saved + L.seg[MACX_SEG_CONTROLS];
@@ -358,9 +381,9 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
 
   // control inputs (mac_cell.py:442-448).  qInput is step-invariant; qInput{i} is batched over steps.
   {
-    LinP l = lin_basic(in->vecQuestions, d, d, B, P->qInput_W, d, P->qInput_b, d, o->control_input_act, saved + L.ctrl_t, d);
+    LinP l = lin_basic(in->vecQuestions, d, d, B, saved + L.wq_p, P->qInput_b, d, o->control_input_act, saved + L.ctrl_t, d);
     CK(small_linear_launch(l, 1, st));
-    LinP u = lin_basic(saved + L.ctrl_t, d, d, B, P->qInputU_W, d, P->qInputU_b, d, MACX_ACT_NON, saved + L.cI, d);
+    LinP u = lin_basic(saved + L.ctrl_t, d, d, B, saved + L.wqU_p, P->qInputU_b, d, MACX_ACT_NON, saved + L.cI, d);
     if (o->control_input_unshared) { u.zW = (size_t)d * d; u.zb = d; }
     u.zout = (size_t)B * d;
     CK(small_linear_launch(u, p, st));
@@ -415,21 +438,35 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md);
   CK(hipGetLastError());
   {
-    LinP l = lin_basic(md, d, d, B, P->projY_W, d, P->projY_b, d, MACX_ACT_NON, y, d);
+    LinP l = lin_basic(md, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON, y, d);
     CK(small_linear_launch(l, 1, st));
+  }
+  // keep bits of the two [B,N,d] read-dropout sites of this step (ops.py:678 and ops.py:312 via :142)
+  const bool rdrop = dp->keep_read < 1.0f;
+  const size_t nwords = (size_t)B * N * d / 32;
+  uint32_t* kb_bits = reinterpret_cast<uint32_t*>(saved + L.kb_bits + (size_t)i * L.bits_stride);
+  uint32_t* att_bits = reinterpret_cast<uint32_t*>(saved + L.att_bits + (size_t)i * L.bits_stride);
+  if (rdrop) {
+    const uint32_t first = (uint32_t)((size_t)s->b0 * N * d);
+    CK(mask_bits(dp->keep_read, dp->seed, SITE_READ_KB, i, first, nwords, kb_bits, st));
+    CK(mask_bits(dp->keep_read, dp->seed, SITE_READ_ATT, i, first, nwords, att_bits, st));
   }
   GemmP g;
   memset(&g, 0, sizeof(g));
-  g.B = B; g.N = N; g.K = d; g.Nout = d; g.b0 = s->b0;
-  g.a_drop = no_drop(); g.e_drop = no_drop();
+  g.B = B; g.N = N; g.K = d; g.Nout = d;
+  g.a_inv_keep = g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
   // X = dropout(KB) Wx + bx  (ops.py:678,688)
   g.A = in->knowledgeBase; g.lda = d;
-  g.a_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
   g.Wp = saved + L.wx_p;
   g.out = X; g.ldo = d; g.bias = P->projX_b; g.act = MACX_ACT_NON;
-  CK((kb_gemm_launch<A_DROP, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  if (rdrop) {
+    g.a_bits = kb_bits;
+    CK((kb_gemm_launch<A_DROP, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  } else {
+    CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  }
   // H1 = act( concat([X*y, X]) W1 + b1 ) = act( X (diag(y) W1a + W1b) + b1 )   (ops.py:703,718; mac_cell.py:237)
-  g.A = X; g.a_drop = no_drop();
+  g.A = X; g.a_bits = nullptr;
   g.Wp = saved + L.w1a_p; g.Wp2 = saved + L.w1b_p; g.y = y; g.ldy = d;
   g.out = H1; g.bias = P->memKbProj_b; g.act = o->read_mem_act;
   CK((kb_gemm_launch<A_PLAIN, B_YMIX_ROW, E_BIAS_ACT, false>(g, st)));
@@ -438,7 +475,7 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   g.out = I2; g.bias = P->memKbProj2_b; g.act = o->read_ctrl_act;
   g.cvec = c_i; g.wvec = P->kbLogits_w;
   g.logit_part = saved + L.logit_part;
-  g.e_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
+  g.e_bits = rdrop ? att_bits : nullptr;
   CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_I2_LOGIT, false>(g, st)));
   // attention over the knowledge base + summary (mac_cell.py:266-275)
   {
@@ -457,22 +494,12 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, info_raw, B, d, (uint32_t)s->b0, dw, no_drop(), info);
     CK(hipGetLastError());
   }
-  // ---- write unit (mac_cell.py:305-375), writeInputs = BOTH: concat([memory, info]) W + b
+  // ---- write unit (mac_cell.py:305-375), writeInputs = BOTH: act(concat([memory, info]) W + b)
   {
-    float* wlin = saved + L.wlin + (size_t)i * Bd;
-    LinP l = lin_basic(m_prev, d, d, B, P->newMemory_W, d, P->newMemory_b, d, MACX_ACT_NON, wlin, d);
+    LinP l = lin_basic(m_prev, d, d, B, saved + L.wm_p, P->newMemory_b, d, o->write_mem_act, m_new, d);
     l.seg[1] = LinSeg{info, d, d, 0};
     l.Ktot = 2 * d;
-    if (o->write_mem_act == MACX_ACT_NON) {
-      l.out = m_new;   // wlin == new memory; no separate pre-activation copy needed
-      CK(small_linear_launch(l, 1, st));
-    } else {
-      CK(small_linear_launch(l, 1, st));
-      LinP a = l;   // second pass just applies the activation into the history slot
-      a.act = o->write_mem_act;
-      a.out = m_new;
-      CK(small_linear_launch(a, 1, st));
-    }
+    CK(small_linear_launch(l, 1, st));
   }
   return MACX_OK;
 }
@@ -503,17 +530,18 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   const size_t dd = (size_t)d * d;
   const int win = write_in_dim(o, d);
   const int nrb = nrb_of(N);
+  const bool rdrop = dp->keep_read < 1.0f;
 
   // ---- weights in the layouts the backward kernels read
   CK(pack(P->projX_W, 1, d, d, d, ws + W.wxT_p, st));            // Wx^T
   CK(pack(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, st));       // W1a^T
   CK(pack(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, st));  // W1b^T
   CK(pack(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, st));       // W2^T
-  CK(transpose(P->projY_W, d, d, ws + W.wyT, st));
-  CK(transpose(P->newMemory_W, win, d, ws + W.wmT, st));         // -> [d][win]
-  CK(transpose(P->qInput_W, d, d, ws + W.wqT, st));
+  CK(pack(P->projY_W, 1, d, d, d, ws + W.wyT, st));              // Wy^T
+  CK(pack(P->newMemory_W, 1, d, d, win, ws + W.wmT, st));        // Wm^T: [d] -> [win]
+  CK(pack(P->qInput_W, 1, d, d, d, ws + W.wqT, st));
   const int nU = o->control_input_unshared ? p : 1;
-  for (int i = 0; i < nU; ++i) CK(transpose(P->qInputU_W + (size_t)i * dd, d, d, ws + W.wqUT + (size_t)i * dd, st));
+  for (int i = 0; i < nU; ++i) CK(pack(P->qInputU_W + (size_t)i * dd, 1, d, d, d, ws + W.wqUT + (size_t)i * dd, st));
 
   float* DM = ws + W.DM;
   float* DC = ws + W.DC;
@@ -545,7 +573,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
                        o->write_mem_act, Bd, dwlin);
     CK(hipGetLastError());
     {
-      LinP l = lin_basic(dwlin, d, d, B, ws + W.wmT, win, nullptr, win, MACX_ACT_NON, dwin, win);
+      LinP l = lin_basic(dwlin, d, d, B, ws + W.wmT, nullptr, win, MACX_ACT_NON, dwin, win);
       CK(small_linear_launch(l, 1, st));
     }
     // d(info) through the write dropout (mac_cell.py:463)
@@ -562,7 +590,8 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
       r.B = B; r.N = N; r.d = d; r.b0 = s->b0;
       r.att = att_kb + (size_t)i * B * N; r.da = ws + W.da; r.I2 = I2; r.c = c_i; r.wk = P->kbLogits_w;
       r.act = o->read_ctrl_act;
-      r.drop = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
+      r.bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.att_bits + (size_t)i * L.bits_stride) : nullptr;
+      r.inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
       r.dI2 = ws + W.dI2;
       r.dc = ws + W.tmpBd[0];
       r.dwk_part = ws + W.dwk_part + (size_t)i * Bd;
@@ -574,8 +603,9 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     }
     GemmP g;
     memset(&g, 0, sizeof(g));
-    g.B = B; g.N = N; g.K = d; g.Nout = d; g.b0 = s->b0;
-    g.a_drop = no_drop(); g.e_drop = no_drop();
+    g.B = B; g.N = N; g.K = d; g.Nout = d;
+    g.a_inv_keep = g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+    const uint32_t* kb_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits + (size_t)i * L.bits_stride) : nullptr;
     // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
     g.A = ws + W.dI2; g.lda = d; g.Wp = ws + W.w2T_p;
     g.out = ws + W.dI1; g.ldo = d; g.aux = H1; g.act = o->read_mem_act;
@@ -586,7 +616,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
       TnP t;
       memset(&t, 0, sizeof(t));
       t.M = B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(B * N, t.nsplit);
-      t.A = H1; t.lda = d; t.G = ws + W.dI2; t.ldg = d; t.a_drop = no_drop();
+      t.A = H1; t.lda = d; t.G = ws + W.dI2; t.ldg = d;
       t.part = ws + W.slab_w2 + (size_t)i * W.ns_big * dd;
       CK(wgrad_tn_launch<A_PLAIN>(t, st));
     }
@@ -608,7 +638,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     // dKB (+)= (dX Wx^T) * kbmask + att * dinfo
     g.A = ws + W.dX; g.Wp = ws + W.wxT_p; g.Wp2 = nullptr; g.y = nullptr;
     g.out = GI->knowledgeBase; g.aux = dinfo; g.att = att_kb + (size_t)i * B * N;
-    g.e_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
+    g.e_bits = kb_bits;
     g.accumulate = (i != p - 1);
     g.colsum_part = nullptr;
     CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_DKB, false>(g, st)));
@@ -618,17 +648,17 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
       memset(&t, 0, sizeof(t));
       t.M = B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(B * N, t.nsplit);
       t.A = in->knowledgeBase; t.lda = d; t.G = ws + W.dX; t.ldg = d;
-      t.a_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
-      t.row0_global = (uint32_t)s->b0 * (uint32_t)N;
+      t.a_bits = kb_bits; t.a_inv_keep = g.a_inv_keep;
       t.part = ws + W.slab_wx + (size_t)i * W.ns_big * dd;
-      CK(wgrad_tn_launch<A_DROP>(t, st));
+      if (rdrop) CK(wgrad_tn_launch<A_DROP>(t, st));
+      else CK(wgrad_tn_launch<A_PLAIN>(t, st));
     }
     // dy -> d(md) -> dL/d m_{i-1} = dwin[:, :d] + (dy Wy^T) * memmask * readmask
     float* DYi = ws + W.DY + (size_t)i * Bd;
     hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dy_part), 2 * d / 128, Bd, DYi);
     CK(hipGetLastError());
     {
-      LinP l = lin_basic(DYi, d, d, B, ws + W.wyT, d, nullptr, d, MACX_ACT_NON, dm_prev, d);
+      LinP l = lin_basic(DYi, d, d, B, ws + W.wyT, nullptr, d, MACX_ACT_NON, dm_prev, d);
       l.use_drop = 1;
       l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
                                            : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
@@ -661,7 +691,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   float* dcI_sum = ws + W.tmpBd[1];
   if (o->control_input_unshared) {
     for (int i = 0; i < p; ++i) {
-      LinP li = lin_basic(ws + W.dcI + (size_t)i * Bd, d, d, B, ws + W.wqUT + (size_t)i * dd, d, nullptr, d, MACX_ACT_NON,
+      LinP li = lin_basic(ws + W.dcI + (size_t)i * Bd, d, d, B, ws + W.wqUT + (size_t)i * dd, nullptr, d, MACX_ACT_NON,
                           ws + W.dt, d);
       if (i > 0) { li.addend = ws + W.dt; li.ld_add = d; }
       CK(small_linear_launch(li, 1, st));
@@ -671,7 +701,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   } else {
     hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dcI), p, Bd, dcI_sum);
     CK(hipGetLastError());
-    LinP ls = lin_basic(dcI_sum, d, d, B, ws + W.wqUT, d, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
+    LinP ls = lin_basic(dcI_sum, d, d, B, ws + W.wqUT, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
     CK(small_linear_launch(ls, 1, st));
     CKI(wgrad_impl(ctrl_t, d, dcI_sum, d, B, d, d, GP->qInputU_W, ws + W.small_slab, st));
     CK(rowsum(dcI_sum, B, d, d, GP->qInputU_b, st));
@@ -680,7 +710,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
                      ws + W.du);
   CK(hipGetLastError());
   {
-    LinP l = lin_basic(ws + W.du, d, d, B, ws + W.wqT, d, nullptr, d, MACX_ACT_NON, GI->vecQuestions, d);
+    LinP l = lin_basic(ws + W.du, d, d, B, ws + W.wqT, nullptr, d, MACX_ACT_NON, GI->vecQuestions, d);
     CK(small_linear_launch(l, 1, st));
   }
   CKI(wgrad_impl(in->vecQuestions, d, ws + W.du, d, B, d, d, GP->qInput_W, ws + W.small_slab, st));
@@ -715,12 +745,12 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
 // =================================================================================================
 // unit-level entry points
 // =================================================================================================
-int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows, const float* Wt, const float* b, float bias_const,
+int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows, const float* Wp, const float* b, float bias_const,
                 int n_out, int act, float* out, void* stream) {
-  if (!x1 || !Wt || !out || rows < 1 || n_out < 1) return MACX_EINVAL;
-  if (k1 % 32 != 0 || k2 % 32 != 0 || k1 < 32 || (x2 == nullptr) != (k2 == 0)) return MACX_EINVAL;
-  if (misaligned(x1) || misaligned(x2)) return MACX_EINVAL;
-  LinP l = lin_basic(x1, k1, k1, rows, Wt, n_out, b, n_out, act, out, n_out);
+  if (!x1 || !Wp || !out || rows < 1 || n_out < 16 || n_out % 16) return MACX_EINVAL;
+  if (k1 % 16 != 0 || k2 % 16 != 0 || k1 < 16 || (x2 == nullptr) != (k2 == 0)) return MACX_EINVAL;
+  if (misaligned(x1) || misaligned(x2) || misaligned(Wp) || misaligned(out)) return MACX_EINVAL;
+  LinP l = lin_basic(x1, k1, k1, rows, Wp, b, n_out, act, out, n_out);
   if (x2) { l.seg[1] = LinSeg{x2, k2, k2, 0}; l.Ktot = k1 + k2; }
   l.bias_const = bias_const;
   CK(small_linear_launch(l, 1, (hipStream_t)stream));
@@ -728,26 +758,33 @@ int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows, cons
 }
 
 int macx_pack_weight(const float* Wt, int K, int n_out, int transpose, float* out, void* stream) {
-  if (!Wt || !out || K < 32 || K % 32 || n_out < 128 || n_out % 128) return MACX_EINVAL;
+  if (!Wt || !out || K < 16 || K % 16 || n_out < 16 || n_out % 16) return MACX_EINVAL;
   if (transpose) CK(pack(Wt, 1, K, K, n_out, out, (hipStream_t)stream));
   else CK(pack(Wt, n_out, 1, K, n_out, out, (hipStream_t)stream));
   return MACX_OK;
 }
 
 int macx_kb_project(const macx_shapes* s, const macx_dropout* dp, int step, const float* kb, const float* Wp, const float* b,
-                    float* out, void* stream) {
+                    float* out, float* bits_ws, void* stream) {
   if (!s || !dp || !kb || !Wp || !b || !out) return MACX_EINVAL;
-  if (s->d % 128 != 0 || s->N > K_MAXN) return MACX_EINVAL;
+  if (s->d % 128 != 0 || s->N > K_MAXN || ((size_t)s->B * s->N * s->d) % 32) return MACX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int d = s->d;
   GemmP g;
   memset(&g, 0, sizeof(g));
-  g.B = s->B; g.N = s->N; g.K = d; g.Nout = d; g.b0 = s->b0;
+  g.B = s->B; g.N = s->N; g.K = d; g.Nout = d;
   g.A = kb; g.lda = d;
-  g.a_drop = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, step);
-  g.e_drop = no_drop();
   g.Wp = Wp; g.out = out; g.ldo = d; g.bias = b; g.act = MACX_ACT_NON;
-  CK((kb_gemm_launch<A_DROP, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  if (dp->keep_read < 1.0f) {
+    if (!bits_ws) return MACX_EINVAL;
+    const size_t nwords = (size_t)s->B * s->N * d / 32;
+    CK(mask_bits(dp->keep_read, dp->seed, SITE_READ_KB, step, (uint32_t)((size_t)s->b0 * s->N * d), nwords, (uint32_t*)bits_ws, st));
+    g.a_bits = (const uint32_t*)bits_ws;
+    g.a_inv_keep = 1.0f / dp->keep_read;
+    CK((kb_gemm_launch<A_DROP, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  } else {
+    CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  }
   return MACX_OK;
 }
 

@@ -1,33 +1,45 @@
 // macx_gemm.cuh -- the knowledge-base GEMM family of the read unit (forward and backward-data).
 //
-// One kernel template covers every  [B*N, K] x [K, 512]  contraction of the read unit
+// One kernel template covers every  [B*N, K] x [K, d]  contraction of the read unit
 // (mac_cell.py:209-277 / ops.py:668-725, 298-333): projX, memKbProj, memKbProj_2 forward and the
 // three dY @ W^T products of the backward pass.  fp32 in / fp32 accumulate on
-// v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf chain, 157 TF peak on MI355X).
+// v_mfma_f32_16x16x4_f32 (exact fp32, bit-equal to an fmaf chain, 157 TF peak on MI355X).
 //
-// Tiling is per QUESTION, not over the flat row index:  a workgroup owns RT*32 consecutive
-// knowledge-base cells of ONE question x 128 output columns.  With N = 196 (CLEVR) and RT = 7 the
-// grid is B x 4 = 256 workgroups for B = 64 -- exactly one per CU -- and every per-question vector
-// the read unit broadcasts over the KB (projected memory y, control c) is workgroup-uniform, which
-// is what allows the row-broadcast products to move out of the [B,N,d] tensors and into the
-// weight tile (B_YMIX_*) or the epilogue (E_I2_LOGIT).
+// Tiling is per QUESTION, not over the flat row index: a workgroup owns RT*16 consecutive
+// knowledge-base cells of ONE question x 128 output columns.  With N = 196 (CLEVR) RT = 13 covers a
+// question in one tile (208 rows, 6 % padding) and the grid is B x 4 = 256 workgroups for B = 64 --
+// one per CU -- and every per-question vector the read unit broadcasts over the KB (projected memory
+// y, control c) is workgroup-uniform, which is what lets the row-broadcast products move out of the
+// [B,N,d] tensors and into the weight tile (B_YMIX_*) or the epilogue (E_I2_LOGIT).
+//
+// Workgroup = 8 waves (2 per SIMD, so one wave's LDS/global/barrier waits hide under the other's
+// MFMAs); wave w owns output columns [16w, 16w+16) of the tile and all RT row tiles.
 //
 // Layouts
 //   A  (activations)  row-major [B][N][lda], read as float4 along k, staged in LDS with a
-//                     36-float row stride (conflict-free ds_read_b128 by 16-lane groups).
-//   W  (weights)      PRE-PACKED [K/8][2][Nout][4]  with  Wp[q][h][j][e] = W[8q + 4h + e][j]
+//                     40-float row stride (conflict-free ds_read_b128 for the 16x16x4 A fragment).
+//   W  (weights)      PRE-PACKED [K/16][4][Nout][4]  with  Wp[Q][g][j][e] = W[16Q + 4g + e][j]
 //                     so a lane's four consecutive MFMA B operands are one ds_read_b128 and the
-//                     global->LDS copy is linear.  The MFMA k-pairing {8q+e, 8q+4+e} is the same
-//                     on the A side (lane half h reads A[i][8q+4h .. 8q+4h+3]).
+//                     global->LDS copy is linear.  MFMA e of group Q contracts k = {16Q+e, 16Q+4+e,
+//                     16Q+8+e, 16Q+12+e}; the A side uses the same pairing (lane group g reads
+//                     A[i][16Q+4g .. 16Q+4g+3]).
+//   dropout masks     1 bit per element, 32 consecutive k (or columns) per uint32 word, produced by
+//                     mask_bits_kernel from the stateless stream of macx_common.cuh.
+//   epilogue          accumulators are transposed through LDS into a row-major [RT*16][132] tile
+//                     and then processed 16 bytes per lane, 512 B per row: coalesced stores, row
+//                     reductions (attention logits) inside one half-wave, column sums (bias
+//                     gradients) by a fixed-order LDS combine.
 #pragma once
 #include "macx_common.cuh"
 
 namespace macx {
 
 constexpr int G_BK = 32;           // reduction slice per stage
-constexpr int G_BN = 128;          // output columns per workgroup (4 waves x 32)
-constexpr int G_LDA = G_BK + 4;    // padded LDS row stride (floats)
+constexpr int G_BN = 128;          // output columns per workgroup (8 waves x 16)
+constexpr int G_LDA = G_BK + 8;    // padded LDS row stride (floats)
 constexpr int G_BTILE = G_BK * G_BN;
+constexpr int G_LDT = G_BN + 4;    // epilogue tile row stride (floats)
+constexpr int G_THREADS = 512;
 
 enum : int { A_PLAIN = 0, A_DROP = 1 };
 enum : int { B_PLAIN = 0, B_YMIX_ROW = 1, B_YMIX_COL = 2 };
@@ -42,11 +54,11 @@ enum : int {
 struct GemmP {
   // problem
   int B, N, K, Nout;
-  int b0;                 // global index of question 0 (dropout stream / data-parallel shard offset)
   // A operand
   const float* A;
   int lda;
-  DropSpec a_drop;        // A_DROP: mask indexed ((b0+b)*N + n)*lda + k
+  const uint32_t* a_bits; // A_DROP: keep bits of A, [B*N][lda/32]
+  float a_inv_keep;
   // weights
   const float* Wp;        // packed
   const float* Wp2;       // packed second weight (B_YMIX_*)
@@ -63,18 +75,32 @@ struct GemmP {
   const float* att;       // E_DKB: kb attention [B][N]
   float* logit_part;      // E_I2_LOGIT: [Nout/128][B*N]
   float* colsum_part;     // optional: column sums of `out` per workgroup-row  [B*nrb][Nout]
-  DropSpec e_drop;        // E_I2_LOGIT: mask on elu(I2*c) indexed ((b0+b)*N+n)*Nout + j ; E_DKB: KB mask
+  const uint32_t* e_bits; // E_I2_LOGIT: keep bits of act(I2*c) [B*N][Nout/32]; E_DKB: keep bits of KB; null = keep all
+  float e_inv_keep;
   int accumulate;         // E_DKB: 1 -> out += , 0 -> out =
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int RT>
+constexpr int kb_gemm_lds_floats() {
+  constexpr int stage = 2 * RT * 16 * G_LDA + 2 * G_BTILE;
+  constexpr int epi = RT * 16 * G_LDT + 16 * 32 * 4;
+  return stage > epi ? stage : epi;
+}
 
 template <int RT, int AP, int BP, int EP, bool COLSUM>
-__global__ __launch_bounds__(256) void kb_gemm_kernel(GemmP p) {
+__global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int A_TILE = RT * 32 * G_LDA;
+  constexpr int ROWS = RT * 16;
+  constexpr int A_TILE = ROWS * G_LDA;
+  constexpr int A_F4 = ROWS * 8;                       // float4 per A stage
+  constexpr int A_IT = (A_F4 + G_THREADS - 1) / G_THREADS;
   float* sA = smem;                  // [2][A_TILE]
   float* sB = smem + 2 * A_TILE;     // [2][G_BTILE]
 
@@ -84,45 +110,54 @@ __global__ __launch_bounds__(256) void kb_gemm_kernel(GemmP p) {
   int v = blockIdx.x;
   if ((nblk & 7) == 0) v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
   const int ncb = p.Nout / G_BN;
-  const int nrb = (p.N + RT * 32 - 1) / (RT * 32);
+  const int nrb = (p.N + ROWS - 1) / ROWS;
   const int cb = v % ncb;
   const int rbi = (v / ncb) % nrb;
   const int b = v / (ncb * nrb);
-  const int row0 = rbi * RT * 32;
+  const int row0 = rbi * ROWS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int nk = p.K / G_BK;
 
-  f32x16 acc[RT];
+  f32x4 acc[RT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[r][e] = 0.0f;
+  for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 ra[RT];
-  f32x4 rw[4];
-  f32x4 rw2[4];
+  f32x4 ra[A_IT];
+  uint32_t rbits[A_IT];
+  f32x4 rw[2];
+  f32x4 rw2[2];
 
   const float* Abase = p.A + (size_t)b * p.N * p.lda;
+  const uint32_t* Bitbase = (AP == A_DROP) ? p.a_bits + (size_t)b * p.N * (p.lda >> 5) : nullptr;
+  // per-thread staging coordinates (k-invariant)
+  int a_off[A_IT];        // float offset of this thread's float4 in A (row clamped into the question)
+  int a_row[A_IT];
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int f = tid + G_THREADS * i;
+    const int n = row0 + (f >> 3);
+    a_ok[i] = (f < A_F4) && (n < p.N);
+    const int nc = min(n, p.N - 1);
+    a_row[i] = nc;
+    a_off[i] = nc * p.lda + (f & 7) * 4;
+  }
+  float ycol = 0.f;
+  if (BP == B_YMIX_COL) ycol = p.y[(size_t)b * p.ldy + cb * G_BN + (tid & 127)];
 
   auto load_tiles = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const int f = tid + 256 * i;
-      const int n = row0 + (f >> 3);
-      const int kq = f & 7;
-      if (n < p.N) {
-        ra[i] = *reinterpret_cast<const f32x4*>(Abase + (size_t)n * p.lda + kt * G_BK + kq * 4);
-      } else {
-        ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+    for (int i = 0; i < A_IT; ++i) {
+      ra[i] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + kt * G_BK);
+      if (AP == A_DROP) rbits[i] = Bitbase[a_row[i] * (p.lda >> 5) + kt];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
-      const int chunk = f >> 7;   // q*2 + h
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + G_THREADS * i;
+      const int chunk = f >> 7;   // Q*4 + g
       const int j = f & 127;
       const size_t off = ((size_t)(kt * 8 + chunk) * p.Nout + cb * G_BN + j) * 4;
       rw[i] = *reinterpret_cast<const f32x4*>(p.Wp + off);
@@ -133,52 +168,49 @@ __global__ __launch_bounds__(256) void kb_gemm_kernel(GemmP p) {
   auto store_tiles = [&](int buf, int kt) {
     float* dA = sA + buf * A_TILE;
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const int f = tid + 256 * i;
-      const int row = f >> 3;
-      const int kq = f & 7;
+    for (int i = 0; i < A_IT; ++i) {
+      const int f = tid + G_THREADS * i;
       f32x4 val = ra[i];
       if (AP == A_DROP) {
-        const int n = row0 + row;
-        const uint32_t idx = (uint32_t)(((size_t)(p.b0 + b) * p.N + n) * p.lda + kt * G_BK + kq * 4);
+        const uint32_t bits = rbits[i] >> ((f & 7) * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = drop_apply(val[e], idx + e, p.a_drop);
+        for (int e = 0; e < 4; ++e) val[e] = ((bits >> e) & 1u) ? val[e] * p.a_inv_keep : 0.f;
       }
-      *reinterpret_cast<f32x4*>(dA + row * G_LDA + kq * 4) = val;
+      if (!a_ok[i]) val = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (f < A_F4) *reinterpret_cast<f32x4*>(dA + (f >> 3) * G_LDA + (f & 7) * 4) = val;
     }
     float* dB = sB + buf * G_BTILE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + G_THREADS * i;
       f32x4 val = rw[i];
       if (BP == B_YMIX_ROW) {
         // B_eff[k][j] = y[b][k] * W1a[k][j] + W1b[k][j]   (ops.py:703,718 folded into the weights)
         const int chunk = f >> 7;
-        const int k = kt * G_BK + (chunk >> 1) * 8 + (chunk & 1) * 4;
+        const int k = kt * G_BK + (chunk >> 2) * 16 + (chunk & 3) * 4;
         const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.y + (size_t)b * p.ldy + k);
         val = val * y4 + rw2[i];
       } else if (BP == B_YMIX_COL) {
         // B_eff[k][j] = y[b][j] * W1a^T[k][j] + W1b^T[k][j]   (backward-data of the same product)
-        const float ys = p.y[(size_t)b * p.ldy + cb * G_BN + (f & 127)];
-        val = val * ys + rw2[i];
+        val = val * ycol + rw2[i];
       }
       *reinterpret_cast<f32x4*>(dB + f * 4) = val;
     }
   };
 
   auto compute = [&](int buf) {
-    const float* a = sA + buf * A_TILE + (lane & 31) * G_LDA + (lane >> 5) * 4;
-    const float* bq = sB + buf * G_BTILE + ((lane >> 5) * G_BN + wave * 32 + (lane & 31)) * 4;
+    const float* a = sA + buf * A_TILE + (lane & 15) * G_LDA + (lane >> 4) * 4;
+    const float* bq = sB + buf * G_BTILE + ((lane >> 4) * G_BN + wave * 16 + (lane & 15)) * 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 bf = *reinterpret_cast<const f32x4*>(bq + q * 2 * G_BN * 4);
+    for (int Q = 0; Q < 2; ++Q) {
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(bq + Q * 4 * G_BN * 4);
       f32x4 af[RT];
 #pragma unroll
-      for (int r = 0; r < RT; ++r) af[r] = *reinterpret_cast<const f32x4*>(a + r * 32 * G_LDA + q * 8);
+      for (int r = 0; r < RT; ++r) af[r] = *reinterpret_cast<const f32x4*>(a + r * 16 * G_LDA + Q * 16);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int r = 0; r < RT; ++r) acc[r] = mfma32(af[r][e], bf[e], acc[r]);
+        for (int r = 0; r < RT; ++r) acc[r] = mfma16(af[r][e], bf[e], acc[r]);
     }
   };
 
@@ -194,89 +226,92 @@ __global__ __launch_bounds__(256) void kb_gemm_kernel(GemmP p) {
     __syncthreads();
   }
 
-  // ---- epilogue.  32x32 accumulator map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int col = cb * G_BN + wave * 32 + (lane & 31);
-  const int rhalf = 4 * (lane >> 5);
-  float bias = 0.f;
-  if (EP == E_BIAS_ACT || EP == E_I2_LOGIT) bias = p.bias[col];
-  float cj = 0.f, wj = 0.f, drj = 0.f;
-  if (EP == E_I2_LOGIT) {
-    cj = p.cvec[(size_t)b * p.Nout + col];
-    wj = p.wvec[col];
-  }
-  if (EP == E_DKB) drj = p.aux[(size_t)b * p.Nout + col];
-  float csum = 0.f;
+  // ---- epilogue, step 1: accumulators -> row-major LDS tile.
+  // 16x16 accumulator map: col = lane & 15, row = (lane >> 4) * 4 + reg
+  float* T = smem;                              // [ROWS][G_LDT]
+  f32x4* red = reinterpret_cast<f32x4*>(smem + ROWS * G_LDT);   // [16][32] column partials
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) T[(r * 16 + (lane >> 4) * 4 + e) * G_LDT + wave * 16 + (lane & 15)] = acc[r][e];
+  __syncthreads();
 
-  float* red = smem;   // [4 waves][RT*32] row partials (E_I2_LOGIT); safe: all LDS reads are done
-#pragma unroll
-  for (int r = 0; r < RT; ++r) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int lrow = r * 32 + (e & 3) + 8 * (e >> 2) + rhalf;
-      const int n = row0 + lrow;
-      const bool ok = n < p.N;
-      const size_t orow = (size_t)b * p.N + n;
-      float val = acc[r][e];
-      if (EP == E_BIAS_ACT) {
-        val = act_apply(p.act, val + bias);
-        if (ok) p.out[orow * p.ldo + col] = val;
-      } else if (EP == E_I2_LOGIT) {
-        val += bias;
-        if (ok) p.out[orow * p.ldo + col] = val;
-        // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w  (bias b_k added in kb_attend)
-        float g = act_apply(p.act, val * cj);
-        const uint32_t idx = (uint32_t)(((size_t)(p.b0 + b) * p.N + n) * p.Nout + col);
-        g = drop_apply(g, idx, p.e_drop);
-        float part = half_sum(g * wj);
-        if ((lane & 31) == 0) red[wave * (RT * 32) + lrow] = part;
-      } else if (EP == E_MUL_DACT) {
-        if (ok) {
-          const float h = p.aux[orow * p.ldo + col];
-          val *= act_grad_from_out(p.act, h);
-          p.out[orow * p.ldo + col] = val;
-        } else {
-          val = 0.f;
-        }
-      } else if (EP == E_PLAIN) {
-        if (ok) p.out[orow * p.ldo + col] = val; else val = 0.f;
-      } else if (EP == E_DKB) {
-        if (ok) {
-          const uint32_t idx = (uint32_t)(((size_t)(p.b0 + b) * p.N + n) * p.ldo + col);
-          val = drop_apply(val, idx, p.e_drop) + p.att[orow] * drj;
-          if (p.accumulate) val += p.out[orow * p.ldo + col];
-          p.out[orow * p.ldo + col] = val;
-        }
-      }
-      if (COLSUM) csum += ok ? val : 0.f;
-    }
-  }
+  // ---- step 2: row-major pass, one float4 per lane, one row per half-wave
+  const int c4 = tid & 31;
+  const int rg = tid >> 5;
+  const int col = cb * G_BN + c4 * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, cj = bias4, wj = bias4, drj = bias4;
+  if (EP == E_BIAS_ACT || EP == E_I2_LOGIT) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
   if (EP == E_I2_LOGIT) {
-    __syncthreads();
-    for (int lrow = tid; lrow < RT * 32; lrow += 256) {
-      const int n = row0 + lrow;
-      if (n < p.N) {
-        const float s = red[lrow] + red[RT * 32 + lrow] + red[2 * RT * 32 + lrow] + red[3 * RT * 32 + lrow];
-        p.logit_part[(size_t)cb * p.B * p.N + (size_t)b * p.N + n] = s;
+    cj = *reinterpret_cast<const f32x4*>(p.cvec + (size_t)b * p.Nout + col);
+    wj = *reinterpret_cast<const f32x4*>(p.wvec + col);
+  }
+  if (EP == E_DKB) drj = *reinterpret_cast<const f32x4*>(p.aux + (size_t)b * p.Nout + col);
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  const int wpr = p.Nout >> 5;   // mask words per output row
+#pragma unroll 1
+  for (int lrow = rg; lrow < ROWS; lrow += 16) {
+    const int n = row0 + lrow;
+    const bool ok = n < p.N;
+    const size_t orow = (size_t)b * p.N + (ok ? n : p.N - 1);
+    f32x4 val = *reinterpret_cast<const f32x4*>(T + lrow * G_LDT + c4 * 4);
+    float* optr = p.out + orow * p.ldo + col;
+    if (EP == E_BIAS_ACT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] = act_apply(p.act, val[e] + bias4[e]);
+      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
+    } else if (EP == E_I2_LOGIT) {
+      val += bias4;
+      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
+      // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w   (bias b_k added in kb_attend)
+      uint32_t bits = 0xFu;
+      if (p.e_bits) bits = p.e_bits[orow * wpr + (col >> 5)] >> (col & 31);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g = act_apply(p.act, val[e] * cj[e]);
+        g = ((bits >> e) & 1u) ? g * p.e_inv_keep : 0.f;
+        part = fmaf(g, wj[e], part);
+      }
+      part = half_sum(part);
+      if (c4 == 0 && ok) p.logit_part[(size_t)cb * p.B * p.N + orow] = part;
+    } else if (EP == E_MUL_DACT) {
+      const f32x4 h = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] *= act_grad_from_out(p.act, h[e]);
+      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
+    } else if (EP == E_PLAIN) {
+      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
+    } else if (EP == E_DKB) {
+      uint32_t bits = 0xFu;
+      if (p.e_bits) bits = p.e_bits[orow * (p.ldo >> 5) + (col >> 5)] >> (col & 31);
+      const float a = p.att[orow];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] = (((bits >> e) & 1u) ? val[e] * p.e_inv_keep : 0.f) + a * drj[e];
+      if (ok) {
+        if (p.accumulate) val += *reinterpret_cast<const f32x4*>(optr);
+        *reinterpret_cast<f32x4*>(optr) = val;
       }
     }
+    if (COLSUM && ok) csum += val;
   }
   if (COLSUM) {
-    // column sum over this workgroup's rows: the two half-waves hold different rows of one column
-    csum += __shfl_xor(csum, 32, 64);
-    if (lane < 32) p.colsum_part[(size_t)(b * nrb + rbi) * p.Nout + col] = csum;
+    red[rg * 32 + c4] = csum;
+    __syncthreads();
+    if (tid < 32) {
+      f32x4 t = red[tid];
+#pragma unroll
+      for (int g = 1; g < 16; ++g) t += red[g * 32 + tid];
+      *reinterpret_cast<f32x4*>(p.colsum_part + (size_t)(b * nrb + rbi) * p.Nout + cb * G_BN + tid * 4) = t;
+    }
   }
-}
-
-template <int RT>
-constexpr size_t kb_gemm_lds_bytes() {
-  return (size_t)(2 * RT * 32 * G_LDA + 2 * G_BTILE) * sizeof(float);
 }
 
 // ---- host-side launcher ---------------------------------------------------------------------
 template <int RT, int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_launch_rt(const GemmP& p, hipStream_t st) {
   auto kern = kb_gemm_kernel<RT, AP, BP, EP, COLSUM>;
-  constexpr size_t lds = kb_gemm_lds_bytes<RT>();
+  constexpr size_t lds = (size_t)kb_gemm_lds_floats<RT>() * sizeof(float);
   static bool attr_set = false;   // one attribute call per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -285,20 +320,22 @@ inline hipError_t kb_gemm_launch_rt(const GemmP& p, hipStream_t st) {
     attr_set = true;
   }
   const int ncb = p.Nout / G_BN;
-  const int nrb = (p.N + RT * 32 - 1) / (RT * 32);
+  const int nrb = (p.N + RT * 16 - 1) / (RT * 16);
   const int grid = p.B * nrb * ncb;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(G_THREADS), lds, st, p);
   return hipGetLastError();
 }
 
-// rows-per-workgroup choice: the smallest RT in {1,2,4,7} whose tile covers a question's N rows
-// in the fewest equal row blocks (196 -> 7, 49 -> 2, 14 -> 1; N > 224 -> 7 with several row blocks).
+// row tiles per workgroup: the smallest of {1,2,4,7,13} x 16 rows that covers a question's N cells
+// (196 -> 13, 49 -> 4, 14 -> 1; N > 208 -> 13 with several row blocks per question).
 inline int kb_gemm_pick_rt(int N) {
-  if (N <= 32) return 1;
-  if (N <= 64) return 2;
-  if (N <= 128) return 4;
-  return 7;
+  if (N <= 16) return 1;
+  if (N <= 32) return 2;
+  if (N <= 64) return 4;
+  if (N <= 112) return 7;
+  return 13;
 }
+inline int kb_gemm_rows(int N) { return kb_gemm_pick_rt(N) * 16; }
 
 template <int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_launch(const GemmP& p, hipStream_t st) {
@@ -306,7 +343,8 @@ inline hipError_t kb_gemm_launch(const GemmP& p, hipStream_t st) {
     case 1: return kb_gemm_launch_rt<1, AP, BP, EP, COLSUM>(p, st);
     case 2: return kb_gemm_launch_rt<2, AP, BP, EP, COLSUM>(p, st);
     case 4: return kb_gemm_launch_rt<4, AP, BP, EP, COLSUM>(p, st);
-    default: return kb_gemm_launch_rt<7, AP, BP, EP, COLSUM>(p, st);
+    case 7: return kb_gemm_launch_rt<7, AP, BP, EP, COLSUM>(p, st);
+    default: return kb_gemm_launch_rt<13, AP, BP, EP, COLSUM>(p, st);
   }
 }
 

@@ -22,8 +22,8 @@ struct TnP {
   int rows_per_split;    // multiple of 2
   const float* A; int lda;
   const float* G; int ldg;
-  DropSpec a_drop;       // A_DROP: mask indexed (row0_global + m)*lda + k
-  uint32_t row0_global;  // b0*N
+  const uint32_t* a_bits; // A_DROP: keep bits of A, [M][lda/32]
+  float a_inv_keep;
   float* part;           // [nsplit][Kd][Jd]
 };
 
@@ -81,10 +81,11 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnP p) {
       const int f = tid + 256 * i;
       f32x4 val = ra[i];
       if (AP == A_DROP) {
-        const int m = m_begin + ch * T_BM + (f >> 5);
-        const uint32_t idx = (uint32_t)(((size_t)p.row0_global + m) * p.lda + tk * T_TILE + (f & 31) * 4);
+        const int m = min(m_begin + ch * T_BM + (f >> 5), p.M - 1);
+        const int k = tk * T_TILE + (f & 31) * 4;
+        const uint32_t bits = p.a_bits[(size_t)m * (p.lda >> 5) + (k >> 5)] >> (k & 31);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = drop_apply(val[e], idx + e, p.a_drop);
+        for (int e = 0; e < 4; ++e) val[e] = ((bits >> e) & 1u) ? val[e] * p.a_inv_keep : 0.f;
       }
       *reinterpret_cast<f32x4*>(sA + buf * T_STAGE + f * 4) = val;
       *reinterpret_cast<f32x4*>(sG + buf * T_STAGE + f * 4) = rg[i];

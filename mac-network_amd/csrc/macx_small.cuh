@@ -8,7 +8,7 @@
 namespace macx {
 
 // ---------------------------------------------------------------------------------------------
-// weight packing for kb_gemm:  dst[q][h][j][e] = src[(8q+4h+e)*ld_k + j*ld_j]
+// weight packing for the MFMA kernels:  dst[Q][g][j][e] = src[(16Q+4g+e)*ld_k + j*ld_j]
 //   (ld_k, ld_j) = (Nout, 1) packs W[K][Nout];  (1, K) packs W^T from W[Nout][K]
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int ld_j, int K, int Nout, float* dst) {
@@ -17,11 +17,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int 
     const int e = i & 3;
     const size_t t = i >> 2;
     const int j = t % Nout;
-    const size_t qh = t / Nout;
-    const int h = qh & 1;
-    const int q = qh >> 1;
-    const int k = 8 * q + 4 * h + e;
+    const size_t qg = t / Nout;
+    const int g = qg & 3;
+    const int Q = qg >> 2;
+    const int k = 16 * Q + 4 * g + e;
     dst[i] = src[(size_t)k * ld_k + (size_t)j * ld_j];
+  }
+}
+
+// keep bits of a dropout site: word w holds elements first + 32w .. first + 32w + 31 (bit i = element i)
+__global__ void mask_bits_kernel(uint32_t key, uint32_t thr24, uint32_t first, size_t nwords, uint32_t* out) {
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t base = first + (uint32_t)(w << 5);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) bits |= (keep_bit(base + i, key, thr24) ? 1u : 0u) << i;
+    out[w] = bits;
   }
 }
 
@@ -43,15 +54,19 @@ __global__ void transpose_kernel(const float* __restrict__ src, int R, int C, fl
 
 // ---------------------------------------------------------------------------------------------
 // small linear:  out[z][r][j] = epi( sum_k x(z,r,k) W[z][k][j] + bias[z][j] + bias_const )
-// x is the concatenation of up to 3 segments along k (ops.concat, ops.py:65-78, without
-// materialising it).  Rows are wave-uniform, so x is fetched through the scalar cache and the
-// vector memory pipe only streams W.  4 waves split K; fixed-order LDS combine.
+// for the [B,d]-sized linears of the cell (ops.linear, ops.py:298-333).  x is the concatenation of
+// up to 3 segments along k (ops.concat, ops.py:65-78, never materialised).
+//
+// fp32 MFMA 16x16x4.  A workgroup owns 64 rows x 16 columns; its 4 waves take interleaved 16-wide
+// k groups of the whole reduction (operands are L2-resident, fragments are loaded straight into
+// registers: A as float4 along k, W from the packed [K/16][4][n_out][4] layout), then a fixed-order
+// LDS combine and a float4 epilogue.  Grid = n_out/16 x ceil(rows/64) x batch.
 // ---------------------------------------------------------------------------------------------
 struct LinSeg { const float* x; int ld; int K; size_t zstride; };
 struct LinP {
   LinSeg seg[3];
   int Ktot, rows, n_out;
-  const float* W; int ldw; size_t zW;
+  const float* W; size_t zW;        // packed [Ktot/16][4][n_out][4]
   const float* bias; size_t zb; float bias_const;
   int act;
   float* out; int ldo; size_t zout;
@@ -61,71 +76,76 @@ struct LinP {
   const float* addend; int ld_add; size_t zadd;                      // val += addend
 };
 
-constexpr int L_ROWS = 16;
+constexpr int L_ROWS = 64;
 
 __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
-  __shared__ float red[4][L_ROWS][64];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = blockIdx.x * 64 + lane;
-  const int jc = min(j, p.n_out - 1);
+  __shared__ float red[4][L_ROWS][20];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = blockIdx.x * 16;
   const int r0 = blockIdx.y * L_ROWS;
   const int z = blockIdx.z;
+  const int li = lane & 15, lg = lane >> 4;
 
-  float acc[L_ROWS];
+  f32x4 acc[4];
 #pragma unroll
-  for (int r = 0; r < L_ROWS; ++r) acc[r] = 0.f;
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int rowc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) rowc[t] = min(r0 + 16 * t + li, p.rows - 1);
 
-  const float* __restrict__ Wz = p.W + (size_t)z * p.zW;
-  for (int kc = wave * 32; kc < p.Ktot; kc += 128) {
-    int s = 0, koff = kc;
-    while (koff >= p.seg[s].K) { koff -= p.seg[s].K; ++s; }
-    const float* __restrict__ xs = p.seg[s].x + (size_t)z * p.seg[s].zstride + koff;
-    const int ld = p.seg[s].ld;
-    const float* __restrict__ w = Wz + (size_t)kc * p.ldw + jc;
+  const float* Wz = p.W + (size_t)z * p.zW + ((size_t)lg * p.n_out + c0 + li) * 4;
+  const int nQ = p.Ktot >> 4;
 #pragma unroll 2
-    for (int kk = 0; kk < 32; kk += 4) {
-      const float w0 = w[(size_t)(kk + 0) * p.ldw];
-      const float w1 = w[(size_t)(kk + 1) * p.ldw];
-      const float w2 = w[(size_t)(kk + 2) * p.ldw];
-      const float w3 = w[(size_t)(kk + 3) * p.ldw];
+  for (int Q = wave; Q < nQ; Q += 4) {
+    int s = 0, koff = Q * 16;
+    while (koff >= p.seg[s].K) { koff -= p.seg[s].K; ++s; }
+    const float* xs = p.seg[s].x + (size_t)z * p.seg[s].zstride + koff + lg * 4;
+    const int ld = p.seg[s].ld;
+    const f32x4 bf = *reinterpret_cast<const f32x4*>(Wz + (size_t)Q * 4 * p.n_out * 4);
+    f32x4 af[4];
 #pragma unroll
-      for (int r = 0; r < L_ROWS; ++r) {
-        const int rr = min(r0 + r, p.rows - 1);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (size_t)rr * ld + kk);
-        acc[r] = fmaf(xv[0], w0, acc[r]);
-        acc[r] = fmaf(xv[1], w1, acc[r]);
-        acc[r] = fmaf(xv[2], w2, acc[r]);
-        acc[r] = fmaf(xv[3], w3, acc[r]);
-      }
-    }
+    for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const f32x4*>(xs + (size_t)rowc[t] * ld);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][e], bf[e], acc[t], 0, 0, 0);
   }
+  // accumulator map: col = lane & 15, row = 16 t + (lane >> 4) * 4 + e
 #pragma unroll
-  for (int r = 0; r < L_ROWS; ++r) red[wave][r][lane] = acc[r];
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][16 * t + lg * 4 + e][li] = acc[t][e];
   __syncthreads();
-  for (int o = threadIdx.x; o < L_ROWS * 64; o += 256) {
-    const int r = o >> 6, l = o & 63;
-    const int row = r0 + r, col = blockIdx.x * 64 + l;
-    if (row >= p.rows || col >= p.n_out) continue;
-    float val = ((red[0][r][l] + red[1][r][l]) + red[2][r][l]) + red[3][r][l];
-    if (p.bias) val += p.bias[(size_t)z * p.zb + col];
-    val += p.bias_const;
-    val = act_apply(p.act, val);
-    if (p.actgrad_src) val *= act_grad_from_out(p.actgrad_act, p.actgrad_src[(size_t)z * p.zag + (size_t)row * p.ld_ag + col]);
+  const int r = tid >> 2, cq = (tid & 3) * 4;
+  const int row = r0 + r;
+  if (row >= p.rows) return;
+  f32x4 val;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) val[e] = ((red[0][r][cq + e] + red[1][r][cq + e]) + red[2][r][cq + e]) + red[3][r][cq + e];
+  const int col = c0 + cq;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = val[e];
+    if (p.bias) v += p.bias[(size_t)z * p.zb + col + e];
+    v += p.bias_const;
+    v = act_apply(p.act, v);
+    if (p.actgrad_src) v *= act_grad_from_out(p.actgrad_act, p.actgrad_src[(size_t)z * p.zag + (size_t)row * p.ld_ag + col + e]);
     if (p.use_drop) {
-      const uint32_t idx = (p.drop_row0 + row) * (uint32_t)p.n_out + col;
+      const uint32_t idx = (p.drop_row0 + row) * (uint32_t)p.n_out + col + e;
       float f = 1.f;
       if (!keep_bit(idx, p.d1.key, p.d1.thr24)) f = 0.f; else f *= p.d1.inv_keep;
       if (!keep_bit(idx, p.d2.key, p.d2.thr24)) f = 0.f; else f *= p.d2.inv_keep;
-      val *= f;
+      v *= f;
     }
-    if (p.addend) val += p.addend[(size_t)z * p.zadd + (size_t)row * p.ld_add + col];
-    p.out[(size_t)z * p.zout + (size_t)row * p.ldo + col] = val;
+    if (p.addend) v += p.addend[(size_t)z * p.zadd + (size_t)row * p.ld_add + col + e];
+    val[e] = v;
   }
+  *reinterpret_cast<f32x4*>(p.out + (size_t)z * p.zout + (size_t)row * p.ldo + col) = val;
 }
 
 inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
-  dim3 grid((p.n_out + 63) / 64, (p.rows + L_ROWS - 1) / L_ROWS, nz);
+  dim3 grid(p.n_out / 16, (p.rows + L_ROWS - 1) / L_ROWS, nz);
   hipLaunchKernelGGL(small_linear_kernel, grid, dim3(256), 0, st, p);
   return hipGetLastError();
 }
@@ -469,7 +489,8 @@ struct ReadAttBwdP {
   const float* c;        // [B][d]   control of this step
   const float* wk;       // [d]
   int act;               // readCtrlAct
-  DropSpec drop;         // SITE_READ_ATT mask of this step
+  const uint32_t* bits;  // keep bits of the SITE_READ_ATT mask of this step, [B*N][d/32]; null = keep all
+  float inv_keep;
   float* dI2;            // [B][N][d]
   float* dc;             // [B][d]        (written)
   float* dwk_part;       // [B][d]        (written)
@@ -510,14 +531,14 @@ __global__ __launch_bounds__(256) void read_att_bwd_kernel(ReadAttBwdP p) {
     const size_t off = ((size_t)b * p.N + n) * p.d + col;
     const f32x4 i2 = *reinterpret_cast<const f32x4*>(p.I2 + off);
     const float dl = s_dl[n];
-    const uint32_t idx = (uint32_t)(((size_t)(p.b0 + b) * p.N + n) * p.d + col);
+    uint32_t bits = 0xFu;
+    if (p.bits) bits = p.bits[((size_t)b * p.N + n) * (p.d >> 5) + (col >> 5)] >> (col & 31);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float zv = i2[e] * cv[e];
       const float g = act_apply(p.act, zv);
-      const bool keep = keep_bit(idx + e, p.drop.key, p.drop.thr24);
-      const float f = keep ? p.drop.inv_keep : 0.f;
+      const float f = ((bits >> e) & 1u) ? p.inv_keep : 0.f;
       a_dw[e] = fmaf(dl, g * f, a_dw[e]);                 // dw_k += dl * dropped(G)
       const float dz = (dl * wv[e]) * f * act_grad_from_out(p.act, g);
       a_dc[e] = fmaf(dz, i2[e], a_dc[e]);                 // dc += dZ * I2

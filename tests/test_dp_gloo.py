@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: the data-parallel path (tower split rule of model.py:139-149 + one
+flat gradient all-reduce) reproduces the full-batch gradient.  Shard gradients come from the oracle
+(the HIP cell cannot run here); what is under test is macx.dp and the global-question-index
+convention of the dropout stream (shard b0)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import macx
+    from oracle import mac_oracle as mo
+    Bg, S, N, d, p = 5, 6, 7, 8, 2            # odd global batch: the last tower takes the remainder
+    cfg = mo.flag_file_config("args", netLength=p, memDim=d, ctrlDim=d, attDim=d)
+    vq, words, lengths, kb = mo.synthetic_inputs(Bg, S, N, d, seed=3, dtype=torch.float64)
+    answers_w = torch.randn(Bg, d, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    keeps = (cfg.memoryDropout, cfg.readDropout, cfg.writeDropout)
+
+    def grads(lo, hi):
+        vs = mo.VarStore(generator=torch.Generator().manual_seed(7), dtype=torch.float64, requires_grad=True)
+        c, m, _ = mo.mac_network(cfg, vs, vq[lo:hi], words[lo:hi], words[lo:hi], lengths[lo:hi], kb[lo:hi], train=True,
+                                 mask_fn=mo.hash_mask_fn(42, keeps, b0=lo), keeps=keeps)
+        loss = (m * answers_w[lo:hi]).sum(dim=1).mean()         # mean over the shard (model.py:596)
+        loss.backward()
+        return vs
+
+    lo, hi = macx.dp.tower_slice(Bg, rank, world)
+    vs = grads(lo, hi)
+    names = sorted(vs.params)
+    tensors = [vs.params[k].float() for k in names]
+    for t, k in zip(tensors, names):
+        t.grad = vs.params[k].grad.float()
+    bucket = macx.dp.GradBucket(tensors)
+    bucket.allreduce_(hi - lo, Bg)
+    if rank == 0:
+        full = grads(0, Bg)
+        worst = 0.0
+        for t, k in zip(tensors, names):
+            ref = full.params[k].grad
+            worst = max(worst, float((t.grad.double() - ref).abs().max() / max(float(ref.abs().max()), 1e-6)))
+        ret["worst"] = worst
+        ret["slices"] = [macx.dp.tower_slice(Bg, r, world) for r in range(world)]
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_equals_full_batch():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["slices"] == [(0, 2), (2, 5)]
+    assert ret["worst"] < 1e-5, ret["worst"]
+
+
+def test_tower_slice_rule():
+    import macx
+    assert [macx.dp.tower_slice(1024, r, 8) for r in (0, 7)] == [(0, 128), (896, 1024)]
+    assert [macx.dp.tower_slice(10, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 10)]

@@ -30,7 +30,7 @@ def test_dropout_stream_matches_numpy(macx, dev):
 
 
 @pytest.mark.parametrize("rows,k1,k2,nout,act", [(64, 512, 0, 512, "NON"), (64, 512, 512, 512, "TANH"),
-                                                  (5, 128, 0, 128, "ELU"), (37, 256, 128, 200, "SIGMOID"), (64, 512, 0, 512, "RELU")])
+                                                  (5, 128, 0, 128, "ELU"), (37, 256, 128, 208, "SIGMOID"), (64, 512, 0, 512, "RELU")])
 def test_linear(macx, dev, rows, k1, k2, nout, act):
     L = macx._lib.lib()
     g = torch.Generator().manual_seed(1)
@@ -45,14 +45,16 @@ def test_linear(macx, dev, rows, k1, k2, nout, act):
     out = torch.empty(rows, nout, device=dev)
     x1d, Wd, bd = x1.to(dev), W.to(dev), b.to(dev)
     x2d = x2.to(dev) if x2 is not None else None
-    macx._lib.check(L.macx_linear(_p(x1d), k1, _p(x2d) if x2d is not None else None, k2, rows, _p(Wd), _p(bd), 0.25, nout,
+    wp = torch.empty_like(Wd)
+    macx._lib.check(L.macx_pack_weight(_p(Wd), k1 + k2, nout, 0, _p(wp), None), "pack")
+    macx._lib.check(L.macx_linear(_p(x1d), k1, _p(x2d) if x2d is not None else None, k2, rows, _p(wp), _p(bd), 0.25, nout,
                                   macx._lib.ACT[act], _p(out), None), "linear")
     torch.cuda.synchronize()
     assert max_abs(out, ref) < 2e-5
 
 
 @pytest.mark.parametrize("B,N,d,keep", [(4, 196, 128, 1.0), (3, 196, 256, 0.85), (5, 49, 128, 0.85), (2, 14, 128, 0.5),
-                                        (2, 100, 128, 0.85), (2, 300, 128, 1.0)])
+                                        (2, 100, 128, 0.85), (2, 300, 128, 1.0), (2, 30, 128, 0.85), (1, 250, 256, 0.85)])
 def test_kb_project(macx, dev, B, N, d, keep):
     """X = dropout(KB) Wx + bx through the MFMA kernel vs fp64, asymmetric W (transpose-detecting)."""
     L = macx._lib.lib()
@@ -66,7 +68,8 @@ def test_kb_project(macx, dev, B, N, d, keep):
     wp = torch.empty(d * d, device=dev)
     kbd, Wd, bd = kb.to(dev), W.to(dev), b.to(dev)
     macx._lib.check(L.macx_pack_weight(_p(Wd), d, d, 0, _p(wp), None), "pack")
-    macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 5, _p(kbd), _p(wp), _p(bd), _p(out), None), "kb_project")
+    bits = torch.empty(B * N * d // 32 + 4, device=dev)
+    macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 5, _p(kbd), _p(wp), _p(bd), _p(out), _p(bits), None), "kb_project")
     torch.cuda.synchronize()
     mask = torch.from_numpy(dh.mask_for(99, dh.SITE_READ_KB, 5, keep, (B, N, d), b0=3)).double()
     ref = ((kb.double() / keep) * mask) @ W.double() + b.double()

@@ -42,7 +42,8 @@ def test_check_and_sizing_without_gpu(macx):
     assert L.macx_check(C.byref(o), C.byref(s)) == 0
     keep = L.macx_saved_floats(C.byref(o), C.byref(s), 1)
     nokeep = L.macx_saved_floats(C.byref(o), C.byref(s), 0)
-    assert keep - nokeep == 3 * 11 * 64 * 196 * 512          # X, H1, I2 kept for 11 more steps
+    # X, H1, I2 (fp32) + the two 1-bit dropout masks, kept for 11 more steps
+    assert keep - nokeep == 11 * 64 * 196 * 512 * 3 + 11 * 2 * (64 * 196 * 512 // 32)
     off, cnt = C.c_size_t(), C.c_size_t()
     assert L.macx_saved_segment(C.byref(o), C.byref(s), 1, macx._lib.SEG["att_kb"], C.byref(off), C.byref(cnt)) == 0
     assert cnt.value == 12 * 64 * 196
