@@ -226,6 +226,9 @@ int macx_wgrad_splits(int M, int Kd, int Jd);
 int macx_wgrad(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd,
                float* out, float* ws, void* stream);
 
+/* tuning hook for A/B measurements: key 0 = waves per workgroup of the knowledge-base GEMM (4 | 8) */
+int macx_debug_set(int key, int value);
+
 const char* macx_strerror(int code);
 int macx_abi_version(void);
 

@@ -60,7 +60,7 @@ class MacxInputGrads(C.Structure):
 EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats", "macx_ws_floats",
            "macx_saved_segment", "macx_cell_begin", "macx_cell_step", "macx_cell_forward", "macx_cell_backward",
            "macx_linear", "macx_pack_weight", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_wgrad_splits",
-           "macx_wgrad")
+           "macx_wgrad", "macx_debug_set")
 
 _lib = None
 
@@ -110,6 +110,7 @@ def lib():
     L.macx_control_attend.argtypes = [P(MacxShapes)] + [C.c_void_p] * 8
     L.macx_dropout_mask.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_void_p,
                                     C.c_void_p]
+    L.macx_debug_set.argtypes = [C.c_int, C.c_int]
     L.macx_wgrad_splits.argtypes = [C.c_int, C.c_int, C.c_int]
     L.macx_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                              C.c_void_p]

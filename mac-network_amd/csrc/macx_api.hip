@@ -119,7 +119,7 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
     L.sc = take(p * B * d);
     L.self_smry = take(p * B * d);
   }
-  L.logit_part = take((d / 128) * B * N);
+  L.logit_part = take((d / 64) * B * N);   // one partial per 64- or 128-column tile
   const size_t pk = keep ? p : 1;
   L.act_stride = keep ? B * N * d : 0;
   L.X = take(pk * B * N * d);
@@ -480,7 +480,7 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   // attention over the knowledge base + summary (mac_cell.py:266-275)
   {
     KbAttP a;
-    a.B = B; a.N = N; a.d = d; a.nparts = d / 128;
+    a.B = B; a.N = N; a.d = d; a.nparts = d / (16 * kb_gemm_nw());
     a.logit_part = saved + L.logit_part; a.bias = P->kbLogits_b;
     a.kb = in->knowledgeBase;
     a.att = saved + L.seg[MACX_SEG_ATT_KB] + (size_t)i * B * N;
@@ -807,6 +807,13 @@ int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, u
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, ds.key, ds.thr24, first, n, out);
   CK(hipGetLastError());
   return MACX_OK;
+}
+
+/* test/tuning hook: key 0 = waves per workgroup of the kb GEMM (4 or 8) */
+int macx_debug_set(int key, int value) {
+  if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }
+  if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
+  return MACX_EINVAL;
 }
 
 int macx_wgrad_splits(int M, int Kd, int Jd) {

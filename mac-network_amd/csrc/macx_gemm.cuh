@@ -17,7 +17,8 @@
 //
 // Layouts
 //   A  (activations)  row-major [B][N][lda], read as float4 along k, staged in LDS with a
-//                     40-float row stride (conflict-free ds_read_b128 for the 16x16x4 A fragment).
+//                     128-byte rows whose 16-byte chunks are XOR-swizzled by (row & 7) (conflict-free
+//                     ds_read_b128 for the 16x16x4 A fragment without padding).
 //   W  (weights)      PRE-PACKED [K/16][4][Nout][4]  with  Wp[Q][g][j][e] = W[16Q + 4g + e][j]
 //                     so a lane's four consecutive MFMA B operands are one ds_read_b128 and the
 //                     global->LDS copy is linear.  MFMA e of group Q contracts k = {16Q+e, 16Q+4+e,
@@ -35,11 +36,7 @@
 namespace macx {
 
 constexpr int G_BK = 32;           // reduction slice per stage
-constexpr int G_BN = 128;          // output columns per workgroup (8 waves x 16)
-constexpr int G_LDA = G_BK + 8;    // padded LDS row stride (floats)
-constexpr int G_BTILE = G_BK * G_BN;
-constexpr int G_LDT = G_BN + 4;    // epilogue tile row stride (floats)
-constexpr int G_THREADS = 512;
+constexpr int G_LDA = G_BK;        // LDS row stride of the A stage (floats); 16-byte chunks XOR-swizzled by row
 
 enum : int { A_PLAIN = 0, A_DROP = 1 };
 enum : int { B_PLAIN = 0, B_YMIX_ROW = 1, B_YMIX_COL = 2 };
@@ -78,6 +75,7 @@ struct GemmP {
   const uint32_t* e_bits; // E_I2_LOGIT: keep bits of act(I2*c) [B*N][Nout/32]; E_DKB: keep bits of KB; null = keep all
   float e_inv_keep;
   int accumulate;         // E_DKB: 1 -> out += , 0 -> out =
+  int dbg;                // measurement knobs (macx_debug_set(1, mask)): 1 skip epilogue, 2 skip in-loop staging, 4 skip fragment reads
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -87,16 +85,27 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int RT>
+// NW = waves per workgroup = 16-column slabs per tile.  NW = 4 (64-column tiles, 256 threads, ~69 KB
+// LDS) lets two independent workgroups share a CU, so one's load/store/barrier phase overlaps the
+// other's MFMA phase; NW = 8 (128-column tiles, 512 threads) reads the A panel half as often.
+template <int RT, int NW>
 constexpr int kb_gemm_lds_floats() {
-  constexpr int stage = 2 * RT * 16 * G_LDA + 2 * G_BTILE;
-  constexpr int epi = RT * 16 * G_LDT + 16 * 32 * 4;
+  constexpr int stage = 2 * RT * 16 * G_LDA + 2 * G_BK * 16 * NW;
+  constexpr int epi = RT * 16 * (16 * NW + 4) + 256 * NW;   // tile + [16 row groups][4 NW float4] column partials
   return stage > epi ? stage : epi;
 }
 
-template <int RT, int AP, int BP, int EP, bool COLSUM>
-__global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
+template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>
+__global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int G_THREADS = 64 * NW;
+  constexpr int G_BN = 16 * NW;             // output columns per workgroup
+  constexpr int G_BTILE = G_BK * G_BN;
+  constexpr int G_LDT = G_BN + 4;           // epilogue tile row stride (floats)
+  constexpr int B_F4 = G_BTILE / 4;         // float4 per B stage
+  constexpr int B_IT = B_F4 / G_THREADS;    // = 2
+  constexpr int CG = G_BN / 4;              // float4 column groups per row in the epilogue
+  constexpr int RG = G_THREADS / CG;        // row groups in the epilogue (= 16)
   constexpr int ROWS = RT * 16;
   constexpr int A_TILE = ROWS * G_LDA;
   constexpr int A_F4 = ROWS * 8;                       // float4 per A stage
@@ -127,8 +136,8 @@ __global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
 
   f32x4 ra[A_IT];
   uint32_t rbits[A_IT];
-  f32x4 rw[2];
-  f32x4 rw2[2];
+  f32x4 rw[B_IT];
+  f32x4 rw2[B_IT];
 
   const float* Abase = p.A + (size_t)b * p.N * p.lda;
   const uint32_t* Bitbase = (AP == A_DROP) ? p.a_bits + (size_t)b * p.N * (p.lda >> 5) : nullptr;
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
     a_off[i] = nc * p.lda + (f & 7) * 4;
   }
   float ycol = 0.f;
-  if (BP == B_YMIX_COL) ycol = p.y[(size_t)b * p.ldy + cb * G_BN + (tid & 127)];
+  if (BP == B_YMIX_COL) ycol = p.y[(size_t)b * p.ldy + cb * G_BN + (tid % G_BN)];
 
   auto load_tiles = [&](int kt) {
 #pragma unroll
@@ -155,10 +164,10 @@ __global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
       if (AP == A_DROP) rbits[i] = Bitbase[a_row[i] * (p.lda >> 5) + kt];
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < B_IT; ++i) {
       const int f = tid + G_THREADS * i;
-      const int chunk = f >> 7;   // Q*4 + g
-      const int j = f & 127;
+      const int chunk = f / G_BN;   // Q*4 + g
+      const int j = f % G_BN;
       const size_t off = ((size_t)(kt * 8 + chunk) * p.Nout + cb * G_BN + j) * 4;
       rw[i] = *reinterpret_cast<const f32x4*>(p.Wp + off);
       if (BP != B_PLAIN) rw2[i] = *reinterpret_cast<const f32x4*>(p.Wp2 + off);
@@ -177,16 +186,17 @@ __global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
         for (int e = 0; e < 4; ++e) val[e] = ((bits >> e) & 1u) ? val[e] * p.a_inv_keep : 0.f;
       }
       if (!a_ok[i]) val = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (f < A_F4) *reinterpret_cast<f32x4*>(dA + (f >> 3) * G_LDA + (f & 7) * 4) = val;
+      // chunk c of row r lives at chunk slot c ^ (r & 7): conflict-free b128 fragment reads, no padding
+      if (f < A_F4) *reinterpret_cast<f32x4*>(dA + (f >> 3) * G_LDA + (((f & 7) ^ ((f >> 3) & 7)) << 2)) = val;
     }
     float* dB = sB + buf * G_BTILE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < B_IT; ++i) {
       const int f = tid + G_THREADS * i;
       f32x4 val = rw[i];
       if (BP == B_YMIX_ROW) {
         // B_eff[k][j] = y[b][k] * W1a[k][j] + W1b[k][j]   (ops.py:703,718 folded into the weights)
-        const int chunk = f >> 7;
+        const int chunk = f / G_BN;
         const int k = kt * G_BK + (chunk >> 2) * 16 + (chunk & 3) * 4;
         const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.y + (size_t)b * p.ldy + k);
         val = val * y4 + rw2[i];
@@ -198,38 +208,43 @@ __global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
     }
   };
 
-  auto compute = [&](int buf) {
-    const float* a = sA + buf * A_TILE + (lane & 15) * G_LDA + (lane >> 4) * 4;
+  auto compute = [&](int buf, int Q) {
+    // lane (i = lane & 15, g = lane >> 4) reads A[i][16Q + 4g ..] = chunk (4Q + g) ^ (i & 7) of row i
+    const float* a = sA + buf * A_TILE + (lane & 15) * G_LDA + ((((Q << 2) + (lane >> 4)) ^ (lane & 7)) << 2);
     const float* bq = sB + buf * G_BTILE + ((lane >> 4) * G_BN + wave * 16 + (lane & 15)) * 4;
+    const f32x4 bf = *reinterpret_cast<const f32x4*>(bq + Q * 4 * G_BN * 4);
+    f32x4 af[RT];
 #pragma unroll
-    for (int Q = 0; Q < 2; ++Q) {
-      const f32x4 bf = *reinterpret_cast<const f32x4*>(bq + Q * 4 * G_BN * 4);
-      f32x4 af[RT];
+    for (int r = 0; r < RT; ++r) af[r] = *reinterpret_cast<const f32x4*>(a + r * 16 * G_LDA);
 #pragma unroll
-      for (int r = 0; r < RT; ++r) af[r] = *reinterpret_cast<const f32x4*>(a + r * 16 * G_LDA + Q * 16);
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int r = 0; r < RT; ++r) acc[r] = mfma16(af[r][e], bf[e], acc[r]);
-    }
+      for (int r = 0; r < RT; ++r) acc[r] = mfma16(af[r][e], bf[e], acc[r]);
   };
 
-  // ---- main loop: register-staged double buffer, one barrier per k-slice
+  // ---- main loop: register-staged double buffer, one barrier per k-slice.  The next slice's LDS
+  // stores sit between the two halves of the current slice's MFMAs so that they drain under them.
   load_tiles(0);
   store_tiles(0, 0);
   __syncthreads();
+  const bool stage = !(p.dbg & 2);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
-    compute(cur);
-    if (kt + 1 < nk) store_tiles(cur ^ 1, kt + 1);
+    const int cur = stage ? (kt & 1) : 0;
+    if (stage && kt + 1 < nk) load_tiles(kt + 1);
+    compute(cur, 0);
+    compute(cur, 1);
+    if (stage && kt + 1 < nk) store_tiles(cur ^ 1, kt + 1);
     __syncthreads();
+  }
+  if (p.dbg & 1) {
+    if (acc[0][0] == 123.456f) p.out[0] = acc[RT - 1][3];
+    return;
   }
 
   // ---- epilogue, step 1: accumulators -> row-major LDS tile.
   // 16x16 accumulator map: col = lane & 15, row = (lane >> 4) * 4 + reg
   float* T = smem;                              // [ROWS][G_LDT]
-  f32x4* red = reinterpret_cast<f32x4*>(smem + ROWS * G_LDT);   // [16][32] column partials
+  f32x4* red = reinterpret_cast<f32x4*>(smem + ROWS * G_LDT);   // [RG][CG] column partials
 #pragma unroll
   for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -237,8 +252,8 @@ __global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
   __syncthreads();
 
   // ---- step 2: row-major pass, one float4 per lane, one row per half-wave
-  const int c4 = tid & 31;
-  const int rg = tid >> 5;
+  const int c4 = tid % CG;
+  const int rg = tid / CG;
   const int col = cb * G_BN + c4 * 4;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, cj = bias4, wj = bias4, drj = bias4;
   if (EP == E_BIAS_ACT || EP == E_I2_LOGIT) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   const int wpr = p.Nout >> 5;   // mask words per output row
 #pragma unroll 1
-  for (int lrow = rg; lrow < ROWS; lrow += 16) {
+  for (int lrow = rg; lrow < ROWS; lrow += RG) {
     const int n = row0 + lrow;
     const bool ok = n < p.N;
     const size_t orow = (size_t)b * p.N + (ok ? n : p.N - 1);
@@ -273,7 +288,9 @@ __global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
         g = ((bits >> e) & 1u) ? g * p.e_inv_keep : 0.f;
         part = fmaf(g, wj[e], part);
       }
-      part = half_sum(part);
+      // the CG lanes of one row are contiguous and CG-aligned inside a wave
+#pragma unroll
+      for (int o = CG / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
       if (c4 == 0 && ok) p.logit_part[(size_t)cb * p.B * p.N + orow] = part;
     } else if (EP == E_MUL_DACT) {
       const f32x4 h = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + col);
@@ -296,22 +313,26 @@ __global__ __launch_bounds__(G_THREADS) void kb_gemm_kernel(GemmP p) {
     if (COLSUM && ok) csum += val;
   }
   if (COLSUM) {
-    red[rg * 32 + c4] = csum;
+    red[rg * CG + c4] = csum;
     __syncthreads();
-    if (tid < 32) {
+    if (tid < CG) {
       f32x4 t = red[tid];
 #pragma unroll
-      for (int g = 1; g < 16; ++g) t += red[g * 32 + tid];
+      for (int g = 1; g < RG; ++g) t += red[g * CG + tid];
       *reinterpret_cast<f32x4*>(p.colsum_part + (size_t)(b * nrb + rbi) * p.Nout + cb * G_BN + tid * 4) = t;
     }
   }
 }
 
 // ---- host-side launcher ---------------------------------------------------------------------
-template <int RT, int AP, int BP, int EP, bool COLSUM>
+// runtime knob (macx_debug_set(0, NW)): waves per workgroup of the kb GEMM, 4 or 8
+inline int& kb_gemm_nw() { static int nw = 8; return nw; }
+inline int& kb_gemm_dbg() { static int m = 0; return m; }
+
+template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_launch_rt(const GemmP& p, hipStream_t st) {
-  auto kern = kb_gemm_kernel<RT, AP, BP, EP, COLSUM>;
-  constexpr size_t lds = (size_t)kb_gemm_lds_floats<RT>() * sizeof(float);
+  auto kern = kb_gemm_kernel<RT, NW, AP, BP, EP, COLSUM>;
+  constexpr size_t lds = (size_t)kb_gemm_lds_floats<RT, NW>() * sizeof(float);
   static bool attr_set = false;   // one attribute call per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -319,10 +340,12 @@ inline hipError_t kb_gemm_launch_rt(const GemmP& p, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int ncb = p.Nout / G_BN;
+  const int ncb = p.Nout / (16 * NW);
   const int nrb = (p.N + RT * 16 - 1) / (RT * 16);
   const int grid = p.B * nrb * ncb;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(G_THREADS), lds, st, p);
+  GemmP q = p;
+  q.dbg = kb_gemm_dbg();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, q);
   return hipGetLastError();
 }
 
@@ -337,15 +360,21 @@ inline int kb_gemm_pick_rt(int N) {
 }
 inline int kb_gemm_rows(int N) { return kb_gemm_pick_rt(N) * 16; }
 
+template <int NW, int AP, int BP, int EP, bool COLSUM>
+inline hipError_t kb_gemm_launch_nw(const GemmP& p, hipStream_t st) {
+  switch (kb_gemm_pick_rt(p.N)) {
+    case 1: return kb_gemm_launch_rt<1, NW, AP, BP, EP, COLSUM>(p, st);
+    case 2: return kb_gemm_launch_rt<2, NW, AP, BP, EP, COLSUM>(p, st);
+    case 4: return kb_gemm_launch_rt<4, NW, AP, BP, EP, COLSUM>(p, st);
+    case 7: return kb_gemm_launch_rt<7, NW, AP, BP, EP, COLSUM>(p, st);
+    default: return kb_gemm_launch_rt<13, NW, AP, BP, EP, COLSUM>(p, st);
+  }
+}
+
 template <int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_launch(const GemmP& p, hipStream_t st) {
-  switch (kb_gemm_pick_rt(p.N)) {
-    case 1: return kb_gemm_launch_rt<1, AP, BP, EP, COLSUM>(p, st);
-    case 2: return kb_gemm_launch_rt<2, AP, BP, EP, COLSUM>(p, st);
-    case 4: return kb_gemm_launch_rt<4, AP, BP, EP, COLSUM>(p, st);
-    case 7: return kb_gemm_launch_rt<7, AP, BP, EP, COLSUM>(p, st);
-    default: return kb_gemm_launch_rt<13, AP, BP, EP, COLSUM>(p, st);
-  }
+  if (kb_gemm_nw() == 8) return kb_gemm_launch_nw<8, AP, BP, EP, COLSUM>(p, st);
+  return kb_gemm_launch_nw<4, AP, BP, EP, COLSUM>(p, st);
 }
 
 }  // namespace macx

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmarks of the individual C-ABI entry points (HIP events on torch's current stream).
+    python tools/microbench.py [--nw 4|8]"""
+import argparse, ctypes as C, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import macx
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3   # us
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--B", type=int, default=64); args = ap.parse_args()
+    L = macx._lib.lib(); dev = torch.device("cuda:0")
+    B, N, d = args.B, 196, 512
+    p = lambda t: C.c_void_p(t.data_ptr())
+    kb = torch.randn(B, N, d, device=dev); W = torch.randn(d, d, device=dev) / 22; b = torch.randn(d, device=dev)
+    wp = torch.empty(d * d, device=dev); out = torch.empty(B, N, d, device=dev); bits = torch.empty(B * N * d // 32, device=dev)
+    L.macx_pack_weight(p(W), d, d, 0, p(wp), None)
+    sh = macx._lib.MacxShapes(B=B, S=50, N=N, d=d, p=12, b0=0)
+    flops = 2.0 * B * N * d * d
+    for nw in (4, 8):
+        L.macx_debug_set(0, nw)
+        for keep in (1.0, 0.85):
+            dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=keep, keep_write=1.0, seed=1)
+            us = timeit(lambda: L.macx_kb_project(C.byref(sh), C.byref(dp), 0, p(kb), p(wp), p(b), p(out), p(bits), None))
+            print("kb_project NW=%d keep=%.2f: %8.1f us  %6.1f TF" % (nw, keep, us, flops / us / 1e6))
+    L.macx_debug_set(0, 8)
+    dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=1)
+    for dbg in (0, 1, 2, 3):
+        L.macx_debug_set(1, dbg)
+        us = timeit(lambda: L.macx_kb_project(C.byref(sh), C.byref(dp), 0, p(kb), p(wp), p(b), p(out), p(bits), None))
+        print("kb_project NW=8 dbg=%d (1 no epilogue, 2 no in-loop staging): %8.1f us  %6.1f TF" % (dbg, us, flops / us / 1e6))
+    L.macx_debug_set(1, 0)
+    M = B * N
+    A = torch.randn(M, d, device=dev); G = torch.randn(M, d, device=dev)
+    ns = L.macx_wgrad_splits(M, d, d); ws = torch.empty(ns * d * d, device=dev); o = torch.empty(d, d, device=dev)
+    us = timeit(lambda: L.macx_wgrad(p(A), d, p(G), d, M, d, d, p(o), p(ws), None))
+    print("wgrad M=%d (%d splits, incl. slab reduce): %8.1f us  %6.1f TF" % (M, ns, us, flops / us / 1e6))
+    x = torch.randn(64, 512, device=dev); o2 = torch.empty(64, 512, device=dev)
+    us = timeit(lambda: L.macx_linear(p(x), 512, None, 0, 64, p(wp), p(b), 0.0, 512, 0, p(o2), None))
+    print("linear 64x512x512: %8.1f us" % us)
+
+if __name__ == "__main__":
+    main()
