@@ -173,7 +173,7 @@ struct BwdLayout {
   size_t dt, du;    // [B,d]
   size_t slab_w2, slab_wx, slab_w1a, slab_w1b;
   size_t ns_big, ngroup;
-  size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part;
+  size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part, ctrl_dl;
   size_t tmpBd[4];  // [B,d] scratch
   size_t small_slab;
   size_t total;
@@ -192,7 +192,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.wqT = take(d * d);
   L.wqUT = take((o->control_input_unshared ? p : 1) * d * d);
   L.wccT = take(2 * d * d); L.wcc2T = take(d * d); L.wscT = take(d * d); L.wgT = take(d * d);
-  L.dI2 = take(B * N * d); L.dI1 = take(B * N * d); L.dX = take(B * N * d); L.da = take(B * N);
+  L.dI2 = take(p * B * N * d); L.dI1 = take(B * N * d); L.dX = take(p * B * N * d); L.da = take(B * N);   // dI2, dX kept per step
   L.DM = take((p + 1) * B * d);
   L.DC = take((p + 1) * B * d);
   L.dcI = take(p * B * d);
@@ -204,10 +204,10 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.DY = take(p * B * d);
   L.dmd = take(B * d);
   L.dt = take(B * d); L.du = take(B * d);
-  L.ns_big = wgrad_splits((int)(B * N), (int)d, (int)d);
+  L.ns_big = wgrad_splits((int)(p * B * N), (int)d, (int)d);
   L.ngroup = (B + sb_qpg((int)B) - 1) / sb_qpg((int)B);
-  L.slab_w2 = take(p * L.ns_big * d * d);
-  L.slab_wx = take(p * L.ns_big * d * d);
+  L.slab_w2 = take(L.ns_big * d * d);
+  L.slab_wx = take(L.ns_big * d * d);
   L.slab_w1a = take(p * L.ngroup * d * d);
   L.slab_w1b = take(p * L.ngroup * d * d);
   const size_t nrb = nrb_of((int)N);
@@ -217,7 +217,8 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dwk_part = take(p * B * d);
   L.dbk_part = take(p * B);
   L.dwc_part = take(B * d);
-  L.dbc_part = take(B);
+  L.dbc_part = take(p * B);
+  L.ctrl_dl = take(p * B * (size_t)s->S);
   for (int i = 0; i < 4; ++i) L.tmpBd[i] = take(B * d);
   // scratch slabs for the small weight gradients (largest: write unit, rows p*B, [win x d])
   size_t small = 0;
@@ -235,7 +236,7 @@ int check_impl(const macx_opts* o, const macx_shapes* s) {
   if (o->abi_version != MACX_ABI_VERSION) return MACX_EINVAL;
   if (s->B < 1 || s->S < 1 || s->N < 1 || s->p < 1 || s->d < 128) return MACX_EINVAL;
   if (s->d % 128 != 0 || s->d > 1024) return MACX_EINVAL;
-  if (s->S > C_MAXS || s->N > K_MAXN) return MACX_EINVAL;
+  if (s->S > C_MAXS || s->N > K_MAXN || s->p > CB_MAXZ) return MACX_EINVAL;
   if ((size_t)(s->b0 + s->B) * s->N * s->d >= (1ull << 32)) return MACX_EINVAL;  // 32-bit dropout index
   if (o->write_inputs != MACX_WRITE_BOTH) return MACX_EUNSUPPORTED;
   if (o->read_mem_act == MACX_ACT_NON) return MACX_EUNSUPPORTED;   // no memKbProj_2 layer then (ops.py:325)
@@ -251,6 +252,20 @@ hipError_t pack(const float* src, int ld_k, int ld_j, int K, int Nout, float* ds
   hipLaunchKernelGGL(pack_weight_kernel, dim3(256), dim3(256), 0, st, src, ld_k, ld_j, K, Nout, dst);
   return hipGetLastError();
 }
+struct Packer {
+  PackList L;
+  int n = 0;
+  void add(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst) {
+    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout};
+  }
+  hipError_t run(hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(64, n), dim3(256), 0, st, L);
+    n = 0;
+    return hipGetLastError();
+  }
+};
+
 hipError_t transpose(const float* src, int R, int C, float* dst, hipStream_t st) {
   hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, src, R, C, dst);
   return hipGetLastError();
@@ -285,7 +300,7 @@ hipError_t mask_bits(float keep, uint32_t seed, uint32_t site, uint32_t step, ui
 
 hipError_t rowsum(const float* src, int rows, int n, size_t ld, float* dst, hipStream_t st) {
   if (!dst) return hipSuccess;
-  hipLaunchKernelGGL(rowsum_kernel, dim3((n + 63) / 64), dim3(256), 0, st, src, rows, n, ld, dst);
+  hipLaunchKernelGGL(rowsum_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, src, rows, n, ld, dst);
   return hipGetLastError();
 }
 hipError_t axpy(const float* x, size_t n, float* y, hipStream_t st) {
@@ -300,7 +315,7 @@ int wgrad_impl(const float* A, int lda, const float* G, int ldg, int M, int Kd, 
   t.M = M; t.Kd = Kd; t.Jd = Jd;
   t.nsplit = wgrad_splits(M, Kd, Jd);
   t.rows_per_split = rows_per_split(M, t.nsplit);
-  t.A = A; t.lda = lda; t.G = G; t.ldg = ldg;
+  t.A = A; t.lda = lda; t.a_mod = M; t.G = G; t.ldg = ldg;
   t.part = (t.nsplit == 1) ? out : ws;
   CK(wgrad_tn_launch<A_PLAIN>(t, st));
   if (t.nsplit > 1) CK(slab_reduce_launch(ws, t.nsplit, (size_t)Kd * Jd, out, 0, st));
@@ -362,15 +377,21 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
   const int B = s->B, d = s->d, p = s->p;
 
   // weights -> MFMA operand layout  (memKbProj rows [0,d) multiply x*y, rows [d,2d) multiply x: ops.py:718)
-  CK(pack(P->projX_W, d, 1, d, d, saved + L.wx_p, st));
-  CK(pack(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, st));
-  CK(pack(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, st));
-  CK(pack(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, st));
-  CK(pack(P->projY_W, d, 1, d, d, saved + L.wy_p, st));
-  CK(pack(P->newMemory_W, d, 1, write_in_dim(o, d), d, saved + L.wm_p, st));
-  CK(pack(P->qInput_W, d, 1, d, d, saved + L.wq_p, st));
-  for (int i = 0; i < (o->control_input_unshared ? p : 1); ++i)
-    CK(pack(P->qInputU_W + (size_t)i * d * d, d, 1, d, d, saved + L.wqU_p + (size_t)i * d * d, st));
+  {
+    Packer pk;
+    pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p);
+    pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p);
+    pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p);
+    pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p);
+    pk.add(P->projY_W, d, 1, d, d, saved + L.wy_p);
+    pk.add(P->newMemory_W, d, 1, write_in_dim(o, d), d, saved + L.wm_p);
+    pk.add(P->qInput_W, d, 1, d, d, saved + L.wq_p);
+    for (int i = 0; i < (o->control_input_unshared ? p : 1); ++i) {
+      if (pk.n == PACK_MAX) CK(pk.run(st));
+      pk.add(P->qInputU_W + (size_t)i * d * d, d, 1, d, d, saved + L.wqU_p + (size_t)i * d * d);
+    }
+    CK(pk.run(st));
+  }
 
   // initial state (mac_cell.py:546-553)
   float* controls = saved + L.seg[MACX_SEG_CONTROLS];
@@ -427,8 +448,9 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   float* X = saved + L.X + (size_t)i * L.act_stride;
   float* H1 = saved + L.H1 + (size_t)i * L.act_stride;
   float* I2 = saved + L.I2 + (size_t)i * L.act_stride;
-  float* info_raw = saved + L.info_raw + (size_t)i * Bd;
   float* info = saved + L.seg[MACX_SEG_INFOS] + (size_t)i * Bd;
+  const bool wdrop = dp->keep_write < 1.0f;
+  float* info_raw = wdrop ? saved + L.info_raw + (size_t)i * Bd : info;
 
   // ---- read unit (mac_cell.py:209-277)
   // memory dropout (mac_cell.py:214-217) then the read-dropout of ops.mul's y input (ops.py:679)
@@ -489,9 +511,9 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     CK(hipGetLastError());
   }
   // write dropout (mac_cell.py:461-463); self.infos keeps the dropped value (mac_cell.py:474)
-  {
+  if (wdrop) {
     const DropSpec dw = make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i);
-    hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, info_raw, B, d, (uint32_t)s->b0, dw, no_drop(), info);
+    hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)info_raw, B, d, (uint32_t)s->b0, dw, no_drop(), info);
     CK(hipGetLastError());
   }
   // ---- write unit (mac_cell.py:305-375), writeInputs = BOTH: act(concat([memory, info]) W + b)
@@ -533,23 +555,31 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   const bool rdrop = dp->keep_read < 1.0f;
 
   // ---- weights in the layouts the backward kernels read
-  CK(pack(P->projX_W, 1, d, d, d, ws + W.wxT_p, st));            // Wx^T
-  CK(pack(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, st));       // W1a^T
-  CK(pack(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, st));  // W1b^T
-  CK(pack(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, st));       // W2^T
-  CK(pack(P->projY_W, 1, d, d, d, ws + W.wyT, st));              // Wy^T
-  CK(pack(P->newMemory_W, 1, d, d, win, ws + W.wmT, st));        // Wm^T: [d] -> [win]
-  CK(pack(P->qInput_W, 1, d, d, d, ws + W.wqT, st));
   const int nU = o->control_input_unshared ? p : 1;
-  for (int i = 0; i < nU; ++i) CK(pack(P->qInputU_W + (size_t)i * dd, 1, d, d, d, ws + W.wqUT + (size_t)i * dd, st));
+  {
+    Packer pk;
+    pk.add(P->projX_W, 1, d, d, d, ws + W.wxT_p);            // Wx^T
+    pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p);       // W1a^T
+    pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p);  // W1b^T
+    pk.add(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p);       // W2^T
+    pk.add(P->projY_W, 1, d, d, d, ws + W.wyT);              // Wy^T
+    pk.add(P->newMemory_W, 1, d, d, win, ws + W.wmT);        // Wm^T: [d] -> [win]
+    pk.add(P->qInput_W, 1, d, d, d, ws + W.wqT);
+    for (int i = 0; i < nU; ++i) {
+      if (pk.n == PACK_MAX) CK(pk.run(st));
+      pk.add(P->qInputU_W + (size_t)i * dd, 1, d, d, d, ws + W.wqUT + (size_t)i * dd);
+    }
+    CK(pk.run(st));
+  }
 
   float* DM = ws + W.DM;
   float* DC = ws + W.DC;
+  // dL/d(newMemory linear output) for all steps; with writeMemAct = NON it IS dL/dm_{1..p}
+  float* dwlin_all = (o->write_mem_act == MACX_ACT_NON) ? DM + Bd : ws + W.dwlin;
   CK(hipMemsetAsync(DM, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
   CK(hipMemsetAsync(DC, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
   if (d_memory) CK(hipMemcpyAsync(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (d_control) CK(hipMemcpyAsync(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  CK(hipMemsetAsync(GI->words, 0, (size_t)B * S * d * sizeof(float), st));
 
   const float* controls = saved + L.seg[MACX_SEG_CONTROLS];
   const float* memories = saved + L.seg[MACX_SEG_MEMORIES];
@@ -564,25 +594,34 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     const float* y = saved + L.y + (size_t)i * Bd;
     const float* dm_i = DM + (size_t)(i + 1) * Bd;   // dL/d m_i, complete at this point
     float* dm_prev = DM + (size_t)i * Bd;
-    float* dwlin = ws + W.dwlin + (size_t)i * Bd;
+    float* dwlin = dwlin_all + (size_t)i * Bd;
+    float* dI2_i = ws + W.dI2 + (size_t)i * BNd;
+    float* dX_i = ws + W.dX + (size_t)i * BNd;
     float* dwin = ws + W.dwin;
-    float* dinfo = ws + W.dinfo;
 
     // ---- write unit backward: dwlin = dm * act'(m_i) ; [dm_prev part | dinfo] = dwlin Wm^T
-    hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, dm_i, memories + (size_t)(i + 1) * Bd,
-                       o->write_mem_act, Bd, dwlin);
-    CK(hipGetLastError());
+    if (o->write_mem_act != MACX_ACT_NON) {
+      hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, dm_i, memories + (size_t)(i + 1) * Bd,
+                         o->write_mem_act, Bd, dwlin);
+      CK(hipGetLastError());
+    }
     {
       LinP l = lin_basic(dwlin, d, d, B, ws + W.wmT, nullptr, win, MACX_ACT_NON, dwin, win);
       CK(small_linear_launch(l, 1, st));
     }
-    // d(info) through the write dropout (mac_cell.py:463)
-    hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)dwin, win, d, B, d, (uint32_t)s->b0,
-                       make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i), dinfo);
-    CK(hipGetLastError());
+    // d(info) through the write dropout (mac_cell.py:463); without write dropout it is a column view of dwin
+    const float* dinfo = dwin + d;
+    int ld_dinfo = win;
+    if (dp->keep_write < 1.0f) {
+      hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)dwin, win, d, B, d, (uint32_t)s->b0,
+                         make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i), ws + W.dinfo);
+      CK(hipGetLastError());
+      dinfo = ws + W.dinfo;
+      ld_dinfo = d;
+    }
 
     // ---- read unit backward
-    hipLaunchKernelGGL(kb_att_da_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, (const float*)dinfo, in->knowledgeBase, B, N, d,
+    hipLaunchKernelGGL(kb_att_da_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, dinfo, ld_dinfo, in->knowledgeBase, B, N, d,
                        ws + W.da);
     CK(hipGetLastError());
     {
@@ -592,14 +631,13 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
       r.act = o->read_ctrl_act;
       r.bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.att_bits + (size_t)i * L.bits_stride) : nullptr;
       r.inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
-      r.dI2 = ws + W.dI2;
-      r.dc = ws + W.tmpBd[0];
+      r.dI2 = dI2_i;
+      r.dc = DC + (size_t)(i + 1) * Bd;   // dL/dc_i += read-unit part
       r.dwk_part = ws + W.dwk_part + (size_t)i * Bd;
       r.db2_part = ws + W.db2_part + (size_t)i * Bd;
       r.dbk_part = ws + W.dbk_part + (size_t)i * B;
-      hipLaunchKernelGGL(read_att_bwd_kernel, dim3(B, d / 128), dim3(256), 0, st, r);
+      hipLaunchKernelGGL(read_att_bwd_kernel, dim3(B, d / 128), dim3(RAB_THREADS), 0, st, r);
       CK(hipGetLastError());
-      CK(axpy(ws + W.tmpBd[0], Bd, DC + (size_t)(i + 1) * Bd, st));   // dL/dc_i += read-unit part
     }
     GemmP g;
     memset(&g, 0, sizeof(g));
@@ -607,22 +645,13 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     g.a_inv_keep = g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
     const uint32_t* kb_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits + (size_t)i * L.bits_stride) : nullptr;
     // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
-    g.A = ws + W.dI2; g.lda = d; g.Wp = ws + W.w2T_p;
+    g.A = dI2_i; g.lda = d; g.Wp = ws + W.w2T_p;
     g.out = ws + W.dI1; g.ldo = d; g.aux = H1; g.act = o->read_mem_act;
     g.colsum_part = ws + W.db1_part + (size_t)i * B * nrb * d;
     CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_MUL_DACT, true>(g, st)));
-    // dW2 slabs = H1^T dI2
-    {
-      TnP t;
-      memset(&t, 0, sizeof(t));
-      t.M = B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(B * N, t.nsplit);
-      t.A = H1; t.lda = d; t.G = ws + W.dI2; t.ldg = d;
-      t.part = ws + W.slab_w2 + (size_t)i * W.ns_big * dd;
-      CK(wgrad_tn_launch<A_PLAIN>(t, st));
-    }
     // dX = dI1 (diag(y) W1a + W1b)^T ; dbx partials
     g.A = ws + W.dI1; g.Wp = ws + W.w1aT_p; g.Wp2 = ws + W.w1bT_p; g.y = y; g.ldy = d;
-    g.out = ws + W.dX; g.aux = nullptr;
+    g.out = dX_i; g.aux = nullptr;
     g.colsum_part = ws + W.dbx_part + (size_t)i * B * nrb * d;
     CK((kb_gemm_launch<A_PLAIN, B_YMIX_COL, E_PLAIN, true>(g, st)));
     // S_b = X_b^T dI1_b -> dW1a / dW1b slabs and dy partials
@@ -636,23 +665,12 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
       CK(sb_wgrad_launch(q, st));
     }
     // dKB (+)= (dX Wx^T) * kbmask + att * dinfo
-    g.A = ws + W.dX; g.Wp = ws + W.wxT_p; g.Wp2 = nullptr; g.y = nullptr;
-    g.out = GI->knowledgeBase; g.aux = dinfo; g.att = att_kb + (size_t)i * B * N;
+    g.A = dX_i; g.Wp = ws + W.wxT_p; g.Wp2 = nullptr; g.y = nullptr;
+    g.out = GI->knowledgeBase; g.aux = dinfo; g.ld_aux = ld_dinfo; g.att = att_kb + (size_t)i * B * N;
     g.e_bits = kb_bits;
     g.accumulate = (i != p - 1);
     g.colsum_part = nullptr;
     CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_DKB, false>(g, st)));
-    // dWx slabs = dropout(KB)^T dX
-    {
-      TnP t;
-      memset(&t, 0, sizeof(t));
-      t.M = B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(B * N, t.nsplit);
-      t.A = in->knowledgeBase; t.lda = d; t.G = ws + W.dX; t.ldg = d;
-      t.a_bits = kb_bits; t.a_inv_keep = g.a_inv_keep;
-      t.part = ws + W.slab_wx + (size_t)i * W.ns_big * dd;
-      if (rdrop) CK(wgrad_tn_launch<A_DROP>(t, st));
-      else CK(wgrad_tn_launch<A_PLAIN>(t, st));
-    }
     // dy -> d(md) -> dL/d m_{i-1} = dwin[:, :d] + (dy Wy^T) * memmask * readmask
     float* DYi = ws + W.DY + (size_t)i * Bd;
     hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dy_part), 2 * d / 128, Bd, DYi);
@@ -678,13 +696,15 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     c.cc = saved + L.cc; c.z_cc = Bd;
     c.att = saved + L.seg[MACX_SEG_ATT_QUESTION]; c.z_att = (size_t)B * S;
     c.words = in->words; c.w = P->ctrlLogits_w;
+    c.dl = ws + W.ctrl_dl;
     c.dcc = ws + W.dcc; c.z_dcc = Bd;
     c.dwords = GI->words;
     c.dw_part = ws + W.dwc_part; c.db_part = ws + W.dbc_part;
-    hipLaunchKernelGGL(control_attend_bwd_kernel, dim3(B), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(control_bwd_dl_kernel, dim3(B, p), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(control_bwd_apply_kernel, dim3(B, d / 64), dim3(256), 0, st, c);
     CK(hipGetLastError());
     CK(rowsum(ws + W.dwc_part, B, d, d, GP->ctrlLogits_w, st));
-    CK(rowsum(ws + W.dbc_part, B, 1, 1, GP->ctrlLogits_b, st));
+    CK(rowsum(ws + W.dbc_part, p * B, 1, 1, GP->ctrlLogits_b, st));
   }
   // ---- control inputs backward (mac_cell.py:442-448): dt = sum_i dcI_i WqU_i^T ; du = dt * act'(t)
   const float* ctrl_t = saved + L.ctrl_t;
@@ -725,13 +745,29 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   // ---- weight gradients of the [B,d] linears, one contraction over all p*B rows each
   CKI(wgrad_impl(saved + L.md, d, ws + W.DY, d, p * B, d, d, GP->projY_W, ws + W.small_slab, st));
   CK(rowsum(ws + W.DY, p * B, d, d, GP->projY_b, st));
-  CKI(wgrad_impl(memories, d, ws + W.dwlin, d, p * B, d, d, GP->newMemory_W, ws + W.small_slab, st));
-  CKI(wgrad_impl(infos, d, ws + W.dwlin, d, p * B, d, d, GP->newMemory_W + dd, ws + W.small_slab, st));
-  CK(rowsum(ws + W.dwlin, p * B, d, d, GP->newMemory_b, st));
+  CKI(wgrad_impl(memories, d, dwlin_all, d, p * B, d, d, GP->newMemory_W, ws + W.small_slab, st));
+  CKI(wgrad_impl(infos, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + dd, ws + W.small_slab, st));
+  CK(rowsum(dwlin_all, p * B, d, d, GP->newMemory_b, st));
 
   // ---- read-unit weights: fixed-order reduction of the per-step slabs
-  CK(slab_reduce_launch(ws + W.slab_w2, (int)(p * W.ns_big), dd, GP->memKbProj2_W, 0, st));
-  CK(slab_reduce_launch(ws + W.slab_wx, (int)(p * W.ns_big), dd, GP->projX_W, 0, st));
+  // dW2 = sum_i H1_i^T dI2_i and dWx = sum_i dropout_i(KB)^T dX_i: ONE contraction each over all
+  // p*B*N rows (the per-step operands are kept; 288 GB of HBM makes that the cheap choice)
+  {
+    TnP t;
+    memset(&t, 0, sizeof(t));
+    t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(t.M, t.nsplit);
+    t.A = saved + L.H1; t.lda = d; t.a_mod = t.M; t.G = ws + W.dI2; t.ldg = d;
+    t.part = ws + W.slab_w2;
+    CK(wgrad_tn_launch<A_PLAIN>(t, st));
+    t.A = in->knowledgeBase; t.a_mod = B * N; t.G = ws + W.dX;
+    t.a_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits) : nullptr;
+    t.a_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+    t.part = ws + W.slab_wx;
+    if (rdrop) CK(wgrad_tn_launch<A_DROP>(t, st));
+    else CK(wgrad_tn_launch<A_PLAIN>(t, st));
+  }
+  CK(slab_reduce_launch(ws + W.slab_w2, (int)W.ns_big, dd, GP->memKbProj2_W, 0, st));
+  CK(slab_reduce_launch(ws + W.slab_wx, (int)W.ns_big, dd, GP->projX_W, 0, st));
   CK(slab_reduce_launch(ws + W.slab_w1a, (int)(p * W.ngroup), dd, GP->memKbProj_W, 0, st));
   CK(slab_reduce_launch(ws + W.slab_w1b, (int)(p * W.ngroup), dd, GP->memKbProj_W + dd, 0, st));
   CK(rowsum(ws + W.db2_part, p * B, d, d, GP->memKbProj2_b, st));

@@ -66,7 +66,8 @@ struct GemmP {
   int ldo;
   const float* bias;      // [Nout]
   int act;                // activation code (E_BIAS_ACT, E_I2_LOGIT, E_MUL_DACT)
-  const float* aux;       // E_MUL_DACT: H1 [B*N][ldo];  E_DKB: dr [B][Nout]
+  const float* aux;       // E_MUL_DACT: H1 [B*N][ldo];  E_DKB: dr [B][ld_aux]
+  int ld_aux;
   const float* cvec;      // E_I2_LOGIT: control [B][Nout]
   const float* wvec;      // E_I2_LOGIT: logits weight [Nout]
   const float* att;       // E_DKB: kb attention [B][N]
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
     cj = *reinterpret_cast<const f32x4*>(p.cvec + (size_t)b * p.Nout + col);
     wj = *reinterpret_cast<const f32x4*>(p.wvec + col);
   }
-  if (EP == E_DKB) drj = *reinterpret_cast<const f32x4*>(p.aux + (size_t)b * p.Nout + col);
+  if (EP == E_DKB) drj = *reinterpret_cast<const f32x4*>(p.aux + (size_t)b * p.ld_aux + col);
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   const int wpr = p.Nout >> 5;   // mask words per output row
 #pragma unroll 1

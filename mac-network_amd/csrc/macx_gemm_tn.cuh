@@ -11,7 +11,7 @@
 
 namespace macx {
 
-constexpr int T_BM = 32;            // reduction rows per stage
+constexpr int T_BM = 64;            // reduction rows per stage
 constexpr int T_TILE = 128;         // output tile edge
 constexpr int T_STAGE = T_BM * T_TILE;
 
@@ -21,14 +21,18 @@ struct TnP {
   int nsplit;
   int rows_per_split;    // multiple of 2
   const float* A; int lda;
+  int a_mod;             // A row of reduction row m is (m % a_mod): the same KB under p different masks
   const float* G; int ldg;
   const uint32_t* a_bits; // A_DROP: keep bits of A, [M][lda/32]
   float a_inv_keep;
   float* part;           // [nsplit][Kd][Jd]
 };
 
+// 8 waves: waves 0-3 and 4-7 each cover the 128x128 tile as 2x2 sub-tiles of 64x64 and take
+// alternate k-steps (row pairs) of every stage, so each SIMD holds two waves whose LDS waits hide
+// under the other's MFMAs; the two half-sums are combined through LDS in a fixed order.
 template <int AP>
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(TnP p) {
+__global__ __launch_bounds__(512) void wgrad_tn_kernel(TnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                  // [2][T_STAGE]
   float* sG = smem + 2 * T_STAGE;    // [2][T_STAGE]
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnP p) {
   const int tk = tile / ntj, tj = tile % ntj;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
   const int nchunk = (m_end - m_begin + T_BM - 1) / T_BM;
@@ -63,31 +67,29 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnP p) {
   auto load_stage = [&](int ch) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
+      const int f = tid + 512 * i;
       const int m = m_begin + ch * T_BM + (f >> 5);
+      const int mc = min(m, p.M - 1);
       const int c4 = (f & 31) * 4;
-      if (m < m_end) {
-        ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)m * p.lda + tk * T_TILE + c4);
-        rg[i] = *reinterpret_cast<const f32x4*>(p.G + (size_t)m * p.ldg + tj * T_TILE + c4);
-      } else {
+      ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)(mc % p.a_mod) * p.lda + tk * T_TILE + c4);
+      rg[i] = *reinterpret_cast<const f32x4*>(p.G + (size_t)mc * p.ldg + tj * T_TILE + c4);
+      if (AP == A_DROP) {
+        const int k = tk * T_TILE + c4;
+        const uint32_t bits = p.a_bits[(size_t)mc * (p.lda >> 5) + (k >> 5)] >> (k & 31);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[i][e] = ((bits >> e) & 1u) ? ra[i][e] * p.a_inv_keep : 0.f;
+      }
+      if (m >= m_end) {
         ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
-  auto store_stage = [&](int buf, int ch) {
+  auto store_stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
-      f32x4 val = ra[i];
-      if (AP == A_DROP) {
-        const int m = min(m_begin + ch * T_BM + (f >> 5), p.M - 1);
-        const int k = tk * T_TILE + (f & 31) * 4;
-        const uint32_t bits = p.a_bits[(size_t)m * (p.lda >> 5) + (k >> 5)] >> (k & 31);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = ((bits >> e) & 1u) ? val[e] * p.a_inv_keep : 0.f;
-      }
-      *reinterpret_cast<f32x4*>(sA + buf * T_STAGE + f * 4) = val;
+      const int f = tid + 512 * i;
+      *reinterpret_cast<f32x4*>(sA + buf * T_STAGE + f * 4) = ra[i];
       *reinterpret_cast<f32x4*>(sG + buf * T_STAGE + f * 4) = rg[i];
     }
   };
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnP p) {
     const float* a = sA + buf * T_STAGE + (lane >> 5) * T_TILE + wr * 64 + (lane & 31);
     const float* g = sG + buf * T_STAGE + (lane >> 5) * T_TILE + wc * 64 + (lane & 31);
 #pragma unroll 4
-    for (int s = 0; s < steps; ++s) {
+    for (int s = grp; s < steps; s += 2) {
       const float a0 = a[s * 2 * T_TILE], a1 = a[s * 2 * T_TILE + 32];
       const float g0 = g[s * 2 * T_TILE], g1 = g[s * 2 * T_TILE + 32];
       acc[0][0] = mfma32(a0, g0, acc[0][0]);
@@ -107,29 +109,42 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnP p) {
 
   if (nchunk > 0) {
     load_stage(0);
-    store_stage(0, 0);
+    store_stage(0);
     __syncthreads();
     for (int ch = 0; ch < nchunk; ++ch) {
       const int cur = ch & 1;
       if (ch + 1 < nchunk) load_stage(ch + 1);
       const int rows = min(T_BM, m_end - (m_begin + ch * T_BM));
       compute(cur, (rows + 1) >> 1);
-      if (ch + 1 < nchunk) store_stage(cur ^ 1, ch + 1);
+      if (ch + 1 < nchunk) store_stage(cur ^ 1);
       __syncthreads();
     }
   }
 
-  float* out = p.part + (size_t)split * p.Kd * p.Jd;
+  // combine the two k-step groups (fixed order: group 0 + group 1), then store
+  float* red = smem;   // [4 waves][4 tiles][16 regs][64 lanes]
+  if (grp == 1) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int k = tk * T_TILE + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int j = tj * T_TILE + wc * 64 + c * 32 + (lane & 31);
-        out[(size_t)k * p.Jd + j] = acc[a][c][e];
-      }
+        for (int e = 0; e < 16; ++e) red[(((wave & 3) * 4 + a * 2 + c) * 16 + e) * 64 + lane] = acc[a][c][e];
+  }
+  __syncthreads();
+  if (grp == 0) {
+    float* out = p.part + (size_t)split * p.Kd * p.Jd;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int k = tk * T_TILE + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int j = tj * T_TILE + wc * 64 + c * 32 + (lane & 31);
+          out[(size_t)k * p.Jd + j] = acc[a][c][e] + red[(((wave & 3) * 4 + a * 2 + c) * 16 + e) * 64 + lane];
+        }
+  }
 }
 
 template <int AP>
@@ -144,7 +159,7 @@ inline hipError_t wgrad_tn_launch(const TnP& p, hipStream_t st) {
     attr_set = true;
   }
   const int grid = (p.Kd / T_TILE) * (p.Jd / T_TILE) * p.nsplit;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(256) void sb_wgrad_kernel(SbP p) {
   const int b_begin = group * p.qpg;
   const int b_end = min(p.B, b_begin + p.qpg);
 
-  f32x4 ra[4], rg[4];
+  f32x4 ra[8], rg[8];
   for (int b = b_begin; b < b_end; ++b) {
     const float* Xb = p.X + (size_t)b * p.N * p.d;
     const float* Gb = p.dI1 + (size_t)b * p.N * p.d;
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(256) void sb_wgrad_kernel(SbP p) {
 
     auto load_stage = [&](int ch) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
         const int f = tid + 256 * i;
         const int n = ch * T_BM + (f >> 5);
         const int c4 = (f & 31) * 4;
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(256) void sb_wgrad_kernel(SbP p) {
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
         const int f = tid + 256 * i;
         *reinterpret_cast<f32x4*>(sA + buf * T_STAGE + f * 4) = ra[i];
         *reinterpret_cast<f32x4*>(sG + buf * T_STAGE + f * 4) = rg[i];

@@ -25,6 +25,23 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int 
   }
 }
 
+// several weights in one launch (blockIdx.y selects the descriptor)
+struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; };
+constexpr int PACK_MAX = 40;
+struct PackList { PackDesc d[PACK_MAX]; };
+__global__ void pack_weights_kernel(PackList L) {
+  const PackDesc q = L.d[blockIdx.y];
+  const size_t total = (size_t)q.K * q.Nout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = i & 3;
+    const size_t t = i >> 2;
+    const int j = t % q.Nout;
+    const size_t qg = t / q.Nout;
+    const int k = 16 * (int)(qg >> 2) + 4 * (int)(qg & 3) + e;
+    q.dst[i] = q.src[(size_t)k * q.ld_k + (size_t)j * q.ld_j];
+  }
+}
+
 // keep bits of a dropout site: word w holds elements first + 32w .. first + 32w + 31 (bit i = element i)
 __global__ void mask_bits_kernel(uint32_t key, uint32_t thr24, uint32_t first, size_t nwords, uint32_t* out) {
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (size_t)gridDim.x * blockDim.x) {
@@ -96,20 +113,31 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
 
   const float* Wz = p.W + (size_t)z * p.zW + ((size_t)lg * p.n_out + c0 + li) * 4;
   const int nQ = p.Ktot >> 4;
-#pragma unroll 2
-  for (int Q = wave; Q < nQ; Q += 4) {
-    int s = 0, koff = Q * 16;
-    while (koff >= p.seg[s].K) { koff -= p.seg[s].K; ++s; }
-    const float* xs = p.seg[s].x + (size_t)z * p.seg[s].zstride + koff + lg * 4;
-    const int ld = p.seg[s].ld;
-    const f32x4 bf = *reinterpret_cast<const f32x4*>(Wz + (size_t)Q * 4 * p.n_out * 4);
-    f32x4 af[4];
+  // Operands are L2-resident and the chain is latency-bound: fetch the fragments of 8 k-groups
+  // (40 x 16 B per lane in flight) before touching the matrix pipe.
+  constexpr int PF = 8;
+  for (int Q0 = wave; Q0 < nQ; Q0 += 4 * PF) {
+    f32x4 bf[PF], af[PF][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const f32x4*>(xs + (size_t)rowc[t] * ld);
+    for (int u = 0; u < PF; ++u) {
+      const int Q = min(Q0 + 4 * u, nQ - 1);
+      int s = 0, koff = Q * 16;
+      while (koff >= p.seg[s].K) { koff -= p.seg[s].K; ++s; }
+      const float* xs = p.seg[s].x + (size_t)z * p.seg[s].zstride + koff + lg * 4;
+      const int ld = p.seg[s].ld;
+      bf[u] = *reinterpret_cast<const f32x4*>(Wz + (size_t)Q * 4 * p.n_out * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int t = 0; t < 4; ++t) af[u][t] = *reinterpret_cast<const f32x4*>(xs + (size_t)rowc[t] * ld);
+    }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][e], bf[e], acc[t], 0, 0, 0);
+    for (int u = 0; u < PF; ++u) {
+      if (Q0 + 4 * u < nQ) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][t][e], bf[u][e], acc[t], 0, 0, 0);
+      }
+    }
   }
   // accumulator map: col = lane & 15, row = 16 t + (lane >> 4) * 4 + e
 #pragma unroll
@@ -182,23 +210,28 @@ __global__ void dropout_mask_kernel(uint32_t key, uint32_t thr24, uint32_t first
 }
 
 // dst[i] = sum over `rows` rows of src[r*ld + i]   (bias gradients from per-question partials).
-// One workgroup per 64 columns; the 4 waves take interleaved rows, fixed-order LDS combine.
-__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ src, int rows, int n, size_t ld, float* dst) {
-  __shared__ float red[4][64];
+// One workgroup (16 waves) per 64 columns; waves take interleaved rows, fixed-order LDS combine.
+__global__ __launch_bounds__(1024) void rowsum_kernel(const float* __restrict__ src, int rows, int n, size_t ld, float* dst) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f;
   if (i < n) {
     int r = wave;
-    for (; r + 4 < rows; r += 8) {
+    for (; r + 16 < rows; r += 32) {
       s0 += src[(size_t)r * ld + i];
-      s1 += src[(size_t)(r + 4) * ld + i];
+      s1 += src[(size_t)(r + 16) * ld + i];
     }
     if (r < rows) s0 += src[(size_t)r * ld + i];
   }
   red[wave][lane] = s0 + s1;
   __syncthreads();
-  if (wave == 0 && i < n) dst[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0 && i < n) {
+    float t = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += red[w][lane];
+    dst[i] = t;
+  }
 }
 
 // dst[r][j] = src[r*ld_src + col0 + j] * dropfactor((row0+r)*d + j)
@@ -299,8 +332,11 @@ __global__ __launch_bounds__(256) void control_attend_kernel(CtrlP p) {
   }
 }
 
-// backward of the above for steps z = 0..nz-1 of one question (one workgroup per question so that
-// d(words) accumulates over steps in a fixed order without atomics).
+// backward of the word attention, in two launches so that every question x step (then every
+// question x column slab) gets its own workgroup and d(words) is written once, without atomics:
+//   (1) per (question, step): da[s] = dc . words[s];  dl = softmax backward;  db partial
+//   (2) per (question, 64-column slab): R[z] = sum_s dl[z][s] words[s];  dcc = w * R;
+//       dw partial = sum_z cc[z] * R[z];  dwords[s] = sum_z att[z][s] dc[z] + dl[z][s] cc[z] w
 struct CtrlBwdP {
   int B, S, d, nz;
   const float* dcontrol; size_t z_dc;   // [z][B][d]  gradient wrt the control of step z
@@ -308,91 +344,110 @@ struct CtrlBwdP {
   const float* att; size_t z_att;       // [z][B][S]
   const float* words;                   // [B][S][d]
   const float* w;                       // [d]
+  float* dl;                            // [z][B][S]   scratch (written by (1), read by (2))
   float* dcc; size_t z_dcc;             // [z][B][d]   out
-  float* dwords;                        // [B][S][d]   out (+= over steps; zeroed by caller)
+  float* dwords;                        // [B][S][d]   out (written, not accumulated)
   float* dw_part;                       // [B][d]      out (sum over steps)
-  float* db_part;                       // [B]         out
+  float* db_part;                       // [nz*B]      out
 };
 
-__global__ __launch_bounds__(256) void control_attend_bwd_kernel(CtrlBwdP p) {
-  __shared__ float s_dl[C_MAXS];
-  __shared__ float s_att[C_MAXS];
+__global__ __launch_bounds__(256) void control_bwd_dl_kernel(CtrlBwdP p) {
+  __shared__ float s_da[C_MAXS];
   __shared__ float s_red[4];
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, z = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* words = p.words + (size_t)b * p.S * p.d;
-  float* dwords = p.dwords + (size_t)b * p.S * p.d;
-  float dbsum = 0.f;
-  // per-thread partial of dw over steps, for the (up to 2) column pairs this thread owns
-  float dw0[2] = {0.f, 0.f}, dw1[2] = {0.f, 0.f};
-
-  for (int z = 0; z < p.nz; ++z) {
-    const float* dc = p.dcontrol + (size_t)z * p.z_dc + (size_t)b * p.d;
-    const float* cc = p.cc + (size_t)z * p.z_cc + (size_t)b * p.d;
-    const float* att = p.att + (size_t)z * p.z_att + (size_t)b * p.S;
-    // da[s] = dc . words[s]
-    for (int s = wave; s < p.S; s += 4) {
-      float part = 0.f;
-      for (int k = lane * 4; k < p.d; k += 256) {
-        const f32x4 wd = *reinterpret_cast<const f32x4*>(words + (size_t)s * p.d + k);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dc + k);
-        part += g[0] * wd[0] + g[1] * wd[1] + g[2] * wd[2] + g[3] * wd[3];
-      }
-      part = wave_sum(part);
-      if (lane == 0) { s_dl[s] = part; s_att[s] = att[s]; }
+  const float* dc = p.dcontrol + (size_t)z * p.z_dc + (size_t)b * p.d;
+  const float* att = p.att + (size_t)z * p.z_att + (size_t)b * p.S;
+  for (int s = wave; s < p.S; s += 4) {
+    float part = 0.f;
+    for (int k = lane * 4; k < p.d; k += 256) {
+      const f32x4 wd = *reinterpret_cast<const f32x4*>(words + (size_t)s * p.d + k);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dc + k);
+      part += g[0] * wd[0] + g[1] * wd[1] + g[2] * wd[2] + g[3] * wd[3];
     }
-    __syncthreads();
-    float dot = 0.f;
-    for (int s = tid; s < p.S; s += 256) dot += s_att[s] * s_dl[s];
-    dot = wave_sum(dot);
-    if (lane == 0) s_red[wave] = dot;
-    __syncthreads();
-    dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    __syncthreads();
-    float dls = 0.f;
-    for (int s = tid; s < p.S; s += 256) {
-      const float dl = s_att[s] * (s_dl[s] - dot);   // masked words have att == 0 -> dl == 0
-      s_dl[s] = dl;
-      dls += dl;
-    }
-    dbsum += dls;
-    __syncthreads();
-    int slot = 0;
-    for (int k = tid * 2; k < p.d; k += 512, ++slot) {
-      const float2 c2 = *reinterpret_cast<const float2*>(cc + k);
-      const float2 w2 = *reinterpret_cast<const float2*>(p.w + k);
-      const float2 g2 = *reinterpret_cast<const float2*>(dc + k);
-      float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
-      for (int s = 0; s < p.S; ++s) {
-        const float dl = s_dl[s], a = s_att[s];
-        const float2 wd = *reinterpret_cast<const float2*>(words + (size_t)s * p.d + k);
-        a0 = fmaf(dl, wd.x, a0);            // sum_s dl[s] words[s]
-        a1 = fmaf(dl, wd.y, a1);
-        float2* dwp = reinterpret_cast<float2*>(dwords + (size_t)s * p.d + k);
-        float2 cur = *dwp;
-        cur.x += a * g2.x + dl * (c2.x * w2.x);
-        cur.y += a * g2.y + dl * (c2.y * w2.y);
-        *dwp = cur;
-      }
-      q0 = a0 * c2.x; q1 = a1 * c2.y;       // dw[d] += sum_s dl[s] cc[d] words[s][d]
-      if (slot < 2) { dw0[slot] += q0; dw1[slot] += q1; }
-      float* dst = p.dcc + (size_t)z * p.z_dcc + (size_t)b * p.d + k;
-      dst[0] = a0 * w2.x;                    // dcc[d] = sum_s dl[s] words[s][d] w[d]
-      dst[1] = a1 * w2.y;
-    }
-    __syncthreads();
+    part = wave_sum(part);
+    if (lane == 0) s_da[s] = part;
   }
-  int slot = 0;
-  for (int k = tid * 2; k < p.d; k += 512, ++slot) {
-    if (slot < 2) {
-      p.dw_part[(size_t)b * p.d + k] = dw0[slot];
-      p.dw_part[(size_t)b * p.d + k + 1] = dw1[slot];
-    }
-  }
-  dbsum = wave_sum(dbsum);
-  if (lane == 0) s_red[wave] = dbsum;
   __syncthreads();
-  if (tid == 0) p.db_part[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  float dot = 0.f;
+  for (int s = tid; s < p.S; s += 256) dot += att[s] * s_da[s];
+  dot = wave_sum(dot);
+  if (lane == 0) s_red[wave] = dot;
+  __syncthreads();
+  dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  __syncthreads();
+  float dls = 0.f;
+  for (int s = tid; s < p.S; s += 256) {
+    const float dl = att[s] * (s_da[s] - dot);   // masked words have att == 0 -> dl == 0
+    p.dl[((size_t)z * p.B + b) * p.S + s] = dl;
+    dls += dl;
+  }
+  dls = wave_sum(dls);
+  if (lane == 0) s_red[wave] = dls;
+  __syncthreads();
+  if (tid == 0) p.db_part[(size_t)z * p.B + b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+constexpr int CB_MAXZ = 32;   // max netLength handled by the slab kernel's LDS staging
+__global__ __launch_bounds__(256) void control_bwd_apply_kernel(CtrlBwdP p) {
+  __shared__ float s_words[64][64];     // [s][col] for the 64 words of the current pass
+  __shared__ float s_dl[CB_MAXZ][64];   // [z][s]
+  __shared__ float s_att[CB_MAXZ][64];
+  __shared__ float s_dc[CB_MAXZ][64];
+  __shared__ float s_ccw[CB_MAXZ][64];
+  __shared__ float s_R[4][64];
+  const int b = blockIdx.x, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, col = tid & 63, grp = tid >> 6;
+  const float wc = p.w[c0 + col];
+  for (int z = grp; z < p.nz; z += 4) {
+    s_dc[z][col] = p.dcontrol[(size_t)z * p.z_dc + (size_t)b * p.d + c0 + col];
+    s_ccw[z][col] = p.cc[(size_t)z * p.z_cc + (size_t)b * p.d + c0 + col] * wc;
+  }
+  float Racc[CB_MAXZ / 4];
+#pragma unroll
+  for (int i = 0; i < CB_MAXZ / 4; ++i) Racc[i] = 0.f;
+  for (int sb = 0; sb < p.S; sb += 64) {
+    const int sn = min(64, p.S - sb);
+    __syncthreads();
+    for (int s = grp; s < sn; s += 4) s_words[s][col] = p.words[((size_t)b * p.S + sb + s) * p.d + c0 + col];
+    for (int i = tid; i < p.nz * 64; i += 256) {
+      const int z = i >> 6, s = i & 63;
+      const bool ok = s < sn;
+      s_dl[z][s] = ok ? p.dl[((size_t)z * p.B + b) * p.S + sb + s] : 0.f;
+      s_att[z][s] = ok ? p.att[(size_t)z * p.z_att + (size_t)b * p.S + sb + s] : 0.f;
+    }
+    __syncthreads();
+    // R[z][col] += sum_s dl[z][s] words[s][col]   (group g takes steps z = g, g+4, ...)
+#pragma unroll
+    for (int i = 0; i < CB_MAXZ / 4; ++i) {
+      const int z = grp + 4 * i;
+      if (z < p.nz) {
+        float r = Racc[i];
+        for (int s = 0; s < sn; ++s) r = fmaf(s_dl[z][s], s_words[s][col], r);
+        Racc[i] = r;
+      }
+    }
+    // dwords[s][col] = sum_z att[z][s] dc[z][col] + dl[z][s] cc[z][col] w[col]   (group g takes s = g, g+4, ...)
+    for (int s = grp; s < sn; s += 4) {
+      float v = 0.f;
+      for (int z = 0; z < p.nz; ++z) v += s_att[z][s] * s_dc[z][col] + s_dl[z][s] * s_ccw[z][col];
+      p.dwords[((size_t)b * p.S + sb + s) * p.d + c0 + col] = v;
+    }
+  }
+  float dwp = 0.f;
+#pragma unroll
+  for (int i = 0; i < CB_MAXZ / 4; ++i) {
+    const int z = grp + 4 * i;
+    if (z < p.nz) {
+      p.dcc[(size_t)z * p.z_dcc + (size_t)b * p.d + c0 + col] = Racc[i] * wc;
+      // dw[col] += cc[z][col] * R[z][col]  (s_ccw holds cc * w; divide out w exactly by recomputing cc)
+      dwp += p.cc[(size_t)z * p.z_cc + (size_t)b * p.d + c0 + col] * Racc[i];
+    }
+  }
+  s_R[grp][col] = dwp;
+  __syncthreads();
+  if (grp == 0) p.dw_part[(size_t)b * p.d + c0 + col] = (s_R[0][col] + s_R[1][col]) + (s_R[2][col] + s_R[3][col]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -463,7 +518,7 @@ __global__ __launch_bounds__(256) void kb_attend_kernel(KbAttP p) {
 }
 
 // backward, part 1: da[b][n] = dr[b] . KB[b][n]   (one wave per knowledge-base cell)
-__global__ __launch_bounds__(256) void kb_att_da_kernel(const float* __restrict__ dr, const float* __restrict__ kb,
+__global__ __launch_bounds__(256) void kb_att_da_kernel(const float* __restrict__ dr, int ld_dr, const float* __restrict__ kb,
                                                         int B, int N, int d, float* da) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t row = (size_t)blockIdx.x * 4 + wave;
@@ -472,7 +527,7 @@ __global__ __launch_bounds__(256) void kb_att_da_kernel(const float* __restrict_
   float part = 0.f;
   for (int k = lane * 4; k < d; k += 256) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(kb + row * d + k);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(dr + (size_t)b * d + k);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dr + (size_t)b * ld_dr + k);
     part += v[0] * g[0] + v[1] * g[1] + v[2] * g[2] + v[3] * g[3];
   }
   part = wave_sum(part);
@@ -492,27 +547,32 @@ struct ReadAttBwdP {
   const uint32_t* bits;  // keep bits of the SITE_READ_ATT mask of this step, [B*N][d/32]; null = keep all
   float inv_keep;
   float* dI2;            // [B][N][d]
-  float* dc;             // [B][d]        (written)
+  float* dc;             // [B][d]        dL/dc_i, accumulated in place (+=)
   float* dwk_part;       // [B][d]        (written)
   float* db2_part;       // [B][d]        column sums of dI2 (written)
   float* dbk_part;       // [B]           (written, by slab 0)
 };
 
-__global__ __launch_bounds__(256) void read_att_bwd_kernel(ReadAttBwdP p) {
+constexpr int RAB_THREADS = 1024;
+constexpr int RAB_RG = RAB_THREADS / 32;
+__global__ __launch_bounds__(RAB_THREADS) void read_att_bwd_kernel(ReadAttBwdP p) {
   __shared__ float s_dl[K_MAXN];
-  __shared__ float s_red[4];
-  __shared__ f32x4 s_acc[3][8][32];
+  __shared__ float s_red[RAB_THREADS / 64];
+  __shared__ f32x4 s_acc[3][RAB_RG][32];
   const int b = blockIdx.x, slab = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NWV = RAB_THREADS / 64;
   float dot = 0.f;
-  for (int n = tid; n < p.N; n += 256) dot += p.att[(size_t)b * p.N + n] * p.da[(size_t)b * p.N + n];
+  for (int n = tid; n < p.N; n += RAB_THREADS) dot += p.att[(size_t)b * p.N + n] * p.da[(size_t)b * p.N + n];
   dot = wave_sum(dot);
   if (lane == 0) s_red[wave] = dot;
   __syncthreads();
-  dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  dot = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) dot += s_red[w];
   __syncthreads();
   float dls = 0.f;
-  for (int n = tid; n < p.N; n += 256) {
+  for (int n = tid; n < p.N; n += RAB_THREADS) {
     const float dl = p.att[(size_t)b * p.N + n] * (p.da[(size_t)b * p.N + n] - dot);
     s_dl[n] = dl;
     dls += dl;
@@ -520,14 +580,19 @@ __global__ __launch_bounds__(256) void read_att_bwd_kernel(ReadAttBwdP p) {
   dls = wave_sum(dls);
   if (lane == 0) s_red[wave] = dls;
   __syncthreads();
-  if (tid == 0 && slab == 0) p.dbk_part[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  if (tid == 0 && slab == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) t += s_red[w];
+    p.dbk_part[b] = t;
+  }
 
   const int rg = tid >> 5, c4 = tid & 31;
   const int col = slab * 128 + c4 * 4;
   const f32x4 cv = *reinterpret_cast<const f32x4*>(p.c + (size_t)b * p.d + col);
   const f32x4 wv = *reinterpret_cast<const f32x4*>(p.wk + col);
   f32x4 a_dc = {0.f, 0.f, 0.f, 0.f}, a_dw = {0.f, 0.f, 0.f, 0.f}, a_db = {0.f, 0.f, 0.f, 0.f};
-  for (int n = rg; n < p.N; n += 8) {
+  for (int n = rg; n < p.N; n += RAB_RG) {
     const size_t off = ((size_t)b * p.N + n) * p.d + col;
     const f32x4 i2 = *reinterpret_cast<const f32x4*>(p.I2 + off);
     const float dl = s_dl[n];
@@ -555,8 +620,9 @@ __global__ __launch_bounds__(256) void read_att_bwd_kernel(ReadAttBwdP p) {
     const int which = tid >> 5, cc4 = tid & 31;
     f32x4 t = s_acc[which][0][cc4];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) t += s_acc[which][g][cc4];
+    for (int g = 1; g < RAB_RG; ++g) t += s_acc[which][g][cc4];
     float* dst = (which == 0 ? p.dc : which == 1 ? p.dwk_part : p.db2_part) + (size_t)b * p.d + slab * 128 + cc4 * 4;
+    if (which == 0) t += *reinterpret_cast<const f32x4*>(dst);
     *reinterpret_cast<f32x4*>(dst) = t;
   }
 }
