@@ -154,7 +154,7 @@ def main():
         dp = macx._lib.MacxDropout(keep_memory=0.85, keep_read=0.85, keep_write=1.0, seed=seed)
         wp = torch.empty(D * D, device=dev)
         xo = torch.empty(B, N, D, device=dev)
-        bits = torch.empty(B * N * D // 32, device=dev)
+        bits = torch.empty(B * N * D + B * N * D // 32, device=dev)
         ptr = lambda t: C.c_void_p(t.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         macx._lib.check(L.macx_pack_weight(ptr(params.projX_W.detach()), D, D, 0, ptr(wp), st), "pack")

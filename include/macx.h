@@ -208,10 +208,10 @@ int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows,
  * out[Q][g][j][e] = W[16Q + 4g + e][j].  K % 16 == 0, n_out % 16 == 0; `out` holds K*n_out floats. */
 int macx_pack_weight(const float* W, int K, int n_out, int transpose, float* out, void* stream);
 /* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688) on fp32 MFMA.
- * `W_packed` from macx_pack_weight(Wx, d, d, 0); `bits_ws` >= B*N*d/32 floats of scratch for the
- * keep bits of this step's mask (may be NULL when keep_read == 1). */
+ * `W_packed` from macx_pack_weight(Wx, d, d, 0); `drop_ws` >= B*N*d + B*N*d/32 floats of scratch
+ * for the dropped KB and its keep bits (may be NULL when keep_read == 1). */
 int macx_kb_project(const macx_shapes*, const macx_dropout*, int step, const float* kb,
-                    const float* W_packed, const float* b, float* out, float* bits_ws, void* stream);
+                    const float* W_packed, const float* b, float* out, float* drop_ws, void* stream);
 /* softmax(expMask(logits)) + att2Smry over the question words for one step
  * (mac_cell.py:155-181; ops.py:114-150, 243-247).  cc: continuous control [B,d]. */
 int macx_control_attend(const macx_shapes*, const float* cc, const float* words, const int32_t* lengths,

@@ -76,6 +76,7 @@ struct SavedLayout {
   size_t self_smry;                 // [p,B,d]
   size_t logit_part;                // [d/128][B*N]
   size_t X, H1, I2;                 // [pk][B,N,d], pk = p (keep) or 1
+  size_t KBd;                       // [pk][B,N,d] dropped knowledge base (ops.py:678)
   size_t act_stride;                // B*N*d if keep else 0
   size_t total;
 };
@@ -125,6 +126,7 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.X = take(pk * B * N * d);
   L.H1 = take(pk * B * N * d);
   L.I2 = take(pk * B * N * d);
+  L.KBd = take(pk * B * N * d);
   L.bits_stride = keep ? B * N * d / 32 : 0;
   L.kb_bits = take(pk * B * N * d / 32);
   L.att_bits = take(pk * B * N * d / 32);
@@ -468,27 +470,26 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   const size_t nwords = (size_t)B * N * d / 32;
   uint32_t* kb_bits = reinterpret_cast<uint32_t*>(saved + L.kb_bits + (size_t)i * L.bits_stride);
   uint32_t* att_bits = reinterpret_cast<uint32_t*>(saved + L.att_bits + (size_t)i * L.bits_stride);
+  float* KBd = saved + L.KBd + (size_t)i * L.act_stride;
   if (rdrop) {
     const uint32_t first = (uint32_t)((size_t)s->b0 * N * d);
-    CK(mask_bits(dp->keep_read, dp->seed, SITE_READ_KB, i, first, nwords, kb_bits, st));
+    const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
+    hipLaunchKernelGGL(kb_dropout_kernel, dim3(2048), dim3(256), 0, st, in->knowledgeBase, (size_t)B * N * d / 4, dk.key, dk.thr24,
+                       dk.inv_keep, first, KBd, kb_bits);
+    CK(hipGetLastError());
     CK(mask_bits(dp->keep_read, dp->seed, SITE_READ_ATT, i, first, nwords, att_bits, st));
   }
   GemmP g;
   memset(&g, 0, sizeof(g));
   g.B = B; g.N = N; g.K = d; g.Nout = d;
-  g.a_inv_keep = g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+  g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
   // X = dropout(KB) Wx + bx  (ops.py:678,688)
-  g.A = in->knowledgeBase; g.lda = d;
+  g.A = rdrop ? KBd : in->knowledgeBase; g.lda = d;
   g.Wp = saved + L.wx_p;
   g.out = X; g.ldo = d; g.bias = P->projX_b; g.act = MACX_ACT_NON;
-  if (rdrop) {
-    g.a_bits = kb_bits;
-    CK((kb_gemm_launch<A_DROP, B_PLAIN, E_BIAS_ACT, false>(g, st)));
-  } else {
-    CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
-  }
+  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
   // H1 = act( concat([X*y, X]) W1 + b1 ) = act( X (diag(y) W1a + W1b) + b1 )   (ops.py:703,718; mac_cell.py:237)
-  g.A = X; g.a_bits = nullptr;
+  g.A = X;
   g.Wp = saved + L.w1a_p; g.Wp2 = saved + L.w1b_p; g.y = y; g.ldy = d;
   g.out = H1; g.bias = P->memKbProj_b; g.act = o->read_mem_act;
   CK((kb_gemm_launch<A_PLAIN, B_YMIX_ROW, E_BIAS_ACT, false>(g, st)));
@@ -642,7 +643,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     GemmP g;
     memset(&g, 0, sizeof(g));
     g.B = B; g.N = N; g.K = d; g.Nout = d;
-    g.a_inv_keep = g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+    g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
     const uint32_t* kb_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits + (size_t)i * L.bits_stride) : nullptr;
     // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
     g.A = dI2_i; g.lda = d; g.Wp = ws + W.w2T_p;
@@ -759,12 +760,11 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     t.A = saved + L.H1; t.lda = d; t.a_mod = t.M; t.G = ws + W.dI2; t.ldg = d;
     t.part = ws + W.slab_w2;
     CK(wgrad_tn_launch<A_PLAIN>(t, st));
-    t.A = in->knowledgeBase; t.a_mod = B * N; t.G = ws + W.dX;
-    t.a_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits) : nullptr;
-    t.a_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+    if (rdrop) { t.A = saved + L.KBd; t.a_mod = t.M; }          // the dropped KB of every step was kept
+    else { t.A = in->knowledgeBase; t.a_mod = B * N; }          // no dropout: the same KB each step
+    t.G = ws + W.dX;
     t.part = ws + W.slab_wx;
-    if (rdrop) CK(wgrad_tn_launch<A_DROP>(t, st));
-    else CK(wgrad_tn_launch<A_PLAIN>(t, st));
+    CK(wgrad_tn_launch<A_PLAIN>(t, st));
   }
   CK(slab_reduce_launch(ws + W.slab_w2, (int)W.ns_big, dd, GP->memKbProj2_W, 0, st));
   CK(slab_reduce_launch(ws + W.slab_wx, (int)W.ns_big, dd, GP->projX_W, 0, st));
@@ -813,14 +813,15 @@ int macx_kb_project(const macx_shapes* s, const macx_dropout* dp, int step, cons
   g.Wp = Wp; g.out = out; g.ldo = d; g.bias = b; g.act = MACX_ACT_NON;
   if (dp->keep_read < 1.0f) {
     if (!bits_ws) return MACX_EINVAL;
-    const size_t nwords = (size_t)s->B * s->N * d / 32;
-    CK(mask_bits(dp->keep_read, dp->seed, SITE_READ_KB, step, (uint32_t)((size_t)s->b0 * s->N * d), nwords, (uint32_t*)bits_ws, st));
-    g.a_bits = (const uint32_t*)bits_ws;
-    g.a_inv_keep = 1.0f / dp->keep_read;
-    CK((kb_gemm_launch<A_DROP, B_PLAIN, E_BIAS_ACT, false>(g, st)));
-  } else {
-    CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+    // scratch: [B*N*d] dropped KB, then [B*N*d/32] keep bits
+    const size_t n = (size_t)s->B * s->N * d;
+    const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, step);
+    hipLaunchKernelGGL(kb_dropout_kernel, dim3(2048), dim3(256), 0, st, kb, n / 4, dk.key, dk.thr24, dk.inv_keep,
+                       (uint32_t)((size_t)s->b0 * s->N * d), bits_ws, reinterpret_cast<uint32_t*>(bits_ws + n));
+    CK(hipGetLastError());
+    g.A = bits_ws;
   }
+  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
   return MACX_OK;
 }
 

@@ -11,9 +11,10 @@
 
 namespace macx {
 
-constexpr int T_BM = 64;            // reduction rows per stage
+constexpr int T_BM = 32;            // reduction rows per LDS stage
 constexpr int T_TILE = 128;         // output tile edge
 constexpr int T_STAGE = T_BM * T_TILE;
+constexpr int T_RING = 4;           // LDS stages of the DMA ring (A and G each): 4 x 32 KB = 128 KB
 
 struct TnP {
   int M;                 // reduction rows (B*N)
@@ -23,19 +24,18 @@ struct TnP {
   const float* A; int lda;
   int a_mod;             // A row of reduction row m is (m % a_mod): the same KB under p different masks
   const float* G; int ldg;
-  const uint32_t* a_bits; // A_DROP: keep bits of A, [M][lda/32]
-  float a_inv_keep;
   float* part;           // [nsplit][Kd][Jd]
 };
 
 // 8 waves: waves 0-3 and 4-7 each cover the 128x128 tile as 2x2 sub-tiles of 64x64 and take
-// alternate k-steps (row pairs) of every stage, so each SIMD holds two waves whose LDS waits hide
-// under the other's MFMAs; the two half-sums are combined through LDS in a fixed order.
+// alternate k-steps (row pairs) of every stage, so each SIMD holds two waves; the two half-sums are
+// combined through LDS in a fixed order.  Both operands stream HBM/L2 -> LDS by DMA through a
+// 4-stage ring (two stages of latency budget, no staging registers, no ds_write).
 template <int AP>
 __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                  // [2][T_STAGE]
-  float* sG = smem + 2 * T_STAGE;    // [2][T_STAGE]
+  float* sA = smem;                       // [T_RING][T_STAGE]
+  float* sG = smem + T_RING * T_STAGE;    // [T_RING][T_STAGE]
 
   const int ntj = p.Jd / T_TILE;
   const int ntk = p.Kd / T_TILE;
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnP p) {
   const int tile = v % ntile;
   const int tk = tile / ntj, tj = tile % ntj;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
@@ -63,34 +64,16 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
 
-  f32x4 ra[4], rg[4];
-  auto load_stage = [&](int ch) {
+  // DMA slots: a stage holds 32 rows x 32 float4 per operand = 1024 slots; 512 threads -> 2 + 2 per stage
+  auto dma_stage = [&](int buf, int ch) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 512 * i;
-      const int m = m_begin + ch * T_BM + (f >> 5);
-      const int mc = min(m, p.M - 1);
+    for (int i = 0; i < 2; ++i) {
+      const int f0 = wave * 64 + 512 * i;
+      const int f = f0 + lane;
+      const int m = min(m_begin + ch * T_BM + (f >> 5), p.M - 1);   // rows past the end are clamped, never multiplied
       const int c4 = (f & 31) * 4;
-      ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)(mc % p.a_mod) * p.lda + tk * T_TILE + c4);
-      rg[i] = *reinterpret_cast<const f32x4*>(p.G + (size_t)mc * p.ldg + tj * T_TILE + c4);
-      if (AP == A_DROP) {
-        const int k = tk * T_TILE + c4;
-        const uint32_t bits = p.a_bits[(size_t)mc * (p.lda >> 5) + (k >> 5)] >> (k & 31);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ra[i][e] = ((bits >> e) & 1u) ? ra[i][e] * p.a_inv_keep : 0.f;
-      }
-      if (m >= m_end) {
-        ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-  };
-  auto store_stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 512 * i;
-      *reinterpret_cast<f32x4*>(sA + buf * T_STAGE + f * 4) = ra[i];
-      *reinterpret_cast<f32x4*>(sG + buf * T_STAGE + f * 4) = rg[i];
+      dma16(p.A + (size_t)(m % p.a_mod) * p.lda + tk * T_TILE + c4, sA + buf * T_STAGE + f0 * 4);
+      dma16(p.G + (size_t)m * p.ldg + tj * T_TILE + c4, sG + buf * T_STAGE + f0 * 4);
     }
   };
   auto compute = [&](int buf, int steps) {
@@ -107,18 +90,29 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnP p) {
     }
   };
 
-  if (nchunk > 0) {
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const int cur = ch & 1;
-      if (ch + 1 < nchunk) load_stage(ch + 1);
-      const int rows = min(T_BM, m_end - (m_begin + ch * T_BM));
-      compute(cur, (rows + 1) >> 1);
-      if (ch + 1 < nchunk) store_stage(cur ^ 1);
-      __syncthreads();
+  // prologue: stages 0..2 in flight, stage 0 awaited
+  for (int s = 0; s < T_RING - 1 && s < nchunk; ++s) dma_stage(s, s);
+  if (nchunk >= 3) wait_vmcnt<8>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int cur = ch % T_RING;
+    // stage (ch-1) % RING was fully read before the barrier that ended iteration ch-1: refill it
+    if (ch + T_RING - 1 < nchunk) dma_stage((ch + T_RING - 1) % T_RING, ch + T_RING - 1);
+    const int rows = min(T_BM, m_end - (m_begin + ch * T_BM));
+    if (rows & 1) {
+      // odd tail: the MFMA consumes rows in pairs -> clear the row after the last one
+      for (int c = tid; c < T_TILE; c += 512) { sA[cur * T_STAGE + rows * T_TILE + c] = 0.f; sG[cur * T_STAGE + rows * T_TILE + c] = 0.f; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
+    compute(cur, (rows + 1) >> 1);
+    // stage ch+1 must have landed before anybody reads it; up to two younger stages may still fly
+    const int ahead = min(nchunk - 1, ch + T_RING - 1) - (ch + 1);   // stages issued after stage ch+1
+    if (ahead >= 2) wait_vmcnt<8>(); else if (ahead == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // combine the two k-step groups (fixed order: group 0 + group 1), then store
@@ -150,7 +144,7 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnP p) {
 template <int AP>
 inline hipError_t wgrad_tn_launch(const TnP& p, hipStream_t st) {
   auto kern = wgrad_tn_kernel<AP>;
-  constexpr size_t lds = 4 * T_STAGE * sizeof(float);
+  constexpr size_t lds = 2 * T_RING * T_STAGE * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -218,7 +212,7 @@ __global__ __launch_bounds__(256) void sb_wgrad_kernel(SbP p) {
   const int b_begin = group * p.qpg;
   const int b_end = min(p.B, b_begin + p.qpg);
 
-  f32x4 ra[8], rg[8];
+  f32x4 ra[4], rg[4];
   for (int b = b_begin; b < b_end; ++b) {
     const float* Xb = p.X + (size_t)b * p.N * p.d;
     const float* Gb = p.dI1 + (size_t)b * p.N * p.d;
@@ -231,7 +225,7 @@ __global__ __launch_bounds__(256) void sb_wgrad_kernel(SbP p) {
 
     auto load_stage = [&](int ch) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 4; ++i) {
         const int f = tid + 256 * i;
         const int n = ch * T_BM + (f >> 5);
         const int c4 = (f & 31) * 4;
@@ -246,7 +240,7 @@ __global__ __launch_bounds__(256) void sb_wgrad_kernel(SbP p) {
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 4; ++i) {
         const int f = tid + 256 * i;
         *reinterpret_cast<f32x4*>(sA + buf * T_STAGE + f * 4) = ra[i];
         *reinterpret_cast<f32x4*>(sG + buf * T_STAGE + f * 4) = rg[i];

@@ -68,7 +68,7 @@ def test_kb_project(macx, dev, B, N, d, keep):
     wp = torch.empty(d * d, device=dev)
     kbd, Wd, bd = kb.to(dev), W.to(dev), b.to(dev)
     macx._lib.check(L.macx_pack_weight(_p(Wd), d, d, 0, _p(wp), None), "pack")
-    bits = torch.empty(B * N * d // 32 + 4, device=dev)
+    bits = torch.empty(B * N * d + B * N * d // 32 + 4, device=dev)
     macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 5, _p(kbd), _p(wp), _p(bd), _p(out), _p(bits), None), "kb_project")
     torch.cuda.synchronize()
     mask = torch.from_numpy(dh.mask_for(99, dh.SITE_READ_KB, 5, keep, (B, N, d), b0=3)).double()

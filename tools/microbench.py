@@ -20,7 +20,7 @@ def main():
     B, N, d = args.B, 196, 512
     p = lambda t: C.c_void_p(t.data_ptr())
     kb = torch.randn(B, N, d, device=dev); W = torch.randn(d, d, device=dev) / 22; b = torch.randn(d, device=dev)
-    wp = torch.empty(d * d, device=dev); out = torch.empty(B, N, d, device=dev); bits = torch.empty(B * N * d // 32, device=dev)
+    wp = torch.empty(d * d, device=dev); out = torch.empty(B, N, d, device=dev); bits = torch.empty(B * N * d + B * N * d // 32, device=dev)
     L.macx_pack_weight(p(W), d, d, 0, p(wp), None)
     sh = macx._lib.MacxShapes(B=B, S=50, N=N, d=d, p=12, b0=0)
     flops = 2.0 * B * N * d * d
@@ -32,10 +32,10 @@ def main():
             print("kb_project NW=%d keep=%.2f: %8.1f us  %6.1f TF" % (nw, keep, us, flops / us / 1e6))
     L.macx_debug_set(0, 8)
     dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=1)
-    for dbg in (0, 1, 2, 3):
+    for dbg in (0, 1):
         L.macx_debug_set(1, dbg)
         us = timeit(lambda: L.macx_kb_project(C.byref(sh), C.byref(dp), 0, p(kb), p(wp), p(b), p(out), p(bits), None))
-        print("kb_project NW=8 dbg=%d (1 no epilogue, 2 no in-loop staging): %8.1f us  %6.1f TF" % (dbg, us, flops / us / 1e6))
+        print("kb_project NW=8 dbg=%d (1 no epilogue, 2 no staging, 8 no in-loop loads, 16 no in-loop stores): %8.1f us  %6.1f TF" % (dbg, us, flops / us / 1e6))
     L.macx_debug_set(1, 0)
     M = B * N
     A = torch.randn(M, d, device=dev); G = torch.randn(M, d, device=dev)
