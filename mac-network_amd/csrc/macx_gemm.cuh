@@ -54,6 +54,8 @@ struct GemmP {
   // A operand
   const float* A;
   int lda;
+  const uint32_t* a_bits; // A_DROP: keep bits of A, [B*N][lda/32]
+  float a_inv_keep;
   // weights
   const float* Wp;        // packed
   const float* Wp2;       // packed second weight (B_YMIX_*)
@@ -74,7 +76,7 @@ struct GemmP {
   const uint32_t* e_bits; // E_I2_LOGIT: keep bits of act(I2*c) [B*N][Nout/32]; E_DKB: keep bits of KB; null = keep all
   float e_inv_keep;
   int accumulate;         // E_DKB: 1 -> out += , 0 -> out =
-  int dbg;                // measurement knob (macx_debug_set(1, mask)): 1 skip epilogue
+  int dbg;                // measurement knobs (macx_debug_set(1, mask)): 1 skip epilogue, 2 skip in-loop staging, 4 skip fragment reads
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -87,14 +89,6 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // NW = waves per workgroup = 16-column slabs per tile.  NW = 4 (64-column tiles, 256 threads, ~69 KB
 // LDS) lets two independent workgroups share a CU, so one's load/store/barrier phase overlaps the
 // other's MFMA phase; NW = 8 (128-column tiles, 512 threads) reads the A panel half as often.
-constexpr int G_RING = 3;          // LDS stages in flight
-template <int RT, int NW>
-constexpr int kb_gemm_lds_floats() {
-  constexpr int stage = G_RING * (RT * 16 * G_LDA + G_BK * 16 * NW);
-  constexpr int epi = RT * 16 * (16 * NW + 4) + 256 * NW;   // tile + [16 row groups][4 NW float4] column partials
-  return stage > epi ? stage : epi;
-}
-
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): the 64 lanes of a wave fetch 64 x 16 B from
 // per-lane global addresses into LDS at wave_base + lane*16.  No VGPR round trip, no ds_write.
 __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
@@ -104,9 +98,15 @@ __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int RT, int NW>
+constexpr int kb_gemm_lds_floats() {
+  constexpr int stage = 2 * RT * 16 * G_LDA + 2 * G_BK * 16 * NW;
+  constexpr int epi = RT * 16 * (16 * NW + 4) + 256 * NW;   // tile + [16 row groups][4 NW float4] column partials
+  return stage > epi ? stage : epi;
+}
+
 template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>
 __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
-  static_assert(AP == A_PLAIN, "dropout on the A operand is applied by kb_dropout_kernel beforehand");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int G_THREADS = 64 * NW;
   constexpr int G_BN = 16 * NW;             // output columns per workgroup
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   constexpr int RG = G_THREADS / CG;        // row groups in the epilogue (= 16)
   constexpr int ROWS = RT * 16;
   constexpr int A_TILE = ROWS * G_LDA;
-  constexpr int A_F4 = ROWS * 8;                       // float4 per A stage (a multiple of 64)
+  constexpr int A_F4 = ROWS * 8;                       // float4 per A stage
   constexpr int A_IT = (A_F4 + G_THREADS - 1) / G_THREADS;
-  float* sA = smem;                       // [G_RING][A_TILE]
-  float* sB = smem + G_RING * A_TILE;     // [G_RING][G_BTILE]
+  float* sA = smem;                  // [2][A_TILE]
+  float* sB = smem + 2 * A_TILE;     // [2][G_BTILE]
 
   // ---- workgroup -> (question, row block, column block); XCD-aware so that the column blocks
   // of one question (which share the A rows) sit on one XCD's L2.
@@ -137,60 +137,68 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = tid >> 6;
   const int nk = p.K / G_BK;
 
   f32x4 acc[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- A stage by DMA.  LDS slot f (16 B) of a stage holds row f>>3, chunk (f&7)^(row&7): the XOR
-  // swizzle is applied on the SOURCE address (the DMA destination is lane-linear), the fragment reads
-  // apply the same XOR.  Rows past the end of the question are clamped: they only feed output rows
-  // that are never stored.  Waves whose slots fall past the stage re-fetch an earlier 64-slot group
-  // so that every wave issues the same number of DMAs (the vmcnt bookkeeping relies on it).
-  const float* a_src[A_IT];
-  int a_slot0[A_IT];
+  f32x4 ra[A_IT];
+  uint32_t rbits[A_IT];
+  f32x4 rw[B_IT];
+  f32x4 rw2[B_IT];
+
+  const float* Abase = p.A + (size_t)b * p.N * p.lda;
+  const uint32_t* Bitbase = (AP == A_DROP) ? p.a_bits + (size_t)b * p.N * (p.lda >> 5) : nullptr;
+  // per-thread staging coordinates (k-invariant)
+  int a_off[A_IT];        // float offset of this thread's float4 in A (row clamped into the question)
+  int a_row[A_IT];
+  bool a_ok[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int f0 = (wave * 64 + G_THREADS * i) % A_F4;
-    const int f = f0 + lane;
-    const int row = f >> 3;
-    const int n = min(row0 + row, p.N - 1);
-    a_slot0[i] = f0;
-    a_src[i] = p.A + ((size_t)b * p.N + n) * p.lda + (((f & 7) ^ (row & 7)) << 2);
-  }
-  const float* b_src[B_IT];
-  const float* b_src2[B_IT];
-#pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
     const int f = tid + G_THREADS * i;
-    const size_t off = ((size_t)(f / G_BN) * p.Nout + cb * G_BN + (f % G_BN)) * 4;   // + kt * 8 * Nout * 4
-    b_src[i] = p.Wp + off;
-    b_src2[i] = (BP != B_PLAIN) ? p.Wp2 + off : nullptr;
+    const int n = row0 + (f >> 3);
+    a_ok[i] = (f < A_F4) && (n < p.N);
+    const int nc = min(n, p.N - 1);
+    a_row[i] = nc;
+    a_off[i] = nc * p.lda + (f & 7) * 4;
   }
-  const size_t b_step = (size_t)8 * p.Nout * 4;
   float ycol = 0.f;
   if (BP == B_YMIX_COL) ycol = p.y[(size_t)b * p.ldy + cb * G_BN + (tid % G_BN)];
-  f32x4 rw[B_IT], rw2[B_IT];
 
-  auto dma_stage = [&](int buf, int kt) {
+  auto load_tiles = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) dma16(a_src[i] + kt * G_BK, sA + buf * A_TILE + a_slot0[i] * 4);
-    if (BP == B_PLAIN) {
-#pragma unroll
-      for (int i = 0; i < B_IT; ++i) dma16(b_src[i] + kt * b_step, sB + buf * G_BTILE + (wave * 64 + G_THREADS * i) * 4);
+    for (int i = 0; i < A_IT; ++i) {
+      ra[i] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + kt * G_BK);
+      if (AP == A_DROP) rbits[i] = Bitbase[a_row[i] * (p.lda >> 5) + kt];
     }
-  };
-  // the mixed weight tile  y (.) W1a + W1b  goes through registers (it is computed, not copied)
-  auto load_b = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      rw[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kt * b_step);
-      rw2[i] = *reinterpret_cast<const f32x4*>(b_src2[i] + kt * b_step);
+      const int f = tid + G_THREADS * i;
+      const int chunk = f / G_BN;   // Q*4 + g
+      const int j = f % G_BN;
+      const size_t off = ((size_t)(kt * 8 + chunk) * p.Nout + cb * G_BN + j) * 4;
+      rw[i] = *reinterpret_cast<const f32x4*>(p.Wp + off);
+      if (BP != B_PLAIN) rw2[i] = *reinterpret_cast<const f32x4*>(p.Wp2 + off);
     }
   };
-  auto store_b = [&](int buf, int kt) {
+
+  auto store_tiles = [&](int buf, int kt) {
+    float* dA = sA + buf * A_TILE;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int f = tid + G_THREADS * i;
+      f32x4 val = ra[i];
+      if (AP == A_DROP) {
+        const uint32_t bits = rbits[i] >> ((f & 7) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = ((bits >> e) & 1u) ? val[e] * p.a_inv_keep : 0.f;
+      }
+      if (!a_ok[i]) val = f32x4{0.f, 0.f, 0.f, 0.f};
+      // chunk c of row r lives at chunk slot c ^ (r & 7): conflict-free b128 fragment reads, no padding
+      if (f < A_F4) *reinterpret_cast<f32x4*>(dA + (f >> 3) * G_LDA + (((f & 7) ^ ((f >> 3) & 7)) << 2)) = val;
+    }
     float* dB = sB + buf * G_BTILE;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
         const int k = kt * G_BK + (chunk >> 2) * 16 + (chunk & 3) * 4;
         const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.y + (size_t)b * p.ldy + k);
         val = val * y4 + rw2[i];
-      } else {
+      } else if (BP == B_YMIX_COL) {
         // B_eff[k][j] = y[b][j] * W1a^T[k][j] + W1b^T[k][j]   (backward-data of the same product)
         val = val * ycol + rw2[i];
       }
@@ -210,66 +218,38 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
     }
   };
 
-  // fragments of one 16-wide k group: lane (i = lane & 15, g = lane >> 4) reads A[i][16Q + 4g ..] =
-  // chunk (4Q + g) ^ (i & 7) of row i, and the packed weights W[16Q + 4g ..][16 wave + i]
-  auto read_frags = [&](int buf, int Q, f32x4 (&af)[RT], f32x4& bf) {
+  auto compute = [&](int buf, int Q) {
+    // lane (i = lane & 15, g = lane >> 4) reads A[i][16Q + 4g ..] = chunk (4Q + g) ^ (i & 7) of row i
     const float* a = sA + buf * A_TILE + (lane & 15) * G_LDA + ((((Q << 2) + (lane >> 4)) ^ (lane & 7)) << 2);
     const float* bq = sB + buf * G_BTILE + ((lane >> 4) * G_BN + wave * 16 + (lane & 15)) * 4;
-    bf = *reinterpret_cast<const f32x4*>(bq + Q * 4 * G_BN * 4);
+    const f32x4 bf = *reinterpret_cast<const f32x4*>(bq + Q * 4 * G_BN * 4);
+    f32x4 af[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) af[r] = *reinterpret_cast<const f32x4*>(a + r * 16 * G_LDA);
-  };
-  auto mma = [&](const f32x4 (&af)[RT], const f32x4& bf) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int r = 0; r < RT; ++r) acc[r] = mfma16(af[r][e], bf[e], acc[r]);
   };
 
-  // ---- main loop.  Three LDS stages; slice t+2 is requested by DMA at the top of iteration t and
-  // must have landed by the middle of iteration t+1 (1.5 iterations of latency budget, no staging
-  // registers).  ONE barrier per slice, placed between the two MFMA groups of the slice: before it a
-  // wave has read every fragment of slice t it needs from LDS (so stage t%3 may be refilled two
-  // iterations later) and has waited for its own share of slice t+1; after it slice t+1 is visible
-  // to everybody and its first fragments are fetched under the second MFMA group.
-  constexpr int N_DMA = A_IT + (BP == B_PLAIN ? B_IT : 0);      // DMAs a wave issues per slice
-  f32x4 afA[RT], afB[RT], bfA, bfB;
-  dma_stage(0, 0);
-  if (BP != B_PLAIN) { load_b(0); store_b(0, 0); }
-  if (nk > 1) {
-    dma_stage(1, 1);
-    if (BP != B_PLAIN) { load_b(1); store_b(1, 1); }
-  }
-  if (BP != B_PLAIN && nk > 2) load_b(2);
-  if (BP == B_PLAIN) wait_vmcnt<0>();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  read_frags(0, 0, afA, bfA);
-#pragma unroll 1
+  // ---- main loop: register-staged double buffer, one barrier per k-slice.  The next slice's LDS
+  // stores sit between the two halves of the current slice's MFMAs so that they drain under them.
+  load_tiles(0);
+  store_tiles(0, 0);
+  __syncthreads();
+  const bool stage = !(p.dbg & 2);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt % G_RING;
-    const bool more = kt + 2 < nk;
-    if (BP != B_PLAIN) {
-      if (more) store_b((kt + 2) % G_RING, kt + 2);   // the compiler drains vmcnt here: all older than one iteration
-      if (kt + 3 < nk) load_b(kt + 3);
-    }
-    if (more) dma_stage((kt + 2) % G_RING, kt + 2);
-    read_frags(cur, 1, afB, bfB);
-    mma(afA, bfA);
-    if (BP == B_PLAIN) {
-      if (more) wait_vmcnt<N_DMA>(); else wait_vmcnt<0>();   // slice t+1 has landed; slice t+2 may still fly
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) read_frags((kt + 1) % G_RING, 0, afA, bfA);
-    mma(afB, bfB);
+    const int cur = stage ? (kt & 1) : 0;
+    if (stage && kt + 1 < nk) load_tiles(kt + 1);
+    compute(cur, 0);
+    compute(cur, 1);
+    if (stage && kt + 1 < nk) store_tiles(cur ^ 1, kt + 1);
+    __syncthreads();
   }
   if (p.dbg & 1) {
     if (acc[0][0] == 123.456f) p.out[0] = acc[RT - 1][3];
     return;
   }
-  __syncthreads();
 
   // ---- epilogue, step 1: accumulators -> row-major LDS tile.
   // 16x16 accumulator map: col = lane & 15, row = (lane >> 4) * 4 + reg
