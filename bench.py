@@ -151,7 +151,7 @@ def main():
         # kernel is launched on (torch's current stream is handed to the C ABI).
         L = macx._lib.lib()
         sh = macx._lib.MacxShapes(B=B, S=S, N=N, d=D, p=p, b0=0)
-        dp = macx._lib.MacxDropout(keep_memory=0.85, keep_read=0.85, keep_write=1.0, seed=seed)
+        dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=seed)   # the GEMM alone (dropout is a separate pass)
         wp = torch.empty(D * D, device=dev)
         xo = torch.empty(B, N, D, device=dev)
         bits = torch.empty(B * N * D + B * N * D // 32, device=dev)
@@ -171,9 +171,14 @@ def main():
         k_ms = e0.elapsed_time(e1) / nrep
         k_flops = 2.0 * B * N * D * D
         achieved = k_flops / (k_ms * 1e-3)
-        roofline = {"bound": "mfma", "kernel": "kb_gemm_kernel<13,A_DROP,B_PLAIN,E_BIAS_ACT> (X = dropout(KB) Wx + bx) [+ mask_bits_kernel]",
+        traffic = None
+        try:   # HBM bytes per launch of this kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        roofline = {"bound": "mfma", "kernel": "kb_gemm_kernel<13,8,A_PLAIN,B_PLAIN,E_BIAS_ACT,false> (X = KBd Wx + bx; 6 of the 9 GEMM-class launches per cell step share this main loop)",
                     "achieved": round(achieved / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
                     "kernel_ms": round(k_ms, 4), "flops_per_launch": k_flops,
                     "whole_step_frac": round(qps / world * 3 * p * F / PEAK_FP32_MFMA, 4)}
         out = {"metric": "questions/sec fwd+bwd (B=64,d=512,p=12,KB=14x14x1024) at 1/2/4/8 MI355X",
