@@ -223,6 +223,8 @@ class MACCell:
         self._infos_all = run.segment("infos", (s.p, s.B, s.d))
         self._att_q = run.segment("att_question", (s.p, s.B, s.S))
         self._att_kb = run.segment("att_kb", (s.p, s.B, s.N))
+        self._att_self = run.segment("att_self", (s.p, s.B, s.p)) if self.opts.write_self_att else None
+        self._att_gate = run.segment("att_gate", (s.p, s.B, s.d)) if self.opts.write_gate else None
 
     # ---- zero_state (mac_cell.py:539-592)
     def zero_state(self, batchSize=None, dtype=torch.float32):
@@ -236,6 +238,10 @@ class MACCell:
     def _publish_step(self, i):
         self.attentions["question"].append(self._att_q[i])
         self.attentions["kb"].append(self._att_kb[i])
+        if self._att_self is not None:      # [B, i+1]: initial state + steps 0..i-1 (mac_cell.py:324-329)
+            self.attentions["self"].append(self._att_self[i, :, : i + 1])
+        if self._att_gate is not None:
+            self.attentions["gate"].append(self._att_gate[i])
 
     # histories as the reference exposes them: [B, steps+1, d] (mac_cell.py:472-474)
     @property

@@ -61,6 +61,7 @@ struct SavedLayout {
   size_t seg_count[MACX_SEG_COUNT];
   size_t wx_p, w1a_p, w1b_p, w2_p;  // packed forward weights (read unit)
   size_t wy_p, wm_p, wq_p, wqU_p;   // packed forward weights of the [B,d] linears
+  size_t wg_p, ws_p;                // packed gate / self-attention control projection
   size_t kb_bits, att_bits;         // [pk][B*N*d/32] keep bits of the two [B,N,d] dropout sites
   size_t bits_stride;               // words per step (0 when activations are not kept)
   size_t ctrl_t;                    // [B,d]   act(qInput(vecQ))
@@ -102,6 +103,8 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.wm_p = take((size_t)write_in_dim(o, s->d) * d);
   L.wq_p = take(d * d);
   L.wqU_p = take((o->control_input_unshared ? p : 1) * d * d);
+  L.wg_p = o->write_gate ? take(d * d) : 0;
+  L.ws_p = o->write_self_att ? take(d * d) : 0;
   L.ctrl_t = take(B * d);
   L.cI = take(p * B * d);
   if (o->control_feed_prev) {
@@ -177,6 +180,9 @@ struct BwdLayout {
   size_t ns_big, ngroup;
   size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part, ctrl_dl;
   size_t tmpBd[4];  // [B,d] scratch
+  size_t dzpre;     // [p,B,d] gate pre-activation gradient
+  size_t dsc;       // [p,B,d] gradient of the projected control of the self attention
+  size_t dws_part, dbs_part;   // [p,B,d], [p,B]
   size_t small_slab;
   size_t total;
 };
@@ -222,6 +228,8 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dbc_part = take(p * B);
   L.ctrl_dl = take(p * B * (size_t)s->S);
   for (int i = 0; i < 4; ++i) L.tmpBd[i] = take(B * d);
+  if (o->write_gate) L.dzpre = take(p * B * d);
+  if (o->write_self_att) { L.dsc = take(p * B * d); L.dws_part = take(p * B * d); L.dbs_part = take(p * B); }
   // scratch slabs for the small weight gradients (largest: write unit, rows p*B, [win x d])
   size_t small = 0;
   {
@@ -243,8 +251,8 @@ int check_impl(const macx_opts* o, const macx_shapes* s) {
   if (o->write_inputs != MACX_WRITE_BOTH) return MACX_EUNSUPPORTED;
   if (o->read_mem_act == MACX_ACT_NON) return MACX_EUNSUPPORTED;   // no memKbProj_2 layer then (ops.py:325)
   if (o->control_feed_prev) return MACX_EUNSUPPORTED;
-  if (o->write_self_att) return MACX_EUNSUPPORTED;
-  if (o->write_gate) return MACX_EUNSUPPORTED;
+  if (o->write_gate && o->write_gate_shared) return MACX_EREJECTED;   // [B,d] * [B] does not broadcast in the reference
+  if (o->write_self_att && s->p + 1 > SA_MAXH) return MACX_EINVAL;
   return MACX_OK;
 }
 
@@ -388,6 +396,8 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
     pk.add(P->projY_W, d, 1, d, d, saved + L.wy_p);
     pk.add(P->newMemory_W, d, 1, write_in_dim(o, d), d, saved + L.wm_p);
     pk.add(P->qInput_W, d, 1, d, d, saved + L.wq_p);
+    if (o->write_gate) pk.add(P->gate_W, d, 1, d, d, saved + L.wg_p);
+    if (o->write_self_att) pk.add(P->selfCtrl_W, d, 1, d, d, saved + L.ws_p);
     for (int i = 0; i < (o->control_input_unshared ? p : 1); ++i) {
       if (pk.n == PACK_MAX) CK(pk.run(st));
       pk.add(P->qInputU_W + (size_t)i * d * d, d, 1, d, d, saved + L.wqU_p + (size_t)i * d * d);
@@ -517,12 +527,40 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)info_raw, B, d, (uint32_t)s->b0, dw, no_drop(), info);
     CK(hipGetLastError());
   }
-  // ---- write unit (mac_cell.py:305-375), writeInputs = BOTH: act(concat([memory, info]) W + b)
+  // ---- write unit (mac_cell.py:305-375), writeInputs = BOTH: act(concat([memory, info (, selfSmry)]) W + b)
+  float* self_smry = nullptr;
+  if (o->write_self_att) {
+    // mac_cell.py:316-330.  selfControl = contControl (CONT) or the new control; histories hold the
+    // initial state and steps 0..i-1 because the appends happen after write (mac_cell.py:472-474)
+    const float* sctl = o->write_self_att_cont ? saved + L.cc + (size_t)i * Bd : c_i;
+    float* sc = saved + L.sc + (size_t)i * Bd;
+    LinP l = lin_basic(sctl, d, d, B, saved + L.ws_p, P->selfCtrl_b, d, MACX_ACT_NON, sc, d);
+    CK(small_linear_launch(l, 1, st));
+    self_smry = saved + L.self_smry + (size_t)i * Bd;
+    SelfAttP q;
+    q.B = B; q.d = d; q.nh = i + 1;
+    q.sc = sc; q.C = controls; q.M = memories; q.w = P->selfLogits_w; q.bias = P->selfLogits_b;
+    q.att = saved + L.seg[MACX_SEG_ATT_SELF] + (size_t)i * B * s->p; q.ld_att = s->p;
+    q.smry = self_smry;
+    hipLaunchKernelGGL(self_attend_kernel, dim3(B), dim3(256), 0, st, q);
+    CK(hipGetLastError());
+  }
   {
-    LinP l = lin_basic(m_prev, d, d, B, saved + L.wm_p, P->newMemory_b, d, o->write_mem_act, m_new, d);
+    float* wout = o->write_gate ? saved + L.mnew + (size_t)i * Bd : m_new;
+    LinP l = lin_basic(m_prev, d, d, B, saved + L.wm_p, P->newMemory_b, d, o->write_mem_act, wout, d);
     l.seg[1] = LinSeg{info, d, d, 0};
     l.Ktot = 2 * d;
+    if (self_smry) { l.seg[2] = LinSeg{self_smry, d, d, 0}; l.Ktot = 3 * d; }
     CK(small_linear_launch(l, 1, st));
+    if (o->write_gate) {
+      // z = sigmoid(control Wg + bg + gateBias); m = newMemory * z + memory * (1 - z)   (mac_cell.py:358-367)
+      float* z = saved + L.seg[MACX_SEG_ATT_GATE] + (size_t)i * Bd;
+      LinP gl = lin_basic(c_i, d, d, B, saved + L.wg_p, P->gate_b, d, MACX_ACT_SIGMOID, z, d);
+      gl.bias_const = o->write_gate_bias;
+      CK(small_linear_launch(gl, 1, st));
+      hipLaunchKernelGGL(gate_mix_kernel, dim3(64), dim3(256), 0, st, (const float*)wout, (const float*)z, m_prev, Bd, m_new);
+      CK(hipGetLastError());
+    }
   }
   return MACX_OK;
 }
@@ -566,6 +604,8 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     pk.add(P->projY_W, 1, d, d, d, ws + W.wyT);              // Wy^T
     pk.add(P->newMemory_W, 1, d, d, win, ws + W.wmT);        // Wm^T: [d] -> [win]
     pk.add(P->qInput_W, 1, d, d, d, ws + W.wqT);
+    if (o->write_gate) pk.add(P->gate_W, 1, d, d, d, ws + W.wgT);
+    if (o->write_self_att) pk.add(P->selfCtrl_W, 1, d, d, d, ws + W.wscT);
     for (int i = 0; i < nU; ++i) {
       if (pk.n == PACK_MAX) CK(pk.run(st));
       pk.add(P->qInputU_W + (size_t)i * dd, 1, d, d, d, ws + W.wqUT + (size_t)i * dd);
@@ -576,7 +616,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   float* DM = ws + W.DM;
   float* DC = ws + W.DC;
   // dL/d(newMemory linear output) for all steps; with writeMemAct = NON it IS dL/dm_{1..p}
-  float* dwlin_all = (o->write_mem_act == MACX_ACT_NON) ? DM + Bd : ws + W.dwlin;
+  float* dwlin_all = (o->write_mem_act == MACX_ACT_NON && !o->write_gate) ? DM + Bd : ws + W.dwlin;
   CK(hipMemsetAsync(DM, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
   CK(hipMemsetAsync(DC, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
   if (d_memory) CK(hipMemcpyAsync(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -600,10 +640,26 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     float* dX_i = ws + W.dX + (size_t)i * BNd;
     float* dwin = ws + W.dwin;
 
-    // ---- write unit backward: dwlin = dm * act'(m_i) ; [dm_prev part | dinfo] = dwlin Wm^T
-    if (o->write_mem_act != MACX_ACT_NON) {
-      hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, dm_i, memories + (size_t)(i + 1) * Bd,
-                         o->write_mem_act, Bd, dwlin);
+    // ---- write unit backward
+    const float* dmnew = dm_i;              // gradient wrt the (post-activation) new memory
+    const float* mnew_out = memories + (size_t)(i + 1) * Bd;
+    if (o->write_gate) {
+      // m_i = mnew * z + m_{i-1} * (1 - z)
+      const float* z = saved + L.seg[MACX_SEG_ATT_GATE] + (size_t)i * Bd;
+      mnew_out = saved + L.mnew + (size_t)i * Bd;
+      float* dzpre = ws + W.dzpre + (size_t)i * Bd;
+      hipLaunchKernelGGL(gate_bwd_kernel, dim3(64), dim3(256), 0, st, dm_i, z, mnew_out, memories + (size_t)i * Bd, Bd,
+                         ws + W.tmpBd[2], ws + W.tmpBd[3], dzpre);
+      CK(hipGetLastError());
+      dmnew = ws + W.tmpBd[2];
+      // dL/dc_i += dzpre Wg^T
+      LinP gl = lin_basic(dzpre, d, d, B, ws + W.wgT, nullptr, d, MACX_ACT_NON, DC + (size_t)(i + 1) * Bd, d);
+      gl.addend = DC + (size_t)(i + 1) * Bd; gl.ld_add = d;
+      CK(small_linear_launch(gl, 1, st));
+    }
+    // dwlin = dmnew * act'(mnew) ; [dm_prev part | dinfo (| dselfSmry)] = dwlin Wm^T
+    if (o->write_mem_act != MACX_ACT_NON || o->write_gate) {
+      hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, dmnew, mnew_out, o->write_mem_act, Bd, dwlin);
       CK(hipGetLastError());
     }
     {
@@ -619,6 +675,20 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
       CK(hipGetLastError());
       dinfo = ws + W.dinfo;
       ld_dinfo = d;
+    }
+
+    if (o->write_self_att) {
+      SelfAttBwdP q;
+      q.B = B; q.d = d; q.nh = i + 1;
+      q.dsmry = dwin + 2 * d; q.ld_ds = win;
+      q.sc = saved + L.sc + (size_t)i * Bd; q.C = controls; q.M = memories; q.w = P->selfLogits_w;
+      q.att = saved + L.seg[MACX_SEG_ATT_SELF] + (size_t)i * B * p; q.ld_att = p;
+      q.DMh = DM; q.DCh = DC;
+      q.dsc = ws + W.dsc + (size_t)i * Bd;
+      q.dw_part = ws + W.dws_part + (size_t)i * Bd;
+      q.db_part = ws + W.dbs_part + (size_t)i * B;
+      hipLaunchKernelGGL(self_attend_bwd_kernel, dim3(B), dim3(256), 0, st, q);
+      CK(hipGetLastError());
     }
 
     // ---- read unit backward
@@ -677,7 +747,9 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dy_part), 2 * d / 128, Bd, DYi);
     CK(hipGetLastError());
     {
-      LinP l = lin_basic(DYi, d, d, B, ws + W.wyT, nullptr, d, MACX_ACT_NON, dm_prev, d);
+      // with self attention DM[i] already holds the parts later steps sent to this memory: accumulate
+      const bool acc_prev = o->write_self_att || o->write_gate;
+      LinP l = lin_basic(DYi, d, d, B, ws + W.wyT, nullptr, d, MACX_ACT_NON, acc_prev ? ws + W.tmpBd[0] : dm_prev, d);
       l.use_drop = 1;
       l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
                                            : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
@@ -685,9 +757,19 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
       l.drop_row0 = (uint32_t)s->b0;
       l.addend = dwin; l.ld_add = win;
       CK(small_linear_launch(l, 1, st));
+      if (acc_prev) {
+        CK(axpy(ws + W.tmpBd[0], Bd, dm_prev, st));
+        if (o->write_gate) CK(axpy(ws + W.tmpBd[3], Bd, dm_prev, st));   // dm * (1 - z)
+      }
     }
   }
 
+  if (o->write_self_att && !o->write_self_att_cont) {
+    // selfControl = the NEW control: dL/dc_i += dsc_i Ws^T before the word attention is differentiated
+    LinP l = lin_basic(ws + W.dsc, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, DC + Bd, d);
+    l.seg[0].zstride = Bd; l.zout = Bd; l.addend = DC + Bd; l.ld_add = d; l.zadd = Bd;
+    CK(small_linear_launch(l, p, st));
+  }
   // ---- control unit backward.  Not recurrent: every control depends on the question only, so all
   // p steps are handled by one launch (one workgroup per question, steps in fixed order).
   {
@@ -706,6 +788,23 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     CK(hipGetLastError());
     CK(rowsum(ws + W.dwc_part, B, d, d, GP->ctrlLogits_w, st));
     CK(rowsum(ws + W.dbc_part, p * B, 1, 1, GP->ctrlLogits_b, st));
+  }
+  if (o->write_self_att) {
+    // the self-attention control projection reads contControl (== controlInput here) or the control:
+    // d(source)_i += dsc_i Ws^T, in place, all steps in one launch
+    float* dst = o->write_self_att_cont ? ws + W.dcc : DC + Bd;
+    LinP l = lin_basic(ws + W.dsc, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, dst, d);
+    l.seg[0].zstride = Bd; l.zout = Bd; l.addend = dst; l.ld_add = d; l.zadd = Bd;
+    if (o->write_self_att_cont) CK(small_linear_launch(l, p, st));
+    const float* src = o->write_self_att_cont ? saved + L.cc : controls + Bd;
+    CKI(wgrad_impl(src, d, ws + W.dsc, d, p * B, d, d, GP->selfCtrl_W, ws + W.small_slab, st));
+    CK(rowsum(ws + W.dsc, p * B, d, d, GP->selfCtrl_b, st));
+    CK(rowsum(ws + W.dws_part, p * B, d, d, GP->selfLogits_w, st));
+    CK(rowsum(ws + W.dbs_part, p * B, 1, 1, GP->selfLogits_b, st));
+  }
+  if (o->write_gate) {
+    CKI(wgrad_impl(controls + Bd, d, ws + W.dzpre, d, p * B, d, d, GP->gate_W, ws + W.small_slab, st));
+    CK(rowsum(ws + W.dzpre, p * B, d, d, GP->gate_b, st));
   }
   // ---- control inputs backward (mac_cell.py:442-448): dt = sum_i dcI_i WqU_i^T ; du = dt * act'(t)
   const float* ctrl_t = saved + L.ctrl_t;
@@ -748,6 +847,8 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   CK(rowsum(ws + W.DY, p * B, d, d, GP->projY_b, st));
   CKI(wgrad_impl(memories, d, dwlin_all, d, p * B, d, d, GP->newMemory_W, ws + W.small_slab, st));
   CKI(wgrad_impl(infos, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + dd, ws + W.small_slab, st));
+  if (o->write_self_att)
+    CKI(wgrad_impl(saved + L.self_smry, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + 2 * dd, ws + W.small_slab, st));
   CK(rowsum(dwlin_all, p * B, d, d, GP->newMemory_b, st));
 
   // ---- read-unit weights: fixed-order reduction of the per-step slabs

@@ -652,6 +652,136 @@ __global__ __launch_bounds__(RAB_THREADS) void read_att_bwd_kernel(ReadAttBwdP p
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// write unit extras: memory gate (mac_cell.py:358-367) and self-attention over the previous
+// control / memory states (mac_cell.py:316-330)
+// ---------------------------------------------------------------------------------------------
+__global__ void gate_mix_kernel(const float* __restrict__ mnew, const float* __restrict__ z, const float* __restrict__ mprev,
+                                size_t n, float* out) {   // newMemory * z + memory * (1 - z)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = mnew[i] * z[i] + mprev[i] * (1.0f - z[i]);
+}
+__global__ void gate_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ z, const float* __restrict__ mnew,
+                                const float* __restrict__ mprev, size_t n, float* dmnew, float* dprev, float* dzpre) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float g = dm[i], zz = z[i];
+    dmnew[i] = g * zz;
+    dprev[i] = g * (1.0f - zz);
+    dzpre[i] = g * (mnew[i] - mprev[i]) * zz * (1.0f - zz);   // through the sigmoid
+  }
+}
+
+struct SelfAttP {
+  int B, d, nh;               // nh = history entries visible at this step (initial state + earlier steps)
+  const float* sc;            // [B][d]  projected (continuous) control
+  const float* C;             // [nh][B][d] controls history
+  const float* M;             // [nh][B][d] memories history
+  const float* w; const float* bias;
+  float* att; int ld_att;     // [B][ld_att]
+  float* smry;                // [B][d]
+};
+constexpr int SA_MAXH = 64;
+
+__global__ __launch_bounds__(256) void self_attend_kernel(SelfAttP p) {
+  __shared__ float s_l[SA_MAXH];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t Bd = (size_t)p.B * p.d;
+  const float* sc = p.sc + (size_t)b * p.d;
+  for (int j = wave; j < p.nh; j += 4) {
+    const float* c = p.C + (size_t)j * Bd + (size_t)b * p.d;
+    float part = 0.f;
+    for (int k = lane * 4; k < p.d; k += 256) {
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(c + k);
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(sc + k);
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + k);
+      part += (cv[0] * sv[0]) * wv[0] + (cv[1] * sv[1]) * wv[1] + (cv[2] * sv[2]) * wv[2] + (cv[3] * sv[3]) * wv[3];
+    }
+    part = wave_sum(part);
+    if (lane == 0) s_l[j] = part + p.bias[0];
+  }
+  __syncthreads();
+  if (tid == 0) {   // nh <= netLength + 1: a serial softmax is the cheapest correct thing
+    float m = -INFINITY, sum = 0.f;
+    for (int j = 0; j < p.nh; ++j) m = fmaxf(m, s_l[j]);
+    for (int j = 0; j < p.nh; ++j) { s_l[j] = expf(s_l[j] - m); sum += s_l[j]; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < p.nh; ++j) { s_l[j] *= inv; p.att[(size_t)b * p.ld_att + j] = s_l[j]; }
+  }
+  __syncthreads();
+  for (int k = tid * 2; k < p.d; k += 512) {
+    float o0 = 0.f, o1 = 0.f;
+    for (int j = 0; j < p.nh; ++j) {
+      const float2 mv = *reinterpret_cast<const float2*>(p.M + (size_t)j * Bd + (size_t)b * p.d + k);
+      o0 = fmaf(s_l[j], mv.x, o0);
+      o1 = fmaf(s_l[j], mv.y, o1);
+    }
+    p.smry[(size_t)b * p.d + k] = o0;
+    p.smry[(size_t)b * p.d + k + 1] = o1;
+  }
+}
+
+struct SelfAttBwdP {
+  int B, d, nh;
+  const float* dsmry; int ld_ds;   // [B][ld_ds] gradient wrt the self summary
+  const float* sc; const float* C; const float* M; const float* w;
+  const float* att; int ld_att;
+  float* DMh;                      // [nh][B][d]  += att[j] * dsmry
+  float* DCh;                      // [nh][B][d]  += dl[j] * w * sc
+  float* dsc;                      // [B][d]      written
+  float* dw_part;                  // [B][d]      written
+  float* db_part;                  // [B]         written
+};
+
+__global__ __launch_bounds__(256) void self_attend_bwd_kernel(SelfAttBwdP p) {
+  __shared__ float s_dl[SA_MAXH];
+  __shared__ float s_att[SA_MAXH];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t Bd = (size_t)p.B * p.d;
+  const float* ds = p.dsmry + (size_t)b * p.ld_ds;
+  for (int j = wave; j < p.nh; j += 4) {
+    const float* m = p.M + (size_t)j * Bd + (size_t)b * p.d;
+    float part = 0.f;
+    for (int k = lane * 4; k < p.d; k += 256) {
+      const f32x4 mv = *reinterpret_cast<const f32x4*>(m + k);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(ds + k);
+      part += mv[0] * gv[0] + mv[1] * gv[1] + mv[2] * gv[2] + mv[3] * gv[3];
+    }
+    part = wave_sum(part);
+    if (lane == 0) { s_dl[j] = part; s_att[j] = p.att[(size_t)b * p.ld_att + j]; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float dot = 0.f, dls = 0.f;
+    for (int j = 0; j < p.nh; ++j) dot += s_att[j] * s_dl[j];
+    for (int j = 0; j < p.nh; ++j) { s_dl[j] = s_att[j] * (s_dl[j] - dot); dls += s_dl[j]; }
+    p.db_part[b] = dls;
+  }
+  __syncthreads();
+  for (int k = tid * 2; k < p.d; k += 512) {
+    const float2 sv = *reinterpret_cast<const float2*>(p.sc + (size_t)b * p.d + k);
+    const float2 wv = *reinterpret_cast<const float2*>(p.w + k);
+    const float2 gv = *reinterpret_cast<const float2*>(ds + k);
+    float q0 = 0.f, q1 = 0.f;   // sum_j dl[j] C[j]
+    for (int j = 0; j < p.nh; ++j) {
+      const size_t off = (size_t)j * Bd + (size_t)b * p.d + k;
+      const float2 cv = *reinterpret_cast<const float2*>(p.C + off);
+      const float dl = s_dl[j], a = s_att[j];
+      q0 = fmaf(dl, cv.x, q0);
+      q1 = fmaf(dl, cv.y, q1);
+      float2 dm = *reinterpret_cast<float2*>(p.DMh + off);
+      dm.x += a * gv.x; dm.y += a * gv.y;
+      *reinterpret_cast<float2*>(p.DMh + off) = dm;
+      float2 dc = *reinterpret_cast<float2*>(p.DCh + off);
+      dc.x += dl * (wv.x * sv.x); dc.y += dl * (wv.y * sv.y);
+      *reinterpret_cast<float2*>(p.DCh + off) = dc;
+    }
+    p.dsc[(size_t)b * p.d + k] = q0 * wv.x;
+    p.dsc[(size_t)b * p.d + k + 1] = q1 * wv.y;
+    p.dw_part[(size_t)b * p.d + k] = q0 * sv.x;
+    p.dw_part[(size_t)b * p.d + k + 1] = q1 * sv.y;
+  }
+}
+
 // dy[b][k] = sum over parts   (S_b kernel leaves 2*d/128 partials)
 __global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, size_t n, float* dst) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

@@ -36,6 +36,9 @@ def build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=0, b0=0, requ
     ("args", 3, 50, 49, 256, 2, True),
     ("args", 2, 7, 14, 128, 2, False),
     ("args2", 5, 12, 100, 128, 2, True),
+    ("args3", 4, 9, 49, 128, 4, True),
+    ("args4", 4, 9, 49, 128, 3, True),
+    ("args4", 3, 9, 196, 128, 2, False),
 ])
 def test_forward_stepwise_matches_oracle(macx, dev, name, B, S, N, d, p, train):
     cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
@@ -58,12 +61,20 @@ def test_forward_stepwise_matches_oracle(macx, dev, name, B, S, N, d, p, train):
         assert max_abs(cell.attentions["question"][i], rc.attentions["question"][i]) < 2e-6
         a = cell.attentions["kb"][i]
         assert float(a.min()) >= 0 and max_abs(a.sum(-1), torch.ones(B)) < 1e-5
+        if cfg.writeSelfAtt:
+            assert cell.attentions["self"][i].shape == (B, i + 1)
+            assert max_abs(cell.attentions["self"][i], rc.attentions["self"][i]) < 2e-6
+        if cfg.writeGate:
+            assert max_abs(cell.attentions["gate"][i], rc.attentions["gate"][i]) < 2e-6
 
 
 @pytest.mark.parametrize("name,B,S,N,d,p,train", [
     ("args", 3, 9, 196, 128, 2, False),
     ("args", 3, 9, 196, 128, 3, True),
     ("args", 2, 11, 49, 256, 2, True),
+    ("args3", 3, 9, 49, 128, 4, True),
+    ("args3", 2, 7, 30, 128, 3, False),
+    ("args4", 3, 9, 49, 128, 3, True),
 ])
 def test_backward_matches_oracle_autograd(macx, dev, name, B, S, N, d, p, train):
     cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)

@@ -42,8 +42,8 @@ def test_check_and_sizing_without_gpu(macx):
     assert L.macx_check(C.byref(o), C.byref(s)) == 0
     keep = L.macx_saved_floats(C.byref(o), C.byref(s), 1)
     nokeep = L.macx_saved_floats(C.byref(o), C.byref(s), 0)
-    # X, H1, I2 (fp32) + the two 1-bit dropout masks, kept for 11 more steps
-    assert keep - nokeep == 11 * 64 * 196 * 512 * 3 + 11 * 2 * (64 * 196 * 512 // 32)
+    # X, H1, I2, dropped KB (fp32) + the two 1-bit dropout masks, kept for 11 more steps
+    assert keep - nokeep == 11 * 64 * 196 * 512 * 4 + 11 * 2 * (64 * 196 * 512 // 32)
     off, cnt = C.c_size_t(), C.c_size_t()
     assert L.macx_saved_segment(C.byref(o), C.byref(s), 1, macx._lib.SEG["att_kb"], C.byref(off), C.byref(cnt)) == 0
     assert cnt.value == 12 * 64 * 196
@@ -53,7 +53,12 @@ def test_check_and_sizing_without_gpu(macx):
     assert b"invalid" in L.macx_strerror(-1)
 
 
-@pytest.mark.parametrize("name", ["args", "args2"])
+def test_recurrent_control_not_yet_on_hip(macx):
+    with pytest.raises(macx.UnsupportedOptions):
+        macx.freeze(mo.flag_file_config("args1"))
+
+
+@pytest.mark.parametrize("name", ["args", "args2", "args3", "args4"])
 def test_supported_flag_files_freeze(macx, name):
     o = macx.freeze(mo.flag_file_config(name))
     assert o.control_input_unshared == 1 and o.init_ctrl == macx._lib.INIT["Q"] and o.init_mem == macx._lib.INIT["PRM"]
