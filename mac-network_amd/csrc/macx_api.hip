@@ -62,6 +62,7 @@ struct SavedLayout {
   size_t wx_p, w1a_p, w1b_p, w2_p;  // packed forward weights (read unit)
   size_t wy_p, wm_p, wq_p, wqU_p;   // packed forward weights of the [B,d] linears
   size_t wg_p, ws_p;                // packed gate / self-attention control projection
+  size_t wc_p, wc2_p;               // packed contControl (+ _2) weights (recurrent control)
   size_t kb_bits, att_bits;         // [pk][B*N*d/32] keep bits of the two [B,N,d] dropout sites
   size_t bits_stride;               // words per step (0 when activations are not kept)
   size_t ctrl_t;                    // [B,d]   act(qInput(vecQ))
@@ -105,6 +106,8 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.wqU_p = take((o->control_input_unshared ? p : 1) * d * d);
   L.wg_p = o->write_gate ? take(d * d) : 0;
   L.ws_p = o->write_self_att ? take(d * d) : 0;
+  L.wc_p = o->control_feed_prev ? take(2 * d * d) : 0;
+  L.wc2_p = o->control_feed_prev ? take(d * d) : 0;
   L.ctrl_t = take(B * d);
   L.cI = take(p * B * d);
   if (o->control_feed_prev) {
@@ -180,10 +183,14 @@ struct BwdLayout {
   size_t ns_big, ngroup;
   size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part, ctrl_dl;
   size_t tmpBd[4];  // [B,d] scratch
+  size_t dccx;      // [p+1,B,d] gradient reaching cc_i from the NEXT step's contControl input (feedPrevAtt off)
+  size_t dlin1;     // [p,B,d] gradient wrt the first contControl layer's pre-activation
+  size_t dxc;       // [B,2d]  gradient wrt the contControl input of the current step
   size_t dzpre;     // [p,B,d] gate pre-activation gradient
   size_t dsc;       // [p,B,d] gradient of the projected control of the self attention
   size_t dws_part, dbs_part;   // [p,B,d], [p,B]
   size_t small_slab;
+  size_t tmp_dd;    // [d,d] scratch
   size_t total;
 };
 
@@ -228,6 +235,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dbc_part = take(p * B);
   L.ctrl_dl = take(p * B * (size_t)s->S);
   for (int i = 0; i < 4; ++i) L.tmpBd[i] = take(B * d);
+  if (o->control_feed_prev) { L.dccx = take((p + 1) * B * d); L.dlin1 = take(p * B * d); L.dxc = take(B * 2 * d); }
   if (o->write_gate) L.dzpre = take(p * B * d);
   if (o->write_self_att) { L.dsc = take(p * B * d); L.dws_part = take(p * B * d); L.dbs_part = take(p * B); }
   // scratch slabs for the small weight gradients (largest: write unit, rows p*B, [win x d])
@@ -237,6 +245,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
     small = (size_t)ns * d * d;
   }
   L.small_slab = take(small);
+  L.tmp_dd = take(d * d);
   L.total = off;
   return L;
 }
@@ -250,7 +259,6 @@ int check_impl(const macx_opts* o, const macx_shapes* s) {
   if ((size_t)(s->b0 + s->B) * s->N * s->d >= (1ull << 32)) return MACX_EINVAL;  // 32-bit dropout index
   if (o->write_inputs != MACX_WRITE_BOTH) return MACX_EUNSUPPORTED;
   if (o->read_mem_act == MACX_ACT_NON) return MACX_EUNSUPPORTED;   // no memKbProj_2 layer then (ops.py:325)
-  if (o->control_feed_prev) return MACX_EUNSUPPORTED;
   if (o->write_gate && o->write_gate_shared) return MACX_EREJECTED;   // [B,d] * [B] does not broadcast in the reference
   if (o->write_self_att && s->p + 1 > SA_MAXH) return MACX_EINVAL;
   return MACX_OK;
@@ -398,6 +406,10 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
     pk.add(P->qInput_W, d, 1, d, d, saved + L.wq_p);
     if (o->write_gate) pk.add(P->gate_W, d, 1, d, d, saved + L.wg_p);
     if (o->write_self_att) pk.add(P->selfCtrl_W, d, 1, d, d, saved + L.ws_p);
+    if (o->control_feed_prev) {
+      pk.add(P->contControl_W, d, 1, o->control_feed_inputs ? 2 * d : d, d, saved + L.wc_p);
+      if (o->control_cont_act != MACX_ACT_NON) pk.add(P->contControl2_W, d, 1, d, d, saved + L.wc2_p);
+    }
     for (int i = 0; i < (o->control_input_unshared ? p : 1); ++i) {
       if (pk.n == PACK_MAX) CK(pk.run(st));
       pk.add(P->qInputU_W + (size_t)i * d * d, d, 1, d, d, saved + L.wqU_p + (size_t)i * d * d);
@@ -464,6 +476,30 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   const bool wdrop = dp->keep_write < 1.0f;
   float* info_raw = wdrop ? saved + L.info_raw + (size_t)i * Bd : info;
 
+  // ---- control unit when it is recurrent (mac_cell.py:141-151, configs/args1.txt)
+  if (o->control_feed_prev) {
+    const float* prev = o->control_feed_prev_att ? controls + (size_t)i * Bd
+                                                 : (i == 0 ? controls : saved + L.cc + (size_t)(i - 1) * Bd);
+    float* cc_i = saved + L.cc + (size_t)i * Bd;
+    const bool two = o->control_cont_act != MACX_ACT_NON;       // ops.linear stacks a second layer (ops.py:325-328)
+    float* lin1 = two ? saved + L.cc_h + (size_t)i * Bd : cc_i;
+    LinP l = lin_basic(prev, d, d, B, saved + L.wc_p, P->contControl_b, d, o->control_cont_act, lin1, d);
+    if (o->control_feed_inputs) { l.seg[1] = LinSeg{saved + L.cI + (size_t)i * Bd, d, d, 0}; l.Ktot = 2 * d; }
+    CK(small_linear_launch(l, 1, st));
+    if (two) {
+      LinP l2 = lin_basic(lin1, d, d, B, saved + L.wc2_p, P->contControl2_b, d, MACX_ACT_NON, cc_i, d);
+      CK(small_linear_launch(l2, 1, st));
+    }
+    CtrlP c;
+    c.B = B; c.S = s->S; c.d = d;
+    c.cc = cc_i; c.z_cc = 0;
+    c.words = in->words; c.lengths = in->questionLengths;
+    c.w = P->ctrlLogits_w; c.bias = P->ctrlLogits_b;
+    c.att = saved + L.seg[MACX_SEG_ATT_QUESTION] + (size_t)i * B * s->S; c.z_att = 0;
+    c.control = controls + (size_t)(i + 1) * Bd; c.z_ctl = 0;
+    hipLaunchKernelGGL(control_attend_kernel, dim3(B, 1), dim3(256), 0, st, c);
+    CK(hipGetLastError());
+  }
   // ---- read unit (mac_cell.py:209-277)
   // memory dropout (mac_cell.py:214-217) then the read-dropout of ops.mul's y input (ops.py:679)
   const DropSpec dm = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
@@ -606,6 +642,10 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     pk.add(P->qInput_W, 1, d, d, d, ws + W.wqT);
     if (o->write_gate) pk.add(P->gate_W, 1, d, d, d, ws + W.wgT);
     if (o->write_self_att) pk.add(P->selfCtrl_W, 1, d, d, d, ws + W.wscT);
+    if (o->control_feed_prev) {
+      pk.add(P->contControl_W, 1, d, d, o->control_feed_inputs ? 2 * d : d, ws + W.wccT);   // Wc^T: [d] -> [d or 2d]
+      if (o->control_cont_act != MACX_ACT_NON) pk.add(P->contControl2_W, 1, d, d, d, ws + W.wcc2T);
+    }
     for (int i = 0; i < nU; ++i) {
       if (pk.n == PACK_MAX) CK(pk.run(st));
       pk.add(P->qInputU_W + (size_t)i * dd, 1, d, d, d, ws + W.wqUT + (size_t)i * dd);
@@ -621,6 +661,11 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   CK(hipMemsetAsync(DC, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
   if (d_memory) CK(hipMemcpyAsync(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (d_control) CK(hipMemcpyAsync(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (o->control_feed_prev) {
+    CK(hipMemsetAsync(GI->words, 0, (size_t)B * S * d * sizeof(float), st));
+    CK(hipMemsetAsync(ws + W.dwc_part, 0, Bd * sizeof(float), st));
+    CK(hipMemsetAsync(ws + W.dccx, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
+  }
 
   const float* controls = saved + L.seg[MACX_SEG_CONTROLS];
   const float* memories = saved + L.seg[MACX_SEG_MEMORIES];
@@ -762,17 +807,97 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
         if (o->write_gate) CK(axpy(ws + W.tmpBd[3], Bd, dm_prev, st));   // dm * (1 - z)
       }
     }
+    // ---- recurrent control backward for this step (dL/dc_i is complete now)
+    if (o->control_feed_prev) {
+      const int cin = o->control_feed_inputs ? 2 * d : d;
+      const bool two = o->control_cont_act != MACX_ACT_NON;
+      if (o->write_self_att && !o->write_self_att_cont) {
+        LinP l = lin_basic(ws + W.dsc + (size_t)i * Bd, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, DC + (size_t)(i + 1) * Bd, d);
+        l.addend = DC + (size_t)(i + 1) * Bd; l.ld_add = d;
+        CK(small_linear_launch(l, 1, st));
+      }
+      CtrlBwdP c;
+      c.B = B; c.S = S; c.d = d; c.nz = 1;
+      c.dcontrol = DC + (size_t)(i + 1) * Bd; c.z_dc = 0;
+      c.cc = saved + L.cc + (size_t)i * Bd; c.z_cc = 0;
+      c.att = saved + L.seg[MACX_SEG_ATT_QUESTION] + (size_t)i * B * S; c.z_att = 0;
+      c.words = in->words; c.w = P->ctrlLogits_w;
+      c.dl = ws + W.ctrl_dl;
+      c.dcc = ws + W.dcc + (size_t)i * Bd; c.z_dcc = 0;
+      c.dwords = GI->words; c.acc_words = 1;
+      c.dw_part = ws + W.dwc_part; c.db_part = ws + W.dbc_part + (size_t)i * B;
+      hipLaunchKernelGGL(control_bwd_dl_kernel, dim3(B, 1), dim3(256), 0, st, c);
+      hipLaunchKernelGGL(control_bwd_apply_kernel, dim3(B, d / 64), dim3(256), 0, st, c);
+      CK(hipGetLastError());
+      float* dcc_i = ws + W.dcc + (size_t)i * Bd;
+      // parts of dL/dcc_i that did not come through the word attention
+      if (!o->control_feed_prev_att) CK(axpy(ws + W.dccx + (size_t)(i + 1) * Bd, Bd, dcc_i, st));
+      if (o->write_self_att && o->write_self_att_cont) {
+        LinP l = lin_basic(ws + W.dsc + (size_t)i * Bd, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, dcc_i, d);
+        l.addend = dcc_i; l.ld_add = d;
+        CK(small_linear_launch(l, 1, st));
+      }
+      // through contControl(_2): dlin1 = (dcc Wc2^T) * act'(h)  or  dcc
+      float* dlin1 = ws + W.dlin1 + (size_t)i * Bd;
+      if (two) {
+        LinP l2 = lin_basic(dcc_i, d, d, B, ws + W.wcc2T, nullptr, d, MACX_ACT_NON, dlin1, d);
+        l2.actgrad_src = saved + L.cc_h + (size_t)i * Bd; l2.actgrad_act = o->control_cont_act; l2.ld_ag = d;
+        CK(small_linear_launch(l2, 1, st));
+      } else {
+        CK(hipMemcpyAsync(dlin1, dcc_i, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+      }
+      // dx = dlin1 Wc^T = [d prev | d cI_i]
+      LinP lx = lin_basic(dlin1, d, d, B, ws + W.wccT, nullptr, cin, MACX_ACT_NON, ws + W.dxc, cin);
+      CK(small_linear_launch(lx, 1, st));
+      float* dprev_dst = o->control_feed_prev_att ? DC + (size_t)i * Bd : (i == 0 ? DC : ws + W.dccx + (size_t)i * Bd);
+      hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dxc), cin, 0, B, d, 0u, no_drop(),
+                         ws + W.tmpBd[0]);
+      CK(hipGetLastError());
+      CK(axpy(ws + W.tmpBd[0], Bd, dprev_dst, st));
+      if (o->control_feed_inputs) {
+        hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dxc), cin, d, B, d, 0u, no_drop(),
+                           ws + W.dcI + (size_t)i * Bd);
+        CK(hipGetLastError());
+      } else {
+        CK(hipMemsetAsync(ws + W.dcI + (size_t)i * Bd, 0, Bd * sizeof(float), st));
+      }
+    }
   }
 
-  if (o->write_self_att && !o->write_self_att_cont) {
+  if (o->write_self_att && !o->write_self_att_cont && !o->control_feed_prev) {
     // selfControl = the NEW control: dL/dc_i += dsc_i Ws^T before the word attention is differentiated
     LinP l = lin_basic(ws + W.dsc, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, DC + Bd, d);
     l.seg[0].zstride = Bd; l.zout = Bd; l.addend = DC + Bd; l.ld_add = d; l.zadd = Bd;
     CK(small_linear_launch(l, p, st));
   }
+  if (o->control_feed_prev) {
+    // word-attention parameter partials were accumulated step by step
+    CK(rowsum(ws + W.dwc_part, B, d, d, GP->ctrlLogits_w, st));
+    CK(rowsum(ws + W.dbc_part, p * B, 1, 1, GP->ctrlLogits_b, st));
+    // contControl weights: one contraction over all p*B rows per input segment
+    const bool two = o->control_cont_act != MACX_ACT_NON;
+    const float* prev_all = o->control_feed_prev_att ? controls : nullptr;   // rows of step i = c_{i-1} = controls[i]
+    if (o->control_feed_prev_att) {
+      CKI(wgrad_impl(prev_all, d, ws + W.dlin1, d, p * B, d, d, GP->contControl_W, ws + W.small_slab, st));
+    } else {
+      // prev of step 0 is the initial control, prev of step i > 0 is cc_{i-1}
+      CKI(wgrad_impl(controls, d, ws + W.dlin1, d, B, d, d, GP->contControl_W, ws + W.small_slab, st));
+      if (p > 1) {
+        CKI(wgrad_impl(saved + L.cc, d, ws + W.dlin1 + Bd, d, (p - 1) * B, d, d, ws + W.tmp_dd, ws + W.small_slab, st));
+        CK(axpy(ws + W.tmp_dd, dd, GP->contControl_W, st));
+      }
+    }
+    if (o->control_feed_inputs)
+      CKI(wgrad_impl(saved + L.cI, d, ws + W.dlin1, d, p * B, d, d, GP->contControl_W + dd, ws + W.small_slab, st));
+    CK(rowsum(ws + W.dlin1, p * B, d, d, GP->contControl_b, st));
+    if (two) {
+      CKI(wgrad_impl(saved + L.cc_h, d, ws + W.dcc, d, p * B, d, d, GP->contControl2_W, ws + W.small_slab, st));
+      CK(rowsum(ws + W.dcc, p * B, d, d, GP->contControl2_b, st));
+    }
+  }
   // ---- control unit backward.  Not recurrent: every control depends on the question only, so all
-  // p steps are handled by one launch (one workgroup per question, steps in fixed order).
-  {
+  // p steps are handled together.
+  if (!o->control_feed_prev) {
     CtrlBwdP c;
     c.B = B; c.S = S; c.d = d; c.nz = p;
     c.dcontrol = DC + Bd; c.z_dc = Bd;
@@ -781,7 +906,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     c.words = in->words; c.w = P->ctrlLogits_w;
     c.dl = ws + W.ctrl_dl;
     c.dcc = ws + W.dcc; c.z_dcc = Bd;
-    c.dwords = GI->words;
+    c.dwords = GI->words; c.acc_words = 0;
     c.dw_part = ws + W.dwc_part; c.db_part = ws + W.dbc_part;
     hipLaunchKernelGGL(control_bwd_dl_kernel, dim3(B, p), dim3(256), 0, st, c);
     hipLaunchKernelGGL(control_bwd_apply_kernel, dim3(B, d / 64), dim3(256), 0, st, c);
@@ -795,7 +920,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     float* dst = o->write_self_att_cont ? ws + W.dcc : DC + Bd;
     LinP l = lin_basic(ws + W.dsc, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, dst, d);
     l.seg[0].zstride = Bd; l.zout = Bd; l.addend = dst; l.ld_add = d; l.zadd = Bd;
-    if (o->write_self_att_cont) CK(small_linear_launch(l, p, st));
+    if (o->write_self_att_cont && !o->control_feed_prev) CK(small_linear_launch(l, p, st));
     const float* src = o->write_self_att_cont ? saved + L.cc : controls + Bd;
     CKI(wgrad_impl(src, d, ws + W.dsc, d, p * B, d, d, GP->selfCtrl_W, ws + W.small_slab, st));
     CK(rowsum(ws + W.dsc, p * B, d, d, GP->selfCtrl_b, st));

@@ -371,7 +371,8 @@ struct CtrlBwdP {
   const float* w;                       // [d]
   float* dl;                            // [z][B][S]   scratch (written by (1), read by (2))
   float* dcc; size_t z_dcc;             // [z][B][d]   out
-  float* dwords;                        // [B][S][d]   out (written, not accumulated)
+  float* dwords;                        // [B][S][d]   out (written; accumulated when acc_words)
+  int acc_words;                        // recurrent control: steps are differentiated one launch at a time
   float* dw_part;                       // [B][d]      out (sum over steps)
   float* db_part;                       // [nz*B]      out
 };
@@ -457,7 +458,8 @@ __global__ __launch_bounds__(256) void control_bwd_apply_kernel(CtrlBwdP p) {
     for (int s = grp; s < sn; s += 4) {
       float v = 0.f;
       for (int z = 0; z < p.nz; ++z) v += s_att[z][s] * s_dc[z][col] + s_dl[z][s] * s_ccw[z][col];
-      p.dwords[((size_t)b * p.S + sb + s) * p.d + c0 + col] = v;
+      float* dst = p.dwords + ((size_t)b * p.S + sb + s) * p.d + c0 + col;
+      *dst = p.acc_words ? *dst + v : v;
     }
   }
   float dwp = 0.f;
@@ -472,7 +474,11 @@ __global__ __launch_bounds__(256) void control_bwd_apply_kernel(CtrlBwdP p) {
   }
   s_R[grp][col] = dwp;
   __syncthreads();
-  if (grp == 0) p.dw_part[(size_t)b * p.d + c0 + col] = (s_R[0][col] + s_R[1][col]) + (s_R[2][col] + s_R[3][col]);
+  if (grp == 0) {
+    float* dst = p.dw_part + (size_t)b * p.d + c0 + col;
+    const float t = (s_R[0][col] + s_R[1][col]) + (s_R[2][col] + s_R[3][col]);
+    *dst = p.acc_words ? *dst + t : t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

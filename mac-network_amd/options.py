@@ -115,8 +115,6 @@ def freeze(config):
     o.memory_variational_dropout = int(bool(g("memoryVariationalDropout")))
     if o.read_mem_act == _lib.ACT["NON"]:
         unsupported.append("readMemAct=NON (no memKbProj_2 layer, ops.py:325)")
-    if o.control_feed_prev:
-        unsupported.append("--controlFeedPrev (recurrent control, configs/args1.txt)")
     if unsupported:
         raise UnsupportedOptions("no HIP path yet for: " + ", ".join(unsupported))
     return o

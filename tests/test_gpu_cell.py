@@ -39,6 +39,7 @@ def build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=0, b0=0, requ
     ("args3", 4, 9, 49, 128, 4, True),
     ("args4", 4, 9, 49, 128, 3, True),
     ("args4", 3, 9, 196, 128, 2, False),
+    ("args1", 4, 9, 49, 128, 4, True),
 ])
 def test_forward_stepwise_matches_oracle(macx, dev, name, B, S, N, d, p, train):
     cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
@@ -75,6 +76,8 @@ def test_forward_stepwise_matches_oracle(macx, dev, name, B, S, N, d, p, train):
     ("args3", 3, 9, 49, 128, 4, True),
     ("args3", 2, 7, 30, 128, 3, False),
     ("args4", 3, 9, 49, 128, 3, True),
+    ("args1", 3, 9, 49, 128, 4, True),
+    ("args1", 2, 7, 30, 128, 3, False),
 ])
 def test_backward_matches_oracle_autograd(macx, dev, name, B, S, N, d, p, train):
     cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
@@ -145,3 +148,38 @@ def test_headline_shape_forward_backward(macx, dev):
     assert torch.equal(state.memory, s2.memory)
     assert torch.equal(kbd.grad, kb2.grad)
     assert torch.equal(params.memKbProj_W.grad, params2.memKbProj_W.grad)
+
+
+@pytest.mark.parametrize("over", [
+    dict(controlFeedPrevAtt=False),                                   # feed the continuous control instead
+    dict(controlFeedInputs=False, controlContAct="NON"),              # single contControl layer on the previous control only
+    dict(controlFeedPrevAtt=False, writeSelfAtt=True, writeSelfAttMod="CONT", writeGate=True),
+    dict(writeSelfAtt=True, writeSelfAttMod="NON"),
+])
+def test_recurrent_control_variants(macx, dev, over):
+    B, S, N, d, p = 3, 8, 30, 128, 3
+    cfg, vq, words, lengths, kb = make_case("args1", B, S, N, d, p, **over)
+    cell, params, (vqd, wd, kbd) = build_cell(macx, dev, cfg, vq, words, lengths, kb, True, seed=3, requires_grad=True)
+    g = torch.Generator().manual_seed(2)
+    dmem = torch.randn(B, d, generator=g) / B
+    dctl = torch.randn(B, d, generator=g) / B
+    state = cell.run()
+    ((state.memory * dmem.to(dev)).sum() + (state.control * dctl.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=True, seed=3, need_grad=True,
+                     d_memory=dmem, d_control=dctl)
+    assert rel_err(state.memory, ref["memory"]) < FWD_TOL and rel_err(state.control, ref["control"]) < FWD_TOL
+    zero_if_none = lambda g, like: torch.zeros_like(like) if g is None else g      # an input this variant never reads
+    rvq, rw, rkb = ref["inputs"]
+    errs = {"vecQuestions": rel_err(vqd.grad, zero_if_none(rvq.grad, rvq)), "words": rel_err(wd.grad, zero_if_none(rw.grad, rw)),
+            "knowledgeBase": rel_err(kbd.grad, rkb.grad)}
+    names = macx.params.reference_names(cfg, p)
+    for f in params.fields:
+        for refname, idx in names[f]:
+            rg = zero_if_none(ref["params"][refname].grad, ref["params"][refname])
+            got = getattr(params, f).grad
+            got = got if idx is None else got[idx]
+            floor = 5e-2 if refname.endswith("linearLayerlogits/biases/bias") else 1e-6
+            errs[refname] = rel_err(got.reshape(rg.shape), rg, floor=floor)
+    bad = {k: v for k, v in errs.items() if not (v < GRAD_TOL)}
+    assert not bad, bad

@@ -53,9 +53,10 @@ def test_check_and_sizing_without_gpu(macx):
     assert b"invalid" in L.macx_strerror(-1)
 
 
-def test_recurrent_control_not_yet_on_hip(macx):
-    with pytest.raises(macx.UnsupportedOptions):
-        macx.freeze(mo.flag_file_config("args1"))
+def test_args1_freezes_recurrent_control(macx):
+    o = macx.freeze(mo.flag_file_config("args1"))
+    assert o.control_feed_prev == 1 and o.control_feed_prev_att == 1 and o.control_feed_inputs == 1
+    assert o.control_cont_act == macx._lib.ACT["TANH"] and o.init_ctrl == macx._lib.INIT["PRM"]
 
 
 @pytest.mark.parametrize("name", ["args", "args2", "args3", "args4"])
