@@ -88,11 +88,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MAC cell has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm.  MACX_BENCH_BACKEND=gloo lets two ranks share ONE GPU to exercise this path
+        # on a single-GPU box (RCCL refuses duplicate devices); it is never used for reported numbers.
+        backend = os.environ.get("MACX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import macx
     from oracle import mac_oracle as mo   # only for synthetic input shapes + the cpu_baseline leg

@@ -197,6 +197,34 @@ int macx_cell_backward(const macx_opts*, const macx_shapes*, const macx_dropout*
                        const float* d_memory, const float* d_control,
                        const macx_param_grads*, const macx_input_grads*, void* stream);
 
+/* ---- output unit + classifier (consumer of the final memory) ------------------ */
+/* outputOp (model.py:512-528, --outQuestion) + classifier (model.py:547-576 -> ops.FCLayer
+ * ops.py:349-359) for outClassifierDims = [hidden]:
+ *   logits = dropout(act(dropout(concat([memory, vecQ Woq + boq])) W0 + b0)) W1 + b1
+ * Variables: outputUnit/linearLayeroutQuestion, classifier/linearLayerfc_0, classifier/linearLayerfc_1. */
+typedef struct macx_out_shapes {
+  int32_t B, d, hidden, answers;  /* batch, memDim == ctrlDim, outClassifierDims[0], answerWordsNum */
+  int32_t b0;                     /* global index of question 0 (dropout stream) */
+} macx_out_shapes;
+typedef struct macx_out_params {
+  const float* outQuestion_W; const float* outQuestion_b;   /* [d,d], [d]              */
+  const float* fc0_W; const float* fc0_b;                   /* [2d,hidden], [hidden]   */
+  const float* fc1_W; const float* fc1_b;                   /* [hidden,answers], [answers] */
+} macx_out_params;
+typedef struct macx_out_grads {
+  float* outQuestion_W; float* outQuestion_b; float* fc0_W; float* fc0_b; float* fc1_W; float* fc1_b;
+} macx_out_grads;
+size_t macx_output_saved_floats(const macx_out_shapes*);
+size_t macx_output_ws_floats(const macx_out_shapes*);
+/* act: resolved activation of "RELU" (config.relu); keep: outputDropout (1.0 in evaluation). */
+int macx_output_forward(const macx_out_shapes*, int act, float keep, uint32_t seed, const macx_out_params*,
+                        const float* memory, const float* vecQuestions, float* logits,
+                        float* saved, size_t saved_floats, void* stream);
+int macx_output_backward(const macx_out_shapes*, int act, float keep, uint32_t seed, const macx_out_params*,
+                         const float* memory, const float* vecQuestions, const float* saved, size_t saved_floats,
+                         float* ws, size_t ws_floats, const float* d_logits, const macx_out_grads*,
+                         float* d_memory, float* d_vecQuestions, void* stream);
+
 /* ---- unit-level entry points (the ops.py primitives; used by the parity tests) -------------- */
 /* out[r, :] = act(concat(x1[r], x2[r]) @ W + b + bias_const)     ops.linear (ops.py:298-333)
  * on fp32 MFMA; `W_packed` from macx_pack_weight(W, k1 + k2, n_out, 0); k1, k2, n_out % 16 == 0. */

@@ -6,5 +6,6 @@ from . import _lib, build, dp, options, params      # noqa: F401
 from .cell import MACCell, MACCellTuple             # noqa: F401
 from .options import UnsupportedOptions, freeze     # noqa: F401
 from .params import MACCellParams                   # noqa: F401
+from .output import OutputClassifier                # noqa: F401
 
-__all__ = ["MACCell", "MACCellTuple", "MACCellParams", "UnsupportedOptions", "freeze"]
+__all__ = ["MACCell", "MACCellTuple", "MACCellParams", "OutputClassifier", "UnsupportedOptions", "freeze"]

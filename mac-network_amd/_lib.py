@@ -48,6 +48,21 @@ class MacxParamGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
 
 
+class MacxOutShapes(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "d", "hidden", "answers", "b0")]
+
+
+OUT_FIELDS = ("outQuestion_W", "outQuestion_b", "fc0_W", "fc0_b", "fc1_W", "fc1_b")
+
+
+class MacxOutParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
+
+
+class MacxOutGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
+
+
 class MacxInputs(C.Structure):
     _fields_ = [("vecQuestions", C.c_void_p), ("words", C.c_void_p), ("questionLengths", C.c_void_p),
                 ("knowledgeBase", C.c_void_p)]
@@ -60,7 +75,8 @@ class MacxInputGrads(C.Structure):
 EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats", "macx_ws_floats",
            "macx_saved_segment", "macx_cell_begin", "macx_cell_step", "macx_cell_forward", "macx_cell_backward",
            "macx_linear", "macx_pack_weight", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_wgrad_splits",
-           "macx_wgrad", "macx_debug_set")
+           "macx_wgrad", "macx_debug_set", "macx_output_saved_floats", "macx_output_ws_floats",
+           "macx_output_forward", "macx_output_backward")
 
 _lib = None
 
@@ -111,6 +127,15 @@ def lib():
     L.macx_dropout_mask.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_void_p,
                                     C.c_void_p]
     L.macx_debug_set.argtypes = [C.c_int, C.c_int]
+    L.macx_output_saved_floats.restype = C.c_size_t
+    L.macx_output_saved_floats.argtypes = [P(MacxOutShapes)]
+    L.macx_output_ws_floats.restype = C.c_size_t
+    L.macx_output_ws_floats.argtypes = [P(MacxOutShapes)]
+    L.macx_output_forward.argtypes = [P(MacxOutShapes), C.c_int, C.c_float, C.c_uint32, P(MacxOutParams), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.macx_output_backward.argtypes = [P(MacxOutShapes), C.c_int, C.c_float, C.c_uint32, P(MacxOutParams), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, P(MacxOutGrads), C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
     L.macx_wgrad_splits.argtypes = [C.c_int, C.c_int, C.c_int]
     L.macx_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                              C.c_void_p]
@@ -118,6 +143,8 @@ def lib():
         f = getattr(L, n)
         if f.restype is C.c_int or n in ("macx_check",):
             f.restype = C.c_int
+    for n in ("macx_output_forward", "macx_output_backward"):
+        getattr(L, n).restype = C.c_int
     _lib = L
     return L
 

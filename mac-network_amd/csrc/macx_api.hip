@@ -273,8 +273,8 @@ hipError_t pack(const float* src, int ld_k, int ld_j, int K, int Nout, float* ds
 struct Packer {
   PackList L;
   int n = 0;
-  void add(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst) {
-    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout};
+  void add(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst, int k_src = -1, int n_src = -1) {
+    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout, k_src < 0 ? K : k_src, n_src < 0 ? Nout : n_src};
   }
   hipError_t run(hipStream_t st) {
     if (n == 0) return hipSuccess;
@@ -1068,6 +1068,139 @@ int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, u
   if (!out) return MACX_EINVAL;
   const DropSpec ds = make_drop(keep, seed, site, step);
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, ds.key, ds.thr24, first, n, out);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
+// =================================================================================================
+// output unit + classifier (model.py:512-576, ops.py:349-359): SURVEY 8f row 2
+// =================================================================================================
+namespace {
+struct OutLayout {
+  size_t woq_p, w0_p, w1_p;   // packed forward weights
+  size_t eq;                  // [B,d]   outQuestion(vecQ)
+  size_t x0;                  // [B,in]  dropped concat([memory, eq])
+  size_t h;                   // [B,H]   act(fc_0)
+  size_t x1;                  // [B,H]   dropped h
+  size_t logits_pad;          // [B,Ap]
+  size_t total;
+};
+inline int pad16(int n) { return (n + 15) & ~15; }
+OutLayout make_out(const macx_out_shapes* s) {
+  OutLayout L;
+  memset(&L, 0, sizeof(L));
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
+  const size_t B = s->B, d = s->d, in = 2 * (size_t)s->d, H = s->hidden, Ap = pad16(s->answers);
+  L.woq_p = take(d * d); L.w0_p = take(in * H); L.w1_p = take(H * Ap);
+  L.eq = take(B * d); L.x0 = take(B * in); L.h = take(B * H); L.x1 = take(B * H); L.logits_pad = take(B * Ap);
+  L.total = off;
+  return L;
+}
+struct OutBwdLayout {
+  size_t woqT, w0T, w1T;
+  size_t dlog_pad, dx1, dh, dx0, deq, total;
+};
+OutBwdLayout make_out_bwd(const macx_out_shapes* s) {
+  OutBwdLayout L;
+  memset(&L, 0, sizeof(L));
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
+  const size_t B = s->B, d = s->d, in = 2 * (size_t)s->d, H = s->hidden, Ap = pad16(s->answers);
+  L.woqT = take(d * d); L.w0T = take(H * in); L.w1T = take(Ap * H);
+  L.dlog_pad = take(B * Ap); L.dx1 = take(B * H); L.dh = take(B * H); L.dx0 = take(B * in); L.deq = take(B * d);
+  L.total = off;
+  return L;
+}
+int out_check(const macx_out_shapes* s) {
+  if (!s || s->B < 1 || s->d < 16 || s->d % 16 || s->hidden < 16 || s->hidden % 16 || s->answers < 1) return MACX_EINVAL;
+  return MACX_OK;
+}
+}  // namespace
+
+size_t macx_output_saved_floats(const macx_out_shapes* s) { return out_check(s) ? 0 : make_out(s).total; }
+size_t macx_output_ws_floats(const macx_out_shapes* s) { return out_check(s) ? 0 : make_out_bwd(s).total; }
+
+int macx_output_forward(const macx_out_shapes* s, int act, float keep, uint32_t seed, const macx_out_params* P, const float* memory,
+                        const float* vecQ, float* logits, float* saved, size_t saved_floats, void* stream) {
+  CKI(out_check(s));
+  if (!P || !memory || !vecQ || !logits || !saved) return MACX_EINVAL;
+  const OutLayout L = make_out(s);
+  if (saved_floats < L.total) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, d = s->d, in = 2 * d, H = s->hidden, A = s->answers, Ap = pad16(A);
+  Packer pk;
+  pk.add(P->outQuestion_W, d, 1, d, d, saved + L.woq_p);
+  pk.add(P->fc0_W, H, 1, in, H, saved + L.w0_p);
+  pk.add(P->fc1_W, A, 1, H, Ap, saved + L.w1_p, H, A);
+  CK(pk.run(st));
+  // outputOp (model.py:512-528): features = concat([memory, outQuestion(vecQ)])
+  LinP q = lin_basic(vecQ, d, d, B, saved + L.woq_p, P->outQuestion_b, d, MACX_ACT_NON, saved + L.eq, d);
+  CK(small_linear_launch(q, 1, st));
+  // classifier (model.py:547-576 -> ops.FCLayer ops.py:349-359): dropout on every layer input, act between layers
+  const DropSpec d0 = make_drop(keep, seed, SITE_OUT_FC0, 0), d1 = make_drop(keep, seed, SITE_OUT_FC1, 0);
+  // the concat is built in place: columns [0,d) memory, [d,2d) eq, with the layer-input mask indexed over [B, 2d]
+  CK(hipMemcpy2DAsync(saved + L.x0, (size_t)in * sizeof(float), memory, (size_t)d * sizeof(float), (size_t)d * sizeof(float), B,
+                      hipMemcpyDeviceToDevice, st));
+  CK(hipMemcpy2DAsync(saved + L.x0 + d, (size_t)in * sizeof(float), saved + L.eq, (size_t)d * sizeof(float), (size_t)d * sizeof(float), B,
+                      hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)(saved + L.x0), B, in, (uint32_t)s->b0, d0, no_drop(),
+                     saved + L.x0);
+  LinP f0 = lin_basic(saved + L.x0, in, in, B, saved + L.w0_p, P->fc0_b, H, act, saved + L.h, H);
+  CK(small_linear_launch(f0, 1, st));
+  hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)(saved + L.h), B, H, (uint32_t)s->b0, d1, no_drop(),
+                     saved + L.x1);
+  CK(hipGetLastError());
+  // fc_1: bias padded with zeros by reading through a guarded copy
+  CK(hipMemsetAsync(saved + L.logits_pad, 0, (size_t)B * Ap * sizeof(float), st));
+  LinP f1 = lin_basic(saved + L.x1, H, H, B, saved + L.w1_p, nullptr, Ap, MACX_ACT_NON, saved + L.logits_pad, Ap);
+  CK(small_linear_launch(f1, 1, st));
+  hipLaunchKernelGGL(crop_cols_kernel, dim3(16), dim3(256), 0, st, (const float*)(saved + L.logits_pad), Ap, B, A, logits);
+  // + bias (the packed layer ran without it because the bias vector is not padded)
+  hipLaunchKernelGGL(add_bias_kernel, dim3(16), dim3(256), 0, st, P->fc1_b, B, A, logits);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
+int macx_output_backward(const macx_out_shapes* s, int act, float keep, uint32_t seed, const macx_out_params* P, const float* memory,
+                         const float* vecQ, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                         const float* d_logits, const macx_out_grads* G, float* d_memory, float* d_vecQ, void* stream) {
+  CKI(out_check(s));
+  if (!P || !memory || !vecQ || !saved || !ws || !d_logits || !G || !d_memory || !d_vecQ) return MACX_EINVAL;
+  const OutLayout L = make_out(s);
+  const OutBwdLayout W = make_out_bwd(s);
+  if (saved_floats < L.total || ws_floats < W.total) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, d = s->d, in = 2 * d, H = s->hidden, A = s->answers, Ap = pad16(A);
+  Packer pk;
+  pk.add(P->outQuestion_W, 1, d, d, d, ws + W.woqT);
+  pk.add(P->fc0_W, 1, H, H, in, ws + W.w0T);          // W0^T: [H] -> [2d]
+  pk.add(P->fc1_W, 1, A, Ap, H, ws + W.w1T, A, H);    // W1^T: [Ap] -> [H], rows past A are zero
+  CK(pk.run(st));
+  const DropSpec d0 = make_drop(keep, seed, SITE_OUT_FC0, 0), d1 = make_drop(keep, seed, SITE_OUT_FC1, 0);
+  hipLaunchKernelGGL(pad_cols_kernel, dim3(16), dim3(256), 0, st, d_logits, A, B, Ap, ws + W.dlog_pad);
+  // fc_1
+  hipLaunchKernelGGL(outer_sum_kernel, dim3(64), dim3(256), 0, st, saved + L.x1, H, d_logits, A, B, H, A, G->fc1_W);
+  CK(rowsum(d_logits, B, A, A, G->fc1_b, st));
+  LinP b1 = lin_basic(ws + W.dlog_pad, Ap, Ap, B, ws + W.w1T, nullptr, H, MACX_ACT_NON, ws + W.dx1, H);
+  CK(small_linear_launch(b1, 1, st));
+  // through dropout(h) and the activation: dh = dx1 * mask1 * act'(h)
+  hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dx1), B, H, (uint32_t)s->b0, d1, no_drop(), ws + W.dx1);
+  hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dx1), saved + L.h, act, (size_t)B * H, ws + W.dh);
+  // fc_0
+  hipLaunchKernelGGL(outer_sum_kernel, dim3(512), dim3(256), 0, st, saved + L.x0, in, (const float*)(ws + W.dh), H, B, in, H, G->fc0_W);
+  CK(rowsum(ws + W.dh, B, H, H, G->fc0_b, st));
+  LinP b0 = lin_basic(ws + W.dh, H, H, B, ws + W.w0T, nullptr, in, MACX_ACT_NON, ws + W.dx0, in);
+  CK(small_linear_launch(b0, 1, st));
+  hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dx0), B, in, (uint32_t)s->b0, d0, no_drop(), ws + W.dx0);
+  // split the concat gradient
+  hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dx0), in, 0, B, d, 0u, no_drop(), d_memory);
+  hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dx0), in, d, B, d, 0u, no_drop(), ws + W.deq);
+  // outQuestion
+  hipLaunchKernelGGL(outer_sum_kernel, dim3(256), dim3(256), 0, st, vecQ, d, (const float*)(ws + W.deq), d, B, d, d, G->outQuestion_W);
+  CK(rowsum(ws + W.deq, B, d, d, G->outQuestion_b, st));
+  LinP bq = lin_basic(ws + W.deq, d, d, B, ws + W.woqT, nullptr, d, MACX_ACT_NON, d_vecQ, d);
+  CK(small_linear_launch(bq, 1, st));
   CK(hipGetLastError());
   return MACX_OK;
 }

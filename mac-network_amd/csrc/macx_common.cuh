@@ -49,7 +49,9 @@ enum : uint32_t {
   SITE_READ_KB = 3,   // ops.py:678   dropout(x) on the knowledge base inside ops.mul(proj=...)
   SITE_READ_MEM = 4,  // ops.py:679   dropout(y) on the memory inside ops.mul(proj=...)
   SITE_READ_ATT = 5,  // ops.py:312 via :142  dropout on the interactions before the d->1 logits
-  SITE_WRITE_INFO = 6 // mac_cell.py:463  dropout on the retrieved information
+  SITE_WRITE_INFO = 6, // mac_cell.py:463  dropout on the retrieved information
+  SITE_OUT_FC0 = 7,   // ops.py:312 via FCLayer (ops.py:349-359): dropout on the classifier's first layer input
+  SITE_OUT_FC1 = 8    // ... and on its second layer input
 };
 
 struct DropSpec {

@@ -26,7 +26,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int 
 }
 
 // several weights in one launch (blockIdx.y selects the descriptor)
-struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; };
+struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; };   // zero fill for k >= k_src or j >= n_src
 constexpr int PACK_MAX = 40;
 struct PackList { PackDesc d[PACK_MAX]; };
 __global__ void pack_weights_kernel(PackList L) {
@@ -38,7 +38,7 @@ __global__ void pack_weights_kernel(PackList L) {
     const int j = t % q.Nout;
     const size_t qg = t / q.Nout;
     const int k = 16 * (int)(qg >> 2) + 4 * (int)(qg & 3) + e;
-    q.dst[i] = q.src[(size_t)k * q.ld_k + (size_t)j * q.ld_j];
+    q.dst[i] = (k < q.k_src && j < q.n_src) ? q.src[(size_t)k * q.ld_k + (size_t)j * q.ld_j] : 0.f;
   }
 }
 
@@ -786,6 +786,40 @@ __global__ __launch_bounds__(256) void self_attend_bwd_kernel(SelfAttBwdP p) {
     p.dw_part[(size_t)b * p.d + k] = q0 * sv.x;
     p.dw_part[(size_t)b * p.d + k + 1] = q1 * sv.y;
   }
+}
+
+// out[k][j] = sum_r x[r][k] g[r][j]  for a few dozen rows and any n: the classifier's weight gradients
+__global__ void outer_sum_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g, int ldg, int rows, int K, int J,
+                                 float* out) {
+  const size_t total = (size_t)K * J;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = i / J, j = i - (size_t)k * J;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc = fmaf(x[(size_t)r * ldx + k], g[(size_t)r * ldg + j], acc);
+    out[i] = acc;
+  }
+}
+
+// dst[r][j] = src[r][j] (j < n_src) else 0, row stride ld_dst   (pads [B, answers] to a multiple of 16 columns)
+__global__ void pad_cols_kernel(const float* __restrict__ src, int n_src, int rows, int ld_dst, float* dst) {
+  const int n = rows * ld_dst;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int r = i / ld_dst, j = i - r * ld_dst;
+    dst[i] = j < n_src ? src[(size_t)r * n_src + j] : 0.f;
+  }
+}
+// dst[r][j] = src[r*ld_src + j] for j < n   (the inverse crop)
+__global__ void crop_cols_kernel(const float* __restrict__ src, int ld_src, int rows, int n, float* dst) {
+  const int t = rows * n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t; i += gridDim.x * blockDim.x) {
+    const int r = i / n, j = i - r * n;
+    dst[i] = src[(size_t)r * ld_src + j];
+  }
+}
+
+__global__ void add_bias_kernel(const float* __restrict__ bias, int rows, int n, float* x) {
+  const int t = rows * n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t; i += gridDim.x * blockDim.x) x[i] += bias[i % n];
 }
 
 // dy[b][k] = sum over parts   (S_b kernel leaves 2*d/128 partials)

@@ -31,19 +31,14 @@ class GradBucket:
 
     def allreduce_(self, shard_size, global_size, group=None):
         """grads <- sum_r (shard_r / global) * grads_r  == gradient of the full-batch mean loss."""
-        off = 0
         w = float(shard_size) / float(global_size)
-        for t, n in zip(self.tensors, self.sizes):
-            g = t.grad if t.grad is not None else torch.zeros_like(t)
-            self.flat[off:off + n].copy_(g.reshape(-1))
-            off += n
+        grads = [(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in self.tensors]
+        torch.cat(grads, out=self.flat)                       # one gather kernel into the flat buffer
         self.flat.mul_(w)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         off = 0
-        for t, n in zip(self.tensors, self.sizes):
-            if t.grad is None:
-                t.grad = torch.empty_like(t)
-            t.grad.copy_(self.flat[off:off + n].view_as(t))
+        for t, n in zip(self.tensors, self.sizes):            # gradients become views of the reduced buffer
+            t.grad = self.flat[off:off + n].view_as(t)
             off += n
         return self.flat

@@ -1,0 +1,67 @@
+"""-m gpu: output unit + classifier (model.py:512-576) and the end-to-end parity bar of the task:
+classifier logits within 1e-4 (fp32) of the oracle and identical answer argmax."""
+import pytest
+import torch
+
+from oracle import dropout_hash as dh
+from oracle import mac_oracle as mo
+from helpers import make_case, oracle_run, rel_err, max_abs
+from test_gpu_cell import build_cell
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_logits(cfg, ref_params, memory, vq, keep, seed, b0=0, dtype=torch.float64, need_grad=False):
+    prm = {k: v.detach().cpu().to(dtype).clone().requires_grad_(need_grad) for k, v in ref_params.items()}
+    vs = mo.VarStore(params=prm, dtype=dtype)
+    B, d = memory.shape
+    masks = None
+    if keep < 1.0:
+        H = cfg.outClassifierDims[0]
+        masks = [torch.from_numpy(dh.mask_for(seed, 7, 0, keep, (B, 2 * d), b0=b0)).to(dtype),
+                 torch.from_numpy(dh.mask_for(seed, 8, 0, keep, (B, H), b0=b0)).to(dtype)]
+    return mo.output_classifier(cfg, vs, memory, vq, output_keep=keep, masks=masks), prm
+
+
+@pytest.mark.parametrize("B,d,H,A,train", [(64, 512, 512, 28, False), (64, 512, 512, 28, True), (5, 128, 64, 7, True), (3, 64, 32, 33, False)])
+def test_classifier_matches_oracle(macx, dev, B, d, H, A, train):
+    cfg = mo.flag_file_config("args", memDim=d, ctrlDim=d, attDim=d, outClassifierDims=[H], answerWordsNum=A)
+    out = macx.OutputClassifier(cfg, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        for f in ("outQuestion_b", "fc0_b", "fc1_b"):
+            getattr(out, f).copy_(torch.rand_like(getattr(out, f)) - 0.5)
+    g = torch.Generator().manual_seed(2)
+    mem = torch.randn(B, d, generator=g)
+    vq = torch.rand(B, d, generator=g) * 2 - 1
+    memd, vqd = mem.to(dev).requires_grad_(True), vq.to(dev).requires_grad_(True)
+    logits = out(memd, vqd, train=train, seed=9, b0=4)
+    dl = torch.randn(B, A, generator=g)
+    (logits * dl.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    keep = cfg.outputDropout if train else 1.0
+    mr, vr = mem.double().requires_grad_(True), vq.double().requires_grad_(True)
+    ref, prm = oracle_logits(cfg, out.to_reference_dict(), mr, vr, keep, 9, b0=4, need_grad=True)
+    (ref * dl.double()).sum().backward()
+    assert max_abs(logits, ref) < 2e-5
+    assert rel_err(memd.grad, mr.grad) < 1e-4 and rel_err(vqd.grad, vr.grad) < 1e-4
+    for f, name in macx.output.REF_NAMES.items():
+        assert rel_err(getattr(out, f).grad, prm[name].grad) < 1e-4, f
+
+
+def test_end_to_end_logits_and_argmax_p12(macx, dev):
+    """The task's parity bar: logits within 1e-4 of the fp32 oracle after p = 12 cell steps, argmax identical
+    (B=64, S=50, N=196, d=512, evaluation mode; oracle in fp32 AND fp64)."""
+    B, S, N, d, p, A = 64, 50, 196, 512, 12, 28
+    cfg, vq, words, lengths, kb = make_case("args", B, S, N, d, p)
+    cfg.answerWordsNum = A
+    cell, params, (vqd, wd, kbd) = build_cell(macx, dev, cfg, vq, words, lengths, kb, False)
+    out = macx.OutputClassifier(cfg, generator=torch.Generator().manual_seed(3)).to(dev)
+    with torch.no_grad():
+        state = cell.run()
+        logits = out(state.memory, vqd)
+    torch.cuda.synchronize()
+    for dtype, tol in ((torch.float32, 1e-4), (torch.float64, 1e-4)):
+        ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, dtype=dtype)
+        rl, _ = oracle_logits(cfg, out.to_reference_dict(), ref["memory"].detach(), vq.to(dtype), 1.0, 0, dtype=dtype)
+        assert max_abs(logits, rl) < tol, (dtype, max_abs(logits, rl))
+        assert torch.equal(logits.argmax(-1).cpu(), rl.argmax(-1))
