@@ -225,6 +225,16 @@ int macx_output_backward(const macx_out_shapes*, int act, float keep, uint32_t s
                          float* ws, size_t ws_floats, const float* d_logits, const macx_out_grads*,
                          float* d_memory, float* d_vecQuestions, void* stream);
 
+/* ---- optimizer step ---------------------------------------------------------- */
+/* addTrainingOp (model.py:639-669) over ONE flat fp32 buffer of n elements:
+ *   norm = ||g||_2 ; g *= clip / max(norm, clip)      tf.clip_by_global_norm, clip_norm <= 0 disables
+ *   Adam (tf.train.AdamOptimizer): m, v, p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+ *   ema -= (1 - decay) * (ema - p)                    tf.train.ExponentialMovingAverage, decay < 0 disables
+ * `step` is 1-based; `ws` >= 1024 floats; `norm_out` (device, may be NULL) receives the pre-clip norm. */
+int macx_adam_ema_step(size_t n, float* params, const float* grads, float* m, float* v, float* ema,
+                       float lr, float beta1, float beta2, float eps, int step, float clip_norm, float ema_decay,
+                       float* ws, float* norm_out, void* stream);
+
 /* ---- unit-level entry points (the ops.py primitives; used by the parity tests) -------------- */
 /* out[r, :] = act(concat(x1[r], x2[r]) @ W + b + bias_const)     ops.linear (ops.py:298-333)
  * on fp32 MFMA; `W_packed` from macx_pack_weight(W, k1 + k2, n_out, 0); k1, k2, n_out % 16 == 0. */

@@ -76,7 +76,7 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_saved_segment", "macx_cell_begin", "macx_cell_step", "macx_cell_forward", "macx_cell_backward",
            "macx_linear", "macx_pack_weight", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_wgrad_splits",
            "macx_wgrad", "macx_debug_set", "macx_output_saved_floats", "macx_output_ws_floats",
-           "macx_output_forward", "macx_output_backward")
+           "macx_output_forward", "macx_output_backward", "macx_adam_ema_step")
 
 _lib = None
 
@@ -127,6 +127,9 @@ def lib():
     L.macx_dropout_mask.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_void_p,
                                     C.c_void_p]
     L.macx_debug_set.argtypes = [C.c_int, C.c_int]
+    L.macx_adam_ema_step.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.macx_adam_ema_step.restype = C.c_int
     L.macx_output_saved_floats.restype = C.c_size_t
     L.macx_output_saved_floats.argtypes = [P(MacxOutShapes)]
     L.macx_output_ws_floats.restype = C.c_size_t
@@ -143,7 +146,7 @@ def lib():
         f = getattr(L, n)
         if f.restype is C.c_int or n in ("macx_check",):
             f.restype = C.c_int
-    for n in ("macx_output_forward", "macx_output_backward"):
+    for n in ("macx_output_forward", "macx_output_backward", "macx_adam_ema_step"):
         getattr(L, n).restype = C.c_int
     _lib = L
     return L

@@ -1205,6 +1205,29 @@ int macx_output_backward(const macx_out_shapes* s, int act, float keep, uint32_t
   return MACX_OK;
 }
 
+// =================================================================================================
+// optimizer step (model.py:615-669): SURVEY 8f row 3
+// =================================================================================================
+int macx_adam_ema_step(size_t n, float* params, const float* grads, float* m, float* v, float* ema, float lr, float beta1,
+                       float beta2, float eps, int step, float clip_norm, float ema_decay, float* ws, float* norm_out,
+                       void* stream) {
+  if (!params || !grads || !m || !v || !ws || n == 0 || step < 1) return MACX_EINVAL;
+  if (ema_decay >= 0.f && !ema) return MACX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > OPT_BLOCKS) blocks = OPT_BLOCKS;
+  hipLaunchKernelGGL(opt_sumsq_kernel, dim3(blocks), dim3(256), 0, st, grads, n, ws);
+  OptP q;
+  q.n = n; q.p = params; q.g = grads; q.m = m; q.v = v; q.ema = ema;
+  // tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+  q.lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step)));
+  q.beta1 = beta1; q.beta2 = beta2; q.eps = eps; q.clip = clip_norm; q.ema_decay = ema_decay;
+  q.part = ws; q.nparts = blocks; q.norm_out = norm_out;
+  hipLaunchKernelGGL(opt_apply_kernel, dim3(blocks), dim3(256), 0, st, q);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
 /* test/tuning hook: key 0 = waves per workgroup of the kb GEMM (4 or 8) */
 int macx_debug_set(int key, int value) {
   if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }

@@ -274,8 +274,29 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   if (EP == E_DKB) drj = *reinterpret_cast<const f32x4*>(p.aux + (size_t)b * p.ld_aux + col);
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   const int wpr = p.Nout >> 5;   // mask words per output row
-#pragma unroll 1
-  for (int lrow = rg; lrow < ROWS; lrow += RG) {
+  // every global operand the epilogue needs (activation outputs for act', the running dKB, mask words,
+  // attention weights) is requested for ALL of this thread's rows before the first one is used: RT
+  // independent loads in flight instead of RT serial round trips
+  f32x4 auxv[RT];
+  uint32_t bitv[RT];
+  float attv[RT];
+  if (EP == E_MUL_DACT || EP == E_DKB || EP == E_I2_LOGIT) {
+#pragma unroll
+    for (int it = 0; it < RT; ++it) {
+      const int n = row0 + rg + it * RG;
+      const size_t orow = (size_t)b * p.N + min(n, p.N - 1);
+      if (EP == E_MUL_DACT) auxv[it] = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + col);
+      if (EP == E_DKB) {
+        auxv[it] = p.accumulate ? *reinterpret_cast<const f32x4*>(p.out + orow * p.ldo + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        attv[it] = p.att[orow];
+        bitv[it] = p.e_bits ? p.e_bits[orow * (p.ldo >> 5) + (col >> 5)] >> (col & 31) : 0xFu;
+      }
+      if (EP == E_I2_LOGIT) bitv[it] = p.e_bits ? p.e_bits[orow * wpr + (col >> 5)] >> (col & 31) : 0xFu;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < RT; ++it) {
+    const int lrow = rg + it * RG;
     const int n = row0 + lrow;
     const bool ok = n < p.N;
     const size_t orow = (size_t)b * p.N + (ok ? n : p.N - 1);
@@ -289,8 +310,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
       val += bias4;
       if (ok) *reinterpret_cast<f32x4*>(optr) = val;
       // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w   (bias b_k added in kb_attend)
-      uint32_t bits = 0xFu;
-      if (p.e_bits) bits = p.e_bits[orow * wpr + (col >> 5)] >> (col & 31);
+      const uint32_t bits = bitv[it];
       float part = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -303,22 +323,19 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
       for (int o = CG / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
       if (c4 == 0 && ok) p.logit_part[(size_t)cb * p.B * p.N + orow] = part;
     } else if (EP == E_MUL_DACT) {
-      const f32x4 h = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + col);
+      const f32x4 h = auxv[it];
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] *= act_grad_from_out(p.act, h[e]);
       if (ok) *reinterpret_cast<f32x4*>(optr) = val;
     } else if (EP == E_PLAIN) {
       if (ok) *reinterpret_cast<f32x4*>(optr) = val;
     } else if (EP == E_DKB) {
-      uint32_t bits = 0xFu;
-      if (p.e_bits) bits = p.e_bits[orow * (p.ldo >> 5) + (col >> 5)] >> (col & 31);
-      const float a = p.att[orow];
+      const uint32_t bits = bitv[it];
+      const float a = attv[it];
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = (((bits >> e) & 1u) ? val[e] * p.e_inv_keep : 0.f) + a * drj[e];
-      if (ok) {
-        if (p.accumulate) val += *reinterpret_cast<const f32x4*>(optr);
-        *reinterpret_cast<f32x4*>(optr) = val;
-      }
+      val += auxv[it];
+      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
     }
     if (COLSUM && ok) csum += val;
   }

@@ -822,6 +822,49 @@ __global__ void add_bias_kernel(const float* __restrict__ bias, int rows, int n,
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t; i += gridDim.x * blockDim.x) x[i] += bias[i % n];
 }
 
+// ---------------------------------------------------------------------------------------------
+// optimizer step over one flat fp32 buffer (model.py:615-669): global-norm clip -> Adam -> EMA.
+// Two launches: per-workgroup partial sums of g^2, then every workgroup folds the (<= 1024) partials in
+// a fixed order and updates its slice.  HBM-bound: reads g, p, m, v, ema and writes p, m, v, ema once.
+// ---------------------------------------------------------------------------------------------
+constexpr int OPT_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void opt_sumsq_kernel(const float* __restrict__ g, size_t n, float* part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+struct OptP {
+  size_t n;
+  float* p; const float* g; float* m; float* v; float* ema;
+  float lr_t, beta1, beta2, eps, clip, ema_decay;   // lr_t already holds sqrt(1-b2^t)/(1-b1^t); clip <= 0: off; ema_decay < 0: off
+  const float* part; int nparts;
+  float* norm_out;                                   // [1] global gradient norm (before clipping)
+};
+__global__ __launch_bounds__(256) void opt_apply_kernel(OptP q) {
+  __shared__ float s_norm;
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < q.nparts; ++i) t += q.part[i];
+    s_norm = sqrtf(t);
+    if (blockIdx.x == 0 && q.norm_out) q.norm_out[0] = s_norm;
+  }
+  __syncthreads();
+  // tf.clip_by_global_norm: g * clip / max(norm, clip)
+  const float scale = q.clip > 0.f ? q.clip / fmaxf(s_norm, q.clip) : 1.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < q.n; i += (size_t)gridDim.x * 256) {
+    const float g = q.g[i] * scale;
+    const float m = q.beta1 * q.m[i] + (1.0f - q.beta1) * g;
+    const float v = q.beta2 * q.v[i] + (1.0f - q.beta2) * g * g;
+    const float p = q.p[i] - q.lr_t * m / (sqrtf(v) + q.eps);
+    q.m[i] = m; q.v[i] = v; q.p[i] = p;
+    if (q.ema_decay >= 0.f) q.ema[i] = q.ema[i] - (1.0f - q.ema_decay) * (q.ema[i] - p);   // tf.train.ExponentialMovingAverage
+  }
+}
+
 // dy[b][k] = sum over parts   (S_b kernel leaves 2*d/128 partials)
 __global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, size_t n, float* dst) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

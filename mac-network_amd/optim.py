@@ -1,0 +1,60 @@
+"""Training step of the reference (model.py:615-669): tf.clip_by_global_norm(8) -> tf.train.AdamOptimizer
+-> tf.train.ExponentialMovingAverage(0.999), as ONE multi-tensor HIP pass over a flat fp32 buffer.
+
+The parameters are re-pointed at slices of one flat tensor; gradients are gathered into (or, after
+macx.dp.GradBucket.allreduce_, already live in) one flat tensor; Adam moments and the EMA shadow are flat
+buffers too.  SURVEY.md 8f row 3."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class FlatAdamEMA:
+    def __init__(self, params, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, clip_norm=8.0, ema_decay=0.999):
+        self.params = [p for p in params]
+        if not self.params or not self.params[0].is_cuda:
+            raise RuntimeError("FlatAdamEMA needs parameters on the HIP device")
+        self.sizes = [p.numel() for p in self.params]
+        n = sum(self.sizes)
+        dev = self.params[0].device
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p, k in zip(self.params, self.sizes):          # parameters become views of the flat buffer
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p.data)
+            off += k
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.ema = self.flat.clone() if ema_decay is not None and ema_decay >= 0 else None   # shadow starts at the initial value
+        self.ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        self.clip_norm = clip_norm if clip_norm else 0.0
+        self.ema_decay = ema_decay if self.ema is not None else -1.0
+        self.t = 0
+
+    def step(self, flat_grad=None):
+        """flat_grad: an already flat gradient (e.g. GradBucket.flat after the all-reduce); otherwise the
+        .grad of every parameter is gathered with one torch.cat."""
+        if flat_grad is None:
+            torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params], out=self.grad)
+            flat_grad = self.grad
+        self.t += 1
+        L = _lib.lib()
+        dev = self.flat.device
+        p_ = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        _lib.check(L.macx_adam_ema_step(self.flat.numel(), p_(self.flat), p_(flat_grad), p_(self.m), p_(self.v), p_(self.ema), self.lr,
+                                        self.beta1, self.beta2, self.eps, self.t, self.clip_norm, self.ema_decay, p_(self.ws),
+                                        p_(self.norm), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "macx_adam_ema_step")
+        return self.norm
+
+    def ema_state(self):
+        """{index: tensor} views of the EMA shadow, shaped like the parameters (what emaSaver restores, main.py:711-729)."""
+        out, off = [], 0
+        for p, k in zip(self.params, self.sizes):
+            out.append(self.ema[off:off + k].view_as(p))
+            off += k
+        return out

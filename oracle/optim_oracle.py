@@ -1,0 +1,19 @@
+"""TEST INFRASTRUCTURE.  fp64 restatement of the reference's training op (model.py:639-669):
+tf.clip_by_global_norm -> tf.train.AdamOptimizer (TF1 formulation with lr_t and epsilon-hat) ->
+tf.train.ExponentialMovingAverage.  PARITY UNPINNED (written from the TF1 documentation of those ops)."""
+import numpy as np
+
+
+def adam_ema_step(p, g, m, v, ema, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, clip=8.0, decay=0.999):
+    p, g, m, v = [np.asarray(x, dtype=np.float64) for x in (p, g, m, v)]
+    norm = np.sqrt((g * g).sum())
+    if clip and clip > 0:
+        g = g * clip / max(norm, clip)
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    lr_t = lr * np.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
+    p = p - lr_t * m / (np.sqrt(v) + eps)
+    if ema is not None:
+        ema = np.asarray(ema, dtype=np.float64)
+        ema = ema - (1 - decay) * (ema - p)
+    return p, m, v, ema, norm

@@ -65,3 +65,29 @@ def test_end_to_end_logits_and_argmax_p12(macx, dev):
         rl, _ = oracle_logits(cfg, out.to_reference_dict(), ref["memory"].detach(), vq.to(dtype), 1.0, 0, dtype=dtype)
         assert max_abs(logits, rl) < tol, (dtype, max_abs(logits, rl))
         assert torch.equal(logits.argmax(-1).cpu(), rl.argmax(-1))
+
+
+@pytest.mark.parametrize("clip", [8.0, 0.0])
+def test_adam_ema_step_matches_oracle(macx, dev, clip):
+    """model.py:639-669 over a flat buffer: 4 steps, clip active (large grads) and inactive."""
+    from oracle import optim_oracle as oo
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(sh, generator=g).to(dev)) for sh in [(300, 70), (513,), (64, 64), (1,)]]
+    ref_p = torch.cat([p.detach().cpu().double().reshape(-1) for p in ps]).numpy()
+    opt = macx.optim.FlatAdamEMA(ps, lr=1e-3, clip_norm=clip, ema_decay=0.999)
+    ref_m = ref_p * 0; ref_v = ref_p * 0; ref_e = ref_p.copy()
+    for t in range(1, 5):
+        scale = 20.0 if t % 2 else 0.01          # alternate above / below the clip threshold
+        grads = [torch.randn(p.shape, generator=g) * scale for p in ps]
+        for p, gr in zip(ps, grads):
+            p.grad = gr.to(dev)
+        norm = opt.step()
+        gflat = torch.cat([gr.double().reshape(-1) for gr in grads]).numpy()
+        ref_p, ref_m, ref_v, ref_e, ref_norm = oo.adam_ema_step(ref_p, gflat, ref_m, ref_v, ref_e, 1e-3, t, clip=clip)
+        torch.cuda.synchronize()
+        assert abs(float(norm) - ref_norm) < 1e-4 * ref_norm
+        got = torch.cat([p.detach().cpu().double().reshape(-1) for p in ps]).numpy()
+        assert abs(got - ref_p).max() < 2e-6
+        assert abs(opt.ema.cpu().double().numpy() - ref_e).max() < 2e-6
+    # parameters are views of the flat buffer
+    assert ps[0].data_ptr() == opt.flat.data_ptr()
