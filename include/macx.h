@@ -225,6 +225,24 @@ int macx_output_backward(const macx_out_shapes*, int act, float keep, uint32_t s
                          float* ws, size_t ws_floats, const float* d_logits, const macx_out_grads*,
                          float* d_memory, float* d_vecQuestions, void* stream);
 
+/* ---- stem CNN (producer of the knowledge base) -------------------------------- */
+/* MACnet.stem (model.py:165-204) -> ops.CNNLayer / ops.cnn (ops.py:380-438) for the default
+ * stemNumLayers = 2, stemKernelSize = 3, stride 1, no batch norm:
+ *   KB = act(conv3x3_SAME(dropout(act(conv3x3_SAME(dropout(images), K0) + b0)), K1) + b1)
+ * images [B, H*W, Cin] NHWC (config.imageDims = 14 x 14 x 1024), KB [B, H*W, Cout] (model.py:202).
+ * Variables: stem/cnnLayercnn_{0,1}/kernels/kernel [3,3,in,out] (HWIO), .../biases/bias [out].
+ * Cin, Cmid, Cout multiples of 128.  No gradient is returned for `images` (pre-extracted features). */
+typedef struct macx_stem_shapes { int32_t B, H, W, Cin, Cmid, Cout, b0; } macx_stem_shapes;
+typedef struct macx_stem_params { const float* kernel0; const float* bias0; const float* kernel1; const float* bias1; } macx_stem_params;
+typedef struct macx_stem_grads { float* kernel0; float* bias0; float* kernel1; float* bias1; } macx_stem_grads;
+size_t macx_stem_saved_floats(const macx_stem_shapes*);
+size_t macx_stem_ws_floats(const macx_stem_shapes*);
+int macx_stem_forward(const macx_stem_shapes*, int act, float keep, uint32_t seed, const macx_stem_params*,
+                      const float* images, float* kb, float* saved, size_t saved_floats, void* stream);
+int macx_stem_backward(const macx_stem_shapes*, int act, float keep, uint32_t seed, const macx_stem_params*,
+                       const float* kb, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                       const float* d_kb, const macx_stem_grads*, void* stream);
+
 /* ---- optimizer step ---------------------------------------------------------- */
 /* addTrainingOp (model.py:639-669) over ONE flat fp32 buffer of n elements:
  *   norm = ||g||_2 ; g *= clip / max(norm, clip)      tf.clip_by_global_norm, clip_norm <= 0 disables

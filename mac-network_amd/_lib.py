@@ -63,6 +63,21 @@ class MacxOutGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
 
 
+class MacxStemShapes(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cmid", "Cout", "b0")]
+
+
+STEM_FIELDS = ("kernel0", "bias0", "kernel1", "bias1")
+
+
+class MacxStemParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in STEM_FIELDS]
+
+
+class MacxStemGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in STEM_FIELDS]
+
+
 class MacxInputs(C.Structure):
     _fields_ = [("vecQuestions", C.c_void_p), ("words", C.c_void_p), ("questionLengths", C.c_void_p),
                 ("knowledgeBase", C.c_void_p)]
@@ -76,7 +91,8 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_saved_segment", "macx_cell_begin", "macx_cell_step", "macx_cell_forward", "macx_cell_backward",
            "macx_linear", "macx_pack_weight", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_wgrad_splits",
            "macx_wgrad", "macx_debug_set", "macx_output_saved_floats", "macx_output_ws_floats",
-           "macx_output_forward", "macx_output_backward", "macx_adam_ema_step")
+           "macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
+           "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward")
 
 _lib = None
 
@@ -130,6 +146,16 @@ def lib():
     L.macx_adam_ema_step.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.macx_adam_ema_step.restype = C.c_int
+    L.macx_stem_saved_floats.restype = C.c_size_t
+    L.macx_stem_saved_floats.argtypes = [P(MacxStemShapes)]
+    L.macx_stem_ws_floats.restype = C.c_size_t
+    L.macx_stem_ws_floats.argtypes = [P(MacxStemShapes)]
+    L.macx_stem_forward.restype = C.c_int
+    L.macx_stem_forward.argtypes = [P(MacxStemShapes), C.c_int, C.c_float, C.c_uint32, P(MacxStemParams), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]
+    L.macx_stem_backward.restype = C.c_int
+    L.macx_stem_backward.argtypes = [P(MacxStemShapes), C.c_int, C.c_float, C.c_uint32, P(MacxStemParams), C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, P(MacxStemGrads), C.c_void_p]
     L.macx_output_saved_floats.restype = C.c_size_t
     L.macx_output_saved_floats.argtypes = [P(MacxOutShapes)]
     L.macx_output_ws_floats.restype = C.c_size_t
@@ -146,7 +172,8 @@ def lib():
         f = getattr(L, n)
         if f.restype is C.c_int or n in ("macx_check",):
             f.restype = C.c_int
-    for n in ("macx_output_forward", "macx_output_backward", "macx_adam_ema_step"):
+    for n in ("macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
+           "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward"):
         getattr(L, n).restype = C.c_int
     _lib = L
     return L

@@ -1206,6 +1206,173 @@ int macx_output_backward(const macx_out_shapes* s, int act, float keep, uint32_t
 }
 
 // =================================================================================================
+// stem CNN (model.py:165-204, ops.CNNLayer ops.py:380-438): SURVEY 8f row 1.  Two 3x3 SAME
+// convolutions as implicit GEMMs on the knowledge-base GEMM kernel (K = 9 * C_in, per-image tiles).
+// =================================================================================================
+namespace {
+struct StemLayout {
+  size_t k0_p, k1_p;     // packed HWIO kernels [9*Cin][Cmid], [9*Cmid][Cout]
+  size_t in0p;           // [B][Np][Cin]   dropped, halo-padded image features
+  size_t X1;             // [B][N][Cmid]   act(conv0)
+  size_t in1p;           // [B][Np][Cmid]  dropped, halo-padded X1
+  size_t bits1;          // [B*N*Cmid/32]  keep bits of the layer-1 input dropout
+  size_t total;
+};
+struct StemGeo { int N, wp, np; };
+inline StemGeo stem_geo(const macx_stem_shapes* s) { return StemGeo{s->H * s->W, s->W + 2, (s->H + 2) * (s->W + 2)}; }
+StemLayout make_stem(const macx_stem_shapes* s) {
+  StemLayout L;
+  memset(&L, 0, sizeof(L));
+  const StemGeo g = stem_geo(s);
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
+  const size_t B = s->B, Ci = s->Cin, Cm = s->Cmid, Co = s->Cout;
+  L.k0_p = take(9 * Ci * Cm); L.k1_p = take(9 * Cm * Co);
+  L.in0p = take(B * g.np * Ci); L.X1 = take(B * g.N * Cm); L.in1p = take(B * g.np * Cm);
+  L.bits1 = take(B * g.N * Cm / 32 + 8);
+  L.total = off;
+  return L;
+}
+inline int conv_splits(int tiles, int M) {
+  // fill whole rounds of 256 workgroups; fewest splits among the best fillings
+  int best = 1; double beff = 0.0;
+  for (int ns = 1; ns <= 16; ++ns) {
+    if ((M + ns - 1) / ns < 256) break;
+    const int blocks = tiles * ns;
+    const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+    if (eff > beff + 0.02) { beff = eff; best = ns; }
+  }
+  return best;
+}
+struct StemBwdLayout {
+  size_t k1T_p;          // packed backward-data weights [9*Cout][Cmid]
+  size_t dY2, dY2p, dY1; // [B][N][Cout], [B][Np][Cout], [B][N][Cmid]
+  size_t slab0, slab1;   // weight-gradient partial slabs
+  int ns0, ns1;
+  size_t total;
+};
+StemBwdLayout make_stem_bwd(const macx_stem_shapes* s) {
+  StemBwdLayout L;
+  memset(&L, 0, sizeof(L));
+  const StemGeo g = stem_geo(s);
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
+  const size_t B = s->B, Ci = s->Cin, Cm = s->Cmid, Co = s->Cout;
+  L.k1T_p = take(9 * Co * Cm);
+  L.dY2 = take(B * g.N * Co); L.dY2p = take(B * g.np * Co); L.dY1 = take(B * g.N * Cm);
+  L.ns0 = conv_splits((int)(9 * Ci / T_TILE * (Cm / T_TILE)), (int)(B * g.N));
+  L.ns1 = conv_splits((int)(9 * Cm / T_TILE * (Co / T_TILE)), (int)(B * g.N));
+  L.slab0 = take((size_t)L.ns0 * 9 * Ci * Cm);
+  L.slab1 = take((size_t)L.ns1 * 9 * Cm * Co);
+  L.total = off;
+  return L;
+}
+int stem_check(const macx_stem_shapes* s) {
+  if (!s || s->B < 1 || s->H < 1 || s->W < 2) return MACX_EINVAL;
+  if (s->Cin % 128 || s->Cmid % 128 || s->Cout % 128 || s->Cin < 128 || s->Cmid < 128 || s->Cout < 128) return MACX_EINVAL;
+  if (s->H * s->W > K_MAXN) return MACX_EINVAL;
+  if ((size_t)(s->b0 + s->B) * s->H * s->W * (size_t)(s->Cin > s->Cmid ? s->Cin : s->Cmid) >= (1ull << 32)) return MACX_EINVAL;
+  return MACX_OK;
+}
+hipError_t launch_pad_drop(const float* src, const PadP& q, float keep, uint32_t seed, uint32_t site, uint32_t first, float* dst,
+                           uint32_t* bits, hipStream_t st) {
+  const DropSpec ds = make_drop(keep, seed, site, 0);
+  hipLaunchKernelGGL(pad_drop_kernel, dim3(2048), dim3(256), 0, st, src, q, ds.key, ds.thr24, ds.inv_keep, first, dst, bits);
+  return hipGetLastError();
+}
+void conv_gemm_params(GemmP& g, const macx_stem_shapes* s, const StemGeo& geo, const float* Apad, int cin, int nout, int sign) {
+  memset(&g, 0, sizeof(g));
+  g.B = s->B; g.N = geo.N; g.K = 9 * cin; g.Nout = nout;
+  g.A = Apad; g.lda = cin; g.a_qstride = (size_t)geo.np * cin;
+  g.conv_taps = 9; g.conv_w = s->W; g.conv_wp = geo.wp; g.conv_cin = cin; g.conv_sign = sign;
+  g.ldo = nout; g.e_inv_keep = 1.0f;
+}
+int conv_wgrad(const macx_stem_shapes* s, const StemGeo& geo, const float* Apad, int cin, const float* G, int cout, int ns, float* slab,
+               float* out, hipStream_t st) {
+  TnP t;
+  memset(&t, 0, sizeof(t));
+  t.M = s->B * geo.N; t.Kd = 9 * cin; t.Jd = cout; t.nsplit = ns; t.rows_per_split = rows_per_split(t.M, ns);
+  t.A = Apad; t.lda = cin; t.a_mod = t.M; t.G = G; t.ldg = cout;
+  t.conv_taps = 9; t.conv_w = s->W; t.conv_wp = geo.wp; t.conv_cin = cin; t.conv_n = geo.N; t.conv_np = geo.np;
+  t.magic_n = (uint32_t)(((1ull << 32) + geo.N - 1) / geo.N);
+  t.magic_w = (uint32_t)(((1ull << 32) + s->W - 1) / s->W);
+  t.part = (ns == 1) ? out : slab;
+  CK(wgrad_tn_launch<A_PLAIN>(t, st));
+  if (ns > 1) CK(slab_reduce_launch(slab, ns, (size_t)t.Kd * t.Jd, out, 0, st));
+  return 0;
+}
+}  // namespace
+
+size_t macx_stem_saved_floats(const macx_stem_shapes* s) { return stem_check(s) ? 0 : make_stem(s).total; }
+size_t macx_stem_ws_floats(const macx_stem_shapes* s) { return stem_check(s) ? 0 : make_stem_bwd(s).total; }
+
+int macx_stem_forward(const macx_stem_shapes* s, int act, float keep, uint32_t seed, const macx_stem_params* P, const float* images,
+                      float* kb, float* saved, size_t saved_floats, void* stream) {
+  CKI(stem_check(s));
+  if (!P || !images || !kb || !saved || misaligned(images) || misaligned(kb) || misaligned(saved)) return MACX_EINVAL;
+  const StemLayout L = make_stem(s);
+  if (saved_floats < L.total) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const StemGeo geo = stem_geo(s);
+  const int Ci = s->Cin, Cm = s->Cmid, Co = s->Cout;
+  Packer pk;
+  pk.add(P->kernel0, Cm, 1, 9 * Ci, Cm, saved + L.k0_p);     // HWIO flattened = [9*Cin][Cmid] row-major
+  pk.add(P->kernel1, Co, 1, 9 * Cm, Co, saved + L.k1_p);
+  CK(pk.run(st));
+  PadP q0{s->B, geo.N, s->W, geo.wp, geo.np, Ci};
+  PadP q1{s->B, geo.N, s->W, geo.wp, geo.np, Cm};
+  // cnn_0: dropout -> conv3x3 SAME -> + b -> act   (ops.py:400-411)
+  CK(launch_pad_drop(images, q0, keep, seed, SITE_STEM0, (uint32_t)((size_t)s->b0 * geo.N * Ci), saved + L.in0p, nullptr, st));
+  GemmP g;
+  conv_gemm_params(g, s, geo, saved + L.in0p, Ci, Cm, +1);
+  g.Wp = saved + L.k0_p; g.out = saved + L.X1; g.bias = P->bias0; g.act = act;
+  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  // cnn_1
+  CK(launch_pad_drop(saved + L.X1, q1, keep, seed, SITE_STEM1, (uint32_t)((size_t)s->b0 * geo.N * Cm), saved + L.in1p,
+                     reinterpret_cast<uint32_t*>(saved + L.bits1), st));
+  conv_gemm_params(g, s, geo, saved + L.in1p, Cm, Co, +1);
+  g.Wp = saved + L.k1_p; g.out = kb; g.bias = P->bias1; g.act = act;
+  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  return MACX_OK;
+}
+
+int macx_stem_backward(const macx_stem_shapes* s, int act, float keep, uint32_t seed, const macx_stem_params* P, const float* kb,
+                       const float* saved, size_t saved_floats, float* ws, size_t ws_floats, const float* d_kb,
+                       const macx_stem_grads* G, void* stream) {
+  CKI(stem_check(s));
+  if (!P || !kb || !saved || !ws || !d_kb || !G) return MACX_EINVAL;
+  const StemLayout L = make_stem(s);
+  const StemBwdLayout W = make_stem_bwd(s);
+  if (saved_floats < L.total || ws_floats < W.total) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const StemGeo geo = stem_geo(s);
+  const int Ci = s->Cin, Cm = s->Cmid, Co = s->Cout, M = s->B * geo.N;
+  (void)seed;
+  // backward-data weights of cnn_1: B[(tap, co)][ci] = K1[tap][ci][co]
+  {
+    Packer pk;
+    for (int tap = 0; tap < 9; ++tap)
+      pk.add(P->kernel1 + (size_t)tap * Cm * Co, 1, Co, Co, Cm, ws + W.k1T_p + (size_t)tap * Co * Cm);
+    CK(pk.run(st));
+  }
+  // dY2 = d_kb * act'(kb)
+  PadP q2{s->B, geo.N, s->W, geo.wp, geo.np, Co};
+  hipLaunchKernelGGL(pad_mul_actgrad_kernel, dim3(2048), dim3(256), 0, st, d_kb, kb, act, q2, ws + W.dY2, ws + W.dY2p);
+  CK(hipGetLastError());
+  CK(rowsum(ws + W.dY2, M, Co, Co, G->bias1, st));
+  CKI(conv_wgrad(s, geo, saved + L.in1p, Cm, ws + W.dY2, Co, W.ns1, ws + W.slab1, G->kernel1, st));
+  // dY1 = convT(dY2) * dropmask1 * act'(X1): gather with the opposite tap offsets
+  GemmP g;
+  conv_gemm_params(g, s, geo, ws + W.dY2p, Co, Cm, -1);
+  g.Wp = ws + W.k1T_p; g.out = ws + W.dY1; g.aux = saved + L.X1; g.act = act;
+  if (keep < 1.0f) { g.e_bits = reinterpret_cast<const uint32_t*>(saved + L.bits1); g.e_inv_keep = 1.0f / keep; }
+  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_MUL_DACT, false>(g, st)));
+  CK(rowsum(ws + W.dY1, M, Cm, Cm, G->bias0, st));
+  CKI(conv_wgrad(s, geo, saved + L.in0p, Ci, ws + W.dY1, Cm, W.ns0, ws + W.slab0, G->kernel0, st));
+  return MACX_OK;
+}
+
+// =================================================================================================
 // optimizer step (model.py:615-669): SURVEY 8f row 3
 // =================================================================================================
 int macx_adam_ema_step(size_t n, float* params, const float* grads, float* m, float* v, float* ema, float lr, float beta1,

@@ -51,7 +51,9 @@ enum : uint32_t {
   SITE_READ_ATT = 5,  // ops.py:312 via :142  dropout on the interactions before the d->1 logits
   SITE_WRITE_INFO = 6, // mac_cell.py:463  dropout on the retrieved information
   SITE_OUT_FC0 = 7,   // ops.py:312 via FCLayer (ops.py:349-359): dropout on the classifier's first layer input
-  SITE_OUT_FC1 = 8    // ... and on its second layer input
+  SITE_OUT_FC1 = 8,   // ... and on its second layer input
+  SITE_STEM0 = 9,     // ops.py:400  dropout on the input of stem conv layer 0 (the image features)
+  SITE_STEM1 = 10     // ... and of stem conv layer 1
 };
 
 struct DropSpec {

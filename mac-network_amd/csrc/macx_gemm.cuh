@@ -56,6 +56,11 @@ struct GemmP {
   int lda;
   const uint32_t* a_bits; // A_DROP: keep bits of A, [B*N][lda/32]
   float a_inv_keep;
+  // implicit-GEMM 3x3 convolution over a halo-padded NHWC image (stem CNN, ops.py:380-438): output
+  // pixel n = (y, x) of a conv_w-wide image reads padded row (y+1)*conv_wp + (x+1) + tap offset, the
+  // reduction index is (tap, channel): K = conv_taps * conv_cin.  conv_taps == 0: plain GEMM.
+  int conv_taps, conv_w, conv_wp, conv_cin, conv_sign;
+  size_t a_qstride;       // floats between consecutive questions/images in A (0: N * lda)
   // weights
   const float* Wp;        // packed
   const float* Wp2;       // packed second weight (B_YMIX_*)
@@ -149,7 +154,8 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   f32x4 rw[B_IT];
   f32x4 rw2[B_IT];
 
-  const float* Abase = p.A + (size_t)b * p.N * p.lda;
+  const bool conv = p.conv_taps > 0;
+  const float* Abase = p.A + (size_t)b * (p.a_qstride ? p.a_qstride : (size_t)p.N * p.lda);
   const uint32_t* Bitbase = (AP == A_DROP) ? p.a_bits + (size_t)b * p.N * (p.lda >> 5) : nullptr;
   // per-thread staging coordinates (k-invariant)
   int a_off[A_IT];        // float offset of this thread's float4 in A (row clamped into the question)
@@ -162,15 +168,23 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
     a_ok[i] = (f < A_F4) && (n < p.N);
     const int nc = min(n, p.N - 1);
     a_row[i] = nc;
-    a_off[i] = nc * p.lda + (f & 7) * 4;
+    const int srow = conv ? (nc / p.conv_w + 1) * p.conv_wp + (nc % p.conv_w) + 1 : nc;
+    a_off[i] = srow * p.lda + (f & 7) * 4;
   }
   float ycol = 0.f;
   if (BP == B_YMIX_COL) ycol = p.y[(size_t)b * p.ldy + cb * G_BN + (tid % G_BN)];
 
   auto load_tiles = [&](int kt) {
+    int koff = kt * G_BK;
+    if (conv) {   // slice kt = 32 channels of one tap: a row shift inside the padded image
+      const int per = p.conv_cin >> 5;
+      const int tap = kt / per;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      koff = p.conv_sign * (dy * p.conv_wp + dx) * p.lda + ((kt - tap * per) << 5);
+    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      ra[i] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + kt * G_BK);
+      ra[i] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff);
       if (AP == A_DROP) rbits[i] = Bitbase[a_row[i] * (p.lda >> 5) + kt];
     }
 #pragma unroll
@@ -285,7 +299,10 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
     for (int it = 0; it < RT; ++it) {
       const int n = row0 + rg + it * RG;
       const size_t orow = (size_t)b * p.N + min(n, p.N - 1);
-      if (EP == E_MUL_DACT) auxv[it] = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + col);
+      if (EP == E_MUL_DACT) {
+        auxv[it] = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + col);
+        bitv[it] = p.e_bits ? p.e_bits[orow * wpr + (col >> 5)] >> (col & 31) : 0xFu;
+      }
       if (EP == E_DKB) {
         auxv[it] = p.accumulate ? *reinterpret_cast<const f32x4*>(p.out + orow * p.ldo + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         attv[it] = p.att[orow];
@@ -324,8 +341,10 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
       if (c4 == 0 && ok) p.logit_part[(size_t)cb * p.B * p.N + orow] = part;
     } else if (EP == E_MUL_DACT) {
       const f32x4 h = auxv[it];
+      const uint32_t bits = bitv[it];      // optional dropout mask of the tensor this gradient flows into
+      const float ik = p.e_bits ? p.e_inv_keep : 1.0f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) val[e] *= act_grad_from_out(p.act, h[e]);
+      for (int e = 0; e < 4; ++e) val[e] *= ((bits >> e) & 1u) ? act_grad_from_out(p.act, h[e]) * ik : 0.f;
       if (ok) *reinterpret_cast<f32x4*>(optr) = val;
     } else if (EP == E_PLAIN) {
       if (ok) *reinterpret_cast<f32x4*>(optr) = val;

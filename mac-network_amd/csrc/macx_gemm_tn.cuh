@@ -25,6 +25,11 @@ struct TnP {
   int a_mod;             // A row of reduction row m is (m % a_mod): the same KB under p different masks
   const float* G; int ldg;
   float* part;           // [nsplit][Kd][Jd]
+  // kernel gradient of a 3x3 convolution over a halo-padded NHWC input (stem CNN): reduction row
+  // m = (image, pixel n) reads padded input row  image*conv_np + (y+1)*conv_wp + (x+1) + tap offset;
+  // output row k = tap * conv_cin + channel  (HWIO order).  conv_taps == 0: plain contraction.
+  int conv_taps, conv_w, conv_wp, conv_cin, conv_n, conv_np;
+  uint32_t magic_n, magic_w;   // ceil(2^32 / conv_n), ceil(2^32 / conv_w)
 };
 
 // 8 waves: waves 0-3 and 4-7 each cover the 128x128 tile as 2x2 sub-tiles of 64x64 and take
@@ -64,6 +69,13 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
 
+  int conv_shift = 0, a_col0 = tk * T_TILE;
+  if (p.conv_taps) {
+    const int per = p.conv_cin / T_TILE;
+    const int tap = tk / per;
+    conv_shift = (tap / 3 - 1) * p.conv_wp + (tap - (tap / 3) * 3 - 1);
+    a_col0 = (tk - tap * per) * T_TILE;
+  }
   // DMA slots: a stage holds 32 rows x 32 float4 per operand = 1024 slots; 512 threads -> 2 + 2 per stage
   auto dma_stage = [&](int buf, int ch) {
 #pragma unroll
@@ -72,7 +84,16 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnP p) {
       const int f = f0 + lane;
       const int m = min(m_begin + ch * T_BM + (f >> 5), p.M - 1);   // rows past the end are clamped, never multiplied
       const int c4 = (f & 31) * 4;
-      dma16(p.A + (size_t)(m % p.a_mod) * p.lda + tk * T_TILE + c4, sA + buf * T_STAGE + f0 * 4);
+      size_t arow;
+      if (p.conv_taps) {
+        const int img = (int)__umulhi((uint32_t)m, p.magic_n);
+        const int n = m - img * p.conv_n;
+        const int yy = (int)__umulhi((uint32_t)n, p.magic_w);
+        arow = (size_t)img * p.conv_np + (yy + 1) * p.conv_wp + (n - yy * p.conv_w) + 1 + conv_shift;
+      } else {
+        arow = (size_t)(m % p.a_mod);
+      }
+      dma16(p.A + arow * p.lda + a_col0 + c4, sA + buf * T_STAGE + f0 * 4);
       dma16(p.G + (size_t)m * p.ldg + tj * T_TILE + c4, sG + buf * T_STAGE + f0 * 4);
     }
   };

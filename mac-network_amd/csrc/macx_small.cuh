@@ -817,6 +817,72 @@ __global__ void crop_cols_kernel(const float* __restrict__ src, int ld_src, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// stem CNN helpers (model.py:165-204, ops.py:380-438): halo-padded NHWC staging.
+// A [B][H*W][C] tensor is copied into [B][(H+2)*(W+2)][C] with a zero border, so that every 3x3 tap of
+// the implicit-GEMM convolution is a plain row offset and never needs a bounds check.
+// ---------------------------------------------------------------------------------------------
+struct PadP { int B, N, w, wp, np, C; };
+// dst_pad[b][pp(n)] = dropout(src[b][n]);  optional keep bits indexed like src ([B*N][C/32])
+__global__ __launch_bounds__(256) void pad_drop_kernel(const float* __restrict__ src, PadP q, uint32_t key, uint32_t thr24, float inv_keep,
+                                                      uint32_t first, float* dst, uint32_t* bits) {
+  const int c4n = q.C >> 2;
+  const size_t total = (size_t)q.B * q.np * c4n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int h = q.N / q.w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ((total + 7) & ~(size_t)7); i += stride) {
+    const bool in = i < total;
+    const size_t pos = in ? i / c4n : 0;
+    const int c4 = in ? (int)(i - pos * c4n) : 0;
+    const int b = (int)(pos / q.np), pq = (int)(pos - (size_t)b * q.np);
+    const int y = pq / q.wp, x = pq - y * q.wp;
+    const bool interior = in && y >= 1 && y <= h && x >= 1 && x <= q.w;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    uint32_t nib = 0;
+    size_t sidx = 0;
+    if (interior) {
+      sidx = ((size_t)b * q.N + (size_t)(y - 1) * q.w + (x - 1)) * c4n + c4;
+      v = reinterpret_cast<const f32x4*>(src)[sidx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool keep = keep_bit(first + (uint32_t)(sidx * 4) + e, key, thr24);
+        nib |= (keep ? 1u : 0u) << e;
+        v[e] = keep ? v[e] * inv_keep : 0.f;
+      }
+    }
+    if (in) reinterpret_cast<f32x4*>(dst)[i] = v;
+    uint32_t w = nib << (4 * (threadIdx.x & 7));
+    w |= __shfl_xor(w, 1, 64);
+    w |= __shfl_xor(w, 2, 64);
+    w |= __shfl_xor(w, 4, 64);
+    if (bits && interior && (threadIdx.x & 7) == 0) bits[sidx >> 3] = w;
+  }
+}
+// gradient through the activation of a conv layer: dy = g * act'(o), written both plain ([B][N][C]: the
+// weight-gradient operand) and halo-padded (the backward-data operand)
+__global__ __launch_bounds__(256) void pad_mul_actgrad_kernel(const float* __restrict__ g, const float* __restrict__ o, int act, PadP q,
+                                                             float* dst_plain, float* dst_pad) {
+  const int c4n = q.C >> 2;
+  const size_t total = (size_t)q.B * q.np * c4n;
+  const int h = q.N / q.w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pos = i / c4n;
+    const int c4 = (int)(i - pos * c4n);
+    const int b = (int)(pos / q.np), pq = (int)(pos - (size_t)b * q.np);
+    const int y = pq / q.wp, x = pq - y * q.wp;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 1 && y <= h && x >= 1 && x <= q.w) {
+      const size_t sidx = ((size_t)b * q.N + (size_t)(y - 1) * q.w + (x - 1)) * c4n + c4;
+      const f32x4 gv = reinterpret_cast<const f32x4*>(g)[sidx];
+      const f32x4 ov = reinterpret_cast<const f32x4*>(o)[sidx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gv[e] * act_grad_from_out(act, ov[e]);
+      reinterpret_cast<f32x4*>(dst_plain)[sidx] = v;
+    }
+    reinterpret_cast<f32x4*>(dst_pad)[i] = v;
+  }
+}
+
 __global__ void add_bias_kernel(const float* __restrict__ bias, int rows, int n, float* x) {
   const int t = rows * n;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t; i += gridDim.x * blockDim.x) x[i] += bias[i % n];
