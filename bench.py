@@ -71,12 +71,51 @@ def cpu_baseline(seed, iters, sample_b, budget_s=25.0):
                       "(oracle/mac_oracle.py), median" % (len(times), sample_b, S, N, D, P)}
 
 
+def model_level(macx, mo, dev, seed, steps=6):
+    """Secondary number that honours "KB = 14x14x1024": stem CNN (1024->512->512) -> MAC cell x p -> output unit +
+    classifier -> mean CE, backward, fused clip + Adam + EMA step; batch 64, train-mode dropouts.  The question
+    encoder (embedding + biLSTM) is not built: its outputs are synthetic inputs here."""
+    cfg = mo.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
+    net = macx.MACNetCore(cfg, generator=torch.Generator().manual_seed(seed)).to(dev)
+    opt = macx.optim.FlatAdamEMA(net.tensors(), lr=1e-4, clip_norm=8.0, ema_decay=0.999)
+    g = torch.Generator().manual_seed(seed)
+    vq, words, lengths, _ = mo.synthetic_inputs(B, S, 1, D, seed=seed)
+    img = torch.relu(torch.randn(B, N, 1024, generator=g)).to(dev)
+    vq, words, lengths = vq.to(dev), words.to(dev), lengths.to(dev)
+    ans = torch.randint(0, 28, (B,), generator=g).to(dev)
+
+    def one(i):
+        for t in net.tensors():
+            t.grad = None
+        logits = net(img, vq, words, lengths, train=True, seed=seed + i)
+        loss, _ = net.loss_and_pred(logits, ans)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(3):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = one(3 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    stem_flops = 2.0 * 9 * N * (1024 * 512 + 512 * 512)          # forward, per question
+    return {"value": round(B / dt, 2), "unit": "questions/s", "ms_per_step": round(dt * 1e3, 3),
+            "includes": "stem CNN + MAC cell (p=%d) + output unit/classifier + CE loss, fwd+bwd, clip+Adam+EMA step; B=%d" % (P, B),
+            "excludes": "question encoder (embedding + biLSTM): synthetic vecQuestions / questionCntxWords",
+            "final_loss": round(float(loss), 4),
+            "flops_per_question_fwd_bwd": 3 * (P * flops_per_question_step() + stem_flops)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-model-level", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--p", type=int, default=P, help=argparse.SUPPRESS)
@@ -198,6 +237,8 @@ def main():
                           "global_batch": B * world, "parallelism": "dp%d" % world,
                           "flops_per_question_fwd_bwd": 3 * p * F},
                "roofline": roofline}
+        if world == 1 and not args.no_model_level:
+            out["model_level"] = model_level(macx, mo, dev, seed)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seed, args.cpu_iters, args.cpu_batch)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

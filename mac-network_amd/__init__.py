@@ -8,5 +8,6 @@ from .options import UnsupportedOptions, freeze     # noqa: F401
 from .params import MACCellParams                   # noqa: F401
 from .output import OutputClassifier                # noqa: F401
 from .stem import Stem                              # noqa: F401
+from .model import MACNetCore                       # noqa: F401
 
 __all__ = ["MACCell", "MACCellTuple", "MACCellParams", "OutputClassifier", "UnsupportedOptions", "freeze"]

@@ -1,0 +1,42 @@
+"""The device-side graph of MACnet.build (model.py:774-824) from the stem to the logits, with the
+question encoder's outputs as inputs:
+
+    images --stem--> knowledgeBase --MACCell x netLength--> memory --outputOp/classifier--> logits
+
+(`embeddingsOp`/`encoder`, model.py:208-307, are SURVEY.md 8f row 4 and not part of this build: their
+outputs vecQuestions / questionCntxWords / questionLengths are what this module consumes.)"""
+import torch
+
+from .cell import MACCell
+from .options import get
+from .output import OutputClassifier, answer_loss_and_pred
+from .params import MACCellParams
+from .stem import Stem
+
+
+class MACNetCore(torch.nn.Module):
+    def __init__(self, config, H=14, W=14, imageInDim=1024, answerWordsNum=28, generator=None):
+        super().__init__()
+        self.config = config
+        self.netLength = int(get(config, "netLength"))
+        self.stem = Stem(config, H=H, W=W, inDim=imageInDim, generator=generator)
+        self.cell = MACCellParams(config, self.netLength, generator=generator)
+        self.out = OutputClassifier(config, answerWordsNum=answerWordsNum, generator=generator)
+
+    def tensors(self):
+        return self.stem.tensors() + self.cell.tensors() + self.out.tensors()
+
+    def forward(self, images, vecQuestions, questionCntxWords, questionLengths, train=False, seed=0, b0=0):
+        cfg = self.config
+        kb = self.stem(images, train=train, seed=seed, b0=b0)                       # model.py:791
+        cell = MACCell(vecQuestions=vecQuestions, questionWords=questionCntxWords, questionCntxWords=questionCntxWords,
+                       questionLengths=questionLengths, knowledgeBase=kb, memoryDropout=get(cfg, "memoryDropout"),
+                       readDropout=get(cfg, "readDropout"), writeDropout=get(cfg, "writeDropout"), batchSize=images.shape[0],
+                       train=train, config=cfg, params=self.cell, netLength=self.netLength, seed=seed, b0=b0)
+        state = cell.run()                                                           # model.py:801 (MACnetwork)
+        self.last_cell = cell
+        return self.out(state.memory, vecQuestions, train=train, seed=seed, b0=b0)   # model.py:805-809
+
+    @staticmethod
+    def loss_and_pred(logits, answers):
+        return answer_loss_and_pred(logits, answers)                                 # model.py:812-813

@@ -50,3 +50,56 @@ def test_stem_clevr_shape_fp32(macx, dev):
     assert rel_err(kb, ref) < 1e-4
     for f, name in macx.stem.REF_NAMES.items():
         assert rel_err(getattr(stem, f).grad, prm[name].grad) < 1e-3, f
+
+
+def test_core_graph_stem_cell_classifier_gradients(macx, dev):
+    """images -> stem -> MAC cell x p -> classifier -> CE: logits and every parameter gradient against the
+    oracle chain (stem_cnn -> mac_network -> output_classifier), identical dropout masks."""
+    from oracle import mac_oracle as mo
+    B, H, W, Cin, d, p, S, A = 3, 5, 4, 128, 128, 2, 6, 7
+    cfg = mo.flag_file_config("args", netLength=p, memDim=d, ctrlDim=d, attDim=d, outClassifierDims=[32], answerWordsNum=A)
+    cfg.stemDim = 128
+    net = macx.MACNetCore(cfg, H=H, W=W, imageInDim=Cin, answerWordsNum=A, generator=torch.Generator().manual_seed(4)).to(dev)
+    g = torch.Generator().manual_seed(6)
+    img = torch.relu(torch.randn(B, H * W, Cin, generator=g))
+    vq, words, lengths, _ = mo.synthetic_inputs(B, S, 1, d, seed=8)
+    ans = torch.tensor([1, 5, 2])
+    logits = net(img.to(dev), vq.to(dev), words.to(dev), lengths.to(dev), train=True, seed=21)
+    loss, pred = net.loss_and_pred(logits, ans.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle chain in fp64
+    dt = torch.float64
+    prm = {}
+    for src in (net.stem.to_reference_dict(), net.cell.to_reference_dict(), net.out.to_reference_dict()):
+        prm.update({k: v.cpu().to(dt).requires_grad_(True) for k, v in src.items()})
+    vs = mo.VarStore(params=prm, dtype=dt)
+    keeps = (cfg.memoryDropout, cfg.readDropout, cfg.writeDropout)
+    sk, ok = net.stem.keep, net.out.keep
+    smasks = [torch.from_numpy(dh.mask_for(21, 9, 0, sk, (B, H * W, Cin))).to(dt), torch.from_numpy(dh.mask_for(21, 10, 0, sk, (B, H * W, 128))).to(dt)]
+    kb = mo.stem_cnn(cfg, vs, img.to(dt), H, W, keep=sk, masks=smasks)
+    c, m, _ = mo.mac_network(cfg, vs, vq.to(dt), words.to(dt), words.to(dt), lengths, kb, train=True, mask_fn=mo.hash_mask_fn(21, keeps), keeps=keeps)
+    omasks = [torch.from_numpy(dh.mask_for(21, 7, 0, ok, (B, 2 * d))).to(dt), torch.from_numpy(dh.mask_for(21, 8, 0, ok, (B, 32))).to(dt)]
+    rl = mo.output_classifier(cfg, vs, m, vq.to(dt), output_keep=ok, masks=omasks)
+    rloss, rpred = mo.answer_loss_and_pred(rl, ans)
+    rloss.backward()
+    assert max_abs(logits, rl) < 5e-5 and torch.equal(pred.cpu(), rpred)
+    assert abs(float(loss) - float(rloss)) < 1e-5
+    names = {}
+    names.update({f: [(n, None)] for f, n in macx.stem.REF_NAMES.items()})
+    bad = {}
+    for mod, refs in ((net.stem, {f: [(n, None)] for f, n in macx.stem.REF_NAMES.items()}),
+                      (net.cell, macx.params.reference_names(cfg, p)),
+                      (net.out, {f: [(n, None)] for f, n in macx.output.REF_NAMES.items()})):
+        for f, lst in refs.items():
+            if not hasattr(mod, f):
+                continue
+            for refname, idx in lst:
+                rg = prm[refname].grad
+                got = getattr(mod, f).grad
+                got = got if idx is None else got[idx]
+                floor = 5e-2 if refname.endswith("linearLayerlogits/biases/bias") else 1e-7
+                e = rel_err(got.reshape(rg.shape), rg, floor=floor)
+                if not e < 3e-4:
+                    bad[refname] = e
+    assert not bad, bad

@@ -15,7 +15,7 @@ def timeit(fn, n=30, warm=5):
     return e0.elapsed_time(e1) / n * 1e3   # us
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--B", type=int, default=64); args = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--B", type=int, default=64); ap.add_argument("--stem", action="store_true"); args = ap.parse_args()
     L = macx._lib.lib(); dev = torch.device("cuda:0")
     B, N, d = args.B, 196, 512
     p = lambda t: C.c_void_p(t.data_ptr())
@@ -46,5 +46,31 @@ def main():
     us = timeit(lambda: L.macx_linear(p(x), 512, None, 0, 64, p(wp), p(b), 0.0, 512, 0, p(o2), None))
     print("linear 64x512x512: %8.1f us" % us)
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--stem" not in sys.argv:
     main()
+
+
+def stem_bench():
+    import time
+    from oracle import mac_oracle as mo
+    dev = torch.device("cuda:0")
+    cfg = mo.flag_file_config("args")
+    stem = macx.Stem(cfg).to(dev)
+    B = 64
+    img = torch.relu(torch.randn(B, 196, 1024, device=dev))
+    dkb = torch.randn(B, 196, 512, device=dev)
+    def fwd():
+        with torch.no_grad():
+            return stem(img, train=True, seed=1)
+    us_f = timeit(fwd, n=10, warm=3)
+    def fb():
+        kb = stem(img, train=True, seed=1)
+        kb.backward(dkb)
+    us_fb = timeit(fb, n=10, warm=3)
+    fl_f = 2.0 * B * 196 * 9 * (1024 * 512 + 512 * 512)
+    fl_b = 2.0 * B * 196 * 9 * (1024 * 512 + 2 * 512 * 512)
+    print("stem fwd B=64: %8.1f us  %6.1f TF ; fwd+bwd: %8.1f us  %6.1f TF" % (us_f, fl_f / us_f / 1e6, us_fb, (fl_f + fl_b) / us_fb / 1e6))
+
+
+if __name__ == "__main__" and "--stem" in sys.argv:
+    stem_bench()
