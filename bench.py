@@ -110,6 +110,7 @@ def model_level(macx, mo, dev, seed, steps=6):
 
 
 def main():
+    global B
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -119,7 +120,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--p", type=int, default=P, help=argparse.SUPPRESS)
+    ap.add_argument("--per-gpu-batch", type=int, default=B, help=argparse.SUPPRESS)   # exploration only; the metric is B=64
     args = ap.parse_args()
+    B = args.per_gpu_batch
 
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))

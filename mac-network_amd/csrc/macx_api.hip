@@ -140,8 +140,8 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   return L;
 }
 
-inline int nrb_of(int N) {
-  const int rows = kb_gemm_rows(N);
+inline int nrb_of(int N, int B, int d) {
+  const int rows = kb_gemm_pick_rt(N, B, d / (16 * kb_gemm_nw())) * 16;
   return (N + rows - 1) / rows;
 }
 
@@ -225,7 +225,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.slab_wx = take(L.ns_big * d * d);
   L.slab_w1a = take(p * L.ngroup * d * d);
   L.slab_w1b = take(p * L.ngroup * d * d);
-  const size_t nrb = nrb_of((int)N);
+  const size_t nrb = nrb_of((int)N, (int)B, (int)d);
   L.db2_part = take(p * B * d);
   L.db1_part = take(p * B * nrb * d);
   L.dbx_part = take(p * B * nrb * d);
@@ -626,7 +626,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   const size_t BNd = (size_t)B * N * d;
   const size_t dd = (size_t)d * d;
   const int win = write_in_dim(o, d);
-  const int nrb = nrb_of(N);
+  const int nrb = nrb_of(N, B, d);
   const bool rdrop = dp->keep_read < 1.0f;
 
   // ---- weights in the layouts the backward kernels read

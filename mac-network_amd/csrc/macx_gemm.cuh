@@ -396,19 +396,22 @@ inline hipError_t kb_gemm_launch_rt(const GemmP& p, hipStream_t st) {
 }
 
 // row tiles per workgroup: the smallest of {1,2,4,7,13} x 16 rows that covers a question's N cells
-// (196 -> 13, 49 -> 4, 14 -> 1; N > 208 -> 13 with several row blocks per question).
-inline int kb_gemm_pick_rt(int N) {
-  if (N <= 16) return 1;
-  if (N <= 32) return 2;
-  if (N <= 64) return 4;
-  if (N <= 112) return 7;
-  return 13;
+// (196 -> 13, 49 -> 4, 14 -> 1; N > 208 -> 13 with several row blocks per question).  With few
+// questions per GPU (small per-rank batches, strong scaling) one tile per question would leave most of
+// the 256 CUs idle, so the tile height drops until the grid reaches ~one workgroup per CU.
+inline int kb_gemm_pick_rt(int N, int B, int ncb = 4) {
+  static const int cand[5] = {13, 7, 4, 2, 1};
+  int k = 0;
+  if (N <= 16) k = 4; else if (N <= 32) k = 3; else if (N <= 64) k = 2; else if (N <= 112) k = 1;
+  auto blocks = [&](int rt) { return B * ncb * ((N + rt * 16 - 1) / (rt * 16)); };
+  while (k < 3 && blocks(cand[k]) < 200) ++k;      // not below 2 x 16 rows: the weight panel traffic grows as tiles shrink
+  return cand[k];
 }
-inline int kb_gemm_rows(int N) { return kb_gemm_pick_rt(N) * 16; }
+inline int kb_gemm_rows(int N, int B) { return kb_gemm_pick_rt(N, B) * 16; }
 
 template <int NW, int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_launch_nw(const GemmP& p, hipStream_t st) {
-  switch (kb_gemm_pick_rt(p.N)) {
+  switch (kb_gemm_pick_rt(p.N, p.B, p.Nout / (16 * NW))) {
     case 1: return kb_gemm_launch_rt<1, NW, AP, BP, EP, COLSUM>(p, st);
     case 2: return kb_gemm_launch_rt<2, NW, AP, BP, EP, COLSUM>(p, st);
     case 4: return kb_gemm_launch_rt<4, NW, AP, BP, EP, COLSUM>(p, st);
