@@ -72,22 +72,26 @@ def cpu_baseline(seed, iters, sample_b, budget_s=25.0):
 
 
 def model_level(macx, mo, dev, seed, steps=6):
-    """Secondary number that honours "KB = 14x14x1024": stem CNN (1024->512->512) -> MAC cell x p -> output unit +
-    classifier -> mean CE, backward, fused clip + Adam + EMA step; batch 64, train-mode dropouts.  The question
-    encoder (embedding + biLSTM) is not built: its outputs are synthetic inputs here."""
+    """Secondary number that honours "KB = 14x14x1024": the whole tower body of MACnet.build -- question encoder
+    (embedding 300 + biLSTM 2x256) and stem CNN (1024->512->512) -> MAC cell x p -> output unit + classifier -> mean CE,
+    backward, fused clip + Adam + EMA step; batch 64, train-mode dropouts.  Inputs are the reference's feed dict:
+    question word ids + lengths, 14x14x1024 image features, answer ids."""
     cfg = mo.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
-    net = macx.MACNetCore(cfg, generator=torch.Generator().manual_seed(seed)).to(dev)
+    VOCAB = 90                                                    # CLEVR question vocabulary size (preprocess.py)
+    net = macx.MACNet(cfg, vocab=VOCAB, generator=torch.Generator().manual_seed(seed)).to(dev)
     opt = macx.optim.FlatAdamEMA(net.tensors(), lr=1e-4, clip_norm=8.0, ema_decay=0.999)
     g = torch.Generator().manual_seed(seed)
-    vq, words, lengths, _ = mo.synthetic_inputs(B, S, 1, D, seed=seed)
+    _, _, lengths, _ = mo.synthetic_inputs(B, S, 1, 8, seed=seed)
     img = torch.relu(torch.randn(B, N, 1024, generator=g)).to(dev)
-    vq, words, lengths = vq.to(dev), words.to(dev), lengths.to(dev)
+    qs = torch.randint(1, VOCAB + 1, (B, S), generator=g, dtype=torch.int32)
+    qs = (qs * (torch.arange(S).unsqueeze(0) < lengths.unsqueeze(1)).to(torch.int32)).to(dev)
+    lengths = lengths.to(dev)
     ans = torch.randint(0, 28, (B,), generator=g).to(dev)
 
     def one(i):
         for t in net.tensors():
             t.grad = None
-        logits = net(img, vq, words, lengths, train=True, seed=seed + i)
+        logits = net(img, qs, lengths, train=True, seed=seed + i, check_ids=False)
         loss, _ = net.loss_and_pred(logits, ans)
         loss.backward()
         opt.step()
@@ -103,8 +107,8 @@ def model_level(macx, mo, dev, seed, steps=6):
     dt = (time.perf_counter() - t0) / steps
     stem_flops = 2.0 * 9 * N * (1024 * 512 + 512 * 512)          # forward, per question
     return {"value": round(B / dt, 2), "unit": "questions/s", "ms_per_step": round(dt * 1e3, 3),
-            "includes": "stem CNN + MAC cell (p=%d) + output unit/classifier + CE loss, fwd+bwd, clip+Adam+EMA step; B=%d" % (P, B),
-            "excludes": "question encoder (embedding + biLSTM): synthetic vecQuestions / questionCntxWords",
+            "includes": "question encoder (emb + biLSTM) + stem CNN + MAC cell (p=%d) + output unit/classifier + CE loss, "
+                        "fwd+bwd, clip+Adam+EMA step; B=%d, S=%d" % (P, B, S),
             "final_loss": round(float(loss), 4),
             "flops_per_question_fwd_bwd": 3 * (P * flops_per_question_step() + stem_flops)}
 

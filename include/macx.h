@@ -243,6 +243,26 @@ int macx_stem_backward(const macx_stem_shapes*, int act, float keep, uint32_t se
                        const float* kb, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
                        const float* d_kb, const macx_stem_grads*, void* stream);
 
+/* ---- question encoder (producer of vecQuestions / questionCntxWords) ---------- */
+/* qEmbeddingsOp (model.py:208-221) + encoder (model.py:255-307) for encType = LSTM, encBi,
+ * encNumLayers = 1: embedding lookup (index 0 = zero pad row), dropout(encInputDropout), a
+ * bidirectional BasicLSTMCell(h = encDim/2) under tf.nn.bidirectional_dynamic_rnn semantics,
+ * questionCntxWords = concat(fw, bw) [B,S,2h], vecQuestions = dropout(concat(final h), qDropout).
+ * Variables: qEmbeddings/emb [V,E]; encoder/birnnLayer/bidirectional_rnn/{fw,bw}/basic_lstm_cell/
+ * {kernel [E+h,4h], bias [4h]} (gate order i, j, f, o; forget bias 1).  h % 128 == 0. */
+typedef struct macx_enc_shapes { int32_t B, S, V, E, h, b0; } macx_enc_shapes;   /* V rows in emb (ids 1..V) */
+typedef struct macx_enc_params { const float* emb; const float* fw_kernel; const float* fw_bias; const float* bw_kernel; const float* bw_bias; } macx_enc_params;
+typedef struct macx_enc_grads { float* emb; float* fw_kernel; float* fw_bias; float* bw_kernel; float* bw_bias; } macx_enc_grads;
+size_t macx_encoder_saved_floats(const macx_enc_shapes*);
+size_t macx_encoder_ws_floats(const macx_enc_shapes*);
+int macx_encoder_forward(const macx_enc_shapes*, float keep_input, float keep_question, uint32_t seed, const macx_enc_params*,
+                         const int32_t* questions /*[B,S]*/, const int32_t* lengths /*[B]*/, float* words /*[B,S,2h]*/,
+                         float* vecQuestions /*[B,2h]*/, float* saved, size_t saved_floats, void* stream);
+int macx_encoder_backward(const macx_enc_shapes*, float keep_input, float keep_question, uint32_t seed, const macx_enc_params*,
+                          const int32_t* questions, const int32_t* lengths, const float* saved, size_t saved_floats,
+                          float* ws, size_t ws_floats, const float* d_words, const float* d_vecQuestions,
+                          const macx_enc_grads*, void* stream);
+
 /* ---- optimizer step ---------------------------------------------------------- */
 /* addTrainingOp (model.py:639-669) over ONE flat fp32 buffer of n elements:
  *   norm = ||g||_2 ; g *= clip / max(norm, clip)      tf.clip_by_global_norm, clip_norm <= 0 disables

@@ -78,6 +78,21 @@ class MacxStemGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in STEM_FIELDS]
 
 
+class MacxEncShapes(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "S", "V", "E", "h", "b0")]
+
+
+ENC_FIELDS = ("emb", "fw_kernel", "fw_bias", "bw_kernel", "bw_bias")
+
+
+class MacxEncParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ENC_FIELDS]
+
+
+class MacxEncGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ENC_FIELDS]
+
+
 class MacxInputs(C.Structure):
     _fields_ = [("vecQuestions", C.c_void_p), ("words", C.c_void_p), ("questionLengths", C.c_void_p),
                 ("knowledgeBase", C.c_void_p)]
@@ -92,7 +107,8 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_linear", "macx_pack_weight", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_wgrad_splits",
            "macx_wgrad", "macx_debug_set", "macx_output_saved_floats", "macx_output_ws_floats",
            "macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
-           "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward")
+           "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward",
+           "macx_encoder_saved_floats", "macx_encoder_ws_floats", "macx_encoder_forward", "macx_encoder_backward")
 
 _lib = None
 
@@ -172,9 +188,18 @@ def lib():
         f = getattr(L, n)
         if f.restype is C.c_int or n in ("macx_check",):
             f.restype = C.c_int
-    for n in ("macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
-           "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward"):
-        getattr(L, n).restype = C.c_int
+    L.macx_encoder_saved_floats.argtypes = [P(MacxEncShapes)]
+    L.macx_encoder_ws_floats.argtypes = [P(MacxEncShapes)]
+    L.macx_encoder_forward.argtypes = [P(MacxEncShapes), C.c_float, C.c_float, C.c_uint32, P(MacxEncParams), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.macx_encoder_backward.argtypes = [P(MacxEncShapes), C.c_float, C.c_float, C.c_uint32, P(MacxEncParams), C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, P(MacxEncGrads),
+                                        C.c_void_p]
+    for n in EXPORTS:
+        if n.endswith("_floats"):
+            getattr(L, n).restype = C.c_size_t
+        elif n not in ("macx_strerror",):
+            getattr(L, n).restype = C.c_int
     _lib = L
     return L
 

@@ -1373,6 +1373,177 @@ int macx_stem_backward(const macx_stem_shapes* s, int act, float keep, uint32_t 
 }
 
 // =================================================================================================
+// question encoder (model.py:208-307; ops.biRNNLayer ops.py:859-911): SURVEY 8f row 4
+// =================================================================================================
+namespace {
+inline int pad128(int n) { return (n + 127) & ~127; }
+struct EncLayout {
+  size_t wx_p, wh_p;     // packed [2][Ep x 4h], [2][h x 4h]
+  size_t Xp;             // [B*S][Ep]  dropped embedded words (columns E..Ep-1 zero)
+  size_t Zx;             // [2][B*S][4h]
+  size_t R;              // [2][B][4h]
+  size_t hs, cs;         // [2][S+1][B][h]
+  size_t gates;          // [2][S][B][4h]
+  size_t total;
+};
+EncLayout make_enc(const macx_enc_shapes* s) {
+  EncLayout L;
+  memset(&L, 0, sizeof(L));
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
+  const size_t B = s->B, S = s->S, h = s->h, Ep = pad128(s->E), G = 4 * h;
+  L.wx_p = take(2 * Ep * G); L.wh_p = take(2 * h * G);
+  L.Xp = take(B * S * Ep); L.Zx = take(2 * B * S * G); L.R = take(2 * B * G);
+  L.hs = take(2 * (S + 1) * B * h); L.cs = take(2 * (S + 1) * B * h);
+  L.gates = take(2 * S * B * G);
+  L.total = off;
+  return L;
+}
+struct EncBwdLayout {
+  size_t wxT_p, whT_p, dG, dZ, dh, dc, dh_pass, dXp, tmpW, slab, dq, total;
+};
+EncBwdLayout make_enc_bwd(const macx_enc_shapes* s) {
+  EncBwdLayout L;
+  memset(&L, 0, sizeof(L));
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
+  const size_t B = s->B, S = s->S, h = s->h, Ep = pad128(s->E), G = 4 * h;
+  L.wxT_p = take(2 * G * Ep); L.whT_p = take(2 * G * h);
+  L.dG = take(2 * S * B * G); L.dZ = take(2 * B * S * G);
+  L.dh = take(2 * B * h); L.dc = take(2 * B * h); L.dh_pass = take(2 * B * h);
+  L.dXp = take(B * S * Ep); L.tmpW = take(Ep * G);
+  L.slab = take((size_t)wgrad_splits((int)(B * S), (int)Ep, (int)G) * Ep * G);
+  L.dq = take(B * 2 * h);
+  L.total = off;
+  return L;
+}
+int enc_check(const macx_enc_shapes* s) {
+  if (!s || s->B < 1 || s->S < 1 || s->V < 1 || s->E < 1 || s->h < 128 || s->h % 128) return MACX_EINVAL;
+  return MACX_OK;
+}
+}  // namespace
+
+size_t macx_encoder_saved_floats(const macx_enc_shapes* s) { return enc_check(s) ? 0 : make_enc(s).total; }
+size_t macx_encoder_ws_floats(const macx_enc_shapes* s) { return enc_check(s) ? 0 : make_enc_bwd(s).total; }
+
+int macx_encoder_forward(const macx_enc_shapes* s, float keep_input, float keep_question, uint32_t seed, const macx_enc_params* P,
+                         const int32_t* questions, const int32_t* lengths, float* words, float* vecQ, float* saved,
+                         size_t saved_floats, void* stream) {
+  CKI(enc_check(s));
+  if (!P || !questions || !lengths || !words || !vecQ || !saved) return MACX_EINVAL;
+  const EncLayout L = make_enc(s);
+  if (saved_floats < L.total) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, S = s->S, E = s->E, h = s->h, Ep = pad128(E), G = 4 * h;
+  const size_t Bh = (size_t)B * h;
+  Packer pk;
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* K = dir ? P->bw_kernel : P->fw_kernel;      // [E + h, 4h]: rows [0,E) input, [E,E+h) recurrent
+    pk.add(K, G, 1, Ep, G, saved + L.wx_p + (size_t)dir * Ep * G, E, G);
+    pk.add(K + (size_t)E * G, G, 1, h, G, saved + L.wh_p + (size_t)dir * h * G);
+  }
+  CK(pk.run(st));
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(512), dim3(256), 0, st, questions, P->emb, B * S, E, Ep, (uint32_t)s->b0 * (uint32_t)S,
+                     make_drop(keep_input, seed, SITE_ENC_INPUT, 0), saved + L.Xp);
+  CK(hipGetLastError());
+  // input projections of every position, both directions
+  {
+    LinP l = lin_basic(saved + L.Xp, Ep, Ep, B * S, saved + L.wx_p, nullptr, G, MACX_ACT_NON, saved + L.Zx, G);
+    l.zW = (size_t)Ep * G; l.zout = (size_t)B * S * G;
+    CK(small_linear_launch(l, 2, st));
+  }
+  CK(hipMemsetAsync(saved + L.hs, 0, 2 * (size_t)(S + 1) * Bh * sizeof(float), st));
+  CK(hipMemsetAsync(saved + L.cs, 0, 2 * (size_t)(S + 1) * Bh * sizeof(float), st));
+  CK(hipMemsetAsync(words, 0, (size_t)B * S * 2 * h * sizeof(float), st));
+  // fw bias and bw bias live in separate tensors: copy them next to each other once
+  float* bias2 = saved + L.R;   // reuse as [2][4h] staging before the loop? -> no: R is written every step. keep biases via zb = 0 trick below
+  (void)bias2;
+  for (int tau = 0; tau < S; ++tau) {
+    // R = h_prev Wh + b, per direction (two launches: the two bias vectors are separate tensors)
+    for (int dir = 0; dir < 2; ++dir) {
+      LinP l = lin_basic(saved + L.hs + ((size_t)dir * (S + 1) + tau) * Bh, h, h, B, saved + L.wh_p + (size_t)dir * h * G,
+                         dir ? P->bw_bias : P->fw_bias, G, MACX_ACT_NON, saved + L.R + (size_t)dir * B * G, G);
+      CK(small_linear_launch(l, 1, st));
+    }
+    LstmP c;
+    c.B = B; c.S = S; c.h = h; c.tau = tau; c.len = lengths;
+    c.R = saved + L.R; c.Zx = saved + L.Zx; c.hs = saved + L.hs; c.cs = saved + L.cs; c.gates = saved + L.gates; c.out = words;
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3(128), dim3(256), 0, st, c);
+    CK(hipGetLastError());
+  }
+  // vecQuestions = dropout(concat([h_fw_final, h_bw_final]))   (ops.py:905-906, model.py:292)
+  for (int dir = 0; dir < 2; ++dir)
+    CK(hipMemcpy2DAsync(vecQ + dir * h, (size_t)2 * h * sizeof(float), saved + L.hs + ((size_t)dir * (S + 1) + S) * Bh,
+                        (size_t)h * sizeof(float), (size_t)h * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)vecQ, B, 2 * h, (uint32_t)s->b0,
+                     make_drop(keep_question, seed, SITE_QUESTION, 0), no_drop(), vecQ);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
+int macx_encoder_backward(const macx_enc_shapes* s, float keep_input, float keep_question, uint32_t seed, const macx_enc_params* P,
+                          const int32_t* questions, const int32_t* lengths, const float* saved, size_t saved_floats, float* ws,
+                          size_t ws_floats, const float* d_words, const float* d_vecQ, const macx_enc_grads* Gr, void* stream) {
+  CKI(enc_check(s));
+  if (!P || !questions || !lengths || !saved || !ws || !d_words || !d_vecQ || !Gr) return MACX_EINVAL;
+  const EncLayout L = make_enc(s);
+  const EncBwdLayout W = make_enc_bwd(s);
+  if (saved_floats < L.total || ws_floats < W.total) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, S = s->S, E = s->E, h = s->h, Ep = pad128(E), G = 4 * h;
+  const size_t Bh = (size_t)B * h;
+  Packer pk;
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* K = dir ? P->bw_kernel : P->fw_kernel;
+    pk.add(K, 1, G, G, Ep, ws + W.wxT_p + (size_t)dir * G * Ep, G, E);           // Wx^T: [4h] -> [Ep], columns >= E zero
+    pk.add(K + (size_t)E * G, 1, G, G, h, ws + W.whT_p + (size_t)dir * G * h);   // Wh^T: [4h] -> [h]
+  }
+  CK(pk.run(st));
+  CK(hipMemsetAsync(ws + W.dZ, 0, 2 * (size_t)B * S * G * sizeof(float), st));
+  CK(hipMemsetAsync(ws + W.dc, 0, 2 * Bh * sizeof(float), st));
+  // d(final states) = d_vecQ through the question dropout, split per direction
+  hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, d_vecQ, B, 2 * h, (uint32_t)s->b0,
+                     make_drop(keep_question, seed, SITE_QUESTION, 0), no_drop(), ws + W.dq);
+  for (int dir = 0; dir < 2; ++dir)
+    CK(hipMemcpy2DAsync(ws + W.dh + (size_t)dir * Bh, (size_t)h * sizeof(float), ws + W.dq + dir * h, (size_t)2 * h * sizeof(float),
+                        (size_t)h * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+  for (int tau = S - 1; tau >= 0; --tau) {
+    LstmBwdP c;
+    c.B = B; c.S = S; c.h = h; c.tau = tau; c.len = lengths;
+    c.cs = saved + L.cs; c.gates = saved + L.gates; c.dout = d_words;
+    c.dh = ws + W.dh; c.dc = ws + W.dc; c.dG = ws + W.dG; c.dZ = ws + W.dZ; c.dh_pass = ws + W.dh_pass;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(128), dim3(256), 0, st, c);
+    CK(hipGetLastError());
+    // dh_prev = dG_tau Wh^T + (dh of the questions that had already ended)
+    LinP l = lin_basic(ws + W.dG + (size_t)tau * B * G, G, G, B, ws + W.whT_p, nullptr, h, MACX_ACT_NON, ws + W.dh, h);
+    l.seg[0].zstride = (size_t)S * B * G; l.zW = (size_t)G * h; l.zout = Bh;
+    l.addend = ws + W.dh_pass; l.ld_add = h; l.zadd = Bh;
+    CK(small_linear_launch(l, 2, st));
+  }
+  for (int dir = 0; dir < 2; ++dir) {
+    float* dK = dir ? Gr->bw_kernel : Gr->fw_kernel;
+    // input block of the kernel: X^T dZ (rows [0,E) of the padded product)
+    CKI(wgrad_impl(saved + L.Xp, Ep, ws + W.dZ + (size_t)dir * B * S * G, G, B * S, Ep, G, ws + W.tmpW, ws + W.slab, st));
+    CK(hipMemcpyAsync(dK, ws + W.tmpW, (size_t)E * G * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // recurrent block: sum_tau h_prev(tau)^T dG_tau  -- one contraction over S*B rows
+    CKI(wgrad_impl(saved + L.hs + (size_t)dir * (S + 1) * Bh, h, ws + W.dG + (size_t)dir * S * B * G, G, S * B, h, G,
+                   dK + (size_t)E * G, ws + W.slab, st));
+    CK(rowsum(ws + W.dG + (size_t)dir * S * B * G, S * B, G, G, dir ? Gr->bw_bias : Gr->fw_bias, st));
+  }
+  // d(embedded words) = [dZ_fw | dZ_bw] [Wx_fw^T ; Wx_bw^T], then through the input dropout into the embedding rows
+  {
+    LinP l = lin_basic(ws + W.dZ, G, G, B * S, ws + W.wxT_p, nullptr, Ep, MACX_ACT_NON, ws + W.dXp, Ep);
+    l.seg[1] = LinSeg{ws + W.dZ + (size_t)B * S * G, G, G, 0};
+    l.Ktot = 2 * G;
+    CK(small_linear_launch(l, 1, st));
+  }
+  hipLaunchKernelGGL(embed_grad_kernel, dim3(s->V), dim3(256), 0, st, questions, (const float*)(ws + W.dXp), B * S, E, Ep,
+                     (uint32_t)s->b0 * (uint32_t)S, make_drop(keep_input, seed, SITE_ENC_INPUT, 0), Gr->emb);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
+// =================================================================================================
 // optimizer step (model.py:615-669): SURVEY 8f row 3
 // =================================================================================================
 int macx_adam_ema_step(size_t n, float* params, const float* grads, float* m, float* v, float* ema, float lr, float beta1,

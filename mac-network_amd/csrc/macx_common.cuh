@@ -53,7 +53,9 @@ enum : uint32_t {
   SITE_OUT_FC0 = 7,   // ops.py:312 via FCLayer (ops.py:349-359): dropout on the classifier's first layer input
   SITE_OUT_FC1 = 8,   // ... and on its second layer input
   SITE_STEM0 = 9,     // ops.py:400  dropout on the input of stem conv layer 0 (the image features)
-  SITE_STEM1 = 10     // ... and of stem conv layer 1
+  SITE_STEM1 = 10,    // ... and of stem conv layer 1
+  SITE_ENC_INPUT = 11, // ops.py:880  dropout on the embedded question words (encInputDropout)
+  SITE_QUESTION = 12  // model.py:292 dropout on the question vector (qDropout)
 };
 
 struct DropSpec {

@@ -883,6 +883,127 @@ __global__ __launch_bounds__(256) void pad_mul_actgrad_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// question encoder (model.py:208-307, ops.py:749-911): embedding lookup + bidirectional
+// BasicLSTMCell(h) under tf.nn.bidirectional_dynamic_rnn semantics (per-question lengths: the state
+// is carried through and the output is zero past the end; the backward direction runs over the
+// length-reversed question).
+// ---------------------------------------------------------------------------------------------
+// x[b][s][0:E] = dropout(embeddings[idx]) with embeddings = concat([zeros(1,E), emb]) (model.py:217); columns E..Ep-1 = 0
+__global__ void embed_gather_kernel(const int32_t* __restrict__ idx, const float* __restrict__ emb, int rows, int E, int Ep, uint32_t row0,
+                                    DropSpec ds, float* x) {
+  const size_t total = (size_t)rows * Ep;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / Ep;
+    const int c = (int)(i - r * Ep);
+    float v = 0.f;
+    if (c < E) {
+      const int t = idx[r];
+      if (t > 0) v = emb[(size_t)(t - 1) * E + c];
+      v = drop_apply(v, (uint32_t)((row0 + r) * E + c), ds);
+    }
+    x[i] = v;
+  }
+}
+struct LstmP {
+  int B, S, h, tau;
+  const int32_t* len;      // [B]
+  const float* R;          // [2][B][4h]    h_prev Wh + b   (this step)
+  const float* Zx;         // [2][B*S][4h]  x Wx            (all positions)
+  float* hs; float* cs;    // [2][S+1][B][h] each: state BEFORE step tau at index tau
+  float* gates;            // [2][S][B][4h] gate activations i, j, f, o (saved for backward)
+  float* out;              // [B][S][2h]    outputs (zero-initialised)
+};
+// BasicLSTMCell (TF1): gates i, j, f, o ; c' = c * sigmoid(f + 1) + sigmoid(i) * tanh(j) ; h' = tanh(c') * sigmoid(o)
+__global__ void lstm_cell_kernel(LstmP p) {
+  const int n = 2 * p.B * p.h;
+  const size_t Bh = (size_t)p.B * p.h;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int dir = i / (p.B * p.h);
+    const int r = i - dir * p.B * p.h;
+    const int b = r / p.h, u = r - b * p.h;
+    const int L = p.len[b];
+    const bool active = p.tau < L;
+    const int pos = dir == 0 ? p.tau : L - 1 - p.tau;
+    const size_t s0 = (size_t)(dir * (p.S + 1) + p.tau) * Bh + r, s1 = s0 + Bh;
+    const float hp = p.hs[s0], cp = p.cs[s0];
+    float hn = hp, cn = cp;
+    float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f;
+    if (active) {
+      const float* R = p.R + ((size_t)dir * p.B + b) * 4 * p.h;
+      const float* Z = p.Zx + ((size_t)dir * p.B * p.S + (size_t)b * p.S + pos) * 4 * p.h;
+      gi = 1.0f / (1.0f + expf(-(R[u] + Z[u])));
+      gj = tanhf(R[p.h + u] + Z[p.h + u]);
+      gf = 1.0f / (1.0f + expf(-(R[2 * p.h + u] + Z[2 * p.h + u] + 1.0f)));
+      go = 1.0f / (1.0f + expf(-(R[3 * p.h + u] + Z[3 * p.h + u])));
+      cn = cp * gf + gi * gj;
+      hn = tanhf(cn) * go;
+      p.out[((size_t)b * p.S + pos) * 2 * p.h + dir * p.h + u] = hn;
+    }
+    p.hs[s1] = hn;
+    p.cs[s1] = cn;
+    float* g = p.gates + ((size_t)(dir * p.S + p.tau) * p.B + b) * 4 * p.h;
+    g[u] = gi; g[p.h + u] = gj; g[2 * p.h + u] = gf; g[3 * p.h + u] = go;
+  }
+}
+struct LstmBwdP {
+  int B, S, h, tau;
+  const int32_t* len;
+  const float* cs;         // saved cell states [2][S+1][B][h]
+  const float* gates;      // saved gate activations
+  const float* dout;       // [B][S][2h]  gradient wrt the outputs
+  float* dh; float* dc;    // [2][B][h]   running state gradients (in/out)
+  float* dG;               // [2][S][B][4h]  gate pre-activation gradients, dense over (tau, b)
+  float* dZ;               // [2][B*S][4h]   the same, scattered to word positions (zero-initialised)
+  float* dh_pass;          // [2][B][h]   part of dh that bypasses the recurrent linear (inactive rows)
+};
+__global__ void lstm_cell_bwd_kernel(LstmBwdP p) {
+  const int n = 2 * p.B * p.h;
+  const size_t Bh = (size_t)p.B * p.h;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int dir = i / (p.B * p.h);
+    const int r = i - dir * p.B * p.h;
+    const int b = r / p.h, u = r - b * p.h;
+    const int L = p.len[b];
+    const bool active = p.tau < L;
+    const int pos = dir == 0 ? p.tau : L - 1 - p.tau;
+    float* g = p.dG + ((size_t)(dir * p.S + p.tau) * p.B + b) * 4 * p.h;
+    float dh = p.dh[i], dc = p.dc[i];
+    float di = 0.f, dj = 0.f, df = 0.f, dO = 0.f, pass = dh;
+    if (active) {
+      const float* ga = p.gates + ((size_t)(dir * p.S + p.tau) * p.B + b) * 4 * p.h;
+      const float gi = ga[u], gj = ga[p.h + u], gf = ga[2 * p.h + u], go = ga[3 * p.h + u];
+      const float cp = p.cs[(size_t)(dir * (p.S + 1) + p.tau) * Bh + r];
+      const float cn = p.cs[(size_t)(dir * (p.S + 1) + p.tau + 1) * Bh + r];
+      dh += p.dout[((size_t)b * p.S + pos) * 2 * p.h + dir * p.h + u];
+      const float tc = tanhf(cn);
+      dO = dh * tc * go * (1.0f - go);
+      const float dct = dc + dh * go * (1.0f - tc * tc);
+      di = dct * gj * gi * (1.0f - gi);
+      dj = dct * gi * (1.0f - gj * gj);
+      df = dct * cp * gf * (1.0f - gf);
+      dc = dct * gf;
+      pass = 0.f;
+      float* z = p.dZ + ((size_t)dir * p.B * p.S + (size_t)b * p.S + pos) * 4 * p.h;
+      z[u] = di; z[p.h + u] = dj; z[2 * p.h + u] = df; z[3 * p.h + u] = dO;
+    }
+    g[u] = di; g[p.h + u] = dj; g[2 * p.h + u] = df; g[3 * p.h + u] = dO;
+    p.dc[i] = dc;
+    p.dh_pass[i] = pass;
+  }
+}
+// d emb[v-1][c] = sum over tokens == v of dropmask * dx[r][c]   (one workgroup per vocabulary row: no atomics)
+__global__ __launch_bounds__(256) void embed_grad_kernel(const int32_t* __restrict__ idx, const float* __restrict__ dx, int rows, int E, int Ep,
+                                                        uint32_t row0, DropSpec ds, float* demb) {
+  const int v = blockIdx.x + 1;
+  for (int c = threadIdx.x; c < E; c += 256) {
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r)
+      if (idx[r] == v) acc += drop_apply(dx[(size_t)r * Ep + c], (uint32_t)((row0 + r) * E + c), ds);
+    demb[(size_t)(v - 1) * E + c] = acc;
+  }
+}
+
 __global__ void add_bias_kernel(const float* __restrict__ bias, int rows, int n, float* x) {
   const int t = rows * n;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t; i += gridDim.x * blockDim.x) x[i] += bias[i % n];

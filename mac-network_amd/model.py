@@ -3,11 +3,14 @@ question encoder's outputs as inputs:
 
     images --stem--> knowledgeBase --MACCell x netLength--> memory --outputOp/classifier--> logits
 
-(`embeddingsOp`/`encoder`, model.py:208-307, are SURVEY.md 8f row 4 and not part of this build: their
-outputs vecQuestions / questionCntxWords / questionLengths are what this module consumes.)"""
+`MACNetCore` takes the question encoder's outputs (vecQuestions / questionCntxWords / questionLengths) as inputs;
+`MACNet` adds `embeddingsOp` + `encoder` (model.py:208-307) in front, so its inputs are exactly
+the reference's feed dict: question word ids, question lengths, image features, (answers).  Out of this graph stay
+only the host side (preprocess.py / main.py) and the baseline / unused stem variants."""
 import torch
 
 from .cell import MACCell
+from .encoder import QuestionEncoder
 from .options import get
 from .output import OutputClassifier, answer_loss_and_pred
 from .params import MACCellParams
@@ -40,3 +43,18 @@ class MACNetCore(torch.nn.Module):
     @staticmethod
     def loss_and_pred(logits, answers):
         return answer_loss_and_pred(logits, answers)                                 # model.py:812-813
+
+
+class MACNet(MACNetCore):
+    """MACnet.build's tower body (model.py:781-813): embeddingsOp -> encoder -> stem -> MACnetwork -> outputOp/classifier."""
+
+    def __init__(self, config, vocab, H=14, W=14, imageInDim=1024, answerWordsNum=28, embInit=None, generator=None):
+        super().__init__(config, H=H, W=W, imageInDim=imageInDim, answerWordsNum=answerWordsNum, generator=generator)
+        self.enc = QuestionEncoder(config, vocab, embInit=embInit, generator=generator)
+
+    def tensors(self):
+        return self.enc.tensors() + super().tensors()
+
+    def forward(self, images, questions, questionLengths, train=False, seed=0, b0=0, check_ids=True):
+        words, vecQ = self.enc(questions, questionLengths, train=train, seed=seed, b0=b0, check_ids=check_ids)   # model.py:783-788
+        return super().forward(images, vecQ, words, questionLengths, train=train, seed=seed, b0=b0)

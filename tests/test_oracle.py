@@ -204,3 +204,39 @@ def test_classifier_logits_and_argmax():
     assert vs.params["classifier/linearLayerfc_0/weights/weight"].shape == (16, 6)
     loss, pred = mo.answer_loss_and_pred(logits, torch.tensor([0, 1, 2]))
     assert pred.dtype == torch.int32 and loss.ndim == 0
+
+
+def test_question_encoder_restatement_matches_torch_lstm():
+    """The biLSTM restatement (tf.nn.bidirectional_dynamic_rnn + BasicLSTMCell, gate order i, j, f, o, forget bias 1)
+    against torch.nn.LSTM over packed ragged sequences -- an independent implementation of the same recurrence."""
+    E, h, V = 5, 4, 6
+    cfg = mo.flag_file_config("args", ctrlDim=2 * h, memDim=2 * h, attDim=2 * h, encDim=2 * h, wrdEmbDim=E)
+    vs = mo.VarStore(generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    q = torch.tensor([[1, 2, 3, 0, 0], [3, 6, 2, 1, 4], [5, 0, 0, 0, 0]])
+    L = torch.tensor([3, 5, 1], dtype=torch.int32)
+    w, v = mo.question_encoder(cfg, vs, q, L, V)
+    P = vs.params
+    for d in ("fw", "bw"):
+        P["encoder/birnnLayer/bidirectional_rnn/%s/basic_lstm_cell/bias" % d] = torch.rand(4 * h, dtype=torch.float64) - 0.5
+    w, v = mo.question_encoder(cfg, vs, q, L, V)
+    lstm = torch.nn.LSTM(E, h, batch_first=True, bidirectional=True).double()
+
+    def load(sfx, K, b):
+        def reord(M):      # TF i, j, f, o -> torch i, f, g, o
+            i, j, f, o = M.split(h, 0)
+            return torch.cat([i, f, j, o], 0)
+        bb = b.clone()
+        bb[2 * h:3 * h] += 1.0
+        getattr(lstm, "weight_ih_l0" + sfx).data = reord(K[:E].T.contiguous())
+        getattr(lstm, "weight_hh_l0" + sfx).data = reord(K[E:].T.contiguous())
+        getattr(lstm, "bias_ih_l0" + sfx).data = reord(bb)
+        getattr(lstm, "bias_hh_l0" + sfx).data.zero_()
+    for d, sfx in (("fw", ""), ("bw", "_reverse")):
+        load(sfx, P["encoder/birnnLayer/bidirectional_rnn/%s/basic_lstm_cell/kernel" % d],
+             P["encoder/birnnLayer/bidirectional_rnn/%s/basic_lstm_cell/bias" % d])
+    table = torch.cat([torch.zeros(1, E, dtype=torch.float64), P["qEmbeddings/emb"]])
+    pk = torch.nn.utils.rnn.pack_padded_sequence(table[q], L.long(), batch_first=True, enforce_sorted=False)
+    out, (hn, _) = lstm(pk)
+    out, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=5)
+    assert (out - w).abs().max() < 1e-12 and (torch.cat([hn[0], hn[1]], 1) - v).abs().max() < 1e-12
+    assert float(w[0, 3:].abs().max()) == 0.0 and float(w[2, 1:].abs().max()) == 0.0

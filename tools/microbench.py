@@ -15,7 +15,7 @@ def timeit(fn, n=30, warm=5):
     return e0.elapsed_time(e1) / n * 1e3   # us
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--B", type=int, default=64); ap.add_argument("--stem", action="store_true"); args = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--B", type=int, default=64); ap.add_argument("--stem", action="store_true"); ap.add_argument("--encoder", action="store_true"); args = ap.parse_args()
     L = macx._lib.lib(); dev = torch.device("cuda:0")
     B, N, d = args.B, 196, 512
     p = lambda t: C.c_void_p(t.data_ptr())
@@ -72,5 +72,27 @@ def stem_bench():
     print("stem fwd B=64: %8.1f us  %6.1f TF ; fwd+bwd: %8.1f us  %6.1f TF" % (us_f, fl_f / us_f / 1e6, us_fb, (fl_f + fl_b) / us_fb / 1e6))
 
 
+def encoder_bench():
+    from oracle import mac_oracle as mo
+    dev = torch.device("cuda:0")
+    cfg = mo.flag_file_config("args")
+    enc = macx.QuestionEncoder(cfg, vocab=90).to(dev)
+    for B, S in ((64, 50), (64, 30), (8, 50)):
+        g = torch.Generator().manual_seed(1)
+        lengths = torch.randint(3, S + 1, (B,), generator=g, dtype=torch.int32)
+        q = torch.randint(1, 91, (B, S), generator=g, dtype=torch.int32) * (torch.arange(S).unsqueeze(0) < lengths.unsqueeze(1)).to(torch.int32)
+        q, lengths = q.to(dev), lengths.to(dev)
+        dW = torch.randn(B, S, 512, device=dev); dQ = torch.randn(B, 512, device=dev)
+        def fwd():
+            with torch.no_grad():
+                return enc(q, lengths, train=True, seed=1, check_ids=False)
+        def fb():
+            w, v = enc(q, lengths, train=True, seed=1, check_ids=False)
+            torch.autograd.backward([w, v], [dW, dQ])
+        print("encoder B=%d S=%d: fwd %8.1f us ; fwd+bwd %8.1f us" % (B, S, timeit(fwd, n=10, warm=3), timeit(fb, n=10, warm=3)))
+
+
 if __name__ == "__main__" and "--stem" in sys.argv:
     stem_bench()
+if __name__ == "__main__" and "--encoder" in sys.argv:
+    encoder_bench()
