@@ -243,6 +243,10 @@ int macx_stem_backward(const macx_stem_shapes*, int act, float keep, uint32_t se
                        const float* kb, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
                        const float* d_kb, const macx_stem_grads*, void* stream);
 
+/* Feed-dict image layout (model.py:67-68): the h5 features are [B, C, H, W] (extract_features.py) and the graph
+ * transposes them to NHWC before the stem.  nhwc[b][hw][c] = nchw[b][c][hw]. */
+int macx_images_to_nhwc(const float* nchw, int B, int C, int HW, float* nhwc, void* stream);
+
 /* ---- question encoder (producer of vecQuestions / questionCntxWords) ---------- */
 /* qEmbeddingsOp (model.py:208-221) + encoder (model.py:255-307) for encType = LSTM, encBi,
  * encNumLayers = 1: embedding lookup (index 0 = zero pad row), dropout(encInputDropout), a

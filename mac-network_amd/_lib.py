@@ -108,7 +108,8 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_wgrad", "macx_debug_set", "macx_output_saved_floats", "macx_output_ws_floats",
            "macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
            "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward",
-           "macx_encoder_saved_floats", "macx_encoder_ws_floats", "macx_encoder_forward", "macx_encoder_backward")
+           "macx_encoder_saved_floats", "macx_encoder_ws_floats", "macx_encoder_forward", "macx_encoder_backward",
+           "macx_images_to_nhwc")
 
 _lib = None
 
@@ -188,6 +189,7 @@ def lib():
         f = getattr(L, n)
         if f.restype is C.c_int or n in ("macx_check",):
             f.restype = C.c_int
+    L.macx_images_to_nhwc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.macx_encoder_saved_floats.argtypes = [P(MacxEncShapes)]
     L.macx_encoder_ws_floats.argtypes = [P(MacxEncShapes)]
     L.macx_encoder_forward.argtypes = [P(MacxEncShapes), C.c_float, C.c_float, C.c_uint32, P(MacxEncParams), C.c_void_p, C.c_void_p,

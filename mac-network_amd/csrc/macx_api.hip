@@ -1372,6 +1372,12 @@ int macx_stem_backward(const macx_stem_shapes* s, int act, float keep, uint32_t 
   return MACX_OK;
 }
 
+int macx_images_to_nhwc(const float* nchw, int B, int C, int HW, float* nhwc, void* stream) {
+  if (!nchw || !nhwc || B < 1 || C < 1 || HW < 1 || B > 65535) return MACX_EINVAL;
+  hipLaunchKernelGGL(transpose_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, nchw, C, HW, nhwc);
+  return (int)hipGetLastError();
+}
+
 // =================================================================================================
 // question encoder (model.py:208-307; ops.biRNNLayer ops.py:859-911): SURVEY 8f row 4
 // =================================================================================================
@@ -1570,6 +1576,7 @@ int macx_adam_ema_step(size_t n, float* params, const float* grads, float* m, fl
 int macx_debug_set(int key, int value) {
   if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }
   if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
+  if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;
 }
 

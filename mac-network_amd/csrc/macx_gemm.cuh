@@ -374,6 +374,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
 // runtime knob (macx_debug_set(0, NW)): waves per workgroup of the kb GEMM, 4 or 8
 inline int& kb_gemm_nw() { static int nw = 8; return nw; }
 inline int& kb_gemm_dbg() { static int m = 0; return m; }
+inline int& kb_gemm_force_rt() { static int rt = 0; return rt; }   // tuning override (macx_debug_set key 2)
 
 template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_launch_rt(const GemmP& p, hipStream_t st) {
@@ -401,6 +402,7 @@ inline hipError_t kb_gemm_launch_rt(const GemmP& p, hipStream_t st) {
 // the 256 CUs idle, so the tile height drops until the grid reaches ~one workgroup per CU.
 inline int kb_gemm_pick_rt(int N, int B, int ncb = 4) {
   static const int cand[5] = {13, 7, 4, 2, 1};
+  if (kb_gemm_force_rt()) return kb_gemm_force_rt();
   int k = 0;
   if (N <= 16) k = 4; else if (N <= 32) k = 3; else if (N <= 64) k = 2; else if (N <= 112) k = 1;
   auto blocks = [&](int rt) { return B * ncb * ((N + rt * 16 - 1) / (rt * 16)); };

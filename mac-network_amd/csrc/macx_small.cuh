@@ -78,9 +78,11 @@ __global__ void mask_bits_kernel(uint32_t key, uint32_t thr24, uint32_t first, s
   }
 }
 
-// dst[c][r] = src[r][c]
+// dst[z][c][r] = src[z][r][c]   (z = blockIdx.z; matrices stored back to back)
 __global__ void transpose_kernel(const float* __restrict__ src, int R, int C, float* dst) {
   __shared__ float tile[32][33];
+  src += (size_t)blockIdx.z * R * C;
+  dst += (size_t)blockIdx.z * R * C;
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
   for (int i = ty; i < 32; i += 8) {

@@ -83,7 +83,17 @@ class Stem(torch.nn.Module):
         return {REF_NAMES[f]: getattr(self, f).detach().clone() for f in _lib.STEM_FIELDS}
 
     def forward(self, images, train=False, seed=0, b0=0):
+        """images: [B, H*W, inDim] / [B, H, W, inDim] (NHWC, what the graph sees after model.py:68) or the feed-dict layout
+        [B, inDim, H, W] (h5 features, extract_features.py), which is transposed on the device first."""
         if not images.is_cuda:
             raise RuntimeError("the stem has no CPU path")
+        if images.dim() == 4 and images.shape[1] == self.inDim and tuple(images.shape[2:]) == (self.H, self.W):
+            src = images.contiguous()
+            images = torch.empty(src.shape[0], self.H * self.W, self.inDim, dtype=torch.float32, device=src.device)
+            st = C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+            _lib.check(_lib.lib().macx_images_to_nhwc(src.data_ptr(), src.shape[0], self.inDim, self.H * self.W, images.data_ptr(), st),
+                       "macx_images_to_nhwc")
+        elif images.dim() == 4:
+            images = images.reshape(images.shape[0], self.H * self.W, self.inDim)
         keep = self.keep if train else 1.0
         return _StemFunction.apply(self, keep, int(seed), int(b0), images, *self.tensors())

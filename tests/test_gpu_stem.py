@@ -103,3 +103,17 @@ def test_core_graph_stem_cell_classifier_gradients(macx, dev):
                 if not e < 3e-4:
                     bad[refname] = e
     assert not bad, bad
+
+
+def test_stem_accepts_feed_dict_layout(macx, dev):
+    """h5 features are [B, C, H, W]; model.py:68 transposes them to NHWC.  macx_images_to_nhwc does that on the device:
+    bit-identical to feeding the NHWC tensor."""
+    cfg = mo.flag_file_config("args", memDim=128, ctrlDim=128, attDim=128)
+    cfg.stemDim = 128
+    stem = macx.Stem(cfg, H=14, W=14, inDim=256, generator=torch.Generator().manual_seed(1)).to(dev)
+    nchw = torch.relu(torch.randn(3, 256, 14, 14, generator=torch.Generator().manual_seed(2))).to(dev)
+    nhwc = nchw.permute(0, 2, 3, 1).contiguous()
+    a = stem(nchw, train=True, seed=3)
+    b = stem(nhwc, train=True, seed=3)
+    c = stem(nhwc.reshape(3, 196, 256), train=True, seed=3)
+    assert torch.equal(a, b) and torch.equal(a, c)

@@ -106,3 +106,41 @@ def test_cell_refuses_cpu_tensors(macx):
     with pytest.raises(RuntimeError, match="no CPU path"):
         macx.MACCell(vq, words, words, lengths, kb, 0.85, 0.85, 1.0, 2, True, config=cfg,
                      params=macx.MACCellParams(cfg, 1))
+
+
+def test_checkpoint_roundtrip_reference_names(tmp_path):
+    """Weights leave and enter under the TF variable names (macModel/...:0), incl. EMA shadows."""
+    import macx
+    from oracle import mac_oracle as mo
+    cfg = mo.flag_file_config("args", netLength=2, memDim=128, ctrlDim=128, attDim=128, encDim=256, wrdEmbDim=12, outClassifierDims=[16])
+    cfg.ctrlDim = cfg.memDim = cfg.attDim = cfg.encDim = 256
+    cfg.stemDim = 128
+    net = macx.MACNet(cfg, vocab=7, H=3, W=2, imageInDim=128, answerWordsNum=5, generator=torch.Generator().manual_seed(0))
+    sd = macx.checkpoint.reference_state_dict(net)
+    assert "macModel/qEmbeddings/emb:0" in sd and "macModel/stem/cnnLayercnn_0/kernels/kernel:0" in sd
+    assert "macModel/MACnetwork/MACCell/read/linearLayermemKbProj/linearLayermemKbProj_2/weights/weight:0" in sd
+    assert "macModel/encoder/birnnLayer/bidirectional_rnn/bw/basic_lstm_cell/kernel:0" in sd
+    assert sum(v.numel() for v in sd.values()) == sum(t.numel() for t in net.tensors())
+    ema = [t.detach() * 0.5 for t in net.tensors()]
+    path = str(tmp_path / "w.npz")
+    macx.checkpoint.save_npz(path, net, ema_tensors=ema)
+    before = [t.detach().clone() for t in net.tensors()]
+    with torch.no_grad():
+        for t in net.tensors():
+            t.add_(1.0)
+    macx.checkpoint.load_npz(path, net)
+    assert all(torch.equal(a, b) for a, b in zip(before, net.tensors()))
+    macx.checkpoint.load_npz(path, net, use_ema=True)
+    assert all(torch.equal(a * 0.5, b) for a, b in zip(before, net.tensors()))
+    # bare names (no macModel/ prefix, no :0), missing and mis-shaped variables
+    bare = {k[len("macModel/"):-2]: v for k, v in sd.items()}
+    macx.checkpoint.load_reference(net, bare)
+    short = dict(bare)
+    short.pop("qEmbeddings/emb")
+    with pytest.raises(KeyError):
+        macx.checkpoint.load_reference(net, short)
+    assert macx.checkpoint.load_reference(net, short, strict=False) == ["qEmbeddings/emb"]
+    bad = dict(bare)
+    bad["qEmbeddings/emb"] = torch.zeros(3, 3)
+    with pytest.raises(ValueError):
+        macx.checkpoint.load_reference(net, bad)
