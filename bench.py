@@ -149,6 +149,8 @@ def main():
 
     import macx
     from oracle import mac_oracle as mo   # only for synthetic input shapes + the cpu_baseline leg
+    if os.environ.get("MACX_DBG"):          # tuning only: kb GEMM debug bits
+        macx._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
     if os.environ.get("MACX_FORCE_RT"):     # tuning only: row tiles per GEMM workgroup
         macx._lib.lib().macx_debug_set(2, int(os.environ["MACX_FORCE_RT"]))
     p = args.p

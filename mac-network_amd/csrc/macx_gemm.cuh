@@ -31,6 +31,7 @@
 //                     reductions (attention logits) inside one half-wave, column sums (bias
 //                     gradients) by a fixed-order LDS combine.
 #pragma once
+#include <type_traits>
 #include "macx_common.cuh"
 
 namespace macx {
@@ -81,7 +82,7 @@ struct GemmP {
   const uint32_t* e_bits; // E_I2_LOGIT: keep bits of act(I2*c) [B*N][Nout/32]; E_DKB: keep bits of KB; null = keep all
   float e_inv_keep;
   int accumulate;         // E_DKB: 1 -> out += , 0 -> out =
-  int dbg;                // measurement knobs (macx_debug_set(1, mask)): 1 skip epilogue, 2 skip in-loop staging, 4 skip fragment reads
+  int dbg;                // measurement knobs (macx_debug_set(1, mask)): 1 skip epilogue, 2 skip in-loop staging, 4 plain (not write-through) stores, 8 no epilogue stores
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -96,6 +97,13 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // other's MFMA phase; NW = 8 (128-column tiles, 512 threads) reads the A panel half as often.
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): the 64 lanes of a wave fetch 64 x 16 B from
 // per-lane global addresses into LDS at wave_base + lane*16.  No VGPR round trip, no ds_write.
+// 16-byte global store, plain or write-through (sc0 sc1: the bytes leave the XCD's L2 as they are issued instead of in
+// the end-of-kernel write-back burst; MI355X_MICROARCH "publish-large")
+__device__ __forceinline__ void store16(float* g, f32x4 v, bool wt) {
+  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g), "v"(v) : "memory");
+  else *reinterpret_cast<f32x4*>(g) = v;
+}
+
 __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -138,7 +146,14 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   const int cb = v % ncb;
   const int rbi = (v / ncb) % nrb;
   const int b = v / (ncb * nrb);
-  const int row0 = rbi * ROWS;
+  // the ceil(N/16) row tiles of a question are dealt evenly over its nrb row blocks (196 rows, RT = 7: 7 + 6 tiles), so
+  // only the question's last tile carries padding; a block with RT - 1 tiles skips the MFMAs of its last slot
+  const int ntiles = (p.N + 15) >> 4;
+  const int tbase = ntiles / nrb, textra = ntiles - tbase * nrb;
+  const int nt = tbase + (rbi < textra ? 1 : 0);
+  const int row0 = (rbi * tbase + min(rbi, textra)) << 4;
+  const int row_end = min(p.N, row0 + (nt << 4));       // rows >= row_end belong to the next block (or to nobody)
+  const bool full = nt >= RT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   for (int i = 0; i < A_IT; ++i) {
     const int f = tid + G_THREADS * i;
     const int n = row0 + (f >> 3);
-    a_ok[i] = (f < A_F4) && (n < p.N);
+    a_ok[i] = (f < A_F4) && (n < row_end);
     const int nc = min(n, p.N - 1);
     a_row[i] = nc;
     const int srow = conv ? (nc / p.conv_w + 1) * p.conv_wp + (nc % p.conv_w) + 1 : nc;
@@ -243,7 +258,11 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int r = 0; r < RT; ++r) acc[r] = mfma16(af[r][e], bf[e], acc[r]);
+      for (int r = 0; r < RT - 1; ++r) acc[r] = mfma16(af[r][e], bf[e], acc[r]);
+    if (full) {      // workgroup-uniform: the last tile slot of a block that was dealt RT - 1 tiles is empty
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[RT - 1] = mfma16(af[RT - 1][e], bf[e], acc[RT - 1]);
+    }
   };
 
   // ---- main loop: register-staged double buffer, one barrier per k-slice.  The next slice's LDS
@@ -287,6 +306,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   }
   if (EP == E_DKB) drj = *reinterpret_cast<const f32x4*>(p.aux + (size_t)b * p.ld_aux + col);
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  const bool wt = !(p.dbg & 4);     // write-through output stores (dbg 4: plain stores, for comparison)
   const int wpr = p.Nout >> 5;   // mask words per output row
   // every global operand the epilogue needs (activation outputs for act', the running dKB, mask words,
   // attention weights) is requested for ALL of this thread's rows before the first one is used: RT
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
 #pragma unroll
     for (int it = 0; it < RT; ++it) {
       const int n = row0 + rg + it * RG;
-      const size_t orow = (size_t)b * p.N + min(n, p.N - 1);
+      const size_t orow = (size_t)b * p.N + min(n, row_end - 1);
       if (EP == E_MUL_DACT) {
         auxv[it] = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + col);
         bitv[it] = p.e_bits ? p.e_bits[orow * wpr + (col >> 5)] >> (col & 31) : 0xFu;
@@ -315,17 +335,17 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   for (int it = 0; it < RT; ++it) {
     const int lrow = rg + it * RG;
     const int n = row0 + lrow;
-    const bool ok = n < p.N;
-    const size_t orow = (size_t)b * p.N + (ok ? n : p.N - 1);
+    const bool ok = n < row_end && !(p.dbg & 8);     // dbg 8: timing experiment, epilogue without its global stores
+    const size_t orow = (size_t)b * p.N + (n < row_end ? n : row_end - 1);
     f32x4 val = *reinterpret_cast<const f32x4*>(T + lrow * G_LDT + c4 * 4);
     float* optr = p.out + orow * p.ldo + col;
     if (EP == E_BIAS_ACT) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = act_apply(p.act, val[e] + bias4[e]);
-      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
+      if (ok) store16(optr, val, wt);
     } else if (EP == E_I2_LOGIT) {
       val += bias4;
-      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
+      if (ok) store16(optr, val, wt);
       // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w   (bias b_k added in kb_attend)
       const uint32_t bits = bitv[it];
       float part = 0.f;
@@ -345,16 +365,16 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
       const float ik = p.e_bits ? p.e_inv_keep : 1.0f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] *= ((bits >> e) & 1u) ? act_grad_from_out(p.act, h[e]) * ik : 0.f;
-      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
+      if (ok) store16(optr, val, wt);
     } else if (EP == E_PLAIN) {
-      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
+      if (ok) store16(optr, val, wt);
     } else if (EP == E_DKB) {
       const uint32_t bits = bitv[it];
       const float a = attv[it];
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = (((bits >> e) & 1u) ? val[e] * p.e_inv_keep : 0.f) + a * drj[e];
       val += auxv[it];
-      if (ok) *reinterpret_cast<f32x4*>(optr) = val;
+      if (ok) store16(optr, val, wt);
     }
     if (COLSUM && ok) csum += val;
   }

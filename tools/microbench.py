@@ -32,10 +32,10 @@ def main():
             print("kb_project NW=%d keep=%.2f: %8.1f us  %6.1f TF" % (nw, keep, us, flops / us / 1e6))
     L.macx_debug_set(0, 8)
     dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=1)
-    for dbg in (0, 1):
+    for dbg in (0, 1, 2, 3, 4, 8):
         L.macx_debug_set(1, dbg)
         us = timeit(lambda: L.macx_kb_project(C.byref(sh), C.byref(dp), 0, p(kb), p(wp), p(b), p(out), p(bits), None))
-        print("kb_project NW=8 dbg=%d (1 no epilogue, 2 no staging, 8 no in-loop loads, 16 no in-loop stores): %8.1f us  %6.1f TF" % (dbg, us, flops / us / 1e6))
+        print("kb_project NW=8 dbg=%d (1 no epilogue, 2 no staging, 4 plain stores, 8 no epilogue stores): %8.1f us  %6.1f TF" % (dbg, us, flops / us / 1e6))
     L.macx_debug_set(1, 0)
     M = B * N
     A = torch.randn(M, d, device=dev); G = torch.randn(M, d, device=dev)
