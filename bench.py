@@ -151,6 +151,8 @@ def main():
     from oracle import mac_oracle as mo   # only for synthetic input shapes + the cpu_baseline leg
     if os.environ.get("MACX_DBG"):          # tuning only: kb GEMM debug bits
         macx._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
+    if os.environ.get("MACX_GEMM"):         # native | split (default): kernel family of the knowledge-base GEMMs
+        macx._lib.lib().macx_gemm_mode({"native": 0, "split": 1}[os.environ["MACX_GEMM"]])
     if os.environ.get("MACX_FORCE_RT"):     # tuning only: row tiles per GEMM workgroup
         macx._lib.lib().macx_debug_set(2, int(os.environ["MACX_FORCE_RT"]))
     p = args.p
@@ -209,12 +211,12 @@ def main():
         L = macx._lib.lib()
         sh = macx._lib.MacxShapes(B=B, S=S, N=N, d=D, p=p, b0=0)
         dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=seed)   # the GEMM alone (dropout is a separate pass)
-        wp = torch.empty(D * D, device=dev)
+        wp = torch.empty(2 * D * D, device=dev)
         xo = torch.empty(B, N, D, device=dev)
         bits = torch.empty(B * N * D + B * N * D // 32, device=dev)
         ptr = lambda t: C.c_void_p(t.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        macx._lib.check(L.macx_pack_weight(ptr(params.projX_W.detach()), D, D, 0, ptr(wp), st), "pack")
+        macx._lib.check(L.macx_pack_weight(ptr(params.projX_W.detach()), D, D, macx._lib.kb_pack_flags(), ptr(wp), st), "pack")
         kbc = kbd.detach()
         for _ in range(3):
             L.macx_kb_project(C.byref(sh), C.byref(dp), 0, ptr(kbc), ptr(wp), ptr(params.projX_b.detach()), ptr(xo), ptr(bits), st)

@@ -283,13 +283,31 @@ int macx_adam_ema_step(size_t n, float* params, const float* grads, float* m, fl
 int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows,
                 const float* W_packed, const float* b, float bias_const, int n_out, int act,
                 float* out, void* stream);
-/* Re-lays a [K, n_out] weight (transpose = 0) or the transpose of a [n_out, K] weight
- * (transpose = 1) into the MFMA operand order the knowledge-base GEMM reads:
- * out[Q][g][j][e] = W[16Q + 4g + e][j].  K % 16 == 0, n_out % 16 == 0; `out` holds K*n_out floats. */
-int macx_pack_weight(const float* W, int K, int n_out, int transpose, float* out, void* stream);
-/* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688) on fp32 MFMA.
- * `W_packed` from macx_pack_weight(Wx, d, d, 0); `drop_ws` >= B*N*d + B*N*d/32 floats of scratch
- * for the dropped KB and its keep bits (may be NULL when keep_read == 1). */
+/* Re-lays a [K, n_out] weight (flags bit 0 = 0) or the transpose of a [n_out, K] weight (bit 0 = 1) into the operand
+ * order a kernel reads; flags bits 1-2 select the format:
+ *   MACX_PACK_F32MFMA (0)  out[Q][g][j][e] = W[16Q + 4g + e][j]            fp32, K*n_out floats   (macx_linear, native GEMM)
+ *   MACX_PACK_BF16X3  (1)  out[K/32][3][n_out][32] bf16: the exact split W = W1 + W2 + W3 of every element into three
+ *                          bf16 pieces (round-to-nearest residual chain), K*n_out*3/2 floats      (split GEMM)
+ *   MACX_PACK_KMAJOR  (2)  out[K/32][n_out][32] fp32 k-major tiles, K*n_out floats
+ * K % 16 == 0 (K % 32 for formats 1, 2), n_out % 16 == 0. */
+#define MACX_PACK_TRANSPOSE 1
+#define MACX_PACK_F32MFMA (0 << 1)
+#define MACX_PACK_BF16X3 (1 << 1)
+#define MACX_PACK_KMAJOR (2 << 1)
+int macx_pack_weight(const float* W, int K, int n_out, int flags, float* out, void* stream);
+/* Which kernel family runs the knowledge-base GEMMs (projX, memKbProj, memKbProj_2, their backward-data products and
+ * the stem's implicit-GEMM convolutions).  gfx950 issues f32-input MFMA at 1/16 of the bf16 rate and has no TF32 form, so
+ * the default is MACX_GEMM_SPLIT: every fp32 operand is split exactly into three bf16 pieces and a product is the six
+ * leading cross terms on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- fp32-class error (measured <= the native
+ * kernel's against fp64, tests/test_gpu_units.py) at 6/16 of the f32 issue time.  MACX_GEMM_NATIVE keeps
+ * v_mfma_f32_16x16x4_f32 (bit-equal to an fmaf chain).  mode < 0 queries.  Returns the mode now in force.
+ * Process-wide; set it before sizing/running (packed-weight formats differ). */
+#define MACX_GEMM_NATIVE 0
+#define MACX_GEMM_SPLIT 1
+int macx_gemm_mode(int mode);
+/* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688) on the knowledge-base GEMM.
+ * `W_packed` from macx_pack_weight(Wx, d, d, macx_gemm_mode(-1) ? MACX_PACK_BF16X3 : MACX_PACK_F32MFMA);
+ * `drop_ws` >= B*N*d + B*N*d/32 floats of scratch for the dropped KB and its keep bits (may be NULL when keep_read == 1). */
 int macx_kb_project(const macx_shapes*, const macx_dropout*, int step, const float* kb,
                     const float* W_packed, const float* b, float* out, float* drop_ws, void* stream);
 /* softmax(expMask(logits)) + att2Smry over the question words for one step
@@ -306,7 +324,8 @@ int macx_wgrad_splits(int M, int Kd, int Jd);
 int macx_wgrad(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd,
                float* out, float* ws, void* stream);
 
-/* tuning hook for A/B measurements: key 0 = waves per workgroup of the knowledge-base GEMM (4 | 8) */
+/* tuning hook for A/B measurements: key 0 = waves per workgroup of the native knowledge-base GEMM (4 | 8), 1 = phase-timing
+ * bits, 2 = forced row tiles per workgroup, 3 = macx_gemm_mode */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

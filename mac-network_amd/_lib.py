@@ -109,7 +109,7 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
            "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward",
            "macx_encoder_saved_floats", "macx_encoder_ws_floats", "macx_encoder_forward", "macx_encoder_backward",
-           "macx_images_to_nhwc")
+           "macx_images_to_nhwc", "macx_gemm_mode")
 
 _lib = None
 
@@ -160,6 +160,7 @@ def lib():
     L.macx_dropout_mask.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_void_p,
                                     C.c_void_p]
     L.macx_debug_set.argtypes = [C.c_int, C.c_int]
+    L.macx_gemm_mode.argtypes = [C.c_int]
     L.macx_adam_ema_step.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.macx_adam_ema_step.restype = C.c_int
@@ -209,3 +210,11 @@ def lib():
 def check(code, where):
     if code != 0:
         raise MacxError(code, where)
+
+
+PACK_TRANSPOSE, PACK_F32MFMA, PACK_BF16X3, PACK_KMAJOR = 1, 0 << 1, 1 << 1, 2 << 1
+
+
+def kb_pack_flags():
+    """macx_pack_weight flags for a weight handed to macx_kb_project under the GEMM mode in force."""
+    return PACK_BF16X3 if lib().macx_gemm_mode(-1) else PACK_F32MFMA

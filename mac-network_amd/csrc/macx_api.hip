@@ -8,6 +8,7 @@
 #include "../../include/macx.h"
 #include "macx_common.cuh"
 #include "macx_gemm.cuh"
+#include "macx_gemm6.cuh"
 #include "macx_gemm_tn.cuh"
 #include "macx_small.cuh"
 
@@ -27,6 +28,19 @@ using namespace macx;
 namespace {
 
 inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+// The knowledge-base GEMM family runs on one of two kernels (macx_debug_set(3, mode), default split):
+//   split (1): macx_gemm6.cuh, fp32 operands as three exact bf16 pieces on the bf16 matrix pipe, fp32 accumulate;
+//   native (0): macx_gemm.cuh, v_mfma_f32_16x16x4_f32.
+// They take different weight packings: plain weights -> format 1 (bf16 planes, 1.5x the floats) / 0, weights mixed
+// with a per-question vector (B_YMIX_*) -> format 2 (fp32 k-major tiles) / 0.  Buffers are sized for the larger one.
+inline int wfmt_plain() { return gemm_split_mode() ? 1 : 0; }
+inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
+inline size_t wsize(size_t K, size_t n) { return K * n * 3 / 2; }
+template <int AP, int BP, int EP, bool COLSUM>
+inline hipError_t kb_gemm(const GemmP& g, hipStream_t st) {
+  return gemm_split_mode() ? kb_gemm6_launch<AP, BP, EP, COLSUM>(g, st) : kb_gemm_launch<AP, BP, EP, COLSUM>(g, st);
+}
 
 inline DropSpec make_drop(float keep, uint32_t seed, uint32_t site, uint32_t step) {
   DropSpec s;
@@ -96,10 +110,10 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
     L.seg_count[i] = counts[i];
     L.seg[i] = take(counts[i]);
   }
-  L.wx_p = take(d * d);
+  L.wx_p = take(wsize(d, d));
   L.w1a_p = take(d * d);
   L.w1b_p = take(d * d);
-  L.w2_p = take(d * d);
+  L.w2_p = take(wsize(d, d));
   L.wy_p = take(d * d);
   L.wm_p = take((size_t)write_in_dim(o, s->d) * d);
   L.wq_p = take(d * d);
@@ -201,7 +215,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   const size_t win = write_in_dim(o, s->d);
   size_t off = 0;
   auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
-  L.wxT_p = take(d * d); L.w1aT_p = take(d * d); L.w1bT_p = take(d * d); L.w2T_p = take(d * d);
+  L.wxT_p = take(wsize(d, d)); L.w1aT_p = take(d * d); L.w1bT_p = take(d * d); L.w2T_p = take(wsize(d, d));
   L.wyT = take(d * d);
   L.wmT = take(win * d);
   L.wqT = take(d * d);
@@ -273,8 +287,8 @@ hipError_t pack(const float* src, int ld_k, int ld_j, int K, int Nout, float* ds
 struct Packer {
   PackList L;
   int n = 0;
-  void add(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst, int k_src = -1, int n_src = -1) {
-    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout, k_src < 0 ? K : k_src, n_src < 0 ? Nout : n_src};
+  void add(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst, int k_src = -1, int n_src = -1, int fmt = 0) {
+    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout, k_src < 0 ? K : k_src, n_src < 0 ? Nout : n_src, fmt};
   }
   hipError_t run(hipStream_t st) {
     if (n == 0) return hipSuccess;
@@ -397,10 +411,10 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
   // weights -> MFMA operand layout  (memKbProj rows [0,d) multiply x*y, rows [d,2d) multiply x: ops.py:718)
   {
     Packer pk;
-    pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p);
-    pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p);
-    pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p);
-    pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p);
+    pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain());
+    pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, wfmt_ymix());
+    pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, wfmt_ymix());
+    pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, -1, -1, wfmt_plain());
     pk.add(P->projY_W, d, 1, d, d, saved + L.wy_p);
     pk.add(P->newMemory_W, d, 1, write_in_dim(o, d), d, saved + L.wm_p);
     pk.add(P->qInput_W, d, 1, d, d, saved + L.wq_p);
@@ -533,19 +547,19 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   g.A = rdrop ? KBd : in->knowledgeBase; g.lda = d;
   g.Wp = saved + L.wx_p;
   g.out = X; g.ldo = d; g.bias = P->projX_b; g.act = MACX_ACT_NON;
-  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  CK((kb_gemm<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
   // H1 = act( concat([X*y, X]) W1 + b1 ) = act( X (diag(y) W1a + W1b) + b1 )   (ops.py:703,718; mac_cell.py:237)
   g.A = X;
   g.Wp = saved + L.w1a_p; g.Wp2 = saved + L.w1b_p; g.y = y; g.ldy = d;
   g.out = H1; g.bias = P->memKbProj_b; g.act = o->read_mem_act;
-  CK((kb_gemm_launch<A_PLAIN, B_YMIX_ROW, E_BIAS_ACT, false>(g, st)));
+  CK((kb_gemm<A_PLAIN, B_YMIX_ROW, E_BIAS_ACT, false>(g, st)));
   // I2 = H1 W2 + b2 ; logits = dropout(act(I2 * c)) . w_k   (ops.py:326; mac_cell.py:248,262,266)
   g.A = H1; g.Wp = saved + L.w2_p; g.Wp2 = nullptr; g.y = nullptr;
   g.out = I2; g.bias = P->memKbProj2_b; g.act = o->read_ctrl_act;
   g.cvec = c_i; g.wvec = P->kbLogits_w;
   g.logit_part = saved + L.logit_part;
   g.e_bits = rdrop ? att_bits : nullptr;
-  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_I2_LOGIT, false>(g, st)));
+  CK((kb_gemm<A_PLAIN, B_PLAIN, E_I2_LOGIT, false>(g, st)));
   // attention over the knowledge base + summary (mac_cell.py:266-275)
   {
     KbAttP a;
@@ -633,10 +647,10 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   const int nU = o->control_input_unshared ? p : 1;
   {
     Packer pk;
-    pk.add(P->projX_W, 1, d, d, d, ws + W.wxT_p);            // Wx^T
-    pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p);       // W1a^T
-    pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p);  // W1b^T
-    pk.add(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p);       // W2^T
+    pk.add(P->projX_W, 1, d, d, d, ws + W.wxT_p, -1, -1, wfmt_plain());            // Wx^T
+    pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, -1, -1, wfmt_ymix());       // W1a^T
+    pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, -1, -1, wfmt_ymix());  // W1b^T
+    pk.add(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, -1, -1, wfmt_plain());       // W2^T
     pk.add(P->projY_W, 1, d, d, d, ws + W.wyT);              // Wy^T
     pk.add(P->newMemory_W, 1, d, d, win, ws + W.wmT);        // Wm^T: [d] -> [win]
     pk.add(P->qInput_W, 1, d, d, d, ws + W.wqT);
@@ -764,12 +778,12 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     g.A = dI2_i; g.lda = d; g.Wp = ws + W.w2T_p;
     g.out = ws + W.dI1; g.ldo = d; g.aux = H1; g.act = o->read_mem_act;
     g.colsum_part = ws + W.db1_part + (size_t)i * B * nrb * d;
-    CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_MUL_DACT, true>(g, st)));
+    CK((kb_gemm<A_PLAIN, B_PLAIN, E_MUL_DACT, true>(g, st)));
     // dX = dI1 (diag(y) W1a + W1b)^T ; dbx partials
     g.A = ws + W.dI1; g.Wp = ws + W.w1aT_p; g.Wp2 = ws + W.w1bT_p; g.y = y; g.ldy = d;
     g.out = dX_i; g.aux = nullptr;
     g.colsum_part = ws + W.dbx_part + (size_t)i * B * nrb * d;
-    CK((kb_gemm_launch<A_PLAIN, B_YMIX_COL, E_PLAIN, true>(g, st)));
+    CK((kb_gemm<A_PLAIN, B_YMIX_COL, E_PLAIN, true>(g, st)));
     // S_b = X_b^T dI1_b -> dW1a / dW1b slabs and dy partials
     {
       SbP q;
@@ -786,7 +800,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     g.e_bits = kb_bits;
     g.accumulate = (i != p - 1);
     g.colsum_part = nullptr;
-    CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_DKB, false>(g, st)));
+    CK((kb_gemm<A_PLAIN, B_PLAIN, E_DKB, false>(g, st)));
     // dy -> d(md) -> dL/d m_{i-1} = dwin[:, :d] + (dy Wy^T) * memmask * readmask
     float* DYi = ws + W.DY + (size_t)i * Bd;
     hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dy_part), 2 * d / 128, Bd, DYi);
@@ -1019,10 +1033,15 @@ int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows, cons
   return MACX_OK;
 }
 
-int macx_pack_weight(const float* Wt, int K, int n_out, int transpose, float* out, void* stream) {
+int macx_pack_weight(const float* Wt, int K, int n_out, int flags, float* out, void* stream) {
+  const int transpose = flags;
   if (!Wt || !out || K < 16 || K % 16 || n_out < 16 || n_out % 16) return MACX_EINVAL;
-  if (transpose) CK(pack(Wt, 1, K, K, n_out, out, (hipStream_t)stream));
-  else CK(pack(Wt, n_out, 1, K, n_out, out, (hipStream_t)stream));
+  const int fmt = transpose >> 1;      // bits 1..: pack format (0 fp32 MFMA layout, 1 split-bf16 planes, 2 fp32 k-major tiles)
+  if (fmt < 0 || fmt > 2 || (fmt && K % 32)) return MACX_EINVAL;
+  Packer pk;
+  if (transpose & 1) pk.add(Wt, 1, K, K, n_out, out, -1, -1, fmt);
+  else pk.add(Wt, n_out, 1, K, n_out, out, -1, -1, fmt);
+  CK(pk.run((hipStream_t)stream));
   return MACX_OK;
 }
 
@@ -1047,7 +1066,7 @@ int macx_kb_project(const macx_shapes* s, const macx_dropout* dp, int step, cons
     CK(hipGetLastError());
     g.A = bits_ws;
   }
-  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  CK((kb_gemm<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));     // Wp: pack format 1 (split mode) or 0
   return MACX_OK;
 }
 
@@ -1227,7 +1246,7 @@ StemLayout make_stem(const macx_stem_shapes* s) {
   size_t off = 0;
   auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
   const size_t B = s->B, Ci = s->Cin, Cm = s->Cmid, Co = s->Cout;
-  L.k0_p = take(9 * Ci * Cm); L.k1_p = take(9 * Cm * Co);
+  L.k0_p = take(wsize(9 * Ci, Cm)); L.k1_p = take(wsize(9 * Cm, Co));
   L.in0p = take(B * g.np * Ci); L.X1 = take(B * g.N * Cm); L.in1p = take(B * g.np * Cm);
   L.bits1 = take(B * g.N * Cm / 32 + 8);
   L.total = off;
@@ -1258,7 +1277,7 @@ StemBwdLayout make_stem_bwd(const macx_stem_shapes* s) {
   size_t off = 0;
   auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
   const size_t B = s->B, Ci = s->Cin, Cm = s->Cmid, Co = s->Cout;
-  L.k1T_p = take(9 * Co * Cm);
+  L.k1T_p = take(wsize(9 * Co, Cm));
   L.dY2 = take(B * g.N * Co); L.dY2p = take(B * g.np * Co); L.dY1 = take(B * g.N * Cm);
   L.ns0 = conv_splits((int)(9 * Ci / T_TILE * (Cm / T_TILE)), (int)(B * g.N));
   L.ns1 = conv_splits((int)(9 * Cm / T_TILE * (Co / T_TILE)), (int)(B * g.N));
@@ -1316,8 +1335,8 @@ int macx_stem_forward(const macx_stem_shapes* s, int act, float keep, uint32_t s
   const StemGeo geo = stem_geo(s);
   const int Ci = s->Cin, Cm = s->Cmid, Co = s->Cout;
   Packer pk;
-  pk.add(P->kernel0, Cm, 1, 9 * Ci, Cm, saved + L.k0_p);     // HWIO flattened = [9*Cin][Cmid] row-major
-  pk.add(P->kernel1, Co, 1, 9 * Cm, Co, saved + L.k1_p);
+  pk.add(P->kernel0, Cm, 1, 9 * Ci, Cm, saved + L.k0_p, -1, -1, wfmt_plain());     // HWIO flattened = [9*Cin][Cmid] row-major
+  pk.add(P->kernel1, Co, 1, 9 * Cm, Co, saved + L.k1_p, -1, -1, wfmt_plain());
   CK(pk.run(st));
   PadP q0{s->B, geo.N, s->W, geo.wp, geo.np, Ci};
   PadP q1{s->B, geo.N, s->W, geo.wp, geo.np, Cm};
@@ -1326,13 +1345,13 @@ int macx_stem_forward(const macx_stem_shapes* s, int act, float keep, uint32_t s
   GemmP g;
   conv_gemm_params(g, s, geo, saved + L.in0p, Ci, Cm, +1);
   g.Wp = saved + L.k0_p; g.out = saved + L.X1; g.bias = P->bias0; g.act = act;
-  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  CK((kb_gemm<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
   // cnn_1
   CK(launch_pad_drop(saved + L.X1, q1, keep, seed, SITE_STEM1, (uint32_t)((size_t)s->b0 * geo.N * Cm), saved + L.in1p,
                      reinterpret_cast<uint32_t*>(saved + L.bits1), st));
   conv_gemm_params(g, s, geo, saved + L.in1p, Cm, Co, +1);
   g.Wp = saved + L.k1_p; g.out = kb; g.bias = P->bias1; g.act = act;
-  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  CK((kb_gemm<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
   return MACX_OK;
 }
 
@@ -1352,7 +1371,8 @@ int macx_stem_backward(const macx_stem_shapes* s, int act, float keep, uint32_t 
   {
     Packer pk;
     for (int tap = 0; tap < 9; ++tap)
-      pk.add(P->kernel1 + (size_t)tap * Cm * Co, 1, Co, Co, Cm, ws + W.k1T_p + (size_t)tap * Co * Cm);
+      pk.add(P->kernel1 + (size_t)tap * Cm * Co, 1, Co, Co, Cm, ws + W.k1T_p + (size_t)tap * (gemm_split_mode() ? wsize(Co, Cm) : (size_t)Co * Cm), -1, -1,
+             wfmt_plain());
     CK(pk.run(st));
   }
   // dY2 = d_kb * act'(kb)
@@ -1366,7 +1386,7 @@ int macx_stem_backward(const macx_stem_shapes* s, int act, float keep, uint32_t 
   conv_gemm_params(g, s, geo, ws + W.dY2p, Co, Cm, -1);
   g.Wp = ws + W.k1T_p; g.out = ws + W.dY1; g.aux = saved + L.X1; g.act = act;
   if (keep < 1.0f) { g.e_bits = reinterpret_cast<const uint32_t*>(saved + L.bits1); g.e_inv_keep = 1.0f / keep; }
-  CK((kb_gemm_launch<A_PLAIN, B_PLAIN, E_MUL_DACT, false>(g, st)));
+  CK((kb_gemm<A_PLAIN, B_PLAIN, E_MUL_DACT, false>(g, st)));
   CK(rowsum(ws + W.dY1, M, Cm, Cm, G->bias0, st));
   CKI(conv_wgrad(s, geo, saved + L.in0p, Ci, ws + W.dY1, Cm, W.ns0, ws + W.slab0, G->kernel0, st));
   return MACX_OK;
@@ -1573,9 +1593,15 @@ int macx_adam_ema_step(size_t n, float* params, const float* grads, float* m, fl
 }
 
 /* test/tuning hook: key 0 = waves per workgroup of the kb GEMM (4 or 8) */
+int macx_gemm_mode(int mode) {
+  if (mode == MACX_GEMM_NATIVE || mode == MACX_GEMM_SPLIT) gemm_split_mode() = mode;
+  return gemm_split_mode();
+}
+
 int macx_debug_set(int key, int value) {
   if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }
   if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
+  if (key == 3 && (value == 0 || value == 1)) { gemm_split_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;
 }

@@ -82,7 +82,7 @@ struct GemmP {
   const uint32_t* e_bits; // E_I2_LOGIT: keep bits of act(I2*c) [B*N][Nout/32]; E_DKB: keep bits of KB; null = keep all
   float e_inv_keep;
   int accumulate;         // E_DKB: 1 -> out += , 0 -> out =
-  int dbg;                // measurement knobs (macx_debug_set(1, mask)): 1 skip epilogue, 2 skip in-loop staging, 4 plain (not write-through) stores, 8 no epilogue stores
+  int dbg;                // measurement knobs (macx_debug_set(1, mask)): 1 skip epilogue, 2 skip in-loop staging, 4 write-through stores (unsafe, see epilogue), 8 no epilogue stores
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -98,7 +98,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): the 64 lanes of a wave fetch 64 x 16 B from
 // per-lane global addresses into LDS at wave_base + lane*16.  No VGPR round trip, no ds_write.
 // 16-byte global store, plain or write-through (sc0 sc1: the bytes leave the XCD's L2 as they are issued instead of in
-// the end-of-kernel write-back burst; MI355X_MICROARCH "publish-large")
+// the end-of-kernel write-back burst; MI355X_MICROARCH "publish-large").  Timing experiment only.
 __device__ __forceinline__ void store16(float* g, f32x4 v, bool wt) {
   if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g), "v"(v) : "memory");
   else *reinterpret_cast<f32x4*>(g) = v;
@@ -116,6 +116,117 @@ constexpr int kb_gemm_lds_floats() {
   constexpr int stage = 2 * RT * 16 * G_LDA + 2 * G_BK * 16 * NW;
   constexpr int epi = RT * 16 * (16 * NW + 4) + 256 * NW;   // tile + [16 row groups][4 NW float4] column partials
   return stage > epi ? stage : epi;
+}
+
+// ---- epilogue, step 2 (shared by the fp32 and the split-bf16 kernels): the workgroup's accumulators sit row-major in
+// LDS (T[ROWS][G_BN + 4]); one float4 per lane, one row per CG lanes.
+template <int RT, int NW, int EP, bool COLSUM>
+__device__ __forceinline__ void kb_epilogue_rows(const GemmP& p, float* smem, int b, int cb, int rbi, int nrb, int row0, int row_end) {
+  constexpr int G_THREADS = 64 * NW;
+  constexpr int G_BN = 16 * NW;
+  constexpr int G_LDT = G_BN + 4;
+  constexpr int CG = G_BN / 4;
+  constexpr int RG = G_THREADS / CG;
+  constexpr int ROWS = RT * 16;
+  const int tid = threadIdx.x;
+  float* T = smem;
+  f32x4* red = reinterpret_cast<f32x4*>(smem + ROWS * G_LDT);   // [RG][CG] column partials
+  // ---- step 2: row-major pass, one float4 per lane, one row per half-wave
+  const int c4 = tid % CG;
+  const int rg = tid / CG;
+  const int col = cb * G_BN + c4 * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, cj = bias4, wj = bias4, drj = bias4;
+  if (EP == E_BIAS_ACT || EP == E_I2_LOGIT) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+  if (EP == E_I2_LOGIT) {
+    cj = *reinterpret_cast<const f32x4*>(p.cvec + (size_t)b * p.Nout + col);
+    wj = *reinterpret_cast<const f32x4*>(p.wvec + col);
+  }
+  if (EP == E_DKB) drj = *reinterpret_cast<const f32x4*>(p.aux + (size_t)b * p.ld_aux + col);
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  // dbg 4: write-through (sc0 sc1) output stores.  Measured -3.7 us per launch, but a following kernel on another XCD was
+  // observed reading stale lines (tests/test_gpu_stem.py, intermittent) -> experiment only, never the default.
+  const bool wt = (p.dbg & 4) != 0;
+  const int wpr = p.Nout >> 5;   // mask words per output row
+  // every global operand the epilogue needs (activation outputs for act', the running dKB, mask words,
+  // attention weights) is requested for ALL of this thread's rows before the first one is used: RT
+  // independent loads in flight instead of RT serial round trips
+  f32x4 auxv[RT];
+  uint32_t bitv[RT];
+  float attv[RT];
+  if (EP == E_MUL_DACT || EP == E_DKB || EP == E_I2_LOGIT) {
+#pragma unroll
+    for (int it = 0; it < RT; ++it) {
+      const int n = row0 + rg + it * RG;
+      const size_t orow = (size_t)b * p.N + min(n, row_end - 1);
+      if (EP == E_MUL_DACT) {
+        auxv[it] = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + col);
+        bitv[it] = p.e_bits ? p.e_bits[orow * wpr + (col >> 5)] >> (col & 31) : 0xFu;
+      }
+      if (EP == E_DKB) {
+        auxv[it] = p.accumulate ? *reinterpret_cast<const f32x4*>(p.out + orow * p.ldo + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        attv[it] = p.att[orow];
+        bitv[it] = p.e_bits ? p.e_bits[orow * (p.ldo >> 5) + (col >> 5)] >> (col & 31) : 0xFu;
+      }
+      if (EP == E_I2_LOGIT) bitv[it] = p.e_bits ? p.e_bits[orow * wpr + (col >> 5)] >> (col & 31) : 0xFu;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < RT; ++it) {
+    const int lrow = rg + it * RG;
+    const int n = row0 + lrow;
+    const bool ok = n < row_end && !(p.dbg & 8);     // dbg 8: timing experiment, epilogue without its global stores
+    const size_t orow = (size_t)b * p.N + (n < row_end ? n : row_end - 1);
+    f32x4 val = *reinterpret_cast<const f32x4*>(T + lrow * G_LDT + c4 * 4);
+    float* optr = p.out + orow * p.ldo + col;
+    if (EP == E_BIAS_ACT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] = act_apply(p.act, val[e] + bias4[e]);
+      if (ok) store16(optr, val, wt);
+    } else if (EP == E_I2_LOGIT) {
+      val += bias4;
+      if (ok) store16(optr, val, wt);
+      // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w   (bias b_k added in kb_attend)
+      const uint32_t bits = bitv[it];
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g = act_apply(p.act, val[e] * cj[e]);
+        g = ((bits >> e) & 1u) ? g * p.e_inv_keep : 0.f;
+        part = fmaf(g, wj[e], part);
+      }
+      // the CG lanes of one row are contiguous and CG-aligned inside a wave
+#pragma unroll
+      for (int o = CG / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+      if (c4 == 0 && ok) p.logit_part[(size_t)cb * p.B * p.N + orow] = part;
+    } else if (EP == E_MUL_DACT) {
+      const f32x4 h = auxv[it];
+      const uint32_t bits = bitv[it];      // optional dropout mask of the tensor this gradient flows into
+      const float ik = p.e_bits ? p.e_inv_keep : 1.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] *= ((bits >> e) & 1u) ? act_grad_from_out(p.act, h[e]) * ik : 0.f;
+      if (ok) store16(optr, val, wt);
+    } else if (EP == E_PLAIN) {
+      if (ok) store16(optr, val, wt);
+    } else if (EP == E_DKB) {
+      const uint32_t bits = bitv[it];
+      const float a = attv[it];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] = (((bits >> e) & 1u) ? val[e] * p.e_inv_keep : 0.f) + a * drj[e];
+      val += auxv[it];
+      if (ok) store16(optr, val, wt);
+    }
+    if (COLSUM && ok) csum += val;
+  }
+  if (COLSUM) {
+    red[rg * CG + c4] = csum;
+    __syncthreads();
+    if (tid < CG) {
+      f32x4 t = red[tid];
+#pragma unroll
+      for (int g = 1; g < RG; ++g) t += red[g * CG + tid];
+      *reinterpret_cast<f32x4*>(p.colsum_part + (size_t)(b * nrb + rbi) * p.Nout + cb * G_BN + tid * 4) = t;
+    }
+  }
 }
 
 template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>
@@ -287,113 +398,20 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   // ---- epilogue, step 1: accumulators -> row-major LDS tile.
   // 16x16 accumulator map: col = lane & 15, row = (lane >> 4) * 4 + reg
   float* T = smem;                              // [ROWS][G_LDT]
-  f32x4* red = reinterpret_cast<f32x4*>(smem + ROWS * G_LDT);   // [RG][CG] column partials
 #pragma unroll
   for (int r = 0; r < RT; ++r)
 #pragma unroll
     for (int e = 0; e < 4; ++e) T[(r * 16 + (lane >> 4) * 4 + e) * G_LDT + wave * 16 + (lane & 15)] = acc[r][e];
   __syncthreads();
 
-  // ---- step 2: row-major pass, one float4 per lane, one row per half-wave
-  const int c4 = tid % CG;
-  const int rg = tid / CG;
-  const int col = cb * G_BN + c4 * 4;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, cj = bias4, wj = bias4, drj = bias4;
-  if (EP == E_BIAS_ACT || EP == E_I2_LOGIT) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
-  if (EP == E_I2_LOGIT) {
-    cj = *reinterpret_cast<const f32x4*>(p.cvec + (size_t)b * p.Nout + col);
-    wj = *reinterpret_cast<const f32x4*>(p.wvec + col);
-  }
-  if (EP == E_DKB) drj = *reinterpret_cast<const f32x4*>(p.aux + (size_t)b * p.ld_aux + col);
-  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-  const bool wt = !(p.dbg & 4);     // write-through output stores (dbg 4: plain stores, for comparison)
-  const int wpr = p.Nout >> 5;   // mask words per output row
-  // every global operand the epilogue needs (activation outputs for act', the running dKB, mask words,
-  // attention weights) is requested for ALL of this thread's rows before the first one is used: RT
-  // independent loads in flight instead of RT serial round trips
-  f32x4 auxv[RT];
-  uint32_t bitv[RT];
-  float attv[RT];
-  if (EP == E_MUL_DACT || EP == E_DKB || EP == E_I2_LOGIT) {
-#pragma unroll
-    for (int it = 0; it < RT; ++it) {
-      const int n = row0 + rg + it * RG;
-      const size_t orow = (size_t)b * p.N + min(n, row_end - 1);
-      if (EP == E_MUL_DACT) {
-        auxv[it] = *reinterpret_cast<const f32x4*>(p.aux + orow * p.ldo + col);
-        bitv[it] = p.e_bits ? p.e_bits[orow * wpr + (col >> 5)] >> (col & 31) : 0xFu;
-      }
-      if (EP == E_DKB) {
-        auxv[it] = p.accumulate ? *reinterpret_cast<const f32x4*>(p.out + orow * p.ldo + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        attv[it] = p.att[orow];
-        bitv[it] = p.e_bits ? p.e_bits[orow * (p.ldo >> 5) + (col >> 5)] >> (col & 31) : 0xFu;
-      }
-      if (EP == E_I2_LOGIT) bitv[it] = p.e_bits ? p.e_bits[orow * wpr + (col >> 5)] >> (col & 31) : 0xFu;
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < RT; ++it) {
-    const int lrow = rg + it * RG;
-    const int n = row0 + lrow;
-    const bool ok = n < row_end && !(p.dbg & 8);     // dbg 8: timing experiment, epilogue without its global stores
-    const size_t orow = (size_t)b * p.N + (n < row_end ? n : row_end - 1);
-    f32x4 val = *reinterpret_cast<const f32x4*>(T + lrow * G_LDT + c4 * 4);
-    float* optr = p.out + orow * p.ldo + col;
-    if (EP == E_BIAS_ACT) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) val[e] = act_apply(p.act, val[e] + bias4[e]);
-      if (ok) store16(optr, val, wt);
-    } else if (EP == E_I2_LOGIT) {
-      val += bias4;
-      if (ok) store16(optr, val, wt);
-      // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w   (bias b_k added in kb_attend)
-      const uint32_t bits = bitv[it];
-      float part = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float g = act_apply(p.act, val[e] * cj[e]);
-        g = ((bits >> e) & 1u) ? g * p.e_inv_keep : 0.f;
-        part = fmaf(g, wj[e], part);
-      }
-      // the CG lanes of one row are contiguous and CG-aligned inside a wave
-#pragma unroll
-      for (int o = CG / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-      if (c4 == 0 && ok) p.logit_part[(size_t)cb * p.B * p.N + orow] = part;
-    } else if (EP == E_MUL_DACT) {
-      const f32x4 h = auxv[it];
-      const uint32_t bits = bitv[it];      // optional dropout mask of the tensor this gradient flows into
-      const float ik = p.e_bits ? p.e_inv_keep : 1.0f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) val[e] *= ((bits >> e) & 1u) ? act_grad_from_out(p.act, h[e]) * ik : 0.f;
-      if (ok) store16(optr, val, wt);
-    } else if (EP == E_PLAIN) {
-      if (ok) store16(optr, val, wt);
-    } else if (EP == E_DKB) {
-      const uint32_t bits = bitv[it];
-      const float a = attv[it];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) val[e] = (((bits >> e) & 1u) ? val[e] * p.e_inv_keep : 0.f) + a * drj[e];
-      val += auxv[it];
-      if (ok) store16(optr, val, wt);
-    }
-    if (COLSUM && ok) csum += val;
-  }
-  if (COLSUM) {
-    red[rg * CG + c4] = csum;
-    __syncthreads();
-    if (tid < CG) {
-      f32x4 t = red[tid];
-#pragma unroll
-      for (int g = 1; g < RG; ++g) t += red[g * CG + tid];
-      *reinterpret_cast<f32x4*>(p.colsum_part + (size_t)(b * nrb + rbi) * p.Nout + cb * G_BN + tid * 4) = t;
-    }
-  }
+  kb_epilogue_rows<RT, NW, EP, COLSUM>(p, smem, b, cb, rbi, nrb, row0, row_end);
 }
 
 // ---- host-side launcher ---------------------------------------------------------------------
 // runtime knob (macx_debug_set(0, NW)): waves per workgroup of the kb GEMM, 4 or 8
 inline int& kb_gemm_nw() { static int nw = 8; return nw; }
 inline int& kb_gemm_dbg() { static int m = 0; return m; }
+inline int& gemm_split_mode() { static int m = 1; return m; }   // 1: knowledge-base GEMMs on the split-bf16 kernel (macx_gemm6.cuh)
 inline int& kb_gemm_force_rt() { static int rt = 0; return rt; }   // tuning override (macx_debug_set key 2)
 
 template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>

@@ -26,19 +26,44 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int 
 }
 
 // several weights in one launch (blockIdx.y selects the descriptor)
-struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; };   // zero fill for k >= k_src or j >= n_src
+//   fmt 0: dst[Q][g][j][e] fp32 (16x16x4 f32 MFMA kernels, small linears)
+//   fmt 1: dst[kt][plane][j][32] bf16 -- the exact 3-way bf16 split of W (macx_gemm6.cuh, B_PLAIN); K*Nout*3/2 floats
+//   fmt 2: dst[kt][j][32] fp32 k-major tiles (macx_gemm6.cuh, B_YMIX_*: mixed in fp32, split while staging)
+struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; int fmt; };   // zero fill for k >= k_src or j >= n_src
 constexpr int PACK_MAX = 40;
 struct PackList { PackDesc d[PACK_MAX]; };
 __global__ void pack_weights_kernel(PackList L) {
   const PackDesc q = L.d[blockIdx.y];
   const size_t total = (size_t)q.K * q.Nout;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int e = i & 3;
-    const size_t t = i >> 2;
-    const int j = t % q.Nout;
-    const size_t qg = t / q.Nout;
-    const int k = 16 * (int)(qg >> 2) + 4 * (int)(qg & 3) + e;
-    q.dst[i] = (k < q.k_src && j < q.n_src) ? q.src[(size_t)k * q.ld_k + (size_t)j * q.ld_j] : 0.f;
+    if (q.fmt == 0) {
+      const int e = i & 3;
+      const size_t t = i >> 2;
+      const int j = t % q.Nout;
+      const size_t qg = t / q.Nout;
+      const int k = 16 * (int)(qg >> 2) + 4 * (int)(qg & 3) + e;
+      q.dst[i] = (k < q.k_src && j < q.n_src) ? q.src[(size_t)k * q.ld_k + (size_t)j * q.ld_j] : 0.f;
+    } else {
+      const int kk = i & 31;
+      const size_t t = i >> 5;
+      const int j = t % q.Nout;
+      const int kt = (int)(t / q.Nout);
+      const int k = kt * 32 + kk;
+      const float x = (k < q.k_src && j < q.n_src) ? q.src[(size_t)k * q.ld_k + (size_t)j * q.ld_j] : 0.f;
+      if (q.fmt == 2) {
+        q.dst[i] = x;
+      } else {
+        // x = h1 + h2 + h3 exactly (round-to-nearest residual chain, the same split the kernel applies to A)
+        const __bf16 h1 = (__bf16)x;
+        const float r1 = x - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const __bf16 h3 = (__bf16)(r1 - (float)h2);
+        __bf16* d = reinterpret_cast<__bf16*>(q.dst);
+        const size_t plane = (size_t)q.Nout * 32;
+        const size_t o = ((size_t)kt * 3 * q.Nout + j) * 32 + kk;
+        d[o] = h1; d[o + plane] = h2; d[o + 2 * plane] = h3;
+      }
+    }
   }
 }
 

@@ -24,3 +24,12 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def native_gemm(macx):
+    """Run one test on the native f32-MFMA knowledge-base GEMM (the default is the split-bf16 kernel); restored afterwards."""
+    L = macx._lib.lib()
+    L.macx_gemm_mode(0)
+    yield
+    L.macx_gemm_mode(1)

@@ -128,6 +128,12 @@ def test_stepwise_final_state_carries_gradient(macx, dev):
     assert torch.equal(params.projX_W.grad, params2.projX_W.grad)
 
 
+def test_native_gemm_mode_matches_oracle(macx, dev, native_gemm):
+    """The same forward/backward parity with the knowledge-base GEMMs on the native f32 MFMA kernel."""
+    test_backward_matches_oracle_autograd(macx, dev, "args", 3, 7, 196, 128, 2, True)
+    test_forward_stepwise_matches_oracle(macx, dev, "args4", 2, 5, 49, 128, 2, True)
+
+
 def test_headline_shape_forward_backward(macx, dev):
     """BASELINE configs[1] shape (B=64,S=50,N=196,d=512,p=4): parity vs the fp32 oracle + invariants."""
     cfg, vq, words, lengths, kb = make_case("args", 64, 50, 196, 512, 4)

@@ -55,8 +55,18 @@ def test_linear(macx, dev, rows, k1, k2, nout, act):
 
 @pytest.mark.parametrize("B,N,d,keep", [(4, 196, 128, 1.0), (3, 196, 256, 0.85), (5, 49, 128, 0.85), (2, 14, 128, 0.5),
                                         (2, 100, 128, 0.85), (2, 300, 128, 1.0), (2, 30, 128, 0.85), (1, 250, 256, 0.85)])
-def test_kb_project(macx, dev, B, N, d, keep):
-    """X = dropout(KB) Wx + bx through the MFMA kernel vs fp64, asymmetric W (transpose-detecting)."""
+@pytest.mark.parametrize("mode", [1, 0])
+def test_kb_project(macx, dev, B, N, d, keep, mode):
+    """X = dropout(KB) Wx + bx through the MFMA kernels (split-bf16 and native f32) vs fp64, asymmetric W (transpose-detecting)."""
+    L = macx._lib.lib()
+    L.macx_gemm_mode(mode)
+    try:
+        _kb_project_case(macx, dev, B, N, d, keep)
+    finally:
+        L.macx_gemm_mode(1)
+
+
+def _kb_project_case(macx, dev, B, N, d, keep):
     L = macx._lib.lib()
     g = torch.Generator().manual_seed(2)
     kb = torch.randn(B, N, d, generator=g)
@@ -65,15 +75,47 @@ def test_kb_project(macx, dev, B, N, d, keep):
     sh = macx._lib.MacxShapes(B=B, S=1, N=N, d=d, p=1, b0=3)
     dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=keep, keep_write=1.0, seed=99)
     out = torch.empty(B, N, d, device=dev)
-    wp = torch.empty(d * d, device=dev)
+    wp = torch.empty(2 * d * d, device=dev)
     kbd, Wd, bd = kb.to(dev), W.to(dev), b.to(dev)
-    macx._lib.check(L.macx_pack_weight(_p(Wd), d, d, 0, _p(wp), None), "pack")
+    macx._lib.check(L.macx_pack_weight(_p(Wd), d, d, macx._lib.kb_pack_flags(), _p(wp), None), "pack")
     bits = torch.empty(B * N * d + B * N * d // 32 + 4, device=dev)
     macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 5, _p(kbd), _p(wp), _p(bd), _p(out), _p(bits), None), "kb_project")
     torch.cuda.synchronize()
     mask = torch.from_numpy(dh.mask_for(99, dh.SITE_READ_KB, 5, keep, (B, N, d), b0=3)).double()
     ref = ((kb.double() / keep) * mask) @ W.double() + b.double()
     assert rel_err(out, ref) < 2e-6
+
+
+def test_split_gemm_error_is_fp32_class(macx, dev):
+    """The split-bf16 kernel (3 exact bf16 pieces per operand, 6 MFMA terms, fp32 accumulate) against fp64, next to the
+    native f32-MFMA kernel on the same data: error per unit of sum|a*b| no larger than 1.5x the native kernel's, over wide
+    dynamic range (1e-30 .. 3e20 entries, fp16-overflowing values, exact zeros)."""
+    L = macx._lib.lib()
+    B, N, d = 6, 196, 512
+    g = torch.Generator().manual_seed(4)
+    kb = torch.randn(B, N, d, generator=g) * torch.exp(4 * torch.randn(B, N, 1, generator=g))
+    kb[0, 0, :8] = torch.tensor([1e-30, -3e20, 1.0, -1.0, 65504.0, 1e-8, 3.14159274, 0.0])
+    W = torch.randn(d, d, generator=g) / 22
+    b = torch.randn(d, generator=g)
+    ref = kb.double().reshape(-1, d) @ W.double() + b.double()
+    scale = kb.double().abs().reshape(-1, d) @ W.double().abs() + b.double().abs() + 1e-300
+    sh = macx._lib.MacxShapes(B=B, S=1, N=N, d=d, p=1, b0=0)
+    dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=1)
+    err = {}
+    try:
+        for mode in (0, 1):
+            L.macx_gemm_mode(mode)
+            wp = torch.zeros(2 * d * d, device=dev)
+            out = torch.empty(B, N, d, device=dev)
+            macx._lib.check(L.macx_pack_weight(_p(W.to(dev)), d, d, macx._lib.kb_pack_flags(), _p(wp), None), "pack")
+            macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 0, _p(kb.to(dev)), _p(wp), _p(b.to(dev)), _p(out), None, None), "proj")
+            torch.cuda.synchronize()
+            e = (out.cpu().double().reshape(-1, d) - ref).abs() / scale
+            err[mode] = (float(e.max()), float(e.mean()))
+    finally:
+        L.macx_gemm_mode(1)
+    assert err[1][0] < 1e-6 and err[1][1] < 5e-8, err
+    assert err[1][0] <= 1.5 * err[0][0] and err[1][1] <= 1.5 * err[0][1], err
 
 
 def test_control_attend(macx, dev):

@@ -20,8 +20,8 @@ def main():
     B, N, d = args.B, 196, 512
     p = lambda t: C.c_void_p(t.data_ptr())
     kb = torch.randn(B, N, d, device=dev); W = torch.randn(d, d, device=dev) / 22; b = torch.randn(d, device=dev)
-    wp = torch.empty(d * d, device=dev); out = torch.empty(B, N, d, device=dev); bits = torch.empty(B * N * d + B * N * d // 32, device=dev)
-    L.macx_pack_weight(p(W), d, d, 0, p(wp), None)
+    wp = torch.empty(2 * d * d, device=dev); out = torch.empty(B, N, d, device=dev); bits = torch.empty(B * N * d + B * N * d // 32, device=dev)
+    L.macx_pack_weight(p(W), d, d, macx._lib.kb_pack_flags(), p(wp), None)
     sh = macx._lib.MacxShapes(B=B, S=50, N=N, d=d, p=12, b0=0)
     flops = 2.0 * B * N * d * d
     for nw in (4, 8):
@@ -35,7 +35,7 @@ def main():
     for dbg in (0, 1, 2, 3, 4, 8):
         L.macx_debug_set(1, dbg)
         us = timeit(lambda: L.macx_kb_project(C.byref(sh), C.byref(dp), 0, p(kb), p(wp), p(b), p(out), p(bits), None))
-        print("kb_project NW=8 dbg=%d (1 no epilogue, 2 no staging, 4 plain stores, 8 no epilogue stores): %8.1f us  %6.1f TF" % (dbg, us, flops / us / 1e6))
+        print("kb_project NW=8 dbg=%d (1 no epilogue, 2 no staging, 4 write-through stores, 8 no epilogue stores): %8.1f us  %6.1f TF" % (dbg, us, flops / us / 1e6))
     L.macx_debug_set(1, 0)
     M = B * N
     A = torch.randn(M, d, device=dev); G = torch.randn(M, d, device=dev)
