@@ -16,15 +16,20 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmacx.so")
 STAMP = LIB_PATH + ".stamp"
 SOURCES = ["macx_api.hip"]
-HEADERS = ["macx_common.cuh", "macx_gemm.cuh", "macx_gemm_tn.cuh", "macx_small.cuh", os.path.join(ROOT, "include", "macx.h")]
 
 
 def _digest():
+    """sha256 over every file the translation unit can include: all of csrc/ and include/ (a fixed header list once let
+    edits to a newly added header go unbuilt)."""
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
-        p = f if os.path.isabs(f) else os.path.join(CSRC, f)
-        with open(p, "rb") as fh:
-            h.update(fh.read())
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    inc = os.path.join(ROOT, "include")
+    files += [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
+    for p in files:
+        if os.path.isfile(p):
+            h.update(os.path.basename(p).encode())
+            with open(p, "rb") as fh:
+                h.update(fh.read())
     return h.hexdigest()
 
 

@@ -10,6 +10,7 @@
 #include "macx_gemm.cuh"
 #include "macx_gemm6.cuh"
 #include "macx_gemm_tn.cuh"
+#include "macx_wgrad6.cuh"
 #include "macx_small.cuh"
 
 using namespace macx;
@@ -37,6 +38,9 @@ inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
 inline int wfmt_plain() { return gemm_split_mode() ? 1 : 0; }
 inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
 inline size_t wsize(size_t K, size_t n) { return K * n * 3 / 2; }
+inline hipError_t wgrad_any(const TnP& t, hipStream_t st) {
+  return (gemm_split_mode() && !(kb_gemm_dbg() & 128)) ? wgrad6_launch(t, st) : wgrad_tn_launch<A_PLAIN>(t, st);   // dbg 128: f32 TN kernel
+}
 template <int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm(const GemmP& g, hipStream_t st) {
   return gemm_split_mode() ? kb_gemm6_launch<AP, BP, EP, COLSUM>(g, st) : kb_gemm_launch<AP, BP, EP, COLSUM>(g, st);
@@ -349,7 +353,7 @@ int wgrad_impl(const float* A, int lda, const float* G, int ldg, int M, int Kd, 
   t.rows_per_split = rows_per_split(M, t.nsplit);
   t.A = A; t.lda = lda; t.a_mod = M; t.G = G; t.ldg = ldg;
   t.part = (t.nsplit == 1) ? out : ws;
-  CK(wgrad_tn_launch<A_PLAIN>(t, st));
+  CK(wgrad_any(t, st));
   if (t.nsplit > 1) CK(slab_reduce_launch(ws, t.nsplit, (size_t)Kd * Jd, out, 0, st));
   return 0;
 }
@@ -999,12 +1003,12 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(t.M, t.nsplit);
     t.A = saved + L.H1; t.lda = d; t.a_mod = t.M; t.G = ws + W.dI2; t.ldg = d;
     t.part = ws + W.slab_w2;
-    CK(wgrad_tn_launch<A_PLAIN>(t, st));
+    CK(wgrad_any(t, st));
     if (rdrop) { t.A = saved + L.KBd; t.a_mod = t.M; }          // the dropped KB of every step was kept
     else { t.A = in->knowledgeBase; t.a_mod = B * N; }          // no dropout: the same KB each step
     t.G = ws + W.dX;
     t.part = ws + W.slab_wx;
-    CK(wgrad_tn_launch<A_PLAIN>(t, st));
+    CK(wgrad_any(t, st));
   }
   CK(slab_reduce_launch(ws + W.slab_w2, (int)W.ns_big, dd, GP->memKbProj2_W, 0, st));
   CK(slab_reduce_launch(ws + W.slab_wx, (int)W.ns_big, dd, GP->projX_W, 0, st));
@@ -1316,7 +1320,7 @@ int conv_wgrad(const macx_stem_shapes* s, const StemGeo& geo, const float* Apad,
   t.magic_n = (uint32_t)(((1ull << 32) + geo.N - 1) / geo.N);
   t.magic_w = (uint32_t)(((1ull << 32) + s->W - 1) / s->W);
   t.part = (ns == 1) ? out : slab;
-  CK(wgrad_tn_launch<A_PLAIN>(t, st));
+  CK(wgrad_any(t, st));
   if (ns > 1) CK(slab_reduce_launch(slab, ns, (size_t)t.Kd * t.Jd, out, 0, st));
   return 0;
 }

@@ -12,8 +12,9 @@
 // Tiling is the same per-question tiling as macx_gemm.cuh (RT*16 rows of one question x 128 columns, 8 waves), with
 // the waves arranged 2 (row halves) x 4 (32-column groups) so that an A fragment read from LDS feeds two MFMAs
 // (three bf16 planes per operand make LDS fragment traffic, not the matrix pipe, the next limit otherwise).
-//   LDS stage:  A planes [3][ROWS][32] bf16 (64 B rows: a wave's 16-row fragment block is 1 KB contiguous, no conflicts)
-//               B planes [3][128 cols][32] bf16 (k-major per column: fragment = 16 B per lane)
+//   LDS stage:  A planes [3][4 k-groups][ROWS] x 16 B (8 bf16 of one row); B planes [3][4 k-groups][128 cols] x 16 B.
+//               A fragment = lane (i, g) reads slot [g][row0 + i]: the 16 lanes of a k-group read 256 contiguous bytes
+//               (conflict-free b128); the k-group stride is padded by 32 B so the staging writes spread over all banks.
 //   weights:    B_PLAIN   -> pre-split planes  Wb[K/32][3][Nout][32] bf16      (pack format 1)
 //               B_YMIX_*  -> fp32 k-major tiles Wt[K/32][Nout][32]             (pack format 2), mixed with the
 //                            per-question vector in fp32, then split while staging
@@ -62,7 +63,7 @@ constexpr size_t gemm6_plane_floats(size_t K, size_t Nout) { return K * Nout * 3
 template <int RT>
 constexpr int kb_gemm6_lds_bytes() {
   constexpr int ROWS = RT * 16;
-  constexpr int stage = 3 * ROWS * 64 + 3 * 128 * 64;
+  constexpr int stage = 3 * 4 * (ROWS * 16 + 32) + 3 * 4 * (128 * 16 + 32);
   constexpr int epi = (ROWS * (128 + 4) + 256 * 8) * 4;
   return 2 * stage > epi ? 2 * stage : epi;
 }
@@ -75,8 +76,10 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
   constexpr int G_BN = 128;
   constexpr int G_LDT = G_BN + 4;
   constexpr int ROWS = RT * 16;
-  constexpr int A_PLANE = ROWS * 64;                 // bytes
-  constexpr int B_PLANE = G_BN * 64;
+  constexpr int A_GS = ROWS * 16 + 32;               // bytes between k-groups of an A plane (padded: see header)
+  constexpr int B_GS = G_BN * 16 + 32;
+  constexpr int A_PLANE = 4 * A_GS;                  // bytes
+  constexpr int B_PLANE = 4 * B_GS;
   constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;
   constexpr int A_F4 = ROWS * 8;                     // float4 (4 k of one row) per A stage
   constexpr int A_IT = (A_F4 + G_THREADS - 1) / G_THREADS;
@@ -181,15 +184,16 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
       u32x2 s0, s1, s2;
       split4(val, s0, s1, s2);
       if (f < A_F4) {
-        *reinterpret_cast<u32x2*>(dA + f * 8) = s0;                 // row (f >> 3) * 64 B + quad (f & 7) * 8 B = f * 8
-        *reinterpret_cast<u32x2*>(dA + A_PLANE + f * 8) = s1;
-        *reinterpret_cast<u32x2*>(dA + 2 * A_PLANE + f * 8) = s2;
+        const int o = ((f & 7) >> 1) * A_GS + (f >> 3) * 16 + (f & 1) * 8;     // k-group, row, half of the 8-element slot
+        *reinterpret_cast<u32x2*>(dA + o) = s0;
+        *reinterpret_cast<u32x2*>(dA + A_PLANE + o) = s1;
+        *reinterpret_cast<u32x2*>(dA + 2 * A_PLANE + o) = s2;
       }
     }
     char* dB = dA + 3 * A_PLANE;
     if (BP == B_PLAIN) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dB + pl * B_PLANE + tid * 16) = rb[pl];
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dB + pl * B_PLANE + (tid & 3) * B_GS + (tid >> 2) * 16) = rb[pl];
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -205,23 +209,23 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
         }
         u32x2 s0, s1, s2;
         split4(val, s0, s1, s2);
-        *reinterpret_cast<u32x2*>(dB + f * 8) = s0;
-        *reinterpret_cast<u32x2*>(dB + B_PLANE + f * 8) = s1;
-        *reinterpret_cast<u32x2*>(dB + 2 * B_PLANE + f * 8) = s2;
+        const int o = ((f & 7) >> 1) * B_GS + (f >> 3) * 16 + (f & 1) * 8;
+        *reinterpret_cast<u32x2*>(dB + o) = s0;
+        *reinterpret_cast<u32x2*>(dB + B_PLANE + o) = s1;
+        *reinterpret_cast<u32x2*>(dB + 2 * B_PLANE + o) = s2;
       }
     }
   };
 
   // lane (i = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7 of row / column i for BOTH operands
-  const int frag = (lane & 15) * 64 + (lane >> 4) * 16;
   auto compute = [&](int buf) {
-    const char* sA = lds + buf * STAGE + (t0 * 16) * 64 + frag;
-    const char* sB = lds + buf * STAGE + 3 * A_PLANE + (cgp * 32) * 64 + frag;
+    const char* sA = lds + buf * STAGE + (lane >> 4) * A_GS + (t0 * 16 + (lane & 15)) * 16;
+    const char* sB = lds + buf * STAGE + 3 * A_PLANE + (lane >> 4) * B_GS + (cgp * 32 + (lane & 15)) * 16;
     u32x4 bf[3][2];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) bf[pl][c] = *reinterpret_cast<const u32x4*>(sB + pl * B_PLANE + c * 16 * 64);
+      for (int c = 0; c < 2; ++c) bf[pl][c] = *reinterpret_cast<const u32x4*>(sB + pl * B_PLANE + c * 16 * 16);
     // term order: smallest products first into the accumulator
     //   A plane 2 x B0 ; A plane 1 x {B1, B0} ; A plane 0 x {B2, B1, B0}
 #pragma unroll
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
       u32x4 af[HT];
 #pragma unroll
       for (int t = 0; t < HT; ++t)
-        if (t < HT - 1 || t < my_nt) af[t] = *reinterpret_cast<const u32x4*>(sA + ap * A_PLANE + t * 16 * 64);
+        if (t < HT - 1 || t < my_nt) af[t] = *reinterpret_cast<const u32x4*>(sA + ap * A_PLANE + t * 16 * 16);
 #pragma unroll
       for (int bp = 2 - ap; bp >= 0; --bp) {
 #pragma unroll

@@ -1,0 +1,204 @@
+// macx_wgrad6.cuh -- the weight-gradient contractions  C[k][j] = sum_m A[m][k] * G[m][j]  (macx_gemm_tn.cuh) on the
+// bf16 matrix pipe with fp32-class numerics: the same exact 3-way bf16 operand split and six MFMA terms as
+// macx_gemm6.cuh.  Both operands are row-major over the reduction index m, and v_mfma_f32_16x16x32_bf16 wants 8
+// consecutive m per lane, so the transpose happens in registers while staging: a thread loads an 8 (m) x 2 (columns)
+// block (eight 8-byte loads, 512 B contiguous per row across a wave), splits the 16 values and writes, per column and
+// plane, one 16-byte slot [m-group][column] -- conflict-free b128 stores, and fragments are conflict-free b128 reads.
+//   workgroup: 128 x 128 output tile, 8 waves SPECIALISED: waves 0-3 produce (load, split, LDS store of stage c+1) while
+//   waves 4-7 consume (fragments + MFMAs of stage c, wave tile 64 x 64 = 4 x 4 MFMA tiles) -- one of each per SIMD, so the
+//   vector ALU work of the split runs beside the matrix pipe instead of in a separate phase of the same waves;
+//   32 reduction rows per stage, two LDS stages, one barrier per stage.
+// Determinism as in macx_gemm_tn.cuh: a workgroup owns one (split, tile) slab, slabs are summed in a fixed order.
+#pragma once
+#include "macx_gemm6.cuh"
+#include "macx_gemm_tn.cuh"
+
+namespace macx {
+
+constexpr int W6_GS = 128 * 16 + 32;       // bytes between m-groups of a plane
+constexpr int W6_PLANE = 4 * W6_GS;
+constexpr int W6_OPER = 3 * W6_PLANE;
+constexpr int W6_STAGE = 2 * W6_OPER;
+
+// exact 3-way split of 8 fp32 values (consecutive m of one column) into three 16-byte bf16x8 slots
+__device__ __forceinline__ void split8(const float* x, u32x4& p0, u32x4& p1, u32x4& p2) {
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const float a = x[2 * h], b = x[2 * h + 1];
+    p0[h] = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0[h] << 16), rb = b - __uint_as_float(p0[h] & 0xFFFF0000u);
+    p1[h] = pk_bf16(ra, rb);
+    p2[h] = pk_bf16(ra - __uint_as_float(p1[h] << 16), rb - __uint_as_float(p1[h] & 0xFFFF0000u));
+  }
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+
+  const int ntj = p.Jd / T_TILE;
+  const int ntk = p.Kd / T_TILE;
+  const int ntile = ntj * ntk;
+  const int nblk = gridDim.x;
+  int v = blockIdx.x;
+  if ((nblk & 7) == 0) v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int split = v / ntile;
+  const int tile = v % ntile;
+  const int tk = tile / ntj, tj = tile % ntj;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int nchunk = (m_end - m_begin + 31) >> 5;
+  const int nloop = (nchunk + 2) / 3 * 3;          // whole groups of three stages; the extra ones multiply zeros
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+
+  if (wave < 4) {
+    // ================= producer waves: global -> registers -> exact bf16 split -> LDS planes =================
+    // wave w stages m-group w (8 rows) of BOTH operands; every row address is wave-uniform (scalar ALU), the lane
+    // contributes its column pair.  Three register sets keep the loads of stages c+1..c+3 in flight.
+    int conv_shift = 0, a_col0 = tk * T_TILE;
+    if (CONV) {
+      const int per = p.conv_cin / T_TILE;
+      const int tap = tk / per;
+      conv_shift = (tap / 3 - 1) * p.conv_wp + (tap - (tap / 3) * 3 - 1);
+      a_col0 = (tk - tap * per) * T_TILE;
+    }
+    const int mg = wave;
+    const float* baseA = p.A + a_col0 + 2 * lane;
+    const float* baseG = p.G + tj * T_TILE + 2 * lane;
+    int amod_row = (m_begin + mg * 8) % p.a_mod;   // A row of reduction row m is m % a_mod, kept incrementally
+    f32x2_t ra[3][8], rg[3][8];
+    auto load = [&](auto slot_c, int ch) {
+      constexpr int SL = decltype(slot_c)::value;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int m = m_begin + ch * 32 + mg * 8 + r;
+        const int mc = min(m, p.M - 1);        // rows past the end are zeroed when the stage is split, not here
+        int arow;
+        if (CONV) {
+          const int img = (int)__umulhi((uint32_t)mc, p.magic_n);
+          const int n = mc - img * p.conv_n;
+          const int yy = (int)__umulhi((uint32_t)n, p.magic_w);
+          arow = img * p.conv_np + (yy + 1) * p.conv_wp + (n - yy * p.conv_w) + 1 + conv_shift;
+        } else {
+          arow = amod_row + r;
+          while (arow >= p.a_mod) arow -= p.a_mod;     // a_mod may be smaller than a stage (tiny [B,d]-sized contractions)
+        }
+        ra[SL][r] = *reinterpret_cast<const f32x2_t*>(baseA + (size_t)arow * p.lda);
+        rg[SL][r] = *reinterpret_cast<const f32x2_t*>(baseG + (size_t)mc * p.ldg);
+      }
+      amod_row += 32;
+      while (amod_row >= p.a_mod) amod_row -= p.a_mod;
+    };
+    auto store = [&](auto slot_c, int ch) {
+      constexpr int SL = decltype(slot_c)::value;
+      const int mrow = m_begin + ch * 32 + mg * 8;
+      char* dst = lds + (ch & 1) * W6_STAGE + mg * W6_GS + (2 * lane) * 16;
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float x[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) x[r] = (mrow + r < m_end) ? (o ? rg[SL][r][c] : ra[SL][r][c]) : 0.f;
+          u32x4 s0, s1, s2;
+          split8(x, s0, s1, s2);
+          char* d = dst + o * W6_OPER + c * 16;
+          *reinterpret_cast<u32x4*>(d) = s0;
+          *reinterpret_cast<u32x4*>(d + W6_PLANE) = s1;
+          *reinterpret_cast<u32x4*>(d + 2 * W6_PLANE) = s2;
+        }
+    };
+    // straight-line pipeline: no conditional loads (a branch around a load drains vmcnt at the join)
+    load(S0{}, 0);
+    load(S1{}, 1);
+    load(S2{}, 2);
+    store(S0{}, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < nloop; ch += 3) {
+      if (p.dbg & 48) {      // timing experiments: 16 = barriers only, 32 = loads but no split/store
+        if (p.dbg & 32) { load(S0{}, ch + 3); load(S1{}, ch + 4); load(S2{}, ch + 5); }
+        __syncthreads(); __syncthreads(); __syncthreads();
+        continue;
+      }
+      load(S0{}, ch + 3); store(S1{}, ch + 1); __syncthreads();
+      load(S1{}, ch + 4); store(S2{}, ch + 2); __syncthreads();
+      load(S2{}, ch + 5); store(S0{}, ch + 3); __syncthreads();
+    }
+  } else {
+    // ================= consumer waves: LDS fragments -> MFMA; wave tile 64 x 64 = 4 x 4 MFMA tiles =================
+    const int cw = wave - 4;
+    const int wr = cw >> 1, wc = cw & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+      const char* sa = lds + buf * W6_STAGE + (lane >> 4) * W6_GS + (wr * 64 + (lane & 15)) * 16;
+      const char* sg = lds + buf * W6_STAGE + W6_OPER + (lane >> 4) * W6_GS + (wc * 64 + (lane & 15)) * 16;
+      u32x4 gf[3][4];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gf[pl][c] = *reinterpret_cast<const u32x4*>(sg + pl * W6_PLANE + c * 256);
+      // smallest terms first: A plane 2 x G0 ; A plane 1 x {G1, G0} ; A plane 0 x {G2, G1, G0}
+#pragma unroll
+      for (int ap = 2; ap >= 0; --ap) {
+        u32x4 af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const u32x4*>(sa + ap * W6_PLANE + t * 256);
+#pragma unroll
+        for (int bp = 2 - ap; bp >= 0; --bp)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[t][c] = mfma_bf16(af[t], gf[bp][c], acc[t][c]);
+      }
+    };
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < nloop; ++ch) {
+      if (!(p.dbg & 64)) compute(ch & 1);      // 64: timing experiment, no MFMAs
+      __syncthreads();
+    }
+    // 16x16 accumulator map: col = lane & 15 (j), row = (lane >> 4) * 4 + reg (k)
+    float* out = p.part + (size_t)split * p.Kd * p.Jd;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
+          const int j = tj * T_TILE + wc * 64 + c * 16 + (lane & 15);
+          out[(size_t)k * p.Jd + j] = acc[t][c][e];
+        }
+  }
+}
+
+inline hipError_t wgrad6_launch(const TnP& p, hipStream_t st) {
+  constexpr size_t lds = 2 * W6_STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = (p.Kd / T_TILE) * (p.Jd / T_TILE) * p.nsplit;
+  TnP q = p;
+  q.dbg = kb_gemm_dbg();
+  if (p.conv_taps) hipLaunchKernelGGL(wgrad6_kernel<true>, dim3(grid), dim3(512), lds, st, q);
+  else hipLaunchKernelGGL(wgrad6_kernel<false>, dim3(grid), dim3(512), lds, st, q);
+  return hipGetLastError();
+}
+
+}  // namespace macx

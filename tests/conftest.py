@@ -15,6 +15,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def macx():
     import macx as m
+    if os.environ.get("MACX_DBG"):          # debugging aid: kernel-selection / timing bits of macx_debug_set(1, .)
+        m._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
     return m
 
 
