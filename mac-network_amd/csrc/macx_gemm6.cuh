@@ -60,10 +60,12 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 a, const u32x4 b, f32x4 c
 //   1: Wb[kt][plane][n][32] bf16 = split planes of W[k][n];  2: Wt[kt][n][32] fp32 k-major tiles
 constexpr size_t gemm6_plane_floats(size_t K, size_t Nout) { return K * Nout * 3 / 2; }   // format 1 size in floats
 
+constexpr int GS_PAD = 64;      // padding of the k-group stride (bytes): 0 keeps the b128 fragment reads conflict-free
+
 template <int RT>
 constexpr int kb_gemm6_lds_bytes() {
   constexpr int ROWS = RT * 16;
-  constexpr int stage = 3 * 4 * (ROWS * 16 + 32) + 3 * 4 * (128 * 16 + 32);
+  constexpr int stage = 3 * 4 * (ROWS * 16 + GS_PAD) + 3 * 4 * (128 * 16 + GS_PAD);
   constexpr int epi = (ROWS * (128 + 4) + 256 * 8) * 4;
   return 2 * stage > epi ? 2 * stage : epi;
 }
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
   constexpr int G_BN = 128;
   constexpr int G_LDT = G_BN + 4;
   constexpr int ROWS = RT * 16;
-  constexpr int A_GS = ROWS * 16 + 32;               // bytes between k-groups of an A plane (padded: see header)
-  constexpr int B_GS = G_BN * 16 + 32;
+  constexpr int A_GS = ROWS * 16 + GS_PAD;           // bytes between k-groups of an A plane
+  constexpr int B_GS = G_BN * 16 + GS_PAD;
   constexpr int A_PLANE = 4 * A_GS;                  // bytes
   constexpr int B_PLANE = 4 * B_GS;
   constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;
