@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 B, S, N, D, P = 64, 50, 196, 512, 12
 PEAK_FP32_MFMA = 157.3e12       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA = 2500e12        # MI355X_MICROARCH.md: bf16 dense MFMA peak (~2.5 PF; 2075 TF measured for the 16x16x32 shape)
 
 
 def flops_per_question_step(n=N, s=S, d=D):
@@ -121,6 +122,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-level", action="store_true")
+    ap.add_argument("--no-native", action="store_true", help="skip the native-f32-MFMA comparison leg")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--p", type=int, default=P, help=argparse.SUPPRESS)
@@ -235,21 +237,47 @@ def main():
             traffic = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roofline = {"bound": "mfma", "kernel": "kb_gemm_kernel<13,8,A_PLAIN,B_PLAIN,E_BIAS_ACT,false> (X = KBd Wx + bx; 6 of the 9 GEMM-class launches per cell step share this main loop)",
+        split = bool(L.macx_gemm_mode(-1))
+        if split:
+            kname = ("kb_gemm6_kernel<13,A_PLAIN,B_PLAIN,E_BIAS_ACT,false> (X = KBd Wx + bx on the bf16 matrix pipe: exact 3-way bf16 "
+                     "operand split, 6 MFMA terms, fp32 accumulate; 6 of the 9 GEMM-class launches per cell step share this main loop)")
+        else:
+            kname = "kb_gemm_kernel<13,8,A_PLAIN,B_PLAIN,E_BIAS_ACT,false> (X = KBd Wx + bx, v_mfma_f32_16x16x4_f32)"
+        roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
                     "kernel_ms": round(k_ms, 4), "flops_per_launch": k_flops,
-                    "whole_step_frac": round(qps / world * 3 * p * F / PEAK_FP32_MFMA, 4)}
+                    "whole_step_frac": round(qps / world * 3 * p * F / PEAK_FP32_MFMA, 4),
+                    "note": "achieved = algorithmic fp32 FLOPs / time; peak = the f32-input MFMA peak (the metric's dtype)"}
+        if split:
+            # the instructions actually issued: 6 bf16 MFMA terms per algorithmic multiply-add, priced against the bf16 pipe
+            roofline["pipe"] = {"dtype": "bf16 (v_mfma_f32_16x16x32_bf16)", "executed": round(6 * achieved / 1e12, 1),
+                                "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(6 * achieved / PEAK_BF16_MFMA, 4)}
         out = {"metric": "questions/sec fwd+bwd (B=64,d=512,p=12,KB=14x14x1024) at 1/2/4/8 MI355X",
                "value": round(qps, 2), "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32" if not split else "f32 (GEMM operands split exactly into 3 bf16 pieces, 6 bf16 MFMA terms, fp32 accumulate; "
+                                                "error vs fp64 <= native f32 MFMA, tests/test_gpu_units.py)", "data": "synthetic",
                "config": {"workload": "MAC cell fwd+bwd, configs/args.txt options, train-mode dropout .85/.85/1.0, "
                                       "per-GPU batch B=%d, S=%d, KB=[B,%d,%d] (stem output of 14x14x1024 features), d=%d, p=%d; "
                                       "cell only (stem/encoder/classifier are SURVEY 8f 'next' rows)" % (B, S, N, D, D, p),
                           "global_batch": B * world, "parallelism": "dp%d" % world,
                           "flops_per_question_fwd_bwd": 3 * p * F},
                "roofline": roofline}
+        if world == 1 and split and not args.no_native:
+            # the same step with every GEMM on the native f32-input MFMA kernels (v_mfma_f32_16x16x4_f32), for comparison
+            L.macx_gemm_mode(0)
+            for i in range(3):
+                step(1000 + i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(5):
+                step(1003 + i)
+            torch.cuda.synchronize()
+            dtn = (time.perf_counter() - t0) / 5
+            L.macx_gemm_mode(1)
+            out["native_f32_mfma"] = {"value": round(B / dtn, 2), "unit": "questions/s", "ms_per_step": round(dtn * 1e3, 3), "steps": 5,
+                                      "whole_step_frac": round(B / dtn * 3 * p * F / PEAK_FP32_MFMA, 4)}
         if world == 1 and not args.no_model_level:
             out["model_level"] = model_level(macx, mo, dev, seed)
         if world == 1 and not args.no_cpu_baseline:

@@ -796,7 +796,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
       q.dW1a_part = ws + W.slab_w1a + (size_t)i * W.ngroup * dd;
       q.dW1b_part = ws + W.slab_w1b + (size_t)i * W.ngroup * dd;
       q.dy_part = ws + W.dy_part;
-      CK(sb_wgrad_launch(q, st));
+      CK((gemm_split_mode() && !(kb_gemm_dbg() & 256)) ? sb6_wgrad_launch(q, st) : sb_wgrad_launch(q, st));   // dbg 256: f32 kernel
     }
     // dKB (+)= (dX Wx^T) * kbmask + att * dinfo
     g.A = dX_i; g.Wp = ws + W.wxT_p; g.Wp2 = nullptr; g.y = nullptr;

@@ -201,4 +201,188 @@ inline hipError_t wgrad6_launch(const TnP& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-question interaction gradient  S_b = X_b^T dI1_b  on the split-bf16 path (see sb_wgrad_kernel in
+// macx_gemm_tn.cuh for what S_b is for):  dW1a += diag(y_b) S_b,  dW1b += S_b,  dy[b][k] = sum_j W1a[k][j] S_b[k][j].
+// 4 waves, one per SIMD (the three 64-register accumulator sets + the W1a tile need the whole 512-entry register file),
+// each wave both stages (8 rows x 2 columns of X and of dI1 per lane, exact bf16 split, in-register transpose) and
+// multiplies its 64 x 64 share of the 128 x 128 tile; the pipeline runs straight through question boundaries.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sum16(float v) {     // sum over the 16 lanes that share lane >> 4
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sb6_wgrad_kernel(SbP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+
+  const int nt = p.d / T_TILE;
+  const int ntile = nt * nt;
+  const int nblk = gridDim.x;
+  int v = blockIdx.x;
+  if ((nblk & 7) == 0) v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int group = v / ntile;
+  const int tile = v % ntile;
+  const int tk = tile / nt, tj = tile % nt;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int mg = wave;                                  // this wave stages rows [8 mg, 8 mg + 8) of every 32-row stage
+
+  f32x4 accS[4][4], accA[4][4], accB[4][4], w1a[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      accS[t][c] = accA[t][c] = accB[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
+        const int j = tj * T_TILE + wc * 64 + c * 16 + (lane & 15);
+        w1a[t][c][e] = p.W1a[(size_t)k * p.d + j];
+      }
+    }
+
+  const int nchunk = (p.N + 31) >> 5;
+  const int b_begin = group * p.qpg;
+  const int b_end = min(p.B, b_begin + p.qpg);
+  const int total = (b_end - b_begin) * nchunk;         // stages of this workgroup, over all its questions
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  f32x2_t ra[2][8], rg[2][8];
+  // stage s = (question qi = s / nchunk, rows [32 ch, 32 ch + 32) of it); every row address is wave-uniform
+  auto load = [&](auto slot_c, int s_raw) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot_c)::value;
+    const int s = min(s_raw, total - 1);
+    const int qi = s / nchunk, ch = s - qi * nchunk;
+    const size_t qoff = (size_t)(b_begin + qi) * p.N * p.d;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int n = min(ch * 32 + mg * 8 + r, p.N - 1);       // rows past N are zeroed when the stage is split
+      ra[SL][r] = *reinterpret_cast<const f32x2_t*>(p.X + qoff + (size_t)n * p.d + tk * T_TILE + 2 * lane);
+      rg[SL][r] = *reinterpret_cast<const f32x2_t*>(p.dI1 + qoff + (size_t)n * p.d + tj * T_TILE + 2 * lane);
+    }
+  };
+  auto store = [&](auto slot_c, int s_raw) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot_c)::value;
+    const int s = min(s_raw, total - 1);
+    const int ch = s % nchunk;
+    const int nrow = ch * 32 + mg * 8;
+    char* dst = lds + (s_raw & 1) * W6_STAGE + mg * W6_GS + (2 * lane) * 16;
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = (nrow + r < p.N) ? (o ? rg[SL][r][c] : ra[SL][r][c]) : 0.f;
+        u32x4 s0, s1, s2;
+        split8(x, s0, s1, s2);
+        char* d = dst + o * W6_OPER + c * 16;
+        *reinterpret_cast<u32x4*>(d) = s0;
+        *reinterpret_cast<u32x4*>(d + W6_PLANE) = s1;
+        *reinterpret_cast<u32x4*>(d + 2 * W6_PLANE) = s2;
+      }
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const char* sa = lds + buf * W6_STAGE + (lane >> 4) * W6_GS + (wr * 64 + (lane & 15)) * 16;
+    const char* sg = lds + buf * W6_STAGE + W6_OPER + (lane >> 4) * W6_GS + (wc * 64 + (lane & 15)) * 16;
+    u32x4 gf[3][4];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gf[pl][c] = *reinterpret_cast<const u32x4*>(sg + pl * W6_PLANE + c * 256);
+#pragma unroll
+    for (int ap = 2; ap >= 0; --ap) {
+      u32x4 af[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const u32x4*>(sa + ap * W6_PLANE + t * 256);
+#pragma unroll
+      for (int bp = 2 - ap; bp >= 0; --bp)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) accS[t][c] = mfma_bf16(af[t], gf[bp][c], accS[t][c]);
+    }
+  };
+  // question finished: fold S_b into the three outputs and clear it
+  auto consume = [&](int b) __attribute__((always_inline)) {
+    const float* yb = p.y + (size_t)b * p.d;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
+        const float yk = yb[k];
+        float dyp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float sv = accS[t][c][e];
+          accB[t][c][e] += sv;
+          accA[t][c][e] = fmaf(yk, sv, accA[t][c][e]);
+          dyp = fmaf(w1a[t][c][e], sv, dyp);
+          accS[t][c][e] = 0.f;
+        }
+        dyp = sum16(dyp);
+        if ((lane & 15) == 0) p.dy_part[((size_t)(tj * 2 + wc) * p.B + b) * p.d + k] = dyp;
+      }
+  };
+
+  if (total > 0) {
+    load(S0{}, 0);
+    load(S1{}, 1);
+    store(S0{}, 0);
+    __syncthreads();
+    int qch = 0, b = b_begin;                           // stage index inside the current question, current question
+    auto step = [&](auto mine, auto next, int s) __attribute__((always_inline)) {
+      load(mine, s + 2);
+      compute(s & 1);
+      store(next, s + 1);
+      if (++qch == nchunk) { consume(b); qch = 0; ++b; }
+      __syncthreads();
+    };
+    int s = 0;
+#pragma unroll 1
+    for (; s + 2 <= total; s += 2) {
+      step(S0{}, S1{}, s);
+      step(S1{}, S0{}, s + 1);
+    }
+    if (s < total) step(S0{}, S1{}, s);
+  }
+
+  float* oa = p.dW1a_part + (size_t)group * p.d * p.d;
+  float* ob = p.dW1b_part + (size_t)group * p.d * p.d;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
+        const int j = tj * T_TILE + wc * 64 + c * 16 + (lane & 15);
+        oa[(size_t)k * p.d + j] = accA[t][c][e];
+        ob[(size_t)k * p.d + j] = accB[t][c][e];
+      }
+}
+
+inline hipError_t sb6_wgrad_launch(const SbP& p, hipStream_t st) {
+  constexpr size_t lds = 2 * W6_STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sb6_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int nt = p.d / T_TILE;
+  const int ngroup = (p.B + p.qpg - 1) / p.qpg;
+  hipLaunchKernelGGL(sb6_wgrad_kernel, dim3(nt * nt * ngroup), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
 }  // namespace macx
