@@ -256,8 +256,11 @@ def main():
         out = {"metric": "questions/sec fwd+bwd (B=64,d=512,p=12,KB=14x14x1024) at 1/2/4/8 MI355X",
                "value": round(qps, 2), "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if not split else "f32 (GEMM operands split exactly into 3 bf16 pieces, 6 bf16 MFMA terms, fp32 accumulate; "
-                                                "error vs fp64 <= native f32 MFMA, tests/test_gpu_units.py)", "data": "synthetic",
+               "dtype": "f32", "data": "synthetic",
+               "dtype_note": ("fp32 in, fp32 accumulate, fp32 out; large contractions multiply on the bf16 matrix pipe: each operand split "
+                              "EXACTLY into 3 bf16 pieces, 6 MFMA terms per product (dropped terms <= 2^-23 |ab|); measured error vs fp64 "
+                              "<= the native f32-MFMA kernel's (tests/test_gpu_units.py); native_f32_mfma = same step on "
+                              "v_mfma_f32_16x16x4_f32") if split else "native f32-input MFMA",
                "config": {"workload": "MAC cell fwd+bwd, configs/args.txt options, train-mode dropout .85/.85/1.0, "
                                       "per-GPU batch B=%d, S=%d, KB=[B,%d,%d] (stem output of 14x14x1024 features), d=%d, p=%d; "
                                       "cell only (stem/encoder/classifier are SURVEY 8f 'next' rows)" % (B, S, N, D, D, p),
