@@ -145,9 +145,11 @@ struct LinP {
   const float* addend; int ld_add; size_t zadd;                      // val += addend
 };
 
-constexpr int L_ROWS = 64;
-
+// RTL row tiles of 16 per workgroup: 4 for tall inputs; 1 for the [B,d] chain (B <= 128 rows), where 64-row workgroups
+// would leave a 32-workgroup grid on a 256-CU chip and the launch is pure latency.
+template <int RTL>
 __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
+  constexpr int L_ROWS = 16 * RTL;
   __shared__ float red[4][L_ROWS][20];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,12 +158,12 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
   const int z = blockIdx.z;
   const int li = lane & 15, lg = lane >> 4;
 
-  f32x4 acc[4];
+  f32x4 acc[RTL];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int rowc[4];
+  for (int t = 0; t < RTL; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int rowc[RTL];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) rowc[t] = min(r0 + 16 * t + li, p.rows - 1);
+  for (int t = 0; t < RTL; ++t) rowc[t] = min(r0 + 16 * t + li, p.rows - 1);
 
   const float* Wz = p.W + (size_t)z * p.zW + ((size_t)lg * p.n_out + c0 + li) * 4;
   const int nQ = p.Ktot >> 4;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
   // (40 x 16 B per lane in flight) before touching the matrix pipe.
   constexpr int PF = 8;
   for (int Q0 = wave; Q0 < nQ; Q0 += 4 * PF) {
-    f32x4 bf[PF], af[PF][4];
+    f32x4 bf[PF], af[PF][RTL];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int Q = min(Q0 + 4 * u, nQ - 1);
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
       const int ld = p.seg[s].ld;
       bf[u] = *reinterpret_cast<const f32x4*>(Wz + (size_t)Q * 4 * p.n_out * 4);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) af[u][t] = *reinterpret_cast<const f32x4*>(xs + (size_t)rowc[t] * ld);
+      for (int t = 0; t < RTL; ++t) af[u][t] = *reinterpret_cast<const f32x4*>(xs + (size_t)rowc[t] * ld);
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -187,19 +189,19 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][t][e], bf[u][e], acc[t], 0, 0, 0);
+          for (int t = 0; t < RTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][t][e], bf[u][e], acc[t], 0, 0, 0);
       }
     }
   }
   // accumulator map: col = lane & 15, row = 16 t + (lane >> 4) * 4 + e
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < RTL; ++t)
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[wave][16 * t + lg * 4 + e][li] = acc[t][e];
   __syncthreads();
   const int r = tid >> 2, cq = (tid & 3) * 4;
   const int row = r0 + r;
-  if (row >= p.rows) return;
+  if (r >= L_ROWS || row >= p.rows) return;
   f32x4 val;
 #pragma unroll
   for (int e = 0; e < 4; ++e) val[e] = ((red[0][r][cq + e] + red[1][r][cq + e]) + red[2][r][cq + e]) + red[3][r][cq + e];
@@ -225,8 +227,11 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
 }
 
 inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
-  dim3 grid(p.n_out / 16, (p.rows + L_ROWS - 1) / L_ROWS, nz);
-  hipLaunchKernelGGL(small_linear_kernel, grid, dim3(256), 0, st, p);
+  if (p.rows <= 128) {
+    hipLaunchKernelGGL(small_linear_kernel<1>, dim3(p.n_out / 16, (p.rows + 15) / 16, nz), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(small_linear_kernel<4>, dim3(p.n_out / 16, (p.rows + 63) / 64, nz), dim3(256), 0, st, p);
+  }
   return hipGetLastError();
 }
 
