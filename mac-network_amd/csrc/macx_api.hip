@@ -164,7 +164,9 @@ inline int nrb_of(int N, int B, int d) {
 }
 
 inline int wgrad_splits(int M, int Kd, int Jd) {
-  const int tiles = (Kd / T_TILE) * (Jd / T_TILE);
+  // workgroups = splits x output tiles ~ one per CU; the split-bf16 kernel uses 128 x 256 tiles when Jd allows
+  const int jw = (gemm_split_mode() && Jd % 256 == 0) ? 2 : 1;
+  const int tiles = (Kd / T_TILE) * (Jd / (jw * T_TILE));
   int ns = 256 / tiles;
   if (ns < 1) ns = 1;
   const int max_by_rows = (M + 63) / 64;   // at least 64 rows per split

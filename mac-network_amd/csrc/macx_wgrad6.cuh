@@ -32,12 +32,21 @@ __device__ __forceinline__ void split8(const float* x, u32x4& p0, u32x4& p1, u32
   }
 }
 
-template <bool CONV>
+// JW = j-width of the output tile in units of 128 columns.  JW = 2 (128 x 256 tiles, consumer wave tile 64 x 128) doubles
+// the MFMA work per barrier and reads the A operand half as often; used whenever Jd is a multiple of 256.
+template <int JW>
+constexpr int w6_stage_bytes() { return W6_OPER + 3 * 4 * (JW * 128 * 16 + 32); }
+
+template <bool CONV, int JW>
 __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
+  constexpr int JT = JW * T_TILE;                   // output tile width
+  constexpr int GG = JW * 128 * 16 + 32;            // bytes between m-groups of a G plane
+  constexpr int GPL = 4 * GG;                       // G plane
+  constexpr int STAGE = W6_OPER + 3 * GPL;
 
-  const int ntj = p.Jd / T_TILE;
+  const int ntj = p.Jd / JT;
   const int ntk = p.Kd / T_TILE;
   const int ntile = ntj * ntk;
   const int nblk = gridDim.x;
@@ -57,11 +66,12 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
+  typedef float gvec __attribute__((ext_vector_type(2 * JW)));     // a lane's columns of one G row
 
   if (wave < 4) {
     // ================= producer waves: global -> registers -> exact bf16 split -> LDS planes =================
     // wave w stages m-group w (8 rows) of BOTH operands; every row address is wave-uniform (scalar ALU), the lane
-    // contributes its column pair.  Three register sets keep the loads of stages c+1..c+3 in flight.
+    // contributes its columns (2 of A, 2 JW of G).  Three register sets keep the loads of stages c+1..c+3 in flight.
     int conv_shift = 0, a_col0 = tk * T_TILE;
     if (CONV) {
       const int per = p.conv_cin / T_TILE;
@@ -71,10 +81,11 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
     }
     const int mg = wave;
     const float* baseA = p.A + a_col0 + 2 * lane;
-    const float* baseG = p.G + tj * T_TILE + 2 * lane;
+    const float* baseG = p.G + tj * JT + 2 * JW * lane;
     int amod_row = (m_begin + mg * 8) % p.a_mod;   // A row of reduction row m is m % a_mod, kept incrementally
-    f32x2_t ra[3][8], rg[3][8];
-    auto load = [&](auto slot_c, int ch) {
+    f32x2_t ra[3][8];
+    gvec rg[3][8];
+    auto load = [&](auto slot_c, int ch) __attribute__((always_inline)) {
       constexpr int SL = decltype(slot_c)::value;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -91,29 +102,38 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
           while (arow >= p.a_mod) arow -= p.a_mod;     // a_mod may be smaller than a stage (tiny [B,d]-sized contractions)
         }
         ra[SL][r] = *reinterpret_cast<const f32x2_t*>(baseA + (size_t)arow * p.lda);
-        rg[SL][r] = *reinterpret_cast<const f32x2_t*>(baseG + (size_t)mc * p.ldg);
+        rg[SL][r] = *reinterpret_cast<const gvec*>(baseG + (size_t)mc * p.ldg);
       }
       amod_row += 32;
       while (amod_row >= p.a_mod) amod_row -= p.a_mod;
     };
-    auto store = [&](auto slot_c, int ch) {
+    auto store = [&](auto slot_c, int ch) __attribute__((always_inline)) {
       constexpr int SL = decltype(slot_c)::value;
       const int mrow = m_begin + ch * 32 + mg * 8;
-      char* dst = lds + (ch & 1) * W6_STAGE + mg * W6_GS + (2 * lane) * 16;
+      char* dA = lds + (ch & 1) * STAGE + mg * W6_GS + (2 * lane) * 16;
+      char* dG = lds + (ch & 1) * STAGE + W6_OPER + mg * GG + (2 * JW * lane) * 16;
 #pragma unroll
-      for (int o = 0; o < 2; ++o)
+      for (int c = 0; c < 2; ++c) {
+        float x[8];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          float x[8];
+        for (int r = 0; r < 8; ++r) x[r] = (mrow + r < m_end) ? ra[SL][r][c] : 0.f;
+        u32x4 s0, s1, s2;
+        split8(x, s0, s1, s2);
+        *reinterpret_cast<u32x4*>(dA + c * 16) = s0;
+        *reinterpret_cast<u32x4*>(dA + W6_PLANE + c * 16) = s1;
+        *reinterpret_cast<u32x4*>(dA + 2 * W6_PLANE + c * 16) = s2;
+      }
 #pragma unroll
-          for (int r = 0; r < 8; ++r) x[r] = (mrow + r < m_end) ? (o ? rg[SL][r][c] : ra[SL][r][c]) : 0.f;
-          u32x4 s0, s1, s2;
-          split8(x, s0, s1, s2);
-          char* d = dst + o * W6_OPER + c * 16;
-          *reinterpret_cast<u32x4*>(d) = s0;
-          *reinterpret_cast<u32x4*>(d + W6_PLANE) = s1;
-          *reinterpret_cast<u32x4*>(d + 2 * W6_PLANE) = s2;
-        }
+      for (int c = 0; c < 2 * JW; ++c) {
+        float x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = (mrow + r < m_end) ? rg[SL][r][c] : 0.f;
+        u32x4 s0, s1, s2;
+        split8(x, s0, s1, s2);
+        *reinterpret_cast<u32x4*>(dG + c * 16) = s0;
+        *reinterpret_cast<u32x4*>(dG + GPL + c * 16) = s1;
+        *reinterpret_cast<u32x4*>(dG + 2 * GPL + c * 16) = s2;
+      }
     };
     // straight-line pipeline: no conditional loads (a branch around a load drains vmcnt at the join)
     load(S0{}, 0);
@@ -123,50 +143,46 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < nloop; ch += 3) {
-      if (p.dbg & 48) {      // timing experiments: 16 = barriers only, 32 = loads but no split/store
-        if (p.dbg & 32) { load(S0{}, ch + 3); load(S1{}, ch + 4); load(S2{}, ch + 5); }
-        __syncthreads(); __syncthreads(); __syncthreads();
-        continue;
-      }
       load(S0{}, ch + 3); store(S1{}, ch + 1); __syncthreads();
       load(S1{}, ch + 4); store(S2{}, ch + 2); __syncthreads();
       load(S2{}, ch + 5); store(S0{}, ch + 3); __syncthreads();
     }
   } else {
-    // ================= consumer waves: LDS fragments -> MFMA; wave tile 64 x 64 = 4 x 4 MFMA tiles =================
+    // ================= consumer waves: LDS fragments -> MFMA; wave tile 64 x (64 JW) = 4 x (4 JW) MFMA tiles =================
     const int cw = wave - 4;
     const int wr = cw >> 1, wc = cw & 1;
-    f32x4 acc[4][4];
+    constexpr int NC = 4 * JW;
+    f32x4 acc[4][NC];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int buf) {
-      const char* sa = lds + buf * W6_STAGE + (lane >> 4) * W6_GS + (wr * 64 + (lane & 15)) * 16;
-      const char* sg = lds + buf * W6_STAGE + W6_OPER + (lane >> 4) * W6_GS + (wc * 64 + (lane & 15)) * 16;
-      u32x4 gf[3][4];
+      for (int c = 0; c < NC; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+      const char* sa = lds + buf * STAGE + (lane >> 4) * W6_GS + (wr * 64 + (lane & 15)) * 16;
+      const char* sg = lds + buf * STAGE + W6_OPER + (lane >> 4) * GG + (wc * 64 * JW + (lane & 15)) * 16;
+      u32x4 af[3][4];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) gf[pl][c] = *reinterpret_cast<const u32x4*>(sg + pl * W6_PLANE + c * 256);
-      // smallest terms first: A plane 2 x G0 ; A plane 1 x {G1, G0} ; A plane 0 x {G2, G1, G0}
+        for (int t = 0; t < 4; ++t) af[pl][t] = *reinterpret_cast<const u32x4*>(sa + pl * W6_PLANE + t * 256);
+      // G plane by plane (smallest terms first): G2 x A0 ; G1 x {A1, A0} ; G0 x {A2, A1, A0}
 #pragma unroll
-      for (int ap = 2; ap >= 0; --ap) {
-        u32x4 af[4];
+      for (int bp = 2; bp >= 0; --bp) {
+        u32x4 gf[NC];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const u32x4*>(sa + ap * W6_PLANE + t * 256);
+        for (int c = 0; c < NC; ++c) gf[c] = *reinterpret_cast<const u32x4*>(sg + bp * GPL + c * 256);
 #pragma unroll
-        for (int bp = 2 - ap; bp >= 0; --bp)
+        for (int ap = 2 - bp; ap >= 0; --ap)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[t][c] = mfma_bf16(af[t], gf[bp][c], acc[t][c]);
+            for (int c = 0; c < NC; ++c) acc[t][c] = mfma_bf16(af[ap][t], gf[c], acc[t][c]);
       }
     };
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < nloop; ++ch) {
-      if (!(p.dbg & 64)) compute(ch & 1);      // 64: timing experiment, no MFMAs
+      compute(ch & 1);
       __syncthreads();
     }
     // 16x16 accumulator map: col = lane & 15 (j), row = (lane >> 4) * 4 + reg (k)
@@ -174,31 +190,36 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
-          const int j = tj * T_TILE + wc * 64 + c * 16 + (lane & 15);
+          const int j = tj * JT + wc * 64 * JW + c * 16 + (lane & 15);
           out[(size_t)k * p.Jd + j] = acc[t][c][e];
         }
   }
 }
 
-inline hipError_t wgrad6_launch(const TnP& p, hipStream_t st) {
-  constexpr size_t lds = 2 * W6_STAGE;
+inline int wgrad6_jw(int Jd) { return (Jd % 256 == 0) ? 2 : 1; }
+
+template <bool CONV, int JW>
+inline hipError_t wgrad6_launch_t(const TnP& p, hipStream_t st) {
+  auto kern = wgrad6_kernel<CONV, JW>;
+  constexpr size_t lds = 2 * w6_stage_bytes<JW>();
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int grid = (p.Kd / T_TILE) * (p.Jd / T_TILE) * p.nsplit;
-  TnP q = p;
-  q.dbg = kb_gemm_dbg();
-  if (p.conv_taps) hipLaunchKernelGGL(wgrad6_kernel<true>, dim3(grid), dim3(512), lds, st, q);
-  else hipLaunchKernelGGL(wgrad6_kernel<false>, dim3(grid), dim3(512), lds, st, q);
+  const int grid = (p.Kd / T_TILE) * (p.Jd / (JW * T_TILE)) * p.nsplit;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
   return hipGetLastError();
+}
+
+inline hipError_t wgrad6_launch(const TnP& p, hipStream_t st) {
+  if (wgrad6_jw(p.Jd) == 2) return p.conv_taps ? wgrad6_launch_t<true, 2>(p, st) : wgrad6_launch_t<false, 2>(p, st);
+  return p.conv_taps ? wgrad6_launch_t<true, 1>(p, st) : wgrad6_launch_t<false, 1>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------
