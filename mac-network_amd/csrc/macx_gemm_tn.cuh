@@ -347,8 +347,20 @@ inline hipError_t sb_wgrad_launch(const SbP& p, hipStream_t st) {
 __global__ void slab_reduce_kernel(const float* __restrict__ part, int nslab, size_t n4, float* dst, int accumulate) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
-    for (int k = 1; k < nslab; ++k) s += reinterpret_cast<const f32x4*>(part + (size_t)k * n4 * 4)[i];
+    // eight slabs in flight per thread; the summation order (four interleaved partial sums, then a fixed tree) does not
+    // depend on anything but nslab, so runs stay bit-identical
+    const f32x4* src = reinterpret_cast<const f32x4*>(part) + i;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * n4];
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+      a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
+    }
+    for (; k < nslab; ++k) a0 += src[(size_t)k * n4];
+    f32x4 s = (a0 + a1) + (a2 + a3);
     if (accumulate) s += reinterpret_cast<const f32x4*>(dst)[i];
     reinterpret_cast<f32x4*>(dst)[i] = s;
   }

@@ -144,8 +144,21 @@ def test_control_attend(macx, dev):
         assert float(att[bi, lengths[bi]:].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("M,Kd,Jd", [(12544, 512, 512), (768, 512, 512), (64, 128, 256), (1001, 256, 128), (49, 128, 128)])
-def test_wgrad(macx, dev, M, Kd, Jd):
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("M,Kd,Jd", [(12544, 512, 512), (768, 512, 512), (64, 128, 256), (1001, 256, 128), (49, 128, 128),
+                                     (1, 128, 128), (3, 128, 256), (6, 256, 512), (31, 128, 128), (33, 128, 384), (97, 384, 256)])
+def test_wgrad(macx, dev, M, Kd, Jd, mode):
+    """C = A^T G on the split-bf16 (128x128 and 128x256 tiles, producer/consumer waves) and the native f32 TN kernel, from a
+    single reduction row up: ragged last stages, fewer rows than one 32-row stage, row counts below a wave's 8-row group."""
+    L = macx._lib.lib()
+    L.macx_gemm_mode(mode)
+    try:
+        _wgrad_case(macx, dev, M, Kd, Jd)
+    finally:
+        L.macx_gemm_mode(1)
+
+
+def _wgrad_case(macx, dev, M, Kd, Jd):
     L = macx._lib.lib()
     g = torch.Generator().manual_seed(4)
     A = torch.randn(M, Kd, generator=g)
