@@ -106,13 +106,16 @@ class _Run:
         ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         gstruct = _lib.MacxParamGrads()
         grads = {}
+        present = [f for f in _lib.PARAM_FIELDS if f in self._ptensors]
+        sizes = [(self._ptensors[f].numel() + 3) & ~3 for f in present]          # 16-byte aligned views
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)           # one fill instead of one per parameter
+        off = 0
+        for f, n in zip(present, sizes):
+            t = self._ptensors[f]
+            grads[f] = flat[off: off + t.numel()].view(t.shape)
+            off += n
         for f in _lib.PARAM_FIELDS:
-            if f in self._ptensors:
-                g = torch.zeros_like(self._ptensors[f])
-                grads[f] = g
-                setattr(gstruct, f, g.data_ptr())
-            else:
-                setattr(gstruct, f, None)
+            setattr(gstruct, f, grads[f].data_ptr() if f in grads else None)
         cell = self.cell
         gi_vq = torch.empty_like(cell.vecQuestions)
         gi_words = torch.empty_like(cell.words)

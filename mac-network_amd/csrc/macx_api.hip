@@ -540,10 +540,10 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   if (rdrop) {
     const uint32_t first = (uint32_t)((size_t)s->b0 * N * d);
     const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
+    const DropSpec da = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);     // same keep probability, own stream
     hipLaunchKernelGGL(kb_dropout_kernel, dim3(2048), dim3(256), 0, st, in->knowledgeBase, (size_t)B * N * d / 4, dk.key, dk.thr24,
-                       dk.inv_keep, first, KBd, kb_bits);
+                       dk.inv_keep, first, KBd, kb_bits, da.key, att_bits);
     CK(hipGetLastError());
-    CK(mask_bits(dp->keep_read, dp->seed, SITE_READ_ATT, i, first, nwords, att_bits, st));
   }
   GemmP g;
   memset(&g, 0, sizeof(g));
@@ -1068,7 +1068,7 @@ int macx_kb_project(const macx_shapes* s, const macx_dropout* dp, int step, cons
     const size_t n = (size_t)s->B * s->N * d;
     const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, step);
     hipLaunchKernelGGL(kb_dropout_kernel, dim3(2048), dim3(256), 0, st, kb, n / 4, dk.key, dk.thr24, dk.inv_keep,
-                       (uint32_t)((size_t)s->b0 * s->N * d), bits_ws, reinterpret_cast<uint32_t*>(bits_ws + n));
+                       (uint32_t)((size_t)s->b0 * s->N * d), bits_ws, reinterpret_cast<uint32_t*>(bits_ws + n), 0u, (uint32_t*)nullptr);
     CK(hipGetLastError());
     g.A = bits_ws;
   }

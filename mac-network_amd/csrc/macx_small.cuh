@@ -70,18 +70,23 @@ __global__ void pack_weights_kernel(PackList L) {
 // dropout of the knowledge base (ops.py:678) as its own pass: out = kb * mask / keep, plus the keep
 // bits (1 per element) the backward pass needs.  16 B per lane; 8 lanes assemble one 32-bit word.
 __global__ __launch_bounds__(256) void kb_dropout_kernel(const float* __restrict__ kb, size_t n4, uint32_t key, uint32_t thr24,
-                                                        float inv_keep, uint32_t first, float* out, uint32_t* bits) {
+                                                        float inv_keep, uint32_t first, float* out, uint32_t* bits, uint32_t key2,
+                                                        uint32_t* bits2) {
+  // bits2 (optional): keep bits of a second dropout site over the same index range (the read unit's attention dropout,
+  // ops.py:312 via :142) -- the pass is HBM-bound, the second hash is free and saves a launch per step
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t n4r = (n4 + 7) & ~(size_t)7;   // whole words: every lane of an 8-lane group takes part in the shuffle
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4r; i += stride) {
     const bool in = i < n4;
     f32x4 v = in ? reinterpret_cast<const f32x4*>(kb)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-    uint32_t nib = 0;
+    uint32_t nib = 0, nib2 = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const bool keep = keep_bit(first + (uint32_t)(i * 4) + e, key, thr24);
+      const uint32_t idx = first + (uint32_t)(i * 4) + e;
+      const bool keep = keep_bit(idx, key, thr24);
       nib |= (keep ? 1u : 0u) << e;
       v[e] = keep ? v[e] * inv_keep : 0.f;
+      if (bits2) nib2 |= (keep_bit(idx, key2, thr24) ? 1u : 0u) << e;
     }
     if (in) reinterpret_cast<f32x4*>(out)[i] = v;
     uint32_t w = nib << (4 * (threadIdx.x & 7));
@@ -89,6 +94,13 @@ __global__ __launch_bounds__(256) void kb_dropout_kernel(const float* __restrict
     w |= __shfl_xor(w, 2, 64);
     w |= __shfl_xor(w, 4, 64);
     if ((threadIdx.x & 7) == 0 && in) bits[i >> 3] = w;
+    if (bits2) {
+      uint32_t w2 = nib2 << (4 * (threadIdx.x & 7));
+      w2 |= __shfl_xor(w2, 1, 64);
+      w2 |= __shfl_xor(w2, 2, 64);
+      w2 |= __shfl_xor(w2, 4, 64);
+      if ((threadIdx.x & 7) == 0 && in) bits2[i >> 3] = w2;
+    }
   }
 }
 
