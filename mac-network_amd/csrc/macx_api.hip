@@ -336,9 +336,9 @@ hipError_t mask_bits(float keep, uint32_t seed, uint32_t site, uint32_t step, ui
   return hipGetLastError();
 }
 
-hipError_t rowsum(const float* src, int rows, int n, size_t ld, float* dst, hipStream_t st) {
+hipError_t rowsum(const float* src, int rows, int n, size_t ld, float* dst, hipStream_t st, int nz = 1, size_t zsrc = 0, size_t zdst = 0) {
   if (!dst) return hipSuccess;
-  hipLaunchKernelGGL(rowsum_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, src, rows, n, ld, dst);
+  hipLaunchKernelGGL(rowsum_kernel, dim3((n + 63) / 64, nz), dim3(1024), 0, st, src, rows, n, ld, dst, zsrc, zdst);
   return hipGetLastError();
 }
 hipError_t axpy(const float* x, size_t n, float* y, hipStream_t st) {
@@ -955,14 +955,27 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   const float* ctrl_t = saved + L.ctrl_t;
   float* dcI_sum = ws + W.tmpBd[1];
   if (o->control_input_unshared) {
-    for (int i = 0; i < p; ++i) {
-      LinP li = lin_basic(ws + W.dcI + (size_t)i * Bd, d, d, B, ws + W.wqUT + (size_t)i * dd, nullptr, d, MACX_ACT_NON,
-                          ws + W.dt, d);
-      if (i > 0) { li.addend = ws + W.dt; li.ld_add = d; }
+    // dt = sum_i dcI_i WqU_i^T: one linear over K = p d (the per-step inputs read as one [B, p d] operand, the per-step
+    // packed transposes are contiguous = one packed [p d, d] matrix)
+    {
+      LinP li = lin_basic(ws + W.dcI, d, d, B, ws + W.wqUT, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
+      li.Ktot = p * d;
+      li.rep_stride = Bd;
       CK(small_linear_launch(li, 1, st));
-      CKI(wgrad_impl(ctrl_t, d, ws + W.dcI + (size_t)i * Bd, d, B, d, d, GP->qInputU_W + (size_t)i * dd, ws + W.small_slab, st));
-      CK(rowsum(ws + W.dcI + (size_t)i * Bd, B, d, d, GP->qInputU_b + (size_t)i * d, st));
     }
+    // the p weight gradients ctrl_t^T dcI_i share A: one batched launch (B rows -> a single split, no slabs)
+    if (gemm_split_mode() && !(kb_gemm_dbg() & 128) && wgrad_splits(B, d, d) == 1) {
+      TnP t;
+      memset(&t, 0, sizeof(t));
+      t.M = B; t.Kd = d; t.Jd = d; t.nsplit = 1; t.rows_per_split = rows_per_split(B, 1);
+      t.A = ctrl_t; t.lda = d; t.a_mod = B; t.G = ws + W.dcI; t.ldg = d;
+      t.part = GP->qInputU_W; t.nz = p; t.zG = Bd; t.zpart = dd;
+      CK(wgrad6_launch(t, st));
+    } else {
+      for (int i = 0; i < p; ++i)
+        CKI(wgrad_impl(ctrl_t, d, ws + W.dcI + (size_t)i * Bd, d, B, d, d, GP->qInputU_W + (size_t)i * dd, ws + W.small_slab, st));
+    }
+    CK(rowsum(ws + W.dcI, B, d, d, GP->qInputU_b, st, p, Bd, d));
   } else {
     hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dcI), p, Bd, dcI_sum);
     CK(hipGetLastError());

@@ -30,6 +30,7 @@ struct TnP {
   // output row k = tap * conv_cin + channel  (HWIO order).  conv_taps == 0: plain contraction.
   int conv_taps, conv_w, conv_wp, conv_cin, conv_n, conv_np;
   uint32_t magic_n, magic_w;   // ceil(2^32 / conv_n), ceil(2^32 / conv_w)
+  int nz; size_t zG, zpart;   // nz > 1: blockIdx.y selects one of nz independent contractions sharing A (G += z*zG, part += z*zpart); split kernel only
   int dbg;               // timing experiments (macx_debug_set(1, mask)): 16 no MFMAs, 32 no in-loop loads, 64 no in-loop split/store
 };
 

@@ -144,6 +144,8 @@ __global__ void transpose_kernel(const float* __restrict__ src, int R, int C, fl
 // LDS combine and a float4 epilogue.  Grid = n_out/16 x ceil(rows/64) x batch.
 // ---------------------------------------------------------------------------------------------
 struct LinSeg { const float* x; int ld; int K; size_t zstride; };
+// rep_stride != 0: the input is seg[0] repeated along k -- block r (k in [r K0, (r+1) K0)) lives at seg[0].x + r * rep_stride
+// (per-step [B,d] tensors stored [p][B][d] read as one [B, p d] operand)
 struct LinP {
   LinSeg seg[3];
   int Ktot, rows, n_out;
@@ -155,6 +157,7 @@ struct LinP {
   const float* actgrad_src; int actgrad_act; int ld_ag; size_t zag;  // val *= act'(src)
   int use_drop; DropSpec d1, d2; uint32_t drop_row0;                // val *= f1*f2, idx=(drop_row0+r)*n_out+j
   const float* addend; int ld_add; size_t zadd;                      // val += addend
+  size_t rep_stride;
 };
 
 // RTL row tiles of 16 per workgroup: 4 for tall inputs; 1 for the [B,d] chain (B <= 128 rows), where 64-row workgroups
@@ -188,8 +191,15 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
     for (int u = 0; u < PF; ++u) {
       const int Q = min(Q0 + 4 * u, nQ - 1);
       int s = 0, koff = Q * 16;
-      while (koff >= p.seg[s].K) { koff -= p.seg[s].K; ++s; }
-      const float* xs = p.seg[s].x + (size_t)z * p.seg[s].zstride + koff + lg * 4;
+      size_t rep_off = 0;
+      if (p.rep_stride) {
+        const int r = koff / p.seg[0].K;
+        koff -= r * p.seg[0].K;
+        rep_off = (size_t)r * p.rep_stride;
+      } else {
+        while (koff >= p.seg[s].K) { koff -= p.seg[s].K; ++s; }
+      }
+      const float* xs = p.seg[s].x + (size_t)z * p.seg[s].zstride + rep_off + koff + lg * 4;
       const int ld = p.seg[s].ld;
       bf[u] = *reinterpret_cast<const f32x4*>(Wz + (size_t)Q * 4 * p.n_out * 4);
 #pragma unroll
@@ -280,8 +290,11 @@ __global__ void dropout_mask_kernel(uint32_t key, uint32_t thr24, uint32_t first
 
 // dst[i] = sum over `rows` rows of src[r*ld + i]   (bias gradients from per-question partials).
 // One workgroup (16 waves) per 64 columns; waves take interleaved rows, fixed-order LDS combine.
-__global__ __launch_bounds__(1024) void rowsum_kernel(const float* __restrict__ src, int rows, int n, size_t ld, float* dst) {
+__global__ __launch_bounds__(1024) void rowsum_kernel(const float* __restrict__ src, int rows, int n, size_t ld, float* dst, size_t zsrc,
+                                                      size_t zdst) {
   __shared__ float red[16][64];
+  src += blockIdx.y * zsrc;      // blockIdx.y: independent sums of one launch
+  dst += blockIdx.y * zdst;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f;

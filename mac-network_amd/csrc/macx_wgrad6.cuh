@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
     }
     const int mg = wave;
     const float* baseA = p.A + a_col0 + 2 * lane;
-    const float* baseG = p.G + tj * JT + 2 * JW * lane;
+    const float* baseG = p.G + (size_t)blockIdx.y * p.zG + tj * JT + 2 * JW * lane;
     int amod_row = (m_begin + mg * 8) % p.a_mod;   // A row of reduction row m is m % a_mod, kept incrementally
     f32x2_t ra[3][8];
     gvec rg[3][8];
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
       __syncthreads();
     }
     // 16x16 accumulator map: col = lane & 15 (j), row = (lane >> 4) * 4 + reg (k)
-    float* out = p.part + (size_t)split * p.Kd * p.Jd;
+    float* out = p.part + (size_t)blockIdx.y * p.zpart + (size_t)split * p.Kd * p.Jd;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -213,7 +213,7 @@ inline hipError_t wgrad6_launch_t(const TnP& p, hipStream_t st) {
     attr_set = true;
   }
   const int grid = (p.Kd / T_TILE) * (p.Jd / (JW * T_TILE)) * p.nsplit;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid, p.nz > 1 ? p.nz : 1), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
