@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def default_gemm_mode():
+    return 0 if os.environ.get("MACX_GEMM") == "native" else 1
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by `pytest -m gpu` on the GPU box)")
 
@@ -15,6 +19,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def macx():
     import macx as m
+    if os.environ.get("MACX_GEMM"):         # run the whole suite on one kernel family: native | split (default)
+        m._lib.lib().macx_gemm_mode({"native": 0, "split": 1}[os.environ["MACX_GEMM"]])
     if os.environ.get("MACX_DBG"):          # debugging aid: kernel-selection / timing bits of macx_debug_set(1, .)
         m._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
     return m
@@ -34,4 +40,4 @@ def native_gemm(macx):
     L = macx._lib.lib()
     L.macx_gemm_mode(0)
     yield
-    L.macx_gemm_mode(1)
+    L.macx_gemm_mode(default_gemm_mode())

@@ -43,3 +43,9 @@ def rel_err(a, b, floor=1e-6):
 
 def max_abs(a, b):
     return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def default_gemm_mode():
+    """Kernel family the session runs on (MACX_GEMM=native|split, default split): what mode-switching tests restore."""
+    import os
+    return 0 if os.environ.get("MACX_GEMM") == "native" else 1

@@ -7,7 +7,7 @@ import torch
 
 from oracle import dropout_hash as dh
 from oracle import mac_oracle as mo
-from helpers import rel_err, max_abs
+from helpers import default_gemm_mode, rel_err, max_abs
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +63,7 @@ def test_kb_project(macx, dev, B, N, d, keep, mode):
     try:
         _kb_project_case(macx, dev, B, N, d, keep)
     finally:
-        L.macx_gemm_mode(1)
+        L.macx_gemm_mode(default_gemm_mode())
 
 
 def _kb_project_case(macx, dev, B, N, d, keep):
@@ -113,7 +113,7 @@ def test_split_gemm_error_is_fp32_class(macx, dev):
             e = (out.cpu().double().reshape(-1, d) - ref).abs() / scale
             err[mode] = (float(e.max()), float(e.mean()))
     finally:
-        L.macx_gemm_mode(1)
+        L.macx_gemm_mode(default_gemm_mode())
     assert err[1][0] < 1e-6 and err[1][1] < 5e-8, err
     assert err[1][0] <= 1.5 * err[0][0] and err[1][1] <= 1.5 * err[0][1], err
 
@@ -155,7 +155,7 @@ def test_wgrad(macx, dev, M, Kd, Jd, mode):
     try:
         _wgrad_case(macx, dev, M, Kd, Jd)
     finally:
-        L.macx_gemm_mode(1)
+        L.macx_gemm_mode(default_gemm_mode())
 
 
 def _wgrad_case(macx, dev, M, Kd, Jd):
