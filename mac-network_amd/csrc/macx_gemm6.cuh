@@ -151,11 +151,13 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
       koff = p.conv_sign * (dy * p.conv_wp + dx) * p.lda + ((kt - tap * per) << 5);
     }
+    if (p.dbg & 32) koff = 0;       // timing experiments: 32 = every slice re-reads slice 0 of A (L1/L2-hot), 64 = of B
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       ra[i] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff);
       if (AP == A_DROP) rbits[i] = Bitbase[a_row[i] * (p.lda >> 5) + kt];
     }
+    if (p.dbg & 64) kt = 0;
     if (BP == B_PLAIN) {
       // plane pl of this slice and column block: 128 cols x 64 B contiguous; thread copies 16 B of each plane
       const char* src = reinterpret_cast<const char*>(p.Wp) + ((size_t)kt * 3 * p.Nout + (size_t)cb * G_BN) * 64 + tid * 16;

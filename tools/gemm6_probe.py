@@ -37,7 +37,7 @@ def main():
             line = "B=%d N=%d d=%d %s: %7.1f us %6.1f TF(f32-equiv)  err/sum|ab| max %.2e mean %.2e" % (
                 B, N, d, "split-bf16x6" if mode else "native f32  ", us, flops / us / 1e6, float(err.max()), float(err.mean()))
             if B == 64:
-                for dbg in (1, 2, 3):
+                for dbg in (1, 2, 3, 32, 64, 96):     # 1 no epilogue, 2 no staging, 32 / 64 A / B re-read slice 0 (cache-hot)
                     L.macx_debug_set(1, dbg)
                     line += " | dbg%d %.1f" % (dbg, timeit(lambda: L.macx_kb_project(C.byref(sh), C.byref(dp), 0, p(kb), p(wp), p(b), p(out), None, None)))
                 L.macx_debug_set(1, 0)
