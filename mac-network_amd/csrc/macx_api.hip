@@ -574,7 +574,7 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     a.kb = in->knowledgeBase;
     a.att = saved + L.seg[MACX_SEG_ATT_KB] + (size_t)i * B * N;
     a.info = info_raw;
-    hipLaunchKernelGGL(kb_attend_kernel, dim3(B, d / 128), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kb_attend_kernel, dim3(B, d / 128), dim3(KA_THREADS), 0, st, a);
     CK(hipGetLastError());
   }
   // write dropout (mac_cell.py:461-463); self.infos keeps the dropped value (mac_cell.py:474)

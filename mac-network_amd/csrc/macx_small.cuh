@@ -553,14 +553,16 @@ struct KbAttP {
 };
 constexpr int K_MAXN = 1024;
 
-__global__ __launch_bounds__(256) void kb_attend_kernel(KbAttP p) {
+constexpr int KA_THREADS = 1024;     // 16 waves: the summary pass is a latency-bound stream of 16-byte loads, so many in flight
+__global__ __launch_bounds__(KA_THREADS) void kb_attend_kernel(KbAttP p) {
+  constexpr int NWV = KA_THREADS / 64, NRG = KA_THREADS / 32;
   __shared__ float s_att[K_MAXN];
-  __shared__ float s_red[8];
-  __shared__ f32x4 s_acc[8][32];
+  __shared__ float s_red[2 * NWV];
+  __shared__ f32x4 s_acc[NRG][32];
   const int b = blockIdx.x, slab = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float m = -INFINITY;
-  for (int n = tid; n < p.N; n += 256) {
+  for (int n = tid; n < p.N; n += KA_THREADS) {
     float l = p.bias[0];
     for (int q = 0; q < p.nparts; ++q) l += p.logit_part[(size_t)q * p.B * p.N + (size_t)b * p.N + n];
     s_att[n] = l;
@@ -569,28 +571,33 @@ __global__ __launch_bounds__(256) void kb_attend_kernel(KbAttP p) {
   m = wave_max(m);
   if (lane == 0) s_red[wave] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  m = s_red[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) m = fmaxf(m, s_red[w]);
   float sum = 0.f;
-  for (int n = tid; n < p.N; n += 256) {
+  for (int n = tid; n < p.N; n += KA_THREADS) {
     const float e = expf(s_att[n] - m);
     s_att[n] = e;
     sum += e;
   }
   sum = wave_sum(sum);
-  if (lane == 0) s_red[4 + wave] = sum;
+  if (lane == 0) s_red[NWV + wave] = sum;
   __syncthreads();
-  const float inv = 1.0f / ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
-  for (int n = tid; n < p.N; n += 256) {
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) tot += s_red[NWV + w];      // fixed order
+  const float inv = 1.0f / tot;
+  for (int n = tid; n < p.N; n += KA_THREADS) {
     const float a = s_att[n] * inv;
     s_att[n] = a;
     if (slab == 0) p.att[(size_t)b * p.N + n] = a;
   }
   __syncthreads();
-  // summary: 8 row groups x 32 float4 columns
+  // summary: NRG row groups x 32 float4 columns
   const int rg = tid >> 5, c4 = tid & 31;
   const float* kb = p.kb + (size_t)b * p.N * p.d + slab * 128 + c4 * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int n = rg; n < p.N; n += 8) {
+  for (int n = rg; n < p.N; n += NRG) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(kb + (size_t)n * p.d);
     const float a = s_att[n];
     acc += v * a;
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(256) void kb_attend_kernel(KbAttP p) {
   if (tid < 32) {
     f32x4 t = s_acc[0][tid];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) t += s_acc[g][tid];
+    for (int g = 1; g < NRG; ++g) t += s_acc[g][tid];
     *reinterpret_cast<f32x4*>(p.info + (size_t)b * p.d + slab * 128 + tid * 4) = t;
   }
 }

@@ -42,11 +42,6 @@ def main():
     ns = L.macx_wgrad_splits(M, d, d); ws = torch.empty(ns * d * d, device=dev); o = torch.empty(d, d, device=dev)
     us = timeit(lambda: L.macx_wgrad(p(A), d, p(G), d, M, d, d, p(o), p(ws), None))
     print("wgrad M=%d (%d splits, incl. slab reduce): %8.1f us  %6.1f TF" % (M, ns, us, flops / us / 1e6))
-    for dbg in (16, 32, 64, 80):
-        L.macx_debug_set(1, dbg)
-        us = timeit(lambda: L.macx_wgrad(p(A), d, p(G), d, M, d, d, p(o), p(ws), None))
-        print("wgrad dbg=%d (16 producers idle, 32 producers load only, 64 consumers idle): %8.1f us" % (dbg, us))
-    L.macx_debug_set(1, 0)
     Mb = 12 * M
     A2 = torch.randn(Mb, d, device=dev); G2 = torch.randn(Mb, d, device=dev)
     ns2 = L.macx_wgrad_splits(Mb, d, d); ws2 = torch.empty(ns2 * d * d, device=dev)
