@@ -1491,24 +1491,22 @@ int macx_encoder_forward(const macx_enc_shapes* s, float keep_input, float keep_
   hipLaunchKernelGGL(embed_gather_kernel, dim3(512), dim3(256), 0, st, questions, P->emb, B * S, E, Ep, (uint32_t)s->b0 * (uint32_t)S,
                      make_drop(keep_input, seed, SITE_ENC_INPUT, 0), saved + L.Xp);
   CK(hipGetLastError());
-  // input projections of every position, both directions
-  {
-    LinP l = lin_basic(saved + L.Xp, Ep, Ep, B * S, saved + L.wx_p, nullptr, G, MACX_ACT_NON, saved + L.Zx, G);
-    l.zW = (size_t)Ep * G; l.zout = (size_t)B * S * G;
-    CK(small_linear_launch(l, 2, st));
+  // input projections of every position, Zx = X Wx + b: the cell bias is added here once per position, so the per-step
+  // recurrent linear needs none and both directions go in one launch (the two bias vectors are separate tensors)
+  for (int dir = 0; dir < 2; ++dir) {
+    LinP l = lin_basic(saved + L.Xp, Ep, Ep, B * S, saved + L.wx_p + (size_t)dir * Ep * G, dir ? P->bw_bias : P->fw_bias, G, MACX_ACT_NON,
+                       saved + L.Zx + (size_t)dir * B * S * G, G);
+    CK(small_linear_launch(l, 1, st));
   }
   CK(hipMemsetAsync(saved + L.hs, 0, 2 * (size_t)(S + 1) * Bh * sizeof(float), st));
   CK(hipMemsetAsync(saved + L.cs, 0, 2 * (size_t)(S + 1) * Bh * sizeof(float), st));
   CK(hipMemsetAsync(words, 0, (size_t)B * S * 2 * h * sizeof(float), st));
-  // fw bias and bw bias live in separate tensors: copy them next to each other once
-  float* bias2 = saved + L.R;   // reuse as [2][4h] staging before the loop? -> no: R is written every step. keep biases via zb = 0 trick below
-  (void)bias2;
   for (int tau = 0; tau < S; ++tau) {
-    // R = h_prev Wh + b, per direction (two launches: the two bias vectors are separate tensors)
-    for (int dir = 0; dir < 2; ++dir) {
-      LinP l = lin_basic(saved + L.hs + ((size_t)dir * (S + 1) + tau) * Bh, h, h, B, saved + L.wh_p + (size_t)dir * h * G,
-                         dir ? P->bw_bias : P->fw_bias, G, MACX_ACT_NON, saved + L.R + (size_t)dir * B * G, G);
-      CK(small_linear_launch(l, 1, st));
+    // R = h_prev Wh for both directions
+    {
+      LinP l = lin_basic(saved + L.hs + (size_t)tau * Bh, h, h, B, saved + L.wh_p, nullptr, G, MACX_ACT_NON, saved + L.R, G);
+      l.seg[0].zstride = (size_t)(S + 1) * Bh; l.zW = (size_t)h * G; l.zout = (size_t)B * G;
+      CK(small_linear_launch(l, 2, st));
     }
     LstmP c;
     c.B = B; c.S = S; c.h = h; c.tau = tau; c.len = lengths;
