@@ -72,17 +72,17 @@ def cpu_baseline(seed, iters, sample_b, budget_s=25.0):
                       "(oracle/mac_oracle.py), median" % (len(times), sample_b, S, N, D, P)}
 
 
-def model_level(macx, mo, dev, seed, steps=6):
+def model_level(macx, dev, seed, steps=6):
     """Secondary number that honours "KB = 14x14x1024": the whole tower body of MACnet.build -- question encoder
     (embedding 300 + biLSTM 2x256) and stem CNN (1024->512->512) -> MAC cell x p -> output unit + classifier -> mean CE,
     backward, fused clip + Adam + EMA step; batch 64, train-mode dropouts.  Inputs are the reference's feed dict:
     question word ids + lengths, 14x14x1024 image features, answer ids."""
-    cfg = mo.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
+    cfg = macx.configs.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
     VOCAB = 90                                                    # CLEVR question vocabulary size (preprocess.py)
     net = macx.MACNet(cfg, vocab=VOCAB, generator=torch.Generator().manual_seed(seed)).to(dev)
     opt = macx.optim.FlatAdamEMA(net.tensors(), lr=1e-4, clip_norm=8.0, ema_decay=0.999)
     g = torch.Generator().manual_seed(seed)
-    _, _, lengths, _ = mo.synthetic_inputs(B, S, 1, 8, seed=seed)
+    _, _, lengths, _ = macx.configs.synthetic_inputs(B, S, 1, 8, seed=seed)
     img = torch.relu(torch.randn(B, N, 1024, generator=g)).to(dev)
     qs = torch.randint(1, VOCAB + 1, (B, S), generator=g, dtype=torch.int32)
     qs = (qs * (torch.arange(S).unsqueeze(0) < lengths.unsqueeze(1)).to(torch.int32)).to(dev)
@@ -150,7 +150,6 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import macx
-    from oracle import mac_oracle as mo   # only for synthetic input shapes + the cpu_baseline leg
     if os.environ.get("MACX_DBG"):          # tuning only: kb GEMM debug bits
         macx._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
     if os.environ.get("MACX_GEMM"):         # native | split (default): kernel family of the knowledge-base GEMMs
@@ -158,10 +157,10 @@ def main():
     if os.environ.get("MACX_FORCE_RT"):     # tuning only: row tiles per GEMM workgroup
         macx._lib.lib().macx_debug_set(2, int(os.environ["MACX_FORCE_RT"]))
     p = args.p
-    cfg = mo.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
     seed = 1234
     b0 = rank * B                                                   # tower rule, equal shards (model.py:139-149)
-    vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, D, seed=seed + rank)
+    vq, words, lengths, kb = macx.configs.synthetic_inputs(B, S, N, D, seed=seed + rank)
     params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(seed)).to(dev)
     vqd, wd, kbd = [t.to(dev).requires_grad_(True) for t in (vq, words, kb)]
     ld = lengths.to(dev)
@@ -283,7 +282,7 @@ def main():
             out["native_f32_mfma"] = {"value": round(B / dtn, 2), "unit": "questions/s", "ms_per_step": round(dtn * 1e3, 3), "steps": 5,
                                       "whole_step_frac": round(B / dtn * 3 * p * F / PEAK_FP32_MFMA, 4)}
         if world == 1 and not args.no_model_level:
-            out["model_level"] = model_level(macx, mo, dev, seed)
+            out["model_level"] = model_level(macx, dev, seed)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seed, args.cpu_iters, args.cpu_batch)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

@@ -144,3 +144,19 @@ def test_checkpoint_roundtrip_reference_names(tmp_path):
     bad["qEmbeddings/emb"] = torch.zeros(3, 3)
     with pytest.raises(ValueError):
         macx.checkpoint.load_reference(net, bad)
+
+
+def test_product_configs_match_the_oracle_copies():
+    """macx.configs (what bench.py / smoke() build workloads from) and the oracle's own copies describe the same flag files
+    and draw the same synthetic inputs -- the measured path never imports oracle/."""
+    import macx
+    from oracle import mac_oracle as mo
+    for name in ("args", "args1", "args2", "args3", "args4"):
+        a = vars(macx.configs.flag_file_config(name, netLength=5))
+        b = vars(mo.flag_file_config(name, netLength=5))
+        assert a == b, name
+    for x, y in zip(macx.configs.synthetic_inputs(3, 7, 5, 8, seed=4), mo.synthetic_inputs(3, 7, 5, 8, seed=4)):
+        assert torch.equal(x, y)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    body = src[src.index("def main():"):]
+    assert "oracle" not in body.replace("cpu_baseline", "")     # only the cpu_baseline leg touches the oracle
