@@ -5,14 +5,13 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import macx
-from oracle import mac_oracle as mo
 
 def main():
     dev = torch.device("cuda:0")
     S, N, D, P = 50, 196, 512, 12
-    cfg = mo.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
+    cfg = macx.configs.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
     for B in [int(a) for a in sys.argv[1:]] or [64, 8]:
-        vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, D, seed=1)
+        vq, words, lengths, kb = macx.configs.synthetic_inputs(B, S, N, D, seed=1)
         params = macx.MACCellParams(cfg, P, generator=torch.Generator().manual_seed(1)).to(dev)
         vqd, wd, kbd = [t.to(dev).requires_grad_(True) for t in (vq, words, kb)]
         ld = lengths.to(dev)

@@ -57,9 +57,8 @@ if __name__ == "__main__" and "--stem" not in sys.argv:
 
 def stem_bench():
     import time
-    from oracle import mac_oracle as mo
-    dev = torch.device("cuda:0")
-    cfg = mo.flag_file_config("args")
+        dev = torch.device("cuda:0")
+    cfg = macx.configs.flag_file_config("args")
     stem = macx.Stem(cfg).to(dev)
     B = 64
     img = torch.relu(torch.randn(B, 196, 1024, device=dev))
@@ -78,9 +77,8 @@ def stem_bench():
 
 
 def encoder_bench():
-    from oracle import mac_oracle as mo
-    dev = torch.device("cuda:0")
-    cfg = mo.flag_file_config("args")
+        dev = torch.device("cuda:0")
+    cfg = macx.configs.flag_file_config("args")
     enc = macx.QuestionEncoder(cfg, vocab=90).to(dev)
     for B, S in ((64, 50), (64, 30), (8, 50)):
         g = torch.Generator().manual_seed(1)
