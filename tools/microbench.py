@@ -57,7 +57,7 @@ if __name__ == "__main__" and "--stem" not in sys.argv:
 
 def stem_bench():
     import time
-        dev = torch.device("cuda:0")
+    dev = torch.device("cuda:0")
     cfg = macx.configs.flag_file_config("args")
     stem = macx.Stem(cfg).to(dev)
     B = 64
@@ -77,7 +77,7 @@ def stem_bench():
 
 
 def encoder_bench():
-        dev = torch.device("cuda:0")
+    dev = torch.device("cuda:0")
     cfg = macx.configs.flag_file_config("args")
     enc = macx.QuestionEncoder(cfg, vocab=90).to(dev)
     for B, S in ((64, 50), (64, 30), (8, 50)):
