@@ -324,8 +324,14 @@ int macx_wgrad_splits(int M, int Kd, int Jd);
 int macx_wgrad(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd,
                float* out, float* ws, void* stream);
 
-/* tuning hook for A/B measurements: key 0 = waves per workgroup of the native knowledge-base GEMM (4 | 8), 1 = phase-timing
- * bits, 2 = forced row tiles per workgroup, 3 = macx_gemm_mode */
+/* tuning hook for A/B measurements (never needed for correct results):
+ *   key 0  waves per workgroup of the NATIVE knowledge-base GEMM (4 | 8)
+ *   key 1  bit mask of timing experiments / kernel selection:
+ *            1 skip the GEMM epilogue, 2 skip the in-loop staging, 4 write-through output stores (unsafe: stale cross-XCD
+ *            reads were observed), 8 epilogue without its global stores, 32 / 64 re-read K-slice 0 of A / of the weights
+ *            (cache-hot), 128 weight-gradient contractions on the f32 TN kernel, 256 S_b kernel on the f32 kernel
+ *   key 2  forced row tiles per GEMM workgroup (0 = automatic | 1 | 2 | 4 | 7 | 13)
+ *   key 3  = macx_gemm_mode */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);
