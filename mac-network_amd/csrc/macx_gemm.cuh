@@ -279,6 +279,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
   uint32_t rbits[A_IT];
   f32x4 rw[B_IT];
   f32x4 rw2[B_IT];
+  f32x4 ry[B_IT];        // B_YMIX_ROW: the slice of y_b the weight rows are scaled by (fetched with the tile, not at use)
 
   const bool conv = p.conv_taps > 0;
   const float* Abase = p.A + (size_t)b * (p.a_qstride ? p.a_qstride : (size_t)p.N * p.lda);
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
       const size_t off = ((size_t)(kt * 8 + chunk) * p.Nout + cb * G_BN + j) * 4;
       rw[i] = *reinterpret_cast<const f32x4*>(p.Wp + off);
       if (BP != B_PLAIN) rw2[i] = *reinterpret_cast<const f32x4*>(p.Wp2 + off);
+      if (BP == B_YMIX_ROW) ry[i] = *reinterpret_cast<const f32x4*>(p.y + (size_t)b * p.ldy + kt * G_BK + (chunk >> 2) * 16 + (chunk & 3) * 4);
     }
   };
 
@@ -346,10 +348,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
       f32x4 val = rw[i];
       if (BP == B_YMIX_ROW) {
         // B_eff[k][j] = y[b][k] * W1a[k][j] + W1b[k][j]   (ops.py:703,718 folded into the weights)
-        const int chunk = f / G_BN;
-        const int k = kt * G_BK + (chunk >> 2) * 16 + (chunk & 3) * 4;
-        const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.y + (size_t)b * p.ldy + k);
-        val = val * y4 + rw2[i];
+        val = val * ry[i] + rw2[i];
       } else if (BP == B_YMIX_COL) {
         // B_eff[k][j] = y[b][j] * W1a^T[k][j] + W1b^T[k][j]   (backward-data of the same product)
         val = val * ycol + rw2[i];

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
   uint32_t rbits[A_IT];
   u32x4 rb[3];            // B_PLAIN: raw plane bytes
   f32x4 rw[2], rw2[2];    // B_YMIX: fp32 k-major tiles
+  f32x4 ry[2];            // B_YMIX_ROW: the slice of y_b the weight rows are scaled by (fetched with the tile, not at use)
 
   const bool conv = p.conv_taps > 0;
   const float* Abase = p.A + (size_t)b * (p.a_qstride ? p.a_qstride : (size_t)p.N * p.lda);
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
         const size_t off = ((size_t)kt * p.Nout + cb * G_BN) * 32 + (size_t)(tid + G_THREADS * i) * 4;
         rw[i] = *reinterpret_cast<const f32x4*>(p.Wp + off);
         rw2[i] = *reinterpret_cast<const f32x4*>(p.Wp2 + off);
+        if (BP == B_YMIX_ROW) ry[i] = *reinterpret_cast<const f32x4*>(p.y + (size_t)b * p.ldy + (kt << 5) + ((tid + G_THREADS * i) & 7) * 4);
       }
     }
   };
@@ -205,8 +207,7 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
         f32x4 val;
         if (BP == B_YMIX_ROW) {
           // B_eff[k][j] = y[b][k] * W1a[k][j] + W1b[k][j]   (ops.py:703,718 folded into the weights)
-          const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.y + (size_t)b * p.ldy + (kt << 5) + (f & 7) * 4);
-          val = rw[i] * y4 + rw2[i];
+          val = rw[i] * ry[i] + rw2[i];
         } else {
           // B_eff[k][j] = y[b][j] * W1a^T[k][j] + W1b^T[k][j]   (backward-data of the same product)
           val = rw[i] * ycol[i] + rw2[i];
