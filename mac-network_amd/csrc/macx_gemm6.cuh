@@ -52,6 +52,18 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& p0, u32x2& p1, u32x
   p2[0] = pk_bf16(q[0], q[1]);
   p2[1] = pk_bf16(q[2], q[3]);
 }
+// exact 3-way split of 8 fp32 values (8 consecutive k of one row / column) into three 16-byte bf16x8 slots
+__device__ __forceinline__ void split8(const float* x, u32x4& p0, u32x4& p1, u32x4& p2) {
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const float a = x[2 * h], b = x[2 * h + 1];
+    p0[h] = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0[h] << 16), rb = b - __uint_as_float(p0[h] & 0xFFFF0000u);
+    p1[h] = pk_bf16(ra, rb);
+    p2[h] = pk_bf16(ra - __uint_as_float(p1[h] << 16), rb - __uint_as_float(p1[h] & 0xFFFF0000u));
+  }
+}
+
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 a, const u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
@@ -60,7 +72,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 a, const u32x4 b, f32x4 c
 //   1: Wb[kt][plane][n][32] bf16 = split planes of W[k][n];  2: Wt[kt][n][32] fp32 k-major tiles
 constexpr size_t gemm6_plane_floats(size_t K, size_t Nout) { return K * Nout * 3 / 2; }   // format 1 size in floats
 
-constexpr int GS_PAD = 64;      // padding of the k-group stride (bytes): 0 keeps the b128 fragment reads conflict-free
+constexpr int GS_PAD = 0;       // padding of the k-group stride (bytes): 0 keeps the b128 fragment reads conflict-free
 
 template <int RT>
 constexpr int kb_gemm6_lds_bytes() {
@@ -83,8 +95,8 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
   constexpr int A_PLANE = 4 * A_GS;                  // bytes
   constexpr int B_PLANE = 4 * B_GS;
   constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;
-  constexpr int A_F4 = ROWS * 8;                     // float4 (4 k of one row) per A stage
-  constexpr int A_IT = (A_F4 + G_THREADS - 1) / G_THREADS;
+  constexpr int A_SLOTS = ROWS * 4;                  // 16-byte slots (8 k of one row) per A plane and stage
+  constexpr int A_IT = (A_SLOTS + G_THREADS - 1) / G_THREADS;
   constexpr int HT = (RT + 1) / 2;                   // row tiles of the upper wave half (the lower one has RT - HT)
   char* lds = reinterpret_cast<char*>(smem);
 
@@ -115,34 +127,41 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
 #pragma unroll
   for (int t = 0; t < HT; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 ra[A_IT];
+  // ---- staging: one thread <-> one 16-byte LDS slot (8 consecutive k of one row of A / one column of the weight tile).
+  // Slots are dealt so that the 64 lanes of a wave cover 16 consecutive rows x 4 k-groups with lane = 16 g + row: the
+  // ds_write_b128 / ds_read_b128 lane groups of gfx950 then hit 16 distinct 4-bank slots, i.e. NO bank conflicts on either
+  // side with an unpadded k-group stride (the PMC pass of the first layout showed half of the LDS-active cycles were
+  // conflict cycles), and a lane's two float4 loads are 32 contiguous bytes of a row (a wave touches 16 full 128-B lines).
+  f32x4 ra[A_IT][2];
   uint32_t rbits[A_IT];
-  u32x4 rb[3];            // B_PLAIN: raw plane bytes
-  f32x4 rw[2], rw2[2];    // B_YMIX: fp32 k-major tiles
-  f32x4 ry[2];            // B_YMIX_ROW: the slice of y_b the weight rows are scaled by (fetched with the tile, not at use)
+  u32x4 rb[3];               // B_PLAIN: raw plane bytes
+  f32x4 rw[2], rw2[2];       // B_YMIX: 8 consecutive k of W1a / W1b for this thread's column
+  f32x4 ry[2];               // B_YMIX_ROW: the matching 8 entries of y_b
 
   const bool conv = p.conv_taps > 0;
   const float* Abase = p.A + (size_t)b * (p.a_qstride ? p.a_qstride : (size_t)p.N * p.lda);
   const uint32_t* Bitbase = (AP == A_DROP) ? p.a_bits + (size_t)b * p.N * (p.lda >> 5) : nullptr;
+  const int sg = lane >> 4;                 // k-group of this thread's slots (A and B)
   int a_off[A_IT];
   int a_row[A_IT];
-  bool a_ok[A_IT];
+  int a_lrow[A_IT];
+  bool a_ok[A_IT], a_in[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int f = tid + G_THREADS * i;
-    const int n = row0 + (f >> 3);
-    a_ok[i] = (f < A_F4) && (n < row_end);
+    const int lrow = (f >> 6) * 16 + (lane & 15);
+    const int n = row0 + lrow;
+    a_lrow[i] = lrow;
+    a_in[i] = f < A_SLOTS;
+    a_ok[i] = a_in[i] && (n < row_end);
     const int nc = min(n, p.N - 1);
     a_row[i] = nc;
     const int srow = conv ? (nc / p.conv_w + 1) * p.conv_wp + (nc % p.conv_w) + 1 : nc;
-    a_off[i] = srow * p.lda + (f & 7) * 4;
+    a_off[i] = srow * p.lda + sg * 8;
   }
-  // B_YMIX staging: thread -> (column j = f >> 3, k quad kq = f & 7) of the 128 x 32 tile, f = tid + 512 i
-  float ycol[2] = {0.f, 0.f};
-  if (BP == B_YMIX_COL) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ycol[i] = p.y[(size_t)b * p.ldy + cb * G_BN + ((tid + G_THREADS * i) >> 3)];
-  }
+  const int bcol = (lane & 15) + 16 * (tid >> 6);      // this thread's column of the 128-column weight tile
+  float ycol = 0.f;
+  if (BP == B_YMIX_COL) ycol = p.y[(size_t)b * p.ldy + cb * G_BN + bcol];
 
   auto load_tiles = [&](int kt) {
     int koff = kt << 5;
@@ -155,22 +174,23 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
     if (p.dbg & 32) koff = 0;       // timing experiments: 32 = every slice re-reads slice 0 of A (L1/L2-hot), 64 = of B
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      ra[i] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff);
+      ra[i][0] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff);
+      ra[i][1] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff + 4);
       if (AP == A_DROP) rbits[i] = Bitbase[a_row[i] * (p.lda >> 5) + kt];
     }
     if (p.dbg & 64) kt = 0;
     if (BP == B_PLAIN) {
-      // plane pl of this slice and column block: 128 cols x 64 B contiguous; thread copies 16 B of each plane
-      const char* src = reinterpret_cast<const char*>(p.Wp) + ((size_t)kt * 3 * p.Nout + (size_t)cb * G_BN) * 64 + tid * 16;
+      // plane pl of this slice and column block: [128 cols][32 k] bf16; the thread copies its slot (column bcol, k-group sg)
+      const char* src = reinterpret_cast<const char*>(p.Wp) + ((size_t)kt * 3 * p.Nout + (size_t)cb * G_BN + bcol) * 64 + sg * 16;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) rb[pl] = *reinterpret_cast<const u32x4*>(src + (size_t)pl * p.Nout * 64);
     } else {
+      const size_t off = ((size_t)kt * p.Nout + cb * G_BN + bcol) * 32 + sg * 8;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const size_t off = ((size_t)kt * p.Nout + cb * G_BN) * 32 + (size_t)(tid + G_THREADS * i) * 4;
-        rw[i] = *reinterpret_cast<const f32x4*>(p.Wp + off);
-        rw2[i] = *reinterpret_cast<const f32x4*>(p.Wp2 + off);
-        if (BP == B_YMIX_ROW) ry[i] = *reinterpret_cast<const f32x4*>(p.y + (size_t)b * p.ldy + (kt << 5) + ((tid + G_THREADS * i) & 7) * 4);
+      for (int h = 0; h < 2; ++h) {
+        rw[h] = *reinterpret_cast<const f32x4*>(p.Wp + off + 4 * h);
+        rw2[h] = *reinterpret_cast<const f32x4*>(p.Wp2 + off + 4 * h);
+        if (BP == B_YMIX_ROW) ry[h] = *reinterpret_cast<const f32x4*>(p.y + (size_t)b * p.ldy + (kt << 5) + sg * 8 + 4 * h);
       }
     }
   };
@@ -179,46 +199,40 @@ __global__ __launch_bounds__(512) void kb_gemm6_kernel(GemmP p) {
     char* dA = lds + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int f = tid + G_THREADS * i;
-      f32x4 val = ra[i];
-      if (AP == A_DROP) {
-        const uint32_t bits = rbits[i] >> ((f & 7) * 4);
+      float x[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = ((bits >> e) & 1u) ? val[e] * p.a_inv_keep : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        float vv = ra[i][e >> 2][e & 3];
+        if (AP == A_DROP) vv = ((rbits[i] >> (sg * 8 + e)) & 1u) ? vv * p.a_inv_keep : 0.f;
+        x[e] = a_ok[i] ? vv : 0.f;
       }
-      if (!a_ok[i]) val = f32x4{0.f, 0.f, 0.f, 0.f};
-      u32x2 s0, s1, s2;
-      split4(val, s0, s1, s2);
-      if (f < A_F4) {
-        const int o = ((f & 7) >> 1) * A_GS + (f >> 3) * 16 + (f & 1) * 8;     // k-group, row, half of the 8-element slot
-        *reinterpret_cast<u32x2*>(dA + o) = s0;
-        *reinterpret_cast<u32x2*>(dA + A_PLANE + o) = s1;
-        *reinterpret_cast<u32x2*>(dA + 2 * A_PLANE + o) = s2;
+      u32x4 s0, s1, s2;
+      split8(x, s0, s1, s2);
+      if (a_in[i]) {
+        char* d = dA + sg * A_GS + a_lrow[i] * 16;
+        *reinterpret_cast<u32x4*>(d) = s0;
+        *reinterpret_cast<u32x4*>(d + A_PLANE) = s1;
+        *reinterpret_cast<u32x4*>(d + 2 * A_PLANE) = s2;
       }
     }
-    char* dB = dA + 3 * A_PLANE;
+    char* dB = dA + 3 * A_PLANE + sg * B_GS + bcol * 16;
     if (BP == B_PLAIN) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dB + pl * B_PLANE + (tid & 3) * B_GS + (tid >> 2) * 16) = rb[pl];
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dB + pl * B_PLANE) = rb[pl];
     } else {
+      float x[8];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int f = tid + G_THREADS * i;
-        f32x4 val;
-        if (BP == B_YMIX_ROW) {
-          // B_eff[k][j] = y[b][k] * W1a[k][j] + W1b[k][j]   (ops.py:703,718 folded into the weights)
-          val = rw[i] * ry[i] + rw2[i];
-        } else {
-          // B_eff[k][j] = y[b][j] * W1a^T[k][j] + W1b^T[k][j]   (backward-data of the same product)
-          val = rw[i] * ycol[i] + rw2[i];
-        }
-        u32x2 s0, s1, s2;
-        split4(val, s0, s1, s2);
-        const int o = ((f & 7) >> 1) * B_GS + (f >> 3) * 16 + (f & 1) * 8;
-        *reinterpret_cast<u32x2*>(dB + o) = s0;
-        *reinterpret_cast<u32x2*>(dB + B_PLANE + o) = s1;
-        *reinterpret_cast<u32x2*>(dB + 2 * B_PLANE + o) = s2;
+      for (int e = 0; e < 8; ++e) {
+        // ROW: B_eff[k][j] = y[b][k] * W1a[k][j] + W1b[k][j]   (ops.py:703,718 folded into the weights)
+        // COL: B_eff[k][j] = y[b][j] * W1a^T[k][j] + W1b^T[k][j]   (backward-data of the same product)
+        const float yy = (BP == B_YMIX_ROW) ? ry[e >> 2][e & 3] : ycol;
+        x[e] = fmaf(rw[e >> 2][e & 3], yy, rw2[e >> 2][e & 3]);
       }
+      u32x4 s0, s1, s2;
+      split8(x, s0, s1, s2);
+      *reinterpret_cast<u32x4*>(dB) = s0;
+      *reinterpret_cast<u32x4*>(dB + B_PLANE) = s1;
+      *reinterpret_cast<u32x4*>(dB + 2 * B_PLANE) = s2;
     }
   };
 

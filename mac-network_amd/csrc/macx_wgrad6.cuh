@@ -20,18 +20,6 @@ constexpr int W6_PLANE = 4 * W6_GS;
 constexpr int W6_OPER = 3 * W6_PLANE;
 constexpr int W6_STAGE = 2 * W6_OPER;
 
-// exact 3-way split of 8 fp32 values (consecutive m of one column) into three 16-byte bf16x8 slots
-__device__ __forceinline__ void split8(const float* x, u32x4& p0, u32x4& p1, u32x4& p2) {
-#pragma unroll
-  for (int h = 0; h < 4; ++h) {
-    const float a = x[2 * h], b = x[2 * h + 1];
-    p0[h] = pk_bf16(a, b);
-    const float ra = a - __uint_as_float(p0[h] << 16), rb = b - __uint_as_float(p0[h] & 0xFFFF0000u);
-    p1[h] = pk_bf16(ra, rb);
-    p2[h] = pk_bf16(ra - __uint_as_float(p1[h] << 16), rb - __uint_as_float(p1[h] & 0xFFFF0000u));
-  }
-}
-
 // JW = j-width of the output tile in units of 128 columns.  JW = 2 (128 x 256 tiles, consumer wave tile 64 x 128) doubles
 // the MFMA work per barrier and reads the A operand half as often; used whenever Jd is a multiple of 256.
 template <int JW>
