@@ -553,7 +553,9 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   g.A = rdrop ? KBd : in->knowledgeBase; g.lda = d;
   g.Wp = saved + L.wx_p;
   g.out = X; g.ldo = d; g.bias = P->projX_b; g.act = MACX_ACT_NON;
-  CK((kb_gemm<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  // Without read dropout the projected knowledge base is the same at every step (the reference recomputes it,
+  // ops.py:688); when the activations are not kept (inference) all steps share one X buffer, so step 0's is reused.
+  if (rdrop || L.act_stride != 0 || i == 0) CK((kb_gemm<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
   // H1 = act( concat([X*y, X]) W1 + b1 ) = act( X (diag(y) W1a + W1b) + b1 )   (ops.py:703,718; mac_cell.py:237)
   g.A = X;
   g.Wp = saved + L.w1a_p; g.Wp2 = saved + L.w1b_p; g.y = y; g.ldy = d;
