@@ -52,6 +52,23 @@ def _resolve_act(config, name):
     raise ValueError("relu=%r" % r)
 
 
+def resolve_activations(config):
+    """Resolve every activation flag the graph would actually apply (the same call sites as the reference:
+    mac_cell.py:149-150, 164, 237, 262, 313, 355, 445), raising what ops.relu raises for LKY / SELU."""
+    g = lambda n: get(config, n)
+    acts = {"controlInputAct": _resolve_act(config, g("controlInputAct")), "writeInfoAct": _resolve_act(config, g("writeInfoAct")),
+            "writeMemAct": _resolve_act(config, g("writeMemAct"))}
+    if g("controlFeedPrev"):
+        acts["controlContAct"] = _resolve_act(config, g("controlContAct"))
+    if g("controlProj"):
+        acts["controlProjAct"] = _resolve_act(config, g("controlProjAct"))
+    if g("readMemProj"):
+        acts["readMemAct"] = _resolve_act(config, g("readMemAct"))
+    if g("readCtrl"):
+        acts["readCtrlAct"] = _resolve_act(config, g("readCtrlAct"))
+    return acts
+
+
 def reject_like_reference(config):
     """Raise what the reference raises at graph-build time for broken option values."""
     g = lambda n: get(config, n)
@@ -66,6 +83,9 @@ def reject_like_reference(config):
     if g("readCtrl") and g("readProjInputs") and g("attDim") != g("ctrlDim"):                  # mac_cell.py:245-246
         raise NameError("name 'ctrlDim' is not defined")
     if g("writeGate") and g("writeGateShared"):   # [B,d] * [B] does not broadcast (ops.py:317, mac_cell.py:367)
+        raise ValueError("Dimensions must be equal")
+    if g("readCtrl") and g("readCtrlConcatInter"):
+        # mac_cell.py:248-250 drops the width ops.mul returns: inter2att builds a [dim] weight for a [.., 2 dim] tensor
         raise ValueError("Dimensions must be equal")
 
 

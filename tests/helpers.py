@@ -49,3 +49,33 @@ def default_gemm_mode():
     """Kernel family the session runs on (MACX_GEMM=native|split, default split): what mode-switching tests restore."""
     import os
     return 0 if os.environ.get("MACX_GEMM") == "native" else 1
+
+
+def hashed_tensor(key, shape, lim=1.0):
+    """Deterministic pseudo-random fp32 tensor in (-lim, lim): integer hash of (key, flat index) -> 24-bit fraction.
+    Pure integer arithmetic + two IEEE roundings, so the generator script (build container) and the GPU tests (GPU box)
+    produce the same bits without shipping the arrays.  Used for the parameters of tests/golden/reference/hip_*.npz."""
+    from oracle import dropout_hash as dh
+    n = int(np.prod(shape)) if len(shape) else 1
+    k = int(dh.hash_mix(np.uint64(key) ^ np.uint64(0x5BD1E995)))
+    bits = dh.hash_mix(np.arange(n, dtype=np.uint64) ^ np.uint64(k)) >> np.uint64(8)          # 24 bits
+    u = (bits.astype(np.float64) + 0.5) / 16777216.0 * 2.0 - 1.0
+    return torch.from_numpy((u * lim).astype(np.float32).reshape(shape))
+
+
+def hashed_reference_params(shapes, seed):
+    """{variable name: fp32 tensor} for an ordered {name: shape} table: xavier-like limits for weights, small non-zero
+    biases (so that bias paths are exercised), N(0,1)-scale state variables."""
+    out = {}
+    for i, (name, shape) in enumerate(shapes.items()):
+        shape = tuple(int(s) for s in shape)
+        if name.endswith("initMem") or name.endswith("initCtrl"):
+            lim = 1.5
+        elif "/biases/" in name or name.endswith("/bias"):
+            lim = 0.1
+        elif len(shape) == 1:
+            lim = (3.0 / shape[0]) ** 0.5
+        else:
+            lim = (6.0 / (shape[-2] + shape[-1])) ** 0.5
+        out[name] = hashed_tensor(seed * 1000 + i, shape, lim)
+    return out

@@ -1,0 +1,290 @@
+"""CPU: the parity anchor.  The reference's own mac_cell.py / ops.py / model.py / config.py are executed
+UNMODIFIED (tests/ref_exec.py over the eager TF-1.x stand-in of tests/tf1_shim) and oracle/mac_oracle.py --
+the checker every GPU parity test uses -- must reproduce them: same parsed flag values, same variable names and
+shapes, same states / attentions / logits / loss / predictions to 1e-12 in fp64, and the same gradients, for all
+five published flag files (configs/args*.txt) in evaluation and in training mode (identical dropout draws), plus
+the legal option values outside the flag files and the option values that raise.
+
+/root/reference only exists in the build container; on the GPU box these tests skip and
+tests/test_reference_golden.py checks the oracle against the vectors this machinery generated
+(tests/golden/reference_*.npz, tests/golden/make_reference_golden.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+import ref_exec as rx
+from oracle import mac_oracle as mo
+
+pytestmark = pytest.mark.skipif(not rx.available(), reason="/root/reference is not present on this machine")
+
+FLAG_FILES = ["args", "args1", "args2", "args3", "args4"]
+B, S, N, D, P, HID, ANS = 3, 6, 10, 16, 3, 8, 7
+
+
+def oracle_config_from(cfg):
+    """An oracle config carrying exactly what the reference's parser produced."""
+    snap = rx.snapshot(cfg)
+    return mo.default_config(answerWordsNum=ANS, **snap)
+
+
+def inputs(seed=11):
+    vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, D, seed=seed, dtype=torch.float64)
+    g = torch.Generator().manual_seed(seed + 1)
+    raw = (torch.rand((B, S, D), generator=g, dtype=torch.float64) * 2 - 1)     # questionWords != questionCntxWords
+    answers = torch.randint(0, ANS, (B,), generator=g)
+    return vq, raw, words, lengths, kb, answers
+
+
+def run_pair(cfg, train, need_grad=False, seed=5, keeps=None, output_keep=None):
+    """reference run, then the oracle on the reference's variables and draws"""
+    vq, raw, words, lengths, kb, answers = inputs()
+    if keeps is None:
+        keeps = (cfg.memoryDropout, cfg.readDropout, 0.9 if train else cfg.writeDropout) if train else (1.0, 1.0, 1.0)
+    if train:
+        cfg.writeDropout = keeps[2]        # the write dropout op exists only if config.writeDropout < 1 (mac_cell.py:461)
+    if output_keep is None:
+        output_keep = cfg.outputDropout if train else 1.0
+    ref = rx.run_reference(cfg, vq, raw, words, lengths, kb, train=train, keeps=keeps, output_keep=output_keep,
+                           seed=seed, need_grad=need_grad, answers=answers, answerWordsNum=ANS)
+    ocfg = oracle_config_from(cfg)
+    params = {k: v.detach().clone().requires_grad_(need_grad) for k, v in ref["variables"].items()}
+    vs = mo.VarStore(params=params, dtype=torch.float64)
+    draws = ref["draws"]
+    if cfg.memoryVariationalDropout and keeps[0] == 1.0:
+        # ops.generateVarDpMask draws even when keep == 1 (ops.py:1054-1059): floor(1 + U) is all ones, the oracle skips it
+        assert bool((torch.floor(1.0 + draws[0]) == 1).all())
+        draws = draws[1:]
+    mask_fn = rx.replay_mask_fn(draws, keeps)
+    ins = [t.clone().requires_grad_(need_grad) for t in (vq, raw, words, kb)]
+    c, m, cell = mo.mac_network(ocfg, vs, ins[0], ins[1], ins[2], lengths, ins[3], train=train, mask_fn=mask_fn, keeps=keeps)
+    masks = mask_fn.rest(output_keep) if output_keep != 1.0 else None
+    logits = mo.output_classifier(ocfg, vs, m, ins[0], output_keep=output_keep, masks=masks)
+    assert mask_fn.left() == 0, "the reference drew more random tensors than the oracle consumed"
+    loss, preds = mo.answer_loss_and_pred(logits, answers)
+    orc = dict(control=c, memory=m, cell=cell, logits=logits, loss=loss, preds=preds, params=params, inputs=ins, store=vs)
+    return ref, orc, answers
+
+
+def assert_same_forward(ref, orc, tol=1e-12):
+    def close(a, b, what):
+        a, b = torch.as_tensor(a).detach().double(), torch.as_tensor(b).detach().double()
+        assert a.shape == b.shape, "%s: shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+        err = float((a - b).abs().max()) if a.numel() else 0.0
+        assert err <= tol, "%s differs from the reference by %.3e" % (what, err)
+
+    rc, oc = ref["cell"], orc["cell"]
+    close(orc["control"], ref["control"], "final control")
+    close(orc["memory"], ref["memory"], "final memory")
+    close(oc.controls, rc.controls, "controls history")
+    close(oc.memories, rc.memories, "memories history")
+    close(oc.infos, rc.infos, "infos history")
+    for key in ("kb", "question", "self", "gate"):
+        assert len(oc.attentions[key]) == len(rc.attentions[key]), "attentions[%s] length" % key
+        for i, (a, b) in enumerate(zip(oc.attentions[key], rc.attentions[key])):
+            close(a, b, "attentions[%s][%d]" % (key, i))
+    close(orc["logits"], ref["logits"], "logits")
+    close(orc["loss"], ref["loss"], "loss")
+    assert torch.equal(orc["preds"].long(), torch.as_tensor(ref["preds"]).long()), "predicted answers"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the flag tables
+# ---------------------------------------------------------------------------------------------------------------
+def test_default_flag_values_match_the_reference_parser():
+    """oracle.default_config(), macx.options.DEFAULTS and macx.configs mirror config.py's defaults."""
+    cfg = rx.parse_flags(None)
+    snap = rx.snapshot(cfg)
+    oc = mo.default_config()
+    for k, v in snap.items():
+        assert getattr(oc, k) == v, "oracle default of --%s is %r, the reference parses %r" % (k, getattr(oc, k), v)
+    import macx
+    for k, v in macx.options.DEFAULTS.items():
+        assert getattr(cfg, k) == v, "options.DEFAULTS[%s] = %r, the reference parses %r" % (k, v, getattr(cfg, k))
+
+
+@pytest.mark.parametrize("name", FLAG_FILES)
+def test_flag_files_parse_to_the_oracle_tables(name):
+    cfg = rx.parse_flags(name + ".txt")
+    snap = rx.snapshot(cfg)
+    oc = mo.flag_file_config(name)
+    for k, v in snap.items():
+        assert getattr(oc, k) == v, "%s: oracle has --%s = %r, the reference parses %r" % (name, k, getattr(oc, k), v)
+    import macx
+    pc = macx.configs.flag_file_config(name)
+    for k, v in snap.items():
+        if hasattr(pc, k):
+            assert getattr(pc, k) == v, "%s: macx.configs has --%s = %r, the reference parses %r" % (name, k, getattr(pc, k), v)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the published configurations
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", FLAG_FILES)
+@pytest.mark.parametrize("train", [False, True])
+def test_oracle_reproduces_the_reference(name, train):
+    cfg = rx.parse_flags(name + ".txt", *rx.dims_flags(D, P, HID))
+    ref, orc, _ = run_pair(cfg, train)
+    assert_same_forward(ref, orc)
+
+
+@pytest.mark.parametrize("name", FLAG_FILES)
+def test_oracle_creates_the_reference_variables(name):
+    """Same variable names, shapes and creation order when the oracle builds its own parameters."""
+    cfg = rx.parse_flags(name + ".txt", *rx.dims_flags(D, P, HID))
+    vq, raw, words, lengths, kb, answers = inputs()
+    ref = rx.run_reference(cfg, vq, raw, words, lengths, kb, answerWordsNum=ANS)
+    vs = mo.VarStore(generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    ocfg = oracle_config_from(cfg)
+    _, m, _ = mo.mac_network(ocfg, vs, vq, raw, words, lengths, kb)
+    mo.output_classifier(ocfg, vs, m, vq)
+    assert list(vs.params.keys()) == list(ref["variables"].keys())
+    for k, v in ref["variables"].items():
+        assert tuple(vs.params[k].shape) == tuple(v.shape), k
+
+
+@pytest.mark.parametrize("name", FLAG_FILES)
+@pytest.mark.parametrize("train", [False, True])
+def test_oracle_gradients_match_the_reference_graph(name, train):
+    """d loss / d (every variable, vecQuestions, words, knowledge base) through the reference's op graph."""
+    cfg = rx.parse_flags(name + ".txt", *rx.dims_flags(D, P, HID))
+    ref, orc, answers = run_pair(cfg, train, need_grad=True)
+    g = torch.Generator().manual_seed(3)
+    dc = torch.randn((B, D), generator=g, dtype=torch.float64)
+    (ref["loss"] + (ref["control"] * dc).sum()).backward()
+    (orc["loss"] + (orc["control"] * dc).sum()).backward()
+    for k, v in ref["variables"].items():
+        a, b = orc["params"][k].grad, v.grad
+        assert (a is None) == (b is None), k
+        if b is not None:
+            assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(b.abs().max())), k
+    names = ["vecQ", "questionWords", "questionCntxWords", "kb"]
+    for nme, t in zip(names, orc["inputs"]):
+        b = ref["inputs"][nme].grad
+        a = t.grad
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, nme
+        else:
+            assert float((a - torch.as_tensor(b)).abs().max()) <= 1e-12 * max(1.0, float(b.abs().max())), nme
+
+
+def test_fp32_reference_execution_tracks_fp64():
+    """The same reference code in fp32 (what TF computes in) stays within fp32 round-off of the fp64 run."""
+    cfg = rx.parse_flags("args.txt", *rx.dims_flags(D, 4, HID))
+    vq, raw, words, lengths, kb, answers = inputs()
+    r64 = rx.run_reference(cfg, vq, raw, words, lengths, kb, answerWordsNum=ANS)
+    r32 = rx.run_reference(cfg, vq, raw, words, lengths, kb, answerWordsNum=ANS, dtype=torch.float32,
+                           preset={k: v.detach() for k, v in r64["variables"].items()})
+    assert float((r32["logits"].double() - r64["logits"]).abs().max()) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# legal option values outside the published flag files
+# ---------------------------------------------------------------------------------------------------------------
+BASE = ["--relu", "ELU", "--initCtrl", "Q"]
+FULLREAD = ["--readProjInputs", "--readMemConcatKB", "--readMemConcatProj", "--readMemProj", "--readCtrl",
+            "--writeMemProj", "--memoryVariationalDropout", "--controlContextual", "--controlInputUnshared"]
+VARIANTS = {
+    "defaults": [],
+    "defaults_std_relu": ["--relu", "STD"],
+    "read_noproj_concat": ["--readMemConcatKB", "--readMemProj", "--readCtrl"] + BASE,
+    "read_proj_shared": FULLREAD + ["--readProjShared"] + BASE,
+    "read_bilinear": FULLREAD + ["--readMemAttType", "BL", "--readCtrlAttType", "BL"] + BASE,
+    "read_additive": FULLREAD + ["--readMemAttType", "ADD", "--readCtrlAttType", "ADD"] + BASE,
+    "read_ctrl_concat_proj": FULLREAD + ["--readCtrlConcatKB", "--readCtrlConcatProj"] + BASE,
+    "read_ctrl_concat_kb": FULLREAD + ["--readCtrlConcatKB"] + BASE,
+    "read_smry_proj": FULLREAD + ["--readSmryKBProj"] + BASE,
+    "read_acts": FULLREAD + ["--readMemAct", "TANH", "--readCtrlAct", "TANH", "--relu", "STD"],
+    "read_memact_non": FULLREAD + ["--readMemAct", "NON", "--readCtrlAct", "NON"] + BASE,
+    "mul_bias": FULLREAD + ["--mulBias", "0.5"] + BASE,
+    "write_mem": FULLREAD + ["--writeInputs", "MEM"] + BASE,
+    "write_info": FULLREAD + ["--writeInputs", "INFO", "--writeInfoProj", "--writeInfoAct", "TANH"] + BASE,
+    "write_sum": FULLREAD + ["--writeInputs", "SUM", "--writeGate"] + BASE,
+    "write_concat_mul": FULLREAD + ["--writeConcatMul", "--writeMemAct", "RELU"] + BASE,
+    "write_merge_ctrl": FULLREAD + ["--writeMergeCtrl", "--writeSelfAtt", "--writeSelfAttMod", "NON"] + BASE,
+    "write_gate_bias": FULLREAD + ["--writeGate", "--writeGateBias", "-0.5"] + BASE,
+    "write_noproj": ["--readProjInputs", "--readMemProj", "--readCtrl", "--writeInputs", "SUM"] + BASE,
+    "control_proj": FULLREAD + ["--controlProj", "--controlProjAct", "TANH", "--controlConcatWords"] + BASE,
+    "control_concat_words": FULLREAD + ["--controlConcatWords"] + BASE,
+    "control_words_proj": FULLREAD + ["--controlInWordsProj"] + BASE,
+    "control_words_proj_out": FULLREAD + ["--controlOutWordsProj"] + BASE,
+    "control_continuous": FULLREAD + ["--controlContinuous", "--controlFeedPrev", "--controlContAct", "RELU"] + BASE,
+    "control_whole_q": FULLREAD + ["--controlWholeQ"] + BASE,
+    "control_feed_cont": FULLREAD + ["--controlFeedPrev", "--controlFeedInputs", "--initCtrl", "ZERO", "--relu", "ELU"],
+    "control_raw_words": [f for f in FULLREAD if f != "--controlContextual"] + BASE,
+    "control_shared_input": [f for f in FULLREAD if f != "--controlInputUnshared"] + BASE,
+    "unshared_cells": FULLREAD + ["--unsharedCells", "1"] + BASE,
+    "relu_prm": FULLREAD + ["--relu", "PRM", "--initCtrl", "Q", "--controlContAct", "RELU", "--controlFeedPrev"],
+    "relu_prm_unshared": FULLREAD + ["--relu", "PRM", "--initCtrl", "Q", "--unsharedCells", "1", "--writeMemAct", "RELU"],
+    "init_zero_mem": FULLREAD + ["--initMem", "ZERO", "--initCtrl", "PRM", "--relu", "ELU"],
+    "init_q_mem": FULLREAD + ["--initMem", "Q"] + BASE,
+    "no_var_dropout": [f for f in FULLREAD if f != "--memoryVariationalDropout"] + BASE,
+    "memory_bn": FULLREAD + ["--memoryBN"] + BASE,
+    "memory_bn_affine": FULLREAD + ["--memoryBN", "--bnCenter", "--bnScale"] + BASE,
+    "out_question_mul": FULLREAD + ["--outQuestion", "--outQuestionMul"] + BASE,
+    "out_no_question": FULLREAD + BASE,
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("train", [False, True])
+def test_oracle_reproduces_the_reference_on_other_legal_options(variant, train):
+    cfg = rx.parse_flags(None, *(VARIANTS[variant] + rx.dims_flags(D, P, HID)))
+    ref, orc, _ = run_pair(cfg, train)
+    assert_same_forward(ref, orc)
+    assert list(orc["store"].params.keys()) == list(ref["variables"].keys())
+
+
+@pytest.mark.parametrize("variant", ["defaults", "read_bilinear", "read_additive", "write_concat_mul", "write_sum",
+                                     "control_proj", "unshared_cells", "relu_prm", "memory_bn", "read_ctrl_concat_proj",
+                                     "write_merge_ctrl", "control_continuous", "mul_bias"])
+def test_oracle_gradients_on_other_legal_options(variant):
+    cfg = rx.parse_flags(None, *(VARIANTS[variant] + rx.dims_flags(D, P, HID)))
+    ref, orc, _ = run_pair(cfg, True, need_grad=True)
+    ref["loss"].backward()
+    orc["loss"].backward()
+    for k, v in ref["variables"].items():
+        a, b = orc["params"][k].grad, v.grad
+        assert (a is None) == (b is None), k
+        if b is not None:
+            assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(b.abs().max())), k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# option values that raise in the reference: the oracle and the product raise the same class
+# ---------------------------------------------------------------------------------------------------------------
+RAISING = {
+    "diag_mem": FULLREAD + ["--readMemAttType", "DIAG"] + BASE,
+    "diag_ctrl": FULLREAD + ["--readCtrlAttType", "DIAG"] + BASE,
+    "concat_proj_without_proj": ["--readMemConcatKB", "--readMemConcatProj", "--readMemProj"] + BASE,
+    "init_kb_with_q": FULLREAD + ["--initKBwithQ", "CNCT"] + BASE,
+    "init_kb_with_q_mul": FULLREAD + ["--initKBwithQ", "MUL"] + BASE,
+    "add_null_word": FULLREAD + ["--addNullWord"] + BASE,
+    "relu_lky": FULLREAD + ["--relu", "LKY", "--initCtrl", "Q"],
+    "relu_selu": FULLREAD + ["--relu", "SELU", "--initCtrl", "Q"],
+    "gate_shared": FULLREAD + ["--writeGate", "--writeGateShared"] + BASE,
+    "att_dim_mismatch": FULLREAD + BASE + ["--attDim", "8"],
+    # mac_cell.py:248-250 keeps `dim` when ops.mul concatenates its x operand: inter2att then gets a [.., 2 dim] tensor
+    "read_ctrl_concat_inter": FULLREAD + ["--readCtrlConcatInter"] + BASE,
+    "read_ctrl_concat_inter_kb": FULLREAD + ["--readCtrlConcatInter", "--readCtrlConcatKB"] + BASE,
+}
+
+
+@pytest.mark.parametrize("variant", sorted(RAISING))
+def test_rejected_option_values_raise_the_same_exception(variant):
+    extra = RAISING[variant]
+    dims = rx.dims_flags(D, P, HID)
+    cfg = rx.parse_flags(None, *(dims + extra))         # `extra` last: it may override a dimension
+    vq, raw, words, lengths, kb, answers = inputs()
+    with pytest.raises(Exception) as ref_exc:
+        rx.run_reference(cfg, vq, raw, words, lengths, kb, answerWordsNum=ANS)
+    ocfg = oracle_config_from(cfg)
+    vs = mo.VarStore(generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    with pytest.raises(Exception) as orc_exc:
+        mo.mac_network(ocfg, vs, vq, raw, words, lengths, kb)
+    assert orc_exc.type is ref_exc.type, "reference raises %r, oracle raises %r" % (ref_exc.value, orc_exc.value)
+    import macx
+    with pytest.raises(Exception) as prod_exc:
+        macx.options.reject_like_reference(ocfg)
+        macx.options.resolve_activations(ocfg)
+    assert prod_exc.type is ref_exc.type, "reference raises %r, macx.options raises %r" % (ref_exc.value, prod_exc.value)
