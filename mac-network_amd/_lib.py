@@ -122,13 +122,13 @@ class MacxError(RuntimeError):
 
 
 def lib():
-    """Load libmacx.so (building it if the sources are newer).  Raises if it cannot be loaded."""
+    """Load libmacx.so, rebuilding it first when the digest of csrc/ + include/ differs from the one it was built from
+    (a sha256 comparison; a no-op when nothing changed).  Where hipcc is absent a library whose digest matches is loaded
+    as it is; a stale one raises.  Raises if the library cannot be loaded."""
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
-    if not os.path.exists(path) or os.environ.get("MACX_REBUILD"):
-        path = _build.build()
+    path = _build.build(force=bool(os.environ.get("MACX_REBUILD")))
     L = C.CDLL(path)
     missing = [n for n in EXPORTS if not hasattr(L, n)]
     if missing:

@@ -23,7 +23,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .options import freeze, get
+from .options import freeze, fresh_seed, get
 from .params import MACCellParams
 
 MACCellTuple = collections.namedtuple("MACCellTuple", ("control", "memory"))   # mac_cell.py:8
@@ -170,7 +170,7 @@ class MACCell:
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
-                 netLength=None, seed=0, b0=0):
+                 netLength=None, seed=None, b0=0):
         from types import SimpleNamespace
         self.config = config if config is not None else SimpleNamespace()
         self.opts = freeze(self.config)           # raises for rejected / unsupported option sets
@@ -182,8 +182,12 @@ class MACCell:
         words = questionCntxWords if get(self.config, "controlContextual") else questionWords
         self._words_src = words
         self.words = _f32c(words, "question words")
+        if not questionLengths.is_cuda:
+            raise RuntimeError("questionLengths must live on the HIP device: the MAC cell has no CPU path")
         if questionLengths.dtype != torch.int32:
             questionLengths = questionLengths.to(torch.int32)
+        if questionLengths.shape != (self.words.shape[0],):
+            raise ValueError("questionLengths must be [batchSize]")
         self.questionLengths = questionLengths.contiguous()
         self._kb_src = knowledgeBase
         self._vq_src = vecQuestions
@@ -196,7 +200,7 @@ class MACCell:
                          "write": float(writeDropout) if train else 1.0}
         self.batchSize = int(batchSize)
         self.reuse = reuse
-        self.seed = int(seed)
+        self.seed = fresh_seed(seed, bool(train))
         self.b0 = int(b0)
         self.params = params if params is not None else MACCellParams(self.config, self.netLength, device=self.knowledgeBase.device)
         self.none = torch.zeros((self.batchSize, 1), dtype=torch.float32, device=self.knowledgeBase.device)

@@ -986,7 +986,7 @@ __global__ void lstm_cell_kernel(LstmP p) {
     const int dir = i / (p.B * p.h);
     const int r = i - dir * p.B * p.h;
     const int b = r / p.h, u = r - b * p.h;
-    const int L = p.len[b];
+    const int L = min(max(p.len[b], 0), p.S);      // never index past the padded question (host validates too)
     const bool active = p.tau < L;
     const int pos = dir == 0 ? p.tau : L - 1 - p.tau;
     const size_t s0 = (size_t)(dir * (p.S + 1) + p.tau) * Bh + r, s1 = s0 + Bh;
@@ -1028,7 +1028,7 @@ __global__ void lstm_cell_bwd_kernel(LstmBwdP p) {
     const int dir = i / (p.B * p.h);
     const int r = i - dir * p.B * p.h;
     const int b = r / p.h, u = r - b * p.h;
-    const int L = p.len[b];
+    const int L = min(max(p.len[b], 0), p.S);      // never index past the padded question (host validates too)
     const bool active = p.tau < L;
     const int pos = dir == 0 ? p.tau : L - 1 - p.tau;
     float* g = p.dG + ((size_t)(dir * p.S + p.tau) * p.B + b) * 4 * p.h;

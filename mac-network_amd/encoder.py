@@ -13,7 +13,7 @@ import math
 import torch
 
 from . import _lib
-from .options import UnsupportedOptions
+from .options import UnsupportedOptions, fresh_seed
 
 REF_NAMES = {"emb": "qEmbeddings/emb",
              "fw_kernel": "encoder/birnnLayer/bidirectional_rnn/fw/basic_lstm_cell/kernel",
@@ -106,14 +106,20 @@ class QuestionEncoder(torch.nn.Module):
             for f in _lib.ENC_FIELDS:
                 getattr(self, f).copy_(torch.as_tensor(d[REF_NAMES[f]]))
 
-    def forward(self, questions, lengths, train=False, seed=0, b0=0, check_ids=True):
+    def forward(self, questions, lengths, train=False, seed=None, b0=0, check_ids=True):
         """questions [B,S] int32 (0 = pad), lengths [B] int32 -> (questionCntxWords [B,S,2h], vecQuestions [B,2h])."""
         if not questions.is_cuda:
             raise RuntimeError("the question encoder has no CPU path")
         questions = questions.to(torch.int32).contiguous()
-        lengths = lengths.to(torch.int32).contiguous()
-        if check_ids and (int(questions.max()) > self.vocab or int(questions.min()) < 0):     # host sync; off in the bench loop
-            raise IndexError("question word id outside [0, %d]" % self.vocab)
+        lengths = lengths.to(device=questions.device, dtype=torch.int32).contiguous()
+        if lengths.shape != (questions.shape[0],):
+            raise ValueError("questionLengths must be [batchSize]")
+        if check_ids:                                                                         # host sync; off in the bench loop
+            if int(questions.max()) > self.vocab or int(questions.min()) < 0:
+                raise IndexError("question word id outside [0, %d]" % self.vocab)
+            # tf.reverse_sequence / dynamic_rnn reject lengths beyond the padded length (InvalidArgumentError)
+            if int(lengths.max()) > questions.shape[1] or int(lengths.min()) < 0:
+                raise ValueError("question length outside [0, %d]" % questions.shape[1])
         keep_in = self.keep_in if train else 1.0
         keep_q = self.keep_q if train else 1.0
-        return _EncoderFunction.apply(self, keep_in, keep_q, int(seed), int(b0), questions, lengths, *self.tensors())
+        return _EncoderFunction.apply(self, keep_in, keep_q, fresh_seed(seed, train), int(b0), questions, lengths, *self.tensors())

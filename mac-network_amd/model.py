@@ -11,7 +11,7 @@ import torch
 
 from .cell import MACCell
 from .encoder import QuestionEncoder
-from .options import get
+from .options import UnsupportedOptions, fresh_seed, get
 from .output import OutputClassifier, answer_loss_and_pred
 from .params import MACCellParams
 from .stem import Stem
@@ -29,10 +29,19 @@ class MACNetCore(torch.nn.Module):
     def tensors(self):
         return self.stem.tensors() + self.cell.tensors() + self.out.tensors()
 
-    def forward(self, images, vecQuestions, questionCntxWords, questionLengths, train=False, seed=0, b0=0):
+    def forward(self, images, vecQuestions, questionCntxWords, questionLengths, train=False, seed=None, b0=0,
+                questionWords=None):
         cfg = self.config
+        if questionWords is None:
+            if not get(cfg, "controlContextual"):
+                # mac_cell.py:570 would select the raw word embeddings; silently attending over the encoder outputs instead
+                # would diverge from the reference
+                raise UnsupportedOptions("without --controlContextual the cell attends over the raw word embeddings "
+                                         "(mac_cell.py:570): pass them as questionWords=[B,S,ctrlDim]")
+            questionWords = questionCntxWords
+        seed = fresh_seed(seed, train)
         kb = self.stem(images, train=train, seed=seed, b0=b0)                       # model.py:791
-        cell = MACCell(vecQuestions=vecQuestions, questionWords=questionCntxWords, questionCntxWords=questionCntxWords,
+        cell = MACCell(vecQuestions=vecQuestions, questionWords=questionWords, questionCntxWords=questionCntxWords,
                        questionLengths=questionLengths, knowledgeBase=kb, memoryDropout=get(cfg, "memoryDropout"),
                        readDropout=get(cfg, "readDropout"), writeDropout=get(cfg, "writeDropout"), batchSize=images.shape[0],
                        train=train, config=cfg, params=self.cell, netLength=self.netLength, seed=seed, b0=b0)
@@ -55,6 +64,7 @@ class MACNet(MACNetCore):
     def tensors(self):
         return self.enc.tensors() + super().tensors()
 
-    def forward(self, images, questions, questionLengths, train=False, seed=0, b0=0, check_ids=True):
+    def forward(self, images, questions, questionLengths, train=False, seed=None, b0=0, check_ids=True):
+        seed = fresh_seed(seed, train)
         words, vecQ = self.enc(questions, questionLengths, train=train, seed=seed, b0=b0, check_ids=check_ids)   # model.py:783-788
         return super().forward(images, vecQ, words, questionLengths, train=train, seed=seed, b0=b0)

@@ -26,6 +26,21 @@ DEFAULTS = dict(
 )
 
 
+_seed_counter = [0x5EED]
+
+
+def fresh_seed(seed, train):
+    """Dropout stream seed of one graph run.  The reference draws fresh masks on every session.run; a caller that does
+    not pass `seed` therefore gets a new one per training call (a process-wide counter), never a repeated sub-network.
+    Data-parallel ranks must pass the same explicit seed so that their shards see the masks of the full batch."""
+    if seed is not None:
+        return int(seed)
+    if not train:
+        return 0
+    _seed_counter[0] += 1
+    return _seed_counter[0]
+
+
 class UnsupportedOptions(NotImplementedError):
     """A legal reference option combination that has no HIP path yet (MACX_EUNSUPPORTED)."""
 

@@ -11,7 +11,7 @@ import math
 import torch
 
 from . import _lib
-from .options import UnsupportedOptions, _resolve_act
+from .options import UnsupportedOptions, _resolve_act, fresh_seed
 
 REF_NAMES = {
     "outQuestion_W": "outputUnit/linearLayeroutQuestion/weights/weight",
@@ -89,11 +89,11 @@ class OutputClassifier(torch.nn.Module):
     def to_reference_dict(self):
         return {REF_NAMES[f]: getattr(self, f).detach().clone() for f in _lib.OUT_FIELDS}
 
-    def forward(self, memory, vecQuestions, train=False, seed=0, b0=0):
+    def forward(self, memory, vecQuestions, train=False, seed=None, b0=0):
         if not memory.is_cuda:
             raise RuntimeError("the output unit has no CPU path")
         keep = self.keep if train else 1.0          # model.py:118-125
-        return _OutFunction.apply(self, keep, int(seed), int(b0), memory, vecQuestions, *self.tensors())
+        return _OutFunction.apply(self, keep, fresh_seed(seed, train), int(b0), memory, vecQuestions, *self.tensors())
 
 
 def answer_loss_and_pred(logits, answers):

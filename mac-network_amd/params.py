@@ -15,7 +15,6 @@ _BIAS = "linearLayer%s/biases/bias"
 def reference_names(config, p):
     """internal field -> list of (reference variable name, index into the stacked tensor or None)."""
     names = {
-        "initMem": [("MACnetwork/initMem", None)],
         "qInput_W": [(SCOPE + _LIN % "qInput", None)],
         "qInput_b": [(SCOPE + _BIAS % "qInput", None)],
         "ctrlLogits_w": [(SCOPE + "control/inter2logits/" + _LIN % "logits", None)],
@@ -39,6 +38,9 @@ def reference_names(config, p):
     else:
         names["qInputU_W"] = [(SCOPE + _LIN % "qInputU", 0)]
         names["qInputU_b"] = [(SCOPE + _BIAS % "qInputU", 0)]
+    # the state variables exist only for parametric initialisation (mac_cell.py:496-505)
+    if get(config, "initMem") == "PRM":
+        names["initMem"] = [("MACnetwork/initMem", None)]
     if get(config, "initCtrl") == "PRM":
         names["initCtrl"] = [("MACnetwork/initCtrl", None)]
     if get(config, "writeSelfAtt"):

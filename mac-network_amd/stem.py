@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib
-from .options import UnsupportedOptions, _resolve_act
+from .options import UnsupportedOptions, _resolve_act, fresh_seed
 
 REF_NAMES = {"kernel0": "stem/cnnLayercnn_0/kernels/kernel", "bias0": "stem/cnnLayercnn_0/biases/bias",
              "kernel1": "stem/cnnLayercnn_1/kernels/kernel", "bias1": "stem/cnnLayercnn_1/biases/bias"}
@@ -82,7 +82,7 @@ class Stem(torch.nn.Module):
     def to_reference_dict(self):
         return {REF_NAMES[f]: getattr(self, f).detach().clone() for f in _lib.STEM_FIELDS}
 
-    def forward(self, images, train=False, seed=0, b0=0):
+    def forward(self, images, train=False, seed=None, b0=0):
         """images: [B, H*W, inDim] / [B, H, W, inDim] (NHWC, what the graph sees after model.py:68) or the feed-dict layout
         [B, inDim, H, W] (h5 features, extract_features.py), which is transposed on the device first."""
         if not images.is_cuda:
@@ -96,4 +96,4 @@ class Stem(torch.nn.Module):
         elif images.dim() == 4:
             images = images.reshape(images.shape[0], self.H * self.W, self.inDim)
         keep = self.keep if train else 1.0
-        return _StemFunction.apply(self, keep, int(seed), int(b0), images, *self.tensors())
+        return _StemFunction.apply(self, keep, fresh_seed(seed, train), int(b0), images, *self.tensors())

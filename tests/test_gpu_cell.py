@@ -142,10 +142,11 @@ def test_headline_shape_forward_backward(macx, dev):
     dmem = torch.randn(64, 512, generator=torch.Generator().manual_seed(1)) / 64
     (state.memory * dmem.to(dev)).sum().backward()
     torch.cuda.synchronize()
-    ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=True, seed=1234, dtype=torch.float32,
-                     need_grad=True, d_memory=dmem)
-    assert rel_err(state.memory, ref["memory"]) < 1e-4
-    assert rel_err(kbd.grad, ref["inputs"][2].grad) < 1e-3
+    sl = slice(16, 24)            # fp64 oracle on a slice (questions are independent); the full-size all-gradient check is
+    ref = oracle_run(cfg, params.to_reference_dict(), vq[sl], words[sl], lengths[sl], kb[sl], train=True, seed=1234, b0=16,
+                     dtype=torch.float64, need_grad=True, d_memory=dmem[sl])     # tests/test_gpu_configs.py
+    assert rel_err(state.memory[sl], ref["memory"]) < 1e-4
+    assert rel_err(kbd.grad[sl], ref["inputs"][2].grad) < 2e-4
     # determinism: a second identical run is bit-identical (no float atomics anywhere)
     cell2, params2, (vq2, w2, kb2) = build_cell(macx, dev, cfg, vq, words, lengths, kb, True, seed=1234, requires_grad=True)
     s2 = cell2.run()
