@@ -73,7 +73,7 @@ def oracle_chunked_grads(cfg, ref_params, vq, words, lengths, kb, train, seed, d
     """fp64 oracle over the whole batch in chunks of questions (questions are independent; parameter gradients add up;
     each chunk sees the masks of its global question indices).  Bounded memory: one chunk's graph at a time."""
     B = vq.shape[0]
-    pg = {k: torch.zeros_like(v, dtype=dtype) for k, v in ref_params.items()}
+    pg = {k: torch.zeros(v.shape, dtype=dtype) for k, v in ref_params.items()}
     mem, ctl, gvq, gw, gkb = [], [], [], [], []
     for lo in range(0, B, chunk):
         sl = slice(lo, min(B, lo + chunk))
