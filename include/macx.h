@@ -304,7 +304,23 @@ int macx_pack_weight(const float* W, int K, int n_out, int flags, float* out, vo
  * Process-wide; set it before sizing/running (packed-weight formats differ). */
 #define MACX_GEMM_NATIVE 0
 #define MACX_GEMM_SPLIT 1
+#define MACX_GEMM_H2 2
 int macx_gemm_mode(int mode);
+
+/* ---- the H2 tensor format (mode MACX_GEMM_H2, the default; mac-network_amd/csrc/macx_h2.hip.h) ---------------------
+ * An fp32 [rows, cols] tensor (cols % 128 == 0) held as two fp16 planes in slot order + one int8 exponent per (row, 128
+ * columns): x * 2^e = hi + lo to 2^-24.  Inside the cell every [B,N,d] activation lives in HBM in this format; these
+ * entry points expose the conversions and one GEMM on it so that the format and its numerics are testable in isolation.
+ *   macx_h2_floats      floats a caller-owned buffer needs for one H2 tensor (0 if cols % 128)
+ *   macx_h2_from_f32    src [B][N][C] fp32 row-major -> h2
+ *   macx_h2_to_f32      h2 -> out [rows][C] fp32 row-major
+ *   macx_h2_gemm        out[B*N, n_out] = act(A[B*N, K] @ W[K, n_out] + bias) through the H2 kernels (three fp16 MFMA
+ *                       terms per product, fp32 accumulate); ws >= h2_floats(B*N,K) + h2_floats(B*N,n_out) + K*n_out + 16 */
+size_t macx_h2_floats(size_t rows, size_t cols);
+int macx_h2_from_f32(const float* src, int B, int N, int C, float* h2, void* stream);
+int macx_h2_to_f32(const float* h2, int rows, int C, float* out, void* stream);
+int macx_h2_gemm(const float* A, int B, int N, int K, const float* W, int n_out, const float* bias, int act, float* out,
+                 float* ws, size_t ws_floats, void* stream);
 /* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688) on the knowledge-base GEMM.
  * `W_packed` from macx_pack_weight(Wx, d, d, macx_gemm_mode(-1) ? MACX_PACK_BF16X3 : MACX_PACK_F32MFMA);
  * `drop_ws` >= B*N*d + B*N*d/32 floats of scratch for the dropped KB and its keep bits (may be NULL when keep_read == 1). */

@@ -109,7 +109,7 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
            "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward",
            "macx_encoder_saved_floats", "macx_encoder_ws_floats", "macx_encoder_forward", "macx_encoder_backward",
-           "macx_images_to_nhwc", "macx_gemm_mode")
+           "macx_images_to_nhwc", "macx_gemm_mode", "macx_h2_floats", "macx_h2_from_f32", "macx_h2_to_f32", "macx_h2_gemm")
 
 _lib = None
 
@@ -198,6 +198,11 @@ def lib():
     L.macx_encoder_backward.argtypes = [P(MacxEncShapes), C.c_float, C.c_float, C.c_uint32, P(MacxEncParams), C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, P(MacxEncGrads),
                                         C.c_void_p]
+    L.macx_h2_floats.argtypes = [C.c_size_t, C.c_size_t]
+    L.macx_h2_from_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.macx_h2_to_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.macx_h2_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                               C.c_void_p, C.c_size_t, C.c_void_p]
     for n in EXPORTS:
         if n.endswith("_floats"):
             getattr(L, n).restype = C.c_size_t
@@ -216,5 +221,6 @@ PACK_TRANSPOSE, PACK_F32MFMA, PACK_BF16X3, PACK_KMAJOR = 1, 0 << 1, 1 << 1, 2 <<
 
 
 def kb_pack_flags():
-    """macx_pack_weight flags for a weight handed to macx_kb_project under the GEMM mode in force."""
+    """macx_pack_weight flags for a weight handed to macx_kb_project (an fp32-operand entry point: native f32 MFMA in mode 0,
+    the split-bf16 kernel otherwise) under the GEMM mode in force."""
     return PACK_BF16X3 if lib().macx_gemm_mode(-1) else PACK_F32MFMA

@@ -3,6 +3,7 @@
 // expressed as a fixed schedule of gfx950 kernels on one HIP stream.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/macx.h"
@@ -11,6 +12,9 @@
 #include "macx_gemm6.cuh"
 #include "macx_gemm_tn.cuh"
 #include "macx_wgrad6.cuh"
+#include "macx_h2.hip.h"
+#include "macx_gemm_h2.hip.h"
+#include "macx_wgrad_h2.hip.h"
 #include "macx_small.cuh"
 
 using namespace macx;
@@ -35,16 +39,22 @@ inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
 //   native (0): macx_gemm.cuh, v_mfma_f32_16x16x4_f32.
 // They take different weight packings: plain weights -> format 1 (bf16 planes, 1.5x the floats) / 0, weights mixed
 // with a per-question vector (B_YMIX_*) -> format 2 (fp32 k-major tiles) / 0.  Buffers are sized for the larger one.
-inline int wfmt_plain() { return gemm_split_mode() ? 1 : 0; }
+//   h2 (2, the default): macx_gemm_h2.hip.h -- every [B,N,d] activation lives in HBM as two fp16 planes + per-row-block
+//     exponents (macx_h2.hip.h), three fp16 MFMA terms per product; plain weights -> format 3 (H2 planes + exponent).
+inline bool h2_mode() { return gemm_split_mode() == 2; }
+inline int wfmt_plain() { return h2_mode() ? 3 : (gemm_split_mode() ? 1 : 0); }
 inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
-inline size_t wsize(size_t K, size_t n) { return K * n * 3 / 2; }
+inline size_t wsize(size_t K, size_t n) { return K * n * 3 / 2; }     // covers format 1 (3/2) and format 3 (1 + the exponent)
 inline hipError_t wgrad_any(const TnP& t, hipStream_t st) {
   return (gemm_split_mode() && !(kb_gemm_dbg() & 128)) ? wgrad6_launch(t, st) : wgrad_tn_launch<A_PLAIN>(t, st);   // dbg 128: f32 TN kernel
 }
+// fp32-operand GEMM (stem convolutions, unit entry points, and the cell in modes 0 / 1); in h2 mode the fp32-operand
+// callers that remain (the stem's implicit GEMM) run on the split-bf16 kernel, whose weight format they pack (1)
 template <int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm(const GemmP& g, hipStream_t st) {
   return gemm_split_mode() ? kb_gemm6_launch<AP, BP, EP, COLSUM>(g, st) : kb_gemm_launch<AP, BP, EP, COLSUM>(g, st);
 }
+inline int wfmt_plain_f32ops() { return gemm_split_mode() ? 1 : 0; }
 
 inline DropSpec make_drop(float keep, uint32_t seed, uint32_t site, uint32_t step) {
   DropSpec s;
@@ -97,7 +107,11 @@ struct SavedLayout {
   size_t logit_part;                // [d/128][B*N]
   size_t X, H1, I2;                 // [pk][B,N,d], pk = p (keep) or 1
   size_t KBd;                       // [pk][B,N,d] dropped knowledge base (ops.py:678)
-  size_t act_stride;                // B*N*d if keep else 0
+  size_t act_stride;                // floats per kept step of X / H1 / I2 / KBd if keep else 0
+  size_t act_floats;                // floats of one such tensor (B*N*d, or the H2 size in h2 mode)
+  size_t wmax;                      // h2: max |W| of projX, memKbProj2, W1a, W1b (4 floats)
+  size_t qmin_X, qmin_H1, qmin_KBd; // h2: [pk][B][d/128] ints, minimum exponent of each question's rows
+  size_t qmin_stride;               // ints per kept step (0 when activations are not kept)
   size_t total;
 };
 
@@ -146,14 +160,23 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   }
   L.logit_part = take((d / 64) * B * N);   // one partial per 64- or 128-column tile
   const size_t pk = keep ? p : 1;
-  L.act_stride = keep ? B * N * d : 0;
-  L.X = take(pk * B * N * d);
-  L.H1 = take(pk * B * N * d);
-  L.I2 = take(pk * B * N * d);
-  L.KBd = take(pk * B * N * d);
-  L.bits_stride = keep ? B * N * d / 32 : 0;
-  L.kb_bits = take(pk * B * N * d / 32);
-  L.att_bits = take(pk * B * N * d / 32);
+  // h2 mode: activations are H2 tensors (4 bytes per element + exponents + pad rows); the attention keep bits are kept as
+  // one byte per 8-column slot in slot order [d/8][Rp]
+  L.act_floats = h2_mode() ? al4(h2_floats(B * N, d)) : B * N * d;
+  L.act_stride = keep ? L.act_floats : 0;
+  L.X = take(pk * L.act_floats);
+  L.H1 = take(pk * L.act_floats);
+  L.I2 = take(pk * L.act_floats);
+  L.KBd = take(pk * L.act_floats);
+  const size_t bits_floats = h2_mode() ? al4(((B * N + H2_PAD_ROWS) * (d / 8) + 3) / 4) : B * N * d / 32;
+  L.bits_stride = keep ? bits_floats : 0;
+  L.kb_bits = take(pk * bits_floats);
+  L.att_bits = take(pk * bits_floats);
+  L.wmax = take(8);
+  L.qmin_stride = keep ? B * (d / 128) : 0;
+  L.qmin_X = take(3 * pk * B * (d / 128));
+  L.qmin_H1 = L.qmin_X + pk * B * (d / 128);
+  L.qmin_KBd = L.qmin_H1 + pk * B * (d / 128);
   L.total = off;
   return L;
 }
@@ -211,6 +234,9 @@ struct BwdLayout {
   size_t dws_part, dbs_part;   // [p,B,d], [p,B]
   size_t small_slab;
   size_t tmp_dd;    // [d,d] scratch
+  size_t act_floats;                 // floats of one [B,N,d] activation (H2 size in h2 mode)
+  size_t qmin_dI2, qmin_dI1, qmin_dX;   // h2: [p][B][d/128] ints
+  size_t ecom;                       // h2: 4 x [d/128] ints, common exponents of H1 / dI2 / KBd / dX over all steps
   size_t total;
 };
 
@@ -227,7 +253,8 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.wqT = take(d * d);
   L.wqUT = take((o->control_input_unshared ? p : 1) * d * d);
   L.wccT = take(2 * d * d); L.wcc2T = take(d * d); L.wscT = take(d * d); L.wgT = take(d * d);
-  L.dI2 = take(p * B * N * d); L.dI1 = take(B * N * d); L.dX = take(p * B * N * d); L.da = take(B * N);   // dI2, dX kept per step
+  L.act_floats = h2_mode() ? al4(h2_floats(B * N, d)) : B * N * d;
+  L.dI2 = take(p * L.act_floats); L.dI1 = take(L.act_floats); L.dX = take(p * L.act_floats); L.da = take(B * N);   // dI2, dX kept per step
   L.DM = take((p + 1) * B * d);
   L.DC = take((p + 1) * B * d);
   L.dcI = take(p * B * d);
@@ -266,6 +293,10 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   }
   L.small_slab = take(small);
   L.tmp_dd = take(d * d);
+  L.qmin_dI2 = take(3 * p * B * (d / 128));
+  L.qmin_dI1 = L.qmin_dI2 + p * B * (d / 128);
+  L.qmin_dX = L.qmin_dI1 + p * B * (d / 128);
+  L.ecom = take(4 * 8);
   L.total = off;
   return L;
 }
@@ -293,8 +324,9 @@ hipError_t pack(const float* src, int ld_k, int ld_j, int K, int Nout, float* ds
 struct Packer {
   PackList L;
   int n = 0;
-  void add(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst, int k_src = -1, int n_src = -1, int fmt = 0) {
-    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout, k_src < 0 ? K : k_src, n_src < 0 ? Nout : n_src, fmt};
+  void add(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst, int k_src = -1, int n_src = -1, int fmt = 0,
+           const float* maxabs = nullptr) {
+    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout, k_src < 0 ? K : k_src, n_src < 0 ? Nout : n_src, fmt, maxabs};
   }
   hipError_t run(hipStream_t st) {
     if (n == 0) return hipSuccess;
@@ -303,6 +335,47 @@ struct Packer {
     return hipGetLastError();
   }
 };
+
+
+// ---- H2 helpers (macx_h2.hip.h) -------------------------------------------------------------------------------
+// min over n entries of [n][cb] minimum-exponent arrays -> out[cb]
+__global__ void qmin_reduce_kernel(const int* q, int n, int cb, int* out) {
+  __shared__ int red[8][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < cb; ++k) {
+    int m = 127;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = min(m, q[(size_t)i * cb + k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[k][wave] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < cb) {
+    int m = red[threadIdx.x][0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = min(m, red[threadIdx.x][w]);
+    out[threadIdx.x] = min(m, 126);       // an all-zero tensor family keeps exponent 0 rows: 127 never reaches a kernel
+  }
+}
+hipError_t qmin_reduce(const int* q, int n, int cb, int* out, hipStream_t st) {
+  hipLaunchKernelGGL(qmin_reduce_kernel, dim3(1), dim3(256), 0, st, q, n, cb, out);
+  return hipGetLastError();
+}
+hipError_t h2_from_f32(const H2FromP& f, hipStream_t st) {
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(h2_from_f32_kernel), H2C_LDS);
+  if (e != hipSuccess) return e;
+  const int nrb = (f.N + H2C_ROWS - 1) / H2C_ROWS;
+  hipLaunchKernelGGL(h2_from_f32_kernel, dim3(f.B * nrb, f.C / 128), dim3(H2C_THREADS), H2C_LDS, st, f);
+  return hipGetLastError();
+}
+hipError_t absmax4(const float* a, size_t na, const float* b, size_t nb, const float* c, size_t nc, const float* d_, size_t nd,
+                   float* out, hipStream_t st) {
+  AbsMaxList L;
+  memset(&L, 0, sizeof(L));
+  L.src[0] = a; L.n[0] = na; L.src[1] = b; L.n[1] = nb; L.src[2] = c; L.n[2] = nc; L.src[3] = d_; L.n[3] = nd;
+  L.out = out;
+  hipLaunchKernelGGL(absmax_kernel, dim3(4), dim3(1024), 0, st, L);
+  return hipGetLastError();
+}
 
 hipError_t transpose(const float* src, int R, int C, float* dst, hipStream_t st) {
   hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, src, R, C, dst);
@@ -417,10 +490,17 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
   // weights -> MFMA operand layout  (memKbProj rows [0,d) multiply x*y, rows [d,2d) multiply x: ops.py:718)
   {
     Packer pk;
-    pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain());
+    if (h2_mode()) {
+      // per-matrix maxima -> weight exponents (plain weights) and the bound of the question-mixed tile (W1a, W1b)
+      const size_t dd_ = (size_t)d * d;
+      CK(absmax4(P->projX_W, dd_, P->memKbProj2_W, dd_, P->memKbProj_W, dd_, P->memKbProj_W + dd_, dd_, saved + L.wmax, st));
+      // minimum-exponent arrays are filled with atomicMin by the producers of X / H1 / KBd
+      CK(hipMemsetAsync(saved + L.qmin_X, 0x7F, 3 * (size_t)(keep ? p : 1) * B * (d / 128) * sizeof(int), st));
+    }
+    pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);
     pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, wfmt_ymix());
     pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, wfmt_ymix());
-    pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, -1, -1, wfmt_plain());
+    pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);
     pk.add(P->projY_W, d, 1, d, d, saved + L.wy_p);
     pk.add(P->newMemory_W, d, 1, write_in_dim(o, d), d, saved + L.wm_p);
     pk.add(P->qInput_W, d, 1, d, d, saved + L.wq_p);
@@ -537,6 +617,54 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   uint32_t* kb_bits = reinterpret_cast<uint32_t*>(saved + L.kb_bits + (size_t)i * L.bits_stride);
   uint32_t* att_bits = reinterpret_cast<uint32_t*>(saved + L.att_bits + (size_t)i * L.bits_stride);
   float* KBd = saved + L.KBd + (size_t)i * L.act_stride;
+  if (h2_mode()) {
+    // the same three products on H2 operands (macx_gemm_h2.hip.h): the knowledge base enters the format (through its
+    // dropout site) once per step -- once per run without read dropout -- and X, H1, I2 never exist as fp32 tensors
+    const int R = B * N, CB = d / 128;
+    const H2View hX = h2_view(X, R, d), hH1 = h2_view(H1, R, d), hI2 = h2_view(I2, R, d);
+    const H2View hKB = h2_view(rdrop ? KBd : saved + L.KBd, R, d);
+    int* qX = reinterpret_cast<int*>(saved + L.qmin_X) + (size_t)i * L.qmin_stride;
+    int* qH1 = reinterpret_cast<int*>(saved + L.qmin_H1) + (size_t)i * L.qmin_stride;
+    int* qKB = reinterpret_cast<int*>(saved + L.qmin_KBd) + (rdrop ? (size_t)i * L.qmin_stride : 0);
+    uint8_t* att_bytes = rdrop ? reinterpret_cast<uint8_t*>(att_bits) : nullptr;
+    if (rdrop || i == 0) {
+      H2FromP f;
+      memset(&f, 0, sizeof(f));
+      f.src = in->knowledgeBase; f.B = B; f.N = N; f.C = d; f.out = hKB;
+      f.first = (uint32_t)((size_t)s->b0 * N * d);
+      f.thr24 = 1u << 24; f.inv_keep = 1.0f; f.thr24_2 = 1u << 24;
+      if (rdrop) {
+        const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
+        const DropSpec da = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
+        f.key = dk.key; f.thr24 = dk.thr24; f.inv_keep = dk.inv_keep; f.bits = kb_bits;
+        f.key2 = da.key; f.thr24_2 = da.thr24; f.bytes2 = att_bytes;
+      }
+      f.qmin = qKB;
+      CK(h2_from_f32(f, st));
+    }
+    GemmH2P g;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.N = N; g.K = d; g.Nout = d;
+    g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+    // X = dropout(KB) Wx + bx  (ops.py:678,688)
+    g.A = hKB;
+    g.Wh = reinterpret_cast<const char*>(saved + L.wx_p); g.w_exp = reinterpret_cast<const int*>(saved + L.wx_p) + (size_t)d * d;
+    g.out = hX; g.bias = P->projX_b; g.act = MACX_ACT_NON; g.out_qmin = qX;
+    if (rdrop || L.act_stride != 0 || i == 0) CK((kb_gemm_h2_launch<B_PLAIN, E_BIAS_ACT, false>(g, st)));
+    // H1 = act( X (diag(y) W1a + W1b) + b1 )   (ops.py:703,718; mac_cell.py:237)
+    g.A = hX; g.Wh = nullptr; g.w_exp = nullptr;
+    g.Wt = saved + L.w1a_p; g.Wt2 = saved + L.w1b_p; g.w_max = saved + L.wmax + 2; g.y = y; g.ldy = d;
+    g.out = hH1; g.bias = P->memKbProj_b; g.act = o->read_mem_act; g.out_qmin = qH1;
+    CK((kb_gemm_h2_launch<B_YMIX_ROW, E_BIAS_ACT, false>(g, st)));
+    // I2 = H1 W2 + b2 ; logits = dropout(act(I2 * c)) . w_k   (ops.py:326; mac_cell.py:248,262,266)
+    g.A = hH1; g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
+    g.Wh = reinterpret_cast<const char*>(saved + L.w2_p); g.w_exp = reinterpret_cast<const int*>(saved + L.w2_p) + (size_t)d * d;
+    g.out = hI2; g.bias = P->memKbProj2_b; g.act = o->read_ctrl_act;
+    g.cvec = c_i; g.wvec = P->kbLogits_w; g.logit_part = saved + L.logit_part;
+    g.e_bytes = att_bytes; g.out_qmin = nullptr;
+    CK((kb_gemm_h2_launch<B_PLAIN, E_I2_LOGIT, false>(g, st)));
+    (void)CB;
+  } else {
   if (rdrop) {
     const uint32_t first = (uint32_t)((size_t)s->b0 * N * d);
     const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
@@ -568,6 +696,7 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   g.logit_part = saved + L.logit_part;
   g.e_bits = rdrop ? att_bits : nullptr;
   CK((kb_gemm<A_PLAIN, B_PLAIN, E_I2_LOGIT, false>(g, st)));
+  }
   // attention over the knowledge base + summary (mac_cell.py:266-275)
   {
     KbAttP a;
@@ -655,10 +784,10 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   const int nU = o->control_input_unshared ? p : 1;
   {
     Packer pk;
-    pk.add(P->projX_W, 1, d, d, d, ws + W.wxT_p, -1, -1, wfmt_plain());            // Wx^T
+    pk.add(P->projX_W, 1, d, d, d, ws + W.wxT_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);            // Wx^T
     pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, -1, -1, wfmt_ymix());       // W1a^T
     pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, -1, -1, wfmt_ymix());  // W1b^T
-    pk.add(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, -1, -1, wfmt_plain());       // W2^T
+    pk.add(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);       // W2^T
     pk.add(P->projY_W, 1, d, d, d, ws + W.wyT);              // Wy^T
     pk.add(P->newMemory_W, 1, d, d, win, ws + W.wmT);        // Wm^T: [d] -> [win]
     pk.add(P->qInput_W, 1, d, d, d, ws + W.wqT);
@@ -675,6 +804,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     CK(pk.run(st));
   }
 
+  if (h2_mode()) CK(hipMemsetAsync(ws + W.qmin_dI2, 0x7F, 3 * (size_t)p * B * (d / 128) * sizeof(int), st));
   float* DM = ws + W.DM;
   float* DC = ws + W.DC;
   // dL/d(newMemory linear output) for all steps; with writeMemAct = NON it IS dL/dm_{1..p}
@@ -696,15 +826,15 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
 
   for (int i = p - 1; i >= 0; --i) {
     const float* c_i = controls + (size_t)(i + 1) * Bd;
-    const float* X = saved + L.X + (size_t)i * BNd;
-    const float* H1 = saved + L.H1 + (size_t)i * BNd;
-    const float* I2 = saved + L.I2 + (size_t)i * BNd;
+    const float* X = saved + L.X + (size_t)i * L.act_stride;
+    const float* H1 = saved + L.H1 + (size_t)i * L.act_stride;
+    const float* I2 = saved + L.I2 + (size_t)i * L.act_stride;
     const float* y = saved + L.y + (size_t)i * Bd;
     const float* dm_i = DM + (size_t)(i + 1) * Bd;   // dL/d m_i, complete at this point
     float* dm_prev = DM + (size_t)i * Bd;
     float* dwlin = dwlin_all + (size_t)i * Bd;
-    float* dI2_i = ws + W.dI2 + (size_t)i * BNd;
-    float* dX_i = ws + W.dX + (size_t)i * BNd;
+    float* dI2_i = ws + W.dI2 + (size_t)i * W.act_floats;
+    float* dX_i = ws + W.dX + (size_t)i * W.act_floats;
     float* dwin = ws + W.dwin;
 
     // ---- write unit backward
@@ -762,6 +892,66 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     hipLaunchKernelGGL(kb_att_da_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, dinfo, ld_dinfo, in->knowledgeBase, B, N, d,
                        ws + W.da);
     CK(hipGetLastError());
+    if (h2_mode()) {
+      const int R = B * N, CB = d / 128;
+      const H2View hI2 = h2_view(I2, R, d), hH1 = h2_view(H1, R, d), hX = h2_view(X, R, d);
+      const H2View hdI2 = h2_view(dI2_i, R, d), hdI1 = h2_view(ws + W.dI1, R, d), hdX = h2_view(dX_i, R, d);
+      int* q_dI2 = reinterpret_cast<int*>(ws + W.qmin_dI2) + (size_t)i * B * CB;
+      int* q_dI1 = reinterpret_cast<int*>(ws + W.qmin_dI1) + (size_t)i * B * CB;
+      int* q_dX = reinterpret_cast<int*>(ws + W.qmin_dX) + (size_t)i * B * CB;
+      {
+        ReadAttBwdH2P r;
+        r.B = B; r.N = N; r.d = d;
+        r.att = att_kb + (size_t)i * B * N; r.da = ws + W.da; r.I2 = hI2; r.c = c_i; r.wk = P->kbLogits_w;
+        r.act = o->read_ctrl_act;
+        r.bytes = rdrop ? reinterpret_cast<const uint8_t*>(saved + L.att_bits + (size_t)i * L.bits_stride) : nullptr;
+        r.inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+        r.dI2 = hdI2;
+        r.dc = DC + (size_t)(i + 1) * Bd;
+        r.dwk_part = ws + W.dwk_part + (size_t)i * Bd;
+        r.db2_part = ws + W.db2_part + (size_t)i * Bd;
+        r.dbk_part = ws + W.dbk_part + (size_t)i * B;
+        r.qmin = q_dI2;
+        hipLaunchKernelGGL(read_att_bwd_h2_kernel, dim3(B, d / 128), dim3(RABH_THREADS), 0, st, r);
+        CK(hipGetLastError());
+      }
+      GemmH2P g;
+      memset(&g, 0, sizeof(g));
+      g.B = B; g.N = N; g.K = d; g.Nout = d;
+      g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+      // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
+      g.A = hdI2;
+      g.Wh = reinterpret_cast<const char*>(ws + W.w2T_p); g.w_exp = reinterpret_cast<const int*>(ws + W.w2T_p) + dd;
+      g.out = hdI1; g.aux = hH1; g.act = o->read_mem_act; g.out_qmin = q_dI1;
+      g.colsum_part = ws + W.db1_part + (size_t)i * B * nrb * d;
+      CK((kb_gemm_h2_launch<B_PLAIN, E_MUL_DACT, true>(g, st)));
+      // dX = dI1 (diag(y) W1a + W1b)^T ; dbx partials
+      g.A = hdI1; g.Wh = nullptr; g.w_exp = nullptr;
+      g.Wt = ws + W.w1aT_p; g.Wt2 = ws + W.w1bT_p; g.w_max = saved + L.wmax + 2; g.y = y; g.ldy = d;
+      g.out = hdX; g.out_qmin = q_dX;
+      g.colsum_part = ws + W.dbx_part + (size_t)i * B * nrb * d;
+      CK((kb_gemm_h2_launch<B_YMIX_COL, E_PLAIN, true>(g, st)));
+      // S_b = X_b^T dI1_b -> dW1a / dW1b slabs and dy partials
+      {
+        SbH2P q;
+        q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B);
+        q.X = hX; q.dI1 = hdI1;
+        q.qminX = reinterpret_cast<const int*>(saved + L.qmin_X) + (size_t)i * L.qmin_stride; q.qminG = q_dI1;
+        q.y = y; q.W1a = P->memKbProj_W;
+        q.dW1a_part = ws + W.slab_w1a + (size_t)i * W.ngroup * dd;
+        q.dW1b_part = ws + W.slab_w1b + (size_t)i * W.ngroup * dd;
+        q.dy_part = ws + W.dy_part;
+        CK(sb_h2_launch(q, st));
+      }
+      // dKB (+)= (dX Wx^T) * kbmask + att * dinfo
+      g.A = hdX; g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
+      g.Wh = reinterpret_cast<const char*>(ws + W.wxT_p); g.w_exp = reinterpret_cast<const int*>(ws + W.wxT_p) + dd;
+      g.out_f32 = GI->knowledgeBase; g.ldo = d; g.dr = dinfo; g.ld_dr = ld_dinfo; g.att = att_kb + (size_t)i * B * N;
+      g.e_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits + (size_t)i * L.bits_stride) : nullptr;
+      g.accumulate = (i != p - 1);
+      g.colsum_part = nullptr; g.out_qmin = nullptr;
+      CK((kb_gemm_h2_launch<B_PLAIN, E_DKB, false>(g, st)));
+    } else {
     {
       ReadAttBwdP r;
       r.B = B; r.N = N; r.d = d; r.b0 = s->b0;
@@ -809,6 +999,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     g.accumulate = (i != p - 1);
     g.colsum_part = nullptr;
     CK((kb_gemm<A_PLAIN, B_PLAIN, E_DKB, false>(g, st)));
+    }
     // dy -> d(md) -> dL/d m_{i-1} = dwin[:, :d] + (dy Wy^T) * memmask * readmask
     float* DYi = ws + W.DY + (size_t)i * Bd;
     hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dy_part), 2 * d / 128, Bd, DYi);
@@ -1014,7 +1205,29 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   // ---- read-unit weights: fixed-order reduction of the per-step slabs
   // dW2 = sum_i H1_i^T dI2_i and dWx = sum_i dropout_i(KB)^T dX_i: ONE contraction each over all
   // p*B*N rows (the per-step operands are kept; 288 GB of HBM makes that the cheap choice)
-  {
+  if (h2_mode()) {
+    const int CB = d / 128;
+    int* ecom = reinterpret_cast<int*>(ws + W.ecom);       // [H1 | dI2 | KBd | dX][8]
+    CK(qmin_reduce(reinterpret_cast<const int*>(saved + L.qmin_H1), p * B, CB, ecom, st));
+    CK(qmin_reduce(reinterpret_cast<const int*>(ws + W.qmin_dI2), p * B, CB, ecom + 8, st));
+    CK(qmin_reduce(reinterpret_cast<const int*>(saved + L.qmin_KBd), (rdrop ? p : 1) * B, CB, ecom + 16, st));
+    CK(qmin_reduce(reinterpret_cast<const int*>(ws + W.qmin_dX), p * B, CB, ecom + 24, st));
+    TnH2P t;
+    memset(&t, 0, sizeof(t));
+    t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(t.M, t.nsplit);
+    t.R = B * N;
+    t.A = reinterpret_cast<const char*>(saved + L.H1); t.a_stride = L.act_stride * sizeof(float); t.a_mod = 0;
+    t.G = reinterpret_cast<const char*>(ws + W.dI2); t.g_stride = W.act_floats * sizeof(float);
+    t.ecomA = ecom; t.ecomG = ecom + 8;
+    t.part = ws + W.slab_w2;
+    CK(wgrad_h2_launch(t, st));
+    t.A = reinterpret_cast<const char*>(saved + L.KBd);
+    t.a_mod = rdrop ? 0 : B * N;                              // no dropout: the same (converted) KB every step
+    t.G = reinterpret_cast<const char*>(ws + W.dX);
+    t.ecomA = ecom + 16; t.ecomG = ecom + 24;
+    t.part = ws + W.slab_wx;
+    CK(wgrad_h2_launch(t, st));
+  } else {
     TnP t;
     memset(&t, 0, sizeof(t));
     t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(t.M, t.nsplit);
@@ -1356,8 +1569,8 @@ int macx_stem_forward(const macx_stem_shapes* s, int act, float keep, uint32_t s
   const StemGeo geo = stem_geo(s);
   const int Ci = s->Cin, Cm = s->Cmid, Co = s->Cout;
   Packer pk;
-  pk.add(P->kernel0, Cm, 1, 9 * Ci, Cm, saved + L.k0_p, -1, -1, wfmt_plain());     // HWIO flattened = [9*Cin][Cmid] row-major
-  pk.add(P->kernel1, Co, 1, 9 * Cm, Co, saved + L.k1_p, -1, -1, wfmt_plain());
+  pk.add(P->kernel0, Cm, 1, 9 * Ci, Cm, saved + L.k0_p, -1, -1, wfmt_plain_f32ops());     // HWIO flattened = [9*Cin][Cmid] row-major
+  pk.add(P->kernel1, Co, 1, 9 * Cm, Co, saved + L.k1_p, -1, -1, wfmt_plain_f32ops());
   CK(pk.run(st));
   PadP q0{s->B, geo.N, s->W, geo.wp, geo.np, Ci};
   PadP q1{s->B, geo.N, s->W, geo.wp, geo.np, Cm};
@@ -1393,7 +1606,7 @@ int macx_stem_backward(const macx_stem_shapes* s, int act, float keep, uint32_t 
     Packer pk;
     for (int tap = 0; tap < 9; ++tap)
       pk.add(P->kernel1 + (size_t)tap * Cm * Co, 1, Co, Co, Cm, ws + W.k1T_p + (size_t)tap * (gemm_split_mode() ? wsize(Co, Cm) : (size_t)Co * Cm), -1, -1,
-             wfmt_plain());
+             wfmt_plain_f32ops());
     CK(pk.run(st));
   }
   // dY2 = d_kb * act'(kb)
@@ -1613,14 +1826,63 @@ int macx_adam_ema_step(size_t n, float* params, const float* grads, float* m, fl
 
 /* test/tuning hook: key 0 = waves per workgroup of the kb GEMM (4 or 8) */
 int macx_gemm_mode(int mode) {
-  if (mode == MACX_GEMM_NATIVE || mode == MACX_GEMM_SPLIT) gemm_split_mode() = mode;
+  if (mode == MACX_GEMM_NATIVE || mode == MACX_GEMM_SPLIT || mode == MACX_GEMM_H2) gemm_split_mode() = mode;
   return gemm_split_mode();
+}
+
+size_t macx_h2_floats(size_t rows, size_t cols) { return (cols % 128) ? 0 : al4(h2_floats(rows, cols)); }
+
+int macx_h2_from_f32(const float* src, int B, int N, int C, float* h2, void* stream) {
+  if (!src || !h2 || B < 1 || N < 1 || C < 128 || C % 128 || misaligned(src) || misaligned(h2)) return MACX_EINVAL;
+  H2FromP f;
+  memset(&f, 0, sizeof(f));
+  f.src = src; f.B = B; f.N = N; f.C = C; f.out = h2_view(h2, B * N, C);
+  f.thr24 = 1u << 24; f.inv_keep = 1.0f; f.thr24_2 = 1u << 24;
+  CK(h2_from_f32(f, (hipStream_t)stream));
+  return MACX_OK;
+}
+
+int macx_h2_to_f32(const float* h2, int rows, int C, float* out, void* stream) {
+  if (!h2 || !out || rows < 1 || C < 128 || C % 128) return MACX_EINVAL;
+  hipLaunchKernelGGL(h2_to_f32_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, h2_view(h2, rows, C), out);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
+int macx_h2_gemm(const float* A, int B, int N, int K, const float* Wm, int n_out, const float* bias, int act, float* out,
+                 float* ws, size_t ws_floats, void* stream) {
+  if (!A || !Wm || !bias || !out || !ws || B < 1 || N < 1 || N > K_MAXN || K < 128 || K % 128 || n_out < 128 || n_out % 128)
+    return MACX_EINVAL;
+  const size_t fa = al4(h2_floats((size_t)B * N, K)), fo = al4(h2_floats((size_t)B * N, n_out));
+  const size_t fw = al4((size_t)K * n_out + 4);
+  if (ws_floats < fa + fo + fw + 8) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  float* hA = ws; float* hO = ws + fa; float* wp = hO + fo; float* wmax = wp + fw;
+  const char* dbg_stage = getenv("MACX_H2_DEBUG_STAGE");
+  const int stage = dbg_stage ? atoi(dbg_stage) : 99;
+  CKI(macx_h2_from_f32(A, B, N, K, hA, stream));
+  if (stage <= 1) return MACX_OK;
+  CK(absmax4(Wm, (size_t)K * n_out, Wm, 1, Wm, 1, Wm, 1, wmax, st));
+  if (stage <= 2) return MACX_OK;
+  Packer pk;
+  pk.add(Wm, n_out, 1, K, n_out, wp, -1, -1, 3, wmax);
+  CK(pk.run(st));
+  if (stage <= 3) return MACX_OK;
+  GemmH2P g;
+  memset(&g, 0, sizeof(g));
+  g.B = B; g.N = N; g.K = K; g.Nout = n_out;
+  g.A = h2_view(hA, B * N, K);
+  g.Wh = reinterpret_cast<const char*>(wp); g.w_exp = reinterpret_cast<const int*>(wp) + (size_t)K * n_out;
+  g.out = h2_view(hO, B * N, n_out); g.bias = bias; g.act = act; g.e_inv_keep = 1.0f;
+  CK((kb_gemm_h2_launch<B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  if (stage <= 4) return MACX_OK;
+  return macx_h2_to_f32(hO, B * N, n_out, out, stream);
 }
 
 int macx_debug_set(int key, int value) {
   if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }
   if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
-  if (key == 3 && (value == 0 || value == 1)) { gemm_split_mode() = value; return MACX_OK; }
+  if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_split_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;
 }

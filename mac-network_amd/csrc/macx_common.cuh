@@ -4,11 +4,30 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace macx {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per-device state, so the
+// cache is keyed by both (a process that drives several GPUs from one thread each must not skip the call on the second
+// device), and it is guarded for concurrent callers.
+inline hipError_t lds_attr_once(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({fn, dev})) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.insert({fn, dev});
+  return e;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based dropout stream.

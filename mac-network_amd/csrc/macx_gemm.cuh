@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
 // runtime knob (macx_debug_set(0, NW)): waves per workgroup of the kb GEMM, 4 or 8
 inline int& kb_gemm_nw() { static int nw = 8; return nw; }
 inline int& kb_gemm_dbg() { static int m = 0; return m; }
-inline int& gemm_split_mode() { static int m = 1; return m; }   // 1: knowledge-base GEMMs on the split-bf16 kernel (macx_gemm6.cuh)
+inline int& gemm_split_mode() { static int m = 2; return m; }   // kernel family of the read unit: 0 native f32 MFMA, 1 split-bf16 (macx_gemm6.cuh), 2 H2 fp16 planes (macx_gemm_h2.hip.h)
 inline int& kb_gemm_force_rt() { static int rt = 0; return rt; }   // tuning override (macx_debug_set key 2)
 
 template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>

@@ -1,0 +1,444 @@
+// macx_gemm_h2.hip.h -- the knowledge-base GEMM family on H2 operands (macx_h2.hip.h): [B*N, K] x [K, Nout] with both
+// operands as two fp16 planes, three MFMA terms per product on v_mfma_f32_16x16x32_f16, fp32 accumulation.
+//
+// Same per-question tiling as the other two families (RT*16 rows of ONE question x 128 columns, 8 waves arranged
+// 2 row halves x 4 column groups, grid = B x Nout/128 = one workgroup per CU at the CLEVR shape), but
+//   * the A operand arrives pre-split from the kernel that produced it: staging is a pure 16-byte copy
+//     (global_load_dwordx4 -> ds_write_b128, lane-linear on both sides), no vector-ALU work per element;
+//   * 32-wide K slices through a THREE-stage LDS ring (43 KB per stage at RT = 13): the loads of slice s+2 are issued
+//     before the MFMAs of slice s and stored after them, so the single barrier per slice only protects the stage being
+//     overwritten -- no wave waits at it for data it is about to use, and the two waves of a SIMD drift into
+//     complementary phases (one multiplying while the other copies);
+//   * per-(row, 128-column block) exponents: the MFMAs of one 128-wide K block accumulate in a block accumulator that is
+//     folded into the running sum with the row's exact power-of-two factor (4 folds per launch at K = 512);
+//   * weights: B_PLAIN pre-split once per call (pack format 3, per-matrix exponent); B_YMIX_* mixed with the question's
+//     vector in fp32 while staging as before, scaled by a per-question bound, then split.
+// Epilogue: accumulators -> row-major LDS tile -> ONE pass with lanes running along rows (bias / activation / act' from an
+// H2 tensor / attention-logit partials), per-row maxima and logit partials combined through small LDS tables, then the
+// tile is written as H2 (a wave stores 64 rows of one slot column = one contiguous KiB per plane).  E_DKB keeps the
+// row-major fp32 epilogue of macx_gemm.cuh (its output is the caller's fp32 gradient).
+#pragma once
+#include "macx_gemm.cuh"
+#include "macx_h2.hip.h"
+
+namespace macx {
+
+struct GemmH2P {
+  int B, N, K, Nout;
+  H2View A;                 // [B*N][K]
+  const char* Wh;           // B_PLAIN: fp16 planes in slot order [K/32][2][4][Nout] x 16 B (pack format 3)
+  const int* w_exp;         // B_PLAIN: device int, exponent of the packed matrix
+  const float* Wt;          // B_YMIX_*: fp32 k-major tiles [K/32][Nout][32] (pack format 2) of W1a / W1a^T
+  const float* Wt2;         // ... of W1b / W1b^T
+  const float* w_max;       // B_YMIX_*: device floats {max |W1a|, max |W1b|}
+  const float* y; int ldy;  // per-question vector mixed into the weight tile
+  H2View out;               // every epilogue but E_DKB
+  float* out_f32; int ldo;  // E_DKB: caller's fp32 [B*N][ldo]
+  const float* bias; int act;
+  H2View aux;               // E_MUL_DACT: the activation OUTPUT whose derivative multiplies the result (H1)
+  const float* dr; int ld_dr;   // E_DKB: dinfo [B][ld_dr]
+  const float* cvec;        // E_I2_LOGIT: control [B][Nout]
+  const float* wvec;        // E_I2_LOGIT: logits weight [Nout]
+  const float* att;         // E_DKB: kb attention [B][N]
+  float* logit_part;        // E_I2_LOGIT: [Nout/128][B*N]
+  float* colsum_part;       // COLSUM: column sums of the result per workgroup row block [B*nrb][Nout]
+  const uint8_t* e_bytes;   // E_I2_LOGIT: keep bits of act(I2*c), one byte per slot, [Nout/8][Rp]; null = keep all
+  const uint32_t* e_bits;   // E_DKB: keep bits of the knowledge base, row-major [B*N][ldo/32]; null = keep all
+  float e_inv_keep;
+  int accumulate;           // E_DKB
+  int* out_qmin;            // [B][Nout/128] minimum exponent of each question's output rows, atomicMin (caller presets 127)
+};
+
+template <int RT>
+constexpr int kb_gemm_h2_lds_bytes() {
+  constexpr int ROWS = RT * 16;
+  constexpr int stage = 2 * 4 * ROWS * 16 + 2 * 4 * 128 * 16;
+  constexpr int ring = 3 * stage + ROWS * 8 + 4096;     // + the A exponents of the tile + the question's mixing vector
+  constexpr int epi = ROWS * 132 * 4 + 2 * 16 * ROWS * 4 + ROWS * 4 + 16 * 32 * 16;
+  return ring > epi ? ring : epi;
+}
+
+template <int RT, int BP, int EP, bool COLSUM>
+__global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+  constexpr int G_THREADS = 512;
+  constexpr int G_BN = 128;
+  constexpr int G_LDT = G_BN + 4;
+  constexpr int ROWS = RT * 16;
+  constexpr int A_GS = ROWS * 16;                    // bytes between k-groups of an A plane
+  constexpr int A_PLANE = 4 * A_GS;
+  constexpr int B_GS = G_BN * 16;
+  constexpr int B_PLANE = 4 * B_GS;
+  constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+  constexpr int A_SLOTS = 2 * 4 * ROWS;
+  constexpr int A_IT = (A_SLOTS + G_THREADS - 1) / G_THREADS;
+  constexpr int HT = (RT + 1) / 2;
+
+  const int nblk = gridDim.x;
+  int v = blockIdx.x;
+  if ((nblk & 7) == 0) v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int ncb = p.Nout / G_BN;
+  const int nrb = (p.N + ROWS - 1) / ROWS;
+  const int cb = v % ncb;
+  const int rbi = (v / ncb) % nrb;
+  const int b = v / (ncb * nrb);
+  const int ntiles = (p.N + 15) >> 4;
+  const int tbase = ntiles / nrb, textra = ntiles - tbase * nrb;
+  const int nt = tbase + (rbi < textra ? 1 : 0);
+  const int row0 = (rbi * tbase + min(rbi, textra)) << 4;
+  const int row_end = min(p.N, row0 + (nt << 4));
+  const int nvalid = row_end - row0;
+  const size_t grow0 = (size_t)b * p.N + row0;       // first global row of the tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2;
+  const int cgp = wave & 3;
+  const int t0 = half * HT;
+  const int my_nt = max(0, min(nt - t0, half ? RT - HT : HT));
+  const int nk = p.K >> 5;
+  const int nkb = p.K >> 7;                          // 128-wide K blocks = exponent blocks of A
+
+  // ---- exponents of this tile's A rows -> LDS; weight exponent
+  int8_t* sE = reinterpret_cast<int8_t*>(lds + 3 * STAGE);         // [ROWS][8]
+  {
+    const int8_t* eA = p.A.exps();
+    const int acb = p.A.cb();
+    for (int i = tid; i < ROWS * acb; i += G_THREADS) {
+      const int r = i / acb, k = i - r * acb;
+      sE[r * 8 + k] = eA[(grow0 + r) * acb + k];                   // rows past the tensor end lie in the pad rows
+    }
+  }
+  float* sY = reinterpret_cast<float*>(lds + 3 * STAGE + ROWS * 8);   // B_YMIX_ROW: y_b[K]
+  int eB = 0;
+  if (BP == B_PLAIN) {
+    eB = *p.w_exp;
+  } else {
+    if (BP == B_YMIX_ROW)
+      for (int k = tid; k < p.K; k += G_THREADS) sY[k] = p.y[(size_t)b * p.ldy + k];
+    // |y W1a + W1b| <= max|y_b| max|W1a| + max|W1b|: a power of two above the bound costs at most the low end of the range
+    float* red = reinterpret_cast<float*>(lds);
+    float m = 0.f;
+    for (int k = tid; k < p.K; k += G_THREADS) m = fmaxf(m, fabsf(p.y[(size_t)b * p.ldy + k]));
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+    eB = h2_weight_exponent(fmaf(m, p.w_max[0], p.w_max[1]));
+    __syncthreads();
+  }
+  const float sB = h2_pow2(eB);
+
+  f32x4 acc[HT][2], tot[HT][2];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) acc[t][0] = acc[t][1] = tot[t][0] = tot[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: pure copies, lane-linear in LDS (slot f of a stage sits at byte 16 f)
+  const size_t Rp = p.A.Rp();
+  const size_t a_kstep = 4 * Rp * 16;                // bytes per K slice in a plane
+  const char* a_base = p.A.base;
+  uint32_t a_off[A_IT];                              // byte offset of this thread's slot in slice 0 (both planes < 4 GB)
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int f = min(tid + G_THREADS * i, A_SLOTS - 1);
+    const int q = f / ROWS, lrow = f - q * ROWS;     // q = 4 plane + k-group
+    a_off[i] = (uint32_t)((q >> 2) * p.A.plane_bytes() + ((size_t)(q & 3) * Rp + grow0 + lrow) * 16);
+  }
+  u32x4 ra[A_IT], rb[2];
+  f32x4 rw[2], rw2[2];
+  const int yg = lane >> 4;                                        // B_YMIX: this thread's k-group and column
+  const int ycolm = (lane & 15) + 16 * (tid >> 6);
+  float ycol = 0.f;
+  if (BP == B_YMIX_COL) ycol = p.y[(size_t)b * p.ldy + cb * G_BN + ycolm];
+
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_base + (size_t)kt * a_kstep + a_off[i]);
+    if (BP == B_PLAIN) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = tid + G_THREADS * i;                         // plane i, k-group (f >> 7) & 3, column f & 127
+        rb[i] = *reinterpret_cast<const u32x4*>(p.Wh + ((((size_t)kt * 2 + i) * 4 + ((f >> 7) & 3)) * p.Nout + cb * G_BN + (f & 127)) * 16);
+      }
+    } else {
+      const size_t off = ((size_t)kt * p.Nout + cb * G_BN + ycolm) * 32 + yg * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        rw[h] = *reinterpret_cast<const f32x4*>(p.Wt + off + 4 * h);
+        rw2[h] = *reinterpret_cast<const f32x4*>(p.Wt2 + off + 4 * h);
+      }
+    }
+  };
+  auto store_tiles = [&](int buf, int kt) {
+    char* dA = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      if (tid + G_THREADS * i < A_SLOTS) *reinterpret_cast<u32x4*>(dA + (tid + G_THREADS * i) * 16) = ra[i];
+    char* dB = dA + 2 * A_PLANE;
+    if (BP == B_PLAIN) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(dB + (tid + G_THREADS * i) * 16) = rb[i];
+    } else {
+      float x[8];
+      f32x4 ry[2];
+      if (BP == B_YMIX_ROW) {
+        ry[0] = *reinterpret_cast<const f32x4*>(sY + (kt << 5) + yg * 8);
+        ry[1] = *reinterpret_cast<const f32x4*>(sY + (kt << 5) + yg * 8 + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // ROW: B_eff[k][j] = y[b][k] W1a[k][j] + W1b[k][j]     (ops.py:703,718 folded into the weights)
+        // COL: B_eff[k][j] = y[b][j] W1a^T[k][j] + W1b^T[k][j] (backward-data of the same product)
+        const float yy = (BP == B_YMIX_ROW) ? ry[e >> 2][e & 3] : ycol;
+        x[e] = fmaf(rw[e >> 2][e & 3], yy, rw2[e >> 2][e & 3]) * sB;
+      }
+      u32x4 hi, lo;
+      h2_split8(x, hi, lo);
+      char* d = dB + yg * B_GS + ycolm * 16;
+      *reinterpret_cast<u32x4*>(d) = hi;
+      *reinterpret_cast<u32x4*>(d + B_PLANE) = lo;
+    }
+  };
+
+  // lane (i = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7 of row / column i for both operands
+  auto compute = [&](int buf) {
+    const char* sA = lds + buf * STAGE + (lane >> 4) * A_GS + (t0 * 16 + (lane & 15)) * 16;
+    const char* sB_ = lds + buf * STAGE + 2 * A_PLANE + (lane >> 4) * B_GS + (cgp * 32 + (lane & 15)) * 16;
+    u32x4 bf[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bf[pl][c] = *reinterpret_cast<const u32x4*>(sB_ + pl * B_PLANE + c * 256);
+    // smallest terms first: A_lo x B_hi ; A_hi x {B_lo, B_hi}
+    // row tiles in groups of TG so that only TG A fragments are live at a time (the kernel runs at the 256-register cap)
+    constexpr int TG = 4;
+#pragma unroll
+    for (int ap = 1; ap >= 0; --ap) {
+#pragma unroll
+      for (int tb = 0; tb < HT; tb += TG) {
+        u32x4 af[TG];
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+          const int t = tb + u;
+          if (t < HT && (t < HT - 1 || t < my_nt)) af[u] = *reinterpret_cast<const u32x4*>(sA + ap * A_PLANE + t * 256);
+        }
+#pragma unroll
+        for (int bp = 1 - ap; bp >= 0; --bp) {
+#pragma unroll
+          for (int u = 0; u < TG; ++u) {
+            const int t = tb + u;
+            if (t < HT && (t < HT - 1 || t < my_nt)) {
+              acc[t][0] = mfma_f16(af[u], bf[bp][0], acc[t][0]);
+              acc[t][1] = mfma_f16(af[u], bf[bp][1], acc[t][1]);
+            }
+          }
+        }
+      }
+    }
+  };
+  // end of a 128-wide K block: running sum += block sum * 2^-(eA[row][kb] + eB)
+  auto fold = [&](int kb) {
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int lrow = (t0 + t) * 16 + (lane >> 4) * 4 + e;
+        const float f = h2_unscale((int)sE[min(lrow, ROWS - 1) * 8 + kb], eB);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          tot[t][c][e] = fmaf(acc[t][c][e], f, tot[t][c][e]);
+          acc[t][c][e] = 0.f;
+        }
+      }
+  };
+
+  load_tiles(0);
+  store_tiles(0, 0);
+  if (nk > 1) { load_tiles(1); store_tiles(1, 1); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 2 < nk) load_tiles(kt + 2);
+    compute(kt % 3);
+    if ((kt & 3) == 3) fold(kt >> 2);
+    __syncthreads();                 // every wave is done with stage (kt + 2) % 3 (read in iteration kt - 1)
+    if (kt + 2 < nk) store_tiles((kt + 2) % 3, kt + 2);
+  }
+  (void)nkb;
+  __syncthreads();
+
+  // ---- epilogue, step 1: accumulators -> row-major LDS tile (16x16 map: col = lane & 15, row = (lane >> 4) * 4 + reg)
+  float* T = smem;
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    if (t0 + t < RT) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          T[((t0 + t) * 16 + (lane >> 4) * 4 + e) * G_LDT + cgp * 32 + c * 16 + (lane & 15)] = tot[t][c][e];
+    }
+  }
+  __syncthreads();
+
+  if (EP == E_DKB) {
+    GemmP q;
+    q.B = p.B; q.N = p.N; q.K = p.K; q.Nout = p.Nout;
+    q.out = p.out_f32; q.ldo = p.ldo; q.aux = p.dr; q.ld_aux = p.ld_dr; q.att = p.att;
+    q.e_bits = p.e_bits; q.e_inv_keep = p.e_inv_keep; q.accumulate = p.accumulate; q.dbg = 0;
+    q.bias = nullptr; q.cvec = nullptr; q.wvec = nullptr; q.logit_part = nullptr; q.colsum_part = nullptr; q.act = 0;
+    kb_epilogue_rows<RT, 8, E_DKB, false>(q, smem, b, cb, rbi, nrb, row0, row_end);
+    return;
+  }
+
+  // ---- step 2: lanes along rows.  item it = tid + 512 i  ->  slot column kgl = it / RP, local row it % RP
+  constexpr int RP = (ROWS + 63) & ~63;
+  constexpr int ITEMS = (16 * RP + G_THREADS - 1) / G_THREADS;
+  float* Mx = smem + ROWS * G_LDT;                 // [16][ROWS] partial row maxima
+  float* Px = Mx + 16 * ROWS;                      // [16][ROWS] partial attention logits
+  int* rexp = reinterpret_cast<int*>(Px + 16 * ROWS);       // [ROWS]
+  f32x4* red = reinterpret_cast<f32x4*>(rexp + ROWS);       // [16][32] column partials
+  float val[ITEMS][8];
+  const size_t oRp = p.out.Rp();
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int it = tid + G_THREADS * i;
+    const int kgl = it / RP, lrow = it - kgl * RP;
+    if (kgl < 16 && lrow < nvalid) {
+      const int col = cb * G_BN + kgl * 8;
+      float* tp = T + lrow * G_LDT + kgl * 8;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(tp), a1 = *reinterpret_cast<const f32x4*>(tp + 4);
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[e] = a0[e]; x[4 + e] = a1[e]; }
+      if (EP == E_BIAS_ACT || EP == E_I2_LOGIT) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] += b0[e]; x[4 + e] += b1[e]; }
+      }
+      if (EP == E_BIAS_ACT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = act_apply(p.act, x[e]);
+      }
+      if (EP == E_I2_LOGIT) {
+        // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w   (the bias b_k is added in kb_attend)
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.cvec + (size_t)b * p.Nout + col);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.cvec + (size_t)b * p.Nout + col + 4);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wvec + col), w1 = *reinterpret_cast<const f32x4*>(p.wvec + col + 4);
+        const uint32_t bits = p.e_bytes ? p.e_bytes[(size_t)(cb * 16 + kgl) * oRp + grow0 + lrow] : 0xFFu;
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float g = act_apply(p.act, x[e] * (e < 4 ? c0[e & 3] : c1[e & 3]));
+          g = ((bits >> e) & 1u) ? g * p.e_inv_keep : 0.f;
+          part = fmaf(g, e < 4 ? w0[e & 3] : w1[e & 3], part);
+        }
+        Px[kgl * ROWS + lrow] = part;
+      }
+      if (EP == E_MUL_DACT) {
+        const size_t arp = p.aux.Rp();
+        const char* ap = p.aux.plane(0) + ((size_t)(cb * 16 + kgl) * arp + grow0 + lrow) * 16;
+        const u32x4 hh = *reinterpret_cast<const u32x4*>(ap), hl = *reinterpret_cast<const u32x4*>(ap + p.aux.plane_bytes());
+        float h[8];
+        h2_join8(hh, hl, h2_pow2(-(int)p.aux.exps()[(grow0 + lrow) * p.aux.cb() + cb]), h);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] *= act_grad_from_out(p.act, h[e]);
+      }
+      float m = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { val[i][e] = x[e]; m = fmaxf(m, fabsf(x[e])); }
+      Mx[kgl * ROWS + lrow] = m;
+      if (COLSUM) {
+        *reinterpret_cast<f32x4*>(tp) = f32x4{x[0], x[1], x[2], x[3]};
+        *reinterpret_cast<f32x4*>(tp + 4) = f32x4{x[4], x[5], x[6], x[7]};
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nvalid) {
+    float m = Mx[tid];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, Mx[k * ROWS + tid]);
+    const int e = h2_exponent(m);
+    rexp[tid] = e;
+    p.out.exps()[(grow0 + tid) * p.out.cb() + cb] = (int8_t)e;
+    if (EP == E_I2_LOGIT) {
+      float s = Px[tid];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) s += Px[k * ROWS + tid];          // fixed order
+      p.logit_part[(size_t)cb * p.B * p.N + grow0 + tid] = s;
+    }
+  }
+  if (p.out_qmin && tid < 64) {
+    // (reads rexp after the barrier below would cost another barrier: recompute from Mx, which is complete here)
+    int mn = 127;
+    for (int r = tid; r < nvalid; r += 64) {
+      float m = Mx[r];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) m = fmaxf(m, Mx[k * ROWS + r]);
+      mn = min(mn, h2_exponent(m));
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) mn = min(mn, __shfl_xor(mn, s, 64));
+    if (tid == 0) atomicMin(p.out_qmin + (size_t)b * p.out.cb() + cb, mn);
+  }
+  if (COLSUM) {
+    const int c4 = tid & 31, rg = tid >> 5;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    for (int lrow = rg; lrow < nvalid; lrow += 16) cs += *reinterpret_cast<const f32x4*>(T + lrow * G_LDT + c4 * 4);
+    red[rg * 32 + c4] = cs;
+  }
+  __syncthreads();
+  if (COLSUM && tid < 32) {
+    f32x4 t = red[tid];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) t += red[g * 32 + tid];
+    *reinterpret_cast<f32x4*>(p.colsum_part + (size_t)(b * nrb + rbi) * p.Nout + cb * G_BN + tid * 4) = t;
+  }
+  char* o0 = p.out.plane(0);
+  const size_t opb = p.out.plane_bytes();
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int it = tid + G_THREADS * i;
+    const int kgl = it / RP, lrow = it - kgl * RP;
+    if (kgl < 16 && lrow < nvalid) {
+      const float s = h2_pow2(rexp[lrow]);
+      float xs[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xs[e] = val[i][e] * s;
+      u32x4 hi, lo;
+      h2_split8(xs, hi, lo);
+      char* d = o0 + ((size_t)(cb * 16 + kgl) * oRp + grow0 + lrow) * 16;
+      *reinterpret_cast<u32x4*>(d) = hi;
+      *reinterpret_cast<u32x4*>(d + opb) = lo;
+    }
+  }
+}
+
+template <int RT, int BP, int EP, bool COLSUM>
+inline hipError_t kb_gemm_h2_launch_rt(const GemmH2P& p, hipStream_t st) {
+  auto kern = kb_gemm_h2_kernel<RT, BP, EP, COLSUM>;
+  constexpr size_t lds = (size_t)kb_gemm_h2_lds_bytes<RT>();
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
+  if (e != hipSuccess) return e;
+  const int ncb = p.Nout / 128;
+  const int nrb = (p.N + RT * 16 - 1) / (RT * 16);
+  hipLaunchKernelGGL(kern, dim3(p.B * nrb * ncb), dim3(512), lds, st, p);
+  return hipGetLastError();
+}
+
+template <int BP, int EP, bool COLSUM>
+inline hipError_t kb_gemm_h2_launch(const GemmH2P& p, hipStream_t st) {
+  switch (kb_gemm_pick_rt(p.N, p.B, p.Nout / 128)) {
+    case 1: return kb_gemm_h2_launch_rt<1, BP, EP, COLSUM>(p, st);
+    case 2: return kb_gemm_h2_launch_rt<2, BP, EP, COLSUM>(p, st);
+    case 4: return kb_gemm_h2_launch_rt<4, BP, EP, COLSUM>(p, st);
+    case 7: return kb_gemm_h2_launch_rt<7, BP, EP, COLSUM>(p, st);
+    default: return kb_gemm_h2_launch_rt<13, BP, EP, COLSUM>(p, st);
+  }
+}
+
+}  // namespace macx

@@ -1,0 +1,337 @@
+// macx_h2.hip.h -- the "H2" tensor format: fp32 values stored ONCE, by the kernel that produces them, as the two fp16
+// planes the matrix pipe consumes.
+//
+// gfx950 multiplies fp16 at the bf16 rate (2.5 PF dense) and f32 at 1/16 of it.  An fp32 value x scaled by a power of two
+// into fp16's range splits as  x 2^e = hi + lo,  hi = fp16(x 2^e),  lo = fp16(x 2^e - hi)  (round-to-nearest both times):
+// 11 + 11 significant bits plus the two rounding halvings leave |x 2^e - hi - lo| <= 2^-24 |x 2^e| -- fp32's own rounding
+// unit -- as long as lo stays a normal fp16, i.e. for elements within 2^-16 of the block maximum; below that the error is
+// absolute, <= 2^-40 of the block maximum.  A product is the three leading terms
+//     a b  ~=  a_lo b_hi + a_hi b_lo + a_hi b_hi                (dropped: a_lo b_lo <= 2^-24 |a b|)
+// on v_mfma_f32_16x16x32_f16 with fp32 accumulation (every fp16 x fp16 product is exact in fp32): fp32-class error
+// (tests/test_gpu_units.py measures it against fp64 next to the native f32 MFMA kernel) at 3/16 of the f32 MFMA issue
+// time, with 4 bytes per element -- the same HBM and LDS bytes as the fp32 tensor it replaces.
+//
+// Layout of an H2 tensor of R rows x C columns (C % 128 == 0), "slot-major":
+//     plane p (0 = hi, 1 = lo):  slot[p][kg][row] = 8 consecutive columns 8 kg .. 8 kg + 7 of one row, 16 bytes,
+//                                at byte ((p * C/8 + kg) * Rp + row) * 16,   Rp = R + H2_PAD_ROWS
+//     exponents:                 e[row][cb] (int8) for the 128-column block cb: the stored fp16 are x * 2^e
+// so the 16 lanes of an MFMA k-group read 16 consecutive rows = 256 contiguous bytes, a wave copies 64 rows of one slot
+// column as one contiguous KiB, and every consumer's staging is a pure copy.  Exponents are per (row, 128 columns): a
+// producer workgroup owns exactly such blocks, so no cross-workgroup reduction is needed and every row keeps its own
+// relative precision.
+#pragma once
+#include "macx_common.cuh"
+
+namespace macx {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H2_PAD_ROWS = 64;      // tiles may read (never use) up to this many rows past the end
+constexpr int H2_E_MIN = -113, H2_E_MAX = 90;   // 2^e stays a normal fp32 for every finite fp32 block maximum
+
+struct H2View {          // device view of one H2 tensor
+  char* base;            // plane 0 | plane 1 | exponents
+  int R, C;
+  __host__ __device__ __forceinline__ int Rp() const { return R + H2_PAD_ROWS; }
+  __host__ __device__ __forceinline__ size_t plane_bytes() const { return (size_t)(C >> 3) * Rp() * 16; }
+  __host__ __device__ __forceinline__ char* plane(int p) const { return base + p * plane_bytes(); }
+  __host__ __device__ __forceinline__ int8_t* exps() const { return reinterpret_cast<int8_t*>(base + 2 * plane_bytes()); }
+  __host__ __device__ __forceinline__ int cb() const { return C >> 7; }
+};
+// floats a caller-owned buffer must hold for an H2 tensor (planes + exponents, 16-byte multiple)
+__host__ __device__ inline size_t h2_floats(size_t R, size_t C) {
+  const size_t Rp = R + H2_PAD_ROWS;
+  const size_t bytes = 2 * (C >> 3) * Rp * 16 + Rp * (C >> 7);
+  return ((bytes + 15) & ~(size_t)15) / 4;
+}
+inline H2View h2_view(float* buf, int R, int C) { return H2View{reinterpret_cast<char*>(buf), R, C}; }
+inline H2View h2_view(const float* buf, int R, int C) { return H2View{reinterpret_cast<char*>(const_cast<float*>(buf)), R, C}; }
+
+// exponent that lifts a block whose largest magnitude is `maxabs` into [2^14, 2^15)
+__device__ __forceinline__ int h2_exponent(float maxabs) {
+  const int be = (int)((__float_as_uint(maxabs) >> 23) & 0xFFu);
+  int e = 141 - be;
+  e = maxabs == 0.0f ? 0 : e;
+  return min(max(e, H2_E_MIN), H2_E_MAX);
+}
+__device__ __forceinline__ float h2_pow2(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }   // 2^e, -126 <= e <= 127
+// 2^-(ea + eb) for two stored exponents: as a product, so that a sum outside fp32's exponent range overflows / underflows
+// the way the true scale would instead of wrapping the bit pattern
+__device__ __forceinline__ float h2_unscale(int ea, int eb) { return h2_pow2(-ea) * h2_pow2(-eb); }
+
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {        // v_cvt_pk_f16_f32 (RNE): low half = a
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ f32x2_t unpk_f16(uint32_t w) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2_t);
+}
+// 8 consecutive columns of one row, already multiplied by 2^e -> the hi and lo slots
+__device__ __forceinline__ void h2_split8(const float* xs, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const float a = xs[2 * h], b = xs[2 * h + 1];
+    hi[h] = pk_f16(a, b);
+    const f32x2_t back = unpk_f16(hi[h]);
+    lo[h] = pk_f16(a - back[0], b - back[1]);
+  }
+}
+// the inverse: (hi + lo) * 2^-e; hi + lo is exact in fp32 (at most 24 significant bits)
+__device__ __forceinline__ void h2_join8(const u32x4 hi, const u32x4 lo, float inv_scale, float* x) {
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const f32x2_t a = unpk_f16(hi[h]), b = unpk_f16(lo[h]);
+    x[2 * h] = (a[0] + b[0]) * inv_scale;
+    x[2 * h + 1] = (a[1] + b[1]) * inv_scale;
+  }
+}
+__device__ __forceinline__ void h2_join4(const u32x2 hi, const u32x2 lo, float inv_scale, float* x) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x2_t a = unpk_f16(hi[h]), b = unpk_f16(lo[h]);
+    x[2 * h] = (a[0] + b[0]) * inv_scale;
+    x[2 * h + 1] = (a[1] + b[1]) * inv_scale;
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma_f16(const u32x4 a, const u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Workgroup tile -> H2.  A workgroup that holds `rows` x 128 finished values (one question's rows, one 128-column
+// block) row-major in LDS (T[lrow * ldt + col]) writes them out: lanes run along ROWS (a wave stores 64 consecutive rows
+// of one slot column = one contiguous KiB per plane), the per-row maximum over the 128 columns is combined across the
+// 16 slot columns through a small LDS table.  NT threads, NT % 64 == 0.  `scratch`: rows * 17 floats of LDS.
+//   item = (slot column kgl in [0,16), local row): item index it = tid + NT * i,  kgl = it / rows_pad, lrow = it % rows_pad
+// with rows_pad = rows rounded up to 64 so that a wave never straddles two slot columns.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, int MAXROWS>
+__device__ __forceinline__ void h2_store_tile(const float* T, int ldt, int rows, const H2View& o, size_t row0, int cb,
+                                              float* scratch, int* qmin_out = nullptr) {
+  constexpr int RP = (MAXROWS + 63) & ~63;
+  constexpr int ITEMS = (16 * RP + NT - 1) / NT;
+  const int tid = threadIdx.x;
+  float* rmax = scratch;                       // [16][rows] partial maxima, then [rows] exponents in row 0
+  float v[ITEMS][8];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int it = tid + NT * i;
+    const int kgl = it / RP, lrow = it - kgl * RP;
+    if (kgl < 16 && lrow < rows) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(T + lrow * ldt + kgl * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(T + lrow * ldt + kgl * 8 + 4);
+      float m = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = b[e]; m = fmaxf(m, fmaxf(fabsf(a[e]), fabsf(b[e]))); }
+      rmax[kgl * rows + lrow] = m;
+    }
+  }
+  __syncthreads();
+  if (tid < rows) {
+    float m = rmax[tid];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, rmax[k * rows + tid]);
+    const int e = h2_exponent(m);
+    o.exps()[(row0 + tid) * o.cb() + cb] = (int8_t)e;
+    reinterpret_cast<int*>(rmax)[16 * rows + tid] = e;
+  }
+  __syncthreads();
+  if (qmin_out && tid < 64) {       // minimum exponent of the tile's rows (several row blocks of one question: atomicMin)
+    int m = 127;
+    for (int r = tid; r < rows; r += 64) m = min(m, reinterpret_cast<const int*>(rmax)[16 * rows + r]);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) m = min(m, __shfl_xor(m, s, 64));
+    if (tid == 0) atomicMin(qmin_out, m);
+  }
+  const int* rexp = reinterpret_cast<const int*>(rmax) + 16 * rows;
+  char* p0 = o.plane(0);
+  const size_t pb = o.plane_bytes();
+  const size_t Rp = o.Rp();
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int it = tid + NT * i;
+    const int kgl = it / RP, lrow = it - kgl * RP;
+    if (kgl < 16 && lrow < rows) {
+      const float s = h2_pow2(rexp[lrow]);
+      float xs[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xs[e] = v[i][e] * s;
+      u32x4 hi, lo;
+      h2_split8(xs, hi, lo);
+      char* d = p0 + ((size_t)(cb * 16 + kgl) * Rp + row0 + lrow) * 16;
+      *reinterpret_cast<u32x4*>(d) = hi;
+      *reinterpret_cast<u32x4*>(d + pb) = lo;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 [B][N][C] row-major -> H2 (the caller's knowledge base enters the format here), optionally through a dropout
+// site (ops.py:678: out = kb * mask / keep) whose keep bits are kept row-major for the dKB epilogue, and optionally
+// emitting the keep BYTES of a second site over the same index range (the attention dropout, ops.py:312 via :142) in
+// slot order -- the pass is HBM-bound, the second hash is free.  One workgroup per (question row block, 128 columns).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int H2C_ROWS = 208;
+constexpr int H2C_THREADS = 512;
+constexpr int H2C_LDT = 132;
+constexpr size_t H2C_LDS = (size_t)H2C_ROWS * H2C_LDT * 4 + (size_t)17 * H2C_ROWS * 4;
+
+struct H2FromP {
+  const float* src; int B, N, C;
+  H2View out;
+  uint32_t first;                        // flat index of element (0,0,0): b0 * N * C
+  uint32_t key, thr24; float inv_keep;   // site 1 (thr24 = 1 << 24: keep everything)
+  uint32_t* bits;                        // site 1 keep bits, row-major [B*N][C/32]; may be null
+  uint32_t key2, thr24_2;                // site 2
+  uint8_t* bytes2;                       // site 2 keep bytes, slot order [C/8][Rp]; may be null
+  int* qmin;                             // [B][C/128] minimum exponent per question, atomicMin (caller presets 127); may be null
+};
+
+__global__ __launch_bounds__(H2C_THREADS) void h2_from_f32_kernel(H2FromP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* T = smem;
+  float* scratch = smem + H2C_ROWS * H2C_LDT;
+  const int nrb = (p.N + H2C_ROWS - 1) / H2C_ROWS;
+  const int b = blockIdx.x / nrb, rbi = blockIdx.x - b * nrb, cb = blockIdx.y;
+  const int row0 = rbi * H2C_ROWS;
+  const int rows = min(H2C_ROWS, p.N - row0);
+  const size_t grow0 = (size_t)b * p.N + row0;
+  const int tid = threadIdx.x, c4 = tid & 31, rg = tid >> 5;
+  const bool drop = p.thr24 < (1u << 24);
+  for (int lrow = rg; lrow < rows; lrow += H2C_THREADS / 32) {
+    const size_t e0 = (grow0 + lrow) * p.C + cb * 128 + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.src + e0);
+    if (drop) {
+      uint32_t nib = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool keep = keep_bit(p.first + (uint32_t)e0 + e, p.key, p.thr24);
+        nib |= (keep ? 1u : 0u) << e;
+        v[e] = keep ? v[e] * p.inv_keep : 0.f;
+      }
+      if (p.bits) {
+        uint32_t w = nib << (4 * (c4 & 7));
+        w |= __shfl_xor(w, 1, 64);
+        w |= __shfl_xor(w, 2, 64);
+        w |= __shfl_xor(w, 4, 64);
+        if ((c4 & 7) == 0) p.bits[e0 >> 5] = w;
+      }
+    }
+    *reinterpret_cast<f32x4*>(T + lrow * H2C_LDT + c4 * 4) = v;
+  }
+  __syncthreads();
+  h2_store_tile<H2C_THREADS, H2C_ROWS>(T, H2C_LDT, rows, p.out, grow0, cb, scratch, p.qmin ? p.qmin + (size_t)b * p.out.cb() + cb : nullptr);
+  if (p.bytes2) {
+    const size_t Rp = p.out.Rp();
+    for (int it = tid; it < 16 * 256; it += H2C_THREADS) {
+      const int kgl = it >> 8, lrow = it & 255;
+      if (lrow < rows) {
+        const uint32_t e0 = p.first + (uint32_t)((grow0 + lrow) * p.C + cb * 128 + kgl * 8);
+        uint32_t byte = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) byte |= (keep_bit(e0 + e, p.key2, p.thr24_2) ? 1u : 0u) << e;
+        p.bytes2[(size_t)(cb * 16 + kgl) * Rp + grow0 + lrow] = (uint8_t)byte;
+      }
+    }
+  }
+}
+
+// H2 -> fp32 row-major (tests and tools; not on the timed path)
+__global__ void h2_to_f32_kernel(H2View in, float* out) {
+  const size_t nslot = (size_t)(in.C >> 3) * in.R;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslot; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t kg = i / in.R, row = i - kg * in.R;
+    const char* s = in.plane(0) + (kg * in.Rp() + row) * 16;
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(s), lo = *reinterpret_cast<const u32x4*>(s + in.plane_bytes());
+    float x[8];
+    h2_join8(hi, lo, h2_pow2(-(int)in.exps()[row * in.cb() + (kg >> 4)]), x);
+    float* d = out + row * in.C + kg * 8;
+    *reinterpret_cast<f32x4*>(d) = f32x4{x[0], x[1], x[2], x[3]};
+    *reinterpret_cast<f32x4*>(d + 4) = f32x4{x[4], x[5], x[6], x[7]};
+  }
+}
+
+// min over the rows of `nt` H2 tensors (consecutive, `stride_bytes` apart) of the exponents, per 128-column block: the
+// common exponent a contraction over rows brings every row to.  out[cb] must be preset to 127.
+__global__ void h2_min_exp_kernel(const char* base, size_t stride_bytes, int nt, int R, int C, int* out) {
+  __shared__ int red[8][16];
+  const int ncb = C >> 7;
+  int m[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m[k] = 127;
+  for (int t = blockIdx.y; t < nt; t += gridDim.y) {
+    const H2View v{const_cast<char*>(base) + (size_t)t * stride_bytes, R, C};
+    const int8_t* e = v.exps();
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x)
+      for (int k = 0; k < ncb; ++k) m[k] = min(m[k], (int)e[(size_t)r * ncb + k]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < ncb; ++k) {
+    int x = m[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = min(x, __shfl_xor(x, o, 64));
+    if (lane == 0) red[k][wave] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < ncb) {
+    int x = red[threadIdx.x][0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) x = min(x, red[threadIdx.x][w]);
+    atomicMin(out + threadIdx.x, x);            // integer min: order-independent, deterministic
+  }
+}
+
+// ---- weights -------------------------------------------------------------------------------------------------
+// max |W| of up to 8 matrices in one launch (blockIdx.x selects the matrix), fixed-order reduction
+struct AbsMaxList { const float* src[8]; size_t n[8]; float* out; };
+__global__ __launch_bounds__(1024) void absmax_kernel(AbsMaxList L) {
+  __shared__ float red[16];
+  const float* s = L.src[blockIdx.x];
+  const size_t n = L.n[blockIdx.x];
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(s[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t = fmaxf(t, red[w]);
+    L.out[blockIdx.x] = t;
+  }
+}
+// pack format 3: W (or W^T) as H2 weight planes  dst[kt][plane][g][Nout] x 16 B  (8 consecutive k of one column),
+// scaled by the per-matrix exponent derived from *maxabs; the exponent is stored as an int after the planes.
+constexpr int H2_WE_LO = -20, H2_WE_HI = 36;
+__device__ __forceinline__ int h2_weight_exponent(float maxabs) { return min(max(h2_exponent(maxabs), H2_WE_LO), H2_WE_HI); }
+__device__ __forceinline__ void pack_h2_weight(const float* src, int ld_k, int ld_j, int K, int Nout, int k_src, int n_src,
+                                               const float* maxabs, float* dst, size_t tid_global, size_t nthreads) {
+  const int e = h2_weight_exponent(*maxabs);
+  const float s = h2_pow2(e);
+  const size_t nslot = (size_t)(K >> 3) * Nout;
+  char* d0 = reinterpret_cast<char*>(dst);
+  for (size_t i = tid_global; i < nslot; i += nthreads) {
+    const int j = (int)(i % Nout);
+    const int kg = (int)(i / Nout);
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = kg * 8 + q;
+      x[q] = (k < k_src && j < n_src) ? src[(size_t)k * ld_k + (size_t)j * ld_j] * s : 0.f;
+    }
+    u32x4 hi, lo;
+    h2_split8(x, hi, lo);
+    const int kt = kg >> 2, g = kg & 3;
+    char* d = d0 + ((((size_t)kt * 2) * 4 + g) * Nout + j) * 16;
+    *reinterpret_cast<u32x4*>(d) = hi;
+    *reinterpret_cast<u32x4*>(d + (size_t)4 * Nout * 16) = lo;
+  }
+  if (tid_global == 0) reinterpret_cast<int*>(dst)[(size_t)K * Nout] = e;
+}
+
+}  // namespace macx

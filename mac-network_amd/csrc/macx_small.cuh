@@ -4,6 +4,7 @@
 // (mac_cell.py:264-275; ops.py:140-150) and their backward twins.
 #pragma once
 #include "macx_common.cuh"
+#include "macx_h2.hip.h"
 
 namespace macx {
 
@@ -29,12 +30,18 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int 
 //   fmt 0: dst[Q][g][j][e] fp32 (16x16x4 f32 MFMA kernels, small linears)
 //   fmt 1: dst[kt][plane][j][32] bf16 -- the exact 3-way bf16 split of W (macx_gemm6.cuh, B_PLAIN); K*Nout*3/2 floats
 //   fmt 2: dst[kt][j][32] fp32 k-major tiles (macx_gemm6.cuh, B_YMIX_*: mixed in fp32, split while staging)
-struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; int fmt; };   // zero fill for k >= k_src or j >= n_src
+//   fmt 3: H2 weight planes dst[kt][plane][g][Nout] x 16 B fp16 + the matrix exponent (macx_h2.hip.h, macx_gemm_h2.hip.h)
+struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; int fmt; const float* maxabs; };   // zero fill for k >= k_src or j >= n_src
 constexpr int PACK_MAX = 40;
 struct PackList { PackDesc d[PACK_MAX]; };
 __global__ void pack_weights_kernel(PackList L) {
   const PackDesc q = L.d[blockIdx.y];
   const size_t total = (size_t)q.K * q.Nout;
+  if (q.fmt == 3) {
+    pack_h2_weight(q.src, q.ld_k, q.ld_j, q.K, q.Nout, q.k_src, q.n_src, q.maxabs, q.dst,
+                   (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+    return;
+  }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     if (q.fmt == 0) {
       const int e = i & 3;

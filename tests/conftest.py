@@ -8,8 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+GEMM_MODES = {"native": 0, "split": 1, "h2": 2}
+
+
 def default_gemm_mode():
-    return 0 if os.environ.get("MACX_GEMM") == "native" else 1
+    return GEMM_MODES.get(os.environ.get("MACX_GEMM", "h2"), 2)
 
 
 def pytest_configure(config):
@@ -19,8 +22,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def macx():
     import macx as m
-    if os.environ.get("MACX_GEMM"):         # run the whole suite on one kernel family: native | split (default)
-        m._lib.lib().macx_gemm_mode({"native": 0, "split": 1}[os.environ["MACX_GEMM"]])
+    if os.environ.get("MACX_GEMM"):         # run the whole suite on one kernel family: native | split | h2 (default)
+        m._lib.lib().macx_gemm_mode(GEMM_MODES[os.environ["MACX_GEMM"]])
     if os.environ.get("MACX_DBG"):          # debugging aid: kernel-selection / timing bits of macx_debug_set(1, .)
         m._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
     return m
@@ -36,8 +39,17 @@ def dev():
 
 @pytest.fixture
 def native_gemm(macx):
-    """Run one test on the native f32-MFMA knowledge-base GEMM (the default is the split-bf16 kernel); restored afterwards."""
+    """Run one test on the native f32-MFMA knowledge-base GEMM (the default is the H2 fp16-plane family); restored afterwards."""
     L = macx._lib.lib()
     L.macx_gemm_mode(0)
+    yield
+    L.macx_gemm_mode(default_gemm_mode())
+
+
+@pytest.fixture
+def split_gemm(macx):
+    """Run one test on the split-bf16 (3 x bf16, six MFMA terms) family; restored afterwards."""
+    L = macx._lib.lib()
+    L.macx_gemm_mode(1)
     yield
     L.macx_gemm_mode(default_gemm_mode())

@@ -46,9 +46,9 @@ def max_abs(a, b):
 
 
 def default_gemm_mode():
-    """Kernel family the session runs on (MACX_GEMM=native|split, default split): what mode-switching tests restore."""
+    """Kernel family the session runs on (MACX_GEMM=native|split|h2, default h2): what mode-switching tests restore."""
     import os
-    return 0 if os.environ.get("MACX_GEMM") == "native" else 1
+    return {"native": 0, "split": 1, "h2": 2}.get(os.environ.get("MACX_GEMM", "h2"), 2)
 
 
 def hashed_tensor(key, shape, lim=1.0):

@@ -102,13 +102,14 @@ def test_split_gemm_error_is_fp32_class(macx, dev):
     sh = macx._lib.MacxShapes(B=B, S=1, N=N, d=d, p=1, b0=0)
     dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=1)
     err = {}
+    Wd, kbd, bd = W.to(dev), kb.to(dev), b.to(dev)      # alive across the asynchronous calls
     try:
         for mode in (0, 1):
             L.macx_gemm_mode(mode)
             wp = torch.zeros(2 * d * d, device=dev)
             out = torch.empty(B, N, d, device=dev)
-            macx._lib.check(L.macx_pack_weight(_p(W.to(dev)), d, d, macx._lib.kb_pack_flags(), _p(wp), None), "pack")
-            macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 0, _p(kb.to(dev)), _p(wp), _p(b.to(dev)), _p(out), None, None), "proj")
+            macx._lib.check(L.macx_pack_weight(_p(Wd), d, d, macx._lib.kb_pack_flags(), _p(wp), None), "pack")
+            macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 0, _p(kbd), _p(wp), _p(bd), _p(out), None, None), "proj")
             torch.cuda.synchronize()
             e = (out.cpu().double().reshape(-1, d) - ref).abs() / scale
             err[mode] = (float(e.max()), float(e.mean()))

@@ -40,10 +40,20 @@ def test_check_and_sizing_without_gpu(macx):
     o = macx.freeze(mo.flag_file_config("args"))
     s = macx._lib.MacxShapes(B=64, S=50, N=196, d=512, p=12, b0=0)
     assert L.macx_check(C.byref(o), C.byref(s)) == 0
+    L.macx_gemm_mode(1)
+    try:
+        keep = L.macx_saved_floats(C.byref(o), C.byref(s), 1)
+        nokeep = L.macx_saved_floats(C.byref(o), C.byref(s), 0)
+        # X, H1, I2, dropped KB (fp32) + the two 1-bit dropout masks, kept for 11 more steps (+ the per-question exponents)
+        assert keep - nokeep == 11 * 64 * 196 * 512 * 4 + 11 * 2 * (64 * 196 * 512 // 32) + 11 * 3 * 64 * 4
+    finally:
+        L.macx_gemm_mode(2)
+    # the default family keeps the same tensors as H2: 4 bytes per element as well (+ exponents and 64 pad rows each)
     keep = L.macx_saved_floats(C.byref(o), C.byref(s), 1)
     nokeep = L.macx_saved_floats(C.byref(o), C.byref(s), 0)
-    # X, H1, I2, dropped KB (fp32) + the two 1-bit dropout masks, kept for 11 more steps
-    assert keep - nokeep == 11 * 64 * 196 * 512 * 4 + 11 * 2 * (64 * 196 * 512 // 32)
+    h2 = L.macx_h2_floats(64 * 196, 512)
+    assert 64 * 196 * 512 < h2 < 1.01 * 64 * 196 * 512
+    assert 11 * 4 * h2 < keep - nokeep < 11 * 4 * h2 + 11 * 2 * (64 * 196 + 64) * 64 // 4 + 11 * 3 * 64 * 4 + 64
     off, cnt = C.c_size_t(), C.c_size_t()
     assert L.macx_saved_segment(C.byref(o), C.byref(s), 1, macx._lib.SEG["att_kb"], C.byref(off), C.byref(cnt)) == 0
     assert cnt.value == 12 * 64 * 196
