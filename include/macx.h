@@ -314,11 +314,17 @@ int macx_gemm_mode(int mode);
  *   macx_h2_floats      floats a caller-owned buffer needs for one H2 tensor (0 if cols % 128)
  *   macx_h2_from_f32    src [B][N][C] fp32 row-major -> h2
  *   macx_h2_to_f32      h2 -> out [rows][C] fp32 row-major
- *   macx_h2_gemm        out[B*N, n_out] = act(A[B*N, K] @ W[K, n_out] + bias) through the H2 kernels (three fp16 MFMA
- *                       terms per product, fp32 accumulate); ws >= h2_floats(B*N,K) + h2_floats(B*N,n_out) + K*n_out + 16 */
+ *   macx_h2_pack_weight W [K, n_out] (or its transpose, from [n_out, K]) -> H2 weight planes + exponent; out >= K*n_out + 16 floats
+ *   macx_h2_gemm_planes hO = act(hA @ Wh + bias) on operands already in the format (what the cell launches per step; timed by
+ *                       bench.py's roofline probe)
+ *   macx_h2_gemm        out[B*N, n_out] = act(A[B*N, K] @ W[K, n_out] + bias): from_f32 + pack + gemm_planes + to_f32 (three fp16
+ *                       MFMA terms per product, fp32 accumulate); ws >= h2_floats(B*N,K) + h2_floats(B*N,n_out) + K*n_out + 16 */
 size_t macx_h2_floats(size_t rows, size_t cols);
 int macx_h2_from_f32(const float* src, int B, int N, int C, float* h2, void* stream);
 int macx_h2_to_f32(const float* h2, int rows, int C, float* out, void* stream);
+int macx_h2_pack_weight(const float* W, int K, int n_out, int transpose, float* out, void* stream);
+int macx_h2_gemm_planes(const float* hA, int B, int N, int K, const float* Wh, int n_out, const float* bias, int act, float* hO,
+                        void* stream);
 int macx_h2_gemm(const float* A, int B, int N, int K, const float* W, int n_out, const float* bias, int act, float* out,
                  float* ws, size_t ws_floats, void* stream);
 /* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688) on the knowledge-base GEMM.

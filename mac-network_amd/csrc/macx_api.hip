@@ -262,7 +262,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dwlin = take(p * B * d);
   L.dwin = take(B * win);
   L.dinfo = take(B * d);
-  L.dy_part = take((2 * d / 128) * B * d);
+  L.dy_part = take((4 * d / 128) * B * d);      // 2 column partials per 128-column tile (4 on the H2 kernel)
   L.DY = take(p * B * d);
   L.dmd = take(B * d);
   L.dt = take(B * d); L.du = take(B * d);
@@ -1002,7 +1002,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     }
     // dy -> d(md) -> dL/d m_{i-1} = dwin[:, :d] + (dy Wy^T) * memmask * readmask
     float* DYi = ws + W.DY + (size_t)i * Bd;
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dy_part), 2 * d / 128, Bd, DYi);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dy_part), (h2_mode() ? SBH_CW / 2 : 2) * d / 128, Bd, DYi);
     CK(hipGetLastError());
     {
       // with self attention DM[i] already holds the parts later steps sent to this memory: accumulate
@@ -1849,6 +1849,33 @@ int macx_h2_to_f32(const float* h2, int rows, int C, float* out, void* stream) {
   return MACX_OK;
 }
 
+int macx_h2_pack_weight(const float* Wm, int K, int n_out, int transpose, float* out, void* stream) {
+  if (!Wm || !out || K < 128 || K % 128 || n_out < 128 || n_out % 128 || misaligned(Wm) || misaligned(out)) return MACX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  float* wmax = out + al4((size_t)K * n_out + 4);
+  CK(absmax4(Wm, (size_t)K * n_out, Wm, 1, Wm, 1, Wm, 1, wmax, st));
+  Packer pk;
+  if (transpose) pk.add(Wm, 1, K, K, n_out, out, -1, -1, 3, wmax);
+  else pk.add(Wm, n_out, 1, K, n_out, out, -1, -1, 3, wmax);
+  CK(pk.run(st));
+  return MACX_OK;
+}
+
+int macx_h2_gemm_planes(const float* hA, int B, int N, int K, const float* Wh, int n_out, const float* bias, int act, float* hO,
+                        void* stream) {
+  if (!hA || !Wh || !bias || !hO || B < 1 || N < 1 || N > K_MAXN || K < 128 || K % 128 || n_out < 128 || n_out % 128)
+    return MACX_EINVAL;
+  GemmH2P g;
+  memset(&g, 0, sizeof(g));
+  g.B = B; g.N = N; g.K = K; g.Nout = n_out;
+  g.A = h2_view(hA, B * N, K);
+  g.Wh = reinterpret_cast<const char*>(Wh); g.w_exp = reinterpret_cast<const int*>(Wh) + (size_t)K * n_out;
+  g.out = h2_view(hO, B * N, n_out); g.bias = bias; g.act = act; g.e_inv_keep = 1.0f;
+  g.dbg = kb_gemm_dbg();
+  CK((kb_gemm_h2_launch<B_PLAIN, E_BIAS_ACT, false>(g, (hipStream_t)stream)));
+  return MACX_OK;
+}
+
 int macx_h2_gemm(const float* A, int B, int N, int K, const float* Wm, int n_out, const float* bias, int act, float* out,
                  float* ws, size_t ws_floats, void* stream) {
   if (!A || !Wm || !bias || !out || !ws || B < 1 || N < 1 || N > K_MAXN || K < 128 || K % 128 || n_out < 128 || n_out % 128)
@@ -1856,26 +1883,10 @@ int macx_h2_gemm(const float* A, int B, int N, int K, const float* Wm, int n_out
   const size_t fa = al4(h2_floats((size_t)B * N, K)), fo = al4(h2_floats((size_t)B * N, n_out));
   const size_t fw = al4((size_t)K * n_out + 4);
   if (ws_floats < fa + fo + fw + 8) return MACX_ESMALL;
-  hipStream_t st = (hipStream_t)stream;
-  float* hA = ws; float* hO = ws + fa; float* wp = hO + fo; float* wmax = wp + fw;
-  const char* dbg_stage = getenv("MACX_H2_DEBUG_STAGE");
-  const int stage = dbg_stage ? atoi(dbg_stage) : 99;
+  float* hA = ws; float* hO = ws + fa; float* wp = hO + fo;
   CKI(macx_h2_from_f32(A, B, N, K, hA, stream));
-  if (stage <= 1) return MACX_OK;
-  CK(absmax4(Wm, (size_t)K * n_out, Wm, 1, Wm, 1, Wm, 1, wmax, st));
-  if (stage <= 2) return MACX_OK;
-  Packer pk;
-  pk.add(Wm, n_out, 1, K, n_out, wp, -1, -1, 3, wmax);
-  CK(pk.run(st));
-  if (stage <= 3) return MACX_OK;
-  GemmH2P g;
-  memset(&g, 0, sizeof(g));
-  g.B = B; g.N = N; g.K = K; g.Nout = n_out;
-  g.A = h2_view(hA, B * N, K);
-  g.Wh = reinterpret_cast<const char*>(wp); g.w_exp = reinterpret_cast<const int*>(wp) + (size_t)K * n_out;
-  g.out = h2_view(hO, B * N, n_out); g.bias = bias; g.act = act; g.e_inv_keep = 1.0f;
-  CK((kb_gemm_h2_launch<B_PLAIN, E_BIAS_ACT, false>(g, st)));
-  if (stage <= 4) return MACX_OK;
+  CKI(macx_h2_pack_weight(Wm, K, n_out, 0, wp, stream));
+  CKI(macx_h2_gemm_planes(hA, B, N, K, wp, n_out, bias, act, hO, stream));
   return macx_h2_to_f32(hO, B * N, n_out, out, stream);
 }
 

@@ -168,9 +168,21 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// weight-gradient contraction over H2 operands.  Reduction row m lives in tensor m / rows_per_tensor of a sequence of
-// H2 tensors `*_stride` bytes apart (the per-step activations kept by the forward / backward pass); A may instead be ONE
-// tensor reused by every step (a_mod = its rows: the undropped knowledge base).
+// weight-gradient contraction over H2 operands.  Reduction row m lives in tensor m / R of a sequence of H2 tensors
+// `*_stride` bytes apart (the per-step activations kept by the forward / backward pass); A may instead be ONE tensor reused
+// by every step (a_mod = its rows: the undropped knowledge base).
+//
+// The contraction reduces over ROWS while an H2 slot holds 8 consecutive COLUMNS of one row, so the operands need a
+// transpose on the way to the MFMA fragments.  It is done by the LDS: the producer waves copy slots exactly as they lie in
+// memory -- lanes along rows, a wave-instruction moves two contiguous 512-byte runs -- into a row-major [32 rows][columns]
+// fp16 image per operand and plane, scaling each row to the tensor family's common exponent with v_pk_mul_f16 by an exact
+// power of two on the way (rows far below the largest lose low bits exactly as their share of the sum warrants), and the
+// consumer waves read their fragments with ds_read_b64_tr_b16, the gfx950 transpose read: within 16 lanes, lane t passes
+// the address of chunk (row t/4, columns 4(t%4)..+3) and receives column t of the four rows -- four consecutive reduction
+// rows of one output row/column, i.e. half an MFMA fragment.  No vector-ALU transpose, no strided global access.
+//   workgroup: 128 x (128 JW) output tile, 8 waves: 0-3 produce, 4-7 consume (wave tile 64 x 64 JW); 32 reduction rows per
+//   stage, three LDS stages, loads two stages ahead in registers, one barrier per stage.
+// Determinism as in macx_gemm_tn.cuh: a workgroup owns one (split, tile) slab, slabs are summed in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------
 struct TnH2P {
   int M;                 // reduction rows over all tensors
@@ -179,26 +191,37 @@ struct TnH2P {
   int R;                 // rows per H2 tensor
   const char* A; size_t a_stride; int a_mod;     // a_mod > 0: A row of reduction row m is m % a_mod of tensor 0
   const char* G; size_t g_stride;
-  const int* ecomA;      // [Kd/128] common exponents (h2_min_exp_kernel)
+  const int* ecomA;      // [Kd/128] common exponents (qmin_reduce)
   const int* ecomG;      // [Jd/128]
   float* part;           // [nsplit][Kd][Jd]
 };
 
-constexpr int WH_GS = 128 * 16 + 32;        // bytes between m-groups of a plane (A operand, 128 columns)
-constexpr int WH_APL = 4 * WH_GS;
-constexpr int WH_AOP = 2 * WH_APL;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// half an MFMA fragment: 4 consecutive reduction rows of column (lane & 15), see the header comment
+__device__ __forceinline__ u32x2 tr_read(const char* lds_addr) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_addr);
+  return __builtin_bit_cast(u32x2, v);
+}
 
-template <int JW>
-constexpr int wh_stage_bytes() { return WH_AOP + 2 * 4 * (JW * 128 * 16 + 32); }
+// LDS image of one operand plane and stage: sub-tiles of [16 reduction rows][16 columns] fp16 = 512 contiguous bytes, laid
+// out [column tile][row half].  One transpose read covers exactly one sub-tile with lane-linear 8-byte chunks -- the
+// conflict-free pattern of the instruction -- and gives lane (i, g) column i of rows 4g..4g+3; the two row halves make the
+// lane's 8-element fragment (reduction rows {4g+e} and {16+4g+e}: any assignment works as long as both operands share it).
+constexpr int WH_APL = 8 * 2 * 512;         // one plane of a 128-column image
+__device__ __forceinline__ int wh_slot_off(int kg, int r) {      // byte offset of slot (8-column group kg, stage row r) in a plane
+  return ((kg >> 1) * 2 + (r >> 4)) * 512 + (r & 15) * 32 + (kg & 1) * 16;
+}
+template <int JW> constexpr int wh_stage_bytes() { return 2 * WH_APL + 2 * JW * WH_APL; }
 
 template <int JW>
 __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
   constexpr int JT = JW * T_TILE;
-  constexpr int GG = JW * 128 * 16 + 32;
-  constexpr int GPL = 4 * GG;
-  constexpr int STAGE = WH_AOP + 2 * GPL;
+  constexpr int GPL = JW * WH_APL;
+  constexpr int STAGE = wh_stage_bytes<JW>();
+  constexpr int NCOL = 32 + 32 * JW;          // 32-row slot columns per stage: A (2 planes x 16) then G (2 planes x 16 JW)
+  constexpr int NLD = NCOL / 8;               // per producer lane
 
   const int ntj = p.Jd / JT;
   const int ntk = p.Kd / T_TILE;
@@ -215,12 +238,6 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
   const int nchunk = (m_end - m_begin + 31) >> 5;
-  const int nloop = (nchunk + 2) / 3 * 3;
-
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  using S2 = std::integral_constant<int, 2>;
-  typedef uint32_t gw_t __attribute__((ext_vector_type(JW)));      // a lane's 2 JW columns of one G row and plane
 
   const H2View a0{const_cast<char*>(p.A), p.R, p.Kd}, g0{const_cast<char*>(p.G), p.R, p.Jd};
   const size_t Rp = a0.Rp();
@@ -228,85 +245,94 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
   const int acb = a0.cb(), gcb = g0.cb();
 
   if (wave < 4) {
-    // ================= producer waves: H2 slots -> common exponent -> in-register transpose -> LDS planes =================
-    const int mg = wave;
-    // this lane's 2 (A) / 2 JW (G) columns: slot column and byte offset inside the slot
-    const size_t a_lane = ((size_t)(tk * 16 + (lane >> 2)) * Rp) * 16 + (lane & 3) * 4;
-    const int gcol = tj * JT + 2 * JW * lane;
-    const size_t g_lane = ((size_t)(gcol >> 3) * Rp) * 16 + (gcol & 7) * 2;
-    const int gblk = gcol >> 7;                                     // 128-column block of this lane's G columns
-    const int eA = p.ecomA[tk], eG = p.ecomG[gblk];
-    uint32_t ra[3][2][8];
-    gw_t rg[3][2][8];
-    uint32_t fa[3][8], fg[3][8];                                    // per-row factors {f, f} (0 for rows past the end)
+    // ================= producer waves: slots as they lie in memory -> common exponent -> row-major LDS image =================
+    const int r = tid & 31;                    // this lane's row of every stage
+    const int c0 = tid >> 5;                   // its slot columns are c0 + 8 i
+    const int eA = p.ecomA[tk];
+    int eG[JW];
+#pragma unroll
+    for (int q = 0; q < JW; ++q) eG[q] = p.ecomG[tj * JW + q];
+    u32x4 rv[3][NLD];
+    int ea_r[3], eg_r[3][JW];      // raw row exponents (-128: row past the end); turned into factors when the stage is stored,
+                                   // so that issuing a stage's loads never waits for them
     auto load = [&](auto slot_c, int ch) __attribute__((always_inline)) {
       constexpr int SL = decltype(slot_c)::value;
+      const int m = m_begin + ch * 32 + r;
+      const bool ok = m < m_end;
+      const int mc = min(m, p.M - 1);
+      const int ti = mc / p.R, rr = mc - ti * p.R;
+      const int ar = p.a_mod ? (mc % p.a_mod) : rr;
+      const char* ab = p.A + (p.a_mod ? 0 : (size_t)ti * p.a_stride);
+      const char* gb = p.G + (size_t)ti * p.g_stride;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int m = m_begin + ch * 32 + mg * 8 + r;
-        const bool ok = m < m_end;
-        const int mc = min(m, p.M - 1);
-        const int ti = mc / p.R, rr = mc - ti * p.R;               // tensor of the sequence, row inside it (wave-uniform)
-        const int ar = p.a_mod ? (mc % p.a_mod) : rr;
-        const char* ab = p.A + (p.a_mod ? 0 : (size_t)ti * p.a_stride);
-        const char* gb = p.G + (size_t)ti * p.g_stride;
-        const char* as = ab + a_lane + (size_t)ar * 16;
-        const char* gs = gb + g_lane + (size_t)rr * 16;
-        ra[SL][0][r] = *reinterpret_cast<const uint32_t*>(as);
-        ra[SL][1][r] = *reinterpret_cast<const uint32_t*>(as + apb);
-        rg[SL][0][r] = *reinterpret_cast<const gw_t*>(gs);
-        rg[SL][1][r] = *reinterpret_cast<const gw_t*>(gs + gpb);
-        const int ea = (int)reinterpret_cast<const int8_t*>(ab + 2 * apb)[(size_t)ar * acb + tk];
-        const int eg = (int)reinterpret_cast<const int8_t*>(gb + 2 * gpb)[(size_t)rr * gcb + gblk];
-        fa[SL][r] = ok ? pk_pow2_f16(eA - ea) : 0u;
-        fg[SL][r] = ok ? pk_pow2_f16(eG - eg) : 0u;
+      for (int i = 0; i < NLD; ++i) {
+        const int c = c0 + 8 * i;              // compile-time operand per i: columns [0,32) are A, the rest G
+        if (8 * i < 32) {
+          const int pl = c >> 4, kg = c & 15;
+          rv[SL][i] = *reinterpret_cast<const u32x4*>(ab + pl * apb + ((size_t)(tk * 16 + kg) * Rp + ar) * 16);
+        } else {
+          const int cg = c - 32;
+          const int pl = cg / (16 * JW), kg = cg - pl * 16 * JW;
+          rv[SL][i] = *reinterpret_cast<const u32x4*>(gb + pl * gpb + ((size_t)(tj * 16 * JW + kg) * Rp + rr) * 16);
+        }
+      }
+      const int8_t* eap = reinterpret_cast<const int8_t*>(ab + 2 * apb) + (size_t)ar * acb + tk;
+      const int8_t* egp = reinterpret_cast<const int8_t*>(gb + 2 * gpb) + (size_t)rr * gcb + tj * JW;
+      ea_r[SL] = *eap;
+#pragma unroll
+      for (int q = 0; q < JW; ++q) eg_r[SL][q] = egp[q];
+      if (!ok) {
+        ea_r[SL] = 1000;
+#pragma unroll
+        for (int q = 0; q < JW; ++q) eg_r[SL][q] = 1000;
       }
     };
     auto store = [&](auto slot_c, int ch) __attribute__((always_inline)) {
       constexpr int SL = decltype(slot_c)::value;
-      char* dA = lds + (ch & 1) * STAGE + mg * WH_GS + (2 * lane) * 16;
-      char* dG = lds + (ch & 1) * STAGE + WH_AOP + mg * GG + (2 * JW * lane) * 16;
+      char* st = lds + (ch % 3) * STAGE;
+      const uint32_t fa_ = pk_pow2_f16(eA - ea_r[SL]);              // 1000 -> 0: a row past the end
+      uint32_t fg_[JW];
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        uint32_t w[8];
+      for (int q = 0; q < JW; ++q) fg_[q] = pk_pow2_f16(eG[q] - eg_r[SL][q]);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) w[r] = fa[SL][r] ? pk_mul_f16(ra[SL][pl][r], fa[SL][r]) : 0u;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const uint32_t sel = c ? 0x07060302u : 0x05040100u;
-          u32x4 s;
-#pragma unroll
-          for (int h = 0; h < 4; ++h) s[h] = __builtin_amdgcn_perm(w[2 * h + 1], w[2 * h], sel);
-          *reinterpret_cast<u32x4*>(dA + pl * WH_APL + c * 16) = s;
+      for (int i = 0; i < NLD; ++i) {
+        const int c = c0 + 8 * i;
+        u32x4 w = rv[SL][i];
+        uint32_t f;
+        char* d;
+        if (8 * i < 32) {
+          const int pl = c >> 4, kg = c & 15;
+          f = fa_;
+          d = st + pl * WH_APL + wh_slot_off(kg, r);
+        } else {
+          const int cg = c - 32;
+          const int pl = cg / (16 * JW), kg = cg - pl * 16 * JW;
+          f = fg_[JW == 1 ? 0 : (kg >> 4)];
+          d = st + 2 * WH_APL + pl * GPL + wh_slot_off(kg, r);
         }
 #pragma unroll
-        for (int q = 0; q < JW; ++q) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) w[r] = fg[SL][r] ? pk_mul_f16(rg[SL][pl][r][q], fg[SL][r]) : 0u;
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const uint32_t sel = c ? 0x07060302u : 0x05040100u;
-            u32x4 s;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) s[h] = __builtin_amdgcn_perm(w[2 * h + 1], w[2 * h], sel);
-            *reinterpret_cast<u32x4*>(dG + pl * GPL + (2 * q + c) * 16) = s;
-          }
-        }
+        for (int h = 0; h < 4; ++h) w[h] = f ? pk_mul_f16(w[h], f) : 0u;      // f == 0: a row past the end (its slot may hold anything)
+        *reinterpret_cast<u32x4*>(d) = w;
       }
     };
-    load(S0{}, 0);
-    load(S1{}, 1);
-    load(S2{}, 2);
-    store(S0{}, 0);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    // LDS stage ch is written during iteration ch - 2 from registers loaded three iterations before that: three register
+    // sets keep the loads of three stages in flight (HBM latency under a full-chip stream is several stage times)
+    load(S0{}, 0); load(S1{}, 1);
+    store(S0{}, 0); store(S1{}, 1);
+    load(S2{}, 2); load(S0{}, 3); load(S1{}, 4);
     __syncthreads();
+    const int nloop = (nchunk + 2) / 3 * 3;     // whole groups of three iterations; stages past the end are zero rows
 #pragma unroll 1
     for (int ch = 0; ch < nloop; ch += 3) {
-      load(S0{}, ch + 3); store(S1{}, ch + 1); __syncthreads();
-      load(S1{}, ch + 4); store(S2{}, ch + 2); __syncthreads();
-      load(S2{}, ch + 5); store(S0{}, ch + 3); __syncthreads();
+      store(S2{}, ch + 2); load(S2{}, ch + 5); __syncthreads();
+      store(S0{}, ch + 3); load(S0{}, ch + 6); __syncthreads();
+      store(S1{}, ch + 4); load(S1{}, ch + 7); __syncthreads();
     }
   } else {
-    // ================= consumer waves: LDS fragments -> MFMA; wave tile 64 x (64 JW) =================
+    // ================= consumer waves: transpose-read fragments -> MFMA; wave tile 64 x (64 JW) =================
     const int cw = wave - 4;
     const int wr = cw >> 1, wc = cw & 1;
     constexpr int NC = 4 * JW;
@@ -315,20 +341,24 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto frag = [&](const char* tile) __attribute__((always_inline)) {       // the two row halves of one column tile
+      const u32x2 lo = tr_read(tile + lane * 8), hi = tr_read(tile + 512 + lane * 8);
+      return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
     auto compute = [&](int buf) __attribute__((always_inline)) {
-      const char* sa = lds + buf * STAGE + (lane >> 4) * WH_GS + (wr * 64 + (lane & 15)) * 16;
-      const char* sg = lds + buf * STAGE + WH_AOP + (lane >> 4) * GG + (wc * 64 * JW + (lane & 15)) * 16;
+      const char* sa = lds + buf * STAGE + (wr * 4) * 1024;
+      const char* sg = lds + buf * STAGE + 2 * WH_APL + (wc * 4 * JW) * 1024;
       u32x4 af[2][4];
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) af[pl][t] = *reinterpret_cast<const u32x4*>(sa + pl * WH_APL + t * 256);
+        for (int t = 0; t < 4; ++t) af[pl][t] = frag(sa + pl * WH_APL + t * 1024);
       // smallest terms first: G_lo x A_hi ; G_hi x {A_lo, A_hi}
 #pragma unroll
       for (int bp = 1; bp >= 0; --bp) {
         u32x4 gf[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) gf[c] = *reinterpret_cast<const u32x4*>(sg + bp * GPL + c * 256);
+        for (int c = 0; c < NC; ++c) gf[c] = frag(sg + bp * GPL + c * 1024);
 #pragma unroll
         for (int ap = 1 - bp; ap >= 0; --ap)
 #pragma unroll
@@ -338,9 +368,10 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
       }
     };
     __syncthreads();
+    const int nloop = (nchunk + 2) / 3 * 3;     // as the producers: the extra stages multiply zero rows
 #pragma unroll 1
     for (int ch = 0; ch < nloop; ++ch) {
-      compute(ch & 1);
+      compute(ch % 3);
       __syncthreads();
     }
     // a consumer wave's 64 JW columns lie inside one 128-column block of G
@@ -364,7 +395,7 @@ inline int wgrad_h2_jw(int Jd) { return (Jd % 256 == 0) ? 2 : 1; }
 template <int JW>
 inline hipError_t wgrad_h2_launch_t(const TnH2P& p, hipStream_t st) {
   auto kern = wgrad_h2_kernel<JW>;
-  constexpr size_t lds = 2 * wh_stage_bytes<JW>();
+  constexpr size_t lds = 3 * wh_stage_bytes<JW>();
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   const int grid = (p.Kd / T_TILE) * (p.Jd / (JW * T_TILE)) * p.nsplit;
@@ -377,9 +408,12 @@ inline hipError_t wgrad_h2_launch(const TnH2P& p, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Per-question interaction gradient  S_b = X_b^T dI1_b  over H2 operands (see sb_wgrad_kernel in macx_gemm_tn.cuh for what
-// S_b is for):  dW1a += diag(y_b) S_b,  dW1b += S_b,  dy[b][k] = sum_j W1a[k][j] S_b[k][j].  4 waves, one per SIMD, each
-// stages and multiplies; the rows of a question are brought to the question's own common exponents (qmin arrays, written by
-// the kernels that produced X and dI1).
+// S_b is for):  dW1a += diag(y_b) S_b,  dW1b += S_b,  dy[b][k] = sum_j W1a[k][j] S_b[k][j].  Same staging as
+// wgrad_h2_kernel (slots copied as they lie, rows scaled to the QUESTION's common exponents -- the qmin arrays written by
+// the kernels that produced X and dI1 -- fragments by transpose reads); 12 waves: 0-3 produce, 4-11 consume one 64 x 32
+// eighth of the 128 x 128 tile each with its three accumulator sets (3 waves per SIMD: 168 registers each); a stage never
+// crosses a question boundary (the last stage of a question is zero-filled past its end), so the fold of S_b happens
+// between stages.
 // ---------------------------------------------------------------------------------------------------------------
 struct SbH2P {
   int B, N, d;
@@ -392,12 +426,15 @@ struct SbH2P {
   const float* W1a;        // [d][d] row-major (k, j)
   float* dW1a_part;        // [ngroup][d][d]
   float* dW1b_part;
-  float* dy_part;          // [2*d/128][B][d]
+  float* dy_part;          // [4*d/128][B][d]
 };
 
-constexpr int SBH_STAGE = 2 * WH_AOP;
+constexpr int SBH_STAGE = 4 * WH_APL;
+constexpr int SBH_CW = 4;                  // consumer waves (see sb_h2_kernel); dy_part holds SBH_CW / 2 partials per 128 columns      // X hi, X lo, dI1 hi, dI1 lo images of 32 rows x 128 columns
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sb_h2_kernel(SbH2P p) {
+// CW consumer waves: 8 (64 x 32 each, 12-wave workgroup, 168 registers) or 4 (64 x 64 each, 8-wave workgroup, 256 registers)
+template <int CW>
+__global__ __launch_bounds__(256 + 64 * CW) void sb_h2_kernel(SbH2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
 
@@ -412,167 +449,187 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int mg = wave;
-
-  f32x4 accS[4][4], accA[4][4], accB[4][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) accS[t][c] = accA[t][c] = accB[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = (p.N + 31) >> 5;
   const int b_begin = group * p.qpg;
   const int b_end = min(p.B, b_begin + p.qpg);
-  const int nq = b_end - b_begin;
-  const int total = nq * nchunk;
-
+  const int total = (b_end - b_begin) * nchunk;         // stages of this workgroup, over all its questions
   const size_t Rp = p.X.Rp();
   const size_t xpb = p.X.plane_bytes(), gpb = p.dI1.plane_bytes();
   const int xcb = p.X.cb(), gcb = p.dI1.cb();
-  const int8_t* xe = p.X.exps();
-  const int8_t* ge = p.dI1.exps();
-  const size_t x_lane = ((size_t)(tk * 16 + (lane >> 2)) * Rp) * 16 + (lane & 3) * 4;
-  const size_t g_lane = ((size_t)(tj * 16 + (lane >> 2)) * Rp) * 16 + (lane & 3) * 4;
 
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  uint32_t ra[2][2][8], rg[2][2][8];
-  int e_row[2][8];                                      // (exponent of the X row) | (exponent of the dI1 row) << 8, both int8
-  auto load = [&](auto slot_c, int s_raw) __attribute__((always_inline)) {
-    constexpr int SL = decltype(slot_c)::value;
-    const int s = min(s_raw, total - 1);
-    const int qi = s / nchunk, ch = s - qi * nchunk;
-    const size_t r0 = (size_t)(b_begin + qi) * p.N;
+  if (wave < 4) {
+    // ---- producers: 64 slot columns per stage (X: 2 planes x 16, dI1: 2 planes x 16), 8 per lane
+    const int r = tid & 31, c0 = tid >> 5;
+    u32x4 rv[2][8];
+    int ex_r[2], eg_r[2], qx_r[2], qg_r[2];     // raw exponents; factors are formed when the stage is stored
+    auto load = [&](auto slot_c, int s_raw) __attribute__((always_inline)) {
+      constexpr int SL = decltype(slot_c)::value;
+      const int s = min(s_raw, total - 1);
+      const int qi = s / nchunk, ch = s - qi * nchunk;
+      const int b = b_begin + qi;
+      const int n = ch * 32 + r;
+      const bool ok = (s_raw < total) && n < p.N;
+      const size_t row = (size_t)b * p.N + min(n, p.N - 1);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int n = min(ch * 32 + mg * 8 + r, p.N - 1);
-      const char* xs = p.X.plane(0) + x_lane + (r0 + n) * 16;
-      const char* gs = p.dI1.plane(0) + g_lane + (r0 + n) * 16;
-      ra[SL][0][r] = *reinterpret_cast<const uint32_t*>(xs);
-      ra[SL][1][r] = *reinterpret_cast<const uint32_t*>(xs + xpb);
-      rg[SL][0][r] = *reinterpret_cast<const uint32_t*>(gs);
-      rg[SL][1][r] = *reinterpret_cast<const uint32_t*>(gs + gpb);
-      e_row[SL][r] = ((int)xe[(r0 + n) * xcb + tk] & 0xFF) | (((int)ge[(r0 + n) * gcb + tj] & 0xFF) << 8);
-    }
-  };
-  auto store = [&](auto slot_c, int s_raw) __attribute__((always_inline)) {
-    constexpr int SL = decltype(slot_c)::value;
-    const int s = min(s_raw, total - 1);
-    const int qi = s / nchunk, ch = s - qi * nchunk;
-    const int nrow = ch * 32 + mg * 8;
-    const int eX = p.qminX[(size_t)(b_begin + qi) * xcb + tk], eG = p.qminG[(size_t)(b_begin + qi) * gcb + tj];
-    char* dst = lds + (s_raw & 1) * SBH_STAGE + mg * WH_GS + (2 * lane) * 16;
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        uint32_t w[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int er = o ? (int)(int8_t)(e_row[SL][r] >> 8) : (int)(int8_t)e_row[SL][r];
-          const uint32_t f = pk_pow2_f16((o ? eG : eX) - er);
-          w[r] = (nrow + r < p.N) ? pk_mul_f16(o ? rg[SL][pl][r] : ra[SL][pl][r], f) : 0u;
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const uint32_t sel = c ? 0x07060302u : 0x05040100u;
-          u32x4 sl;
-#pragma unroll
-          for (int h = 0; h < 4; ++h) sl[h] = __builtin_amdgcn_perm(w[2 * h + 1], w[2 * h], sel);
-          *reinterpret_cast<u32x4*>(dst + o * WH_AOP + pl * WH_APL + c * 16) = sl;
-        }
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + 8 * i;
+        const int pl = (c >> 4) & 1, kg = c & 15;
+        rv[SL][i] = (i < 4) ? *reinterpret_cast<const u32x4*>(p.X.plane(0) + pl * xpb + ((size_t)(tk * 16 + kg) * Rp + row) * 16)
+                            : *reinterpret_cast<const u32x4*>(p.dI1.plane(0) + pl * gpb + ((size_t)(tj * 16 + kg) * Rp + row) * 16);
       }
-  };
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const char* sa = lds + buf * SBH_STAGE + (lane >> 4) * WH_GS + (wr * 64 + (lane & 15)) * 16;
-    const char* sg = lds + buf * SBH_STAGE + WH_AOP + (lane >> 4) * WH_GS + (wc * 64 + (lane & 15)) * 16;
-    u32x4 gf[2][4];
+      ex_r[SL] = p.X.exps()[row * xcb + tk];
+      eg_r[SL] = p.dI1.exps()[row * gcb + tj];
+      qx_r[SL] = p.qminX[(size_t)b * xcb + tk];
+      qg_r[SL] = p.qminG[(size_t)b * gcb + tj];
+      if (!ok) { ex_r[SL] = 1000; eg_r[SL] = 1000; }
+    };
+    auto store = [&](auto slot_c, int s_raw) __attribute__((always_inline)) {
+      constexpr int SL = decltype(slot_c)::value;
+      char* st = lds + (s_raw % 3) * SBH_STAGE;
+      const uint32_t fx_ = pk_pow2_f16(qx_r[SL] - ex_r[SL]), fg_ = pk_pow2_f16(qg_r[SL] - eg_r[SL]);     // 1000 -> 0: row past the end
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + 8 * i;
+        const int kg = c & 15;
+        const uint32_t f = (i < 4) ? fx_ : fg_;
+        u32x4 w = rv[SL][i];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) gf[pl][c] = *reinterpret_cast<const u32x4*>(sg + pl * WH_APL + c * 256);
-#pragma unroll
-    for (int ap = 1; ap >= 0; --ap) {
-      u32x4 af[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const u32x4*>(sa + ap * WH_APL + t * 256);
-#pragma unroll
-      for (int bp = 1 - ap; bp >= 0; --bp)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) accS[t][c] = mfma_f16(af[t], gf[bp][c], accS[t][c]);
+        for (int h = 0; h < 4; ++h) w[h] = f ? pk_mul_f16(w[h], f) : 0u;
+        *reinterpret_cast<u32x4*>(st + (c >> 4) * WH_APL + wh_slot_off(kg, r)) = w;
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    // LDS stage s is written during iteration s - 2 from registers loaded two iterations before that: two register sets keep
+    // the loads of two stages in flight (a third set does not fit the 168-register budget of this 12-wave workgroup, and a
+    // spilled set is worse than none: its scratch reloads drain the whole load queue)
+    if (total > 0) {
+      load(S0{}, 0); load(S1{}, 1);
+      store(S0{}, 0); store(S1{}, 1);
+      load(S0{}, 2); load(S1{}, 3);
+      __syncthreads();
+      const int nloop = (total + 1) / 2 * 2;
+#pragma unroll 1
+      for (int s = 0; s < nloop; s += 2) {
+        store(S0{}, s + 2); load(S0{}, s + 4); __syncthreads();
+        store(S1{}, s + 3); load(S1{}, s + 5); __syncthreads();
+      }
     }
-  };
-  // question finished: fold S_b (in units of its two common exponents) into the three outputs and clear it
-  auto consume = [&](int b) __attribute__((always_inline)) {
-    const float sc = h2_unscale(p.qminX[(size_t)b * xcb + tk], p.qminG[(size_t)b * gcb + tj]);
-    const float* yb = p.y + (size_t)b * p.d;
+  } else {
+    // ---- consumers
+    constexpr int NC = 16 / CW;                           // 16-column tiles per consumer wave
+    constexpr int WCN = CW / 2;                           // column groups of the tile
+    const int cw = wave - 4;
+    const int wr = cw / WCN, wc = cw % WCN;               // 64 rows (k) x 16 NC columns (j) of the tile
+    f32x4 accS[4][NC], accA[4][NC], accB[4][NC];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
-        const float yk = yb[k];
-        float dyp = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float sv = accS[t][c][e] * sc;
-          accB[t][c][e] += sv;
-          accA[t][c][e] = fmaf(yk, sv, accA[t][c][e]);
-          dyp = fmaf(p.W1a[(size_t)k * p.d + tj * T_TILE + wc * 64 + c * 16 + (lane & 15)], sv, dyp);   // L2-resident, once per question
-          accS[t][c][e] = 0.f;
-        }
-        dyp = sum16_h2(dyp);
-        if ((lane & 15) == 0) p.dy_part[((size_t)(tj * 2 + wc) * p.B + b) * p.d + k] = dyp;
-      }
-  };
-
-  if (total > 0) {
-    load(S0{}, 0);
-    load(S1{}, 1);
-    store(S0{}, 0);
-    __syncthreads();
-    int qch = 0, b = b_begin;
-    auto step = [&](auto mine, auto next, int s) __attribute__((always_inline)) {
-      load(mine, s + 2);
-      compute(s & 1);
-      store(next, s + 1);
-      if (++qch == nchunk) { consume(b); qch = 0; ++b; }
-      __syncthreads();
+      for (int c = 0; c < NC; ++c) accS[t][c] = accA[t][c] = accB[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto frag = [&](const char* tile) __attribute__((always_inline)) {
+      const u32x2 lo = tr_read(tile + lane * 8), hi = tr_read(tile + 512 + lane * 8);
+      return u32x4{lo[0], lo[1], hi[0], hi[1]};
     };
-    int s = 0;
-#pragma unroll 1
-    for (; s + 2 <= total; s += 2) {
-      step(S0{}, S1{}, s);
-      step(S1{}, S0{}, s + 1);
-    }
-    if (s < total) step(S0{}, S1{}, s);
-  }
-
-  float* oa = p.dW1a_part + (size_t)group * p.d * p.d;
-  float* ob = p.dW1b_part + (size_t)group * p.d * p.d;
+    // smallest terms first: X_lo x dI1_hi ; X_hi x {dI1_lo, dI1_hi}
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+      const char* sa = lds + buf * SBH_STAGE + (wr * 4) * 1024;
+      const char* sg = lds + buf * SBH_STAGE + 2 * WH_APL + (wc * NC) * 1024;
+      u32x4 gf[2][NC];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+      for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < NC; ++c) gf[pl][c] = frag(sg + pl * WH_APL + c * 1024);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
-        const int j = tj * T_TILE + wc * 64 + c * 16 + (lane & 15);
-        oa[(size_t)k * p.d + j] = accA[t][c][e];
-        ob[(size_t)k * p.d + j] = accB[t][c][e];
+      for (int ap = 1; ap >= 0; --ap) {
+        u32x4 af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = frag(sa + ap * WH_APL + t * 1024);
+#pragma unroll
+        for (int bp = 1 - ap; bp >= 0; --bp)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) accS[t][c] = mfma_f16(af[t], gf[bp][c], accS[t][c]);
       }
+    };
+    // question finished: fold S_b (in units of its two common exponents) into the three outputs and clear it.  The wave's
+    // 64 x 32 share of W1a and its 16 entries of y_b are requested together up front (the fragment registers are free here):
+    // 48 loads in flight once per question instead of 16 dependent round trips.
+    auto consume = [&](int b) __attribute__((always_inline)) {
+      const float sc = h2_unscale(p.qminX[(size_t)b * xcb + tk], p.qminG[(size_t)b * gcb + tj]);
+      // the addresses below are loop-invariant; laundering the row pitch keeps the compiler from hoisting all 48 of them out of
+      // the stage loop, where they would occupy (and spill) registers the whole time for a once-per-question use
+      int pitch = p.d;
+      asm volatile("" : "+s"(pitch));
+      const float* yb = p.y + (size_t)b * pitch + tk * T_TILE + wr * 64 + (lane >> 4) * 4;
+      const float* wb = p.W1a + (size_t)(tk * T_TILE + wr * 64 + (lane >> 4) * 4) * pitch + tj * T_TILE + wc * 16 * NC + (lane & 15);
+      float w1[4][4][NC];
+      f32x4 y4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        y4[t] = *reinterpret_cast<const f32x4*>(yb + t * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) w1[t][e][c] = wb[(size_t)(t * 16 + e) * pitch + c * 16];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
+          const float yk = y4[t][e];
+          float dyp = 0.f;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const float sv = accS[t][c][e] * sc;
+            accB[t][c][e] += sv;
+            accA[t][c][e] = fmaf(yk, sv, accA[t][c][e]);
+            dyp = fmaf(w1[t][e][c], sv, dyp);
+            accS[t][c][e] = 0.f;
+          }
+          dyp = sum16_h2(dyp);
+          if ((lane & 15) == 0) p.dy_part[((size_t)(tj * WCN + wc) * p.B + b) * pitch + k] = dyp;
+        }
+    };
+    if (total > 0) {
+      __syncthreads();
+      const int nloop = (total + 1) / 2 * 2;      // as the producers; the stages past the end hold zero rows
+      int qch = 0, b = b_begin;
+#pragma unroll 1
+      for (int s = 0; s < nloop; ++s) {
+        if (s < total) {
+          compute(s % 3);
+          if (++qch == nchunk) { consume(b); qch = 0; ++b; }
+        }
+        __syncthreads();
+      }
+    }
+    float* oa = p.dW1a_part + (size_t)group * p.d * p.d;
+    float* ob = p.dW1b_part + (size_t)group * p.d * p.d;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
+          const int j = tj * T_TILE + wc * 16 * NC + c * 16 + (lane & 15);
+          oa[(size_t)k * p.d + j] = accA[t][c][e];
+          ob[(size_t)k * p.d + j] = accB[t][c][e];
+        }
+  }
 }
 
 inline hipError_t sb_h2_launch(const SbH2P& p, hipStream_t st) {
-  constexpr size_t lds = 2 * SBH_STAGE;
-  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2_kernel), lds);
+  constexpr size_t lds = 3 * SBH_STAGE;
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2_kernel<SBH_CW>), lds);
   if (e != hipSuccess) return e;
   const int nt = p.d / T_TILE;
   const int ngroup = (p.B + p.qpg - 1) / p.qpg;
-  hipLaunchKernelGGL(sb_h2_kernel, dim3(nt * nt * ngroup), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(sb_h2_kernel<SBH_CW>, dim3(nt * nt * ngroup), dim3(256 + 64 * SBH_CW), lds, st, p);
   return hipGetLastError();
 }
 
