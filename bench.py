@@ -4,9 +4,10 @@
 A "step" is one pass of the hot path over one synthetic CLEVR-shaped batch: p = 12 applications of
 the MAC cell (control -> read -> write) forward in training mode (dropout keep .85/.85/1.0) plus the
 full backward (parameter, knowledge-base, question-word and question-vector gradients), through the
-C ABI of libmacx.so.  For N > 1 every rank runs the same per-GPU batch (weak scaling) on its own
-shard of a global batch of N*B questions and the flat gradient buffer is all-reduced over RCCL
-inside the timed step.
+C ABI of libmacx.so.  For N > 1 the metric's batch of 64 questions is split over the ranks by the
+reference's tower rule (strong scaling: the configuration BASELINE.json's metric names) and the flat
+gradient buffer is all-reduced over RCCL inside the timed step; the same line also carries the
+weak-scaling number (64 questions per GPU) and BASELINE configs[3] (128 per GPU, p = 16).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -38,6 +39,24 @@ def flops_per_question_step(n=N, s=S, d=D):
     return 2 * d * d * (4 * n + 5) + 6 * n * d + 5 * s * d
 
 
+def physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo; None if it cannot be read"""
+    try:
+        cores, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        return len(cores) or None
+    except Exception:
+        return None
+
+
 def cpu_baseline(seed, iters, sample_b, budget_s=25.0):
     """The op-for-op torch-CPU restatement of the reference graph (oracle/, kind = "port") timed on
     this host's cores over a bounded sample of the same workload."""
@@ -67,7 +86,8 @@ def cpu_baseline(seed, iters, sample_b, budget_s=25.0):
             v.grad = None
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(sample_b / med, 3), "unit": "questions/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(sample_b / med, 3), "unit": "questions/s", "cores": torch.get_num_threads(),
+            "host_logical_cpus": os.cpu_count(), "host_physical_cores": physical_cores(), "kind": "port",
             "sample": "%d x (B=%d, S=%d, N=%d, d=%d, p=%d) fwd+bwd, torch-CPU fp32 op-for-op restatement of the TF1 graph "
                       "(oracle/mac_oracle.py), median" % (len(times), sample_b, S, N, D, P)}
 
@@ -114,21 +134,66 @@ def model_level(macx, dev, seed, steps=6):
             "flops_per_question_fwd_bwd": 3 * (P * flops_per_question_step() + stem_flops)}
 
 
+def time_steps(step, steps, warmup, prime, barrier, world, dev, dist):
+    for i in range(prime + warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(prime + warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def make_step(macx, dev, dist, world, rank, global_batch, p, seed):
+    """One data-parallel step of the cell on `global_batch` questions split by the tower rule (model.py:139-149):
+    forward + backward on this rank's shard, then ONE all-reduce of the flat gradient buffer."""
+    lo, hi = macx.dp.tower_slice(global_batch, rank, world)
+    bl = hi - lo
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
+    vq, words, lengths, kb = macx.configs.synthetic_inputs(bl, S, N, D, seed=seed + rank)
+    params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(seed)).to(dev)
+    vqd, wd, kbd = [t.to(dev).requires_grad_(True) for t in (vq, words, kb)]
+    ld = lengths.to(dev)
+    gmem = (torch.randn(bl, D, generator=torch.Generator().manual_seed(1)) / global_batch).to(dev)
+    bucket = macx.dp.GradBucket(params.tensors(), flat=params.grad_buffer())
+
+    def step(i):
+        cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=ld,
+                            knowledgeBase=kbd, memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout,
+                            writeDropout=cfg.writeDropout, batchSize=bl, train=True, config=cfg, params=params,
+                            seed=seed + i, b0=lo)
+        state = cell.run()
+        for t in (vqd, wd, kbd):
+            t.grad = None
+        for t in params.tensors():
+            t.grad = None
+        torch.autograd.backward([state.memory], [gmem])
+        if world > 1:
+            bucket.allreduce_(bl, global_batch)
+
+    return step, params, kbd, bl
+
+
 def main():
-    global B
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-level", action="store_true")
-    ap.add_argument("--no-native", action="store_true", help="skip the native-f32-MFMA comparison leg")
+    ap.add_argument("--no-native", action="store_true", help="skip the comparison legs on the other two kernel families")
+    ap.add_argument("--no-extra-dp", action="store_true", help="N > 1: only the metric's (strong-scaling) configuration")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--p", type=int, default=P, help=argparse.SUPPRESS)
-    ap.add_argument("--per-gpu-batch", type=int, default=B, help=argparse.SUPPRESS)   # exploration only; the metric is B=64
+    ap.add_argument("--per-gpu-batch", type=int, default=0, help=argparse.SUPPRESS)   # exploration only; the metric is global B=64
     args = ap.parse_args()
-    B = args.per_gpu_batch
 
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +204,7 @@ def main():
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  MACX_BENCH_BACKEND=gloo lets two ranks share ONE GPU to exercise this path
@@ -150,36 +216,16 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import macx
+    L = macx._lib.lib()
     if os.environ.get("MACX_DBG"):          # tuning only: kb GEMM debug bits
-        macx._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
-    if os.environ.get("MACX_GEMM"):         # native | split (default): kernel family of the knowledge-base GEMMs
-        macx._lib.lib().macx_gemm_mode({"native": 0, "split": 1}[os.environ["MACX_GEMM"]])
+        L.macx_debug_set(1, int(os.environ["MACX_DBG"]))
+    if os.environ.get("MACX_GEMM"):         # native | split | h2 (default): kernel family of the read unit
+        L.macx_gemm_mode({"native": 0, "split": 1, "h2": 2}[os.environ["MACX_GEMM"]])
     if os.environ.get("MACX_FORCE_RT"):     # tuning only: row tiles per GEMM workgroup
-        macx._lib.lib().macx_debug_set(2, int(os.environ["MACX_FORCE_RT"]))
+        L.macx_debug_set(2, int(os.environ["MACX_FORCE_RT"]))
     p = args.p
-    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
     seed = 1234
-    b0 = rank * B                                                   # tower rule, equal shards (model.py:139-149)
-    vq, words, lengths, kb = macx.configs.synthetic_inputs(B, S, N, D, seed=seed + rank)
-    params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(seed)).to(dev)
-    vqd, wd, kbd = [t.to(dev).requires_grad_(True) for t in (vq, words, kb)]
-    ld = lengths.to(dev)
-    gmem = (torch.randn(B, D, generator=torch.Generator().manual_seed(1)) / B).to(dev)
-    bucket = macx.dp.GradBucket(params.tensors())
-
-    def step(i):
-        cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=ld,
-                            knowledgeBase=kbd, memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout,
-                            writeDropout=cfg.writeDropout, batchSize=B, train=True, config=cfg, params=params,
-                            seed=seed + i, b0=b0)
-        state = cell.run()
-        for t in (vqd, wd, kbd):
-            t.grad = None
-        for t in params.tensors():
-            t.grad = None
-        torch.autograd.backward([state.memory], [gmem])
-        if world > 1:
-            bucket.allreduce_(B, B * world)
+    global_batch = args.per_gpu_batch * world if args.per_gpu_batch else B      # the metric: 64 questions in all
 
     def barrier():
         if world > 1:
@@ -189,104 +235,147 @@ def main():
     # untimed priming before the W requested warmup steps: the caching allocator settles on the saved/ws block sizes in the
     # first two, the rest (~0.1 s of work) lets the clocks of an idle GPU ramp before anything is timed
     PRIME = 16
-    for i in range(PRIME + args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(PRIME + args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    step, params, kbd, bl = make_step(macx, dev, dist, world, rank, global_batch, p, seed)
+    dt = time_steps(step, args.steps, args.warmup, PRIME, barrier, world, dev, dist)
     ms_per_step = dt / args.steps * 1e3
-    qps = B * world * args.steps / dt
+    qps = global_batch * args.steps / dt
+    F = flops_per_question_step()
 
-    out = None
+    extra = {}
+    if world > 1 and not args.no_extra_dp:
+        # the same line carries the weak-scaling reading (64 questions per GPU) and BASELINE configs[3] (128 per GPU, p = 16)
+        for key, gb, pp in (("weak_scaling_b64_per_gpu", B * world, p), ("config3_dp_b128_per_gpu_p16", 128 * world, 16)):
+            st2, _, _, _ = make_step(macx, dev, dist, world, rank, gb, pp, seed)
+            d2 = time_steps(st2, max(5, args.steps // 2), 2, 3, barrier, world, dev, dist)
+            n2 = max(5, args.steps // 2)
+            extra[key] = {"value": round(gb * n2 / d2, 2), "unit": "questions/s", "global_batch": gb, "p": pp,
+                          "ms_per_step": round(d2 / n2 * 1e3, 3), "steps": n2, "scaling": "weak"}
+            del st2
+            torch.cuda.empty_cache()
+
     if rank == 0:
-        F = flops_per_question_step()
-        # ---- roofline of the dominant kernel: the knowledge-base GEMM (kb_gemm_kernel, fp32 MFMA).
-        # algorithmic FLOPs per launch = 2 * (B*N) * d * d ; duration from HIP events on the stream the
-        # kernel is launched on (torch's current stream is handed to the C ABI).
-        L = macx._lib.lib()
-        sh = macx._lib.MacxShapes(B=B, S=S, N=N, d=D, p=p, b0=0)
-        dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=seed)   # the GEMM alone (dropout is a separate pass)
-        wp = torch.empty(2 * D * D, device=dev)
-        bits = torch.empty(B * N * D + B * N * D // 32, device=dev)
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        macx._lib.check(L.macx_pack_weight(ptr(params.projX_W.detach()), D, D, macx._lib.kb_pack_flags(), ptr(wp), st), "pack")
-        # As in the step, every launch reads a different [B,N,d] input and writes a different output (there the twelve
-        # dropped copies of the KB and twelve X buffers): NBUF rotating pairs, 2 x NBUF x 25.7 MB > the 256 MB Infinity Cache,
-        # so the timing is HBM-fed like the in-step launches the rocprof summary averages over.
+        mode = L.macx_gemm_mode(-1)
+        st = None
+        # ---- roofline of the dominant kernel: the knowledge-base GEMM X = KBd Wx + bx (6 of the 9 GEMM-class launches per
+        # cell step share its main loop).  Algorithmic FLOPs per launch = 2 (B N) d d; duration from HIP events on the stream
+        # the kernel is launched on (torch's current stream is what the C ABI receives), averaged over 32 launches that each
+        # read a different input and write a different output (8 rotating pairs, 2 x 8 x 25.7 MB > the 256 MB Infinity
+        # Cache share that matters), as the in-step launches do.
+        Bp = bl
         NBUF = 8
-        kbs = [kbd.detach().clone() for _ in range(NBUF)]
-        xos = [torch.empty(B, N, D, device=dev) for _ in range(NBUF)]
         bx = params.projX_b.detach()
-        for i in range(NBUF):
-            L.macx_kb_project(C.byref(sh), C.byref(dp), 0, ptr(kbs[i]), ptr(wp), ptr(bx), ptr(xos[i]), ptr(bits), st)
+        k_flops = 2.0 * Bp * N * D * D
         nrep = 32
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(nrep):
-            L.macx_kb_project(C.byref(sh), C.byref(dp), 0, ptr(kbs[i % NBUF]), ptr(wp), ptr(bx), ptr(xos[i % NBUF]), ptr(bits), st)
-        e1.record()
-        torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / nrep
-        del kbs, xos
-        k_flops = 2.0 * B * N * D * D
-        achieved = k_flops / (k_ms * 1e-3)
-        traffic = None
-        try:   # HBM bytes per launch of this kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE)
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))["hbm_bytes_per_launch"]
+        if mode == 2:
+            hf = L.macx_h2_floats(Bp * N, D)
+            wh = torch.empty(D * D + 64, device=dev)
+            macx._lib.check(L.macx_h2_pack_weight(ptr(params.projX_W.detach()), D, D, 0, ptr(wh), st), "pack")
+            hin = [torch.empty(hf, device=dev) for _ in range(NBUF)]
+            hout = [torch.empty(hf, device=dev) for _ in range(NBUF)]
+            src = [(kbd.detach() * (1.0 + 0.01 * i)).contiguous() for i in range(NBUF)]
+            for i in range(NBUF):
+                macx._lib.check(L.macx_h2_from_f32(ptr(src[i]), Bp, N, D, ptr(hin[i]), st), "from")
+                macx._lib.check(L.macx_h2_gemm_planes(ptr(hin[i]), Bp, N, D, ptr(wh), D, ptr(bx), 0, ptr(hout[i]), st), "gemm")
+            e0.record()
+            for i in range(nrep):
+                L.macx_h2_gemm_planes(ptr(hin[i % NBUF]), Bp, N, D, ptr(wh), D, ptr(bx), 0, ptr(hout[i % NBUF]), st)
+            e1.record()
+            torch.cuda.synchronize()
+            k_ms = e0.elapsed_time(e1) / nrep
+            # an HBM-bound kernel of the same step, timed the same way: fp32 knowledge base -> H2 (read 4 B, write 4 B per element)
+            e0.record()
+            for i in range(nrep):
+                L.macx_h2_from_f32(ptr(src[i % NBUF]), Bp, N, D, ptr(hin[i % NBUF]), st)
+            e1.record()
+            torch.cuda.synchronize()
+            c_ms = e0.elapsed_time(e1) / nrep
+            del hin, hout, src
+            kname = ("kb_gemm_h2_kernel<13,B_PLAIN,E_BIAS_ACT,false> (X = KBd Wx + bx; operands as two fp16 planes with per-(row,128-col) "
+                     "exponents, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)")
+            terms, pipe = 3, "fp16 (v_mfma_f32_16x16x32_f16)"
+        else:
+            sh = macx._lib.MacxShapes(B=Bp, S=S, N=N, d=D, p=p, b0=0)
+            dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=seed)
+            wp = torch.empty(2 * D * D, device=dev)
+            macx._lib.check(L.macx_pack_weight(ptr(params.projX_W.detach()), D, D, macx._lib.kb_pack_flags(), ptr(wp), st), "pack")
+            kbs = [kbd.detach().clone() for _ in range(NBUF)]
+            xos = [torch.empty(Bp, N, D, device=dev) for _ in range(NBUF)]
+            for i in range(NBUF):
+                L.macx_kb_project(C.byref(sh), C.byref(dp), 0, ptr(kbs[i]), ptr(wp), ptr(bx), ptr(xos[i]), None, st)
+            e0.record()
+            for i in range(nrep):
+                L.macx_kb_project(C.byref(sh), C.byref(dp), 0, ptr(kbs[i % NBUF]), ptr(wp), ptr(bx), ptr(xos[i % NBUF]), None, st)
+            e1.record()
+            torch.cuda.synchronize()
+            k_ms = e0.elapsed_time(e1) / nrep
+            c_ms = None
+            del kbs, xos
+            kname = ("kb_gemm6_kernel<13,A_PLAIN,B_PLAIN,E_BIAS_ACT,false> (3 x bf16 split, 6 MFMA terms)" if mode == 1 else
+                     "kb_gemm_kernel<13,8,A_PLAIN,B_PLAIN,E_BIAS_ACT,false> (v_mfma_f32_16x16x4_f32)")
+            terms, pipe = (6, "bf16 (v_mfma_f32_16x16x32_bf16)") if mode == 1 else (1, "f32 (v_mfma_f32_16x16x4_f32)")
+        alg = k_flops / (k_ms * 1e-3)
+        peak = PEAK_BF16_MFMA if mode else PEAK_FP32_MFMA
+        prof = {}
+        try:   # per-launch HBM bytes (PMC) and in-step kernel averages (rocprofv3 --kernel-trace), written by tools/profile_round.sh
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline_inputs.json")))
         except Exception:
             pass
-        split = bool(L.macx_gemm_mode(-1))
-        if split:
-            kname = ("kb_gemm6_kernel<13,A_PLAIN,B_PLAIN,E_BIAS_ACT,false> (X = KBd Wx + bx on the bf16 matrix pipe: exact 3-way bf16 "
-                     "operand split, 6 MFMA terms, fp32 accumulate; 6 of the 9 GEMM-class launches per cell step share this main loop)")
-        else:
-            kname = "kb_gemm_kernel<13,8,A_PLAIN,B_PLAIN,E_BIAS_ACT,false> (X = KBd Wx + bx, v_mfma_f32_16x16x4_f32)"
         roofline = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(achieved / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
-                    "kernel_ms": round(k_ms, 4), "flops_per_launch": k_flops,
-                    "whole_step_frac": round(qps / world * 3 * p * F / PEAK_FP32_MFMA, 4),
-                    "note": "achieved = algorithmic fp32 FLOPs / time; peak = the f32-input MFMA peak (the metric's dtype)"}
-        if split:
-            # the instructions actually issued: 6 bf16 MFMA terms per algorithmic multiply-add, priced against the bf16 pipe
-            roofline["pipe"] = {"dtype": "bf16 (v_mfma_f32_16x16x32_bf16)", "executed": round(6 * achieved / 1e12, 1),
-                                "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(6 * achieved / PEAK_BF16_MFMA, 4)}
+                    # achieved = the FLOPs the matrix pipe EXECUTES for this launch (terms x the algorithmic 2 (B N) d^2) per second,
+                    # priced against the dense peak of the pipe they execute on
+                    "achieved": round(terms * alg / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                    "frac": round(terms * alg / peak, 4), "pipe": pipe, "mfma_terms_per_product": terms,
+                    "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": k_flops,
+                    "algorithmic_tflops": round(alg / 1e12, 2),
+                    "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("source"),
+                    "algorithmic_bytes_per_launch": 2 * Bp * N * D * 4 + D * D * 4,
+                    "in_step_kernel_ms": prof.get("in_step_kernel_ms"),
+                    # the whole step priced by the REFERENCE's op count (3 p F per question) against the f32-input MFMA
+                    # peak, the arithmetic the metric is stated in
+                    "whole_step_fp32_equiv_frac": round(qps / world * 3 * p * F / PEAK_FP32_MFMA, 4)}
+        hbm = []
+        if c_ms:
+            byt = 2.0 * Bp * N * D * 4
+            hbm.append({"kernel": "h2_from_f32_kernel (fp32 knowledge base -> H2 through the read-dropout site)", "bound": "hbm",
+                        "bytes_per_launch": byt, "kernel_ms": round(c_ms, 4), "achieved": round(byt / (c_ms * 1e-3) / 1e9, 1),
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(byt / (c_ms * 1e-3) / 8e12, 4), "timed": "live, HIP events"})
+        for row in prof.get("hbm_kernels", []):
+            hbm.append(dict(row, timed="rocprofv3 in-step average (profiles/)"))
+        if hbm:
+            roofline["hbm_kernels"] = hbm
         out = {"metric": "questions/sec fwd+bwd (B=64,d=512,p=12,KB=14x14x1024) at 1/2/4/8 MI355X",
                "value": round(qps, 2), "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+               "scaling": "weak" if args.per_gpu_batch else "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "dtype_note": ("fp32 in, fp32 accumulate, fp32 out; large contractions multiply on the bf16 matrix pipe: each operand split "
-                              "EXACTLY into 3 bf16 pieces, 6 MFMA terms per product (dropped terms <= 2^-23 |ab|); measured error vs fp64 "
-                              "<= the native f32-MFMA kernel's (tests/test_gpu_units.py); native_f32_mfma = same step on "
-                              "v_mfma_f32_16x16x4_f32") if split else "native f32-input MFMA",
-               "config": {"workload": "MAC cell fwd+bwd, configs/args.txt options, train-mode dropout .85/.85/1.0, "
-                                      "per-GPU batch B=%d, S=%d, KB=[B,%d,%d] (stem output of 14x14x1024 features), d=%d, p=%d; "
-                                      "cell only (stem/encoder/classifier are SURVEY 8f 'next' rows)" % (B, S, N, D, D, p),
-                          "global_batch": B * world, "parallelism": "dp%d" % world,
+               "dtype_note": ("fp32 in, fp32 accumulate, fp32-class results; the large contractions multiply on the fp16 matrix pipe: every "
+                              "operand is stored once as x 2^e = hi + lo (two fp16, |error| <= 2^-24) with one exponent per (row, 128 "
+                              "columns), a product is the 3 leading terms (dropped: lo*lo <= 2^-24 |ab|); measured error vs fp64 <= the "
+                              "native f32-MFMA kernel's (tests/test_gpu_h2.py); other_families = the same step on the 6-term bf16 split "
+                              "and on v_mfma_f32_16x16x4_f32") if mode == 2 else "kernel family %d" % mode,
+               "config": {"workload": "MAC cell fwd+bwd, configs/args.txt options, train-mode dropout .85/.85/1.0, global batch %d "
+                                      "split over %d rank(s) by the tower rule (%d questions on rank 0), S=%d, KB=[B,%d,%d] (stem output of "
+                                      "14x14x1024 features), d=%d, p=%d; cell only (stem/encoder/classifier: model_level)"
+                                      % (global_batch, world, bl, S, N, D, D, p),
+                          "global_batch": global_batch, "parallelism": "dp%d" % world,
+                          "collective": None if world == 1 else "%s all-reduce of the flat gradient buffer, world size %d" % (
+                              "RCCL (backend nccl)" if backend == "nccl" else backend, dist.get_world_size()),
                           "flops_per_question_fwd_bwd": 3 * p * F},
                "roofline": roofline}
-        if world == 1 and split and not args.no_native:
-            # the same step with every GEMM on the native f32-input MFMA kernels (v_mfma_f32_16x16x4_f32), for comparison
-            L.macx_gemm_mode(0)
-            for i in range(3):
-                step(1000 + i)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(5):
-                step(1003 + i)
-            torch.cuda.synchronize()
-            dtn = (time.perf_counter() - t0) / 5
-            L.macx_gemm_mode(1)
-            out["native_f32_mfma"] = {"value": round(B / dtn, 2), "unit": "questions/s", "ms_per_step": round(dtn * 1e3, 3), "steps": 5,
-                                      "whole_step_frac": round(B / dtn * 3 * p * F / PEAK_FP32_MFMA, 4)}
+        out.update(extra)
+        if world == 1 and mode == 2 and not args.no_native:
+            # the same step on the other two kernel families of the library
+            fam = {}
+            for name, m in (("split_bf16_6term", 1), ("native_f32_mfma", 0)):
+                L.macx_gemm_mode(m)
+                st3, _, _, _ = make_step(macx, dev, dist, 1, 0, global_batch, p, seed)
+                d3 = time_steps(st3, 5, 1, 2, barrier, 1, dev, dist)
+                fam[name] = {"value": round(global_batch * 5 / d3, 2), "unit": "questions/s", "ms_per_step": round(d3 / 5 * 1e3, 3), "steps": 5}
+                del st3
+            L.macx_gemm_mode(2)
+            out["other_families"] = fam
         if world == 1 and not args.no_model_level:
             out["model_level"] = model_level(macx, dev, seed)
         if world == 1 and not args.no_cpu_baseline:
@@ -294,6 +383,7 @@ def main():
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

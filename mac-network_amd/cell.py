@@ -108,7 +108,16 @@ class _Run:
         grads = {}
         present = [f for f in _lib.PARAM_FIELDS if f in self._ptensors]
         sizes = [(self._ptensors[f].numel() + 3) & ~3 for f in present]          # 16-byte aligned views
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)           # one fill instead of one per parameter
+        # the parameters' persistent flat gradient buffer (one fill instead of one per parameter; the views below become the
+        # parameters' .grad, so a flat all-reduce / optimizer needs no gather).  A second backward before the first one's
+        # gradients are consumed (gradient accumulation across calls) would overwrite them: such callers get a fresh buffer.
+        flat = None
+        if hasattr(self.params, "grad_buffer") and present == list(self.params.fields):
+            buf = self.params.grad_buffer()
+            if buf.numel() == sum(sizes) and all(getattr(self.params, f).grad is None for f in present):
+                flat = buf.zero_()
+        if flat is None:
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         off = 0
         for f, n in zip(present, sizes):
             t = self._ptensors[f]

@@ -21,24 +21,51 @@ def tower_slice(batch_size, rank, world):
 
 
 class GradBucket:
-    """Flat gradient buffer reused across steps; one all-reduce (sum) per step."""
+    """Flat gradient buffer reused across steps; one all-reduce (sum) per step.
 
-    def __init__(self, tensors):
+    `flat`: a persistent buffer the backward pass already writes into (MACCellParams.grad_buffer(): macx_cell_backward
+    receives pointers into it, and autograd hands the views through as `.grad`).  When every gradient is found to be a
+    view of that buffer at its expected offset the all-reduce runs on it in place -- no gather copy; anything else (a
+    gradient produced elsewhere, accumulated, or absent) falls back to one gather kernel into the buffer."""
+
+    def __init__(self, tensors, flat=None):
         self.tensors = list(tensors)
         self.sizes = [t.numel() for t in self.tensors]
-        n = sum(self.sizes)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=self.tensors[0].device)
+        self.offsets, off = [], 0
+        for n in self.sizes:
+            self.offsets.append(off)
+            off += (n + 3) & ~3                      # 16-byte aligned segments (what the kernels write through)
+        if flat is None:
+            flat = torch.zeros(off, dtype=torch.float32, device=self.tensors[0].device)
+        if flat.numel() < off:
+            raise ValueError("flat buffer holds %d floats, the gradients need %d" % (flat.numel(), off))
+        self.flat = flat
+        self.zero_copy_steps = 0
+
+    def _in_place(self):
+        base = self.flat.data_ptr()
+        for t, o in zip(self.tensors, self.offsets):
+            g = t.grad
+            if g is None or not g.is_contiguous() or g.data_ptr() != base + 4 * o:
+                return False
+        return True
 
     def allreduce_(self, shard_size, global_size, group=None):
         """grads <- sum_r (shard_r / global) * grads_r  == gradient of the full-batch mean loss."""
         w = float(shard_size) / float(global_size)
-        grads = [(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in self.tensors]
-        torch.cat(grads, out=self.flat)                       # one gather kernel into the flat buffer
-        self.flat.mul_(w)
+        if self._in_place():
+            self.zero_copy_steps += 1
+        else:
+            for t, o, n in zip(self.tensors, self.offsets, self.sizes):
+                dst = self.flat[o:o + n]
+                if t.grad is None:
+                    dst.zero_()
+                else:
+                    dst.copy_(t.grad.reshape(-1))
+        if w != 1.0:
+            self.flat.mul_(w)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for t, n in zip(self.tensors, self.sizes):            # gradients become views of the reduced buffer
-            t.grad = self.flat[off:off + n].view_as(t)
-            off += n
+        for t, o, n in zip(self.tensors, self.offsets, self.sizes):            # gradients are views of the reduced buffer
+            t.grad = self.flat[o:o + n].view_as(t)
         return self.flat

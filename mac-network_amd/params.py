@@ -105,6 +105,18 @@ class MACCellParams(torch.nn.Module):
     def tensors(self):
         return [getattr(self, f) for f in self.fields]
 
+    def grad_buffer(self):
+        """Persistent flat fp32 buffer the backward pass writes the parameter gradients into (16-byte aligned segments in
+        `fields` order): the gradients autograd hands out are views of it, so a data-parallel all-reduce (macx.dp.GradBucket)
+        and a flat optimizer can run on it without a gather copy.  Allocated on first use, reused by every backward."""
+        dev = self.tensors()[0].device
+        n = sum((t.numel() + 3) & ~3 for t in self.tensors())
+        buf = getattr(self, "_grad_flat", None)
+        if buf is None or buf.numel() != n or buf.device != dev:
+            buf = torch.zeros(n, dtype=torch.float32, device=dev)
+            object.__setattr__(self, "_grad_flat", buf)
+        return buf
+
     def to_reference_dict(self):
         """{TF variable name: tensor} with the reference's shapes (scalar biases are 0-d)."""
         out = {}
