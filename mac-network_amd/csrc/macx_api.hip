@@ -201,9 +201,15 @@ inline int rows_per_split(int M, int ns) {
   int r = (M + ns - 1) / ns;
   return (r + 1) & ~1;
 }
-inline int sb_qpg(int B) {   // questions per workgroup group in the S_b kernel: 16 tiles x groups ~ 256
+inline int sb_qpg(int B, int N = 0) {   // questions per workgroup group in the S_b kernel: 16 tiles x groups ~ 256
   int qpg = (B + 15) / 16;
-  return qpg < 1 ? 1 : qpg;
+  if (qpg < 1) qpg = 1;
+  if (h2_mode() && N > 0) {                 // the H2 kernel keeps one fp16 factor per (question, row) of a group in LDS
+    const int rows_q = ((N + 31) / 32) * 32;
+    const int cap = SBH_MAXROWS / rows_q;
+    if (qpg > cap) qpg = cap < 1 ? 1 : cap;
+  }
+  return qpg;
 }
 
 // ---- layout of the backward workspace ---------------------------------------------------------
@@ -267,7 +273,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dmd = take(B * d);
   L.dt = take(B * d); L.du = take(B * d);
   L.ns_big = wgrad_splits((int)(p * B * N), (int)d, (int)d);
-  L.ngroup = (B + sb_qpg((int)B) - 1) / sb_qpg((int)B);
+  L.ngroup = (B + sb_qpg((int)B, (int)N) - 1) / sb_qpg((int)B, (int)N);
   L.slab_w2 = take(L.ns_big * d * d);
   L.slab_wx = take(L.ns_big * d * d);
   L.slab_w1a = take(p * L.ngroup * d * d);
@@ -373,7 +379,9 @@ hipError_t absmax4(const float* a, size_t na, const float* b, size_t nb, const f
   memset(&L, 0, sizeof(L));
   L.src[0] = a; L.n[0] = na; L.src[1] = b; L.n[1] = nb; L.src[2] = c; L.n[2] = nc; L.src[3] = d_; L.n[3] = nd;
   L.out = out;
-  hipLaunchKernelGGL(absmax_kernel, dim3(4), dim3(1024), 0, st, L);
+  hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(absmax_kernel, dim3(64, 4), dim3(256), 0, st, L);
   return hipGetLastError();
 }
 
@@ -934,13 +942,14 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
       // S_b = X_b^T dI1_b -> dW1a / dW1b slabs and dy partials
       {
         SbH2P q;
-        q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B);
+        q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B, N);
         q.X = hX; q.dI1 = hdI1;
         q.qminX = reinterpret_cast<const int*>(saved + L.qmin_X) + (size_t)i * L.qmin_stride; q.qminG = q_dI1;
         q.y = y; q.W1a = P->memKbProj_W;
         q.dW1a_part = ws + W.slab_w1a + (size_t)i * W.ngroup * dd;
         q.dW1b_part = ws + W.slab_w1b + (size_t)i * W.ngroup * dd;
         q.dy_part = ws + W.dy_part;
+        q.dbg = kb_gemm_dbg();
         CK(sb_h2_launch(q, st));
       }
       // dKB (+)= (dX Wx^T) * kbmask + att * dinfo
@@ -985,7 +994,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     // S_b = X_b^T dI1_b -> dW1a / dW1b slabs and dy partials
     {
       SbP q;
-      q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B);
+      q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B, N);
       q.X = X; q.dI1 = ws + W.dI1; q.y = y; q.W1a = P->memKbProj_W;
       q.dW1a_part = ws + W.slab_w1a + (size_t)i * W.ngroup * dd;
       q.dW1b_part = ws + W.slab_w1b + (size_t)i * W.ngroup * dd;
@@ -1872,7 +1881,8 @@ int macx_h2_gemm_planes(const float* hA, int B, int N, int K, const float* Wh, i
   g.Wh = reinterpret_cast<const char*>(Wh); g.w_exp = reinterpret_cast<const int*>(Wh) + (size_t)K * n_out;
   g.out = h2_view(hO, B * N, n_out); g.bias = bias; g.act = act; g.e_inv_keep = 1.0f;
   g.dbg = kb_gemm_dbg();
-  CK((kb_gemm_h2_launch<B_PLAIN, E_BIAS_ACT, false>(g, (hipStream_t)stream)));
+  static const int reps = getenv("MACX_H2_DEBUG_REPS") ? atoi(getenv("MACX_H2_DEBUG_REPS")) : 1;   // timing aid (tools/h2_gemm_time.py)
+  for (int r = 0; r < reps; ++r) CK((kb_gemm_h2_launch<B_PLAIN, E_BIAS_ACT, false>(g, (hipStream_t)stream)));
   return MACX_OK;
 }
 

@@ -287,22 +287,22 @@ __global__ void h2_min_exp_kernel(const char* base, size_t stride_bytes, int nt,
 }
 
 // ---- weights -------------------------------------------------------------------------------------------------
-// max |W| of up to 8 matrices in one launch (blockIdx.x selects the matrix), fixed-order reduction
+// max |W| of up to 8 matrices in one launch: blockIdx.y selects the matrix, gridDim.x workgroups share it and combine with an
+// integer atomicMax on the bit pattern (non-negative floats order like their bit patterns: order-independent, deterministic;
+// NaN entries are skipped by fmaxf).  out[] must be zeroed by the caller.
 struct AbsMaxList { const float* src[8]; size_t n[8]; float* out; };
-__global__ __launch_bounds__(1024) void absmax_kernel(AbsMaxList L) {
-  __shared__ float red[16];
-  const float* s = L.src[blockIdx.x];
-  const size_t n = L.n[blockIdx.x];
+__global__ __launch_bounds__(256) void absmax_kernel(AbsMaxList L) {
+  __shared__ float red[4];
+  const float* s = L.src[blockIdx.y];
+  const size_t n = L.n[blockIdx.y];
   float m = 0.f;
-  for (size_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(s[i]));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(s[i]));
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float t = red[0];
-#pragma unroll
-    for (int w = 1; w < 16; ++w) t = fmaxf(t, red[w]);
-    L.out[blockIdx.x] = t;
+    const float t = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(reinterpret_cast<int*>(L.out) + blockIdx.y, __float_as_int(t));
   }
 }
 // pack format 3: W (or W^T) as H2 weight planes  dst[kt][plane][g][Nout] x 16 B  (8 consecutive k of one column),

@@ -408,12 +408,17 @@ inline hipError_t wgrad_h2_launch(const TnH2P& p, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Per-question interaction gradient  S_b = X_b^T dI1_b  over H2 operands (see sb_wgrad_kernel in macx_gemm_tn.cuh for what
-// S_b is for):  dW1a += diag(y_b) S_b,  dW1b += S_b,  dy[b][k] = sum_j W1a[k][j] S_b[k][j].  Same staging as
-// wgrad_h2_kernel (slots copied as they lie, rows scaled to the QUESTION's common exponents -- the qmin arrays written by
-// the kernels that produced X and dI1 -- fragments by transpose reads); 12 waves: 0-3 produce, 4-11 consume one 64 x 32
-// eighth of the 128 x 128 tile each with its three accumulator sets (3 waves per SIMD: 168 registers each); a stage never
-// crosses a question boundary (the last stage of a question is zero-filled past its end), so the fold of S_b happens
-// between stages.
+// S_b is for):  dW1a += diag(y_b) S_b,  dW1b += S_b,  dy[b][k] = sum_j W1a[k][j] S_b[k][j].
+//
+// All 8 waves multiply (one 64 x 32 eighth of the 128 x 128 tile each, three accumulator sets = 96 registers, two waves per
+// SIMD).  Staging costs no registers and no vector ALU: the H2 slots go from HBM/L2 straight into the LDS images by LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 B land lane-linear, which is exactly one [2 row halves][16 rows][16 columns]
+// column tile of the transpose-read image) through a four-stage ring, and the wait for a stage is an explicit s_waitcnt vmcnt(8)
+// -- this wave's eight DMA instructions of the next two stages stay in flight.  The rows of a question are brought to the
+// question's common exponents on the way from LDS to the MFMA: one combined factor per row, 2^(EX - ex_row + EG - eg_row)
+// (0 for rows past the question's end), precomputed for all of the workgroup's questions into an LDS table when the kernel
+// starts and applied to the dI1 fragments only (two v_pk_mul_f16 per transpose read).  A stage never crosses a question
+// boundary, so the fold of S_b happens between stages.
 // ---------------------------------------------------------------------------------------------------------------
 struct SbH2P {
   int B, N, d;
@@ -427,16 +432,24 @@ struct SbH2P {
   float* dW1a_part;        // [ngroup][d][d]
   float* dW1b_part;
   float* dy_part;          // [4*d/128][B][d]
+  int dbg;                 // measurement knobs (macx_debug_set(1, mask)): 512 skip the per-question fold, 1024 skip fragments + MFMAs,
+                           // 2048 skip the DMA issue
 };
 
-constexpr int SBH_STAGE = 4 * WH_APL;
-constexpr int SBH_CW = 4;                  // consumer waves (see sb_h2_kernel); dy_part holds SBH_CW / 2 partials per 128 columns      // X hi, X lo, dI1 hi, dI1 lo images of 32 rows x 128 columns
+constexpr int SBH_STAGE = 4 * WH_APL;      // X hi, X lo, dI1 hi, dI1 lo images of 32 rows x 128 columns
+constexpr int SBH_CW = 8;                  // multiplying waves; dy_part holds SBH_CW / 2 partials per 128 columns
+constexpr int SBH_MAXROWS = 4096;          // rows of one workgroup's questions covered by the factor table (8 KB)
+constexpr int SBH_RING = 4;                // LDS stages: three stages of DMA in flight behind the one being multiplied
 
-// CW consumer waves: 8 (64 x 32 each, 12-wave workgroup, 168 registers) or 4 (64 x 64 each, 8-wave workgroup, 256 registers)
-template <int CW>
-__global__ __launch_bounds__(256 + 64 * CW) void sb_h2_kernel(SbH2P p) {
+__device__ __forceinline__ void dma16b(const char* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
+  uint16_t* ftab = reinterpret_cast<uint16_t*>(lds + SBH_RING * SBH_STAGE);      // [questions][nchunk * 32] combined row factors (fp16)
 
   const int nt = p.d / T_TILE;
   const int ntile = nt * nt;
@@ -449,187 +462,184 @@ __global__ __launch_bounds__(256 + 64 * CW) void sb_h2_kernel(SbH2P p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;                // 64 rows (k) x 32 columns (j) of the tile
 
   const int nchunk = (p.N + 31) >> 5;
   const int b_begin = group * p.qpg;
   const int b_end = min(p.B, b_begin + p.qpg);
-  const int total = (b_end - b_begin) * nchunk;         // stages of this workgroup, over all its questions
+  const int nq = b_end - b_begin;
+  const int total = nq * nchunk;                          // stages of this workgroup, over all its questions
   const size_t Rp = p.X.Rp();
   const size_t xpb = p.X.plane_bytes(), gpb = p.dI1.plane_bytes();
   const int xcb = p.X.cb(), gcb = p.dI1.cb();
+  const int rows_q = nchunk * 32;                         // table rows per question (rows past N hold factor 0)
 
-  if (wave < 4) {
-    // ---- producers: 64 slot columns per stage (X: 2 planes x 16, dI1: 2 planes x 16), 8 per lane
-    const int r = tid & 31, c0 = tid >> 5;
-    u32x4 rv[2][8];
-    int ex_r[2], eg_r[2], qx_r[2], qg_r[2];     // raw exponents; factors are formed when the stage is stored
-    auto load = [&](auto slot_c, int s_raw) __attribute__((always_inline)) {
-      constexpr int SL = decltype(slot_c)::value;
-      const int s = min(s_raw, total - 1);
-      const int qi = s / nchunk, ch = s - qi * nchunk;
-      const int b = b_begin + qi;
-      const int n = ch * 32 + r;
-      const bool ok = (s_raw < total) && n < p.N;
-      const size_t row = (size_t)b * p.N + min(n, p.N - 1);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + 8 * i;
-        const int pl = (c >> 4) & 1, kg = c & 15;
-        rv[SL][i] = (i < 4) ? *reinterpret_cast<const u32x4*>(p.X.plane(0) + pl * xpb + ((size_t)(tk * 16 + kg) * Rp + row) * 16)
-                            : *reinterpret_cast<const u32x4*>(p.dI1.plane(0) + pl * gpb + ((size_t)(tj * 16 + kg) * Rp + row) * 16);
-      }
-      ex_r[SL] = p.X.exps()[row * xcb + tk];
-      eg_r[SL] = p.dI1.exps()[row * gcb + tj];
-      qx_r[SL] = p.qminX[(size_t)b * xcb + tk];
-      qg_r[SL] = p.qminG[(size_t)b * gcb + tj];
-      if (!ok) { ex_r[SL] = 1000; eg_r[SL] = 1000; }
-    };
-    auto store = [&](auto slot_c, int s_raw) __attribute__((always_inline)) {
-      constexpr int SL = decltype(slot_c)::value;
-      char* st = lds + (s_raw % 3) * SBH_STAGE;
-      const uint32_t fx_ = pk_pow2_f16(qx_r[SL] - ex_r[SL]), fg_ = pk_pow2_f16(qg_r[SL] - eg_r[SL]);     // 1000 -> 0: row past the end
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + 8 * i;
-        const int kg = c & 15;
-        const uint32_t f = (i < 4) ? fx_ : fg_;
-        u32x4 w = rv[SL][i];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) w[h] = f ? pk_mul_f16(w[h], f) : 0u;
-        *reinterpret_cast<u32x4*>(st + (c >> 4) * WH_APL + wh_slot_off(kg, r)) = w;
-      }
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2 = std::integral_constant<int, 2>;
-    // LDS stage s is written during iteration s - 2 from registers loaded two iterations before that: two register sets keep
-    // the loads of two stages in flight (a third set does not fit the 168-register budget of this 12-wave workgroup, and a
-    // spilled set is worse than none: its scratch reloads drain the whole load queue)
-    if (total > 0) {
-      load(S0{}, 0); load(S1{}, 1);
-      store(S0{}, 0); store(S1{}, 1);
-      load(S0{}, 2); load(S1{}, 3);
-      __syncthreads();
-      const int nloop = (total + 1) / 2 * 2;
-#pragma unroll 1
-      for (int s = 0; s < nloop; s += 2) {
-        store(S0{}, s + 2); load(S0{}, s + 4); __syncthreads();
-        store(S1{}, s + 3); load(S1{}, s + 5); __syncthreads();
-      }
+  // ---- factor table
+  for (int i = tid; i < nq * rows_q; i += 512) {
+    const int qi = i / rows_q, n = i - qi * rows_q;
+    const int b = b_begin + qi;
+    uint16_t f = 0;
+    if (n < p.N) {
+      const size_t row = (size_t)b * p.N + n;
+      const int k = (p.qminX[(size_t)b * xcb + tk] - (int)p.X.exps()[row * xcb + tk]) +
+                    (p.qminG[(size_t)b * gcb + tj] - (int)p.dI1.exps()[row * gcb + tj]);
+      f = (uint16_t)(pk_pow2_f16(k) & 0xFFFFu);
     }
-  } else {
-    // ---- consumers
-    constexpr int NC = 16 / CW;                           // 16-column tiles per consumer wave
-    constexpr int WCN = CW / 2;                           // column groups of the tile
-    const int cw = wave - 4;
-    const int wr = cw / WCN, wc = cw % WCN;               // 64 rows (k) x 16 NC columns (j) of the tile
-    f32x4 accS[4][NC], accA[4][NC], accB[4][NC];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int c = 0; c < NC; ++c) accS[t][c] = accA[t][c] = accB[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto frag = [&](const char* tile) __attribute__((always_inline)) {
-      const u32x2 lo = tr_read(tile + lane * 8), hi = tr_read(tile + 512 + lane * 8);
-      return u32x4{lo[0], lo[1], hi[0], hi[1]};
-    };
-    // smallest terms first: X_lo x dI1_hi ; X_hi x {dI1_lo, dI1_hi}
-    auto compute = [&](int buf) __attribute__((always_inline)) {
-      const char* sa = lds + buf * SBH_STAGE + (wr * 4) * 1024;
-      const char* sg = lds + buf * SBH_STAGE + 2 * WH_APL + (wc * NC) * 1024;
-      u32x4 gf[2][NC];
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) gf[pl][c] = frag(sg + pl * WH_APL + c * 1024);
-#pragma unroll
-      for (int ap = 1; ap >= 0; --ap) {
-        u32x4 af[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[t] = frag(sa + ap * WH_APL + t * 1024);
-#pragma unroll
-        for (int bp = 1 - ap; bp >= 0; --bp)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) accS[t][c] = mfma_f16(af[t], gf[bp][c], accS[t][c]);
-      }
-    };
-    // question finished: fold S_b (in units of its two common exponents) into the three outputs and clear it.  The wave's
-    // 64 x 32 share of W1a and its 16 entries of y_b are requested together up front (the fragment registers are free here):
-    // 48 loads in flight once per question instead of 16 dependent round trips.
-    auto consume = [&](int b) __attribute__((always_inline)) {
-      const float sc = h2_unscale(p.qminX[(size_t)b * xcb + tk], p.qminG[(size_t)b * gcb + tj]);
-      // the addresses below are loop-invariant; laundering the row pitch keeps the compiler from hoisting all 48 of them out of
-      // the stage loop, where they would occupy (and spill) registers the whole time for a once-per-question use
-      int pitch = p.d;
-      asm volatile("" : "+s"(pitch));
-      const float* yb = p.y + (size_t)b * pitch + tk * T_TILE + wr * 64 + (lane >> 4) * 4;
-      const float* wb = p.W1a + (size_t)(tk * T_TILE + wr * 64 + (lane >> 4) * 4) * pitch + tj * T_TILE + wc * 16 * NC + (lane & 15);
-      float w1[4][4][NC];
-      f32x4 y4[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        y4[t] = *reinterpret_cast<const f32x4*>(yb + t * 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int c = 0; c < NC; ++c) w1[t][e][c] = wb[(size_t)(t * 16 + e) * pitch + c * 16];
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
-          const float yk = y4[t][e];
-          float dyp = 0.f;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const float sv = accS[t][c][e] * sc;
-            accB[t][c][e] += sv;
-            accA[t][c][e] = fmaf(yk, sv, accA[t][c][e]);
-            dyp = fmaf(w1[t][e][c], sv, dyp);
-            accS[t][c][e] = 0.f;
-          }
-          dyp = sum16_h2(dyp);
-          if ((lane & 15) == 0) p.dy_part[((size_t)(tj * WCN + wc) * p.B + b) * pitch + k] = dyp;
-        }
-    };
-    if (total > 0) {
-      __syncthreads();
-      const int nloop = (total + 1) / 2 * 2;      // as the producers; the stages past the end hold zero rows
-      int qch = 0, b = b_begin;
-#pragma unroll 1
-      for (int s = 0; s < nloop; ++s) {
-        if (s < total) {
-          compute(s % 3);
-          if (++qch == nchunk) { consume(b); qch = 0; ++b; }
-        }
-        __syncthreads();
-      }
-    }
-    float* oa = p.dW1a_part + (size_t)group * p.d * p.d;
-    float* ob = p.dW1b_part + (size_t)group * p.d * p.d;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
-          const int j = tj * T_TILE + wc * 16 * NC + c * 16 + (lane & 15);
-          oa[(size_t)k * p.d + j] = accA[t][c][e];
-          ob[(size_t)k * p.d + j] = accB[t][c][e];
-        }
+    ftab[i] = f;
   }
+
+  f32x4 accS[4][2], accA[4][2], accB[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) accS[t][c] = accA[t][c] = accB[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: instruction u of a stage (u = 4 wave .. 4 wave + 3) fills column tile u & 7 of image u >> 3
+  //      (0: X hi, 1: X lo, 2: dI1 hi, 3: dI1 lo); lane q of it copies slot (row half q / 32, row (q % 32) / 2, 8-column group
+  //      2 (u & 7) + q % 2), the lane-linear order of the [half][row][16 columns] tile
+  const int sl_half = lane >> 5, sl_row = (lane & 31) >> 1, sl_kg = lane & 1;
+  const int sl_m = sl_half * 16 + sl_row;                 // stage row of this lane's slot
+  auto issue = [&](int s_raw) __attribute__((always_inline)) {
+    const int s = min(s_raw, total - 1);
+    const int qi = s / nchunk, ch = s - qi * nchunk;
+    const int n = min(ch * 32 + sl_m, p.N - 1);           // rows past the end re-read the last row (finite data, factor 0)
+    const size_t row = (size_t)(b_begin + qi) * p.N + n;
+    char* st = lds + (s_raw % SBH_RING) * SBH_STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = wave * 4 + j;
+      const int im = u >> 3, ct = u & 7;
+      const char* src = (im < 2 ? p.X.plane(0) + (im & 1) * xpb + ((size_t)(tk * 16 + 2 * ct + sl_kg) * Rp + row) * 16
+                                : p.dI1.plane(0) + (im & 1) * gpb + ((size_t)(tj * 16 + 2 * ct + sl_kg) * Rp + row) * 16);
+      dma16b(src, st + im * WH_APL + ct * 1024);
+    }
+  };
+  auto frag = [&](const char* tile) __attribute__((always_inline)) {
+    const u32x2 lo = tr_read(tile + lane * 8), hi = tr_read(tile + 512 + lane * 8);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
+  // smallest terms first: X_lo x dI1_hi ; X_hi x {dI1_lo, dI1_hi}
+  auto compute = [&](int buf, int qi, int ch) __attribute__((always_inline)) {
+    const char* sa = lds + buf * SBH_STAGE + (wr * 4) * 1024;
+    const char* sg = lds + buf * SBH_STAGE + 2 * WH_APL + (wc * 2) * 1024;
+    // this lane's reduction rows: 4 g + {0..3} of each row half -> two packed factor pairs per half
+    const uint16_t* ft = ftab + qi * rows_q + ch * 32 + (lane >> 4) * 4;
+    const u32x2 f0 = *reinterpret_cast<const u32x2*>(ft), f1 = *reinterpret_cast<const u32x2*>(ft + 16);
+    u32x4 gf[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        u32x4 w = frag(sg + pl * WH_APL + c * 1024);
+        w[0] = pk_mul_f16(w[0], f0[0]); w[1] = pk_mul_f16(w[1], f0[1]);
+        w[2] = pk_mul_f16(w[2], f1[0]); w[3] = pk_mul_f16(w[3], f1[1]);
+        gf[pl][c] = w;
+      }
+#pragma unroll
+    for (int ap = 1; ap >= 0; --ap) {
+      u32x4 af[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[t] = frag(sa + ap * WH_APL + t * 1024);
+#pragma unroll
+      for (int bp = 1 - ap; bp >= 0; --bp)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) accS[t][c] = mfma_f16(af[t], gf[bp][c], accS[t][c]);
+    }
+  };
+  // this wave's 64 x 32 share of W1a stays in registers for the whole kernel (32 per lane; the staging needs none), and the
+  // 16 entries of y_b a lane needs are requested one question ahead: the per-question fold then has no load to wait for, so it
+  // does not drain the DMA queue
+  float w1[4][4][2];
+  {
+    const float* wb = p.W1a + (size_t)(tk * T_TILE + wr * 64 + (lane >> 4) * 4) * p.d + tj * T_TILE + wc * 32 + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) w1[t][e][c] = wb[(size_t)(t * 16 + e) * p.d + c * 16];
+  }
+  f32x4 ynext[4];
+  auto load_y = [&](int b) __attribute__((always_inline)) {
+    const float* yb = p.y + (size_t)min(b, p.B - 1) * p.d + tk * T_TILE + wr * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ynext[t] = *reinterpret_cast<const f32x4*>(yb + t * 16);
+  };
+  // question finished: fold S_b (in units of its two common exponents) into the three outputs and clear it
+  auto consume = [&](int b) __attribute__((always_inline)) {
+    const float sc = h2_unscale(p.qminX[(size_t)b * xcb + tk], p.qminG[(size_t)b * gcb + tj]);
+    f32x4 y4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y4[t] = ynext[t];
+    load_y(b + 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
+        const float yk = y4[t][e];
+        float dyp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float sv = accS[t][c][e] * sc;
+          accB[t][c][e] += sv;
+          accA[t][c][e] = fmaf(yk, sv, accA[t][c][e]);
+          dyp = fmaf(w1[t][e][c], sv, dyp);
+          accS[t][c][e] = 0.f;
+        }
+        dyp = sum16_h2(dyp);
+        if ((lane & 15) == 0) p.dy_part[((size_t)(tj * 4 + wc) * p.B + b) * p.d + k] = dyp;
+      }
+  };
+
+  if (total > 0) {
+    load_y(b_begin);
+    issue(0);
+    issue(1);
+    issue(2);
+    wait_vmcnt<8>();                                      // stage 0 has landed (stages 1, 2 may be in flight)
+    __syncthreads();                                      // ... for every wave's share of it, and the factor table is complete
+    int qi = 0, qch = 0;
+#pragma unroll 1
+    for (int s = 0; s < total; ++s) {
+      if (!(p.dbg & 2048)) issue(s + 3);                  // ring slot (s + 3) % 4 was last read in iteration s - 1
+      if (!(p.dbg & 1024)) compute(s % SBH_RING, qi, qch);
+      if (++qch == nchunk) {
+        if (!(p.dbg & 512)) consume(b_begin + qi);        // (its loads drain the DMA queue too: once per question)
+        qch = 0; ++qi;
+      }
+      wait_vmcnt<8>();                                    // stage s + 1 has landed; this wave's 8 instructions of stages s + 2, s + 3 may fly
+      __syncthreads();
+    }
+    wait_vmcnt<0>();                                      // the speculative stages past the end
+  }
+
+  float* oa = p.dW1a_part + (size_t)group * p.d * p.d;
+  float* ob = p.dW1b_part + (size_t)group * p.d * p.d;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
+        const int j = tj * T_TILE + wc * 32 + c * 16 + (lane & 15);
+        oa[(size_t)k * p.d + j] = accA[t][c][e];
+        ob[(size_t)k * p.d + j] = accB[t][c][e];
+      }
 }
 
 inline hipError_t sb_h2_launch(const SbH2P& p, hipStream_t st) {
-  constexpr size_t lds = 3 * SBH_STAGE;
-  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2_kernel<SBH_CW>), lds);
+  const int nchunk = (p.N + 31) >> 5;
+  if (p.qpg * nchunk * 32 > SBH_MAXROWS) return hipErrorInvalidValue;
+  constexpr size_t lds = SBH_RING * SBH_STAGE + SBH_MAXROWS * 2;
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2_kernel), lds);
   if (e != hipSuccess) return e;
   const int nt = p.d / T_TILE;
   const int ngroup = (p.B + p.qpg - 1) / p.qpg;
-  hipLaunchKernelGGL(sb_h2_kernel<SBH_CW>, dim3(nt * nt * ngroup), dim3(256 + 64 * SBH_CW), lds, st, p);
+  hipLaunchKernelGGL(sb_h2_kernel, dim3(nt * nt * ngroup), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 

@@ -7,9 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def child(mask, reps):
+def child(mask, reps, rt=0):
+    os.environ["MACX_H2_DEBUG_REPS"] = "10"        # launches per C call: the host's per-call cost (tens of us on some boxes) drops out
     import macx
     L = macx._lib.lib()
+    if rt:
+        L.macx_debug_set(2, rt)
     p = lambda t: C.c_void_p(t.data_ptr())
     dev = torch.device("cuda:0")
     B, N, K = 64, 196, 512
@@ -17,26 +20,36 @@ def child(mask, reps):
     A = torch.randn(B, N, K, generator=g).to(dev)
     W = (torch.randn(K, K, generator=g) / 22).to(dev)
     b = torch.randn(K, generator=g).to(dev)
-    n = 2 * L.macx_h2_floats(B * N, K) + K * K + 64
-    ws = torch.zeros(n, device=dev)
-    out = torch.zeros(B * N, K, device=dev)
+    hf = L.macx_h2_floats(B * N, K)
+    NBUF = 4
+    hin = [torch.zeros(hf, device=dev) for _ in range(NBUF)]
+    hout = [torch.zeros(hf, device=dev) for _ in range(NBUF)]
+    wh = torch.zeros(K * K + 64, device=dev)
+    macx._lib.check(L.macx_h2_pack_weight(p(W), K, K, 0, p(wh), None), "pack")
+    for i in range(NBUF):
+        macx._lib.check(L.macx_h2_from_f32(p(A), B, N, K, p(hin[i]), None), "from")
     L.macx_debug_set(1, mask)
-    ts = []
-    for r in (1, reps + 1):
-        os.environ["MACX_H2_DEBUG_REPS"] = str(r)
-        for it in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            macx._lib.check(L.macx_h2_gemm(p(A), B, N, K, p(W), K, p(b), 0, p(out), p(ws), n, None), "g")
-            e1.record()
-            torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    print("mask %3d: %.2f us per launch" % (mask, (ts[1] - ts[0]) / reps * 1e3), flush=True)
+    for i in range(8):
+        macx._lib.check(L.macx_h2_gemm_planes(p(hin[i % NBUF]), B, N, K, p(wh), K, p(b), 0, p(hout[i % NBUF]), None), "g")
+    torch.cuda.synchronize()
+    best = 1e9
+    for it in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            L.macx_h2_gemm_planes(p(hin[i % NBUF]), B, N, K, p(wh), K, p(b), 0, p(hout[i % NBUF]), None)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps * 1e3 / 10)
+    ts = [0.0, best * reps / 1e3]
+    print("mask %3d rt %2d: %.2f us per launch" % (mask, rt, (ts[1] - ts[0]) / reps * 1e3), flush=True)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
-        child(int(sys.argv[1]), 50)
+    if len(sys.argv) > 2:
+        child(int(sys.argv[1]), 50, int(sys.argv[2]))
     else:
-        for mask in (0, 1, 2, 32, 2 | 32, 64, 64 | 2 | 32, 1 | 64 | 2 | 32, 1 | 64, 1 | 2 | 32):
-            subprocess.run([sys.executable, __file__, str(mask)])
+        masks = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else (0, 128, 1, 1 | 128, 64, 1 | 64, 1 | 2 | 32, 1 | 64 | 2 | 32)
+        for rt in (0, 7):
+            for mask in masks:
+                subprocess.run([sys.executable, __file__, str(mask), str(rt)])
