@@ -197,9 +197,17 @@ inline int wgrad_splits(int M, int Kd, int Jd) {
   if (ns < 1) ns = 1;
   return ns;
 }
+// ... of the deferred H2 contractions (macx_wgrad_h2.hip.h: up to 256 x 256 output tiles)
+inline int wgrad_big_splits(int M, int Kd, int Jd) {
+  if (!h2_mode()) return wgrad_splits(M, Kd, Jd);
+  int ns = 256 / wgrad_h2_tiles(Kd, Jd);
+  const int max_by_rows = (M + 255) / 256;
+  if (ns > max_by_rows) ns = max_by_rows;
+  return ns < 1 ? 1 : ns;
+}
 inline int rows_per_split(int M, int ns) {
   int r = (M + ns - 1) / ns;
-  return (r + 1) & ~1;
+  return h2_mode() ? (r + 31) & ~31 : (r + 1) & ~1;       // H2: a 32-row stage never straddles two splits
 }
 inline int sb_qpg(int B, int N = 0) {   // questions per workgroup group in the S_b kernel: 16 tiles x groups ~ 256
   int qpg = (B + 15) / 16;
@@ -208,6 +216,7 @@ inline int sb_qpg(int B, int N = 0) {   // questions per workgroup group in the 
     const int rows_q = ((N + 31) / 32) * 32;
     const int cap = SBH_MAXROWS / rows_q;
     if (qpg > cap) qpg = cap < 1 ? 1 : cap;
+    if (qpg > SBH_MAXQ) qpg = SBH_MAXQ;
   }
   return qpg;
 }
@@ -243,6 +252,7 @@ struct BwdLayout {
   size_t act_floats;                 // floats of one [B,N,d] activation (H2 size in h2 mode)
   size_t qmin_dI2, qmin_dI1, qmin_dX;   // h2: [p][B][d/128] ints
   size_t ecom;                       // h2: 4 x [d/128] ints, common exponents of H1 / dI2 / KBd / dX over all steps
+  size_t wg_ftab;                    // h2: [d/128][d/128][Mpad] fp16 row factors of the deferred weight-gradient contractions
   size_t total;
 };
 
@@ -272,7 +282,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.DY = take(p * B * d);
   L.dmd = take(B * d);
   L.dt = take(B * d); L.du = take(B * d);
-  L.ns_big = wgrad_splits((int)(p * B * N), (int)d, (int)d);
+  L.ns_big = wgrad_big_splits((int)(p * B * N), (int)d, (int)d);
   L.ngroup = (B + sb_qpg((int)B, (int)N) - 1) / sb_qpg((int)B, (int)N);
   L.slab_w2 = take(L.ns_big * d * d);
   L.slab_wx = take(L.ns_big * d * d);
@@ -303,6 +313,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.qmin_dI1 = L.qmin_dI2 + p * B * (d / 128);
   L.qmin_dX = L.qmin_dI1 + p * B * (d / 128);
   L.ecom = take(4 * 8);
+  L.wg_ftab = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
   L.total = off;
   return L;
 }
@@ -1228,6 +1239,8 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     t.A = reinterpret_cast<const char*>(saved + L.H1); t.a_stride = L.act_stride * sizeof(float); t.a_mod = 0;
     t.G = reinterpret_cast<const char*>(ws + W.dI2); t.g_stride = W.act_floats * sizeof(float);
     t.ecomA = ecom; t.ecomG = ecom + 8;
+    t.ftab = reinterpret_cast<uint16_t*>(ws + W.wg_ftab);
+    t.dbg = kb_gemm_dbg();
     t.part = ws + W.slab_w2;
     CK(wgrad_h2_launch(t, st));
     t.A = reinterpret_cast<const char*>(saved + L.KBd);

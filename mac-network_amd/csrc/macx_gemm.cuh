@@ -110,6 +110,28 @@ __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// ... for a wave-uniform run-time n (the immediate has to be a constant); n > 16 waits for everything
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+  switch (n) {
+    case 1: wait_vmcnt<1>(); break;
+    case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
+    case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;
+    case 7: wait_vmcnt<7>(); break;
+    case 8: wait_vmcnt<8>(); break;
+    case 9: wait_vmcnt<9>(); break;
+    case 10: wait_vmcnt<10>(); break;
+    case 11: wait_vmcnt<11>(); break;
+    case 12: wait_vmcnt<12>(); break;
+    case 13: wait_vmcnt<13>(); break;
+    case 14: wait_vmcnt<14>(); break;
+    case 15: wait_vmcnt<15>(); break;
+    case 16: wait_vmcnt<16>(); break;
+    default: wait_vmcnt<0>(); break;
+  }
+}
 
 template <int RT, int NW>
 constexpr int kb_gemm_lds_floats() {

@@ -3,12 +3,12 @@
 //
 // Same per-question tiling as the other two families (RT*16 rows of ONE question x 128 columns, 8 waves arranged
 // 2 row halves x 4 column groups, grid = B x Nout/128 = one workgroup per CU at the CLEVR shape), but
-//   * the A operand arrives pre-split from the kernel that produced it: staging is a pure 16-byte copy
-//     (global_load_dwordx4 -> ds_write_b128, lane-linear on both sides), no vector-ALU work per element;
-//   * 32-wide K slices through a THREE-stage LDS ring (43 KB per stage at RT = 13): the loads of slice s+2 are issued
-//     before the MFMAs of slice s and stored after them, so the single barrier per slice only protects the stage being
-//     overwritten -- no wave waits at it for data it is about to use, and the two waves of a SIMD drift into
-//     complementary phases (one multiplying while the other copies);
+//   * the A operand arrives pre-split from the kernel that produced it and goes from HBM/L2 straight into LDS by LDS-DMA
+//     (global_load_lds_dwordx4, 64 lanes x 16 B landing lane-linear): no registers, no ds_write, no vector-ALU work;
+//     pre-split weights (B_PLAIN) travel the same way;
+//   * 32-wide K slices through a THREE-stage LDS ring (43 KB per stage at RT = 13): the DMA of slice s+2 is issued before
+//     the MFMAs of slice s, and the wait at the end of slice s (an explicit s_waitcnt vmcnt(n) -- see dma16b in
+//     macx_h2.hip.h for why it has to be explicit) only asks for slice s+1, so a slice has two multiply phases to land;
 //   * per-(row, 128-column block) exponents: the MFMAs of one 128-wide K block accumulate in a block accumulator that is
 //     folded into the running sum with the row's exact power-of-two factor (4 folds per launch at K = 512);
 //   * weights: B_PLAIN pre-split once per call (pack format 3, per-matrix exponent); B_YMIX_* mixed with the question's
@@ -47,15 +47,15 @@ struct GemmH2P {
   float e_inv_keep;
   int accumulate;           // E_DKB
   int* out_qmin;            // [B][Nout/128] minimum exponent of each question's output rows, atomicMin (caller presets 127)
-  int dbg;                  // measurement knobs (macx_debug_set(1, mask)): 1 skip the epilogue, 2 skip the in-loop staging,
-                            // 16 skip the MFMAs, 32 skip the in-loop global loads, 64 skip the fragment reads + MFMAs
+  int dbg;                  // measurement knobs (macx_debug_set(1, mask)): 1 skip the epilogue, 32 skip the in-loop staging,
+                            // 64 skip the fragment reads + MFMAs, 256 return at once, 512 return in front of the K loop
 };
 
 template <int RT>
 constexpr int kb_gemm_h2_lds_bytes() {
   constexpr int ROWS = RT * 16;
   constexpr int stage = 2 * 4 * ROWS * 16 + 2 * 4 * 128 * 16;
-  constexpr int ring = 3 * stage + ROWS * 8 + 4096;     // + the A exponents of the tile + the question's mixing vector
+  constexpr int ring = 3 * stage + ROWS * 32 + 4096;    // + the fold factors of the tile's rows + the question's mixing vector
   constexpr int epi = ROWS * 132 * 4 + 2 * 16 * ROWS * 4 + ROWS * 4 + 16 * 32 * 16;
   return ring > epi ? ring : epi;
 }
@@ -64,6 +64,7 @@ template <int RT, int BP, int EP, bool COLSUM>
 __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
+  if (p.dbg & 256) return;
   constexpr int G_THREADS = 512;
   constexpr int G_BN = 128;
   constexpr int G_LDT = G_BN + 4;
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   constexpr int B_PLANE = 4 * B_GS;
   constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
   constexpr int A_SLOTS = 2 * 4 * ROWS;
-  constexpr int A_IT = (A_SLOTS + G_THREADS - 1) / G_THREADS;
+  constexpr int NA = A_SLOTS / 64;                   // DMA instructions per slice for A (one KiB each); wave w issues w, w + 8, ...
+  constexpr int A_IT = (NA + 7) / 8;
   constexpr int HT = (RT + 1) / 2;
 
   const int nblk = gridDim.x;
@@ -103,17 +105,9 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   const int nk = p.K >> 5;
   const int nkb = p.K >> 7;                          // 128-wide K blocks = exponent blocks of A
 
-  // ---- exponents of this tile's A rows -> LDS; weight exponent
-  int8_t* sE = reinterpret_cast<int8_t*>(lds + 3 * STAGE);         // [ROWS][8]
-  {
-    const int8_t* eA = p.A.exps();
-    const int acb = p.A.cb();
-    for (int i = tid; i < ROWS * acb; i += G_THREADS) {
-      const int r = i / acb, k = i - r * acb;
-      sE[r * 8 + k] = eA[(grow0 + r) * acb + k];                   // rows past the tensor end lie in the pad rows
-    }
-  }
-  float* sY = reinterpret_cast<float*>(lds + 3 * STAGE + ROWS * 8);   // B_YMIX_ROW: y_b[K]
+  // ---- weight exponent; fold factors of this tile's rows (below, once it is known)
+  float* sF = reinterpret_cast<float*>(lds + 3 * STAGE);           // [K / 128][ROWS]: 2^-(eA[row][kb] + eB)
+  float* sY = reinterpret_cast<float*>(lds + 3 * STAGE + ROWS * 32);  // B_YMIX_ROW: y_b[K]
   int eB = 0;
   if (BP == B_PLAIN) {
     eB = *p.w_exp;
@@ -134,80 +128,104 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
     __syncthreads();
   }
   const float sB = h2_pow2(eB);
+  {
+    const int8_t* eA = p.A.exps();
+    const int acb = p.A.cb();
+    for (int i = tid; i < ROWS * acb; i += G_THREADS) {
+      const int r = i / acb, k = i - r * acb;                      // rows past the tensor end lie in the pad rows
+      sF[k * ROWS + r] = h2_unscale((int)eA[(grow0 + r) * acb + k], eB);
+    }
+  }
 
   f32x4 acc[HT][2], tot[HT][2];
 #pragma unroll
   for (int t = 0; t < HT; ++t) acc[t][0] = acc[t][1] = tot[t][0] = tot[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging: pure copies, lane-linear in LDS (slot f of a stage sits at byte 16 f)
+  // ---- staging: slot f of a stage sits at byte 16 f; DMA instruction u covers slots 64 u .. 64 u + 63
   const size_t Rp = p.A.Rp();
   const size_t a_kstep = 4 * Rp * 16;                // bytes per K slice in a plane
   const char* a_base = p.A.base;
-  uint32_t a_off[A_IT];                              // byte offset of this thread's slot in slice 0 (both planes < 4 GB)
+  uint32_t a_off[A_IT];                              // byte offset of this lane's slot in slice 0 (both planes < 4 GB)
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int f = min(tid + G_THREADS * i, A_SLOTS - 1);
     const int q = f / ROWS, lrow = f - q * ROWS;     // q = 4 plane + k-group
     a_off[i] = (uint32_t)((q >> 2) * p.A.plane_bytes() + ((size_t)(q & 3) * Rp + grow0 + lrow) * 16);
   }
-  u32x4 ra[A_IT], rb[2];
-  f32x4 rw[2], rw2[2];
+  const int my_na = wave < NA ? (NA - wave + 7) >> 3 : 0;          // this wave's A instructions per slice
+  const int my_n = my_na + (BP == B_PLAIN ? 2 : 4);                // ... plus its share of B (DMA) / its 4 weight loads
+  f32x4 rwa[2][2], rwb[2][2];                                      // B_YMIX: raw W1a / W1b of a slice, two register sets
   const int yg = lane >> 4;                                        // B_YMIX: this thread's k-group and column
   const int ycolm = (lane & 15) + 16 * (tid >> 6);
   float ycol = 0.f;
   if (BP == B_YMIX_COL) ycol = p.y[(size_t)b * p.ldy + cb * G_BN + ycolm];
 
-  auto load_tiles = [&](int kt) {
+  // B_YMIX: the raw fp32 weights of a slice -> register set S.  Inline assembly like the DMA and for the same reason: a
+  // load the compiler knows about is waited for with a vmcnt that ignores the DMA instructions queued behind it, i.e. with
+  // far too small a count -- it would drain the slice that was just requested.  The registers are handed back to the
+  // compiler by settle_w(), behind an explicit wait that counts everything.
+  auto load_w = [&](auto set_c, int kt) {
+    constexpr int S = decltype(set_c)::value;
+    const size_t off = ((size_t)kt * p.Nout + cb * G_BN + ycolm) * 32 + yg * 8;
+    const float* pa = p.Wt + off;
+    const float* pb = p.Wt2 + off;
+    f32x4 a0, a1, b0, b1;                                          // (plain names: an asm operand cannot name a captured array)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a0) : "v"(pa) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(a1) : "v"(pa) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b0) : "v"(pb) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(b1) : "v"(pb) : "memory");
+    rwa[S][0] = a0; rwa[S][1] = a1; rwb[S][0] = b0; rwb[S][1] = b1;
+  };
+  auto settle_w = [&](auto set_c, int n) {                         // at most n younger VMEM instructions may still fly
+    constexpr int S = decltype(set_c)::value;
+    wait_vmcnt_n(n);
+    f32x4 a0 = rwa[S][0], a1 = rwa[S][1], b0 = rwb[S][0], b1 = rwb[S][1];
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+    rwa[S][0] = a0; rwa[S][1] = a1; rwb[S][0] = b0; rwb[S][1] = b1;
+  };
+  auto issue = [&](int kt) {                                       // DMA of slice kt into ring stage kt % 3
+    char* dA = lds + (kt % 3) * STAGE;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_base + (size_t)kt * a_kstep + a_off[i]);
+    for (int i = 0; i < A_IT; ++i)
+      if (wave + 8 * i < NA) dma16b(a_base + (size_t)kt * a_kstep + a_off[i], dA + (wave + 8 * i) * 1024);
     if (BP == B_PLAIN) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int f = tid + G_THREADS * i;                         // plane i, k-group (f >> 7) & 3, column f & 127
-        rb[i] = *reinterpret_cast<const u32x4*>(p.Wh + ((((size_t)kt * 2 + i) * 4 + ((f >> 7) & 3)) * p.Nout + cb * G_BN + (f & 127)) * 16);
-      }
-    } else {
-      const size_t off = ((size_t)kt * p.Nout + cb * G_BN + ycolm) * 32 + yg * 8;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        rw[h] = *reinterpret_cast<const f32x4*>(p.Wt + off + 4 * h);
-        rw2[h] = *reinterpret_cast<const f32x4*>(p.Wt2 + off + 4 * h);
+        dma16b(p.Wh + ((((size_t)kt * 2 + i) * 4 + ((f >> 7) & 3)) * p.Nout + cb * G_BN + (f & 127)) * 16,
+               dA + 2 * A_PLANE + (wave + 8 * i) * 1024);
       }
     }
   };
-  auto store_tiles = [&](int buf, int kt) {
-    char* dA = lds + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i)
-      if (tid + G_THREADS * i < A_SLOTS) *reinterpret_cast<u32x4*>(dA + (tid + G_THREADS * i) * 16) = ra[i];
-    char* dB = dA + 2 * A_PLANE;
-    if (BP == B_PLAIN) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(dB + (tid + G_THREADS * i) * 16) = rb[i];
-    } else {
-      float x[8];
-      f32x4 ry[2];
-      if (BP == B_YMIX_ROW) {
-        ry[0] = *reinterpret_cast<const f32x4*>(sY + (kt << 5) + yg * 8);
-        ry[1] = *reinterpret_cast<const f32x4*>(sY + (kt << 5) + yg * 8 + 4);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        // ROW: B_eff[k][j] = y[b][k] W1a[k][j] + W1b[k][j]     (ops.py:703,718 folded into the weights)
-        // COL: B_eff[k][j] = y[b][j] W1a^T[k][j] + W1b^T[k][j] (backward-data of the same product)
-        const float yy = (BP == B_YMIX_ROW) ? ry[e >> 2][e & 3] : ycol;
-        x[e] = fmaf(rw[e >> 2][e & 3], yy, rw2[e >> 2][e & 3]) * sB;
-      }
-      u32x4 hi, lo;
-      h2_split8(x, hi, lo);
-      char* d = dB + yg * B_GS + ycolm * 16;
-      *reinterpret_cast<u32x4*>(d) = hi;
-      *reinterpret_cast<u32x4*>(d + B_PLANE) = lo;
+  auto store_w = [&](auto set_c, int kt) {                         // B_YMIX: mix, scale, split -> ring stage kt % 3
+    constexpr int S = decltype(set_c)::value;
+    char* dB = lds + (kt % 3) * STAGE + 2 * A_PLANE;
+    float x[8];
+    f32x4 ry[2];
+    if (BP == B_YMIX_ROW) {
+      ry[0] = *reinterpret_cast<const f32x4*>(sY + (kt << 5) + yg * 8);
+      ry[1] = *reinterpret_cast<const f32x4*>(sY + (kt << 5) + yg * 8 + 4);
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // ROW: B_eff[k][j] = y[b][k] W1a[k][j] + W1b[k][j]     (ops.py:703,718 folded into the weights)
+      // COL: B_eff[k][j] = y[b][j] W1a^T[k][j] + W1b^T[k][j] (backward-data of the same product)
+      const float yy = (BP == B_YMIX_ROW) ? ry[e >> 2][e & 3] : ycol;
+      x[e] = fmaf(rwa[S][e >> 2][e & 3], yy, rwb[S][e >> 2][e & 3]) * sB;
+    }
+    u32x4 hi, lo;
+    h2_split8(x, hi, lo);
+    char* d = dB + yg * B_GS + ycolm * 16;
+    *reinterpret_cast<u32x4*>(d) = hi;
+    *reinterpret_cast<u32x4*>(d + B_PLANE) = lo;
   };
 
   // lane (i = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7 of row / column i for both operands
-  auto compute = [&](int buf) {
+  // first: the slice opens a 128-wide K block -- its first product per tile starts from zero (C = 0 costs nothing on the
+  // MFMA) instead of from an accumulator cleared by the fold
+  auto compute = [&](int buf, auto first_c) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const char* sA = lds + buf * STAGE + (lane >> 4) * A_GS + (t0 * 16 + (lane & 15)) * 16;
     const char* sB_ = lds + buf * STAGE + 2 * A_PLANE + (lane >> 4) * B_GS + (cgp * 32 + (lane & 15)) * 16;
     u32x4 bf[2][2];
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
       for (int c = 0; c < 2; ++c) bf[pl][c] = *reinterpret_cast<const u32x4*>(sB_ + pl * B_PLANE + c * 256);
     // smallest terms first: A_lo x B_hi ; A_hi x {B_lo, B_hi}
     // row tiles in groups of TG so that only TG A fragments are live at a time (the kernel runs at the 256-register cap)
-    constexpr int TG = 4;
+    constexpr int TG = BP == B_PLAIN ? 4 : 1;        // (the y-mixing kernels also hold two sets of raw weights)
 #pragma unroll
     for (int ap = 1; ap >= 0; --ap) {
 #pragma unroll
@@ -234,48 +252,89 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
           for (int u = 0; u < TG; ++u) {
             const int t = tb + u;
             if (t < HT && (t < HT - 1 || t < my_nt)) {
-              acc[t][0] = mfma_f16(af[u], bf[bp][0], acc[t][0]);
-              acc[t][1] = mfma_f16(af[u], bf[bp][1], acc[t][1]);
+              acc[t][0] = mfma_f16(af[u], bf[bp][0], (FIRST && ap == 1) ? zero : acc[t][0]);
+              acc[t][1] = mfma_f16(af[u], bf[bp][1], (FIRST && ap == 1) ? zero : acc[t][1]);
             }
           }
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 3");       // 20 wait states: more than any MFMA-result -> VALU-read distance
+    __builtin_amdgcn_sched_barrier(0);
   };
   // end of a 128-wide K block: running sum += block sum * 2^-(eA[row][kb] + eB)
   auto fold = [&](int kb) {
 #pragma unroll
-    for (int t = 0; t < HT; ++t)
+    for (int t = 0; t < HT; ++t) {
+      const f32x4 f = *reinterpret_cast<const f32x4*>(sF + kb * ROWS + min((t0 + t) * 16, ROWS - 16) + (lane >> 4) * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int lrow = (t0 + t) * 16 + (lane >> 4) * 4 + e;
-        const float f = h2_unscale((int)sE[min(lrow, ROWS - 1) * 8 + kb], eB);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          tot[t][c][e] = fmaf(acc[t][c][e], f, tot[t][c][e]);
-          acc[t][c][e] = 0.f;
-        }
-      }
+      for (int c = 0; c < 2; ++c) tot[t][c] += acc[t][c] * f;
+    }
   };
+  using FirstT = std::integral_constant<bool, true>;
+  using FirstF = std::integral_constant<bool, false>;
+  // The K loop runs in groups of the four slices of one 128-wide block, written out: the zero-C variant of the first slice
+  // and the accumulating variant of the other three must NOT meet in a control-flow join.  (At a join the accumulators pass
+  // through copies -- v_mov reads of MFMA results, which need software wait states on this hardware -- and the compiler's
+  // hazard pass was seen to leave them out there: rows 4g, 4g+1 of every tile came out stale.)  compute() also ends in
+  // enough wait states for any vector-ALU read of its results, whatever follows it.
 
-  load_tiles(0);
-  store_tiles(0, 0);
-  if (nk > 1) { load_tiles(1); store_tiles(1, 1); }
-  __syncthreads();
-  const bool do_load = !(p.dbg & 32), do_store = !(p.dbg & 2), do_compute = !(p.dbg & 64);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 2 < nk && do_load) load_tiles(kt + 2);
-    if (do_compute) compute(kt % 3);
-    if ((kt & 3) == 3) fold(kt >> 2);
-    __syncthreads();                 // every wave is done with stage (kt + 2) % 3 (read in iteration kt - 1)
-    if (kt + 2 < nk && do_store) store_tiles((kt + 2) % 3, kt + 2);
+  const bool do_stage = !(p.dbg & 32), do_compute = !(p.dbg & 64);
+  if (BP == B_PLAIN) {
+    issue(0);
+    if (nk > 1) { issue(1); wait_vmcnt_n(my_n); } else wait_vmcnt<0>();
+    __syncthreads();                   // slice 0 has landed, for every wave's share of it
+    if (p.dbg & 512) { wait_vmcnt<0>(); return; }
+    auto step = [&](auto first_c, int kt) {
+      if (kt + 2 < nk && do_stage) issue(kt + 2);       // ring stage (kt + 2) % 3 was last read in iteration kt - 1
+      if (do_compute) compute(kt % 3, first_c);
+      if ((kt & 3) == 3) fold(kt >> 2);
+      if (kt + 2 < nk) wait_vmcnt_n(my_n); else wait_vmcnt<0>();     // slice kt + 1 has landed; slice kt + 2 may fly
+      __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 4) {
+      step(FirstT{}, kt);
+      step(FirstF{}, kt + 1);
+      step(FirstF{}, kt + 2);
+      step(FirstF{}, kt + 3);
+    }
+  } else {
+    // the mixed weights pass through registers, two slices ahead like the DMA (two register sets, the loop runs in pairs;
+    // K / 32 is a multiple of 4).  Iteration kt: request slice kt + 2 (weights, then A rows); wait until the weights of slice
+    // kt + 1 are in (everything younger -- A rows of kt + 1, all of kt + 2 -- may still fly); mix / split / store them as
+    // ordinary code next to the MFMAs of slice kt, so the scheduler can interleave the two; wait for the A rows of kt + 1
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_w(S0{}, 0);
+    issue(0);
+    if (nk > 1) { load_w(S1{}, 1); issue(1); settle_w(S0{}, my_n); } else settle_w(S0{}, 0);
+    store_w(S0{}, 0);
+    __syncthreads();
+    auto iter = [&](auto cur_c, auto nxt_c, auto first_c, int kt) {   // cur: set of slice kt (and kt + 2), nxt: of slice kt + 1
+      const bool more2 = kt + 2 < nk, more1 = kt + 1 < nk;
+      if (more2 && do_stage) { load_w(cur_c, kt + 2); issue(kt + 2); }
+      if (more1) {
+        settle_w(nxt_c, more2 ? my_n + my_na : my_na);
+        if (do_stage) store_w(nxt_c, kt + 1);                       // ring stage (kt + 1) % 3 was last read in iteration kt - 2
+      }
+      if (do_compute) compute(kt % 3, first_c);
+      if ((kt & 3) == 3) fold(kt >> 2);
+      if (more2) wait_vmcnt_n(my_n); else wait_vmcnt<0>();
+      __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 4) {
+      iter(S0{}, S1{}, FirstT{}, kt);
+      iter(S1{}, S0{}, FirstF{}, kt + 1);
+      iter(S0{}, S1{}, FirstF{}, kt + 2);
+      iter(S1{}, S0{}, FirstF{}, kt + 3);
+    }
   }
   if (p.dbg & 1) {
     if (tot[0][0][0] == 123.456f) p.out.exps()[0] = 1;
     return;
   }
   (void)nkb;
-  __syncthreads();
 
   // ---- epilogue, step 1: accumulators -> row-major LDS tile (16x16 map: col = lane & 15, row = (lane >> 4) * 4 + reg)
   float* T = smem;

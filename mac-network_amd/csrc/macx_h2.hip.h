@@ -98,6 +98,19 @@ __device__ __forceinline__ void h2_join4(const u32x2 hi, const u32x2 lo, float i
   }
 }
 
+// 16-byte global -> LDS DMA (global_load_lds_dwordx4): the 64 lanes of a wave fetch 64 x 16 B from per-lane global
+// addresses into LDS at lds_wave_base + lane * 16.  No VGPR round trip, no ds_write; counted by vmcnt.
+// Issued as inline assembly ON PURPOSE: the compiler's wait-count pass answers an LDS-DMA it knows about with
+// s_waitcnt vmcnt(0) in front of the next LDS read (it cannot prove the two do not alias), which drains the whole
+// prefetch queue every stage.  Written this way the queue depth is ours: every consumer of a stage must sit behind
+// wait_vmcnt<N>() + a workgroup barrier placed by hand.  (Loads the compiler does know about can only over-wait:
+// vmcnt retires in order.)
+__device__ __forceinline__ void dma16b(const char* g, char* lds_wave_base) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+}
+
 __device__ __forceinline__ f32x4 mfma_f16(const u32x4 a, const u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }

@@ -173,28 +173,38 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
 // by every step (a_mod = its rows: the undropped knowledge base).
 //
 // The contraction reduces over ROWS while an H2 slot holds 8 consecutive COLUMNS of one row, so the operands need a
-// transpose on the way to the MFMA fragments.  It is done by the LDS: the producer waves copy slots exactly as they lie in
-// memory -- lanes along rows, a wave-instruction moves two contiguous 512-byte runs -- into a row-major [32 rows][columns]
-// fp16 image per operand and plane, scaling each row to the tensor family's common exponent with v_pk_mul_f16 by an exact
-// power of two on the way (rows far below the largest lose low bits exactly as their share of the sum warrants), and the
-// consumer waves read their fragments with ds_read_b64_tr_b16, the gfx950 transpose read: within 16 lanes, lane t passes
-// the address of chunk (row t/4, columns 4(t%4)..+3) and receives column t of the four rows -- four consecutive reduction
-// rows of one output row/column, i.e. half an MFMA fragment.  No vector-ALU transpose, no strided global access.
-//   workgroup: 128 x (128 JW) output tile, 8 waves: 0-3 produce, 4-7 consume (wave tile 64 x 64 JW); 32 reduction rows per
-//   stage, three LDS stages, loads two stages ahead in registers, one barrier per stage.
+// transpose on the way to the MFMA fragments.  It is done by the LDS: slots travel exactly as they lie in memory, by
+// LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land lane-linear = one [2 row halves][16 rows][16 columns] column tile
+// of the image below), and the waves read their fragments with ds_read_b64_tr_b16, the gfx950 transpose read: within 16
+// lanes, lane t passes the address of chunk (row t/4, columns 4(t%4)..+3) and receives column t of the four rows -- four
+// consecutive reduction rows of one output row/column, i.e. half an MFMA fragment.  No registers, no vector ALU and no
+// strided global access in the staging.
+//   Rows are brought to the tensor family's common exponents on the way from LDS to the MFMA: ONE combined factor per
+//   (row, 128-column block of A, 128-column block of G), 2^(EA - ea_row + EG - eg_row) as fp16 (0 past the last row), written
+//   by wgrad_h2_factors_kernel before the contraction and fetched per stage by a 4-byte LDS-DMA; it multiplies the G fragments
+//   only (two v_pk_mul_f16 per transpose read).  Rows far below the largest lose low bits exactly as their share of the sum
+//   warrants.
+//   workgroup: (128 KW) x (128 JW) output tile, all 8 waves multiply (2 x 4, wave tile 64 KW x 32 JW); 32 reduction rows per
+//   stage.  The kernel is bound by the L2 -> LDS traffic of its operands (every A column is read by Jd / (128 JW) workgroups,
+//   every G column by Kd / (128 KW)), so the tile is as large as the accumulators allow: 256 x 256 (128 registers per lane,
+//   64 KB stages, ring of 2) when both dimensions allow, else ring of 3 (48 KB stages) or 4; the wait for a stage is an
+//   explicit s_waitcnt vmcnt(n) that leaves the younger stages' DMA in flight (see dma16b).
 // Determinism as in macx_gemm_tn.cuh: a workgroup owns one (split, tile) slab, slabs are summed in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------
 struct TnH2P {
   int M;                 // reduction rows over all tensors
   int Kd, Jd;            // output dims (multiples of 128)
-  int nsplit, rows_per_split;
+  int nsplit, rows_per_split;                    // rows_per_split % 32 == 0: a stage never straddles two splits
   int R;                 // rows per H2 tensor
   const char* A; size_t a_stride; int a_mod;     // a_mod > 0: A row of reduction row m is m % a_mod of tensor 0
   const char* G; size_t g_stride;
   const int* ecomA;      // [Kd/128] common exponents (qmin_reduce)
   const int* ecomG;      // [Jd/128]
+  uint16_t* ftab;        // [Kd/128][Jd/128][Mpad] combined row factors, Mpad = wgrad_h2_mpad(M)
   float* part;           // [nsplit][Kd][Jd]
+  int dbg;               // measurement knobs (macx_debug_set(1, mask)): 1024 skip fragments + MFMAs, 2048 skip the in-loop DMA
 };
+__host__ __device__ inline size_t wgrad_h2_mpad(size_t M) { return (M + 63) & ~(size_t)31; }       // a stage starting below M stays inside
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // half an MFMA fragment: 4 consecutive reduction rows of column (lane & 15), see the header comment
@@ -208,23 +218,54 @@ __device__ __forceinline__ u32x2 tr_read(const char* lds_addr) {
 // conflict-free pattern of the instruction -- and gives lane (i, g) column i of rows 4g..4g+3; the two row halves make the
 // lane's 8-element fragment (reduction rows {4g+e} and {16+4g+e}: any assignment works as long as both operands share it).
 constexpr int WH_APL = 8 * 2 * 512;         // one plane of a 128-column image
-__device__ __forceinline__ int wh_slot_off(int kg, int r) {      // byte offset of slot (8-column group kg, stage row r) in a plane
-  return ((kg >> 1) * 2 + (r >> 4)) * 512 + (r & 15) * 32 + (kg & 1) * 16;
-}
-template <int JW> constexpr int wh_stage_bytes() { return 2 * WH_APL + 2 * JW * WH_APL; }
+template <int KW, int JW> constexpr int wh_stage_bytes() { return 2 * (KW + JW) * WH_APL + 256; }   // + the stage's factors
+template <int KW, int JW> constexpr int wh_ring() { return KW + JW == 4 ? 2 : (KW + JW == 3 ? 3 : 4); }
 
-template <int JW>
+// one thread per reduction row: the fp16 factor of every (A block, G block) pair
+__global__ __launch_bounds__(256) void wgrad_h2_factors_kernel(TnH2P p) {
+  const size_t mpad = wgrad_h2_mpad((size_t)p.M);
+  const size_t m = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= mpad) return;
+  const int acb = p.Kd >> 7, gcb = p.Jd >> 7;
+  const H2View a0{const_cast<char*>(p.A), p.R, p.Kd}, g0{const_cast<char*>(p.G), p.R, p.Jd};
+  if (m >= (size_t)p.M) {
+    for (int i = 0; i < acb * gcb; ++i) p.ftab[(size_t)i * mpad + m] = 0;
+    return;
+  }
+  const int ti = (int)(m / p.R), rr = (int)(m - (size_t)ti * p.R);
+  const int ar = p.a_mod ? (int)(m % p.a_mod) : rr;
+  const int8_t* ea = reinterpret_cast<const int8_t*>(p.A + (p.a_mod ? 0 : (size_t)ti * p.a_stride) + 2 * a0.plane_bytes()) + (size_t)ar * acb;
+  const int8_t* eg = reinterpret_cast<const int8_t*>(p.G + (size_t)ti * p.g_stride + 2 * g0.plane_bytes()) + (size_t)rr * gcb;
+  for (int k = 0; k < acb; ++k) {
+    const int da = p.ecomA[k] - (int)ea[k];
+    for (int j = 0; j < gcb; ++j)
+      p.ftab[((size_t)k * gcb + j) * mpad + m] = (uint16_t)(pk_pow2_f16(da + p.ecomG[j] - (int)eg[j]) & 0xFFFFu);
+  }
+}
+
+__device__ __forceinline__ void dma4b(const char* g, char* lds_wave_base) {     // 64 lanes x 4 B, lane-linear (see dma16b)
+  const uint32_t l = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+}
+
+template <int KW, int JW>
 __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
+  constexpr int KT = KW * T_TILE;
   constexpr int JT = JW * T_TILE;
+  constexpr int APL = KW * WH_APL;
   constexpr int GPL = JW * WH_APL;
-  constexpr int STAGE = wh_stage_bytes<JW>();
-  constexpr int NCOL = 32 + 32 * JW;          // 32-row slot columns per stage: A (2 planes x 16) then G (2 planes x 16 JW)
-  constexpr int NLD = NCOL / 8;               // per producer lane
+  constexpr int DATA = 2 * APL + 2 * GPL;
+  constexpr int STAGE = wh_stage_bytes<KW, JW>();
+  constexpr int RING = wh_ring<KW, JW>();
+  constexpr int NI = 2 * (KW + JW);           // data DMA instructions per wave and stage (16 (KW + JW) in all)
+  constexpr int NR = 4 * KW;                  // 16-row tiles of a wave
+  constexpr int NC = 2 * JW;                  // 16-column tiles of a wave
 
   const int ntj = p.Jd / JT;
-  const int ntk = p.Kd / T_TILE;
+  const int ntk = p.Kd / KT;
   const int ntile = ntj * ntk;
   const int nblk = gridDim.x;
   int v = blockIdx.x;
@@ -235,6 +276,9 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;    // 64 KW rows (k) x 32 JW columns (j) of the tile
+  const int aq = KW == 2 ? wr : 0;            // the 128-column block of A this wave's rows lie in
+  const int gq = JW == 2 ? (wc >> 1) : 0;     // the 128-column block of G this wave's columns lie in
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
   const int nchunk = (m_end - m_begin + 31) >> 5;
@@ -242,168 +286,144 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
   const H2View a0{const_cast<char*>(p.A), p.R, p.Kd}, g0{const_cast<char*>(p.G), p.R, p.Jd};
   const size_t Rp = a0.Rp();
   const size_t apb = a0.plane_bytes(), gpb = g0.plane_bytes();
-  const int acb = a0.cb(), gcb = g0.cb();
+  const int gcb = g0.cb();
+  const size_t mpad = wgrad_h2_mpad((size_t)p.M);
 
-  if (wave < 4) {
-    // ================= producer waves: slots as they lie in memory -> common exponent -> row-major LDS image =================
-    const int r = tid & 31;                    // this lane's row of every stage
-    const int c0 = tid >> 5;                   // its slot columns are c0 + 8 i
-    const int eA = p.ecomA[tk];
-    int eG[JW];
+  f32x4 acc[NR][NC];
 #pragma unroll
-    for (int q = 0; q < JW; ++q) eG[q] = p.ecomG[tj * JW + q];
-    u32x4 rv[3][NLD];
-    int ea_r[3], eg_r[3][JW];      // raw row exponents (-128: row past the end); turned into factors when the stage is stored,
-                                   // so that issuing a stage's loads never waits for them
-    auto load = [&](auto slot_c, int ch) __attribute__((always_inline)) {
-      constexpr int SL = decltype(slot_c)::value;
-      const int m = m_begin + ch * 32 + r;
-      const bool ok = m < m_end;
-      const int mc = min(m, p.M - 1);
-      const int ti = mc / p.R, rr = mc - ti * p.R;
-      const int ar = p.a_mod ? (mc % p.a_mod) : rr;
-      const char* ab = p.A + (p.a_mod ? 0 : (size_t)ti * p.a_stride);
-      const char* gb = p.G + (size_t)ti * p.g_stride;
+  for (int t = 0; t < NR; ++t)
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int c = c0 + 8 * i;              // compile-time operand per i: columns [0,32) are A, the rest G
-        if (8 * i < 32) {
-          const int pl = c >> 4, kg = c & 15;
-          rv[SL][i] = *reinterpret_cast<const u32x4*>(ab + pl * apb + ((size_t)(tk * 16 + kg) * Rp + ar) * 16);
-        } else {
-          const int cg = c - 32;
-          const int pl = cg / (16 * JW), kg = cg - pl * 16 * JW;
-          rv[SL][i] = *reinterpret_cast<const u32x4*>(gb + pl * gpb + ((size_t)(tj * 16 * JW + kg) * Rp + rr) * 16);
-        }
+    for (int c = 0; c < NC; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: data instruction u of a stage (u = NI wave .. NI wave + NI - 1) fills one column tile: u < 16 KW -> plane
+  //      u / (8 KW), tile u % (8 KW) of A; else plane, tile of G likewise.  Lane q of it copies slot (row half q / 32,
+  //      row (q % 32) / 2, 8-column group 2 tile + q % 2), the lane-linear order of the [half][row][16 columns] tile.
+  //      Wave 0 also fetches the stage's factors: lane l < 16 KW JW -> fp16 pair l % 16 of table (l / 16) = (A block, G block).
+  const int sl_m = (lane >> 5) * 16 + ((lane & 31) >> 1), sl_kg = lane & 1;
+  const int ft_t = lane < 16 * KW * JW ? (lane >> 4) : 0;
+  const uint16_t* ft_src = p.ftab + ((size_t)(tk * KW + ft_t / JW) * gcb + tj * JW + ft_t % JW) * mpad + (lane < 16 * KW * JW ? (lane & 15) * 2 : 0);
+  auto issue = [&](int s_raw) __attribute__((always_inline)) {
+    const int ch = min(s_raw, nchunk - 1);
+    const int m0 = m_begin + ch * 32;
+    const int mc = min(m0 + sl_m, p.M - 1);               // rows past the end re-read the last row (finite data, factor 0)
+    const int ti = mc / p.R, rr = mc - ti * p.R;
+    const int ar = p.a_mod ? (mc % p.a_mod) : rr;
+    const char* ab = p.A + (p.a_mod ? 0 : (size_t)ti * p.a_stride);
+    const char* gb = p.G + (size_t)ti * p.g_stride;
+    char* st = lds + (s_raw % RING) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int u = wave * NI + j;
+      if (u < 16 * KW) {
+        const int pl = u / (8 * KW), ct = u - pl * 8 * KW;
+        dma16b(ab + pl * apb + ((size_t)(tk * 16 * KW + 2 * ct + sl_kg) * Rp + ar) * 16, st + pl * APL + ct * 1024);
+      } else {
+        const int ug = u - 16 * KW;
+        const int pl = ug / (8 * JW), ct = ug - pl * 8 * JW;
+        dma16b(gb + pl * gpb + ((size_t)(tj * 16 * JW + 2 * ct + sl_kg) * Rp + rr) * 16, st + 2 * APL + pl * GPL + ct * 1024);
       }
-      const int8_t* eap = reinterpret_cast<const int8_t*>(ab + 2 * apb) + (size_t)ar * acb + tk;
-      const int8_t* egp = reinterpret_cast<const int8_t*>(gb + 2 * gpb) + (size_t)rr * gcb + tj * JW;
-      ea_r[SL] = *eap;
-#pragma unroll
-      for (int q = 0; q < JW; ++q) eg_r[SL][q] = egp[q];
-      if (!ok) {
-        ea_r[SL] = 1000;
-#pragma unroll
-        for (int q = 0; q < JW; ++q) eg_r[SL][q] = 1000;
-      }
-    };
-    auto store = [&](auto slot_c, int ch) __attribute__((always_inline)) {
-      constexpr int SL = decltype(slot_c)::value;
-      char* st = lds + (ch % 3) * STAGE;
-      const uint32_t fa_ = pk_pow2_f16(eA - ea_r[SL]);              // 1000 -> 0: a row past the end
-      uint32_t fg_[JW];
-#pragma unroll
-      for (int q = 0; q < JW; ++q) fg_[q] = pk_pow2_f16(eG[q] - eg_r[SL][q]);
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int c = c0 + 8 * i;
-        u32x4 w = rv[SL][i];
-        uint32_t f;
-        char* d;
-        if (8 * i < 32) {
-          const int pl = c >> 4, kg = c & 15;
-          f = fa_;
-          d = st + pl * WH_APL + wh_slot_off(kg, r);
-        } else {
-          const int cg = c - 32;
-          const int pl = cg / (16 * JW), kg = cg - pl * 16 * JW;
-          f = fg_[JW == 1 ? 0 : (kg >> 4)];
-          d = st + 2 * WH_APL + pl * GPL + wh_slot_off(kg, r);
-        }
-#pragma unroll
-        for (int h = 0; h < 4; ++h) w[h] = f ? pk_mul_f16(w[h], f) : 0u;      // f == 0: a row past the end (its slot may hold anything)
-        *reinterpret_cast<u32x4*>(d) = w;
-      }
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2 = std::integral_constant<int, 2>;
-    // LDS stage ch is written during iteration ch - 2 from registers loaded three iterations before that: three register
-    // sets keep the loads of three stages in flight (HBM latency under a full-chip stream is several stage times)
-    load(S0{}, 0); load(S1{}, 1);
-    store(S0{}, 0); store(S1{}, 1);
-    load(S2{}, 2); load(S0{}, 3); load(S1{}, 4);
-    __syncthreads();
-    const int nloop = (nchunk + 2) / 3 * 3;     // whole groups of three iterations; stages past the end are zero rows
-#pragma unroll 1
-    for (int ch = 0; ch < nloop; ch += 3) {
-      store(S2{}, ch + 2); load(S2{}, ch + 5); __syncthreads();
-      store(S0{}, ch + 3); load(S0{}, ch + 6); __syncthreads();
-      store(S1{}, ch + 4); load(S1{}, ch + 7); __syncthreads();
     }
-  } else {
-    // ================= consumer waves: transpose-read fragments -> MFMA; wave tile 64 x (64 JW) =================
-    const int cw = wave - 4;
-    const int wr = cw >> 1, wc = cw & 1;
-    constexpr int NC = 4 * JW;
-    f32x4 acc[4][NC];
+    if (wave == 0) dma4b(reinterpret_cast<const char*>(ft_src + m0), st + DATA);
+  };
+  auto frag = [&](const char* tile) __attribute__((always_inline)) {       // the two row halves of one column tile
+    const u32x2 lo = tr_read(tile + lane * 8), hi = tr_read(tile + 512 + lane * 8);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
+  // smallest terms first: A_lo x G_hi ; A_hi x {G_lo, G_hi}
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const char* sa = lds + buf * STAGE + (wr * NR) * 1024;
+    const char* sg = lds + buf * STAGE + 2 * APL + (wc * NC) * 1024;
+    // this lane's reduction rows: 4 g + {0..3} of each row half -> two packed factor pairs per half
+    const uint16_t* ft = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + DATA) + (aq * JW + gq) * 32 + (lane >> 4) * 4;
+    const u32x2 f0 = *reinterpret_cast<const u32x2*>(ft), f1 = *reinterpret_cast<const u32x2*>(ft + 16);
+    u32x4 gf[2][NC];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto frag = [&](const char* tile) __attribute__((always_inline)) {       // the two row halves of one column tile
-      const u32x2 lo = tr_read(tile + lane * 8), hi = tr_read(tile + 512 + lane * 8);
-      return u32x4{lo[0], lo[1], hi[0], hi[1]};
-    };
-    auto compute = [&](int buf) __attribute__((always_inline)) {
-      const char* sa = lds + buf * STAGE + (wr * 4) * 1024;
-      const char* sg = lds + buf * STAGE + 2 * WH_APL + (wc * 4 * JW) * 1024;
-      u32x4 af[2][4];
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[pl][t] = frag(sa + pl * WH_APL + t * 1024);
-      // smallest terms first: G_lo x A_hi ; G_hi x {A_lo, A_hi}
-#pragma unroll
-      for (int bp = 1; bp >= 0; --bp) {
-        u32x4 gf[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) gf[c] = frag(sg + bp * GPL + c * 1024);
-#pragma unroll
-        for (int ap = 1 - bp; ap >= 0; --ap)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) acc[t][c] = mfma_f16(af[ap][t], gf[c], acc[t][c]);
+      for (int c = 0; c < NC; ++c) {
+        u32x4 w = frag(sg + pl * GPL + c * 1024);
+        w[0] = pk_mul_f16(w[0], f0[0]); w[1] = pk_mul_f16(w[1], f0[1]);
+        w[2] = pk_mul_f16(w[2], f1[0]); w[3] = pk_mul_f16(w[3], f1[1]);
+        gf[pl][c] = w;
       }
-    };
+#pragma unroll
+    for (int ap = 1; ap >= 0; --ap) {
+      u32x4 af[NR];
+#pragma unroll
+      for (int t = 0; t < NR; ++t) af[t] = frag(sa + ap * APL + t * 1024);
+#pragma unroll
+      for (int bp = 1 - ap; bp >= 0; --bp)
+#pragma unroll
+        for (int t = 0; t < NR; ++t)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[t][c] = mfma_f16(af[t], gf[bp][c], acc[t][c]);
+    }
+  };
+
+  if (nchunk > 0) {
+    const int my_n = (NI + (wave == 0 ? 1 : 0)) * (RING - 2);     // this wave's DMA instructions of the stages that may stay in flight
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) issue(s);
+    wait_vmcnt_n(my_n);                                   // stage 0 has landed
     __syncthreads();
-    const int nloop = (nchunk + 2) / 3 * 3;     // as the producers: the extra stages multiply zero rows
 #pragma unroll 1
-    for (int ch = 0; ch < nloop; ++ch) {
-      compute(ch % 3);
+    for (int s = 0; s < nchunk; ++s) {
+      if (!(p.dbg & 2048)) issue(s + RING - 1);           // ring slot (s - 1) % RING was last read in iteration s - 1
+      if (!(p.dbg & 1024)) compute(s % RING);
+      wait_vmcnt_n(my_n);                                 // stage s + 1 has landed
       __syncthreads();
     }
-    // a consumer wave's 64 JW columns lie inside one 128-column block of G
-    const float sc = h2_unscale(p.ecomA[tk], p.ecomG[(tj * JT + wc * 64 * JW) >> 7]);
-    float* out = p.part + (size_t)split * p.Kd * p.Jd;
+    wait_vmcnt<0>();                                      // the speculative stages past the end
+  }
+
+  __syncthreads();                                        // every wave's DMA has landed: the ring is about to be reused
+
+  // ---- the slab leaves through LDS, 32 rows of the wave's share at a time (row-major in the wave's own corner of the idle
+  //      ring, read back as float4): a store instruction writes whole 128 / 256-byte row segments instead of 64-byte pieces
+  const float sc = h2_unscale(p.ecomA[tk * KW + aq], p.ecomG[tj * JW + gq]);
+  float* out = p.part + (size_t)split * p.Kd * p.Jd + (size_t)(tk * KT + wr * 16 * NR) * p.Jd + tj * JT + wc * 32 * JW;
+  constexpr int CW = 32 * JW, LDW = CW + 4;
+  constexpr int LPR = CW / 4, RPI = 64 / LPR;             // lanes per row, rows per store instruction
+  float* tw = reinterpret_cast<float*>(lds) + wave * (32 * LDW);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+  for (int tp = 0; tp < NR; tp += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
-          const int j = tj * JT + wc * 64 * JW + c * 16 + (lane & 15);
-          out[(size_t)k * p.Jd + j] = acc[t][c][e] * sc;
-        }
+        for (int e = 0; e < 4; ++e) tw[(u * 16 + (lane >> 4) * 4 + e) * LDW + c * 16 + (lane & 15)] = acc[tp + u][c][e] * sc;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int r = i * RPI + lane / LPR, c4 = (lane % LPR) * 4;
+      *reinterpret_cast<f32x4*>(out + (size_t)(tp * 16 + r) * p.Jd + c4) = *reinterpret_cast<const f32x4*>(tw + r * LDW + c4);
+    }
   }
 }
 
 inline int wgrad_h2_jw(int Jd) { return (Jd % 256 == 0) ? 2 : 1; }
+inline int wgrad_h2_kw(int Kd) { return (Kd % 256 == 0) ? 2 : 1; }
+inline int wgrad_h2_tiles(int Kd, int Jd) { return (Kd / (wgrad_h2_kw(Kd) * T_TILE)) * (Jd / (wgrad_h2_jw(Jd) * T_TILE)); }
 
-template <int JW>
+template <int KW, int JW>
 inline hipError_t wgrad_h2_launch_t(const TnH2P& p, hipStream_t st) {
-  auto kern = wgrad_h2_kernel<JW>;
-  constexpr size_t lds = 3 * wh_stage_bytes<JW>();
+  auto kern = wgrad_h2_kernel<KW, JW>;
+  constexpr size_t lds = (size_t)wh_ring<KW, JW>() * wh_stage_bytes<KW, JW>();
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
-  const int grid = (p.Kd / T_TILE) * (p.Jd / (JW * T_TILE)) * p.nsplit;
+  const int grid = wgrad_h2_tiles(p.Kd, p.Jd) * p.nsplit;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 inline hipError_t wgrad_h2_launch(const TnH2P& p, hipStream_t st) {
-  return wgrad_h2_jw(p.Jd) == 2 ? wgrad_h2_launch_t<2>(p, st) : wgrad_h2_launch_t<1>(p, st);
+  if (p.rows_per_split % 32 != 0 || !p.ftab) return hipErrorInvalidValue;
+  const size_t mpad = wgrad_h2_mpad((size_t)p.M);
+  hipLaunchKernelGGL(wgrad_h2_factors_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int kw = wgrad_h2_kw(p.Kd), jw = wgrad_h2_jw(p.Jd);
+  if (kw == 2) return jw == 2 ? wgrad_h2_launch_t<2, 2>(p, st) : wgrad_h2_launch_t<2, 1>(p, st);
+  return jw == 2 ? wgrad_h2_launch_t<1, 2>(p, st) : wgrad_h2_launch_t<1, 1>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -440,16 +460,13 @@ constexpr int SBH_STAGE = 4 * WH_APL;      // X hi, X lo, dI1 hi, dI1 lo images 
 constexpr int SBH_CW = 8;                  // multiplying waves; dy_part holds SBH_CW / 2 partials per 128 columns
 constexpr int SBH_MAXROWS = 4096;          // rows of one workgroup's questions covered by the factor table (8 KB)
 constexpr int SBH_RING = 4;                // LDS stages: three stages of DMA in flight behind the one being multiplied
-
-__device__ __forceinline__ void dma16b(const char* g, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
+constexpr int SBH_MAXQ = 32;               // questions per workgroup (their y_b[128] shares sit in LDS: 16 KB)
 
 __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
   uint16_t* ftab = reinterpret_cast<uint16_t*>(lds + SBH_RING * SBH_STAGE);      // [questions][nchunk * 32] combined row factors (fp16)
+  float* ytab = reinterpret_cast<float*>(lds + SBH_RING * SBH_STAGE + SBH_MAXROWS * 2);   // [questions][128] y_b of this tile's k rows
 
   const int nt = p.d / T_TILE;
   const int ntile = nt * nt;
@@ -474,26 +491,6 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   const int xcb = p.X.cb(), gcb = p.dI1.cb();
   const int rows_q = nchunk * 32;                         // table rows per question (rows past N hold factor 0)
 
-  // ---- factor table
-  for (int i = tid; i < nq * rows_q; i += 512) {
-    const int qi = i / rows_q, n = i - qi * rows_q;
-    const int b = b_begin + qi;
-    uint16_t f = 0;
-    if (n < p.N) {
-      const size_t row = (size_t)b * p.N + n;
-      const int k = (p.qminX[(size_t)b * xcb + tk] - (int)p.X.exps()[row * xcb + tk]) +
-                    (p.qminG[(size_t)b * gcb + tj] - (int)p.dI1.exps()[row * gcb + tj]);
-      f = (uint16_t)(pk_pow2_f16(k) & 0xFFFFu);
-    }
-    ftab[i] = f;
-  }
-
-  f32x4 accS[4][2], accA[4][2], accB[4][2];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) accS[t][c] = accA[t][c] = accB[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   // ---- staging: instruction u of a stage (u = 4 wave .. 4 wave + 3) fills column tile u & 7 of image u >> 3
   //      (0: X hi, 1: X lo, 2: dI1 hi, 3: dI1 lo); lane q of it copies slot (row half q / 32, row (q % 32) / 2, 8-column group
   //      2 (u & 7) + q % 2), the lane-linear order of the [half][row][16 columns] tile
@@ -514,6 +511,36 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
       dma16b(src, st + im * WH_APL + ct * 1024);
     }
   };
+  if (total > 0) {                                        // in flight while the tables below are built
+    issue(0);
+    issue(1);
+    issue(2);
+  }
+
+  // ---- factor table
+  for (int i = tid; i < nq * rows_q; i += 512) {
+    const int qi = i / rows_q, n = i - qi * rows_q;
+    const int b = b_begin + qi;
+    uint16_t f = 0;
+    if (n < p.N) {
+      const size_t row = (size_t)b * p.N + n;
+      const int k = (p.qminX[(size_t)b * xcb + tk] - (int)p.X.exps()[row * xcb + tk]) +
+                    (p.qminG[(size_t)b * gcb + tj] - (int)p.dI1.exps()[row * gcb + tj]);
+      f = (uint16_t)(pk_pow2_f16(k) & 0xFFFFu);
+    }
+    ftab[i] = f;
+  }
+  for (int i = tid; i < nq * T_TILE; i += 512)
+    ytab[i] = p.y[(size_t)(b_begin + (i >> 7)) * p.d + tk * T_TILE + (i & 127)];
+  float* sctab = ytab + SBH_MAXQ * T_TILE;                // [questions] 2^-(EX + EG): the unit of a question's S_b
+  if (tid < nq) sctab[tid] = h2_unscale(p.qminX[(size_t)(b_begin + tid) * xcb + tk], p.qminG[(size_t)(b_begin + tid) * gcb + tj]);
+
+  f32x4 accS[4][2], accA[4][2], accB[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) accS[t][c] = accA[t][c] = accB[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   auto frag = [&](const char* tile) __attribute__((always_inline)) {
     const u32x2 lo = tr_read(tile + lane * 8), hi = tr_read(tile + 512 + lane * 8);
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -548,9 +575,8 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
           for (int c = 0; c < 2; ++c) accS[t][c] = mfma_f16(af[t], gf[bp][c], accS[t][c]);
     }
   };
-  // this wave's 64 x 32 share of W1a stays in registers for the whole kernel (32 per lane; the staging needs none), and the
-  // 16 entries of y_b a lane needs are requested one question ahead: the per-question fold then has no load to wait for, so it
-  // does not drain the DMA queue
+  // this wave's 64 x 32 share of W1a stays in registers for the whole kernel (32 per lane; the staging needs none) and y_b
+  // comes from the LDS table: the per-question fold has no global load to wait for, so it does not drain the DMA queue
   float w1[4][4][2];
   {
     const float* wb = p.W1a + (size_t)(tk * T_TILE + wr * 64 + (lane >> 4) * 4) * p.d + tj * T_TILE + wc * 32 + (lane & 15);
@@ -560,20 +586,21 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int c = 0; c < 2; ++c) w1[t][e][c] = wb[(size_t)(t * 16 + e) * p.d + c * 16];
-  }
-  f32x4 ynext[4];
-  auto load_y = [&](int b) __attribute__((always_inline)) {
-    const float* yb = p.y + (size_t)min(b, p.B - 1) * p.d + tk * T_TILE + wr * 64 + (lane >> 4) * 4;
+    // a use here makes the compiler wait for these loads NOW; left to itself it waits at the first fold inside the loop,
+    // with vmcnt(0), on every trip -- draining the DMA queue it knows nothing about
 #pragma unroll
-    for (int t = 0; t < 4; ++t) ynext[t] = *reinterpret_cast<const f32x4*>(yb + t * 16);
-  };
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(w1[t][e][c]));
+  }
   // question finished: fold S_b (in units of its two common exponents) into the three outputs and clear it
   auto consume = [&](int b) __attribute__((always_inline)) {
-    const float sc = h2_unscale(p.qminX[(size_t)b * xcb + tk], p.qminG[(size_t)b * gcb + tj]);
+    const float sc = sctab[b - b_begin];
     f32x4 y4[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) y4[t] = ynext[t];
-    load_y(b + 1);
+    for (int t = 0; t < 4; ++t) y4[t] = *reinterpret_cast<const f32x4*>(ytab + (b - b_begin) * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -595,10 +622,6 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   };
 
   if (total > 0) {
-    load_y(b_begin);
-    issue(0);
-    issue(1);
-    issue(2);
     wait_vmcnt<8>();                                      // stage 0 has landed (stages 1, 2 may be in flight)
     __syncthreads();                                      // ... for every wave's share of it, and the factor table is complete
     int qi = 0, qch = 0;
@@ -606,35 +629,47 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
     for (int s = 0; s < total; ++s) {
       if (!(p.dbg & 2048)) issue(s + 3);                  // ring slot (s + 3) % 4 was last read in iteration s - 1
       if (!(p.dbg & 1024)) compute(s % SBH_RING, qi, qch);
+      // stage s + 1 must have landed; this wave's 8 DMA instructions of stages s + 2, s + 3 stay in flight.  The wait sits in
+      // front of the fold so that the fold's dy stores (younger than every DMA; vmcnt retires in order) are not waited for
+      wait_vmcnt<8>();
       if (++qch == nchunk) {
-        if (!(p.dbg & 512)) consume(b_begin + qi);        // (its loads drain the DMA queue too: once per question)
+        if (!(p.dbg & 512)) consume(b_begin + qi);
         qch = 0; ++qi;
       }
-      wait_vmcnt<8>();                                    // stage s + 1 has landed; this wave's 8 instructions of stages s + 2, s + 3 may fly
       __syncthreads();
     }
     wait_vmcnt<0>();                                      // the speculative stages past the end
   }
+  __syncthreads();                                        // ... of every wave: the ring is about to be reused
 
+  // ---- the two slabs leave through LDS: a wave's 64 x 32 share row-major in its own 9 KB of the (now idle) ring, read back
+  //      as float4 so that a store instruction writes 8 rows x 128 contiguous bytes instead of 64-byte pieces
   float* oa = p.dW1a_part + (size_t)group * p.d * p.d;
   float* ob = p.dW1b_part + (size_t)group * p.d * p.d;
+  constexpr int LDW = 36;
+  float* tw = reinterpret_cast<float*>(lds) + wave * (64 * LDW);
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int which = 0; which < 2; ++which) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = tk * T_TILE + wr * 64 + t * 16 + (lane >> 4) * 4 + e;
-        const int j = tj * T_TILE + wc * 32 + c * 16 + (lane & 15);
-        oa[(size_t)k * p.d + j] = accA[t][c][e];
-        ob[(size_t)k * p.d + j] = accB[t][c][e];
-      }
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          tw[(t * 16 + (lane >> 4) * 4 + e) * LDW + c * 16 + (lane & 15)] = which ? accB[t][c][e] : accA[t][c][e];
+    float* o = (which ? ob : oa) + (size_t)(tk * T_TILE + wr * 64) * p.d + tj * T_TILE + wc * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = i * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+      *reinterpret_cast<f32x4*>(o + (size_t)r * p.d + c4) = *reinterpret_cast<const f32x4*>(tw + r * LDW + c4);
+    }
+  }
 }
 
 inline hipError_t sb_h2_launch(const SbH2P& p, hipStream_t st) {
   const int nchunk = (p.N + 31) >> 5;
-  if (p.qpg * nchunk * 32 > SBH_MAXROWS) return hipErrorInvalidValue;
-  constexpr size_t lds = SBH_RING * SBH_STAGE + SBH_MAXROWS * 2;
+  if (p.qpg * nchunk * 32 > SBH_MAXROWS || p.qpg > SBH_MAXQ) return hipErrorInvalidValue;
+  constexpr size_t lds = SBH_RING * SBH_STAGE + SBH_MAXROWS * 2 + SBH_MAXQ * T_TILE * 4 + SBH_MAXQ * 4;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2_kernel), lds);
   if (e != hipSuccess) return e;
   const int nt = p.d / T_TILE;
