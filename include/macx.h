@@ -346,6 +346,37 @@ int macx_wgrad_splits(int M, int Kd, int Jd);
 int macx_wgrad(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd,
                float* out, float* ws, void* stream);
 
+/* ---- the ops.py primitives as single kernels (mac-network_amd/csrc/macx_ops.hip.h) -------------------------------
+ * The building blocks of the GENERIC option path (mac-network_amd/generic.py): every legal option combination the fused
+ * cell kernels above answer with MACX_EUNSUPPORTED runs as one kernel per reference op -- these, macx_linear / macx_h2_gemm
+ * and macx_wgrad -- chained by the host exactly as mac_cell.py chains ops.py.  fp32, contiguous, device pointers.
+ *   macx_op_act      out = act(x); act = MACX_ACT_* or MACX_OP_PRELU (relu(x) - alpha[c] relu(-x), c = index % inner; ops.py:171-173)
+ *   macx_op_act_bwd  dx = dy act'(x); PRELU also writes dalpha_elem = dy min(x, 0) for the caller to reduce over rows
+ *   macx_op_binary   out = scale (a + b) or scale (a * b); a, out hold n floats viewed [.., mid, inner]; b by `bmode`:
+ *                    SAME [n] | MID [n / (mid inner)][inner], broadcast over the middle axis (ops.mul's extendY, ops.py:693-695) |
+ *                    CHANNEL [inner] | ROW [n / inner], one scalar per row (ops.att2Smry, ops.py:150)
+ *   macx_op_reduce   MID: x [outer][mid][inner] -> out [outer][inner];  LAST: x [outer][inner] -> out [outer];
+ *                    ROWS: x [outer][inner] -> out [inner], ws >= 64 inner floats.  Fixed summation order.
+ *   macx_op_softmax  softmax over the last axis of [rows][n]; with `lengths`, columns >= lengths[row / rows_per_len] are
+ *                    masked to -inf first (ops.expMask, ops.py:243-247; mac_cell.py:176)
+ *   macx_op_softmax_bwd  dx = a (da - sum a da)
+ *   macx_op_dropout  out = x / keep * mask(seed, site, step, first + index): tf.nn.dropout on the stateless stream of
+ *                    macx_dropout_mask (ops.py:312, mac_cell.py:217,463); its own backward (apply it to dy) */
+#define MACX_OP_PRELU 16
+enum { MACX_OP_ADD = 0, MACX_OP_MUL = 1 };
+enum { MACX_OP_B_SAME = 0, MACX_OP_B_MID = 1, MACX_OP_B_CHANNEL = 2, MACX_OP_B_ROW = 3 };
+enum { MACX_OP_R_MID = 0, MACX_OP_R_LAST = 1, MACX_OP_R_ROWS = 2 };
+int macx_op_act(int act, const float* x, const float* alpha, size_t n, int inner, float* out, void* stream);
+int macx_op_act_bwd(int act, const float* x, const float* alpha, const float* dy, size_t n, int inner, float* dx,
+                    float* dalpha_elem, void* stream);
+int macx_op_binary(int op, int bmode, const float* a, const float* b, size_t n, int mid, int inner, float scale, float* out,
+                   void* stream);
+int macx_op_reduce(int mode, const float* x, size_t outer, int mid, int inner, float* out, float* ws, void* stream);
+int macx_op_softmax(const float* x, const int32_t* lengths, int rows_per_len, size_t rows, int n, float* out, void* stream);
+int macx_op_softmax_bwd(const float* a, const float* da, size_t rows, int n, float* dx, void* stream);
+int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
+                    float* out, void* stream);
+
 /* tuning hook for A/B measurements (never needed for correct results):
  *   key 0  waves per workgroup of the NATIVE knowledge-base GEMM (4 | 8)
  *   key 1  bit mask of timing experiments / kernel selection:

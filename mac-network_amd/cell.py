@@ -177,6 +177,19 @@ class MACCell:
     seed     dropout stream seed;  b0  global index of this shard's first question (data parallel)
     """
 
+    def __new__(cls, *args, config=None, **kw):
+        """Option sets without fused kernels (the reference's default configuration among them) are built on the generic
+        one-kernel-per-op path (generic.GenericMACCell, same interface); option values the reference itself rejects raise
+        what the reference raises."""
+        from types import SimpleNamespace
+        from .options import UnsupportedOptions
+        try:
+            freeze(config if config is not None else SimpleNamespace())
+        except UnsupportedOptions:
+            from .generic import GenericMACCell
+            return GenericMACCell(*args, config=config, **kw)
+        return super().__new__(cls)
+
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
                  netLength=None, seed=None, b0=0):

@@ -16,6 +16,7 @@
 #include "macx_gemm_h2.hip.h"
 #include "macx_wgrad_h2.hip.h"
 #include "macx_small.cuh"
+#include "macx_ops.hip.h"
 
 using namespace macx;
 
@@ -1343,6 +1344,73 @@ int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, u
   if (!out) return MACX_EINVAL;
   const DropSpec ds = make_drop(keep, seed, site, step);
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, ds.key, ds.thr24, first, n, out);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
+// ---- the ops.py primitives as single kernels (macx_ops.hip.h): the generic option path ---------------------------
+int macx_op_act(int act, const float* x, const float* alpha, size_t n, int inner, float* out, void* stream) {
+  if (!x || !out || inner < 1 || (act == OP_ACT_PRELU && !alpha) || (act != OP_ACT_PRELU && (act < 0 || act > ACT_RELU))) return MACX_EINVAL;
+  if (n == 0) return MACX_OK;
+  hipLaunchKernelGGL(op_act_kernel, dim3(op_grid(n)), dim3(256), 0, (hipStream_t)stream, act, x, alpha, n, inner, out);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+int macx_op_act_bwd(int act, const float* x, const float* alpha, const float* dy, size_t n, int inner, float* dx, float* dalpha_elem,
+                    void* stream) {
+  if (!x || !dy || !dx || inner < 1 || (act == OP_ACT_PRELU && (!alpha || !dalpha_elem)) ||
+      (act != OP_ACT_PRELU && (act < 0 || act > ACT_RELU)))
+    return MACX_EINVAL;
+  if (n == 0) return MACX_OK;
+  hipLaunchKernelGGL(op_act_bwd_kernel, dim3(op_grid(n)), dim3(256), 0, (hipStream_t)stream, act, x, alpha, dy, n, inner, dx, dalpha_elem);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+int macx_op_binary(int op, int bmode, const float* a, const float* b, size_t n, int mid, int inner, float scale, float* out, void* stream) {
+  if (!a || !b || !out || op < OP_ADD || op > OP_MUL || bmode < OP_B_SAME || bmode > OP_B_ROW || mid < 1 || inner < 1) return MACX_EINVAL;
+  if (n % ((size_t)inner * (bmode == OP_B_MID ? mid : 1))) return MACX_EINVAL;
+  if (n == 0) return MACX_OK;
+  hipLaunchKernelGGL(op_binary_kernel, dim3(op_grid(n)), dim3(256), 0, (hipStream_t)stream, op, bmode, a, b, n, mid, inner, scale, out);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+int macx_op_reduce(int mode, const float* x, size_t outer, int mid, int inner, float* out, float* ws, void* stream) {
+  if (!x || !out || outer < 1 || mid < 1 || inner < 1) return MACX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == OP_R_MID) {
+    if (outer > 0x7FFFFFFF) return MACX_EINVAL;
+    hipLaunchKernelGGL(op_reduce_mid_kernel, dim3((unsigned)((outer * inner + 255) / 256)), dim3(256), 0, st, x, (int)outer, mid, inner, out);
+  } else if (mode == OP_R_LAST) {
+    hipLaunchKernelGGL(op_reduce_last_kernel, dim3((unsigned)((outer + 3) / 4)), dim3(256), 0, st, x, outer, inner, out);
+  } else if (mode == OP_R_ROWS) {
+    if (!ws) return MACX_EINVAL;
+    hipLaunchKernelGGL(op_reduce_rows_kernel, dim3((inner + 255) / 256, OP_ROWS_SPLIT), dim3(256), 0, st, x, outer, inner, ws);
+    hipLaunchKernelGGL(op_reduce_rows_final_kernel, dim3((inner + 255) / 256), dim3(256), 0, st, ws, inner, out);
+  } else {
+    return MACX_EINVAL;
+  }
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+int macx_op_softmax(const float* x, const int32_t* lengths, int rows_per_len, size_t rows, int n, float* out, void* stream) {
+  if (!x || !out || rows < 1 || n < 1 || (lengths && rows_per_len < 1)) return MACX_EINVAL;
+  hipLaunchKernelGGL(op_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, lengths, rows_per_len, rows, n,
+                     out);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+int macx_op_softmax_bwd(const float* a, const float* da, size_t rows, int n, float* dx, void* stream) {
+  if (!a || !da || !dx || rows < 1 || n < 1) return MACX_EINVAL;
+  hipLaunchKernelGGL(op_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, da, rows, n, dx);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first, float* out,
+                    void* stream) {
+  if (!x || !out || !(keep > 0.f) || keep > 1.f) return MACX_EINVAL;
+  if (n == 0) return MACX_OK;
+  const DropSpec ds = make_drop(keep, seed, site, step);
+  hipLaunchKernelGGL(op_dropout_kernel, dim3(op_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, first, ds.key, ds.thr24, ds.inv_keep, out);
   CK(hipGetLastError());
   return MACX_OK;
 }

@@ -1,0 +1,140 @@
+"""CPU: the HOST LOGIC of the generic option path (mac-network_amd/generic.py) -- scope stacking and variable names, the
+chaining of ops per option, and the backward formulas of its autograd nodes -- with the nine kernel-call functions
+(generic.k_*) swapped for torch restatements.  The kernels themselves are checked on the GPU (tests/test_gpu_generic.py);
+nothing here runs product arithmetic, and the product never takes this route (it refuses CPU tensors)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dropout_hash as dh
+from oracle import mac_oracle as mo
+from helpers import oracle_run, rel_err, max_abs
+from test_gpu_generic import VARIANTS, make_cfg, oracle_params, assert_grad
+
+
+def _torch_kernels(G):
+    def binary(op, bmode, a, b, mid, inner, scale=1.0):
+        if bmode == G.B_MID:
+            aa, bb = a.reshape(-1, mid, inner), b.reshape(-1, 1, inner)
+        elif bmode == G.B_CHANNEL:
+            aa, bb = a.reshape(-1, inner), b.reshape(1, inner)
+        elif bmode == G.B_ROW:
+            aa, bb = a.reshape(-1, inner), b.reshape(-1, 1)
+        else:
+            aa, bb = a, b.reshape(a.shape)
+        return (scale * (aa * bb if op == G.OP_MUL else aa + bb)).reshape(a.shape).contiguous()
+
+    def reduce(mode, x, outer, mid, inner):
+        if mode == G.R_MID:
+            return x.reshape(outer, mid, inner).sum(1)
+        return x.reshape(outer, inner).sum(1 if mode == G.R_LAST else 0)
+
+    def act(a, x, alpha):
+        if a == G.ACT_PRELU:
+            return torch.where(x > 0, x, alpha * x)
+        return {0: lambda v: v, 1: torch.tanh, 2: torch.sigmoid, 3: torch.nn.functional.elu, 4: torch.relu}[a](x)
+
+    def act_bwd(a, x, alpha, g):
+        if a == G.ACT_PRELU:
+            return g * torch.where(x > 0, torch.ones_like(x), alpha.expand_as(x)), torch.where(x > 0, torch.zeros_like(x), g * x)
+        xx = x.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            act(a, xx, None).backward(g)
+        return xx.grad, None
+
+    def softmax(x, lengths):
+        if lengths is not None:
+            n = x.shape[-1]
+            m = torch.arange(n).unsqueeze(0) < lengths.reshape(-1, 1)
+            x = torch.where(m.reshape(x.shape), x, torch.full_like(x, float("-inf")))
+        return torch.softmax(x, dim=-1)
+
+    def softmax_bwd(a, g):
+        return a * (g - (a * g).sum(-1, keepdim=True))
+
+    def dropout(x, seed, site, step, keep, first):
+        m = torch.as_tensor(dh.keep_mask(seed, site, step, keep, first, x.numel())).reshape(x.shape).to(x.dtype)
+        return x * np.float32(1.0 / keep) * m
+
+    def matmul(x, W, b, big):
+        return x @ W + (b if b is not None else 0)
+
+    def wgrad(x2, g2):
+        return x2.t() @ g2
+
+    return dict(k_binary=binary, k_reduce=reduce, k_act=act, k_act_bwd=act_bwd, k_softmax=softmax, k_softmax_bwd=softmax_bwd,
+                k_dropout=dropout, k_matmul=matmul, k_wgrad=wgrad)
+
+
+@pytest.fixture
+def host_generic(macx, monkeypatch):
+    G = macx.generic
+    for k, f in _torch_kernels(G).items():
+        monkeypatch.setattr(G, k, f)
+    monkeypatch.setattr(G, "_require_device", lambda t, name: None)
+    return G
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("train", [False, True])
+def test_generic_host_logic_matches_oracle(macx, host_generic, variant, train):
+    B, S, N, d, p = 3, 7, 10, 128, 3
+    cfg = make_cfg(variant, d, p)
+    vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, d, seed=11)
+    params = oracle_params(cfg, vq, words, lengths, kb)
+    g = torch.Generator().manual_seed(3)
+    dM, dC = torch.randn(B, d, generator=g), torch.randn(B, d, generator=g)
+    ref = oracle_run(cfg, params, vq, words, lengths, kb, train=train, seed=91, b0=1, need_grad=True, d_memory=dM, d_control=dC)
+    gp = macx.GenericParams().load_reference_dict(params)
+    vqd, wd, kbd = [t.clone().requires_grad_(True) for t in (vq, words, kb)]
+    cell = macx.GenericMACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=lengths, knowledgeBase=kbd,
+                               memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout, writeDropout=cfg.writeDropout,
+                               batchSize=B, train=train, config=cfg, params=gp, seed=91, b0=1)
+    state = cell.run()
+    ((state.memory * dM).sum() + (state.control * dC).sum()).backward()
+    rc = ref["cell"]
+    assert list(gp.names) == list(params), "variables are created in the reference's order under the reference's names"
+    assert rel_err(state.memory, ref["memory"]) < 2e-5 and rel_err(state.control, ref["control"]) < 2e-5
+    assert rel_err(cell.memories, rc.memories) < 2e-5 and rel_err(cell.controls, rc.controls) < 2e-5
+    for kind in ("kb", "question", "self", "gate"):
+        assert len(cell.attentions[kind]) == len(rc.attentions[kind])
+        for a, b in zip(cell.attentions[kind], rc.attentions[kind]):
+            assert max_abs(a, b) < 2e-6
+    grads = gp.grads_by_name()
+    for k, v in ref["params"].items():
+        if v.grad is None:
+            assert grads[k] is None or float(grads[k].abs().max()) == 0.0, k
+        else:
+            assert_grad(grads[k], v.grad, k)
+    for got, want in zip((vqd, wd, kbd), ref["inputs"]):
+        if want.grad is not None:
+            assert rel_err(got.grad, want.grad) < 2e-4
+
+
+def test_generic_path_refuses_cpu_tensors(macx):
+    cfg = mo.default_config(netLength=1, memDim=128, ctrlDim=128, attDim=128)
+    vq, words, lengths, kb = mo.synthetic_inputs(2, 4, 5, 128)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        macx.MACCell(vq, words, words, lengths, kb, 0.85, 0.85, 1.0, 2, True, config=cfg)
+
+
+def test_macx_maccell_dispatches_unfused_option_sets_to_the_generic_path(macx, host_generic):
+    vq, words, lengths, kb = mo.synthetic_inputs(2, 4, 5, 128)
+    for variant in ("defaults", "write_sum", "read_bilinear", "relu_prm", "unshared_cells", "control_proj", "write_concat_mul"):
+        cell = macx.MACCell(vq, words, words, lengths, kb, 0.85, 0.85, 1.0, 2, False, config=make_cfg(variant, 128, 2))
+        assert type(cell) is macx.GenericMACCell, variant
+
+
+def test_generic_path_rejections(macx, host_generic):
+    vq, words, lengths, kb = mo.synthetic_inputs(2, 4, 5, 128)
+    mk = lambda **over: macx.GenericMACCell(vq, words, words, lengths, kb, 1.0, 1.0, 1.0, 2, False,
+                                     config=mo.flag_file_config("args", netLength=1, memDim=128, ctrlDim=128, attDim=128, **over))
+    with pytest.raises(macx.UnsupportedOptions):
+        mk(memoryBN=True)
+    with pytest.raises(UnboundLocalError):
+        mk(readMemAttType="DIAG")
+    with pytest.raises(UnboundLocalError):
+        mk(relu="SELU", writeMemAct="RELU").run()
+    with pytest.raises(macx.UnsupportedOptions):
+        macx.GenericMACCell(vq[:, :64], words[:, :, :64], words[:, :, :64], lengths, kb[:, :, :64], 1.0, 1.0, 1.0, 2, False,
+                     config=mo.default_config(netLength=1, memDim=64, ctrlDim=64, attDim=64))
