@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MACX_ABI_VERSION 1
+#define MACX_ABI_VERSION 2
 
 enum {
   MACX_OK = 0,
@@ -65,6 +65,10 @@ typedef struct macx_opts {
   int32_t write_gate_shared;        /* --writeGateShared          (mac_cell.py:360-361)        */
   float   write_gate_bias;          /* --writeGateBias            (mac_cell.py:363)            */
   int32_t memory_variational_dropout; /* --memoryVariationalDropout (mac_cell.py:214-217)      */
+  int32_t gemm_family;              /* kernel family of the knowledge-base GEMMs for EVERY call made with these options
+                                       (sizing, begin, step, backward): 0 = the process default (macx_gemm_mode),
+                                       1 + MACX_GEMM_NATIVE / _SPLIT / _H2 = that family.  Per call and per thread: two
+                                       cells of one process can run on different families side by side               */
 } macx_opts;
 
 typedef struct macx_shapes {

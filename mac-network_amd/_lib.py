@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MACX_OK, MACX_EINVAL, MACX_EUNSUPPORTED, MACX_EREJECTED, MACX_ESMALL = 0, -1, -2, -3, -4
 ACT = {"NON": 0, "TANH": 1, "SIGMOID": 2, "ELU": 3, "RELU": 4}
@@ -22,7 +22,7 @@ class MacxOpts(C.Structure):
         "abi_version", "init_ctrl", "init_mem", "control_input_unshared", "control_input_act", "control_feed_prev",
         "control_feed_prev_att", "control_feed_inputs", "control_cont_act", "read_mem_act", "read_ctrl_act",
         "write_inputs", "write_self_att", "write_self_att_cont", "write_mem_act", "write_gate", "write_gate_shared")]
-    _fields_ += [("write_gate_bias", C.c_float), ("memory_variational_dropout", C.c_int32)]
+    _fields_ += [("write_gate_bias", C.c_float), ("memory_variational_dropout", C.c_int32), ("gemm_family", C.c_int32)]
 
 
 class MacxShapes(C.Structure):

@@ -175,9 +175,10 @@ class MACCell:
     config   object with the reference's flag names (default: the reference defaults)
     params   MACCellParams (default: freshly initialised like tf.get_variable would)
     seed     dropout stream seed;  b0  global index of this shard's first question (data parallel)
+    gemm     kernel family of the knowledge-base GEMMs of THIS cell: "h2" | "split" | "native" (None: the process default)
     """
 
-    def __new__(cls, *args, config=None, **kw):
+    def __new__(cls, *args, config=None, gemm=None, **kw):
         """Option sets without fused kernels (the reference's default configuration among them) are built on the generic
         one-kernel-per-op path (generic.GenericMACCell, same interface); option values the reference itself rejects raise
         what the reference raises."""
@@ -192,10 +193,10 @@ class MACCell:
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
-                 netLength=None, seed=None, b0=0):
+                 netLength=None, seed=None, b0=0, gemm=None):
         from types import SimpleNamespace
         self.config = config if config is not None else SimpleNamespace()
-        self.opts = freeze(self.config)           # raises for rejected / unsupported option sets
+        self.opts = freeze(self.config, gemm)     # raises for rejected / unsupported option sets
         self.netLength = int(netLength if netLength is not None else get(self.config, "netLength"))
         self.vecQuestions = _f32c(vecQuestions, "vecQuestions")
         self.questionWords = questionWords

@@ -42,6 +42,14 @@ inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
 // with a per-question vector (B_YMIX_*) -> format 2 (fp32 k-major tiles) / 0.  Buffers are sized for the larger one.
 //   h2 (2, the default): macx_gemm_h2.hip.h -- every [B,N,d] activation lives in HBM as two fp16 planes + per-row-block
 //     exponents (macx_h2.hip.h), three fp16 MFMA terms per product; plain weights -> format 3 (H2 planes + exponent).
+// the kernel family an ABI call runs on: macx_opts.gemm_family (when set) for the duration of the call, on this thread
+struct ModeScope {
+  int saved;
+  explicit ModeScope(const macx_opts* o) : saved(gemm_call_override()) {
+    if (o && o->gemm_family >= 1 && o->gemm_family <= 3) gemm_call_override() = o->gemm_family - 1;
+  }
+  ~ModeScope() { gemm_call_override() = saved; }
+};
 inline bool h2_mode() { return gemm_split_mode() == 2; }
 inline int wfmt_plain() { return h2_mode() ? 3 : (gemm_split_mode() ? 1 : 0); }
 inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
@@ -471,20 +479,23 @@ const char* macx_strerror(int code) {
   }
 }
 
-int macx_check(const macx_opts* o, const macx_shapes* s) { return check_impl(o, s); }
+int macx_check(const macx_opts* o, const macx_shapes* s) { ModeScope ms(o); return check_impl(o, s); }
 
 size_t macx_saved_floats(const macx_opts* o, const macx_shapes* s, int keep) {
+  ModeScope ms(o);
   if (check_impl(o, s) != MACX_OK) return 0;
   return make_saved(o, s, keep).total;
 }
 
 size_t macx_ws_floats(const macx_opts* o, const macx_shapes* s, int for_backward) {
+  ModeScope ms(o);
   if (check_impl(o, s) != MACX_OK) return 0;
   if (!for_backward) return 4;   // forward keeps everything in `saved`
   return make_bwd(o, s).total;
 }
 
 int macx_saved_segment(const macx_opts* o, const macx_shapes* s, int keep, int segment, size_t* offset, size_t* count) {
+  ModeScope ms(o);
   CKI(check_impl(o, s));
   if (segment < 0 || segment >= MACX_SEG_COUNT || !offset || !count) return MACX_EINVAL;
   SavedLayout L = make_saved(o, s, keep);
@@ -497,6 +508,7 @@ int macx_saved_segment(const macx_opts* o, const macx_shapes* s, int keep, int s
 int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
                     const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
                     int keep, void* stream) {
+  ModeScope ms(o);
   CKI(check_impl(o, s));
   if (!dp || !P || !in || !saved) return MACX_EINVAL;
   if (misaligned(saved) || misaligned(in->knowledgeBase) || misaligned(in->words) || misaligned(in->vecQuestions))
@@ -571,6 +583,7 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
 int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
                    const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
                    int keep, int step, void* stream) {
+  ModeScope ms(o);
   CKI(check_impl(o, s));
   if (!dp || !P || !in || !saved) return MACX_EINVAL;
   if (step < 0 || step >= s->p) return MACX_EINVAL;
@@ -785,6 +798,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
                        const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
                        const float* d_memory, const float* d_control, const macx_param_grads* GP,
                        const macx_input_grads* GI, void* stream) {
+  ModeScope ms(o);
   CKI(check_impl(o, s));
   if (!dp || !P || !in || !saved || !ws || !GP || !GI) return MACX_EINVAL;
   if (!GI->knowledgeBase || !GI->words || !GI->vecQuestions) return MACX_EINVAL;
@@ -1916,7 +1930,7 @@ int macx_adam_ema_step(size_t n, float* params, const float* grads, float* m, fl
 
 /* test/tuning hook: key 0 = waves per workgroup of the kb GEMM (4 or 8) */
 int macx_gemm_mode(int mode) {
-  if (mode == MACX_GEMM_NATIVE || mode == MACX_GEMM_SPLIT || mode == MACX_GEMM_H2) gemm_split_mode() = mode;
+  if (mode == MACX_GEMM_NATIVE || mode == MACX_GEMM_SPLIT || mode == MACX_GEMM_H2) gemm_default_mode() = mode;
   return gemm_split_mode();
 }
 
@@ -1984,7 +1998,7 @@ int macx_h2_gemm(const float* A, int B, int N, int K, const float* Wm, int n_out
 int macx_debug_set(int key, int value) {
   if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }
   if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
-  if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_split_mode() = value; return MACX_OK; }
+  if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;
 }

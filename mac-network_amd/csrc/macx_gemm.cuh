@@ -432,19 +432,18 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
 // runtime knob (macx_debug_set(0, NW)): waves per workgroup of the kb GEMM, 4 or 8
 inline int& kb_gemm_nw() { static int nw = 8; return nw; }
 inline int& kb_gemm_dbg() { static int m = 0; return m; }
-inline int& gemm_split_mode() { static int m = 2; return m; }   // kernel family of the read unit: 0 native f32 MFMA, 1 split-bf16 (macx_gemm6.cuh), 2 H2 fp16 planes (macx_gemm_h2.hip.h)
+inline int& gemm_default_mode() { static int m = 2; return m; }     // process default (macx_gemm_mode)
+inline int& gemm_call_override() { static thread_local int m = -1; return m; }   // set for the duration of one ABI call (macx_opts.gemm_family)
+inline int gemm_split_mode() { return gemm_call_override() >= 0 ? gemm_call_override() : gemm_default_mode(); }   // kernel family of the read unit: 0 native f32 MFMA, 1 split-bf16 (macx_gemm6.cuh), 2 H2 fp16 planes (macx_gemm_h2.hip.h)
 inline int& kb_gemm_force_rt() { static int rt = 0; return rt; }   // tuning override (macx_debug_set key 2)
 
 template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_launch_rt(const GemmP& p, hipStream_t st) {
   auto kern = kb_gemm_kernel<RT, NW, AP, BP, EP, COLSUM>;
   constexpr size_t lds = (size_t)kb_gemm_lds_floats<RT, NW>() * sizeof(float);
-  static bool attr_set = false;   // one attribute call per instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);   // per (kernel, device)
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int ncb = p.Nout / (16 * NW);
   const int nrb = (p.N + RT * 16 - 1) / (RT * 16);

@@ -304,11 +304,9 @@ template <int RT, int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm6_launch_rt(const GemmP& p, hipStream_t st) {
   auto kern = kb_gemm6_kernel<RT, AP, BP, EP, COLSUM>;
   constexpr size_t lds = (size_t)kb_gemm6_lds_bytes<RT>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);   // per (kernel, device)
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int ncb = p.Nout / 128;
   const int nrb = (p.N + RT * 16 - 1) / (RT * 16);

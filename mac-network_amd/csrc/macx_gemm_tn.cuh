@@ -168,12 +168,9 @@ template <int AP>
 inline hipError_t wgrad_tn_launch(const TnP& p, hipStream_t st) {
   auto kern = wgrad_tn_kernel<AP>;
   constexpr size_t lds = 2 * T_RING * T_STAGE * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);   // per (kernel, device)
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int grid = (p.Kd / T_TILE) * (p.Jd / T_TILE) * p.nsplit;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
@@ -329,12 +326,9 @@ __global__ __launch_bounds__(256) void sb_wgrad_kernel(SbP p) {
 
 inline hipError_t sb_wgrad_launch(const SbP& p, hipStream_t st) {
   constexpr size_t lds = 4 * T_STAGE * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sb_wgrad_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_wgrad_kernel), lds);   // per (kernel, device)
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int nt = p.d / T_TILE;
   const int ngroup = (p.B + p.qpg - 1) / p.qpg;

@@ -194,11 +194,9 @@ template <bool CONV, int JW>
 inline hipError_t wgrad6_launch_t(const TnP& p, hipStream_t st) {
   auto kern = wgrad6_kernel<CONV, JW>;
   constexpr size_t lds = 2 * w6_stage_bytes<JW>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);   // per (kernel, device)
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int grid = (p.Kd / T_TILE) * (p.Jd / (JW * T_TILE)) * p.nsplit;
   hipLaunchKernelGGL(kern, dim3(grid, p.nz > 1 ? p.nz : 1), dim3(512), lds, st, p);
@@ -382,11 +380,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 inline hipError_t sb6_wgrad_launch(const SbP& p, hipStream_t st) {
   constexpr size_t lds = 2 * W6_STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sb6_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb6_wgrad_kernel), lds);   // per (kernel, device)
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int nt = p.d / T_TILE;
   const int ngroup = (p.B + p.qpg - 1) / p.qpg;

@@ -104,9 +104,15 @@ def reject_like_reference(config):
         raise ValueError("Dimensions must be equal")
 
 
-def freeze(config):
-    """config -> (MacxOpts, dict of python-side facts)."""
+GEMM_FAMILIES = {None: 0, "default": 0, "native": 1, "split": 2, "h2": 3}
+
+
+def freeze(config, gemm=None):
+    """config -> MacxOpts.  gemm: kernel family of the knowledge-base GEMMs for every call made with these options
+    ("native" | "split" | "h2"; None = the process default, macx_gemm_mode) -- macx_opts.gemm_family."""
     g = lambda n: get(config, n)
+    if gemm not in GEMM_FAMILIES:
+        raise ValueError("gemm=%r: one of %s" % (gemm, sorted(k for k in GEMM_FAMILIES if k)))
     reject_like_reference(config)
     unsupported = []
     d = g("memDim")
@@ -148,6 +154,7 @@ def freeze(config):
     o.write_gate_shared = int(bool(g("writeGateShared")))
     o.write_gate_bias = float(g("writeGateBias"))
     o.memory_variational_dropout = int(bool(g("memoryVariationalDropout")))
+    o.gemm_family = GEMM_FAMILIES[gemm]
     if o.read_mem_act == _lib.ACT["NON"]:
         unsupported.append("readMemAct=NON (no memKbProj_2 layer, ops.py:325)")
     if unsupported:

@@ -190,3 +190,28 @@ def test_recurrent_control_variants(macx, dev, over):
             errs[refname] = rel_err(got.reshape(rg.shape), rg, floor=floor)
     bad = {k: v for k, v in errs.items() if not (v < GRAD_TOL)}
     assert not bad, bad
+
+
+def test_kernel_family_is_a_per_cell_option(macx, dev):
+    """macx_opts.gemm_family: three cells of ONE process on the three kernel families, forward + backward, without touching
+    the process default; every family within the parity tolerance of the oracle."""
+    cfg, vq, words, lengths, kb = make_case("args", 3, 9, 49, 128, 2)
+    L = macx._lib.lib()
+    default = L.macx_gemm_mode(-1)
+    params = macx.MACCellParams(cfg, 2, generator=torch.Generator().manual_seed(5)).to(dev)
+    ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=True, seed=3, need_grad=True,
+                     d_memory=torch.ones(3, 128))
+    for fam in ("h2", "split", "native"):
+        for t in params.tensors():
+            t.grad = None
+        kbd = kb.to(dev).requires_grad_(True)
+        cell = macx.MACCell(vq.to(dev), words.to(dev), words.to(dev), lengths.to(dev), kbd, cfg.memoryDropout, cfg.readDropout,
+                            cfg.writeDropout, 3, True, config=cfg, params=params, seed=3, gemm=fam)
+        assert cell.opts.gemm_family == {"native": 1, "split": 2, "h2": 3}[fam]
+        state = cell.run()
+        state.memory.sum().backward()
+        torch.cuda.synchronize()
+        assert L.macx_gemm_mode(-1) == default
+        assert rel_err(state.memory, ref["memory"]) < FWD_TOL, fam
+        assert rel_err(kbd.grad, ref["inputs"][2].grad) < GRAD_TOL, fam
+        assert rel_err(params.memKbProj_W.grad, ref["params"]["MACnetwork/MACCell/read/linearLayermemKbProj/weights/weight"].grad) < GRAD_TOL, fam

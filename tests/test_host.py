@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_builds_loads_and_exports_the_header(macx):
     L = macx._lib.lib()
-    assert L.macx_abi_version() == 1
+    assert L.macx_abi_version() == 2
     header = open(os.path.join(ROOT, "include", "macx.h")).read()
     declared = set(re.findall(r"\b(macx_[a-z_0-9]+)\s*\(", header))
     declared -= {"macx_opts", "macx_shapes"}
@@ -25,7 +25,7 @@ def test_library_builds_loads_and_exports_the_header(macx):
 
 
 def test_struct_layouts_match_header(macx):
-    assert C.sizeof(macx._lib.MacxOpts) == 19 * 4
+    assert C.sizeof(macx._lib.MacxOpts) == 20 * 4
     assert C.sizeof(macx._lib.MacxShapes) == 6 * 4
     assert C.sizeof(macx._lib.MacxDropout) == 4 * 4
     assert C.sizeof(macx._lib.MacxParams) == 30 * 8 == C.sizeof(macx._lib.MacxParamGrads)
@@ -40,14 +40,14 @@ def test_check_and_sizing_without_gpu(macx):
     o = macx.freeze(mo.flag_file_config("args"))
     s = macx._lib.MacxShapes(B=64, S=50, N=196, d=512, p=12, b0=0)
     assert L.macx_check(C.byref(o), C.byref(s)) == 0
-    L.macx_gemm_mode(1)
-    try:
-        keep = L.macx_saved_floats(C.byref(o), C.byref(s), 1)
-        nokeep = L.macx_saved_floats(C.byref(o), C.byref(s), 0)
-        # X, H1, I2, dropped KB (fp32) + the two 1-bit dropout masks, kept for 11 more steps (+ the per-question exponents)
-        assert keep - nokeep == 11 * 64 * 196 * 512 * 4 + 11 * 2 * (64 * 196 * 512 // 32) + 11 * 3 * 64 * 4
-    finally:
-        L.macx_gemm_mode(2)
+    # the kernel family is a field of the options (per call, not process state): sizing under "split" without touching the default
+    o1 = macx.freeze(mo.flag_file_config("args"), gemm="split")
+    assert L.macx_gemm_mode(-1) == 2
+    keep = L.macx_saved_floats(C.byref(o1), C.byref(s), 1)
+    nokeep = L.macx_saved_floats(C.byref(o1), C.byref(s), 0)
+    # X, H1, I2, dropped KB (fp32) + the two 1-bit dropout masks, kept for 11 more steps (+ the per-question exponents)
+    assert keep - nokeep == 11 * 64 * 196 * 512 * 4 + 11 * 2 * (64 * 196 * 512 // 32) + 11 * 3 * 64 * 4
+    assert L.macx_gemm_mode(-1) == 2
     # the default family keeps the same tensors as H2: 4 bytes per element as well (+ exponents and 64 pad rows each)
     keep = L.macx_saved_floats(C.byref(o), C.byref(s), 1)
     nokeep = L.macx_saved_floats(C.byref(o), C.byref(s), 0)
