@@ -341,7 +341,7 @@ int macx_kb_project(const macx_shapes*, const macx_dropout*, int step, const flo
 int macx_control_attend(const macx_shapes*, const float* cc, const float* words, const int32_t* lengths,
                         const float* w, const float* b, float* att, float* control, void* stream);
 /* Materialises the 0/1 keep mask of a dropout site for n elements starting at flat index
- * `first` (test hook for the stateless stream; site numbers in macx_common.cuh). */
+ * `first` (test hook for the stateless stream; site numbers in macx_common.hip.h). */
 int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
                       size_t n, float* out, void* stream);
 /* weight-gradient contraction out[k][j] = sum_m A[m][k] G[m][j]  (fixed-order split reduction).

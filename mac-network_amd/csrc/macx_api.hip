@@ -7,15 +7,15 @@
 #include <string.h>
 
 #include "../../include/macx.h"
-#include "macx_common.cuh"
-#include "macx_gemm.cuh"
-#include "macx_gemm6.cuh"
-#include "macx_gemm_tn.cuh"
-#include "macx_wgrad6.cuh"
+#include "macx_common.hip.h"
+#include "macx_gemm.hip.h"
+#include "macx_gemm6.hip.h"
+#include "macx_gemm_tn.hip.h"
+#include "macx_wgrad6.hip.h"
 #include "macx_h2.hip.h"
 #include "macx_gemm_h2.hip.h"
 #include "macx_wgrad_h2.hip.h"
-#include "macx_small.cuh"
+#include "macx_small.hip.h"
 #include "macx_ops.hip.h"
 
 using namespace macx;
@@ -36,8 +36,8 @@ namespace {
 inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 // The knowledge-base GEMM family runs on one of two kernels (macx_debug_set(3, mode), default split):
-//   split (1): macx_gemm6.cuh, fp32 operands as three exact bf16 pieces on the bf16 matrix pipe, fp32 accumulate;
-//   native (0): macx_gemm.cuh, v_mfma_f32_16x16x4_f32.
+//   split (1): macx_gemm6.hip.h, fp32 operands as three exact bf16 pieces on the bf16 matrix pipe, fp32 accumulate;
+//   native (0): macx_gemm.hip.h, v_mfma_f32_16x16x4_f32.
 // They take different weight packings: plain weights -> format 1 (bf16 planes, 1.5x the floats) / 0, weights mixed
 // with a per-question vector (B_YMIX_*) -> format 2 (fp32 k-major tiles) / 0.  Buffers are sized for the larger one.
 //   h2 (2, the default): macx_gemm_h2.hip.h -- every [B,N,d] activation lives in HBM as two fp16 planes + per-row-block

@@ -1,4 +1,4 @@
-// macx_common.cuh -- shared device helpers for the MI355X (gfx950) MAC-cell kernels.
+// macx_common.hip.h -- shared device helpers for the MI355X (gfx950) MAC-cell kernels.
 //
 // Everything here is wave64 / CDNA4 specific on purpose: no CUDA shims, no dual paths.
 #pragma once

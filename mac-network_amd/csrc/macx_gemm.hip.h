@@ -1,4 +1,4 @@
-// macx_gemm.cuh -- the knowledge-base GEMM family of the read unit (forward and backward-data).
+// macx_gemm.hip.h -- the knowledge-base GEMM family of the read unit (forward and backward-data).
 //
 // One kernel template covers every  [B*N, K] x [K, d]  contraction of the read unit
 // (mac_cell.py:209-277 / ops.py:668-725, 298-333): projX, memKbProj, memKbProj_2 forward and the
@@ -25,14 +25,14 @@
 //                     16Q+8+e, 16Q+12+e}; the A side uses the same pairing (lane group g reads
 //                     A[i][16Q+4g .. 16Q+4g+3]).
 //   dropout masks     1 bit per element, 32 consecutive k (or columns) per uint32 word, produced by
-//                     mask_bits_kernel from the stateless stream of macx_common.cuh.
+//                     mask_bits_kernel from the stateless stream of macx_common.hip.h.
 //   epilogue          accumulators are transposed through LDS into a row-major [RT*16][132] tile
 //                     and then processed 16 bytes per lane, 512 B per row: coalesced stores, row
 //                     reductions (attention logits) inside one half-wave, column sums (bias
 //                     gradients) by a fixed-order LDS combine.
 #pragma once
 #include <type_traits>
-#include "macx_common.cuh"
+#include "macx_common.hip.h"
 
 namespace macx {
 
@@ -434,7 +434,7 @@ inline int& kb_gemm_nw() { static int nw = 8; return nw; }
 inline int& kb_gemm_dbg() { static int m = 0; return m; }
 inline int& gemm_default_mode() { static int m = 2; return m; }     // process default (macx_gemm_mode)
 inline int& gemm_call_override() { static thread_local int m = -1; return m; }   // set for the duration of one ABI call (macx_opts.gemm_family)
-inline int gemm_split_mode() { return gemm_call_override() >= 0 ? gemm_call_override() : gemm_default_mode(); }   // kernel family of the read unit: 0 native f32 MFMA, 1 split-bf16 (macx_gemm6.cuh), 2 H2 fp16 planes (macx_gemm_h2.hip.h)
+inline int gemm_split_mode() { return gemm_call_override() >= 0 ? gemm_call_override() : gemm_default_mode(); }   // kernel family of the read unit: 0 native f32 MFMA, 1 split-bf16 (macx_gemm6.hip.h), 2 H2 fp16 planes (macx_gemm_h2.hip.h)
 inline int& kb_gemm_force_rt() { static int rt = 0; return rt; }   // tuning override (macx_debug_set key 2)
 
 template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>

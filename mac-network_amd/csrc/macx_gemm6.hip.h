@@ -1,4 +1,4 @@
-// macx_gemm6.cuh -- the knowledge-base GEMM family on the bf16 matrix pipe with fp32-equivalent numerics.
+// macx_gemm6.hip.h -- the knowledge-base GEMM family on the bf16 matrix pipe with fp32-equivalent numerics.
 //
 // gfx950 runs f32-input MFMA at 1/16 of the bf16 rate (157 TF vs 2.5 PF) and has no TF32/xf32 form.  Every fp32
 // operand x is therefore split EXACTLY into three bf16 pieces  x = x1 + x2 + x3  (round-to-nearest residual
@@ -9,7 +9,7 @@
 // the same fp32 accumulator the f32 MFMA uses, so the result carries fp32-class error (measured against fp64 in
 // tests/test_gpu_units.py next to the native f32 kernel) at 6/16 of the f32 MFMA issue time.
 //
-// Tiling is the same per-question tiling as macx_gemm.cuh (RT*16 rows of one question x 128 columns, 8 waves), with
+// Tiling is the same per-question tiling as macx_gemm.hip.h (RT*16 rows of one question x 128 columns, 8 waves), with
 // the waves arranged 2 (row halves) x 4 (32-column groups) so that an A fragment read from LDS feeds two MFMAs
 // (three bf16 planes per operand make LDS fragment traffic, not the matrix pipe, the next limit otherwise).
 //   LDS stage:  A planes [3][4 k-groups][ROWS] x 16 B (8 bf16 of one row); B planes [3][4 k-groups][128 cols] x 16 B.
@@ -18,9 +18,9 @@
 //   weights:    B_PLAIN   -> pre-split planes  Wb[K/32][3][Nout][32] bf16      (pack format 1)
 //               B_YMIX_*  -> fp32 k-major tiles Wt[K/32][Nout][32]             (pack format 2), mixed with the
 //                            per-question vector in fp32, then split while staging
-// The epilogues are the shared kb_epilogue_rows of macx_gemm.cuh.
+// The epilogues are the shared kb_epilogue_rows of macx_gemm.hip.h.
 #pragma once
-#include "macx_gemm.cuh"
+#include "macx_gemm.hip.h"
 
 namespace macx {
 
@@ -68,7 +68,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 a, const u32x4 b, f32x4 c
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-// weight formats for this kernel (macx_small.cuh pack_weights_kernel, PackDesc::fmt)
+// weight formats for this kernel (macx_small.hip.h pack_weights_kernel, PackDesc::fmt)
 //   1: Wb[kt][plane][n][32] bf16 = split planes of W[k][n];  2: Wt[kt][n][32] fp32 k-major tiles
 constexpr size_t gemm6_plane_floats(size_t K, size_t Nout) { return K * Nout * 3 / 2; }   // format 1 size in floats
 

@@ -16,9 +16,9 @@
 // Epilogue: accumulators -> row-major LDS tile -> ONE pass with lanes running along rows (bias / activation / act' from an
 // H2 tensor / attention-logit partials), per-row maxima and logit partials combined through small LDS tables, then the
 // tile is written as H2 (a wave stores 64 rows of one slot column = one contiguous KiB per plane).  E_DKB keeps the
-// row-major fp32 epilogue of macx_gemm.cuh (its output is the caller's fp32 gradient).
+// row-major fp32 epilogue of macx_gemm.hip.h (its output is the caller's fp32 gradient).
 #pragma once
-#include "macx_gemm.cuh"
+#include "macx_gemm.hip.h"
 #include "macx_h2.hip.h"
 
 namespace macx {

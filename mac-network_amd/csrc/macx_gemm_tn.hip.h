@@ -1,4 +1,4 @@
-// macx_gemm_tn.cuh -- weight-gradient contractions of the read unit:  C[k][j] = sum_m A[m][k] * G[m][j]
+// macx_gemm_tn.hip.h -- weight-gradient contractions of the read unit:  C[k][j] = sum_m A[m][k] * G[m][j]
 // reduced over the B*N knowledge-base rows (dW2 = H1^T dI2, dWx = KBd^T dX,
 // dW1 = [X*y, X]^T dI1).  Both operands are row-major over m, which is already the MFMA-friendly
 // layout for a TN product (fragments read along the contiguous dimension, conflict-free b32).
@@ -6,8 +6,8 @@
 // Determinism: no float atomics.  Every workgroup owns one (split, 128x128 tile) slab of a partial
 // buffer; a fixed-order reduction kernel sums the slabs.
 #pragma once
-#include "macx_common.cuh"
-#include "macx_gemm.cuh"
+#include "macx_common.hip.h"
+#include "macx_gemm.hip.h"
 
 namespace macx {
 

@@ -20,7 +20,7 @@
 // producer workgroup owns exactly such blocks, so no cross-workgroup reduction is needed and every row keeps its own
 // relative precision.
 #pragma once
-#include "macx_common.cuh"
+#include "macx_common.hip.h"
 
 namespace macx {
 

@@ -6,10 +6,10 @@
 //   binary               out = scale * (a (+|*) b) with b the same shape, [B,d] over [B,N,d], [d] over rows, or [rows] over columns
 //   reduce               sum over the middle axis of [B,N,d], over the last axis of [rows,d], or over the rows of [rows,d]
 //   softmax / _bwd       softmax over the last axis with the -inf length mask of ops.expMask (ops.py:243-247)
-//   dropout              x / keep * mask from the stateless stream (macx_common.cuh), any site / step / first element
+//   dropout              x / keep * mask from the stateless stream (macx_common.hip.h), any site / step / first element
 // Deterministic: every output element is produced by one thread or one fixed-order tree.
 #pragma once
-#include "macx_common.cuh"
+#include "macx_common.hip.h"
 
 namespace macx {
 

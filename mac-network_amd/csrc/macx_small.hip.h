@@ -1,9 +1,9 @@
-// macx_small.cuh -- the [B,d]-sized and HBM-bound kernels of the cell: weight packing, the small
+// macx_small.hip.h -- the [B,d]-sized and HBM-bound kernels of the cell: weight packing, the small
 // linears (ops.py:298-333 on [B,d] inputs), the control unit's word attention
 // (mac_cell.py:153-181), the read unit's softmax + summary over the knowledge base
 // (mac_cell.py:264-275; ops.py:140-150) and their backward twins.
 #pragma once
-#include "macx_common.cuh"
+#include "macx_common.hip.h"
 #include "macx_h2.hip.h"
 
 namespace macx {
@@ -28,8 +28,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int 
 
 // several weights in one launch (blockIdx.y selects the descriptor)
 //   fmt 0: dst[Q][g][j][e] fp32 (16x16x4 f32 MFMA kernels, small linears)
-//   fmt 1: dst[kt][plane][j][32] bf16 -- the exact 3-way bf16 split of W (macx_gemm6.cuh, B_PLAIN); K*Nout*3/2 floats
-//   fmt 2: dst[kt][j][32] fp32 k-major tiles (macx_gemm6.cuh, B_YMIX_*: mixed in fp32, split while staging)
+//   fmt 1: dst[kt][plane][j][32] bf16 -- the exact 3-way bf16 split of W (macx_gemm6.hip.h, B_PLAIN); K*Nout*3/2 floats
+//   fmt 2: dst[kt][j][32] fp32 k-major tiles (macx_gemm6.hip.h, B_YMIX_*: mixed in fp32, split while staging)
 //   fmt 3: H2 weight planes dst[kt][plane][g][Nout] x 16 B fp16 + the matrix exponent (macx_h2.hip.h, macx_gemm_h2.hip.h)
 struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; int fmt; const float* maxabs; };   // zero fill for k >= k_src or j >= n_src
 constexpr int PACK_MAX = 40;

@@ -1,6 +1,6 @@
-// macx_wgrad6.cuh -- the weight-gradient contractions  C[k][j] = sum_m A[m][k] * G[m][j]  (macx_gemm_tn.cuh) on the
+// macx_wgrad6.hip.h -- the weight-gradient contractions  C[k][j] = sum_m A[m][k] * G[m][j]  (macx_gemm_tn.hip.h) on the
 // bf16 matrix pipe with fp32-class numerics: the same exact 3-way bf16 operand split and six MFMA terms as
-// macx_gemm6.cuh.  Both operands are row-major over the reduction index m, and v_mfma_f32_16x16x32_bf16 wants 8
+// macx_gemm6.hip.h.  Both operands are row-major over the reduction index m, and v_mfma_f32_16x16x32_bf16 wants 8
 // consecutive m per lane, so the transpose happens in registers while staging: a thread loads an 8 (m) x 2 (columns)
 // block (eight 8-byte loads, 512 B contiguous per row across a wave), splits the 16 values and writes, per column and
 // plane, one 16-byte slot [m-group][column] -- conflict-free b128 stores, and fragments are conflict-free b128 reads.
@@ -8,10 +8,10 @@
 //   waves 4-7 consume (fragments + MFMAs of stage c, wave tile 64 x 64 = 4 x 4 MFMA tiles) -- one of each per SIMD, so the
 //   vector ALU work of the split runs beside the matrix pipe instead of in a separate phase of the same waves;
 //   32 reduction rows per stage, two LDS stages, one barrier per stage.
-// Determinism as in macx_gemm_tn.cuh: a workgroup owns one (split, tile) slab, slabs are summed in a fixed order.
+// Determinism as in macx_gemm_tn.hip.h: a workgroup owns one (split, tile) slab, slabs are summed in a fixed order.
 #pragma once
-#include "macx_gemm6.cuh"
-#include "macx_gemm_tn.cuh"
+#include "macx_gemm6.hip.h"
+#include "macx_gemm_tn.hip.h"
 
 namespace macx {
 
@@ -210,7 +210,7 @@ inline hipError_t wgrad6_launch(const TnP& p, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // Per-question interaction gradient  S_b = X_b^T dI1_b  on the split-bf16 path (see sb_wgrad_kernel in
-// macx_gemm_tn.cuh for what S_b is for):  dW1a += diag(y_b) S_b,  dW1b += S_b,  dy[b][k] = sum_j W1a[k][j] S_b[k][j].
+// macx_gemm_tn.hip.h for what S_b is for):  dW1a += diag(y_b) S_b,  dW1b += S_b,  dy[b][k] = sum_j W1a[k][j] S_b[k][j].
 // 4 waves, one per SIMD (the three 64-register accumulator sets + the W1a tile need the whole 512-entry register file),
 // each wave both stages (8 rows x 2 columns of X and of dI1 per lane, exact bf16 split, in-register transpose) and
 // multiplies its 64 x 64 share of the 128 x 128 tile; the pipeline runs straight through question boundaries.

@@ -6,9 +6,9 @@
 // consecutive columns of one row: the producer waves transpose in registers while staging (one v_perm_b32 per two
 // elements) and bring every row to the tensor's common exponent with one v_pk_mul_f16 by an exact power of two (rows far
 // below the largest lose low bits exactly as their share of the sum warrants).  Two fp16 planes, three MFMA terms.
-// Tiling, slabs and the fixed-order slab reduction are those of macx_wgrad6.cuh.
+// Tiling, slabs and the fixed-order slab reduction are those of macx_wgrad6.hip.h.
 #pragma once
-#include "macx_gemm_tn.cuh"
+#include "macx_gemm_tn.hip.h"
 #include "macx_h2.hip.h"
 
 namespace macx {
@@ -30,7 +30,7 @@ __device__ __forceinline__ uint32_t pk_pow2_f16(int k) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// read-unit attention backward (the same arithmetic as read_att_bwd_kernel in macx_small.cuh); one workgroup per
+// read-unit attention backward (the same arithmetic as read_att_bwd_kernel in macx_small.hip.h); one workgroup per
 // (question, 128-column block), a row's 128 columns live in the 32 lanes of a half-wave.
 // ---------------------------------------------------------------------------------------------------------------
 struct ReadAttBwdH2P {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
 //   every G column by Kd / (128 KW)), so the tile is as large as the accumulators allow: 256 x 256 (128 registers per lane,
 //   64 KB stages, ring of 2) when both dimensions allow, else ring of 3 (48 KB stages) or 4; the wait for a stage is an
 //   explicit s_waitcnt vmcnt(n) that leaves the younger stages' DMA in flight (see dma16b).
-// Determinism as in macx_gemm_tn.cuh: a workgroup owns one (split, tile) slab, slabs are summed in a fixed order.
+// Determinism as in macx_gemm_tn.hip.h: a workgroup owns one (split, tile) slab, slabs are summed in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------
 struct TnH2P {
   int M;                 // reduction rows over all tensors
@@ -427,7 +427,7 @@ inline hipError_t wgrad_h2_launch(const TnH2P& p, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Per-question interaction gradient  S_b = X_b^T dI1_b  over H2 operands (see sb_wgrad_kernel in macx_gemm_tn.cuh for what
+// Per-question interaction gradient  S_b = X_b^T dI1_b  over H2 operands (see sb_wgrad_kernel in macx_gemm_tn.hip.h for what
 // S_b is for):  dW1a += diag(y_b) S_b,  dW1b += S_b,  dy[b][k] = sum_j W1a[k][j] S_b[k][j].
 //
 // All 8 waves multiply (one 64 x 32 eighth of the 128 x 128 tile each, three accumulator sets = 96 registers, two waves per

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- not part of the product path.
 
 numpy restatement of the stateless dropout stream the HIP kernels use
-(mac-network_amd/csrc/macx_common.cuh: hash_mix / site_key / keep_bit).
+(mac-network_amd/csrc/macx_common.hip.h: hash_mix / site_key / keep_bit).
 
 The reference draws its masks from TensorFlow's stateful RNG (ops.py:312, :674-679, :1054-1059;
 mac_cell.py:217, :463): `floor(keep + U[0,1))`.  That stream cannot be reproduced outside TF, so
