@@ -161,7 +161,9 @@ def make_step(macx, dev, dist, world, rank, global_batch, p, seed):
     vqd, wd, kbd = [t.to(dev).requires_grad_(True) for t in (vq, words, kb)]
     ld = lengths.to(dev)
     gmem = (torch.randn(bl, D, generator=torch.Generator().manual_seed(1)) / global_batch).to(dev)
-    bucket = macx.dp.GradBucket(params.tensors(), flat=params.grad_buffer())
+    # two buckets over the flat gradient buffer: everything but the read unit's deferred contractions is all-reduced on a
+    # side stream while the last phase of the backward pass still runs (macx.dp.OverlappedBuckets)
+    bucket = macx.dp.OverlappedBuckets(params) if world > 1 else None
 
     def step(i):
         cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=ld,
@@ -173,6 +175,8 @@ def make_step(macx, dev, dist, world, rank, global_batch, p, seed):
             t.grad = None
         for t in params.tensors():
             t.grad = None
+        if world > 1:
+            bucket.begin_step(bl, global_batch)
         torch.autograd.backward([state.memory], [gmem])
         if world > 1:
             bucket.allreduce_(bl, global_batch)
@@ -360,7 +364,7 @@ def main():
                                       "14x14x1024 features), d=%d, p=%d; cell only (stem/encoder/classifier: model_level)"
                                       % (global_batch, world, bl, S, N, D, D, p),
                           "global_batch": global_batch, "parallelism": "dp%d" % world,
-                          "collective": None if world == 1 else "%s all-reduce of the flat gradient buffer, world size %d" % (
+                          "collective": None if world == 1 else "%s all-reduce of the flat gradient buffer in two buckets (the first overlapped with the last phase of the backward pass on a side stream), world size %d" % (
                               "RCCL (backend nccl)" if backend == "nccl" else backend, dist.get_world_size()),
                           "flops_per_question_fwd_bwd": 3 * p * F},
                "roofline": roofline}

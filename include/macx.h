@@ -200,6 +200,15 @@ int macx_cell_backward(const macx_opts*, const macx_shapes*, const macx_dropout*
                        float* ws, size_t ws_floats,
                        const float* d_memory, const float* d_control,
                        const macx_param_grads*, const macx_input_grads*, void* stream);
+/* The same in two parts for data-parallel overlap: phase 1 = everything except the read unit's deferred weight contractions
+ * (dW2, dWx over all p*B*N rows, the S_b slab sums for dW1 and their bias sums), phase 2 = only those, on the buffers of a
+ * phase-1 call; phase 0 = both (= macx_cell_backward).  After phase 1 every other parameter gradient and all input
+ * gradients are final, so a host can all-reduce them on a side stream while phase 2 runs (mac-network_amd/dp.py). */
+int macx_cell_backward_phase(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*,
+                       const macx_inputs*, const float* saved, size_t saved_floats,
+                       float* ws, size_t ws_floats,
+                       const float* d_memory, const float* d_control,
+                       const macx_param_grads*, const macx_input_grads*, int phase, void* stream);
 
 /* ---- output unit + classifier (consumer of the final memory) ------------------ */
 /* outputOp (model.py:512-528, --outQuestion) + classifier (model.py:547-576 -> ops.FCLayer

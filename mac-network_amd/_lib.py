@@ -104,6 +104,7 @@ class MacxInputGrads(C.Structure):
 
 EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats", "macx_ws_floats",
            "macx_saved_segment", "macx_cell_begin", "macx_cell_step", "macx_cell_forward", "macx_cell_backward",
+           "macx_cell_backward_phase",
            "macx_linear", "macx_pack_weight", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_wgrad_splits",
            "macx_wgrad", "macx_debug_set", "macx_output_saved_floats", "macx_output_ws_floats",
            "macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
@@ -153,6 +154,7 @@ def lib():
     L.macx_cell_step.argtypes = common + [C.c_int, C.c_int, C.c_void_p]
     L.macx_cell_forward.argtypes = common + [C.c_int, C.c_void_p]
     L.macx_cell_backward.argtypes = common + [C.c_void_p, C.c_void_p, P(MacxParamGrads), P(MacxInputGrads), C.c_void_p]
+    L.macx_cell_backward_phase.argtypes = common + [C.c_void_p, C.c_void_p, P(MacxParamGrads), P(MacxInputGrads), C.c_int, C.c_void_p]
     L.macx_linear.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                               C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.macx_pack_weight.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

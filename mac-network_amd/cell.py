@@ -106,7 +106,7 @@ class _Run:
         ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         gstruct = _lib.MacxParamGrads()
         grads = {}
-        present = [f for f in _lib.PARAM_FIELDS if f in self._ptensors]
+        present = [f for f in self.params.fields if f in self._ptensors]
         sizes = [(self._ptensors[f].numel() + 3) & ~3 for f in present]          # 16-byte aligned views
         # the parameters' persistent flat gradient buffer (one fill instead of one per parameter; the views below become the
         # parameters' .grad, so a flat all-reduce / optimizer needs no gather).  A second backward before the first one's
@@ -134,10 +134,17 @@ class _Run:
         dm = _f32c(d_memory, "d_memory") if d_memory is not None else None
         dc = _f32c(d_control, "d_control") if d_control is not None else None
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(self.L.macx_cell_backward(
-            C.byref(self.opts), C.byref(self.shapes), C.byref(self.drop), C.byref(self.pstruct), C.byref(self.inputs),
-            _ptr(self.saved), C.c_size_t(self.saved_floats), _ptr(ws), C.c_size_t(ws_floats), _ptr(dm), _ptr(dc),
-            C.byref(gstruct), C.byref(gistruct), stream), "macx_cell_backward")
+        args = (C.byref(self.opts), C.byref(self.shapes), C.byref(self.drop), C.byref(self.pstruct), C.byref(self.inputs),
+                _ptr(self.saved), C.c_size_t(self.saved_floats), _ptr(ws), C.c_size_t(ws_floats), _ptr(dm), _ptr(dc),
+                C.byref(gstruct), C.byref(gistruct))
+        hook = getattr(self.params, "after_backward_phase1", None)
+        if hook is not None and flat is getattr(self.params, "_grad_flat", None):
+            # every gradient except the read unit's big contractions is final: let the data-parallel layer start on it
+            _lib.check(self.L.macx_cell_backward_phase(*args, 1, stream), "macx_cell_backward_phase(1)")
+            hook(flat)
+            _lib.check(self.L.macx_cell_backward_phase(*args, 2, stream), "macx_cell_backward_phase(2)")
+        else:
+            _lib.check(self.L.macx_cell_backward(*args, stream), "macx_cell_backward")
         return grads, gi_vq, gi_words, gi_kb
 
 

@@ -794,10 +794,14 @@ int macx_cell_forward(const macx_opts* o, const macx_shapes* s, const macx_dropo
 }
 
 // -------------------------------------------------------------------------------------------------
-int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
-                       const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
-                       const float* d_memory, const float* d_control, const macx_param_grads* GP,
-                       const macx_input_grads* GI, void* stream) {
+// phase 0: everything; 1: all of it except the deferred read-unit weight contractions; 2: only those (after a phase-1 call
+// on the same buffers).  A data-parallel host launches the all-reduce of every gradient phase 1 completes on a side stream
+// while phase 2 -- the last ~10 % of the backward pass -- still runs (macx.dp.OverlappedBuckets).
+int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                             const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                             const float* d_memory, const float* d_control, const macx_param_grads* GP,
+                             const macx_input_grads* GI, int phase, void* stream) {
+  if (phase < 0 || phase > 2) return MACX_EINVAL;
   ModeScope ms(o);
   CKI(check_impl(o, s));
   if (!dp || !P || !in || !saved || !ws || !GP || !GI) return MACX_EINVAL;
@@ -814,6 +818,7 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   const int nrb = nrb_of(N, B, d);
   const bool rdrop = dp->keep_read < 1.0f;
 
+  if (phase != 2) {
   // ---- weights in the layouts the backward kernels read
   const int nU = o->control_input_unshared ? p : 1;
   {
@@ -1237,6 +1242,9 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
     CKI(wgrad_impl(saved + L.self_smry, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + 2 * dd, ws + W.small_slab, st));
   CK(rowsum(dwlin_all, p * B, d, d, GP->newMemory_b, st));
 
+  }   // phase != 2
+  if (phase == 1) return MACX_OK;
+
   // ---- read-unit weights: fixed-order reduction of the per-step slabs
   // dW2 = sum_i H1_i^T dI2_i and dWx = sum_i dropout_i(KB)^T dX_i: ONE contraction each over all
   // p*B*N rows (the per-step operands are kept; 288 GB of HBM makes that the cheap choice)
@@ -1287,6 +1295,13 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
   CK(rowsum(ws + W.dwk_part, p * B, d, d, GP->kbLogits_w, st));
   CK(rowsum(ws + W.dbk_part, p * B, 1, 1, GP->kbLogits_b, st));
   return MACX_OK;
+}
+
+int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                       const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                       const float* d_memory, const float* d_control, const macx_param_grads* GP,
+                       const macx_input_grads* GI, void* stream) {
+  return macx_cell_backward_phase(o, s, dp, P, in, saved, saved_floats, ws, ws_floats, d_memory, d_control, GP, GI, 0, stream);
 }
 
 // =================================================================================================

@@ -69,3 +69,78 @@ class GradBucket:
         for t, o, n in zip(self.tensors, self.offsets, self.sizes):            # gradients are views of the reduced buffer
             t.grad = self.flat[o:o + n].view_as(t)
         return self.flat
+
+
+class OverlappedBuckets(GradBucket):
+    """Two buckets over MACCellParams.grad_buffer(), the first in flight while the backward pass is still running.
+
+    The cell's backward pass produces its gradients in two parts (macx_cell_backward_phase): everything except the read
+    unit's [B,N,d]-contraction weights is final after phase 1 -- 80 % of the bytes at p = 12 -- and sits in ONE contiguous
+    range at the front of the flat buffer (MACCellParams.fields puts the late tensors last).  The cell calls
+    `after_backward_phase1` between the phases; this class answers by starting the all-reduce of that range on a side stream
+    (RCCL over xGMI), so it overlaps phase 2, the last ~10 % of the backward pass.  `allreduce_()` after backward() reduces the
+    rest and joins the side stream.  Falls back to the single all-reduce of GradBucket whenever the gradients are not the
+    zero-copy views of the flat buffer.
+
+        bucket = OverlappedBuckets(params)
+        bucket.begin_step(shard_size, global_size)     # before backward(): the hook needs the shard weight
+        loss.backward()
+        bucket.allreduce_(shard_size, global_size)
+    """
+
+    def __init__(self, params, group=None):
+        super().__init__(params.tensors(), flat=params.grad_buffer())
+        self.early = params.early_floats()
+        self.group = group
+        self.weight = 1.0
+        self._early_work = None
+        self._early_started = False
+        self.side = torch.cuda.Stream(device=self.flat.device) if self.flat.is_cuda else None
+        self.overlapped_steps = 0
+        params.after_backward_phase1 = self._phase1
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def begin_step(self, shard_size, global_size):
+        self.weight = float(shard_size) / float(global_size)
+        self._early_started = False
+        self._early_work = None
+
+    def _phase1(self, flat):
+        if not self._active() or flat.data_ptr() != self.flat.data_ptr() or self.early == 0:
+            return
+        part = self.flat[: self.early]
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.side):
+                if self.weight != 1.0:
+                    part.mul_(self.weight)
+                self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            if self.weight != 1.0:
+                part.mul_(self.weight)
+            self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._early_started = True
+
+    def allreduce_(self, shard_size, global_size, group=None):
+        w = float(shard_size) / float(global_size)
+        if not (self._early_started and w == self.weight and self._in_place()):
+            if self._early_started:
+                raise RuntimeError("the early bucket is already in flight but the gradients are not views of the flat buffer")
+            return super().allreduce_(shard_size, global_size, group if group is not None else self.group)
+        late = self.flat[self.early:]
+        if w != 1.0:
+            late.mul_(w)
+        if late.numel():
+            dist.all_reduce(late, op=dist.ReduceOp.SUM, group=self.group)
+        if self._early_work is not None:
+            self._early_work.wait()
+        if self.side is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+        self._early_started = False
+        self.overlapped_steps += 1
+        self.zero_copy_steps += 1
+        for t, o, n in zip(self.tensors, self.offsets, self.sizes):
+            t.grad = self.flat[o:o + n].view_as(t)
+        return self.flat

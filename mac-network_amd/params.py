@@ -8,6 +8,8 @@ from . import _lib
 from .options import get
 
 SCOPE = "MACnetwork/MACCell/"
+# gradients written by phase 2 of the backward pass (the deferred contractions over all p*B*N rows and their bias sums)
+LATE_FIELDS = ("projX_W", "projX_b", "memKbProj_W", "memKbProj_b", "memKbProj2_W", "memKbProj2_b", "kbLogits_w", "kbLogits_b")
 _LIN = "linearLayer%s/weights/weight"
 _BIAS = "linearLayer%s/biases/bias"
 
@@ -85,9 +87,13 @@ class MACCellParams(torch.nn.Module):
         self.p = int(netLength if netLength is not None else get(config, "netLength"))
         self._names = reference_names(config, self.p)
         sh = shapes(config, self.p)
-        self.fields = [f for f in _lib.PARAM_FIELDS if f in self._names]
+        created = [f for f in _lib.PARAM_FIELDS if f in self._names]
+        # order of tensors() / of the flat gradient buffer: the read unit's [B,N,d]-contraction weights LAST.  Their gradients
+        # are the last thing the backward pass produces (macx_cell_backward_phase, phase 2), so everything in front of them
+        # is one contiguous range that a data-parallel all-reduce can take while phase 2 still runs (dp.OverlappedBuckets)
+        self.fields = [f for f in created if f not in LATE_FIELDS] + [f for f in created if f in LATE_FIELDS]
         gen = generator
-        for f in self.fields:
+        for f in created:
             shape = sh[f]
             if f in ("initMem", "initCtrl"):
                 t = torch.randn(shape, generator=gen, dtype=torch.float64)          # mac_cell.py:498-499
@@ -104,6 +110,10 @@ class MACCellParams(torch.nn.Module):
 
     def tensors(self):
         return [getattr(self, f) for f in self.fields]
+
+    def early_floats(self):
+        """Floats of grad_buffer() in front of the first LATE_FIELDS segment: complete after phase 1 of the backward pass."""
+        return sum((getattr(self, f).numel() + 3) & ~3 for f in self.fields if f not in LATE_FIELDS)
 
     def grad_buffer(self):
         """Persistent flat fp32 buffer the backward pass writes the parameter gradients into (16-byte aligned segments in

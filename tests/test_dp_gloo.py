@@ -66,3 +66,48 @@ def test_tower_slice_rule():
     import macx
     assert [macx.dp.tower_slice(1024, r, 8) for r in (0, 7)] == [(0, 128), (896, 1024)]
     assert [macx.dp.tower_slice(10, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 10)]
+
+
+def _overlap_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import macx
+    from oracle import mac_oracle as mo
+    cfg = mo.flag_file_config("args", netLength=3, memDim=128, ctrlDim=128, attDim=128)
+    params = macx.MACCellParams(cfg, 3)
+    bucket = macx.dp.OverlappedBuckets(params)
+    flat = params.grad_buffer()
+    assert 0 < bucket.early < flat.numel() and bucket.early == params.early_floats()
+    late_names = [f for f in params.fields if f in macx.params.LATE_FIELDS]
+    assert params.fields[-len(late_names):] == late_names          # the phase-2 gradients close the buffer
+    shard, glob = (2, 5) if rank == 0 else (3, 5)
+    bucket.begin_step(shard, glob)
+    # what the cell's backward does: gradients are views of the flat buffer; phase 1 fills the front, calls the hook, phase 2 the rest
+    off = 0
+    for t in params.tensors():
+        t.grad = flat[off: off + t.numel()].view_as(t)
+        off += (t.numel() + 3) & ~3
+    flat.zero_()
+    flat[: bucket.early] = float(rank + 1)
+    params.after_backward_phase1(flat)
+    flat[bucket.early:] = float(10 * (rank + 1))
+    bucket.allreduce_(shard, glob)
+    want_early = 1.0 * 2 / 5 + 2.0 * 3 / 5
+    ok = bool(torch.allclose(flat[: bucket.early], torch.full((bucket.early,), want_early)))
+    ok = ok and bool(torch.allclose(flat[bucket.early:], torch.full((flat.numel() - bucket.early,), 10 * want_early)))
+    ok = ok and all(t.grad.data_ptr() >= flat.data_ptr() for t in params.tensors())
+    if rank == 0:
+        ret["ok"], ret["overlapped"] = ok, bucket.overlapped_steps
+    dist.destroy_process_group()
+
+
+def test_overlapped_buckets_two_ranks():
+    """macx.dp.OverlappedBuckets: the early bucket starts from the backward pass's phase-1 hook, the late one after it; both
+    weighted by shard size; gradients stay views of the flat buffer."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_overlap_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["ok"] and ret["overlapped"] == 1
