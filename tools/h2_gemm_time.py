@@ -15,7 +15,7 @@ def child(mask, reps, rt=0):
         L.macx_debug_set(2, rt)
     p = lambda t: C.c_void_p(t.data_ptr())
     dev = torch.device("cuda:0")
-    B, N, K = 64, 196, 512
+    B, N, K = int(os.environ.get('MACX_TIME_B', '64')), 196, 512
     g = torch.Generator().manual_seed(1)
     A = torch.randn(B, N, K, generator=g).to(dev)
     W = (torch.randn(K, K, generator=g) / 22).to(dev)
