@@ -308,13 +308,19 @@ int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows,
 #define MACX_PACK_BF16X3 (1 << 1)
 #define MACX_PACK_KMAJOR (2 << 1)
 int macx_pack_weight(const float* W, int K, int n_out, int flags, float* out, void* stream);
-/* Which kernel family runs the knowledge-base GEMMs (projX, memKbProj, memKbProj_2, their backward-data products and
- * the stem's implicit-GEMM convolutions).  gfx950 issues f32-input MFMA at 1/16 of the bf16 rate and has no TF32 form, so
- * the default is MACX_GEMM_SPLIT: every fp32 operand is split exactly into three bf16 pieces and a product is the six
- * leading cross terms on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- fp32-class error (measured <= the native
- * kernel's against fp64, tests/test_gpu_units.py) at 6/16 of the f32 issue time.  MACX_GEMM_NATIVE keeps
- * v_mfma_f32_16x16x4_f32 (bit-equal to an fmaf chain).  mode < 0 queries.  Returns the mode now in force.
- * Process-wide; set it before sizing/running (packed-weight formats differ). */
+/* Which kernel family runs the knowledge-base GEMMs (projX, memKbProj, memKbProj_2, their backward-data products, the
+ * weight-gradient contractions and the stem's implicit-GEMM convolutions).  gfx950 issues f32-input MFMA at 1/16 of the
+ * 16-bit rate and has no TF32 form, so the large contractions run on the 16-bit matrix pipe at fp32-class accuracy:
+ *   MACX_GEMM_H2 (default)  every [B,N,d] activation is stored ONCE, by its producer, as x 2^e = hi + lo (two fp16 planes,
+ *                           |error| <= 2^-24, one int8 exponent per row and 128 columns); a product is 3 MFMA terms on
+ *                           v_mfma_f32_16x16x32_f16 with fp32 accumulation (see "the H2 tensor format" below)
+ *   MACX_GEMM_SPLIT         every fp32 operand is split exactly into three bf16 pieces while it is staged, 6 terms on
+ *                           v_mfma_f32_16x16x32_bf16
+ *   MACX_GEMM_NATIVE        v_mfma_f32_16x16x4_f32 (bit-equal to an fmaf chain)
+ * Measured error against fp64 of all three: tests/test_gpu_h2.py, tests/test_gpu_units.py.
+ * This call sets / queries (mode < 0) the PROCESS DEFAULT and returns it; a run selects its own family with
+ * macx_opts.gemm_family, which is applied per call on the calling thread.  Packed-weight formats and buffer sizes differ
+ * between families: use one family for the sizing, forward and backward calls of a run. */
 #define MACX_GEMM_NATIVE 0
 #define MACX_GEMM_SPLIT 1
 #define MACX_GEMM_H2 2
