@@ -678,6 +678,7 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     GemmH2P g;
     memset(&g, 0, sizeof(g));
     g.B = B; g.N = N; g.K = d; g.Nout = d;
+    g.dbg = kb_gemm_dbg() & (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128);      // phase-timing knobs (results are wrong under a non-zero mask)
     g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
     // X = dropout(KB) Wx + bx  (ops.py:678,688)
     g.A = hKB;
@@ -957,6 +958,7 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
       GemmH2P g;
       memset(&g, 0, sizeof(g));
       g.B = B; g.N = N; g.K = d; g.Nout = d;
+      g.dbg = kb_gemm_dbg() & (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128);      // phase-timing knobs (results are wrong under a non-zero mask)
       g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
       // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
       g.A = hdI2;

@@ -349,6 +349,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
     }
   }
   __syncthreads();
+  if (p.dbg & 128) return;                         // timing experiment: stop after the accumulator tile is in LDS
 
   if (EP == E_DKB) {
     GemmP q;
@@ -369,6 +370,12 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   f32x4* red = reinterpret_cast<f32x4*>(rexp + ROWS);       // [16][32] column partials
   float val[ITEMS][8];
   const size_t oRp = p.out.Rp();
+  // The activation is a run-time option but must not be a per-value branch: with `switch (p.act)` inside, the 64 values of a
+  // thread unrolled into ~9400 instructions of branch chains (tanh / sigmoid / elu / relu bodies per value) -- more code than
+  // the instruction cache holds, a taken branch every few instructions -- and this pass took 13 of the kernel's 41 us.
+  // The pass is instantiated once per activation and selected by ONE switch.
+  auto row_pass = [&](auto act_c) {
+  constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const int it = tid + G_THREADS * i;
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
       }
       if (EP == E_BIAS_ACT) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = act_apply(p.act, x[e]);
+        for (int e = 0; e < 8; ++e) x[e] = act_apply(ACT, x[e]);
       }
       if (EP == E_I2_LOGIT) {
         // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w   (the bias b_k is added in kb_attend)
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
         float part = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float g = act_apply(p.act, x[e] * (e < 4 ? c0[e & 3] : c1[e & 3]));
+          float g = act_apply(ACT, x[e] * (e < 4 ? c0[e & 3] : c1[e & 3]));
           g = ((bits >> e) & 1u) ? g * p.e_inv_keep : 0.f;
           part = fmaf(g, e < 4 ? w0[e & 3] : w1[e & 3], part);
         }
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
         float h[8];
         h2_join8(hh, hl, h2_pow2(-(int)p.aux.exps()[(grow0 + lrow) * p.aux.cb() + cb]), h);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] *= act_grad_from_out(p.act, h[e]);
+        for (int e = 0; e < 8; ++e) x[e] *= act_grad_from_out(ACT, h[e]);
       }
       float m = 0.f;
 #pragma unroll
@@ -423,7 +430,16 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
       }
     }
   }
+  };
+  switch (p.act) {
+    case ACT_TANH: row_pass(std::integral_constant<int, ACT_TANH>{}); break;
+    case ACT_SIGMOID: row_pass(std::integral_constant<int, ACT_SIGMOID>{}); break;
+    case ACT_ELU: row_pass(std::integral_constant<int, ACT_ELU>{}); break;
+    case ACT_RELU: row_pass(std::integral_constant<int, ACT_RELU>{}); break;
+    default: row_pass(std::integral_constant<int, ACT_NON>{}); break;
+  }
   __syncthreads();
+  if (p.dbg & 2) return;                           // timing experiment: stop after the row pass
   if (tid < nvalid) {
     float m = Mx[tid];
 #pragma unroll
@@ -478,8 +494,17 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
       u32x4 hi, lo;
       h2_split8(xs, hi, lo);
       char* d = o0 + ((size_t)(cb * 16 + kgl) * oRp + grow0 + lrow) * 16;
-      *reinterpret_cast<u32x4*>(d) = hi;
-      *reinterpret_cast<u32x4*>(d + opb) = lo;
+      if (p.dbg & 8) continue;                       // timing experiment: no output stores
+      if (p.dbg & 4) {                               // timing experiment: write-through stores
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d), "v"(hi) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d + opb), "v"(lo) : "memory");
+      } else if (p.dbg & 16) {                       // timing experiment: non-temporal stores
+        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(d), "v"(hi) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(d + opb), "v"(lo) : "memory");
+      } else {
+        *reinterpret_cast<u32x4*>(d) = hi;
+        *reinterpret_cast<u32x4*>(d + opb) = lo;
+      }
     }
   }
 }

@@ -98,6 +98,9 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
   const int icb = p.I2.cb(), ocb = p.dI2.cb();
   f32x4 a_dc = {0.f, 0.f, 0.f, 0.f}, a_dw = {0.f, 0.f, 0.f, 0.f}, a_db = {0.f, 0.f, 0.f, 0.f};
   int emin = 127;
+  // (the activation is selected by ONE switch around the row loop, not per value: see the row pass of kb_gemm_h2_kernel)
+  auto rows = [&](auto act_c) {
+  constexpr int ACT = decltype(act_c)::value;
   for (int n0 = 0; n0 < p.N; n0 += RABH_RG) {
     const int n = n0 + rg;
     const bool ok = n < p.N;
@@ -114,9 +117,9 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float zv = i2[e] * cv[e];
-      const float g = act_apply(p.act, zv);
+      const float g = act_apply(ACT, zv);
       const float f = ((bits >> e) & 1u) ? p.inv_keep : 0.f;
-      const float dz = (dl * wv[e]) * f * act_grad_from_out(p.act, g);
+      const float dz = (dl * wv[e]) * f * act_grad_from_out(ACT, g);
       o[e] = dz * cv[e];                                  // dI2 = dZ * c
       if (ok) {
         a_dw[e] = fmaf(dl, g * f, a_dw[e]);               // dw_k += dl * dropped(G)
@@ -140,6 +143,14 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
       if (c4 == 0) p.dI2.exps()[row * ocb + slab] = (int8_t)ex;
       emin = min(emin, ex);
     }
+  }
+  };
+  switch (p.act) {
+    case ACT_TANH: rows(std::integral_constant<int, ACT_TANH>{}); break;
+    case ACT_SIGMOID: rows(std::integral_constant<int, ACT_SIGMOID>{}); break;
+    case ACT_ELU: rows(std::integral_constant<int, ACT_ELU>{}); break;
+    case ACT_RELU: rows(std::integral_constant<int, ACT_RELU>{}); break;
+    default: rows(std::integral_constant<int, ACT_NON>{}); break;
   }
   __syncthreads();
 #pragma unroll
