@@ -56,7 +56,7 @@ constexpr int kb_gemm_h2_lds_bytes() {
   constexpr int ROWS = RT * 16;
   constexpr int stage = 2 * 4 * ROWS * 16 + 2 * 4 * 128 * 16;
   constexpr int ring = 3 * stage + ROWS * 32 + 4096;    // + the fold factors of the tile's rows + the question's mixing vector
-  constexpr int epi = ROWS * 132 * 4 + 2 * 16 * ROWS * 4 + ROWS * 4 + 16 * 32 * 16;
+  constexpr int epi = ROWS * 132 * 4 + 2 * 16 * ROWS * 4 + ROWS * 4 + 16 * 32 * 16 + 3 * 128 * 4;
   return ring > epi ? ring : epi;
 }
 
@@ -338,6 +338,16 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
 
   // ---- epilogue, step 1: accumulators -> row-major LDS tile (16x16 map: col = lane & 15, row = (lane >> 4) * 4 + reg)
   float* T = smem;
+  // the per-column constants of the row pass (bias | control vector | logits weight of this 128-column block) go to LDS
+  // once: in the row pass all 64 lanes of a wave work on the same slot column, so these become broadcast LDS reads instead
+  // of six dependent global loads per item
+  float* sC = smem + ROWS * G_LDT + 2 * 16 * ROWS + ROWS + 16 * 32 * 4;      // [3][128], behind T | Mx | Px | rexp | red
+  if (EP != E_DKB && tid < 96) {
+    const int which = tid >> 5, c4 = (tid & 31) * 4;
+    const float* src = which == 0 ? p.bias : (which == 1 ? p.cvec + (size_t)b * p.Nout : p.wvec);
+    const bool have = which == 0 ? (EP == E_BIAS_ACT || EP == E_I2_LOGIT) : (EP == E_I2_LOGIT);
+    if (have) *reinterpret_cast<f32x4*>(sC + which * 128 + c4) = *reinterpret_cast<const f32x4*>(src + cb * G_BN + c4);
+  }
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
     if (t0 + t < RT) {
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { x[e] = a0[e]; x[4 + e] = a1[e]; }
       if (EP == E_BIAS_ACT || EP == E_I2_LOGIT) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sC + kgl * 8), b1 = *reinterpret_cast<const f32x4*>(sC + kgl * 8 + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { x[e] += b0[e]; x[4 + e] += b1[e]; }
       }
@@ -398,9 +408,8 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
       }
       if (EP == E_I2_LOGIT) {
         // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w   (the bias b_k is added in kb_attend)
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.cvec + (size_t)b * p.Nout + col);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.cvec + (size_t)b * p.Nout + col + 4);
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wvec + col), w1 = *reinterpret_cast<const f32x4*>(p.wvec + col + 4);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(sC + 128 + kgl * 8), c1 = *reinterpret_cast<const f32x4*>(sC + 128 + kgl * 8 + 4);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sC + 256 + kgl * 8), w1 = *reinterpret_cast<const f32x4*>(sC + 256 + kgl * 8 + 4);
         const uint32_t bits = p.e_bytes ? p.e_bytes[(size_t)(cb * 16 + kgl) * oRp + grow0 + lrow] : 0xFFu;
         float part = 0.f;
 #pragma unroll
