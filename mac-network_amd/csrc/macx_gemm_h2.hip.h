@@ -55,7 +55,7 @@ template <int RT>
 constexpr int kb_gemm_h2_lds_bytes() {
   constexpr int ROWS = RT * 16;
   constexpr int stage = 2 * 4 * ROWS * 16 + 2 * 4 * 128 * 16;
-  constexpr int ring = 3 * stage + ROWS * 32 + 4096;    // + the fold factors of the tile's rows + the question's mixing vector
+  constexpr int ring = 3 * stage + ROWS * 32 + 4096 + 64;   // + the fold factors of the tile's rows + the question's mixing vector + a reduction scratch
   constexpr int epi = ROWS * 132 * 4 + 2 * 16 * ROWS * 4 + ROWS * 4 + 16 * 32 * 16 + 3 * 128 * 4;
   return ring > epi ? ring : epi;
 }
@@ -105,37 +105,12 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   const int nk = p.K >> 5;
   const int nkb = p.K >> 7;                          // 128-wide K blocks = exponent blocks of A
 
-  // ---- weight exponent; fold factors of this tile's rows (below, once it is known)
+  // ---- LDS behind the ring: fold factors, the question's mixing vector, a reduction scratch.  They are filled AFTER the first
+  //      two K slices have been requested (below): their global loads then overlap the DMA instead of preceding it
   float* sF = reinterpret_cast<float*>(lds + 3 * STAGE);           // [K / 128][ROWS]: 2^-(eA[row][kb] + eB)
   float* sY = reinterpret_cast<float*>(lds + 3 * STAGE + ROWS * 32);  // B_YMIX_ROW: y_b[K]
   int eB = 0;
-  if (BP == B_PLAIN) {
-    eB = *p.w_exp;
-  } else {
-    if (BP == B_YMIX_ROW)
-      for (int k = tid; k < p.K; k += G_THREADS) sY[k] = p.y[(size_t)b * p.ldy + k];
-    // |y W1a + W1b| <= max|y_b| max|W1a| + max|W1b|: a power of two above the bound costs at most the low end of the range
-    float* red = reinterpret_cast<float*>(lds);
-    float m = 0.f;
-    for (int k = tid; k < p.K; k += G_THREADS) m = fmaxf(m, fabsf(p.y[(size_t)b * p.ldy + k]));
-    m = wave_max(m);
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    m = red[0];
-#pragma unroll
-    for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
-    eB = h2_weight_exponent(fmaf(m, p.w_max[0], p.w_max[1]));
-    __syncthreads();
-  }
-  const float sB = h2_pow2(eB);
-  {
-    const int8_t* eA = p.A.exps();
-    const int acb = p.A.cb();
-    for (int i = tid; i < ROWS * acb; i += G_THREADS) {
-      const int r = i / acb, k = i - r * acb;                      // rows past the tensor end lie in the pad rows
-      sF[k * ROWS + r] = h2_unscale((int)eA[(grow0 + r) * acb + k], eB);
-    }
-  }
+  float sB = 1.f;
 
   f32x4 acc[HT][2], tot[HT][2];
 #pragma unroll
@@ -281,10 +256,47 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   // enough wait states for any vector-ALU read of its results, whatever follows it.
 
   const bool do_stage = !(p.dbg & 32), do_compute = !(p.dbg & 64);
+  // the first two K slices are requested before anything else is loaded
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
   if (BP == B_PLAIN) {
     issue(0);
-    if (nk > 1) { issue(1); wait_vmcnt_n(my_n); } else wait_vmcnt<0>();
-    __syncthreads();                   // slice 0 has landed, for every wave's share of it
+    if (nk > 1) issue(1);
+  } else {
+    load_w(S0{}, 0);
+    issue(0);
+    if (nk > 1) { load_w(S1{}, 1); issue(1); }
+  }
+  // ---- weight exponent; fold factors of this tile's rows
+  if (BP == B_PLAIN) {
+    eB = *p.w_exp;
+  } else {
+    if (BP == B_YMIX_ROW)
+      for (int k = tid; k < p.K; k += G_THREADS) sY[k] = p.y[(size_t)b * p.ldy + k];
+    // |y W1a + W1b| <= max|y_b| max|W1a| + max|W1b|: a power of two above the bound costs at most the low end of the range
+    float* red = reinterpret_cast<float*>(lds + 3 * STAGE + ROWS * 32 + 4096);
+    float m = 0.f;
+    for (int k = tid; k < p.K; k += G_THREADS) m = fmaxf(m, fabsf(p.y[(size_t)b * p.ldy + k]));
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+    eB = h2_weight_exponent(fmaf(m, p.w_max[0], p.w_max[1]));
+  }
+  sB = h2_pow2(eB);
+  {
+    const int8_t* eA = p.A.exps();
+    const int acb = p.A.cb();
+    for (int i = tid; i < ROWS * acb; i += G_THREADS) {
+      const int r = i / acb, k = i - r * acb;                      // rows past the tensor end lie in the pad rows
+      sF[k * ROWS + r] = h2_unscale((int)eA[(grow0 + r) * acb + k], eB);
+    }
+  }
+  if (BP == B_PLAIN) {
+    if (nk > 1) wait_vmcnt_n(my_n); else wait_vmcnt<0>();
+    __syncthreads();                   // slice 0 has landed, for every wave's share of it; the tables are complete
     if (p.dbg & 512) { wait_vmcnt<0>(); return; }
     auto step = [&](auto first_c, int kt) {
       if (kt + 2 < nk && do_stage) issue(kt + 2);       // ring stage (kt + 2) % 3 was last read in iteration kt - 1
@@ -304,11 +316,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
     // K / 32 is a multiple of 4).  Iteration kt: request slice kt + 2 (weights, then A rows); wait until the weights of slice
     // kt + 1 are in (everything younger -- A rows of kt + 1, all of kt + 2 -- may still fly); mix / split / store them as
     // ordinary code next to the MFMAs of slice kt, so the scheduler can interleave the two; wait for the A rows of kt + 1
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    load_w(S0{}, 0);
-    issue(0);
-    if (nk > 1) { load_w(S1{}, 1); issue(1); settle_w(S0{}, my_n); } else settle_w(S0{}, 0);
+    if (nk > 1) settle_w(S0{}, my_n); else settle_w(S0{}, 0);
     store_w(S0{}, 0);
     __syncthreads();
     auto iter = [&](auto cur_c, auto nxt_c, auto first_c, int kt) {   // cur: set of slice kt (and kt + 2), nxt: of slice kt + 1
