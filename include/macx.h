@@ -382,6 +382,7 @@ int macx_wgrad(const float* A, int lda, const float* G, int ldg, int M, int Kd, 
  *   macx_op_dropout  out = x / keep * mask(seed, site, step, first + index): tf.nn.dropout on the stateless stream of
  *                    macx_dropout_mask (ops.py:312, mac_cell.py:217,463); its own backward (apply it to dy) */
 #define MACX_OP_PRELU 16
+#define MACX_OP_RSQRT_EPS 17   /* out = 1 / sqrt(x + alpha[0]): batch-norm normaliser (mac_cell.py:370-373); no dalpha */
 enum { MACX_OP_ADD = 0, MACX_OP_MUL = 1 };
 enum { MACX_OP_B_SAME = 0, MACX_OP_B_MID = 1, MACX_OP_B_CHANNEL = 2, MACX_OP_B_ROW = 3 };
 enum { MACX_OP_R_MID = 0, MACX_OP_R_LAST = 1, MACX_OP_R_ROWS = 2 };

@@ -1381,7 +1381,8 @@ int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, u
 
 // ---- the ops.py primitives as single kernels (macx_ops.hip.h): the generic option path ---------------------------
 int macx_op_act(int act, const float* x, const float* alpha, size_t n, int inner, float* out, void* stream) {
-  if (!x || !out || inner < 1 || (act == OP_ACT_PRELU && !alpha) || (act != OP_ACT_PRELU && (act < 0 || act > ACT_RELU))) return MACX_EINVAL;
+  const bool ext = act == OP_ACT_PRELU || act == OP_ACT_RSQRT_EPS;
+  if (!x || !out || inner < 1 || (ext && !alpha) || (!ext && (act < 0 || act > ACT_RELU))) return MACX_EINVAL;
   if (n == 0) return MACX_OK;
   hipLaunchKernelGGL(op_act_kernel, dim3(op_grid(n)), dim3(256), 0, (hipStream_t)stream, act, x, alpha, n, inner, out);
   CK(hipGetLastError());
@@ -1389,8 +1390,8 @@ int macx_op_act(int act, const float* x, const float* alpha, size_t n, int inner
 }
 int macx_op_act_bwd(int act, const float* x, const float* alpha, const float* dy, size_t n, int inner, float* dx, float* dalpha_elem,
                     void* stream) {
-  if (!x || !dy || !dx || inner < 1 || (act == OP_ACT_PRELU && (!alpha || !dalpha_elem)) ||
-      (act != OP_ACT_PRELU && (act < 0 || act > ACT_RELU)))
+  const bool ext = act == OP_ACT_PRELU || act == OP_ACT_RSQRT_EPS;
+  if (!x || !dy || !dx || inner < 1 || (ext && !alpha) || (act == OP_ACT_PRELU && !dalpha_elem) || (!ext && (act < 0 || act > ACT_RELU)))
     return MACX_EINVAL;
   if (n == 0) return MACX_OK;
   hipLaunchKernelGGL(op_act_bwd_kernel, dim3(op_grid(n)), dim3(256), 0, (hipStream_t)stream, act, x, alpha, dy, n, inner, dx, dalpha_elem);

@@ -14,6 +14,7 @@
 namespace macx {
 
 constexpr int OP_ACT_PRELU = 16;        // beyond MACX_ACT_*: relu(x) - alpha[c] * relu(-x)  (ops.py:171-173)
+constexpr int OP_ACT_RSQRT_EPS = 17;    // 1 / sqrt(x + alpha[0]): the normaliser of tf.contrib.layers.batch_norm (mac_cell.py:370-373)
 
 enum { OP_ADD = 0, OP_MUL = 1 };
 enum { OP_B_SAME = 0, OP_B_MID = 1, OP_B_CHANNEL = 2, OP_B_ROW = 3 };
@@ -23,7 +24,8 @@ enum { OP_R_MID = 0, OP_R_LAST = 1, OP_R_ROWS = 2 };
 __global__ __launch_bounds__(256) void op_act_kernel(int act, const float* x, const float* alpha, size_t n, int inner, float* out) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float v = x[i];
-    out[i] = act == OP_ACT_PRELU ? (v > 0.f ? v : alpha[i % inner] * v) : act_apply(act, v);
+    out[i] = act == OP_ACT_PRELU ? (v > 0.f ? v : alpha[i % inner] * v)
+             : act == OP_ACT_RSQRT_EPS ? 1.0f / sqrtf(v + alpha[0]) : act_apply(act, v);
   }
 }
 // dx = dy * act'(x); PRELU also needs d alpha[c] = sum_rows dy * min(x, 0): the caller reduces `dalpha_elem` over rows
@@ -35,6 +37,9 @@ __global__ __launch_bounds__(256) void op_act_bwd_kernel(int act, const float* x
     if (act == OP_ACT_PRELU) {
       d = v > 0.f ? 1.f : alpha[i % inner];
       dalpha_elem[i] = v > 0.f ? 0.f : g * v;
+    } else if (act == OP_ACT_RSQRT_EPS) {
+      const float r = 1.0f / sqrtf(v + alpha[0]);
+      d = -0.5f * r * r * r;
     } else if (act == ACT_ELU) {
       d = elu_grad_from_in(v);
     } else {

@@ -10,8 +10,7 @@ orders the backward kernels -- plumbing.  There is no CPU path: tensors must liv
 Variables are created on first use under the reference's TF names (the same scope stacking as ops.py / mac_cell.py), so a
 reference checkpoint loads by name (GenericParams.load_reference_dict) whatever the option set.
 
-Not covered (UnsupportedOptions, never a silent fallback): memoryBN (tf.contrib.layers.batch_norm), dimensions that are
-not multiples of 128.
+Not covered (UnsupportedOptions, never a silent fallback): dimensions that are not multiples of 128.
 """
 import collections
 import ctypes as C
@@ -30,6 +29,7 @@ OP_ADD, OP_MUL = 0, 1
 B_SAME, B_MID, B_CHANNEL, B_ROW = 0, 1, 2, 3
 R_MID, R_LAST, R_ROWS = 0, 1, 2
 ACT_PRELU = 16
+ACT_RSQRT_EPS = 17
 SITE_MEM_VAR, SITE_MEM, SITE_READ_KB, SITE_READ_MEM, SITE_READ_ATT, SITE_WRITE_INFO = 1, 2, 3, 4, 5, 6
 
 
@@ -83,7 +83,7 @@ def k_act(act, x, alpha):
 
 def k_act_bwd(act, x, alpha, g):
     dx = torch.empty_like(x)
-    de = torch.empty_like(x) if act == ACT_PRELU else None
+    de = torch.empty_like(x) if act == ACT_PRELU else None          # (ACT_RSQRT_EPS: alpha holds eps, no gradient)
     _lib.check(_L().macx_op_act_bwd(act, _p(x), _p(alpha), _p(g), x.numel(), x.shape[-1], _p(dx), _p(de), _st(x)), "macx_op_act_bwd")
     return dx, de
 
@@ -203,6 +203,21 @@ class _Reduce(torch.autograd.Function):
         if ctx.mode == R_MID:
             return k_binary(OP_MUL, B_MID, ones, g, ctx.shape[1], ctx.shape[2]), None
         return k_binary(OP_MUL, B_ROW, ones, g.reshape(-1), 1, ctx.shape[-1]), None
+
+
+class _RowSum(torch.autograd.Function):
+    """Sum over the rows of [rows, c] (macx_op_reduce ROWS): batch statistics."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _dev(x)
+        ctx.shape = tuple(x.shape)
+        return k_reduce(R_ROWS, x, x.shape[0], 1, x.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        ones = torch.ones(ctx.shape, dtype=torch.float32, device=g.device)
+        return k_binary(OP_MUL, B_CHANNEL, ones, g.contiguous(), 1, ctx.shape[1])
 
 
 class _Act(torch.autograd.Function):
@@ -386,6 +401,37 @@ class _Ops:
             name = "ELU" if r == "ELU" else "RELU"
         return _Act.apply(x, _lib.ACT[name], None)
 
+    # tf.contrib.layers.batch_norm(updates_collections=None) on the last axis of a [B, c] tensor (mac_cell.py:370-373):
+    # batch statistics (biased variance) in training, moving averages in evaluation; eps = 0.001
+    def batch_norm(self, x, decay, center, scale, is_training, epsilon=0.001):
+        with self.vs.scope("BatchNorm"):
+            c = x.shape[-1]
+            beta = self.vs.get("beta", (c,), "zeros") if center else None
+            gamma = self.vs.get("gamma", (c,), 1.0) if scale else None
+            mm = self.vs.get("moving_mean", (c,), "zeros")
+            mv = self.vs.get("moving_variance", (c,), 1.0)
+            B = x.shape[0]
+            ones_c = torch.ones(c, dtype=torch.float32, device=x.device)
+            eps = torch.full((1,), epsilon, dtype=torch.float32, device=x.device)
+            x = x.contiguous()
+            if is_training:
+                mean = _Binary.apply(_RowSum.apply(x), ones_c, OP_MUL, B_SAME, 1.0 / B)
+                cen = _Binary.apply(x, _Binary.apply(mean, ones_c, OP_MUL, B_SAME, -1.0), OP_ADD, B_CHANNEL, 1.0)
+                var = _Binary.apply(_RowSum.apply(_Binary.apply(cen, cen, OP_MUL, B_SAME, 1.0)), ones_c, OP_MUL, B_SAME, 1.0 / B)
+                with torch.no_grad():          # assign_moving_average: m -= (1 - decay) (m - stat), outside the gradient
+                    for mov, stat in ((mm, mean), (mv, var)):
+                        kept = k_binary(OP_MUL, B_SAME, mov.detach().contiguous(), ones_c, 1, c, decay)
+                        mov.copy_(k_binary(OP_ADD, B_SAME, kept, k_binary(OP_MUL, B_SAME, stat.detach().contiguous(), ones_c, 1, c, 1.0 - decay), 1, c))
+            else:
+                cen = _Binary.apply(x, _Binary.apply(mm.detach(), ones_c, OP_MUL, B_SAME, -1.0), OP_ADD, B_CHANNEL, 1.0)
+                var = mv.detach()
+            out = _Binary.apply(cen, _Act.apply(var, ACT_RSQRT_EPS, eps), OP_MUL, B_CHANNEL, 1.0)
+            if gamma is not None:
+                out = _Binary.apply(out, gamma, OP_MUL, B_CHANNEL, 1.0)
+            if beta is not None:
+                out = _Binary.apply(out, beta, OP_ADD, B_CHANNEL, 1.0)
+        return out
+
     # ops.linear (ops.py:298-333)
     def linear(self, inp, inDim, outDim, dropout=None, addBias=True, bias=0.0, act="NON", actLayer=True, name=""):
         with self.vs.scope("linearLayer" + name):
@@ -490,8 +536,6 @@ class GenericMACCell:
         self.config = config if config is not None else SimpleNamespace()
         reject_like_reference(self.config)
         g = self.g
-        if g("memoryBN"):
-            raise UnsupportedOptions("no HIP path yet for: --memoryBN")
         for dname in ("memDim", "ctrlDim", "attDim"):
             if g(dname) % 128:
                 raise UnsupportedOptions("the generic path needs %s %% 128 == 0" % dname)
@@ -658,6 +702,8 @@ class GenericMACCell:
                 one_minus = _Binary.apply(_Binary.apply(z, torch.ones_like(z), OP_MUL, B_SAME, -1.0), torch.ones_like(z), OP_ADD, B_SAME, 1.0)
                 newMemory = _Binary.apply(_Binary.apply(newMemory.contiguous(), z, OP_MUL, B_SAME, 1.0),
                                           _Binary.apply(memory.contiguous(), one_minus, OP_MUL, B_SAME, 1.0), OP_ADD, B_SAME, 1.0)
+            if g("memoryBN"):
+                newMemory = ops.batch_norm(newMemory, g("bnDecay"), g("bnCenter"), g("bnScale"), self.train)
         return newMemory
 
     @contextmanager

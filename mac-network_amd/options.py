@@ -22,7 +22,7 @@ DEFAULTS = dict(
     writeInfoProj=False, writeInfoAct="NON", writeSelfAtt=False, writeSelfAttMod="NON", writeMergeCtrl=False,
     writeMemProj=False, writeMemAct="NON", writeGate=False, writeGateShared=False, writeGateBias=1.0,
     memoryVariationalDropout=False, memoryDropout=0.85, readDropout=0.85, writeDropout=1.0, relu="STD", mulBias=0.0,
-    memoryBN=False, netLength=16,
+    memoryBN=False, bnDecay=0.999, bnCenter=False, bnScale=False, netLength=16,
 )
 
 

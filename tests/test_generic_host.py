@@ -9,7 +9,7 @@ import torch
 from oracle import dropout_hash as dh
 from oracle import mac_oracle as mo
 from helpers import oracle_run, rel_err, max_abs
-from test_gpu_generic import VARIANTS, make_cfg, oracle_params, assert_grad
+from test_gpu_generic import VARIANTS, make_cfg, oracle_params, assert_grad, bn_slack
 
 
 def _torch_kernels(G):
@@ -32,6 +32,8 @@ def _torch_kernels(G):
     def act(a, x, alpha):
         if a == G.ACT_PRELU:
             return torch.where(x > 0, x, alpha * x)
+        if a == G.ACT_RSQRT_EPS:
+            return 1.0 / torch.sqrt(x + alpha[0])
         return {0: lambda v: v, 1: torch.tanh, 2: torch.sigmoid, 3: torch.nn.functional.elu, 4: torch.relu}[a](x)
 
     def act_bwd(a, x, alpha, g):
@@ -39,7 +41,7 @@ def _torch_kernels(G):
             return g * torch.where(x > 0, torch.ones_like(x), alpha.expand_as(x)), torch.where(x > 0, torch.zeros_like(x), g * x)
         xx = x.detach().clone().requires_grad_(True)
         with torch.enable_grad():
-            act(a, xx, None).backward(g)
+            act(a, xx, alpha).backward(g)
         return xx.grad, None
 
     def softmax(x, lengths):
@@ -93,22 +95,23 @@ def test_generic_host_logic_matches_oracle(macx, host_generic, variant, train):
     state = cell.run()
     ((state.memory * dM).sum() + (state.control * dC).sum()).backward()
     rc = ref["cell"]
+    k = bn_slack(variant)
     assert list(gp.names) == list(params), "variables are created in the reference's order under the reference's names"
-    assert rel_err(state.memory, ref["memory"]) < 2e-5 and rel_err(state.control, ref["control"]) < 2e-5
-    assert rel_err(cell.memories, rc.memories) < 2e-5 and rel_err(cell.controls, rc.controls) < 2e-5
+    assert rel_err(state.memory, ref["memory"]) < 2e-5 * k and rel_err(state.control, ref["control"]) < 2e-5 * k
+    assert rel_err(cell.memories, rc.memories) < 2e-5 * k and rel_err(cell.controls, rc.controls) < 2e-5 * k
     for kind in ("kb", "question", "self", "gate"):
         assert len(cell.attentions[kind]) == len(rc.attentions[kind])
         for a, b in zip(cell.attentions[kind], rc.attentions[kind]):
-            assert max_abs(a, b) < 2e-6
+            assert max_abs(a, b) < 2e-6 * k
     grads = gp.grads_by_name()
     for k, v in ref["params"].items():
         if v.grad is None:
             assert grads[k] is None or float(grads[k].abs().max()) == 0.0, k
         else:
-            assert_grad(grads[k], v.grad, k)
+            assert_grad(grads[k], v.grad, k, 2e-4 * bn_slack(variant))
     for got, want in zip((vqd, wd, kbd), ref["inputs"]):
         if want.grad is not None:
-            assert rel_err(got.grad, want.grad) < 2e-4
+            assert rel_err(got.grad, want.grad) < 2e-4 * bn_slack(variant)
 
 
 def test_generic_path_refuses_cpu_tensors(macx):
@@ -129,8 +132,6 @@ def test_generic_path_rejections(macx, host_generic):
     vq, words, lengths, kb = mo.synthetic_inputs(2, 4, 5, 128)
     mk = lambda **over: macx.GenericMACCell(vq, words, words, lengths, kb, 1.0, 1.0, 1.0, 2, False,
                                      config=mo.flag_file_config("args", netLength=1, memDim=128, ctrlDim=128, attDim=128, **over))
-    with pytest.raises(macx.UnsupportedOptions):
-        mk(memoryBN=True)
     with pytest.raises(UnboundLocalError):
         mk(readMemAttType="DIAG")
     with pytest.raises(UnboundLocalError):

@@ -42,7 +42,14 @@ VARIANTS = {
     "relu_prm": ("args", dict(relu="PRM", initCtrl="Q", controlContAct="RELU", controlFeedPrev=True)),
     "relu_prm_unshared": ("args", dict(relu="PRM", initCtrl="Q", unsharedCells=True, writeMemAct="RELU")),
     "no_var_dropout": ("args", dict(memoryVariationalDropout=False)),
+    "memory_bn": ("args", dict(memoryBN=True)),
+    "memory_bn_affine": ("args", dict(memoryBN=True, bnCenter=True, bnScale=True)),
 }
+
+
+def bn_slack(variant):
+    """Batch norm over a batch of 3 divides by a small standard deviation: fp32 round-off is amplified ~5x."""
+    return 5.0 if variant.startswith("memory_bn") else 1.0
 
 
 def make_cfg(variant, d, p):
@@ -58,14 +65,14 @@ def oracle_params(cfg, vq, words, lengths, kb, seed=5):
     mo.mac_network(cfg, vs, vq, words, words, lengths, kb)
     g = torch.Generator().manual_seed(seed + 1)
     for k, v in vs.params.items():
-        if "/biases/" in k or k.endswith("alpha"):
+        if "/biases/" in k or k.endswith("alpha") or k.endswith("BatchNorm/beta") or k.endswith("BatchNorm/gamma"):
             v.add_((torch.rand(v.shape, generator=g) - 0.5) * 0.2)
     return {k: v.clone() for k, v in vs.params.items()}
 
 
 def assert_grad(got, want, name, tol=GRAD_TOL):
     if float(want.abs().max()) < 1e-9:          # analytically zero (the bias in front of a softmax): absolute
-        assert float(got.abs().max()) < 2e-5, name
+        assert float(got.abs().max()) < 2e-5 * (tol / GRAD_TOL), name
     else:
         assert rel_err(got.reshape(want.shape), want) < tol, name
 
@@ -100,25 +107,26 @@ def test_generic_path_matches_oracle(macx, dev, variant, train):
     loss.backward()
     torch.cuda.synchronize()
     rc = ref["cell"]
+    slack = bn_slack(variant)
     assert set(gp.names) == set(params), "variable names differ from the reference's"
-    assert rel_err(state.memory, ref["memory"]) < FWD_TOL
-    assert rel_err(state.control, ref["control"]) < FWD_TOL
-    assert rel_err(cell.memories, rc.memories) < FWD_TOL and rel_err(cell.infos, rc.infos) < FWD_TOL
+    assert rel_err(state.memory, ref["memory"]) < FWD_TOL * slack
+    assert rel_err(state.control, ref["control"]) < FWD_TOL * slack
+    assert rel_err(cell.memories, rc.memories) < FWD_TOL * slack and rel_err(cell.infos, rc.infos) < FWD_TOL * slack
     for kind in ("kb", "question", "self", "gate"):
         assert len(cell.attentions[kind]) == len(rc.attentions[kind])
         for a, b in zip(cell.attentions[kind], rc.attentions[kind]):
-            assert max_abs(a, b) < 2e-6
+            assert max_abs(a, b) < 2e-6 * slack
     grads = gp.grads_by_name()
     for k, v in ref["params"].items():
         if v.grad is None:
             assert grads[k] is None or float(grads[k].abs().max()) == 0.0, k
             continue
         assert grads[k] is not None, k
-        assert_grad(grads[k], v.grad, k)
+        assert_grad(grads[k], v.grad, k, GRAD_TOL * slack)
     for name, got, want in zip(("vecQuestions", "words", "knowledgeBase"), (vqd, wd, kbd), ref["inputs"]):
         if want.grad is None:
             continue
-        assert rel_err(got.grad, want.grad) < GRAD_TOL, name
+        assert rel_err(got.grad, want.grad) < GRAD_TOL * slack, name
 
 
 def test_dispatch_between_the_fused_and_the_generic_path(macx, dev):
