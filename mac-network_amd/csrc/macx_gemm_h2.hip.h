@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   }
 
   // ---- step 2: lanes along rows.  item it = tid + 512 i  ->  slot column kgl = it / RP, local row it % RP
-  constexpr int RP = (ROWS + 63) & ~63;
+  constexpr int RP = ROWS;                        // (not rounded to whole waves: at ROWS = 208 that would idle a fifth of the lanes)
   constexpr int ITEMS = (16 * RP + G_THREADS - 1) / G_THREADS;
   float* Mx = smem + ROWS * G_LDT;                 // [16][ROWS] partial row maxima
   float* Px = Mx + 16 * ROWS;                      // [16][ROWS] partial attention logits
