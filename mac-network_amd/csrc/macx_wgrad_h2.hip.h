@@ -30,8 +30,7 @@ __device__ __forceinline__ uint32_t pk_pow2_f16(int k) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// read-unit attention backward (the same arithmetic as read_att_bwd_kernel in macx_small.hip.h); one workgroup per
-// (question, 128-column block), a row's 128 columns live in the 32 lanes of a half-wave.
+// read-unit attention backward (the same arithmetic as read_att_bwd_kernel in macx_small.hip.h).
 // ---------------------------------------------------------------------------------------------------------------
 struct ReadAttBwdH2P {
   int B, N, d;
@@ -51,14 +50,21 @@ struct ReadAttBwdH2P {
   int* qmin;             // [B][d/128] common (minimum) exponent of the question's dI2 rows, written
 };
 
+// One workgroup per (question, 128-column block), 16 waves: wave w owns slot column w (8 columns) and its lanes run along
+// ROWS -- a wave instruction reads / writes 64 consecutive slots of one slot column = one contiguous KiB per plane (the
+// first version ran lanes along columns on this slot-major data: 8-byte pieces of 32 different cache lines per
+// instruction, 2.0 TB/s).  A row's exponent needs the maximum over the 16 slot columns: partial maxima go through a small
+// LDS table, the values wait in registers (128 rows per pass).  The three column sums stay inside a wave (it owns its 8
+// columns): lanes accumulate their rows, one wave reduction per value at the end, no cross-wave combine.
 constexpr int RABH_THREADS = 1024;
-constexpr int RABH_RG = RABH_THREADS / 32;
+constexpr int RABH_CHUNK = 128;           // rows per pass (values wait in registers: 16 per lane at the 128-register cap of 1024 threads)
 __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBwdH2P p) {
   __shared__ float s_dl[1024];
   __shared__ float s_red[RABH_THREADS / 64];
-  __shared__ f32x4 s_acc[3][RABH_RG][32];
+  __shared__ float s_mx[16][RABH_CHUNK];
   const int b = blockIdx.x, slab = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NWV = RABH_THREADS / 64;
   float dot = 0.f;
   for (int n = tid; n < p.N; n += RABH_THREADS) dot += p.att[(size_t)b * p.N + n] * p.da[(size_t)b * p.N + n];
@@ -85,65 +91,83 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
     p.dbk_part[b] = t;
   }
 
-  const int rg = tid >> 5, c4 = tid & 31;
-  const int col = slab * 128 + c4 * 4;
-  const int kg = slab * 16 + (c4 >> 1);                 // slot column of this lane's 4 values; (c4 & 1) selects the half
-  const size_t hoff = (size_t)(c4 & 1) * 8;
-  const f32x4 cv = *reinterpret_cast<const f32x4*>(p.c + (size_t)b * p.d + col);
-  const f32x4 wv = *reinterpret_cast<const f32x4*>(p.wk + col);
+  const int kg = slab * 16 + wave;                       // this wave's slot column
+  const int col0 = slab * 128 + wave * 8;
+  float cv[8], wv[8];
+  {
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.c + (size_t)b * p.d + col0), c1 = *reinterpret_cast<const f32x4*>(p.c + (size_t)b * p.d + col0 + 4);
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wk + col0), w1 = *reinterpret_cast<const f32x4*>(p.wk + col0 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { cv[e] = c0[e]; cv[4 + e] = c1[e]; wv[e] = w0[e]; wv[4 + e] = w1[e]; }
+  }
   const size_t iRp = p.I2.Rp(), oRp = p.dI2.Rp();
   const char* i0 = p.I2.plane(0);
   const size_t ipb = p.I2.plane_bytes(), opb = p.dI2.plane_bytes();
   char* o0 = p.dI2.plane(0);
   const int icb = p.I2.cb(), ocb = p.dI2.cb();
-  f32x4 a_dc = {0.f, 0.f, 0.f, 0.f}, a_dw = {0.f, 0.f, 0.f, 0.f}, a_db = {0.f, 0.f, 0.f, 0.f};
+  float a_dc[8], a_dw[8], a_db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a_dc[e] = a_dw[e] = a_db[e] = 0.f;
   int emin = 127;
+
   // (the activation is selected by ONE switch around the row loop, not per value: see the row pass of kb_gemm_h2_kernel)
   auto rows = [&](auto act_c) {
-  constexpr int ACT = decltype(act_c)::value;
-  for (int n0 = 0; n0 < p.N; n0 += RABH_RG) {
-    const int n = n0 + rg;
-    const bool ok = n < p.N;
-    const size_t row = (size_t)b * p.N + min(n, p.N - 1);
-    const char* src = i0 + ((size_t)kg * iRp + row) * 16 + hoff;
-    float i2[4];
-    h2_join4(*reinterpret_cast<const u32x2*>(src), *reinterpret_cast<const u32x2*>(src + ipb),
-             h2_pow2(-(int)p.I2.exps()[row * icb + slab]), i2);
-    const float dl = s_dl[min(n, p.N - 1)];
-    uint32_t bits = 0xFu;
-    if (p.bytes) bits = (uint32_t)p.bytes[(size_t)kg * iRp + row] >> (4 * (c4 & 1));
-    float o[4];
-    float m = 0.f;
+    constexpr int ACT = decltype(act_c)::value;
+    for (int n0 = 0; n0 < p.N; n0 += RABH_CHUNK) {
+      float o[RABH_CHUNK / 64][8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float zv = i2[e] * cv[e];
-      const float g = act_apply(ACT, zv);
-      const float f = ((bits >> e) & 1u) ? p.inv_keep : 0.f;
-      const float dz = (dl * wv[e]) * f * act_grad_from_out(ACT, g);
-      o[e] = dz * cv[e];                                  // dI2 = dZ * c
-      if (ok) {
-        a_dw[e] = fmaf(dl, g * f, a_dw[e]);               // dw_k += dl * dropped(G)
-        a_dc[e] = fmaf(dz, i2[e], a_dc[e]);               // dc += dZ * I2
-        a_db[e] += o[e];
+      for (int j = 0; j < RABH_CHUNK / 64; ++j) {
+        const int lrow = lane + 64 * j, n = n0 + lrow;
+        float m = 0.f;
+        if (n < p.N) {
+          const size_t row = (size_t)b * p.N + n;
+          const char* src = i0 + ((size_t)kg * iRp + row) * 16;
+          float i2[8];
+          h2_join8(*reinterpret_cast<const u32x4*>(src), *reinterpret_cast<const u32x4*>(src + ipb),
+                   h2_pow2(-(int)p.I2.exps()[row * icb + slab]), i2);
+          const float dl = s_dl[n];
+          const uint32_t bits = p.bytes ? (uint32_t)p.bytes[(size_t)kg * iRp + row] : 0xFFu;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float zv = i2[e] * cv[e];
+            const float g = act_apply(ACT, zv);
+            const float f = ((bits >> e) & 1u) ? p.inv_keep : 0.f;
+            const float dz = (dl * wv[e]) * f * act_grad_from_out(ACT, g);
+            const float ov = dz * cv[e];                      // dI2 = dZ * c
+            o[j][e] = ov;
+            a_dw[e] = fmaf(dl, g * f, a_dw[e]);               // dw_k += dl * dropped(G)
+            a_dc[e] = fmaf(dz, i2[e], a_dc[e]);               // dc += dZ * I2
+            a_db[e] += ov;
+            m = fmaxf(m, fabsf(ov));
+          }
+        }
+        s_mx[wave][lrow] = m;
       }
-      m = fmaxf(m, fabsf(o[e]));
-    }
-    // the row's 128 columns sit in this half-wave: its exponent needs no shared memory
+      __syncthreads();
 #pragma unroll
-    for (int s = 16; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-    const int ex = h2_exponent(m);
-    const float sc = h2_pow2(ex);
-    const uint32_t h0 = pk_f16(o[0] * sc, o[1] * sc), h1 = pk_f16(o[2] * sc, o[3] * sc);
-    const f32x2_t b0 = unpk_f16(h0), b1 = unpk_f16(h1);
-    const uint32_t l0 = pk_f16(o[0] * sc - b0[0], o[1] * sc - b0[1]), l1 = pk_f16(o[2] * sc - b1[0], o[3] * sc - b1[1]);
-    if (ok) {
-      char* dst = o0 + ((size_t)kg * oRp + row) * 16 + hoff;
-      *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(dst + opb) = u32x2{l0, l1};
-      if (c4 == 0) p.dI2.exps()[row * ocb + slab] = (int8_t)ex;
-      emin = min(emin, ex);
+      for (int j = 0; j < RABH_CHUNK / 64; ++j) {
+        const int lrow = lane + 64 * j, n = n0 + lrow;
+        if (n < p.N) {
+          float m = s_mx[0][lrow];
+#pragma unroll
+          for (int k = 1; k < 16; ++k) m = fmaxf(m, s_mx[k][lrow]);
+          const int ex = h2_exponent(m);
+          const float sc = h2_pow2(ex);
+          float xs[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xs[e] = o[j][e] * sc;
+          u32x4 hi, lo;
+          h2_split8(xs, hi, lo);
+          const size_t row = (size_t)b * p.N + n;
+          char* dst = o0 + ((size_t)kg * oRp + row) * 16;
+          *reinterpret_cast<u32x4*>(dst) = hi;
+          *reinterpret_cast<u32x4*>(dst + opb) = lo;
+          if (wave == 0) p.dI2.exps()[row * ocb + slab] = (int8_t)ex;
+          emin = min(emin, ex);
+        }
+      }
+      __syncthreads();                    // s_mx is reused by the next pass
     }
-  }
   };
   switch (p.act) {
     case ACT_TANH: rows(std::integral_constant<int, ACT_TANH>{}); break;
@@ -152,29 +176,26 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
     case ACT_RELU: rows(std::integral_constant<int, ACT_RELU>{}); break;
     default: rows(std::integral_constant<int, ACT_NON>{}); break;
   }
-  __syncthreads();
+  if (wave == 0) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) emin = min(emin, __shfl_xor(emin, o, 64));
-  if (lane == 0) s_red[wave] = __int_as_float(emin);
-  __syncthreads();
-  if (tid == 0) {
-    int t = __float_as_int(s_red[0]);
-#pragma unroll
-    for (int w = 1; w < NWV; ++w) t = min(t, __float_as_int(s_red[w]));
-    p.qmin[(size_t)b * ocb + slab] = t;
+    for (int s = 32; s > 0; s >>= 1) emin = min(emin, __shfl_xor(emin, s, 64));
+    if (lane == 0) p.qmin[(size_t)b * ocb + slab] = emin;
   }
-  s_acc[0][rg][c4] = a_dc;
-  s_acc[1][rg][c4] = a_dw;
-  s_acc[2][rg][c4] = a_db;
-  __syncthreads();
-  if (tid < 96) {
-    const int which = tid >> 5, cc4 = tid & 31;
-    f32x4 t = s_acc[which][0][cc4];
+  // column sums: this wave's 8 columns, summed over its lanes' rows
 #pragma unroll
-    for (int g = 1; g < RABH_RG; ++g) t += s_acc[which][g][cc4];
-    float* dst = (which == 0 ? p.dc : which == 1 ? p.dwk_part : p.db2_part) + (size_t)b * p.d + slab * 128 + cc4 * 4;
-    if (which == 0) t += *reinterpret_cast<const f32x4*>(dst);
-    *reinterpret_cast<f32x4*>(dst) = t;
+  for (int e = 0; e < 8; ++e) {
+    a_dc[e] = wave_sum(a_dc[e]);
+    a_dw[e] = wave_sum(a_dw[e]);
+    a_db[e] = wave_sum(a_db[e]);
+  }
+  if (lane == 0) {
+    float* dc = p.dc + (size_t)b * p.d + col0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dc[e] += a_dc[e];
+      p.dwk_part[(size_t)b * p.d + col0 + e] = a_dw[e];
+      p.db2_part[(size_t)b * p.d + col0 + e] = a_db[e];
+    }
   }
 }
 
