@@ -240,7 +240,7 @@ struct BwdLayout {
   size_t dcI;       // [p,B,d]    dL/d controlInput_i
   size_t dcc;       // [p,B,d]    dL/d continuous control (alias dcI unless controlFeedPrev)
   size_t dwlin;     // [p,B,d]    dL/d (newMemory linear output)
-  size_t dwin;      // [B, win]   dL/d write inputs of the current step
+  size_t dwin;      // [p][B, win]   dL/d write inputs of every step
   size_t dinfo;     // [B,d]
   size_t dy_part;   // [2*d/128][B][d]
   size_t DY;        // [p,B,d]
@@ -285,8 +285,8 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dcI = take(p * B * d);
   L.dcc = o->control_feed_prev ? take(p * B * d) : L.dcI;
   L.dwlin = take(p * B * d);
-  L.dwin = take(B * win);
-  L.dinfo = take(B * d);
+  L.dwin = take(p * B * win);     // per step: the deferred dKB launch reads every step's dinfo (a column view of it)
+  L.dinfo = take(p * B * d);
   L.dy_part = take((4 * d / 128) * B * d);      // 2 column partials per 128-column tile (4 on the H2 kernel)
   L.DY = take(p * B * d);
   L.dmd = take(B * d);
@@ -875,7 +875,7 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
     float* dwlin = dwlin_all + (size_t)i * Bd;
     float* dI2_i = ws + W.dI2 + (size_t)i * W.act_floats;
     float* dX_i = ws + W.dX + (size_t)i * W.act_floats;
-    float* dwin = ws + W.dwin;
+    float* dwin = ws + W.dwin + (size_t)i * B * win;
 
     // ---- write unit backward
     const float* dmnew = dm_i;              // gradient wrt the (post-activation) new memory
@@ -908,9 +908,9 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
     int ld_dinfo = win;
     if (dp->keep_write < 1.0f) {
       hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)dwin, win, d, B, d, (uint32_t)s->b0,
-                         make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i), ws + W.dinfo);
+                         make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i), ws + W.dinfo + (size_t)i * Bd);
       CK(hipGetLastError());
-      dinfo = ws + W.dinfo;
+      dinfo = ws + W.dinfo + (size_t)i * Bd;
       ld_dinfo = d;
     }
 
@@ -985,14 +985,21 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
         q.dbg = kb_gemm_dbg();
         CK(sb_h2_launch(q, st));
       }
-      // dKB (+)= (dX Wx^T) * kbmask + att * dinfo
-      g.A = hdX; g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
-      g.Wh = reinterpret_cast<const char*>(ws + W.wxT_p); g.w_exp = reinterpret_cast<const int*>(ws + W.wxT_p) + dd;
-      g.out_f32 = GI->knowledgeBase; g.ldo = d; g.dr = dinfo; g.ld_dr = ld_dinfo; g.att = att_kb + (size_t)i * B * N;
-      g.e_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits + (size_t)i * L.bits_stride) : nullptr;
-      g.accumulate = (i != p - 1);
-      g.colsum_part = nullptr; g.out_qmin = nullptr;
-      CK((kb_gemm_h2_launch<B_PLAIN, E_DKB, false>(g, st)));
+      // dKB = sum_i (dX_i Wx^T) * kbmask_i + att_i (x) dinfo_i: ONE launch over all steps, after step 0 (below)
+      if (i == 0) {
+        g.A = h2_view(ws + W.dX, B * N, d); g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
+        g.Wh = reinterpret_cast<const char*>(ws + W.wxT_p); g.w_exp = reinterpret_cast<const int*>(ws + W.wxT_p) + dd;
+        g.nsteps = p; g.a_step_bytes = W.act_floats * sizeof(float);
+        g.out_f32 = GI->knowledgeBase; g.ldo = d;
+        const bool wd = dp->keep_write < 1.0f;
+        g.dr = wd ? ws + W.dinfo : ws + W.dwin + d; g.ld_dr = wd ? d : win; g.dr_step = wd ? Bd : (size_t)B * win;
+        g.att = att_kb; g.att_step = (size_t)B * N;
+        g.e_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits) : nullptr;
+        g.bits_step_words = L.bits_stride;
+        g.accumulate = 0;
+        g.colsum_part = nullptr; g.out_qmin = nullptr; g.aux = H2View{nullptr, 0, 0};
+        CK((kb_gemm_h2_launch<B_PLAIN, E_DKB, false>(g, st)));
+      }
     } else {
     {
       ReadAttBwdP r;

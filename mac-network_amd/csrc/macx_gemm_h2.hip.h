@@ -45,7 +45,13 @@ struct GemmH2P {
   const uint8_t* e_bytes;   // E_I2_LOGIT: keep bits of act(I2*c), one byte per slot, [Nout/8][Rp]; null = keep all
   const uint32_t* e_bits;   // E_DKB: keep bits of the knowledge base, row-major [B*N][ldo/32]; null = keep all
   float e_inv_keep;
-  int accumulate;           // E_DKB
+  int accumulate;           // E_DKB (unused by the multi-step form: the output is written once)
+  // E_DKB runs ALL steps of the backward pass in one launch: the K loop walks `nsteps` A tensors (the kept dX_i, `a_step_bytes`
+  // apart) against the same weight, the step's keep bits multiply each block sum as it is folded, and the epilogue adds
+  // sum_i att_i (x) dinfo_i -- the caller's fp32 gradient is written once instead of read-modify-written every step
+  int nsteps; size_t a_step_bytes;
+  size_t bits_step_words;   // uint32 words between the keep bits of consecutive steps
+  size_t att_step, dr_step; // floats between att_i / dinfo_i of consecutive steps
   int* out_qmin;            // [B][Nout/128] minimum exponent of each question's output rows, atomicMin (caller presets 127)
   int dbg;                  // measurement knobs (macx_debug_set(1, mask)): 1 skip the epilogue, 32 skip the in-loop staging,
                             // 64 skip the fragment reads + MFMAs, 256 return at once, 512 return in front of the K loop
@@ -55,8 +61,8 @@ template <int RT>
 constexpr int kb_gemm_h2_lds_bytes() {
   constexpr int ROWS = RT * 16;
   constexpr int stage = 2 * 4 * ROWS * 16 + 2 * 4 * 128 * 16;
-  constexpr int ring = 3 * stage + ROWS * 32 + 4096 + 64;   // + the fold factors of the tile's rows + the question's mixing vector + a reduction scratch
-  constexpr int epi = ROWS * 132 * 4 + 2 * 16 * ROWS * 4 + ROWS * 4 + 16 * 32 * 16 + 3 * 128 * 4;
+  constexpr int ring = 3 * stage + 2 * ROWS * 32 + 4096 + 64 + 256 * 12 + 2 * 256 * 16;   // ... + E_DKB: raw exponents and keep bits of the next step   // + the fold factors of the tile's rows + the question's mixing vector + a reduction scratch
+  constexpr int epi = ROWS * 132 * 4 + 2 * 16 * ROWS * 4 + ROWS * 4 + 16 * 32 * 16 + 3 * 128 * 4;   // (E_DKB: tile + 16 x (ROWS + 128) floats, smaller)
   return ring > epi ? ring : epi;
 }
 
@@ -107,10 +113,15 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
 
   // ---- LDS behind the ring: fold factors, the question's mixing vector, a reduction scratch.  They are filled AFTER the first
   //      two K slices have been requested (below): their global loads then overlap the DMA instead of preceding it
-  float* sF = reinterpret_cast<float*>(lds + 3 * STAGE);           // [K / 128][ROWS]: 2^-(eA[row][kb] + eB)
-  float* sY = reinterpret_cast<float*>(lds + 3 * STAGE + ROWS * 32);  // B_YMIX_ROW: y_b[K]
+  float* sF = reinterpret_cast<float*>(lds + 3 * STAGE);           // [2 (E_DKB: step parity)][K / 128][ROWS]: 2^-(eA[row][kb] + eB)
+  float* sY = reinterpret_cast<float*>(lds + 3 * STAGE + 2 * ROWS * 32);  // B_YMIX_ROW: y_b[K]
   int eB = 0;
   float sB = 1.f;
+  // E_DKB: raw exponents / keep bits of the step after the current one (filled by DMA, see issue_tables below)
+  constexpr int X_OFF = 3 * STAGE + 2 * ROWS * 32 + 4096 + 64;
+  uint32_t* sRaw = reinterpret_cast<uint32_t*>(lds + X_OFF);              // [3][256] dwords
+  uint32_t* sM = reinterpret_cast<uint32_t*>(lds + X_OFF + 256 * 12);     // [2 (step parity)][256 rows][4 words]
+  const bool fast_tables = EP == E_DKB && nk >= 12;
 
   f32x4 acc[HT][2], tot[HT][2];
 #pragma unroll
@@ -158,11 +169,19 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
     rwa[S][0] = a0; rwa[S][1] = a1; rwb[S][0] = b0; rwb[S][1] = b1;
   };
-  auto issue = [&](int kt) {                                       // DMA of slice kt into ring stage kt % 3
-    char* dA = lds + (kt % 3) * STAGE;
+  const uint32_t lds0 = lds_addr_of(lds);
+  auto issue = [&](int g) {                                        // DMA of (global) slice g into ring stage g % 3
+    const uint32_t dA = lds0 + (uint32_t)(g % 3) * STAGE;
+    int kt = g;
+    const char* ab = a_base;
+    if (EP == E_DKB) {                                             // slice g = step g / nk, K slice g % nk
+      const int stp = g / nk;
+      kt = g - stp * nk;
+      ab = a_base + (size_t)stp * p.a_step_bytes;
+    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
-      if (wave + 8 * i < NA) dma16b(a_base + (size_t)kt * a_kstep + a_off[i], dA + (wave + 8 * i) * 1024);
+      if (wave + 8 * i < NA) dma16b(ab + (size_t)kt * a_kstep + a_off[i], dA + (wave + 8 * i) * 1024);
     if (BP == B_PLAIN) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
       for (int c = 0; c < 2; ++c) bf[pl][c] = *reinterpret_cast<const u32x4*>(sB_ + pl * B_PLANE + c * 256);
     // smallest terms first: A_lo x B_hi ; A_hi x {B_lo, B_hi}
     // row tiles in groups of TG so that only TG A fragments are live at a time (the kernel runs at the 256-register cap)
-    constexpr int TG = BP == B_PLAIN ? 4 : 1;        // (the y-mixing kernels also hold two sets of raw weights)
+    constexpr int TG = BP != B_PLAIN ? 1 : 4;        // (the y-mixing kernels also hold two sets of raw weights)
 #pragma unroll
     for (int ap = 1; ap >= 0; --ap) {
 #pragma unroll
@@ -239,12 +258,29 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
     __builtin_amdgcn_sched_barrier(0);
   };
   // end of a 128-wide K block: running sum += block sum * 2^-(eA[row][kb] + eB)
-  auto fold = [&](int kb) {
+  auto fold = [&](int blk) {                                       // blk = global 128-wide block = step * nkb + kb
+    int kb = blk, stp = 0;
+    if (EP == E_DKB) { stp = blk / nkb; kb = blk - stp * nkb; }
+    const int toff = (stp & 1) * (8 * ROWS) + kb * ROWS;
+    const bool masked = EP == E_DKB && p.e_bits != nullptr;
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
-      const f32x4 f = *reinterpret_cast<const f32x4*>(sF + kb * ROWS + min((t0 + t) * 16, ROWS - 16) + (lane >> 4) * 4);
+      f32x4 f = *reinterpret_cast<const f32x4*>(sF + toff + min((t0 + t) * 16, ROWS - 16) + (lane >> 4) * 4);
+      if (masked) {
+        // the step's keep bits of the knowledge base (ops.py:678): row-major words, this lane's two columns are bits
+        // (lane & 15) and 16 + (lane & 15) of word `cgp` of the row's 128-column block
 #pragma unroll
-      for (int c = 0; c < 2; ++c) tot[t][c] += acc[t][c] * f;
+        for (int e = 0; e < 4; ++e) {
+          const int lrow = min((t0 + t) * 16 + (lane >> 4) * 4 + e, nvalid - 1);
+          const uint32_t w = sM[((stp & 1) * 256 + lrow) * 4 + cgp];
+          const float fe = f[e] * p.e_inv_keep;
+          tot[t][0][e] = fmaf(acc[t][0][e], ((w >> (lane & 15)) & 1u) ? fe : 0.f, tot[t][0][e]);
+          tot[t][1][e] = fmaf(acc[t][1][e], ((w >> (16 + (lane & 15))) & 1u) ? fe : 0.f, tot[t][1][e]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) tot[t][c] += acc[t][c] * f;
+      }
     }
   };
   using FirstT = std::integral_constant<bool, true>;
@@ -274,7 +310,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
     if (BP == B_YMIX_ROW)
       for (int k = tid; k < p.K; k += G_THREADS) sY[k] = p.y[(size_t)b * p.ldy + k];
     // |y W1a + W1b| <= max|y_b| max|W1a| + max|W1b|: a power of two above the bound costs at most the low end of the range
-    float* red = reinterpret_cast<float*>(lds + 3 * STAGE + ROWS * 32 + 4096);
+    float* red = reinterpret_cast<float*>(lds + 3 * STAGE + 2 * ROWS * 32 + 4096);
     float m = 0.f;
     for (int k = tid; k < p.K; k += G_THREADS) m = fmaxf(m, fabsf(p.y[(size_t)b * p.ldy + k]));
     m = wave_max(m);
@@ -286,26 +322,78 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
     eB = h2_weight_exponent(fmaf(m, p.w_max[0], p.w_max[1]));
   }
   sB = h2_pow2(eB);
-  {
-    const int8_t* eA = p.A.exps();
+  const int nsteps = (EP == E_DKB) ? p.nsteps : 1;
+  auto fill_sF = [&](int stp) {                                    // fold factors of step `stp` -> table stp & 1
+    const int8_t* eA = reinterpret_cast<const int8_t*>(p.A.base + (size_t)stp * p.a_step_bytes + 2 * p.A.plane_bytes());
     const int acb = p.A.cb();
+    const int toff = (stp & 1) * (8 * ROWS);
     for (int i = tid; i < ROWS * acb; i += G_THREADS) {
       const int r = i / acb, k = i - r * acb;                      // rows past the tensor end lie in the pad rows
-      sF[k * ROWS + r] = h2_unscale((int)eA[(grow0 + r) * acb + k], eB);
+      sF[toff + k * ROWS + r] = h2_unscale((int)eA[(grow0 + r) * acb + k], eB);
     }
-  }
+  };
+  fill_sF(0);
+  // E_DKB, steps after the first: the next step's row exponents and keep bits arrive by DMA while the current step is being
+  // multiplied (global loads the compiler knows about would drain the DMA queue at every fold): three dwords per row
+  // covering the row's K / 128 exponent bytes wherever they start, and the 16 bytes of keep bits of the row's 128 columns
+  const int xrow = min(wave * 64 + lane, nvalid - 1);                     // waves 0..3: the tile row this lane fetches for
+  auto issue_tables = [&](int stp) {
+    if (wave < 4) {
+      const int acb = p.A.cb();
+      const char* eA = p.A.base + (size_t)stp * p.a_step_bytes + 2 * p.A.plane_bytes();
+      const size_t start = (grow0 + xrow) * (size_t)acb;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dma4b(eA + (start & ~(size_t)3) + 4 * j, lds0 + X_OFF + (j * 256 + wave * 64) * 4);
+      if (p.e_bits)
+        dma16b(reinterpret_cast<const char*>(p.e_bits + (size_t)stp * p.bits_step_words + (grow0 + xrow) * (size_t)(p.ldo >> 5) + cb * 4),
+               lds0 + X_OFF + 256 * 12 + ((stp & 1) * 256 + wave * 64) * 16);
+    }
+  };
+  auto convert_tables = [&](int stp) {                                    // raw exponent bytes -> fold factors (LDS to LDS)
+    const int acb = p.A.cb();
+    const int toff = (stp & 1) * (8 * ROWS);
+    for (int i = tid; i < ROWS * acb; i += G_THREADS) {
+      const int r = i / acb, k = i - r * acb;
+      const int rr = min(r, nvalid - 1);
+      const int sh = (int)(((grow0 + rr) * (size_t)acb) & 3) + k;         // byte offset inside the row's three dwords
+      const uint32_t w = sRaw[(sh >> 2) * 256 + rr];
+      const int e = (int)(int8_t)((w >> (8 * (sh & 3))) & 0xFFu);
+      sF[toff + k * ROWS + r] = h2_unscale(e, eB);
+    }
+  };
+  auto fill_sM = [&](int stp) {                                           // keep bits by ordinary loads (step 0; short K)
+    if (p.e_bits)
+      for (int i = tid; i < 256 * 4; i += G_THREADS) {
+        const int r = min(i >> 2, nvalid - 1);
+        sM[(stp & 1) * 1024 + i] = p.e_bits[(size_t)stp * p.bits_step_words + (grow0 + r) * (size_t)(p.ldo >> 5) + cb * 4 + (i & 3)];
+      }
+  };
+  if (EP == E_DKB) fill_sM(0);
   if (BP == B_PLAIN) {
     if (nk > 1) wait_vmcnt_n(my_n); else wait_vmcnt<0>();
     __syncthreads();                   // slice 0 has landed, for every wave's share of it; the tables are complete
     if (p.dbg & 512) { wait_vmcnt<0>(); return; }
+    const int nkt = nk * nsteps;                        // E_DKB: the K loop runs through all steps
     auto step = [&](auto first_c, int kt) {
-      if (kt + 2 < nk && do_stage) issue(kt + 2);       // ring stage (kt + 2) % 3 was last read in iteration kt - 1
+      if (kt + 2 < nkt && do_stage) issue(kt + 2);      // ring stage (kt + 2) % 3 was last read in iteration kt - 1
       if (do_compute) compute(kt % 3, first_c);
       if ((kt & 3) == 3) fold(kt >> 2);
-      if (kt + 2 < nk) wait_vmcnt_n(my_n); else wait_vmcnt<0>();     // slice kt + 1 has landed; slice kt + 2 may fly
+      if (kt + 2 < nkt) wait_vmcnt_n(my_n); else wait_vmcnt<0>();    // slice kt + 1 has landed; slice kt + 2 may fly
       __syncthreads();
     };
-    for (int kt = 0; kt < nk; kt += 4) {
+    for (int kt = 0; kt < nkt; kt += 4) {
+      if (EP == E_DKB && nsteps > 1) {
+        // half-way through a step the fold factors of the next one are built (the other table; its global loads make
+        // the compiler drain the DMA queue -- once per step)
+        const int stp = kt / nk, loc = kt - stp * nk;
+        if (fast_tables) {
+          if (loc == 4 && stp + 1 < nsteps) issue_tables(stp + 1);     // older than this iteration's slice DMA: landed by its wait
+          if (loc == 8 && stp + 1 < nsteps) convert_tables(stp + 1);
+        } else if (loc == (nk >> 1 & ~3) && stp + 1 < nsteps) {
+          fill_sF(stp + 1);
+          fill_sM(stp + 1);
+        }
+      }
       step(FirstT{}, kt);
       step(FirstF{}, kt + 1);
       step(FirstF{}, kt + 2);
@@ -370,12 +458,42 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   if (p.dbg & 128) return;                         // timing experiment: stop after the accumulator tile is in LDS
 
   if (EP == E_DKB) {
-    GemmP q;
-    q.B = p.B; q.N = p.N; q.K = p.K; q.Nout = p.Nout;
-    q.out = p.out_f32; q.ldo = p.ldo; q.aux = p.dr; q.ld_aux = p.ld_dr; q.att = p.att;
-    q.e_bits = p.e_bits; q.e_inv_keep = p.e_inv_keep; q.accumulate = p.accumulate; q.dbg = 0;
-    q.bias = nullptr; q.cvec = nullptr; q.wvec = nullptr; q.logit_part = nullptr; q.colsum_part = nullptr; q.act = 0;
-    kb_epilogue_rows<RT, 8, E_DKB, false>(q, smem, b, cb, rbi, nrb, row0, row_end);
+    // dKB = sum_i (dX_i Wx^T) * kbmask_i  [in T: the masks were applied block by block]  +  sum_i att_i (x) dinfo_i.
+    // att_i of this tile's rows and dinfo_i of its 128 columns go to LDS 16 steps at a time; one float4 per lane,
+    // a row's 128 columns in 32 consecutive lanes (512-byte row segments)
+    constexpr int SCH = 16;
+    float* sAtt = smem + ROWS * G_LDT;                 // [SCH][ROWS]
+    float* sDr = sAtt + SCH * ROWS;                    // [SCH][128]
+    constexpr int NIT = (ROWS * 32 + G_THREADS - 1) / G_THREADS;
+    f32x4 o[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = tid + G_THREADS * i, lrow = it >> 5, c4 = (it & 31) * 4;
+      o[i] = lrow < nvalid ? *reinterpret_cast<const f32x4*>(T + lrow * G_LDT + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += SCH) {
+      const int ns = min(SCH, nsteps - s0);
+      __syncthreads();
+      for (int i = tid; i < ns * ROWS; i += G_THREADS) {
+        const int si = i / ROWS, r = i - si * ROWS;
+        sAtt[i] = r < nvalid ? p.att[(size_t)(s0 + si) * p.att_step + grow0 + r] : 0.f;
+      }
+      for (int i = tid; i < ns * 128; i += G_THREADS) {
+        const int si = i >> 7, c = i & 127;
+        sDr[i] = p.dr[(size_t)(s0 + si) * p.dr_step + (size_t)b * p.ld_dr + cb * G_BN + c];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int it = tid + G_THREADS * i, lrow = min(it >> 5, ROWS - 1), c4 = (it & 31) * 4;
+        for (int si = 0; si < ns; ++si) o[i] += sAtt[si * ROWS + lrow] * *reinterpret_cast<const f32x4*>(sDr + si * 128 + c4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = tid + G_THREADS * i, lrow = it >> 5, c4 = (it & 31) * 4;
+      if (lrow < nvalid) *reinterpret_cast<f32x4*>(p.out_f32 + (grow0 + lrow) * (size_t)p.ldo + cb * G_BN + c4) = o[i];
+    }
     return;
   }
 

@@ -111,6 +111,20 @@ __device__ __forceinline__ void dma16b(const char* g, char* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
 }
 
+// ... with the LDS address as an integer (lds_addr_of() once per kernel + offsets): keeps pointer casts out of loops
+__device__ __forceinline__ uint32_t lds_addr_of(const void* lds_ptr) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_ptr;
+}
+__device__ __forceinline__ void dma16b(const char* g, uint32_t lds_wave_addr) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane(lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+}
+
+__device__ __forceinline__ void dma4b(const char* g, uint32_t lds_wave_addr) {      // 64 lanes x 4 B, lane-linear
+  const uint32_t l = __builtin_amdgcn_readfirstlane(lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+}
+
 __device__ __forceinline__ f32x4 mfma_f16(const u32x4 a, const u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
