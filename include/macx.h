@@ -365,6 +365,19 @@ int macx_wgrad_splits(int M, int Kd, int Jd);
 int macx_wgrad(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd,
                float* out, float* ws, void* stream);
 
+/* ---- the knowledge-base attention unit on its own (mac_cell.py:266-272: inter2att's softmax + att2Smry) ------------
+ * The fused cell's own kernels behind a per-unit contract, so that the unit is testable in isolation:
+ *   macx_kb_attend_fwd   att[B,N] = softmax_n(logits[B,N] + bias[0]);  info[B,d] = sum_n att KB        (ops.py:140-150)
+ *   macx_kb_attend_bwd   da = dinfo . KB;  dlogits = att (da - sum_n att da);  dkb (= | +=) att (x) dinfo (dkb may be NULL);
+ *                        ws >= macx_kb_attend_bwd_ws_floats(B, N, d) floats
+ * N <= 1024, d % 128 == 0.  (The control / read / write units as wholes are exposed per op on the generic path --
+ * macx_op_*, macx_linear, macx_h2_gemm -- and per step through macx_cell_step; tests/test_gpu_unit_parity.py.) */
+int macx_kb_attend_fwd(int B, int N, int d, const float* logits, const float* bias, const float* kb, float* att, float* info,
+                       void* stream);
+size_t macx_kb_attend_bwd_ws_floats(int B, int N, int d);
+int macx_kb_attend_bwd(int B, int N, int d, const float* att, const float* kb, const float* dinfo, float* dlogits, float* dkb,
+                       int accumulate, float* ws, size_t ws_floats, void* stream);
+
 /* ---- the ops.py primitives as single kernels (mac-network_amd/csrc/macx_ops.hip.h) -------------------------------
  * The building blocks of the GENERIC option path (mac-network_amd/generic.py): every legal option combination the fused
  * cell kernels above answer with MACX_EUNSUPPORTED runs as one kernel per reference op -- these, macx_linear / macx_h2_gemm

@@ -112,7 +112,8 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_encoder_saved_floats", "macx_encoder_ws_floats", "macx_encoder_forward", "macx_encoder_backward",
            "macx_images_to_nhwc", "macx_gemm_mode", "macx_h2_floats", "macx_h2_from_f32", "macx_h2_to_f32", "macx_h2_gemm",
            "macx_h2_pack_weight", "macx_h2_gemm_planes", "macx_op_act", "macx_op_act_bwd", "macx_op_binary", "macx_op_reduce",
-           "macx_op_softmax", "macx_op_softmax_bwd", "macx_op_dropout")
+           "macx_op_softmax", "macx_op_softmax_bwd", "macx_op_dropout", "macx_kb_attend_fwd", "macx_kb_attend_bwd",
+           "macx_kb_attend_bwd_ws_floats")
 
 _lib = None
 
@@ -209,6 +210,9 @@ def lib():
     L.macx_h2_gemm_planes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.macx_h2_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                C.c_void_p, C.c_size_t, C.c_void_p]
+    L.macx_kb_attend_fwd.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+    L.macx_kb_attend_bwd_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.macx_kb_attend_bwd.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     L.macx_op_act.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     L.macx_op_act_bwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.macx_op_binary.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]

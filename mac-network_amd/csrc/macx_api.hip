@@ -1386,6 +1386,36 @@ int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, u
   return MACX_OK;
 }
 
+// ---- the knowledge-base attention unit on its own (the fused cell's kernels behind a per-unit contract) -----------------
+// forward: att = softmax_n(logits + bias), info = sum_n att KB       (ops.inter2att :140-146 + ops.att2Smry :149-150)
+int macx_kb_attend_fwd(int B, int N, int d, const float* logits, const float* bias, const float* kb, float* att, float* info,
+                       void* stream) {
+  if (!logits || !bias || !kb || !att || !info || B < 1 || N < 1 || N > K_MAXN || d < 128 || d % 128) return MACX_EINVAL;
+  KbAttP a;
+  a.B = B; a.N = N; a.d = d; a.nparts = 1;
+  a.logit_part = logits; a.bias = bias; a.kb = kb; a.att = att; a.info = info;
+  hipLaunchKernelGGL(kb_attend_kernel, dim3(B, d / 128), dim3(KA_THREADS), 0, (hipStream_t)stream, a);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+size_t macx_kb_attend_bwd_ws_floats(int B, int N, int d) { return (size_t)B * N + 8; (void)d; }
+// backward: da = dinfo . KB ; dlogits = att (da - sum_n att da) ; dKB (=, or += with accumulate) att (x) dinfo
+int macx_kb_attend_bwd(int B, int N, int d, const float* att, const float* kb, const float* dinfo, float* dlogits, float* dkb,
+                       int accumulate, float* ws, size_t ws_floats, void* stream) {
+  if (!att || !kb || !dinfo || !dlogits || !ws || B < 1 || N < 1 || d < 128 || d % 128) return MACX_EINVAL;
+  if (ws_floats < macx_kb_attend_bwd_ws_floats(B, N, d)) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  float* da = ws;
+  hipLaunchKernelGGL(kb_att_da_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, dinfo, d, kb, B, N, d, da);
+  hipLaunchKernelGGL(op_softmax_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, att, (const float*)da, (size_t)B, N, dlogits);
+  if (dkb) {
+    const size_t n = (size_t)B * N * d;
+    hipLaunchKernelGGL(kb_attend_dkb_kernel, dim3(op_grid(n)), dim3(256), 0, st, att, dinfo, n, N, d, accumulate, dkb);
+  }
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
 // ---- the ops.py primitives as single kernels (macx_ops.hip.h): the generic option path ---------------------------
 int macx_op_act(int act, const float* x, const float* alpha, size_t n, int inner, float* out, void* stream) {
   const bool ext = act == OP_ACT_PRELU || act == OP_ACT_RSQRT_EPS;

@@ -140,6 +140,16 @@ __global__ __launch_bounds__(256) void op_dropout_kernel(const float* x, size_t 
     out[i] = keep_bit((uint32_t)(first + i), key, thr24) ? x[i] * inv_keep : 0.f;
 }
 
+// dKB[b][n][c] (+)= att[b][n] * dinfo[b][c]: the knowledge-base gradient of ops.att2Smry
+__global__ __launch_bounds__(256) void kb_attend_dkb_kernel(const float* att, const float* dinfo, size_t n, int N, int d, int accumulate,
+                                                            float* dkb) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / d, b = row / N;
+    const float v = att[row] * dinfo[b * d + i % d];
+    dkb[i] = accumulate ? dkb[i] + v : v;
+  }
+}
+
 inline unsigned op_grid(size_t n) {
   const size_t g = (n + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));

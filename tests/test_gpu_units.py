@@ -178,3 +178,33 @@ def _wgrad_case(macx, dev, M, Kd, Jd):
     macx._lib.check(L.macx_wgrad(_p(Ad), Kd, _p(Gd), Jd, M, Kd, Jd, _p(out2), _p(ws), None), "wgrad")
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("B,N,d", [(3, 196, 128), (2, 49, 256), (4, 1, 128), (2, 250, 512)])
+def test_kb_attend_unit_forward_and_backward(macx, dev, B, N, d):
+    """macx_kb_attend_fwd / _bwd: the attention unit on its own (softmax over the knowledge-base cells + att2Smry,
+    ops.py:140-150) against fp64 autograd, <= 1e-5 per the per-unit contract of SURVEY 8b."""
+    L = macx._lib.lib()
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    logits = torch.randn(B, N, generator=g) * 3
+    bias = torch.tensor([0.3])
+    kb = torch.randn(B, N, d, generator=g)
+    dinfo = torch.randn(B, d, generator=g)
+    lg, kbd_ = logits.double().requires_grad_(True), kb.double().requires_grad_(True)
+    att_ref = torch.softmax(lg + 0.3, dim=-1)
+    info_ref = (att_ref.unsqueeze(-1) * kbd_).sum(1)
+    (info_ref * dinfo.double()).sum().backward()
+    lo, bi, kbt, di = logits.to(dev), bias.to(dev), kb.to(dev), dinfo.to(dev)
+    att, info = torch.empty(B, N, device=dev), torch.empty(B, d, device=dev)
+    macx._lib.check(L.macx_kb_attend_fwd(B, N, d, _p(lo), _p(bi), _p(kbt), _p(att), _p(info), None), "fwd")
+    nws = L.macx_kb_attend_bwd_ws_floats(B, N, d)
+    ws = torch.empty(nws, device=dev)
+    dl = torch.empty(B, N, device=dev)
+    dkb = torch.full((B, N, d), 2.0, device=dev)
+    macx._lib.check(L.macx_kb_attend_bwd(B, N, d, _p(att), _p(kbt), _p(di), _p(dl), _p(dkb), 1, _p(ws), nws, None), "bwd")
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.cpu().double() - b).abs().max() / max(float(b.abs().max()), 1e-6))
+    assert rel(att, att_ref.detach()) < 1e-5 and rel(info, info_ref.detach()) < 1e-5
+    assert rel(dl, lg.grad) < 1e-5
+    assert rel(dkb - 2.0, kbd_.grad) < 1e-5
+    assert L.macx_kb_attend_bwd(B, N, d, _p(att), _p(kbt), _p(di), _p(dl), None, 0, _p(ws), 1, None) == macx._lib.MACX_ESMALL
