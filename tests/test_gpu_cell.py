@@ -78,6 +78,8 @@ def test_forward_stepwise_matches_oracle(macx, dev, name, B, S, N, d, p, train):
     ("args4", 3, 9, 49, 128, 3, True),
     ("args1", 3, 9, 49, 128, 4, True),
     ("args1", 2, 7, 30, 128, 3, False),
+    ("args", 2, 7, 30, 128, 18, True),        # more than 16 steps: the deferred dKB launch adds att (x) dinfo in two chunks
+    ("args", 2, 5, 20, 128, 1, True),         # a single step
 ])
 def test_backward_matches_oracle_autograd(macx, dev, name, B, S, N, d, p, train):
     cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
