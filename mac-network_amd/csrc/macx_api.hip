@@ -1051,7 +1051,7 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
     }
     // dy -> d(md) -> dL/d m_{i-1} = dwin[:, :d] + (dy Wy^T) * memmask * readmask
     float* DYi = ws + W.DY + (size_t)i * Bd;
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dy_part), (h2_mode() ? SBH_CW / 2 : 2) * d / 128, Bd, DYi);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(256), dim3(256), 0, st, (const float*)(ws + W.dy_part), (h2_mode() ? SBH_CW / 2 : 2) * d / 128, Bd, DYi);
     CK(hipGetLastError());
     {
       // with self attention DM[i] already holds the parts later steps sent to this memory: accumulate
@@ -1219,7 +1219,7 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
     }
     CK(rowsum(ws + W.dcI, B, d, d, GP->qInputU_b, st, p, Bd, d));
   } else {
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dcI), p, Bd, dcI_sum);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(256), dim3(256), 0, st, (const float*)(ws + W.dcI), p, Bd, dcI_sum);
     CK(hipGetLastError());
     LinP ls = lin_basic(dcI_sum, d, d, B, ws + W.wqUT, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
     CK(small_linear_launch(ls, 1, st));
