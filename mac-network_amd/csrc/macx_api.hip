@@ -439,7 +439,7 @@ hipError_t mask_bits(float keep, uint32_t seed, uint32_t site, uint32_t step, ui
 
 hipError_t rowsum(const float* src, int rows, int n, size_t ld, float* dst, hipStream_t st, int nz = 1, size_t zsrc = 0, size_t zdst = 0) {
   if (!dst) return hipSuccess;
-  hipLaunchKernelGGL(rowsum_kernel, dim3((n + 63) / 64, nz), dim3(1024), 0, st, src, rows, n, ld, dst, zsrc, zdst);
+  hipLaunchKernelGGL(rowsum_kernel, dim3((n + ROWSUM_COLS - 1) / ROWSUM_COLS, nz), dim3(1024), 0, st, src, rows, n, ld, dst, zsrc, zdst);
   return hipGetLastError();
 }
 hipError_t axpy(const float* x, size_t n, float* y, hipStream_t st) {

@@ -296,29 +296,32 @@ __global__ void dropout_mask_kernel(uint32_t key, uint32_t thr24, uint32_t first
 }
 
 // dst[i] = sum over `rows` rows of src[r*ld + i]   (bias gradients from per-question partials).
-// One workgroup (16 waves) per 64 columns; waves take interleaved rows, fixed-order LDS combine.
+// One workgroup (1024 threads) per 16 columns: 64 row groups x 16 columns, each thread sums its interleaved rows, then a
+// fixed-order LDS combine.  (16 rather than 64 columns per workgroup: at n = 512 that is 32 workgroups instead of 8 on a
+// 256-CU chip; the launch is latency-bound.)
+constexpr int ROWSUM_COLS = 16;
 __global__ __launch_bounds__(1024) void rowsum_kernel(const float* __restrict__ src, int rows, int n, size_t ld, float* dst, size_t zsrc,
                                                       size_t zdst) {
-  __shared__ float red[16][64];
+  __shared__ float red[64][ROWSUM_COLS + 1];
   src += blockIdx.y * zsrc;      // blockIdx.y: independent sums of one launch
   dst += blockIdx.y * zdst;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;
+  const int c = threadIdx.x & (ROWSUM_COLS - 1), rg = threadIdx.x / ROWSUM_COLS;
+  const int i = blockIdx.x * ROWSUM_COLS + c;
   float s0 = 0.f, s1 = 0.f;
   if (i < n) {
-    int r = wave;
-    for (; r + 16 < rows; r += 32) {
+    int r = rg;
+    for (; r + 64 < rows; r += 128) {
       s0 += src[(size_t)r * ld + i];
-      s1 += src[(size_t)(r + 16) * ld + i];
+      s1 += src[(size_t)(r + 64) * ld + i];
     }
     if (r < rows) s0 += src[(size_t)r * ld + i];
   }
-  red[wave][lane] = s0 + s1;
+  red[rg][c] = s0 + s1;
   __syncthreads();
-  if (wave == 0 && i < n) {
-    float t = red[0][lane];
+  if (rg == 0 && i < n) {
+    float t = red[0][c];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) t += red[w][lane];
+    for (int w = 1; w < 64; ++w) t += red[w][c];
     dst[i] = t;
   }
 }
