@@ -204,7 +204,8 @@ __device__ __forceinline__ void h2_store_tile(const float* T, int ldt, int rows,
 // emitting the keep BYTES of a second site over the same index range (the attention dropout, ops.py:312 via :142) in
 // slot order -- the pass is HBM-bound, the second hash is free.  One workgroup per (question row block, 128 columns).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int H2C_ROWS = 208;
+constexpr int H2C_ROWS = 64;           // rows per workgroup: 38 KB of LDS, four workgroups per CU -- one's load, hash and
+                                       // store phases overlap the others' (208-row tiles: one workgroup per CU, 17 us)
 constexpr int H2C_THREADS = 512;
 constexpr int H2C_LDT = 132;
 constexpr size_t H2C_LDS = (size_t)H2C_ROWS * H2C_LDT * 4 + (size_t)17 * H2C_ROWS * 4;
@@ -256,8 +257,9 @@ __global__ __launch_bounds__(H2C_THREADS) void h2_from_f32_kernel(H2FromP p) {
   h2_store_tile<H2C_THREADS, H2C_ROWS>(T, H2C_LDT, rows, p.out, grow0, cb, scratch, p.qmin ? p.qmin + (size_t)b * p.out.cb() + cb : nullptr);
   if (p.bytes2) {
     const size_t Rp = p.out.Rp();
-    for (int it = tid; it < 16 * 256; it += H2C_THREADS) {
-      const int kgl = it >> 8, lrow = it & 255;
+    static_assert((H2C_ROWS & (H2C_ROWS - 1)) == 0, "row index by mask");
+    for (int it = tid; it < 16 * H2C_ROWS; it += H2C_THREADS) {
+      const int kgl = it / H2C_ROWS, lrow = it & (H2C_ROWS - 1);
       if (lrow < rows) {
         const uint32_t e0 = p.first + (uint32_t)((grow0 + lrow) * p.C + cb * 128 + kgl * 8);
         uint32_t byte = 0;
