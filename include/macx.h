@@ -365,6 +365,13 @@ int macx_wgrad_splits(int M, int Kd, int Jd);
 int macx_wgrad(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd,
                float* out, float* ws, void* stream);
 
+/* ---- answer loss and prediction (addAnswerLossOp model.py:593-599, addPredOp model.py:603-612) ----
+ * loss_rows[b] = -log softmax(logits[b])[answers[b]]  (tf.nn.sparse_softmax_cross_entropy_with_logits; the model's loss is
+ * their mean), pred[b] = argmax_c logits[b][c] (first maximum, tf.argmax), dlogits (may be NULL) = (softmax - onehot) *
+ * grad_scale -- grad_scale = 1/B is the gradient of the mean loss.  logits [B][A] fp32 contiguous, answers / pred int32. */
+int macx_answer_loss(const float* logits, const int32_t* answers, int B, int A, float* loss_rows, int32_t* pred,
+                     float* dlogits, float grad_scale, void* stream);
+
 /* ---- the knowledge-base attention unit on its own (mac_cell.py:266-272: inter2att's softmax + att2Smry) ------------
  * The fused cell's own kernels behind a per-unit contract, so that the unit is testable in isolation:
  *   macx_kb_attend_fwd   att[B,N] = softmax_n(logits[B,N] + bias[0]);  info[B,d] = sum_n att KB        (ops.py:140-150)

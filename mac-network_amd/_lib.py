@@ -113,7 +113,7 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_images_to_nhwc", "macx_gemm_mode", "macx_h2_floats", "macx_h2_from_f32", "macx_h2_to_f32", "macx_h2_gemm",
            "macx_h2_pack_weight", "macx_h2_gemm_planes", "macx_op_act", "macx_op_act_bwd", "macx_op_binary", "macx_op_reduce",
            "macx_op_softmax", "macx_op_softmax_bwd", "macx_op_dropout", "macx_kb_attend_fwd", "macx_kb_attend_bwd",
-           "macx_kb_attend_bwd_ws_floats")
+           "macx_kb_attend_bwd_ws_floats", "macx_answer_loss")
 
 _lib = None
 
@@ -210,6 +210,7 @@ def lib():
     L.macx_h2_gemm_planes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.macx_h2_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                C.c_void_p, C.c_size_t, C.c_void_p]
+    L.macx_answer_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     L.macx_kb_attend_fwd.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
     L.macx_kb_attend_bwd_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     L.macx_kb_attend_bwd.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]

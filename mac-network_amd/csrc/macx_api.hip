@@ -1386,6 +1386,18 @@ int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, u
   return MACX_OK;
 }
 
+// ---- answer loss + prediction (model.py:593-612): SURVEY 8f row 2 -------------------------------------------------
+// loss_rows[b] = sparse softmax cross-entropy of question b (the caller's loss is their mean: tf.reduce_mean, model.py:596);
+// pred[b] = argmax; dlogits (may be NULL) = (softmax - onehot) * grad_scale, i.e. pass 1/B for the gradient of the mean loss
+int macx_answer_loss(const float* logits, const int32_t* answers, int B, int A, float* loss_rows, int32_t* pred, float* dlogits,
+                     float grad_scale, void* stream) {
+  if (!logits || !answers || !loss_rows || !pred || B < 1 || A < 1) return MACX_EINVAL;
+  hipLaunchKernelGGL(answer_loss_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, answers, B, A, loss_rows, pred,
+                     dlogits, grad_scale);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
 // ---- the knowledge-base attention unit on its own (the fused cell's kernels behind a per-unit contract) -----------------
 // forward: att = softmax_n(logits + bias), info = sum_n att KB       (ops.inter2att :140-146 + ops.att2Smry :149-150)
 int macx_kb_attend_fwd(int B, int N, int d, const float* logits, const float* bias, const float* kb, float* att, float* info,

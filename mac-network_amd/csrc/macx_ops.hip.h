@@ -140,6 +140,42 @@ __global__ __launch_bounds__(256) void op_dropout_kernel(const float* x, size_t 
     out[i] = keep_bit((uint32_t)(first + i), key, thr24) ? x[i] * inv_keep : 0.f;
 }
 
+// addAnswerLossOp + addPredOp (model.py:593-612): per question the sparse softmax cross-entropy of its logits row and the
+// argmax (first maximum, as tf.argmax); one wave per question.  dlogits = (softmax - onehot) * scale for the backward pass.
+__global__ __launch_bounds__(256) void answer_loss_kernel(const float* logits, const int32_t* answers, int B, int A, float* loss_rows,
+                                                          int32_t* pred, float* dlogits, float scale) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = logits + (size_t)b * A;
+  float m = -INFINITY;
+  int am = 0x7FFFFFFF;
+  for (int c = lane; c < A; c += 64) {
+    const float v = p[c];
+    if (v > m) { m = v; am = c; }                       // strict: keeps the first maximum of this lane's columns
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    const float om = __shfl_xor(m, s, 64);
+    const int oa = __shfl_xor(am, s, 64);
+    if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+  }
+  float z = 0.f;
+  for (int c = lane; c < A; c += 64) z += expf(p[c] - m);
+  z = wave_sum(z);
+  const int ans = answers[b];
+  const bool valid = ans >= 0 && ans < A;               // an out-of-range label gives a NaN loss (TF's GPU kernel) and no gradient
+  if (lane == 0) {
+    loss_rows[b] = valid ? (m + logf(z)) - p[ans] : NAN;   // -log softmax[ans]
+    pred[b] = am;
+  }
+  if (dlogits) {
+    const float inv = 1.0f / z;
+    for (int c = lane; c < A; c += 64)
+      dlogits[(size_t)b * A + c] = valid ? (expf(p[c] - m) * inv - (c == ans ? 1.f : 0.f)) * scale : 0.f;
+  }
+}
+
 // dKB[b][n][c] (+)= att[b][n] * dinfo[b][c]: the knowledge-base gradient of ops.att2Smry
 __global__ __launch_bounds__(256) void kb_attend_dkb_kernel(const float* att, const float* dinfo, size_t n, int N, int d, int accumulate,
                                                             float* dkb) {

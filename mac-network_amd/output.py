@@ -13,6 +13,10 @@ import torch
 from . import _lib
 from .options import UnsupportedOptions, _resolve_act, fresh_seed
 
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
 REF_NAMES = {
     "outQuestion_W": "outputUnit/linearLayeroutQuestion/weights/weight",
     "outQuestion_b": "outputUnit/linearLayeroutQuestion/biases/bias",
@@ -96,7 +100,36 @@ class OutputClassifier(torch.nn.Module):
         return _OutFunction.apply(self, keep, fresh_seed(seed, train), int(b0), memory, vecQuestions, *self.tensors())
 
 
+class _AnswerLoss(torch.autograd.Function):
+    """macx_answer_loss: per-question cross-entropy + argmax in one kernel; the backward pass returns the dlogits the same
+    kernel wrote (gradient of the MEAN loss), scaled by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, answers):
+        if not logits.is_cuda:
+            raise RuntimeError("logits must live on the HIP device: the loss has no CPU path")
+        L = _lib.lib()
+        lg = logits.detach().contiguous()
+        B, A = lg.shape
+        ans = answers.to(device=lg.device, dtype=torch.int32).contiguous()      # out-of-range labels: NaN loss, as TF on a GPU
+        rows = torch.empty(B, dtype=torch.float32, device=lg.device)
+        pred = torch.empty(B, dtype=torch.int32, device=lg.device)
+        dl = torch.empty_like(lg)
+        st = C.c_void_p(torch.cuda.current_stream(lg.device).cuda_stream)
+        _lib.check(L.macx_answer_loss(_ptr(lg), _ptr(ans), B, A, _ptr(rows), _ptr(pred), _ptr(dl), 1.0 / B, st), "macx_answer_loss")
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(pred)
+        return rows, pred
+
+    @staticmethod
+    def backward(ctx, g_rows, _g_pred):
+        (dl,) = ctx.saved_tensors
+        # rows feed a mean: g_rows is constant 1/B * upstream; dl already carries 1/B, so scale by B * g_rows per row
+        return dl * (g_rows * dl.shape[0]).unsqueeze(1), None
+
+
 def answer_loss_and_pred(logits, answers):
-    """addAnswerLossOp (model.py:593-599) + addPredOp (model.py:603-612): mean sparse CE, int32 argmax."""
-    loss = torch.nn.functional.cross_entropy(logits, answers.long())
-    return loss, logits.argmax(dim=-1).to(torch.int32)
+    """addAnswerLossOp (model.py:593-599) + addPredOp (model.py:603-612): mean sparse CE, int32 argmax -- one HIP kernel
+    (macx_answer_loss) for both and for the gradient."""
+    rows, pred = _AnswerLoss.apply(logits, answers)
+    return rows.mean(), pred

@@ -91,3 +91,28 @@ def test_adam_ema_step_matches_oracle(macx, dev, clip):
         assert abs(opt.ema.cpu().double().numpy() - ref_e).max() < 2e-6
     # parameters are views of the flat buffer
     assert ps[0].data_ptr() == opt.flat.data_ptr()
+
+
+@pytest.mark.parametrize("B,A", [(64, 28), (5, 3), (130, 100), (2, 1)])
+def test_answer_loss_and_pred_kernel(macx, dev, B, A):
+    """macx_answer_loss (addAnswerLossOp + addPredOp, model.py:593-612): mean sparse CE, first-maximum argmax and the
+    gradient of the mean loss in one kernel vs fp64 torch; ties resolve to the first index like tf.argmax."""
+    g = torch.Generator().manual_seed(B * 131 + A)
+    logits = torch.randn(B, A, generator=g) * 4
+    if A > 2:
+        logits[0, 1] = logits[0, 2] = logits[0].max() + 1.0           # a tie: argmax must be 1
+    answers = torch.randint(0, A, (B,), generator=g)
+    ld = logits.to(dev).requires_grad_(True)
+    loss, pred = macx.output.answer_loss_and_pred(ld, answers.to(dev))
+    (loss * 3.0).backward()
+    torch.cuda.synchronize()
+    ref = logits.double().requires_grad_(True)
+    rloss = torch.nn.functional.cross_entropy(ref, answers)
+    (rloss * 3.0).backward()
+    assert abs(float(loss) - float(rloss)) < 1e-5
+    assert torch.equal(pred.cpu().long(), logits.argmax(-1)) and (A <= 2 or int(pred[0]) == 1)
+    assert float((ld.grad.cpu().double() - ref.grad).abs().max()) < 1e-6
+    bad = answers.clone()
+    bad[0] = A
+    l2, _ = macx.output.answer_loss_and_pred(logits.to(dev), bad.to(dev))
+    assert not torch.isfinite(l2)                                      # out-of-range label: NaN loss, as TF's GPU kernel
