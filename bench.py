@@ -139,8 +139,15 @@ def time_steps(step, steps, warmup, prime, barrier, world, dev, dist):
         step(i)
     barrier()
     t0 = time.perf_counter()
+    trace = os.environ.get("MACX_BENCH_TRACE")
     for i in range(steps):
+        if trace:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
         step(prime + warmup + i)
+        if trace:
+            torch.cuda.synchronize()
+            print("[trace] step %d: %.1f ms" % (i, (time.perf_counter() - t1) * 1e3), file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -163,7 +170,15 @@ def make_step(macx, dev, dist, world, rank, global_batch, p, seed):
     gmem = (torch.randn(bl, D, generator=torch.Generator().manual_seed(1)) / global_batch).to(dev)
     # two buckets over the flat gradient buffer: everything but the read unit's deferred contractions is all-reduced on a
     # side stream while the last phase of the backward pass still runs (macx.dp.OverlappedBuckets)
-    bucket = macx.dp.OverlappedBuckets(params) if world > 1 else None
+    # RCCL: two buckets, the first in flight on a side stream while the backward pass finishes.  gloo (only ever used to exercise
+    # this path with two ranks on ONE GPU) stages CUDA tensors through the host from a worker thread; with two collectives in
+    # flight it was seen to stall for seconds, so it gets the single all-reduce.  MACX_BENCH_BUCKET=single|overlap overrides.
+    kind = os.environ.get("MACX_BENCH_BUCKET") or ("overlap" if dist.get_backend() == "nccl" else "single") if world > 1 else None
+    if kind == "single":
+        bucket = macx.dp.GradBucket(params.tensors(), flat=params.grad_buffer())
+        bucket.begin_step = lambda shard, glob: None
+    else:
+        bucket = macx.dp.OverlappedBuckets(params) if world > 1 else None
 
     def step(i):
         cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=ld,
@@ -369,7 +384,7 @@ def main():
                                       "14x14x1024 features), d=%d, p=%d; cell only (stem/encoder/classifier: model_level)"
                                       % (global_batch, world, bl, S, N, D, D, p),
                           "global_batch": global_batch, "parallelism": "dp%d" % world,
-                          "collective": None if world == 1 else "%s all-reduce of the flat gradient buffer in two buckets (the first overlapped with the last phase of the backward pass on a side stream), world size %d" % (
+                          "collective": None if world == 1 else "%s all-reduce of the flat gradient buffer (RCCL: in two buckets, the first overlapped with the last phase of the backward pass on a side stream), world size %d" % (
                               "RCCL (backend nccl)" if backend == "nccl" else backend, dist.get_world_size()),
                           "flops_per_question_fwd_bwd": 3 * p * F},
                "roofline": roofline}
