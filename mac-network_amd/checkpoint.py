@@ -1,7 +1,8 @@
 """Weights in and out under the reference's TF variable names (SURVEY.md 8b "parameters", 8f row 4 "ckpt formats").
 
-A TF1 checkpoint is an SSTable of protobuf-framed tensors and cannot be parsed without TensorFlow, which is not
-available here; the bridge is the name -> array mapping a maintainer dumps in a TF environment
+Two carriers: the reference's own V2 checkpoint files (`load_tf_checkpoint` / `save_tf_checkpoint`, read and written by
+tf_bundle.py without TensorFlow), and an .npz of the same name -> array mapping, which a maintainer can also dump in a
+TF environment
 
     np.savez("macx_weights.npz", **{v.name: sess.run(v) for v in tf.global_variables()})      # main.py:185-193 restores them
 
@@ -102,3 +103,17 @@ def save_npz(path, net, ema_tensors=None):
 def load_npz(path, net, use_ema=False, strict=True):
     with np.load(path) as z:
         return load_reference(net, {k: z[k] for k in z.files}, use_ema=use_ema, strict=strict)
+
+
+def load_tf_checkpoint(prefix, net, use_ema=False, strict=True, verify=True):
+    """Restore `net` from a TensorFlow V2 checkpoint written by the reference's saver (main.py:236-262), e.g.
+    prefix = "weights/clevrExperiment/weights25.ckpt".  Returns the list of missing variables (empty under strict)."""
+    from . import tf_bundle
+    return load_reference(net, tf_bundle.read_checkpoint(prefix, verify=verify), use_ema=use_ema, strict=strict)
+
+
+def save_tf_checkpoint(prefix, net):
+    """Write the reference-named weights as a V2 checkpoint the reference's `saver.restore` (main.py:185-193) can read
+    for every variable it finds (variable names carry no ":0" in a checkpoint)."""
+    from . import tf_bundle
+    return tf_bundle.write_checkpoint(prefix, {k[:-2]: v.numpy() for k, v in reference_state_dict(net).items()})
