@@ -377,13 +377,37 @@ int macx_answer_loss(const float* logits, const int32_t* answers, int B, int A, 
  *   macx_kb_attend_fwd   att[B,N] = softmax_n(logits[B,N] + bias[0]);  info[B,d] = sum_n att KB        (ops.py:140-150)
  *   macx_kb_attend_bwd   da = dinfo . KB;  dlogits = att (da - sum_n att da);  dkb (= | +=) att (x) dinfo (dkb may be NULL);
  *                        ws >= macx_kb_attend_bwd_ws_floats(B, N, d) floats
- * N <= 1024, d % 128 == 0.  (The control / read / write units as wholes are exposed per op on the generic path --
- * macx_op_*, macx_linear, macx_h2_gemm -- and per step through macx_cell_step; tests/test_gpu_unit_parity.py.) */
+ * N <= 1024, d % 128 == 0. */
 int macx_kb_attend_fwd(int B, int N, int d, const float* logits, const float* bias, const float* kb, float* att, float* info,
                        void* stream);
 size_t macx_kb_attend_bwd_ws_floats(int B, int N, int d);
 int macx_kb_attend_bwd(int B, int N, int d, const float* att, const float* kb, const float* dinfo, float* dlogits, float* dkb,
                        int accumulate, float* ws, size_t ws_floats, void* stream);
+
+/* ---- the read unit and the write unit as wholes (macx_<unit>_{fwd,bwd}) ----------------------------------
+ * ONE unit of the fused cell on caller-owned buffers -- the cell's own step code restricted to that unit, so per-unit
+ * parity against mac_cell.py:209-277 (read) and :305-375 (write) is testable without running a cell.
+ *   shapes->p must be 1: it is the unit of step 0 (dropout streams are keyed by (seed, site, step 0)); S is ignored.
+ *   saved >= macx_saved_floats(opts, shapes, 1) floats, written by *_fwd and read by the matching *_bwd;
+ *   ws >= macx_workspace_bytes(opts, shapes, 1) bytes (= 4 * macx_ws_floats).  Only the unit's fields of macx_params /
+ *   macx_param_grads are read / written (read: projX, projY, memKbProj, memKbProj2, kbLogits; write: newMemory, gate).
+ *   read:  info[B,d], att[B,N] = read(knowledgeBase[B,N,d], memory[B,d], control[B,d]); memory / read dropout per macx_dropout
+ *          bwd: d_info -> d_knowledgeBase[B,N,d], d_memory, d_control and the unit's parameter gradients
+ *   write: new_memory[B,d] = write(memory, info, control); the write dropout (mac_cell.py:461-463) is applied to `info`
+ *          bwd: d_new_memory -> d_memory, d_info, d_control (the gate's; zeros without --writeGate) + parameter gradients
+ *          opts->write_self_att needs the histories of a running cell: MACX_EUNSUPPORTED here (use macx_cell_step). */
+size_t macx_workspace_bytes(const macx_opts*, const macx_shapes*, int for_backward);
+int macx_read_fwd(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*, const float* knowledgeBase,
+                  const float* memory, const float* control, float* saved, size_t saved_floats, float* info, float* att,
+                  void* stream);
+int macx_read_bwd(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*, const float* knowledgeBase,
+                  const float* saved, size_t saved_floats, float* ws, size_t ws_floats, const float* d_info,
+                  const macx_param_grads*, float* d_knowledgeBase, float* d_memory, float* d_control, void* stream);
+int macx_write_fwd(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*, const float* memory,
+                   const float* info, const float* control, float* saved, size_t saved_floats, float* new_memory, void* stream);
+int macx_write_bwd(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*, const float* saved,
+                   size_t saved_floats, float* ws, size_t ws_floats, const float* d_new_memory, const macx_param_grads*,
+                   float* d_memory, float* d_info, float* d_control, void* stream);
 
 /* ---- the ops.py primitives as single kernels (mac-network_amd/csrc/macx_ops.hip.h) -------------------------------
  * The building blocks of the GENERIC option path (mac-network_amd/generic.py): every legal option combination the fused

@@ -505,6 +505,50 @@ int macx_saved_segment(const macx_opts* o, const macx_shapes* s, int keep, int s
 }
 
 // -------------------------------------------------------------------------------------------------
+namespace {
+enum { U_CONTROL = 1, U_READ = 2, U_WRITE = 4, U_ALL = 7 };   // which units of a step an entry point runs
+
+// weights -> MFMA operand layout  (memKbProj rows [0,d) multiply x*y, rows [d,2d) multiply x: ops.py:718)
+int pack_forward_weights(const macx_opts* o, const macx_shapes* s, const macx_params* P, float* saved, const SavedLayout& L,
+                         int keep, int units, hipStream_t st) {
+  const int B = s->B, d = s->d, p = s->p;
+  {
+    Packer pk;
+    if (h2_mode() && (units & U_READ)) {
+      // per-matrix maxima -> weight exponents (plain weights) and the bound of the question-mixed tile (W1a, W1b)
+      const size_t dd_ = (size_t)d * d;
+      CK(absmax4(P->projX_W, dd_, P->memKbProj2_W, dd_, P->memKbProj_W, dd_, P->memKbProj_W + dd_, dd_, saved + L.wmax, st));
+      // minimum-exponent arrays are filled with atomicMin by the producers of X / H1 / KBd
+      CK(hipMemsetAsync(saved + L.qmin_X, 0x7F, 3 * (size_t)(keep ? p : 1) * B * (d / 128) * sizeof(int), st));
+    }
+    if (units & U_READ) {
+      pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);
+      pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, wfmt_ymix());
+      pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, wfmt_ymix());
+      pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);
+      pk.add(P->projY_W, d, 1, d, d, saved + L.wy_p);
+    }
+    if (units & U_WRITE) {
+      pk.add(P->newMemory_W, d, 1, write_in_dim(o, d), d, saved + L.wm_p);
+      if (o->write_gate) pk.add(P->gate_W, d, 1, d, d, saved + L.wg_p);
+      if (o->write_self_att) pk.add(P->selfCtrl_W, d, 1, d, d, saved + L.ws_p);
+    }
+    if (!(units & U_CONTROL)) return pk.n ? pk.run(st) : hipSuccess;
+    pk.add(P->qInput_W, d, 1, d, d, saved + L.wq_p);
+    if (o->control_feed_prev) {
+      pk.add(P->contControl_W, d, 1, o->control_feed_inputs ? 2 * d : d, d, saved + L.wc_p);
+      if (o->control_cont_act != MACX_ACT_NON) pk.add(P->contControl2_W, d, 1, d, d, saved + L.wc2_p);
+    }
+    for (int i = 0; i < (o->control_input_unshared ? p : 1); ++i) {
+      if (pk.n == PACK_MAX) CK(pk.run(st));
+      pk.add(P->qInputU_W + (size_t)i * d * d, d, 1, d, d, saved + L.wqU_p + (size_t)i * d * d);
+    }
+    CK(pk.run(st));
+  }
+  return MACX_OK;
+}
+}  // namespace
+
 int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
                     const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
                     int keep, void* stream) {
@@ -519,35 +563,7 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
   (void)ws; (void)ws_floats;
   const int B = s->B, d = s->d, p = s->p;
 
-  // weights -> MFMA operand layout  (memKbProj rows [0,d) multiply x*y, rows [d,2d) multiply x: ops.py:718)
-  {
-    Packer pk;
-    if (h2_mode()) {
-      // per-matrix maxima -> weight exponents (plain weights) and the bound of the question-mixed tile (W1a, W1b)
-      const size_t dd_ = (size_t)d * d;
-      CK(absmax4(P->projX_W, dd_, P->memKbProj2_W, dd_, P->memKbProj_W, dd_, P->memKbProj_W + dd_, dd_, saved + L.wmax, st));
-      // minimum-exponent arrays are filled with atomicMin by the producers of X / H1 / KBd
-      CK(hipMemsetAsync(saved + L.qmin_X, 0x7F, 3 * (size_t)(keep ? p : 1) * B * (d / 128) * sizeof(int), st));
-    }
-    pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);
-    pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, wfmt_ymix());
-    pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, wfmt_ymix());
-    pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);
-    pk.add(P->projY_W, d, 1, d, d, saved + L.wy_p);
-    pk.add(P->newMemory_W, d, 1, write_in_dim(o, d), d, saved + L.wm_p);
-    pk.add(P->qInput_W, d, 1, d, d, saved + L.wq_p);
-    if (o->write_gate) pk.add(P->gate_W, d, 1, d, d, saved + L.wg_p);
-    if (o->write_self_att) pk.add(P->selfCtrl_W, d, 1, d, d, saved + L.ws_p);
-    if (o->control_feed_prev) {
-      pk.add(P->contControl_W, d, 1, o->control_feed_inputs ? 2 * d : d, d, saved + L.wc_p);
-      if (o->control_cont_act != MACX_ACT_NON) pk.add(P->contControl2_W, d, 1, d, d, saved + L.wc2_p);
-    }
-    for (int i = 0; i < (o->control_input_unshared ? p : 1); ++i) {
-      if (pk.n == PACK_MAX) CK(pk.run(st));
-      pk.add(P->qInputU_W + (size_t)i * d * d, d, 1, d, d, saved + L.wqU_p + (size_t)i * d * d);
-    }
-    CK(pk.run(st));
-  }
+  CKI(pack_forward_weights(o, s, P, saved, L, keep, U_ALL, st));
 
   // initial state (mac_cell.py:546-553)
   float* controls = saved + L.seg[MACX_SEG_CONTROLS];
@@ -580,17 +596,15 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
   return MACX_OK;
 }
 
-int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
-                   const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
-                   int keep, int step, void* stream) {
-  ModeScope ms(o);
+namespace {
+int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                   const macx_inputs* in, float* saved, size_t saved_floats, int keep, int step, int units, void* stream) {
   CKI(check_impl(o, s));
   if (!dp || !P || !in || !saved) return MACX_EINVAL;
   if (step < 0 || step >= s->p) return MACX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const SavedLayout L = make_saved(o, s, keep);
   if (saved_floats < L.total) return MACX_ESMALL;
-  (void)ws; (void)ws_floats;
   const int B = s->B, N = s->N, d = s->d;
   const size_t Bd = (size_t)B * d;
   const int i = step;
@@ -610,7 +624,7 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   float* info_raw = wdrop ? saved + L.info_raw + (size_t)i * Bd : info;
 
   // ---- control unit when it is recurrent (mac_cell.py:141-151, configs/args1.txt)
-  if (o->control_feed_prev) {
+  if ((units & U_CONTROL) && o->control_feed_prev) {
     const float* prev = o->control_feed_prev_att ? controls + (size_t)i * Bd
                                                  : (i == 0 ? controls : saved + L.cc + (size_t)(i - 1) * Bd);
     float* cc_i = saved + L.cc + (size_t)i * Bd;
@@ -634,6 +648,7 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     CK(hipGetLastError());
   }
   // ---- read unit (mac_cell.py:209-277)
+  if (units & U_READ) {
   // memory dropout (mac_cell.py:214-217) then the read-dropout of ops.mul's y input (ops.py:679)
   const DropSpec dm = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
                                                     : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
@@ -742,6 +757,8 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     hipLaunchKernelGGL(kb_attend_kernel, dim3(B, d / 128), dim3(KA_THREADS), 0, st, a);
     CK(hipGetLastError());
   }
+  }   // U_READ
+  if (!(units & U_WRITE)) return MACX_OK;
   // write dropout (mac_cell.py:461-463); self.infos keeps the dropped value (mac_cell.py:474)
   if (wdrop) {
     const DropSpec dw = make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i);
@@ -785,6 +802,15 @@ int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   }
   return MACX_OK;
 }
+}  // namespace
+
+int macx_cell_step(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                   const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                   int keep, int step, void* stream) {
+  ModeScope ms(o);
+  (void)ws; (void)ws_floats;
+  return cell_step_impl(o, s, dp, P, in, saved, saved_floats, keep, step, U_ALL, stream);
+}
 
 int macx_cell_forward(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
                       const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
@@ -798,15 +824,25 @@ int macx_cell_forward(const macx_opts* o, const macx_shapes* s, const macx_dropo
 // phase 0: everything; 1: all of it except the deferred read-unit weight contractions; 2: only those (after a phase-1 call
 // on the same buffers).  A data-parallel host launches the all-reduce of every gradient phase 1 completes on a side stream
 // while phase 2 -- the last ~10 % of the backward pass -- still runs (macx.dp.OverlappedBuckets).
-int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
-                             const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
-                             const float* d_memory, const float* d_control, const macx_param_grads* GP,
-                             const macx_input_grads* GI, int phase, void* stream) {
+namespace {
+// gradients that cross a unit's boundary when one unit is differentiated on its own (macx_read_bwd / macx_write_bwd)
+struct UnitGrads {
+  const float* d_info_in = nullptr;     // read: dL/d(info), [B,d]
+  float* d_memory = nullptr;            // out: dL/d(memory input of the unit)
+  float* d_control = nullptr;           // out: dL/d(control input of the unit)
+  float* d_info_out = nullptr;          // write: dL/d(info) (before the write dropout)
+};
+
+int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                       const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                       const float* d_memory, const float* d_control, const macx_param_grads* GP,
+                       const macx_input_grads* GI, int phase, int units, const UnitGrads* ug, void* stream) {
   if (phase < 0 || phase > 2) return MACX_EINVAL;
-  ModeScope ms(o);
   CKI(check_impl(o, s));
   if (!dp || !P || !in || !saved || !ws || !GP || !GI) return MACX_EINVAL;
-  if (!GI->knowledgeBase || !GI->words || !GI->vecQuestions) return MACX_EINVAL;
+  if ((units & U_READ) && !GI->knowledgeBase) return MACX_EINVAL;
+  if ((units & U_CONTROL) && (!GI->words || !GI->vecQuestions)) return MACX_EINVAL;
+  if (units != U_ALL && (!ug || s->p != 1)) return MACX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const SavedLayout L = make_saved(o, s, 1);
   const BwdLayout W = make_bwd(o, s);
@@ -824,20 +860,24 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
   const int nU = o->control_input_unshared ? p : 1;
   {
     Packer pk;
-    pk.add(P->projX_W, 1, d, d, d, ws + W.wxT_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);            // Wx^T
-    pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, -1, -1, wfmt_ymix());       // W1a^T
-    pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, -1, -1, wfmt_ymix());  // W1b^T
-    pk.add(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);       // W2^T
-    pk.add(P->projY_W, 1, d, d, d, ws + W.wyT);              // Wy^T
-    pk.add(P->newMemory_W, 1, d, d, win, ws + W.wmT);        // Wm^T: [d] -> [win]
-    pk.add(P->qInput_W, 1, d, d, d, ws + W.wqT);
-    if (o->write_gate) pk.add(P->gate_W, 1, d, d, d, ws + W.wgT);
-    if (o->write_self_att) pk.add(P->selfCtrl_W, 1, d, d, d, ws + W.wscT);
-    if (o->control_feed_prev) {
+    if (units & U_READ) {
+      pk.add(P->projX_W, 1, d, d, d, ws + W.wxT_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);            // Wx^T
+      pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, -1, -1, wfmt_ymix());       // W1a^T
+      pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, -1, -1, wfmt_ymix());  // W1b^T
+      pk.add(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);       // W2^T
+      pk.add(P->projY_W, 1, d, d, d, ws + W.wyT);              // Wy^T
+    }
+    if (units & U_WRITE) {
+      pk.add(P->newMemory_W, 1, d, d, win, ws + W.wmT);        // Wm^T: [d] -> [win]
+      if (o->write_gate) pk.add(P->gate_W, 1, d, d, d, ws + W.wgT);
+      if (o->write_self_att) pk.add(P->selfCtrl_W, 1, d, d, d, ws + W.wscT);
+    }
+    if (units & U_CONTROL) pk.add(P->qInput_W, 1, d, d, d, ws + W.wqT);
+    if ((units & U_CONTROL) && o->control_feed_prev) {
       pk.add(P->contControl_W, 1, d, d, o->control_feed_inputs ? 2 * d : d, ws + W.wccT);   // Wc^T: [d] -> [d or 2d]
       if (o->control_cont_act != MACX_ACT_NON) pk.add(P->contControl2_W, 1, d, d, d, ws + W.wcc2T);
     }
-    for (int i = 0; i < nU; ++i) {
+    for (int i = 0; i < ((units & U_CONTROL) ? nU : 0); ++i) {
       if (pk.n == PACK_MAX) CK(pk.run(st));
       pk.add(P->qInputU_W + (size_t)i * dd, 1, d, d, d, ws + W.wqUT + (size_t)i * dd);
     }
@@ -853,7 +893,7 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
   CK(hipMemsetAsync(DC, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
   if (d_memory) CK(hipMemcpyAsync(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (d_control) CK(hipMemcpyAsync(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (o->control_feed_prev) {
+  if ((units & U_CONTROL) && o->control_feed_prev) {
     CK(hipMemsetAsync(GI->words, 0, (size_t)B * S * d * sizeof(float), st));
     CK(hipMemsetAsync(ws + W.dwc_part, 0, Bd * sizeof(float), st));
     CK(hipMemsetAsync(ws + W.dccx, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
@@ -877,6 +917,9 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
     float* dX_i = ws + W.dX + (size_t)i * W.act_floats;
     float* dwin = ws + W.dwin + (size_t)i * B * win;
 
+    const float* dinfo = ug ? ug->d_info_in : nullptr;
+    int ld_dinfo = d;
+    if (units & U_WRITE) {
     // ---- write unit backward
     const float* dmnew = dm_i;              // gradient wrt the (post-activation) new memory
     const float* mnew_out = memories + (size_t)(i + 1) * Bd;
@@ -904,8 +947,8 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
       CK(small_linear_launch(l, 1, st));
     }
     // d(info) through the write dropout (mac_cell.py:463); without write dropout it is a column view of dwin
-    const float* dinfo = dwin + d;
-    int ld_dinfo = win;
+    dinfo = dwin + d;
+    ld_dinfo = win;
     if (dp->keep_write < 1.0f) {
       hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)dwin, win, d, B, d, (uint32_t)s->b0,
                          make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i), ws + W.dinfo + (size_t)i * Bd);
@@ -926,6 +969,16 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
       q.db_part = ws + W.dbs_part + (size_t)i * B;
       hipLaunchKernelGGL(self_attend_bwd_kernel, dim3(B), dim3(256), 0, st, q);
       CK(hipGetLastError());
+    }
+    }   // U_WRITE
+    if (!(units & U_READ)) {
+      // the write unit alone: dL/d(memory) = dwin[:, :d] (+ dm (1 - z) under the gate), dL/d(info), dL/d(control) (the gate's)
+      const size_t pitch = (size_t)win * sizeof(float), wbytes = (size_t)d * sizeof(float);
+      CK(hipMemcpy2DAsync(ug->d_memory, wbytes, dwin, pitch, wbytes, B, hipMemcpyDeviceToDevice, st));
+      if (o->write_gate) CK(axpy(ws + W.tmpBd[3], Bd, ug->d_memory, st));
+      CK(hipMemcpy2DAsync(ug->d_info_out, wbytes, dinfo, (size_t)ld_dinfo * sizeof(float), wbytes, B, hipMemcpyDeviceToDevice, st));
+      CK(hipMemcpyAsync(ug->d_control, DC + (size_t)(i + 1) * Bd, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+      continue;
     }
 
     // ---- read unit backward
@@ -993,6 +1046,7 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
         g.out_f32 = GI->knowledgeBase; g.ldo = d;
         const bool wd = dp->keep_write < 1.0f;
         g.dr = wd ? ws + W.dinfo : ws + W.dwin + d; g.ld_dr = wd ? d : win; g.dr_step = wd ? Bd : (size_t)B * win;
+        if (!(units & U_WRITE)) { g.dr = dinfo; g.ld_dr = d; g.dr_step = Bd; }
         g.att = att_kb; g.att_step = (size_t)B * N;
         g.e_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits) : nullptr;
         g.bits_step_words = L.bits_stride;
@@ -1055,14 +1109,14 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
     CK(hipGetLastError());
     {
       // with self attention DM[i] already holds the parts later steps sent to this memory: accumulate
-      const bool acc_prev = o->write_self_att || o->write_gate;
+      const bool acc_prev = (units & U_WRITE) && (o->write_self_att || o->write_gate);
       LinP l = lin_basic(DYi, d, d, B, ws + W.wyT, nullptr, d, MACX_ACT_NON, acc_prev ? ws + W.tmpBd[0] : dm_prev, d);
       l.use_drop = 1;
       l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
                                            : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
       l.d2 = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i);
       l.drop_row0 = (uint32_t)s->b0;
-      l.addend = dwin; l.ld_add = win;
+      if (units & U_WRITE) { l.addend = dwin; l.ld_add = win; }
       CK(small_linear_launch(l, 1, st));
       if (acc_prev) {
         CK(axpy(ws + W.tmpBd[0], Bd, dm_prev, st));
@@ -1070,7 +1124,7 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
       }
     }
     // ---- recurrent control backward for this step (dL/dc_i is complete now)
-    if (o->control_feed_prev) {
+    if ((units & U_CONTROL) && o->control_feed_prev) {
       const int cin = o->control_feed_inputs ? 2 * d : d;
       const bool two = o->control_cont_act != MACX_ACT_NON;
       if (o->write_self_att && !o->write_self_att_cont) {
@@ -1126,6 +1180,7 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
     }
   }
 
+  if (units == U_ALL) {
   if (o->write_self_att && !o->write_self_att_cont && !o->control_feed_prev) {
     // selfControl = the NEW control: dL/dc_i += dsc_i Ws^T before the word attention is differentiated
     LinP l = lin_basic(ws + W.dsc, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, DC + Bd, d);
@@ -1189,10 +1244,12 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
     CK(rowsum(ws + W.dws_part, p * B, d, d, GP->selfLogits_w, st));
     CK(rowsum(ws + W.dbs_part, p * B, 1, 1, GP->selfLogits_b, st));
   }
-  if (o->write_gate) {
+  }   // U_ALL
+  if (o->write_gate && (units & U_WRITE)) {
     CKI(wgrad_impl(controls + Bd, d, ws + W.dzpre, d, p * B, d, d, GP->gate_W, ws + W.small_slab, st));
     CK(rowsum(ws + W.dzpre, p * B, d, d, GP->gate_b, st));
   }
+  if (units == U_ALL) {
   // ---- control inputs backward (mac_cell.py:442-448): dt = sum_i dcI_i WqU_i^T ; du = dt * act'(t)
   const float* ctrl_t = saved + L.ctrl_t;
   float* dcI_sum = ws + W.tmpBd[1];
@@ -1242,17 +1299,27 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
   if (o->init_ctrl == MACX_INIT_PRM) CK(rowsum(DC, B, d, d, GP->initCtrl, st));
   else if (o->init_ctrl == MACX_INIT_Q) CK(axpy(DC, Bd, GI->vecQuestions, st));
 
+  }   // U_ALL
   // ---- weight gradients of the [B,d] linears, one contraction over all p*B rows each
-  CKI(wgrad_impl(saved + L.md, d, ws + W.DY, d, p * B, d, d, GP->projY_W, ws + W.small_slab, st));
-  CK(rowsum(ws + W.DY, p * B, d, d, GP->projY_b, st));
-  CKI(wgrad_impl(memories, d, dwlin_all, d, p * B, d, d, GP->newMemory_W, ws + W.small_slab, st));
-  CKI(wgrad_impl(infos, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + dd, ws + W.small_slab, st));
-  if (o->write_self_att)
-    CKI(wgrad_impl(saved + L.self_smry, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + 2 * dd, ws + W.small_slab, st));
-  CK(rowsum(dwlin_all, p * B, d, d, GP->newMemory_b, st));
+  if (units & U_READ) {
+    CKI(wgrad_impl(saved + L.md, d, ws + W.DY, d, p * B, d, d, GP->projY_W, ws + W.small_slab, st));
+    CK(rowsum(ws + W.DY, p * B, d, d, GP->projY_b, st));
+  }
+  if (units & U_WRITE) {
+    CKI(wgrad_impl(memories, d, dwlin_all, d, p * B, d, d, GP->newMemory_W, ws + W.small_slab, st));
+    CKI(wgrad_impl(infos, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + dd, ws + W.small_slab, st));
+    if (o->write_self_att)
+      CKI(wgrad_impl(saved + L.self_smry, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + 2 * dd, ws + W.small_slab, st));
+    CK(rowsum(dwlin_all, p * B, d, d, GP->newMemory_b, st));
+  }
+  if (units == U_READ) {
+    // the read unit alone: dL/d(memory) = (dy Wy^T) through the two masks, dL/d(control) from the attention logits
+    CK(hipMemcpyAsync(ug->d_memory, DM, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+    CK(hipMemcpyAsync(ug->d_control, DC + Bd, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
 
   }   // phase != 2
-  if (phase == 1) return MACX_OK;
+  if (phase == 1 || !(units & U_READ)) return MACX_OK;
 
   // ---- read-unit weights: fixed-order reduction of the per-step slabs
   // dW2 = sum_i H1_i^T dI2_i and dWx = sum_i dropout_i(KB)^T dX_i: ONE contraction each over all
@@ -1305,6 +1372,15 @@ int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const mac
   CK(rowsum(ws + W.dbk_part, p * B, 1, 1, GP->kbLogits_b, st));
   return MACX_OK;
 }
+}  // namespace
+
+int macx_cell_backward_phase(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                             const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                             const float* d_memory, const float* d_control, const macx_param_grads* GP,
+                             const macx_input_grads* GI, int phase, void* stream) {
+  ModeScope ms(o);
+  return cell_backward_impl(o, s, dp, P, in, saved, saved_floats, ws, ws_floats, d_memory, d_control, GP, GI, phase, U_ALL, nullptr, stream);
+}
 
 int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
                        const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
@@ -1316,6 +1392,101 @@ int macx_cell_backward(const macx_opts* o, const macx_shapes* s, const macx_drop
 // =================================================================================================
 // unit-level entry points
 // =================================================================================================
+// ---- one read / write unit on caller-owned buffers: the cell's own step code restricted to a unit.
+// shapes->p == 1: the unit of step 0 (the dropout streams are keyed by (seed, site, step 0)).
+namespace {
+int unit_check(const macx_opts* o, const macx_shapes* s, int units) {
+  CKI(check_impl(o, s));
+  if (s->p != 1) return MACX_EINVAL;
+  if ((units & U_WRITE) && o->write_self_att) return MACX_EUNSUPPORTED;   // needs the histories of a running cell
+  return MACX_OK;
+}
+}  // namespace
+
+size_t macx_workspace_bytes(const macx_opts* o, const macx_shapes* s, int for_backward) {
+  return macx_ws_floats(o, s, for_backward) * sizeof(float);
+}
+
+int macx_read_fwd(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                  const float* knowledgeBase, const float* memory, const float* control, float* saved, size_t saved_floats,
+                  float* info, float* att, void* stream) {
+  ModeScope ms(o);
+  CKI(unit_check(o, s, U_READ));
+  if (!dp || !P || !knowledgeBase || !memory || !control || !saved || !info || !att) return MACX_EINVAL;
+  if (misaligned(saved) || misaligned(knowledgeBase)) return MACX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const SavedLayout L = make_saved(o, s, 1);
+  if (saved_floats < L.total) return MACX_ESMALL;
+  const size_t Bd = (size_t)s->B * s->d;
+  CKI(pack_forward_weights(o, s, P, saved, L, 1, U_READ, st));
+  CK(hipMemcpyAsync(saved + L.seg[MACX_SEG_MEMORIES], memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(hipMemcpyAsync(saved + L.seg[MACX_SEG_CONTROLS] + Bd, control, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  macx_inputs in;
+  memset(&in, 0, sizeof(in));
+  in.knowledgeBase = knowledgeBase;
+  CKI(cell_step_impl(o, s, dp, P, &in, saved, saved_floats, 1, 0, U_READ, stream));
+  const float* info_raw = dp->keep_write < 1.0f ? saved + L.info_raw : saved + L.seg[MACX_SEG_INFOS];
+  CK(hipMemcpyAsync(info, info_raw, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(hipMemcpyAsync(att, saved + L.seg[MACX_SEG_ATT_KB], (size_t)s->B * s->N * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return MACX_OK;
+}
+
+int macx_read_bwd(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                  const float* knowledgeBase, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
+                  const float* d_info, const macx_param_grads* GP, float* d_knowledgeBase, float* d_memory, float* d_control,
+                  void* stream) {
+  ModeScope ms(o);
+  CKI(unit_check(o, s, U_READ));
+  if (!knowledgeBase || !d_info || !d_knowledgeBase || !d_memory || !d_control) return MACX_EINVAL;
+  macx_inputs in;
+  memset(&in, 0, sizeof(in));
+  in.knowledgeBase = knowledgeBase;
+  macx_input_grads GI;
+  memset(&GI, 0, sizeof(GI));
+  GI.knowledgeBase = d_knowledgeBase;
+  UnitGrads ug;
+  ug.d_info_in = d_info; ug.d_memory = d_memory; ug.d_control = d_control;
+  return cell_backward_impl(o, s, dp, P, &in, saved, saved_floats, ws, ws_floats, nullptr, nullptr, GP, &GI, 0, U_READ, &ug, stream);
+}
+
+int macx_write_fwd(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                   const float* memory, const float* info, const float* control, float* saved, size_t saved_floats,
+                   float* new_memory, void* stream) {
+  ModeScope ms(o);
+  CKI(unit_check(o, s, U_WRITE));
+  if (!dp || !P || !memory || !info || !control || !saved || !new_memory) return MACX_EINVAL;
+  if (misaligned(saved)) return MACX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const SavedLayout L = make_saved(o, s, 1);
+  if (saved_floats < L.total) return MACX_ESMALL;
+  const size_t Bd = (size_t)s->B * s->d;
+  CKI(pack_forward_weights(o, s, P, saved, L, 1, U_WRITE, st));
+  float* info_raw = dp->keep_write < 1.0f ? saved + L.info_raw : saved + L.seg[MACX_SEG_INFOS];
+  CK(hipMemcpyAsync(saved + L.seg[MACX_SEG_MEMORIES], memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(hipMemcpyAsync(info_raw, info, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(hipMemcpyAsync(saved + L.seg[MACX_SEG_CONTROLS] + Bd, control, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  macx_inputs in;
+  memset(&in, 0, sizeof(in));
+  CKI(cell_step_impl(o, s, dp, P, &in, saved, saved_floats, 1, 0, U_WRITE, stream));
+  CK(hipMemcpyAsync(new_memory, saved + L.seg[MACX_SEG_MEMORIES] + Bd, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return MACX_OK;
+}
+
+int macx_write_bwd(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                   const float* saved, size_t saved_floats, float* ws, size_t ws_floats, const float* d_new_memory,
+                   const macx_param_grads* GP, float* d_memory, float* d_info, float* d_control, void* stream) {
+  ModeScope ms(o);
+  CKI(unit_check(o, s, U_WRITE));
+  if (!d_new_memory || !d_memory || !d_info || !d_control) return MACX_EINVAL;
+  macx_inputs in;
+  memset(&in, 0, sizeof(in));
+  macx_input_grads GI;
+  memset(&GI, 0, sizeof(GI));
+  UnitGrads ug;
+  ug.d_memory = d_memory; ug.d_info_out = d_info; ug.d_control = d_control;
+  return cell_backward_impl(o, s, dp, P, &in, saved, saved_floats, ws, ws_floats, d_new_memory, nullptr, GP, &GI, 0, U_WRITE, &ug, stream);
+}
+
 int macx_linear(const float* x1, int k1, const float* x2, int k2, int rows, const float* Wp, const float* b, float bias_const,
                 int n_out, int act, float* out, void* stream) {
   if (!x1 || !Wp || !out || rows < 1 || n_out < 16 || n_out % 16) return MACX_EINVAL;
