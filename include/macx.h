@@ -355,6 +355,12 @@ int macx_kb_project(const macx_shapes*, const macx_dropout*, int step, const flo
  * (mac_cell.py:155-181; ops.py:114-150, 243-247).  cc: continuous control [B,d]. */
 int macx_control_attend(const macx_shapes*, const float* cc, const float* words, const int32_t* lengths,
                         const float* w, const float* b, float* att, float* control, void* stream);
+/* its backward: d_control[B,d] -> d_cc[B,d], d_words[B,S,d] (written), d_w[d], d_b[1]; `att` is what the forward call
+ * returned; ws >= macx_control_attend_bwd_ws_floats(shapes) floats.  d % 64 == 0. */
+size_t macx_control_attend_bwd_ws_floats(const macx_shapes*);
+int macx_control_attend_bwd(const macx_shapes*, const float* d_control, const float* cc, const float* att, const float* words,
+                            const float* w, float* ws, size_t ws_floats, float* d_cc, float* d_words, float* d_w, float* d_b,
+                            void* stream);
 /* Materialises the 0/1 keep mask of a dropout site for n elements starting at flat index
  * `first` (test hook for the stateless stream; site numbers in macx_common.hip.h). */
 int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,

@@ -1549,6 +1549,35 @@ int macx_control_attend(const macx_shapes* s, const float* cc, const float* word
   return MACX_OK;
 }
 
+size_t macx_control_attend_bwd_ws_floats(const macx_shapes* s) {
+  if (!s) return 0;
+  return al4((size_t)s->B * s->S) + al4((size_t)s->B * s->d) + al4((size_t)s->B);
+}
+
+int macx_control_attend_bwd(const macx_shapes* s, const float* d_control, const float* cc, const float* att, const float* words,
+                            const float* w, float* ws, size_t ws_floats, float* d_cc, float* d_words, float* d_w, float* d_b,
+                            void* stream) {
+  if (!s || !d_control || !cc || !att || !words || !w || !ws || !d_cc || !d_words || !d_w || !d_b) return MACX_EINVAL;
+  if (s->S > C_MAXS || s->d % 64 != 0) return MACX_EINVAL;
+  if (ws_floats < macx_control_attend_bwd_ws_floats(s)) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, S = s->S, d = s->d;
+  CtrlBwdP c;
+  c.B = B; c.S = S; c.d = d; c.nz = 1;
+  c.dcontrol = d_control; c.z_dc = 0; c.cc = cc; c.z_cc = 0; c.att = att; c.z_att = 0;
+  c.words = words; c.w = w;
+  c.dl = ws;
+  c.dw_part = ws + al4((size_t)B * S);
+  c.db_part = c.dw_part + al4((size_t)B * d);
+  c.dcc = d_cc; c.z_dcc = 0; c.dwords = d_words; c.acc_words = 0;
+  hipLaunchKernelGGL(control_bwd_dl_kernel, dim3(B, 1), dim3(256), 0, st, c);
+  hipLaunchKernelGGL(control_bwd_apply_kernel, dim3(B, d / 64), dim3(256), 0, st, c);
+  CK(hipGetLastError());
+  CK(rowsum(c.dw_part, B, d, d, d_w, st));
+  CK(rowsum(c.db_part, B, 1, 1, d_b, st));
+  return MACX_OK;
+}
+
 int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first, size_t n, float* out, void* stream) {
   if (!out) return MACX_EINVAL;
   const DropSpec ds = make_drop(keep, seed, site, step);

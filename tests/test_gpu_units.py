@@ -143,6 +143,25 @@ def test_control_attend(macx, dev):
     # padded words get exactly zero attention
     for bi in range(B):
         assert float(att[bi, lengths[bi]:].abs().sum()) == 0.0
+    # and the unit's backward (macx_control_attend_bwd) for a caller-chosen d_control, against autograd in fp64
+    ccd, wdd, wwd = [t.double().requires_grad_(True) for t in (cc, words, w)]
+    bd = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    lg = ((ccd.unsqueeze(1) * wdd) * wwd).sum(-1) + bd
+    a2 = torch.softmax(mo.Ops.expMask(lg, lengths), dim=-1)
+    c2 = (a2.unsqueeze(-1) * wdd).sum(1)
+    dctl = torch.randn(B, d, generator=g)
+    (c2 * dctl.double()).sum().backward()
+    n_ws = L.macx_control_attend_bwd_ws_floats(C.byref(sh))
+    ws = torch.empty(n_ws, device=dev)
+    dcc, dwords, dw, db = torch.empty(B, d, device=dev), torch.empty(B, S, d, device=dev), torch.empty(d, device=dev), torch.empty(1, device=dev)
+    dctl_d = dctl.to(dev)
+    macx._lib.check(L.macx_control_attend_bwd(C.byref(sh), _p(dctl_d), _p(args[0]), _p(att), _p(args[1]), _p(args[3]), _p(ws), n_ws,
+                                              _p(dcc), _p(dwords), _p(dw), _p(db), None), "control_attend_bwd")
+    torch.cuda.synchronize()
+    assert rel_err(dcc, ccd.grad) < 2e-5 and rel_err(dwords, wdd.grad) < 2e-5 and rel_err(dw, wwd.grad) < 2e-5
+    assert abs(float(db) - float(bd.grad)) < 1e-5          # analytically zero (a bias in front of a softmax)
+    assert L.macx_control_attend_bwd(C.byref(sh), _p(dctl_d), _p(args[0]), _p(att), _p(args[1]), _p(args[3]), _p(ws), 8,
+                                     _p(dcc), _p(dwords), _p(dw), _p(db), None) == -4
 
 
 @pytest.mark.parametrize("mode", [1, 0])
