@@ -1,0 +1,37 @@
+"""-m gpu: the documented maxima and minima of the fused cell (include/macx.h, macx_check: S <= 256, N <= 1024, p <= 32,
+d <= 1024; a single question, a single knowledge-base cell, a single step) -- forward state and every gradient against
+the fp64 oracle, and the first size past each limit is rejected with MACX_EINVAL rather than computed wrongly."""
+import ctypes as C
+
+import pytest
+import torch
+
+from helpers import make_case
+from test_gpu_cell import test_backward_matches_oracle_autograd as parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,B,S,N,d,p,train", [
+    ("args", 2, 5, 1024, 1024, 2, True),       # widest cell the kernels take: N = 1024 cells, d = 1024
+    ("args4", 2, 256, 16, 128, 2, True),       # longest question
+    ("args", 2, 6, 9, 128, 32, True),          # most reasoning steps (deferred dKB: 32 steps in chunks of 16)
+    ("args3", 2, 6, 9, 128, 32, False),        # ... with self-attention over 32 histories
+    ("args1", 1, 3, 1, 128, 1, True),          # one question, one knowledge-base cell, one step
+    ("args", 1, 3, 209, 128, 2, True),         # one question whose knowledge base crosses a 208-row tile
+    ("args", 64, 8, 196, 128, 1, False),       # the metric's batch and grid at the narrowest width
+])
+def test_extreme_shapes_match_the_oracle(macx, dev, name, B, S, N, d, p, train):
+    parity(macx, dev, name, B, S, N, d, p, train)
+
+
+@pytest.mark.parametrize("over", [dict(S=257), dict(N=1025), dict(p=33), dict(d=1152), dict(d=192), dict(B=0)])
+def test_first_size_past_each_limit_is_rejected(macx, over):
+    cfg, *_ = make_case("args", 2, 4, 8, 128, 2)
+    opts = macx.options.freeze(cfg)
+    kw = dict(B=2, S=4, N=8, d=128, p=2, b0=0)
+    kw.update(over)
+    sh = macx._lib.MacxShapes(**kw)
+    L = macx._lib.lib()
+    assert L.macx_check(C.byref(opts), C.byref(sh)) == -1            # MACX_EINVAL
+    assert L.macx_saved_floats(C.byref(opts), C.byref(sh), 1) == 0
