@@ -309,14 +309,30 @@ class GenericParams(torch.nn.Module):
         self.table = torch.nn.ParameterDict()
         self.names = {}               # reference name -> ParameterDict key
         self._stack = []
+        self._counts = {}             # full scope name -> times opened (default-name scopes: prelu, prelu_1, ...)
 
     @contextmanager
-    def scope(self, name):
+    def scope(self, name, default=False):
+        """tf.variable_scope(name); default=True: tf.variable_scope(None, default_name=name) -- `name`, then `name_1`, ... within
+        one opening of the enclosing scope (ops.py:163; the counts of a scope's children reset when it closes, as in TF)."""
+        if default:
+            cur = "/".join(self._stack + [name])
+            if self._counts.get(cur, 0) > 0:
+                idx = 1
+                while self._counts.get("%s_%d" % (cur, idx), 0) > 0:
+                    idx += 1
+                name = "%s_%d" % (name, idx)
         self._stack.append(name)
+        full = "/".join(self._stack)
+        self._counts[full] = self._counts.get(full, 0) + 1
         try:
             yield
         finally:
             self._stack.pop()
+            pre = full + "/"
+            for k in list(self._counts):
+                if k.startswith(pre):
+                    self._counts[k] = 0
 
     def get(self, name, shape, init):
         key = "/".join(self._stack + [name])
@@ -391,7 +407,7 @@ class _Ops:
         if name == "RELU":
             r = self.g("relu")
             if r == "PRM":
-                with self.vs.scope("prelu"):
+                with self.vs.scope("prelu", default=True):
                     alpha = self.vs.get("alpha", (x.shape[-1],), 0.25)
                 return _Act.apply(x, ACT_PRELU, alpha)
             if r == "LKY":
@@ -404,7 +420,7 @@ class _Ops:
     # tf.contrib.layers.batch_norm(updates_collections=None) on the last axis of a [B, c] tensor (mac_cell.py:370-373):
     # batch statistics (biased variance) in training, moving averages in evaluation; eps = 0.001
     def batch_norm(self, x, decay, center, scale, is_training, epsilon=0.001):
-        with self.vs.scope("BatchNorm"):
+        with self.vs.scope("BatchNorm", default=True):
             c = x.shape[-1]
             beta = self.vs.get("beta", (c,), "zeros") if center else None
             gamma = self.vs.get("gamma", (c,), 1.0) if scale else None

@@ -41,6 +41,7 @@ VARIANTS = {
     "unshared_cells": ("args", dict(unsharedCells=True)),
     "relu_prm": ("args", dict(relu="PRM", initCtrl="Q", controlContAct="RELU", controlFeedPrev=True)),
     "relu_prm_unshared": ("args", dict(relu="PRM", initCtrl="Q", unsharedCells=True, writeMemAct="RELU")),
+    "relu_prm_two_in_one_scope": ("args", dict(relu="PRM", writeInfoAct="RELU", writeMemAct="RELU")),     # write/prelu, write/prelu_1
     "no_var_dropout": ("args", dict(memoryVariationalDropout=False)),
     "memory_bn": ("args", dict(memoryBN=True)),
     "memory_bn_affine": ("args", dict(memoryBN=True, bnCenter=True, bnScale=True)),

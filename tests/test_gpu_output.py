@@ -116,3 +116,15 @@ def test_answer_loss_and_pred_kernel(macx, dev, B, A):
     bad[0] = A
     l2, _ = macx.output.answer_loss_and_pred(logits.to(dev), bad.to(dev))
     assert not torch.isfinite(l2)                                      # out-of-range label: NaN loss, as TF's GPU kernel
+
+
+@pytest.mark.parametrize("variant", ["no_question", "question_mul", "deep", "no_hidden", "prelu", "std_relu_mul_deep"])
+@pytest.mark.parametrize("train", [False, True])
+def test_generic_output_unit_matches_oracle(macx, dev, variant, train):
+    """macx.OutputClassifier on the option sets the fused kernels refuse (no --outQuestion, --outQuestionMul, 0 / 2 / 3 hidden
+    layers, --relu PRM / STD): one HIP kernel per reference op, against the fp64 oracle with identical dropout masks --
+    logits <= 2e-5, every parameter / input gradient <= 1e-4."""
+    from test_generic_output_host import out_cfg, run_pair, check
+    out, logits, ref, mem, vq, prm = run_pair(macx, out_cfg(variant), train, dev=dev)
+    torch.cuda.synchronize()
+    check(out, logits, ref, mem, vq, prm, gtol=1e-4)

@@ -216,6 +216,7 @@ VARIANTS = {
     "unshared_cells": FULLREAD + ["--unsharedCells", "1"] + BASE,
     "relu_prm": FULLREAD + ["--relu", "PRM", "--initCtrl", "Q", "--controlContAct", "RELU", "--controlFeedPrev"],
     "relu_prm_unshared": FULLREAD + ["--relu", "PRM", "--initCtrl", "Q", "--unsharedCells", "1", "--writeMemAct", "RELU"],
+    "relu_prm_two_in_one_scope": FULLREAD + ["--relu", "PRM", "--writeInfoAct", "RELU", "--writeMemAct", "RELU"],
     "init_zero_mem": FULLREAD + ["--initMem", "ZERO", "--initCtrl", "PRM", "--relu", "ELU"],
     "init_q_mem": FULLREAD + ["--initMem", "Q"] + BASE,
     "no_var_dropout": [f for f in FULLREAD if f != "--memoryVariationalDropout"] + BASE,
@@ -223,13 +224,20 @@ VARIANTS = {
     "memory_bn_affine": FULLREAD + ["--memoryBN", "--bnCenter", "--bnScale"] + BASE,
     "out_question_mul": FULLREAD + ["--outQuestion", "--outQuestionMul"] + BASE,
     "out_no_question": FULLREAD + BASE,
+    "out_deep_classifier": FULLREAD + ["--outQuestion", "--outQuestionMul", "--outClassifierDims", "12", "10", "9", "--relu", "PRM"],
+    "out_no_hidden_layer": FULLREAD + ["--outQuestion", "--outClassifierDims"] + BASE,
 }
+
+
+def variant_flags(variant):
+    flags = VARIANTS[variant]
+    return flags + rx.dims_flags(D, P, None if "--outClassifierDims" in flags else HID)
 
 
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
 @pytest.mark.parametrize("train", [False, True])
 def test_oracle_reproduces_the_reference_on_other_legal_options(variant, train):
-    cfg = rx.parse_flags(None, *(VARIANTS[variant] + rx.dims_flags(D, P, HID)))
+    cfg = rx.parse_flags(None, *variant_flags(variant))
     ref, orc, _ = run_pair(cfg, train)
     assert_same_forward(ref, orc)
     assert list(orc["store"].params.keys()) == list(ref["variables"].keys())
@@ -237,9 +245,10 @@ def test_oracle_reproduces_the_reference_on_other_legal_options(variant, train):
 
 @pytest.mark.parametrize("variant", ["defaults", "read_bilinear", "read_additive", "write_concat_mul", "write_sum",
                                      "control_proj", "unshared_cells", "relu_prm", "memory_bn", "read_ctrl_concat_proj",
-                                     "write_merge_ctrl", "control_continuous", "mul_bias"])
+                                     "write_merge_ctrl", "control_continuous", "mul_bias", "relu_prm_two_in_one_scope",
+                                     "out_deep_classifier"])
 def test_oracle_gradients_on_other_legal_options(variant):
-    cfg = rx.parse_flags(None, *(VARIANTS[variant] + rx.dims_flags(D, P, HID)))
+    cfg = rx.parse_flags(None, *variant_flags(variant))
     ref, orc, _ = run_pair(cfg, True, need_grad=True)
     ref["loss"].backward()
     orc["loss"].backward()
