@@ -93,15 +93,26 @@ def reject_like_reference(config):
         raise UnboundLocalError("local variable 'questionLengths' referenced before assignment")
     if g("readMemAttType") == "DIAG" or (g("readCtrl") and g("readCtrlAttType") == "DIAG"):   # ops.py:704-707
         raise UnboundLocalError("local variable 'output' referenced before assignment")
-    if g("readMemConcatProj") and not g("readProjInputs") and (g("readMemConcatKB")):          # ops.py:691,716
+    if g("readMemConcatProj") and not g("readProjInputs"):          # ops.py:691,716 (evaluated whether or not concat["x"] is set)
         raise UnboundLocalError("local variable 'projVals' referenced before assignment")
     if g("readCtrl") and g("readProjInputs") and g("attDim") != g("ctrlDim"):                  # mac_cell.py:245-246
         raise NameError("name 'ctrlDim' is not defined")
     if g("writeGate") and g("writeGateShared"):   # [B,d] * [B] does not broadcast (ops.py:317, mac_cell.py:367)
         raise ValueError("Dimensions must be equal")
+    if g("readCtrl") and g("readCtrlConcatKB") and g("readCtrlConcatProj") and not g("readProjInputs") and not g("readCtrlConcatInter"):
+        # mac_cell.py:252-258: tf.concat([interactions, projectedKB]) with projectedKB = None (ops.convert_to_tensor(None))
+        raise ValueError("None values not supported.")
     if g("readCtrl") and g("readCtrlConcatInter"):
         # mac_cell.py:248-250 drops the width ops.mul returns: inter2att builds a [dim] weight for a [.., 2 dim] tensor
         raise ValueError("Dimensions must be equal")
+    if g("readSmryKBProj") and not g("readProjInputs"):
+        # mac_cell.py:271-272: att2Smry(attention, None) -> tensor * None (ops.py:150)
+        raise ValueError("None values not supported.")
+    if g("relu") == "PRM" and g("controlInputAct") == "RELU" and int(g("netLength")) > 1:
+        # mac_cell.py:445 applies the activation in the cell's own scope (reuse=None, mac_cell.py:422): step 1 creates
+        # MACCell/prelu/alpha a second time
+        raise ValueError("Variable MACnetwork/MACCell/prelu/alpha already exists, disallowed. "
+                         "Did you mean to set reuse=True in VarScope?")
 
 
 GEMM_FAMILIES = {None: 0, "default": 0, "native": 1, "split": 2, "h2": 3}

@@ -139,3 +139,77 @@ def test_generic_path_rejections(macx, host_generic):
     with pytest.raises(macx.UnsupportedOptions):
         macx.GenericMACCell(vq[:, :64], words[:, :, :64], words[:, :, :64], lengths, kb[:, :, :64], 1.0, 1.0, 1.0, 2, False,
                      config=mo.default_config(netLength=1, memDim=64, ctrlDim=64, attDim=64))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# random option sets: the product's host logic builds and differentiates what the oracle builds, and raises where it raises
+# ---------------------------------------------------------------------------------------------------------------------
+FUZZ_BOOL = ["readProjInputs", "readProjShared", "readMemConcatKB", "readMemConcatProj", "readMemProj", "readCtrl", "readCtrlConcatKB",
+             "readCtrlConcatProj", "readSmryKBProj", "writeConcatMul", "writeInfoProj", "writeSelfAtt", "writeMergeCtrl", "writeMemProj",
+             "writeGate", "memoryVariationalDropout", "controlContextual", "controlInWordsProj", "controlOutWordsProj",
+             "controlInputUnshared", "controlFeedPrev", "controlFeedPrevAtt", "controlFeedInputs", "controlConcatWords", "controlProj",
+             "controlContinuous", "controlWholeQ", "memoryBN", "bnCenter", "bnScale", "unsharedCells"]
+FUZZ_CHOICE = {"initCtrl": ["PRM", "ZERO", "Q"], "initMem": ["PRM", "ZERO", "Q"], "controlInputAct": ["NON", "RELU", "TANH"],
+               "controlContAct": ["NON", "RELU", "TANH"], "controlProjAct": ["NON", "RELU", "TANH"],
+               "readMemAttType": ["MUL", "BL", "ADD"], "readCtrlAttType": ["MUL", "BL", "ADD"], "readMemAct": ["NON", "RELU", "TANH"],
+               "readCtrlAct": ["NON", "RELU", "TANH"], "writeInputs": ["MEM", "INFO", "SUM", "BOTH"],
+               "writeInfoAct": ["NON", "RELU", "TANH"], "writeSelfAttMod": ["NON", "CONT"], "writeMemAct": ["NON", "RELU", "TANH"],
+               "relu": ["STD", "PRM", "ELU"], "mulBias": [0.0, 0.5], "writeGateBias": [0.0, 1.0]}
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_option_sets_host_logic(macx, host_generic, seed):
+    import random
+    rnd = random.Random(500 + seed)
+    B, S, N, d, p = 3, 6, 8, 128, 3
+    built = 0
+    for case in range(8):
+        over = {}
+        on = 0.85 if rnd.random() < 0.7 else 0.4
+        for b in FUZZ_BOOL:
+            if rnd.random() < (on if b in ("readProjInputs", "readMemProj", "readCtrl") else 0.35):
+                over[b] = True
+        for k, vals in FUZZ_CHOICE.items():
+            if rnd.random() < 0.5:
+                over[k] = rnd.choice(vals)
+        train = rnd.random() < 0.5
+        cfg = mo.default_config(netLength=p, memDim=d, ctrlDim=d, attDim=d, **over)
+        vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, d, seed=11)
+        g = torch.Generator().manual_seed(3)
+        dM, dC = torch.randn(B, d, generator=g), torch.randn(B, d, generator=g)
+        oexc = pexc = params = None
+        try:
+            params = oracle_params(cfg, vq, words, lengths, kb)
+            ref = oracle_run(cfg, params, vq, words, lengths, kb, train=train, seed=91, b0=1, need_grad=True, d_memory=dM, d_control=dC)
+        except Exception as e:          # noqa: BLE001 -- the oracle raises what the reference raises (tests/test_reference_exec.py)
+            oexc = e
+        try:
+            gp = macx.GenericParams()
+            if params is not None:
+                gp.load_reference_dict(params)
+            vqd, wd, kbd = [t.clone().requires_grad_(True) for t in (vq, words, kb)]
+            cell = macx.GenericMACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=lengths,
+                                       knowledgeBase=kbd, memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout,
+                                       writeDropout=cfg.writeDropout, batchSize=B, train=train, config=cfg, params=gp, seed=91, b0=1)
+            state = cell.run()
+            ((state.memory * dM).sum() + (state.control * dC).sum()).backward()
+        except Exception as e:          # noqa: BLE001
+            pexc = e
+        if oexc is not None or pexc is not None:
+            assert type(oexc) is type(pexc), "%s: oracle raises %r, product %r" % (over, oexc, pexc)
+            continue
+        built += 1
+        k = 5.0 if cfg.memoryBN else 1.0
+        # (absolute floor: writeInputs=MEM under batch norm normalises identical rows -- the memory is round-off around zero)
+        assert list(gp.names) == list(params), over
+        assert rel_err(state.memory, ref["memory"], floor=1e-3) < 2e-5 * k and rel_err(state.control, ref["control"], floor=1e-3) < 2e-5 * k, over
+        grads = gp.grads_by_name()
+        for name, v in ref["params"].items():
+            if v.grad is None:
+                assert grads[name] is None or float(grads[name].abs().max()) == 0.0, (over, name)
+            elif float(v.grad.abs().max()) > 1e-6:
+                assert_grad(grads[name], v.grad, name, 2e-4 * k)
+        for got, want in zip((vqd, wd, kbd), ref["inputs"]):
+            if want.grad is not None and float(want.grad.abs().max()) > 1e-6:
+                assert rel_err(got.grad, want.grad) < 2e-4 * k, over
+    assert built >= 2

@@ -276,6 +276,12 @@ RAISING = {
     # mac_cell.py:248-250 keeps `dim` when ops.mul concatenates its x operand: inter2att then gets a [.., 2 dim] tensor
     "read_ctrl_concat_inter": FULLREAD + ["--readCtrlConcatInter"] + BASE,
     "read_ctrl_concat_inter_kb": FULLREAD + ["--readCtrlConcatInter", "--readCtrlConcatKB"] + BASE,
+    # found by the random option sets below: tf.concat / tensor * None reject None with ValueError (ops.convert_to_tensor) ...
+    "ctrl_concat_proj_without_proj": ["--readMemProj", "--readCtrl", "--readCtrlConcatKB", "--readCtrlConcatProj"] + BASE,
+    "smry_proj_without_proj": ["--readMemProj", "--readCtrl", "--readSmryKBProj"] + BASE,
+    "concat_proj_without_proj_no_x": ["--readMemConcatProj", "--readMemProj"] + BASE,
+    # ... and PReLU on the control input lives in the cell's own scope (reuse=None): step 1 creates its slope again
+    "prelu_on_control_input": FULLREAD + ["--relu", "PRM", "--controlInputAct", "RELU", "--initCtrl", "Q"],
 }
 
 
@@ -297,3 +303,67 @@ def test_rejected_option_values_raise_the_same_exception(variant):
         macx.options.reject_like_reference(ocfg)
         macx.options.resolve_activations(ocfg)
     assert prod_exc.type is ref_exc.type, "reference raises %r, macx.options raises %r" % (ref_exc.value, prod_exc.value)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# random option sets: whatever the reference does with a combination -- build and run, or raise -- the oracle does too
+# ---------------------------------------------------------------------------------------------------------------
+FUZZ_BOOL = ["readProjInputs", "readProjShared", "readMemConcatKB", "readMemConcatProj", "readMemProj", "readCtrl", "readCtrlConcatKB",
+             "readCtrlConcatProj", "readSmryKBProj", "writeConcatMul", "writeInfoProj", "writeSelfAtt", "writeMergeCtrl", "writeMemProj",
+             "writeGate", "memoryVariationalDropout", "controlContextual", "controlInWordsProj", "controlOutWordsProj",
+             "controlInputUnshared", "controlFeedPrev", "controlFeedPrevAtt", "controlFeedInputs", "controlConcatWords", "controlProj",
+             "controlContinuous", "controlWholeQ", "memoryBN", "bnCenter", "bnScale", "outQuestion", "outQuestionMul"]
+FUZZ_CHOICE = {"initCtrl": ["PRM", "ZERO", "Q"], "initMem": ["PRM", "ZERO", "Q"], "controlInputAct": ["NON", "RELU", "TANH"],
+               "controlContAct": ["NON", "RELU", "TANH"], "controlProjAct": ["NON", "RELU", "TANH"],
+               "readMemAttType": ["MUL", "BL", "ADD"], "readCtrlAttType": ["MUL", "BL", "ADD"], "readMemAct": ["NON", "RELU", "TANH"],
+               "readCtrlAct": ["NON", "RELU", "TANH"], "writeInputs": ["MEM", "INFO", "SUM", "BOTH"],
+               "writeInfoAct": ["NON", "RELU", "TANH"], "writeSelfAttMod": ["NON", "CONT"], "writeMemAct": ["NON", "RELU", "TANH"],
+               "relu": ["STD", "PRM", "ELU"], "unsharedCells": [None, "1"], "mulBias": ["0", "0.5"], "writeGateBias": ["0", "1.0"],
+               "outClassifierDims": [["8"], ["8", "6"], []]}
+
+
+def random_flags(rnd):
+    flags = []
+    on = 0.85 if rnd.random() < 0.6 else 0.4             # mostly the projecting read structure, so that most graphs build
+    for b in FUZZ_BOOL:
+        pr = on if b in ("readProjInputs", "readMemProj", "readCtrl") else 0.4
+        if rnd.random() < pr:
+            flags.append("--" + b)
+    for k, vals in FUZZ_CHOICE.items():
+        if rnd.random() < 0.5:
+            v = rnd.choice(vals)
+            if v is not None:
+                flags += ["--" + k] + (v if isinstance(v, list) else [v])
+    return flags
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_option_sets_match_the_reference(seed):
+    import random
+    rnd = random.Random(1000 + seed)
+    built = 0
+    for case in range(12):
+        flags = random_flags(rnd)
+        train = rnd.random() < 0.5
+        cfg = rx.parse_flags(None, *(flags + rx.dims_flags(D, P, None if "--outClassifierDims" in flags else HID)))
+        vq, raw, words, lengths, kb, answers = inputs()
+        ref_exc = orc_exc = None
+        try:
+            rx.run_reference(cfg, vq, raw, words, lengths, kb, answerWordsNum=ANS)
+        except Exception as e:          # noqa: BLE001 -- whatever the reference raises is the specification
+            ref_exc = e
+        if ref_exc is None:
+            ref, orc, _ = run_pair(cfg, train)
+            assert_same_forward(ref, orc)
+            assert list(orc["store"].params.keys()) == list(ref["variables"].keys()), flags
+            built += 1
+            continue
+        ocfg = oracle_config_from(cfg)
+        vs = mo.VarStore(generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+        try:
+            c, m, cell = mo.mac_network(ocfg, vs, vq, raw, words, lengths, kb)
+            mo.output_classifier(ocfg, vs, m, vq)
+        except Exception as e:          # noqa: BLE001
+            orc_exc = e
+        assert type(orc_exc) is type(ref_exc), "%s: reference raises %r, oracle %r" % (" ".join(flags), ref_exc, orc_exc)
+    assert built >= 3

@@ -108,6 +108,32 @@ class TFTensor(torch.Tensor):
     def __itruediv__(self, o):
         return self / o
 
+    # TF converts the other operand of a tensor operator with ops.convert_to_tensor, which rejects None with
+    # ValueError("None values not supported.") -- Python / torch would raise TypeError
+    def _none_check(o):
+        if o is None:
+            raise ValueError("None values not supported.")
+
+    def __mul__(self, o):
+        TFTensor._none_check(o)
+        return super().__mul__(o)
+
+    def __rmul__(self, o):
+        TFTensor._none_check(o)
+        return super().__rmul__(o)
+
+    def __add__(self, o):
+        TFTensor._none_check(o)
+        return super().__add__(o)
+
+    def __radd__(self, o):
+        TFTensor._none_check(o)
+        return super().__radd__(o)
+
+    def __sub__(self, o):
+        TFTensor._none_check(o)
+        return super().__sub__(o)
+
     def get_shape(self):          # `inp.get_shape()[-1]` (ops.py:164)
         return tuple(int(s) for s in self.shape)
 
@@ -304,6 +330,8 @@ def reshape(x, new_shape):
 
 
 def concat(values, axis):
+    if any(v is None for v in values):
+        raise ValueError("None values not supported.")          # ops.convert_to_tensor(None)
     return torch.cat([_t(v) for v in values], dim=axis)
 
 
