@@ -159,7 +159,13 @@ FUZZ_CHOICE = {"initCtrl": ["PRM", "ZERO", "Q"], "initMem": ["PRM", "ZERO", "Q"]
 
 @pytest.mark.parametrize("seed", range(6))
 def test_random_option_sets_host_logic(macx, host_generic, seed):
+    run_random_sets(macx, seed)
+
+
+def run_random_sets(macx, seed, dev=None):
+    """dev=None: CPU tensors through the torch kernel stand-ins (host logic); a device: the HIP kernels (tests/test_gpu_generic.py)."""
     import random
+    to = (lambda t: t.to(dev)) if dev is not None else (lambda t: t.clone())
     rnd = random.Random(500 + seed)
     B, S, N, d, p = 3, 6, 8, 128, 3
     built = 0
@@ -184,15 +190,15 @@ def test_random_option_sets_host_logic(macx, host_generic, seed):
         except Exception as e:          # noqa: BLE001 -- the oracle raises what the reference raises (tests/test_reference_exec.py)
             oexc = e
         try:
-            gp = macx.GenericParams()
+            gp = macx.GenericParams(device=dev)
             if params is not None:
                 gp.load_reference_dict(params)
-            vqd, wd, kbd = [t.clone().requires_grad_(True) for t in (vq, words, kb)]
-            cell = macx.GenericMACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=lengths,
+            vqd, wd, kbd = [to(t).requires_grad_(True) for t in (vq, words, kb)]
+            cell = macx.GenericMACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=to(lengths),
                                        knowledgeBase=kbd, memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout,
                                        writeDropout=cfg.writeDropout, batchSize=B, train=train, config=cfg, params=gp, seed=91, b0=1)
             state = cell.run()
-            ((state.memory * dM).sum() + (state.control * dC).sum()).backward()
+            ((state.memory * to(dM)).sum() + (state.control * to(dC)).sum()).backward()
         except Exception as e:          # noqa: BLE001
             pexc = e
         if oexc is not None or pexc is not None:

@@ -150,3 +150,12 @@ def test_generic_path_shards_like_the_full_batch(macx, dev):
         part, _, _ = run_generic(macx, dev, cfg, params, vq[2:], words[2:], lengths[2:], kb[2:], True, 7, 2, False)
         mp = part.run().memory
     assert torch.equal(mf[2:], mp)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_option_sets_on_the_gpu(macx, dev, seed):
+    """48 random option combinations (the generator of tests/test_generic_host.py): where the oracle builds, the HIP kernels
+    of the generic path give its state (<= 2e-5) and every gradient (<= 2e-4); where it raises, the product raises the same class."""
+    from test_generic_host import run_random_sets
+    run_random_sets(macx, seed, dev=dev)
+    torch.cuda.synchronize()
