@@ -84,30 +84,101 @@ def resolve_activations(config):
     return acts
 
 
+def _relu_check(config, act):
+    """What ops.activations[act] raises when it is applied (ops.py:161-187)."""
+    if act != "RELU":
+        return
+    r = get(config, "relu")
+    if r == "LKY":   # config.reluAlpha's flag is commented out (config.py:221)
+        raise AttributeError("'Config' object has no attribute 'reluAlpha'")
+    if r == "SELU":  # accepted by argparse (config.py:220), no branch in ops.relu (ops.py:171-179)
+        raise UnboundLocalError("local variable 'output' referenced before assignment")
+
+
 def reject_like_reference(config):
-    """Raise what the reference raises at graph-build time for broken option values."""
+    """Raise what the reference raises while it builds the graph for these option values (SURVEY appendix B and what running
+    the reference on random combinations added) -- as a DRY RUN of mac_cell.py in the reference's own order, so that a
+    combination with several defects raises the one the reference meets first (tests/test_reference_exec.py)."""
     g = lambda n: get(config, n)
+    none = lambda: ValueError("None values not supported.")          # ops.convert_to_tensor(None): tf.concat / tensor * None
+    # ---- zero_state (mac_cell.py:539-592)
     if g("initKBwithQ") != "NON":          # mac_cell.py:564 passes expandY=, ops.concat takes extendY (ops.py:65)
         raise TypeError("concat() got an unexpected keyword argument 'expandY'")
     if g("addNullWord"):                   # mac_cell.py:519,573-574
         raise UnboundLocalError("local variable 'questionLengths' referenced before assignment")
-    if g("readMemAttType") == "DIAG" or (g("readCtrl") and g("readCtrlAttType") == "DIAG"):   # ops.py:704-707
-        raise UnboundLocalError("local variable 'output' referenced before assignment")
-    if g("readMemConcatProj") and not g("readProjInputs"):          # ops.py:691,716 (evaluated whether or not concat["x"] is set)
+    # ---- step 0: control input and control unit (mac_cell.py:442-451, 133-187)
+    _relu_check(config, g("controlInputAct"))
+    if g("controlFeedPrev"):
+        _relu_check(config, g("controlContAct"))
+    if g("controlProj"):
+        _relu_check(config, g("controlProjAct"))
+    # ---- read unit (mac_cell.py:209-277)
+    mem, att, ctrl = g("memDim"), g("attDim"), g("ctrlDim")
+    proj = bool(g("readProjInputs"))
+    dim = att if proj else mem
+    inter = dim
+    if g("readMemConcatProj") and not proj:          # ops.py:716 (evaluated whether or not concat["x"] is set)
         raise UnboundLocalError("local variable 'projVals' referenced before assignment")
-    if g("readCtrl") and g("readProjInputs") and g("attDim") != g("ctrlDim"):                  # mac_cell.py:245-246
-        raise NameError("name 'ctrlDim' is not defined")
-    if g("writeGate") and g("writeGateShared"):   # [B,d] * [B] does not broadcast (ops.py:317, mac_cell.py:367)
+    if g("readMemAttType") == "DIAG":                # ops.py:704-707: the DIAG branch assigns `activations`, not `output`
+        raise UnboundLocalError("local variable 'output' referenced before assignment")
+    if g("readMemConcatKB"):
+        inter += att if g("readMemConcatProj") else mem
+    if g("readMemProj"):
+        _relu_check(config, g("readMemAct"))
+    else:
+        dim = inter
+    width = dim
+    if g("readCtrl"):
+        if ctrl != dim:                              # mac_cell.py:245-246 references an undefined `ctrlDim`
+            raise NameError("name 'ctrlDim' is not defined")
+        if g("readCtrlAttType") == "DIAG":
+            raise UnboundLocalError("local variable 'output' referenced before assignment")
+        if g("readCtrlConcatInter"):
+            width = 2 * dim                          # ops.mul returns the wider tensor, mac_cell.py:248-250 keeps `dim`
+        if g("readCtrlConcatKB"):
+            if g("readCtrlConcatProj") and not proj:
+                raise none()                         # mac_cell.py:252-258: tf.concat([interactions, projectedKB = None])
+            added = att if g("readCtrlConcatProj") else mem
+            width, dim = width + added, dim + added
+        _relu_check(config, g("readCtrlAct"))
+    if width != dim:                                 # inter2att builds a [dim] weight for a wider tensor
         raise ValueError("Dimensions must be equal")
-    if g("readCtrl") and g("readCtrlConcatKB") and g("readCtrlConcatProj") and not g("readProjInputs") and not g("readCtrlConcatInter"):
-        # mac_cell.py:252-258: tf.concat([interactions, projectedKB]) with projectedKB = None (ops.convert_to_tensor(None))
-        raise ValueError("None values not supported.")
-    if g("readCtrl") and g("readCtrlConcatInter"):
-        # mac_cell.py:248-250 drops the width ops.mul returns: inter2att builds a [dim] weight for a [.., 2 dim] tensor
-        raise ValueError("Dimensions must be equal")
-    if g("readSmryKBProj") and not g("readProjInputs"):
-        # mac_cell.py:271-272: att2Smry(attention, None) -> tensor * None (ops.py:150)
-        raise ValueError("None values not supported.")
+    if g("readSmryKBProj") and not proj:             # mac_cell.py:271-275: att2Smry(attention, None) -> tensor * None
+        raise none()
+    # ---- write unit (mac_cell.py:305-375); widths as TF's shape inference sees them
+    dims = lambda: ValueError("Dimensions must be equal")
+    iw = att if (g("readSmryKBProj") and proj) else mem          # the summary of the PROJECTED knowledge base is attDim wide
+    if g("writeInfoProj"):
+        if iw != mem:
+            raise dims()
+    _relu_check(config, g("writeInfoAct"))
+    nw = dim = mem
+    if g("writeInputs") == "INFO":
+        nw = iw
+    elif g("writeInputs") == "SUM":
+        if iw != mem:
+            raise dims()
+    elif g("writeInputs") == "BOTH":
+        if g("writeConcatMul") and iw != mem:
+            raise dims()
+        nw, dim = (2 * mem + iw, 3 * mem) if g("writeConcatMul") else (mem + iw, 2 * mem)
+    if g("writeSelfAtt"):
+        nw, dim = nw + mem, dim + mem
+    if g("writeMergeCtrl"):
+        nw, dim = nw + ctrl, dim + mem
+    if g("writeMemProj") or dim != mem:
+        if nw != dim:
+            raise dims()
+        nw = mem
+    _relu_check(config, g("writeMemAct"))
+    if g("writeGate"):
+        if g("writeGateShared"):      # [B,d] * [B] does not broadcast (ops.py:317, mac_cell.py:367)
+            raise dims()
+        if nw != mem:
+            raise dims()
+    if nw != mem and int(g("netLength")) > 1:            # the next step multiplies / projects a memory of the wrong width
+        raise dims()
+    # ---- step 1
     if g("relu") == "PRM" and g("controlInputAct") == "RELU" and int(g("netLength")) > 1:
         # mac_cell.py:445 applies the activation in the cell's own scope (reuse=None, mac_cell.py:422): step 1 creates
         # MACCell/prelu/alpha a second time

@@ -31,3 +31,87 @@ def test_split_and_native_kernels_agree_on_random_shapes(macx, dev):
                         assert float((a[k] - b[k]).abs().max()) / den < 2e-4, (mode, case, name, B, S, N, d, p, train, k)
     finally:
         macx._lib.lib().macx_gemm_mode(default_gemm_mode())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MACX_FUZZ_SEEDS", "6"))))      # more seeds for a bug hunt
+def test_fused_cell_matches_the_oracle_on_random_shapes_and_options(macx, dev, seed):
+    """The fused kernels against the fp64 oracle -- final state, every parameter gradient, dKB / dwords / dvecQ -- on random
+    draws from the option surface they cover (flag file, initial states, activations, gate / self-attention / recurrent
+    control switches, variational or plain memory dropout, any keep values) and random shapes (odd batches, N from one
+    cell to beyond a row tile, d in {128, 256}, 1-5 steps)."""
+    import torch
+    from helpers import make_case, oracle_run, rel_err
+    from test_gpu_cell import build_cell, FWD_TOL, GRAD_TOL
+    rnd = random.Random(7000 + seed)
+    ran = 0
+    for case in range(6):
+        name = rnd.choice(["args", "args1", "args3", "args4"])
+        over = {}
+        if rnd.random() < 0.5:
+            over["initCtrl"] = rnd.choice(["PRM", "ZERO", "Q"])
+        if rnd.random() < 0.5:
+            over["initMem"] = rnd.choice(["PRM", "ZERO", "Q"])
+        if rnd.random() < 0.4:
+            over["controlInputUnshared"] = rnd.random() < 0.5
+        if rnd.random() < 0.4:
+            over["controlInputAct"] = rnd.choice(["NON", "RELU", "TANH"])
+        if rnd.random() < 0.5:
+            over["relu"] = rnd.choice(["STD", "ELU"])
+        if rnd.random() < 0.4:
+            over["readMemAct"] = rnd.choice(["RELU", "TANH"])
+        if rnd.random() < 0.4:
+            over["readCtrlAct"] = rnd.choice(["NON", "RELU", "TANH"])
+        if rnd.random() < 0.4:
+            over["writeMemAct"] = rnd.choice(["NON", "RELU", "TANH"])
+        if rnd.random() < 0.3:
+            over["writeGate"] = True
+            over["writeGateBias"] = rnd.choice([0.0, 1.0, -0.5])
+        if rnd.random() < 0.3:
+            over["writeSelfAtt"] = True
+            over["writeSelfAttMod"] = rnd.choice(["NON", "CONT"])
+        if rnd.random() < 0.3:
+            over["memoryVariationalDropout"] = rnd.random() < 0.5
+        over["memoryDropout"] = rnd.choice([1.0, 0.85, 0.6])
+        over["readDropout"] = rnd.choice([1.0, 0.85, 0.5])
+        over["writeDropout"] = rnd.choice([1.0, 1.0, 0.9])
+        B = rnd.choice([1, 2, 3, 5, 9]); S = rnd.randint(3, 14)
+        N = rnd.choice([1, 7, 30, 49, 100, 196, 209]); d = rnd.choice([128, 128, 256]); p = rnd.randint(1, 5)
+        train = rnd.random() < 0.7
+        cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p, **over)
+        try:
+            macx.options.freeze(cfg)
+        except macx.UnsupportedOptions:
+            continue                                      # (lands on the generic path: tests/test_gpu_generic.py)
+        cell, params, (vqd, wd, kbd) = build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=5 + case, requires_grad=True)
+        assert type(cell) is macx.MACCell
+        g = torch.Generator().manual_seed(9)
+        dmem, dctl = torch.randn(B, d, generator=g) / B, torch.randn(B, d, generator=g) / B
+        state = cell.run()
+        ((state.memory * dmem.to(dev)).sum() + (state.control * dctl.to(dev)).sum()).backward()
+        torch.cuda.synchronize()
+        ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=train, seed=5 + case, need_grad=True,
+                         d_memory=dmem, d_control=dctl)
+        what = (seed, case, name, over, B, S, N, d, p, train)
+        assert rel_err(state.memory, ref["memory"]) < FWD_TOL and rel_err(state.control, ref["control"]) < FWD_TOL, what
+        rvq, rwords, rkb = ref["inputs"]
+        for got, want, nm in ((vqd, rvq, "vecQ"), (wd, rwords, "words"), (kbd, rkb, "kb")):
+            if want.grad is not None and float(want.grad.abs().max()) > 1e-9:
+                assert rel_err(got.grad, want.grad) < GRAD_TOL, (what, nm)
+        names = macx.params.reference_names(cfg, p)
+        for f in params.fields:
+            gt = getattr(params, f).grad
+            for refname, idx in names[f]:
+                rg = ref["params"][refname].grad
+                got = gt if idx is None else gt[idx]
+                if rg is None:
+                    assert float(got.abs().max()) == 0.0, (what, refname)
+                    continue
+                if float(rg.abs().max()) < 1e-9:
+                    # analytically zero (a bias that shifts every logit of a softmax alike, e.g. memKbProj_2's under
+                    # readCtrlAct = NON): the fp64 oracle leaves 1e-18, fp32 kernels 1e-9 -- compare absolutely
+                    assert float(got.abs().max()) < 1e-6, (what, refname)
+                    continue
+                floor = 5e-2 if refname.endswith("linearLayerlogits/biases/bias") else 1e-6
+                assert rel_err(got.reshape(rg.shape), rg, floor=floor) < GRAD_TOL, (what, refname)
+        ran += 1
+    assert ran >= 3

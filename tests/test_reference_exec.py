@@ -10,6 +10,8 @@ tests/test_reference_golden.py checks the oracle against the vectors this machin
 (tests/golden/reference_*.npz, tests/golden/make_reference_golden.py).
 """
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -85,7 +87,10 @@ def assert_same_forward(ref, orc, tol=1e-12):
             close(a, b, "attentions[%s][%d]" % (key, i))
     close(orc["logits"], ref["logits"], "logits")
     close(orc["loss"], ref["loss"], "loss")
-    assert torch.equal(orc["preds"].long(), torch.as_tensor(ref["preds"]).long()), "predicted answers"
+    # (rows whose two largest logits tie to round-off -- e.g. a memory that batch norm turned into zeros -- have no defined argmax)
+    top2 = torch.topk(torch.as_tensor(ref["logits"]).detach().double(), 2, dim=-1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 1e-9
+    assert torch.equal(orc["preds"].long()[decided], torch.as_tensor(ref["preds"]).long()[decided]), "predicted answers"
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -319,7 +324,8 @@ FUZZ_CHOICE = {"initCtrl": ["PRM", "ZERO", "Q"], "initMem": ["PRM", "ZERO", "Q"]
                "readCtrlAct": ["NON", "RELU", "TANH"], "writeInputs": ["MEM", "INFO", "SUM", "BOTH"],
                "writeInfoAct": ["NON", "RELU", "TANH"], "writeSelfAttMod": ["NON", "CONT"], "writeMemAct": ["NON", "RELU", "TANH"],
                "relu": ["STD", "PRM", "ELU"], "unsharedCells": [None, "1"], "mulBias": ["0", "0.5"], "writeGateBias": ["0", "1.0"],
-               "outClassifierDims": [["8"], ["8", "6"], []]}
+               "outClassifierDims": [["8"], ["8", "6"], []], "attDim": [None, None, "32"]}          # attDim != memDim = 16
+FUZZ_RARE = {"readMemAttType": "DIAG", "readCtrlAttType": "DIAG", "relu": "LKY", "initKBwithQ": "CNCT"}      # values that raise
 
 
 def random_flags(rnd):
@@ -334,6 +340,12 @@ def random_flags(rnd):
             v = rnd.choice(vals)
             if v is not None:
                 flags += ["--" + k] + (v if isinstance(v, list) else [v])
+    for k, v in FUZZ_RARE.items():
+        if rnd.random() < 0.04:
+            flags += ["--" + k, v]
+    for b in ("readCtrlConcatInter", "writeGateShared", "addNullWord"):
+        if rnd.random() < 0.04:
+            flags.append("--" + b)
     return flags
 
 
@@ -342,10 +354,10 @@ def test_random_option_sets_match_the_reference(seed):
     import random
     rnd = random.Random(1000 + seed)
     built = 0
-    for case in range(12):
+    for case in range(int(os.environ.get("MACX_FUZZ_CASES", "14"))):
         flags = random_flags(rnd)
         train = rnd.random() < 0.5
-        cfg = rx.parse_flags(None, *(flags + rx.dims_flags(D, P, None if "--outClassifierDims" in flags else HID)))
+        cfg = rx.parse_flags(None, *(rx.dims_flags(D, P, None if "--outClassifierDims" in flags else HID) + flags))
         vq, raw, words, lengths, kb, answers = inputs()
         ref_exc = orc_exc = None
         try:
@@ -354,7 +366,7 @@ def test_random_option_sets_match_the_reference(seed):
             ref_exc = e
         if ref_exc is None:
             ref, orc, _ = run_pair(cfg, train)
-            assert_same_forward(ref, orc)
+            assert_same_forward(ref, orc, tol=1e-10)      # (batch norm over 3 questions amplifies fp64 round-off past 1e-12)
             assert list(orc["store"].params.keys()) == list(ref["variables"].keys()), flags
             built += 1
             continue
@@ -366,4 +378,4 @@ def test_random_option_sets_match_the_reference(seed):
         except Exception as e:          # noqa: BLE001
             orc_exc = e
         assert type(orc_exc) is type(ref_exc), "%s: reference raises %r, oracle %r" % (" ".join(flags), ref_exc, orc_exc)
-    assert built >= 3
+    assert built >= 1

@@ -144,7 +144,9 @@ class TFTensor(torch.Tensor):
             return super().__torch_function__(func, types, args, kwargs or {})
         except RuntimeError as e:
             msg = str(e)
-            if "must match the size" in msg or "cannot be multiplied" in msg or "Sizes of tensors must match" in msg:
+            if any(t in msg for t in ("must match the size", "cannot be multiplied", "Sizes of tensors must match",
+                                      "is invalid for input of size", "must match except in dimension")):
+                # (tf.reshape to a fully specified shape with another element count is a graph-build ValueError too)
                 raise ValueError("Dimensions must be equal (shape inference): " + msg) from None
             raise
 
