@@ -1,5 +1,6 @@
 """GPU box: one fused-cell configuration against the fp64 oracle in each kernel family -- per-tensor relative errors.
-python tools/case_probe.py name B S N d p train seed key=value ...   (tests-only helper: imports the oracle)"""
+python tests/case_probe.py name B S N d p train seed key=value ...   (test infrastructure: it uses the oracle, so it lives
+under tests/)"""
 import ast
 import os
 import sys
@@ -8,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import macx  # noqa: E402
 from helpers import make_case, oracle_run, rel_err  # noqa: E402
 from test_gpu_cell import build_cell  # noqa: E402

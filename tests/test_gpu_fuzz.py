@@ -94,7 +94,7 @@ def test_fused_cell_matches_the_oracle_on_random_shapes_and_options(macx, dev, s
         what = (seed, case, name, over, B, S, N, d, p, train)
         # plain ReLU has a derivative jump at 0: a pre-activation within round-off of zero lands on the other side in fp32 than
         # in the fp64 oracle and moves ONE (row, column) of dI1 by its whole contribution -- dW1 / db1 / dWx / dKB then differ
-        # at ~5e-4 of their largest entry (tools/case_probe.py: seen identically in the H2 and the split family, absent in the
+        # at ~5e-4 of their largest entry (tests/case_probe.py: seen identically in the H2 and the split family, absent in the
         # native one and for ELU in all three).  Gradients under --relu STD get a tolerance that admits a flipped element.
         gtol = GRAD_TOL * (25.0 if cfg.relu == "STD" else 1.0)
         assert rel_err(state.memory, ref["memory"]) < FWD_TOL and rel_err(state.control, ref["control"]) < FWD_TOL, what
