@@ -154,3 +154,19 @@ def replay_mask_fn(draws, keeps, output_keep=1.0):
     fn.rest = rest
     fn.left = lambda: len(q)
     return fn
+
+
+def run_reference_stem(cfg, images_nhwc, keep=1.0, seed=0, dtype=torch.float64, need_grad=False, draws=None, out_dim=None):
+    """MACnet.stem (model.py:165-204) exactly as the reference builds it: ops.CNNLayer -> ops.cnn (ops.py:380-438).
+    images_nhwc [B,H,W,C] (the graph's layout after model.py:67-68).  Returns dict(kb [B,H*W,outDim], variables, draws, images)."""
+    M = load()
+    tf, model = M["tf"], M["model"]
+    tf.shim_reset(dtype=dtype, seed=seed, require_grad=need_grad)
+    if draws is not None:
+        q = list(draws)
+        tf.state.uniform_hook = lambda shape: _pop(q, shape)
+    B, H, W, C = images_nhwc.shape
+    img = tf.wrap(images_nhwc.detach().to(dtype).clone()).requires_grad_(need_grad)
+    fake = SimpleNamespace(dropouts={"stem": keep}, batchSize=B, H=H, W=W, batchNorm=None)
+    kb = model.MACnet.stem(fake, img, C, out_dim if out_dim is not None else cfg.memDim)
+    return dict(kb=kb, variables=dict(tf.state.variables), draws=[u for _, u in tf.state.draws], images=img)

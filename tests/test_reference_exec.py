@@ -379,3 +379,39 @@ def test_random_option_sets_match_the_reference(seed):
             orc_exc = e
         assert type(orc_exc) is type(ref_exc), "%s: reference raises %r, oracle %r" % (" ".join(flags), ref_exc, orc_exc)
     assert built >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the stem: the reference's own MACnet.stem / ops.CNNLayer / ops.cnn against the oracle's stem_cnn
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("relu", ["ELU", "STD"])
+def test_oracle_stem_reproduces_the_reference(train, relu):
+    Bs, H, W, C, stem_dim, out_dim = 2, 4, 3, 10, 12, D
+    cfg = rx.parse_flags(None, *(rx.dims_flags(D, P, HID) + ["--stemDim", str(stem_dim), "--relu", relu]))
+    g = torch.Generator().manual_seed(5)
+    images = torch.randn(Bs, H, W, C, generator=g, dtype=torch.float64)
+    keep = cfg.stemDropout if train else 1.0
+    assert 0.0 < cfg.stemDropout < 1.0
+    ref = rx.run_reference_stem(cfg, images, keep=keep, need_grad=True)
+    assert list(ref["variables"]) == ["stem/cnnLayercnn_0/kernels/kernel", "stem/cnnLayercnn_0/biases/bias",
+                                      "stem/cnnLayercnn_1/kernels/kernel", "stem/cnnLayercnn_1/biases/bias"]
+    assert tuple(ref["variables"]["stem/cnnLayercnn_0/kernels/kernel"].shape) == (3, 3, C, stem_dim)          # HWIO
+    assert tuple(ref["kb"].shape) == (Bs, H * W, out_dim)
+    ocfg = mo.default_config(memDim=out_dim, relu=relu)
+    ocfg.stemDim = stem_dim
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in ref["variables"].items()}
+    vs = mo.VarStore(params=params, dtype=torch.float64)
+    masks = None
+    if train:       # tf.nn.dropout draws once per layer input, in layer order
+        assert [tuple(u.shape) for u in ref["draws"]] == [(Bs, H, W, C), (Bs, H, W, stem_dim)]
+        masks = [torch.floor(keep + u).reshape(Bs, H * W, -1) for u in ref["draws"]]
+    img = images.clone().requires_grad_(True)
+    kb = mo.stem_cnn(ocfg, vs, img.reshape(Bs, H * W, C), H, W, keep=keep, masks=masks)
+    assert float((kb - ref["kb"]).abs().max()) <= 1e-12
+    w = torch.randn(kb.shape, generator=g, dtype=torch.float64)
+    (kb * w).sum().backward()
+    (ref["kb"] * w).sum().backward()
+    assert float((img.grad - ref["images"].grad).abs().max()) <= 1e-12
+    for k, v in ref["variables"].items():
+        assert float((params[k].grad - v.grad).abs().max()) <= 1e-12 * max(1.0, float(v.grad.abs().max())), k
