@@ -170,3 +170,20 @@ def run_reference_stem(cfg, images_nhwc, keep=1.0, seed=0, dtype=torch.float64, 
     fake = SimpleNamespace(dropouts={"stem": keep}, batchSize=B, H=H, W=W, batchNorm=None)
     kb = model.MACnet.stem(fake, img, C, out_dim if out_dim is not None else cfg.memDim)
     return dict(kb=kb, variables=dict(tf.state.variables), draws=[u for _, u in tf.state.draws], images=img)
+
+
+def run_reference_encoder(cfg, questions, lengths, emb, keep_input=1.0, keep_question=1.0, seed=0, dtype=torch.float64,
+                          need_grad=False, draws=None):
+    """qEmbeddingsOp (model.py:207-219) + encoder (model.py:279-307 -> ops.RNNLayer / biRNNLayer, ops.py:859-950) as the
+    reference builds them; the recurrent cell and tf.nn.bidirectional_dynamic_rnn are the shim's restatement of TF's.
+    Returns dict(words [B,S,encDim], vecQ [B,encDim], variables, draws)."""
+    M = load()
+    tf, model = M["tf"], M["model"]
+    tf.shim_reset(dtype=dtype, seed=seed, require_grad=need_grad)
+    if draws is not None:
+        q = list(draws)
+        tf.state.uniform_hook = lambda shape: _pop(q, shape)
+    fake = SimpleNamespace(dropouts={"encInput": keep_input, "question": keep_question, "stateInput": 1.0}, batchSize=questions.shape[0])
+    qs, _ = model.MACnet.qEmbeddingsOp(fake, tf.wrap(questions.clone()), emb.detach().to(dtype).clone())
+    words, vecQ = model.MACnet.encoder(fake, qs, tf.wrap(lengths.clone()))
+    return dict(words=words, vecQ=vecQ, variables=dict(tf.state.variables), draws=[u for _, u in tf.state.draws])

@@ -415,3 +415,40 @@ def test_oracle_stem_reproduces_the_reference(train, relu):
     assert float((img.grad - ref["images"].grad).abs().max()) <= 1e-12
     for k, v in ref["variables"].items():
         assert float((params[k].grad - v.grad).abs().max()) <= 1e-12 * max(1.0, float(v.grad.abs().max())), k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the question encoder: the reference's qEmbeddingsOp + encoder / ops.RNNLayer / ops.biRNNLayer -- scopes,
+# variable names, the input dropout, which final state is kept, the concat order -- against the oracle's question_encoder
+# (the cell and the dynamic-rnn loop are the shim's restatement of TF's; the oracle's LSTM is also pinned to torch.nn.LSTM)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("train", [False, True])
+def test_oracle_encoder_reproduces_the_reference(train):
+    Bq, Sq, vocab, E, enc = 4, 6, 9, 5, 8
+    cfg = rx.parse_flags(None, *(rx.dims_flags(D, P, HID) + ["--encDim", str(enc), "--wrdEmbDim", str(E), "--encBi"]))
+    g = torch.Generator().manual_seed(3)
+    lengths = torch.tensor([6, 1, 4, 3], dtype=torch.int32)
+    questions = torch.randint(1, vocab + 1, (Bq, Sq), generator=g)
+    questions = questions * (torch.arange(Sq).unsqueeze(0) < lengths.unsqueeze(1))          # 0 = pad
+    emb = torch.randn(vocab, E, generator=g, dtype=torch.float64)
+    ki, kq = (cfg.encInputDropout, cfg.qDropout) if train else (1.0, 1.0)
+    ref = rx.run_reference_encoder(cfg, questions, lengths, emb, keep_input=ki, keep_question=kq, need_grad=True)
+    assert list(ref["variables"]) == ["qEmbeddings/emb", "encoder/birnnLayer/bidirectional_rnn/fw/basic_lstm_cell/kernel",
+                                      "encoder/birnnLayer/bidirectional_rnn/fw/basic_lstm_cell/bias",
+                                      "encoder/birnnLayer/bidirectional_rnn/bw/basic_lstm_cell/kernel",
+                                      "encoder/birnnLayer/bidirectional_rnn/bw/basic_lstm_cell/bias"]
+    ocfg = mo.default_config(encDim=enc, wrdEmbDim=E)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in ref["variables"].items()}
+    vs = mo.VarStore(params=params, dtype=torch.float64)
+    masks = None
+    if train:
+        assert [tuple(u.shape) for u in ref["draws"]] == [(Bq, Sq, E), (Bq, enc)]
+        masks = [torch.floor(ki + ref["draws"][0]), torch.floor(kq + ref["draws"][1])]
+    words, vecQ = mo.question_encoder(ocfg, vs, questions, lengths, vocab, keep_input=ki, keep_question=kq, masks=masks)
+    assert float((words - ref["words"]).abs().max()) <= 1e-12 and float((vecQ - ref["vecQ"]).abs().max()) <= 1e-12
+    w1 = torch.randn(words.shape, generator=g, dtype=torch.float64)
+    w2 = torch.randn(vecQ.shape, generator=g, dtype=torch.float64)
+    ((words * w1).sum() + (vecQ * w2).sum()).backward()
+    ((ref["words"] * w1).sum() + (ref["vecQ"] * w2).sum()).backward()
+    for k, v in ref["variables"].items():
+        assert float((params[k].grad - v.grad).abs().max()) <= 1e-12 * max(1.0, float(v.grad.abs().max())), k

@@ -277,6 +277,8 @@ def get_variable(name, shape=None, initializer=None, dtype=None, trainable=True,
         raise ValueError("Variable %s already exists, disallowed. Did you mean to set reuse=True in VarScope?" % full)
     if isinstance(shape, int):
         shape = (shape,)
+    if shape is None and isinstance(initializer, torch.Tensor):
+        shape = tuple(initializer.shape)          # tf.get_variable(name, initializer=<tensor>): the tensor gives the shape
     shape = tuple(_ints(shape if shape is not None else ()))
     if full in state.preset:
         v = torch.as_tensor(state.preset[full]).to(state.dtype).clone()
@@ -574,9 +576,87 @@ class LSTMStateTuple(tuple):
     h = property(lambda self: self[1])
 
 
+class BasicLSTMCell(RNNCell):
+    """tf.nn.rnn_cell.BasicLSTMCell (rnn_cell_impl.py): variables `kernel` [in + n, 4 n] (get_variable's default glorot
+    initialiser) and `bias` [4 n] (zeros) under <scope of the first call>/basic_lstm_cell; gates i, j, f, o =
+    split([x, h] kernel + bias); c' = c sigmoid(f + forget_bias) + sigmoid(i) act(j); h' = act(c') sigmoid(o)."""
+
+    def __init__(self, num_units, forget_bias=1.0, state_is_tuple=True, activation=None, reuse=None, name=None):
+        self._n, self._fb, self._act, self._reuse = int(num_units), float(forget_bias), activation or torch.tanh, reuse
+        self._vars = None
+
+    state_size = property(lambda self: LSTMStateTuple(self._n, self._n))
+    output_size = property(lambda self: self._n)
+
+    def zero_state(self, batch_size, dtype):
+        b = int(batch_size)
+        return LSTMStateTuple(_w(torch.zeros((b, self._n), dtype=state.dtype)), _w(torch.zeros((b, self._n), dtype=state.dtype)))
+
+    def __call__(self, inputs, st, scope=None):
+        c, h = st
+        if self._vars is None:          # Layer.__call__: the variables are built once, in the scope of the first call
+            with variable_scope(scope or "basic_lstm_cell", reuse=self._reuse):
+                kernel = get_variable("kernel", (int(inputs.shape[-1]) + self._n, 4 * self._n))
+                bias = get_variable("bias", (4 * self._n,), zeros_initializer())
+            self._vars = (kernel, bias)
+        kernel, bias = self._vars
+        z = torch.cat([inputs, h], dim=1) @ kernel + bias
+        i, j, f, o = torch.split(z, self._n, dim=1)
+        new_c = c * torch.sigmoid(f + self._fb) + torch.sigmoid(i) * self._act(j)
+        new_h = self._act(new_c) * torch.sigmoid(o)
+        return new_h, LSTMStateTuple(new_c, new_h)
+
+
+def reverse_sequence(x, seq_lengths, seq_axis=1, batch_axis=0, seq_dim=None, batch_dim=None):
+    """array_ops.reverse_sequence: the first seq_lengths[b] positions of row b reversed, the rest left where they are."""
+    out = x.clone()
+    for b in builtins.range(x.shape[0]):
+        n = int(seq_lengths[b])
+        out[b, :n] = torch.flip(x[b, :n], dims=[0])
+    return _w(out)
+
+
+def _dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, scope=None, **_ignored):
+    """tf.nn.dynamic_rnn: past a sequence's end the output is zero and the state is copied through (rnn._rnn_step)."""
+    B, T = inputs.shape[0], inputs.shape[1]
+    st = initial_state
+    outs = []
+    for t in builtins.range(T):
+        out, new = cell(inputs[:, t], st)
+        if sequence_length is not None:
+            live = (t < torch.as_tensor(sequence_length).reshape(B, 1)).to(out.dtype)
+            out = live * out
+            new = LSTMStateTuple(live * new[0] + (1 - live) * st[0], live * new[1] + (1 - live) * st[1])
+        st = new
+        outs.append(out)
+    return _w(torch.stack(outs, dim=1)), st
+
+
+def _bidirectional_dynamic_rnn(cell_fw, cell_bw, inputs, sequence_length=None, initial_state_fw=None, initial_state_bw=None,
+                               **_ignored):
+    """tf.nn.bidirectional_dynamic_rnn (rnn.py): scopes bidirectional_rnn/{fw,bw}; the backward cell runs over the
+    length-reversed input and its outputs are reversed back."""
+    with variable_scope("bidirectional_rnn"):
+        with variable_scope("fw"):
+            out_fw, st_fw = _dynamic_rnn(cell_fw, inputs, sequence_length, initial_state_fw)
+        rev = reverse_sequence(inputs, sequence_length)
+        with variable_scope("bw"):
+            tmp, st_bw = _dynamic_rnn(cell_bw, rev, sequence_length, initial_state_bw)
+        out_bw = reverse_sequence(tmp, sequence_length)
+    return (out_fw, out_bw), (st_fw, st_bw)
+
+
+def _embedding_lookup(params, ids, **_ignored):
+    return _w(params[torch.as_tensor(ids).long()])
+
+
+nn.dynamic_rnn = _dynamic_rnn
+nn.bidirectional_dynamic_rnn = _bidirectional_dynamic_rnn
+nn.embedding_lookup = _embedding_lookup
 rnn_cell.RNNCell = RNNCell
 rnn_cell.LSTMStateTuple = LSTMStateTuple
-for _n in ("BasicRNNCell", "GRUCell", "BasicLSTMCell", "LSTMCell"):
+rnn_cell.BasicLSTMCell = BasicLSTMCell
+for _n in ("BasicRNNCell", "GRUCell", "LSTMCell"):
     setattr(rnn_cell, _n, type(_n, (RNNCell,), {"__init__": lambda self, *a, **k: (_ for _ in ()).throw(
         NotImplementedError("the TF recurrent cells are outside the MAC-cell path and not shimmed"))}))
 nn.rnn_cell = rnn_cell
