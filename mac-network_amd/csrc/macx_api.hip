@@ -2043,7 +2043,12 @@ EncBwdLayout make_enc_bwd(const macx_enc_shapes* s) {
   L.dG = take(2 * S * B * G); L.dZ = take(2 * B * S * G);
   L.dh = take(2 * B * h); L.dc = take(2 * B * h); L.dh_pass = take(2 * B * h);
   L.dXp = take(B * S * Ep); L.tmpW = take(Ep * G);
-  L.slab = take((size_t)wgrad_splits((int)(B * S), (int)Ep, (int)G) * Ep * G);
+  // split-reduction slabs of the two kernel-gradient contractions (input block [Ep, 4h], recurrent block [h, 4h]): the larger
+  {
+    const size_t in_blk = (size_t)wgrad_splits((int)(B * S), (int)Ep, (int)G) * Ep * G;
+    const size_t rec_blk = (size_t)wgrad_splits((int)(B * S), (int)h, (int)G) * h * G;
+    L.slab = take(in_blk > rec_blk ? in_blk : rec_blk);
+  }
   L.dq = take(B * 2 * h);
   L.total = off;
   return L;

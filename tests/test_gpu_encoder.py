@@ -49,7 +49,10 @@ def run_case(macx, dev, B, S, V, E, h, train, dtype=torch.float64, b0=0, fixed=F
 
 
 @pytest.mark.parametrize("B,S,V,E,h,train", [(3, 5, 11, 20, 128, False), (4, 7, 13, 300, 128, True), (2, 9, 30, 64, 256, True),
-                                             (1, 1, 4, 16, 128, False)])
+                                             (1, 1, 4, 16, 128, False),
+                                             # hidden width above the padded embedding width with more than 64 positions: the
+                                             # recurrent block's split-reduction slabs are the larger ones (found by the fuzz)
+                                             (7, 11, 33, 4, 256, False)])
 def test_encoder_matches_bilstm_oracle(macx, dev, B, S, V, E, h, train):
     enc, words, vecQ, rw, rq, prm, lengths = run_case(macx, dev, B, S, V, E, h, train, b0=2)
     assert rel_err(words, rw) < 1e-5 and rel_err(vecQ, rq) < 1e-5

@@ -120,3 +120,57 @@ def test_fused_cell_matches_the_oracle_on_random_shapes_and_options(macx, dev, s
                 assert rel_err(got.reshape(rg.shape), rg, floor=floor) < gtol, (what, refname)
         ran += 1
     assert ran >= 3
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MACX_FUZZ_SEEDS", "3"))))
+def test_stem_encoder_and_classifier_on_random_shapes(macx, dev, seed):
+    """The three modules around the cell against their oracles on random shapes: odd image grids down to 1 x 2, one image,
+    any multiple-of-128 widths; one-word questions, one question, embedding widths that are not multiples of anything,
+    vocabularies of one word; classifier widths down to 16 and answer counts that are not multiples of anything."""
+    import torch
+    from helpers import rel_err, max_abs
+    import test_gpu_stem as TS
+    import test_gpu_encoder as TE
+    import test_gpu_output as TO
+    from oracle import mac_oracle as mo
+    rnd = random.Random(9000 + seed)
+    for case in range(4):
+        # ---- stem
+        B, H, W = rnd.choice([1, 2, 3, 5]), rnd.randint(1, 9), rnd.randint(2, 9)
+        Cin, Cmid, Cout = [rnd.choice([128, 256, 384]) for _ in range(3)]
+        train = rnd.random() < 0.6
+        stem, kb, ref, prm = TS.run_case(macx, dev, B, H, W, Cin, Cmid, Cout, train, b0=rnd.randint(0, 3))
+        what = ("stem", seed, case, B, H, W, Cin, Cmid, Cout, train)
+        assert rel_err(kb, ref) < 1e-5, what
+        for f, name in macx.stem.REF_NAMES.items():
+            assert rel_err(getattr(stem, f).grad, prm[name].grad, floor=1e-7) < 2e-4, (what, f)
+        # ---- question encoder
+        B, S, V, E, h = rnd.choice([1, 2, 4, 7]), rnd.randint(1, 12), rnd.randint(1, 40), rnd.choice([4, 7, 50, 300]), rnd.choice([128, 256])
+        train = rnd.random() < 0.6
+        enc, words, vecQ, rw, rq, prm, lengths = TE.run_case(macx, dev, B, S, V, E, h, train, b0=rnd.randint(0, 3))
+        what = ("encoder", seed, case, B, S, V, E, h, train)
+        assert rel_err(words, rw) < 1e-5 and rel_err(vecQ, rq) < 1e-5, what
+        for f, name in macx.encoder.REF_NAMES.items():
+            assert rel_err(getattr(enc, f).grad, prm[name].grad, floor=1e-7) < 2e-4, (what, f)
+        # ---- output unit + classifier (fused)
+        B, d, Hd, A = rnd.choice([1, 3, 8, 64]), rnd.choice([64, 128, 256]), rnd.choice([16, 48, 128, 512]), rnd.choice([2, 7, 28, 33])
+        train = rnd.random() < 0.6
+        cfg = mo.flag_file_config("args", memDim=d, ctrlDim=d, attDim=d, outClassifierDims=[Hd], answerWordsNum=A)
+        out = macx.OutputClassifier(cfg, generator=torch.Generator().manual_seed(1)).to(dev)
+        assert type(out) is macx.OutputClassifier
+        g = torch.Generator().manual_seed(2 + case)
+        mem, vq, dl = torch.randn(B, d, generator=g), torch.rand(B, d, generator=g) * 2 - 1, torch.randn(B, A, generator=g)
+        memd, vqd = mem.to(dev).requires_grad_(True), vq.to(dev).requires_grad_(True)
+        b0 = rnd.randint(0, 5)
+        logits = out(memd, vqd, train=train, seed=9, b0=b0)
+        (logits * dl.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        keep = cfg.outputDropout if train else 1.0
+        mr, vr = mem.double().requires_grad_(True), vq.double().requires_grad_(True)
+        refl, prm = TO.oracle_logits(cfg, out.to_reference_dict(), mr, vr, keep, 9, b0=b0, need_grad=True)
+        (refl * dl.double()).sum().backward()
+        what = ("classifier", seed, case, B, d, Hd, A, train)
+        assert max_abs(logits, refl) < 2e-5, what
+        assert rel_err(memd.grad, mr.grad) < 1e-4 and rel_err(vqd.grad, vr.grad) < 1e-4, what
+        for f, name in macx.output.REF_NAMES.items():
+            assert rel_err(getattr(out, f).grad, prm[name].grad, floor=1e-7) < 1e-4, (what, f)
