@@ -49,6 +49,20 @@ def main():
     with h5py.File(os.path.join(HERE, "many_links.h5"), "w") as f:
         for i in range(40):
             f.create_dataset("d%02d" % i, data=np.full((3,), i, dtype=np.float32))
+    # 6. other element types / filters, attributes (ignored by the reader), a user block in front of the superblock
+    with h5py.File(os.path.join(HERE, "types_and_filters.h5"), "w", userblock_size=512) as f:
+        f.create_dataset("f8", data=x.astype(np.float64)[:2])
+        f.create_dataset("f4_be", data=x.astype(">f4")[:2])
+        f.create_dataset("checked", data=x, chunks=(3, 8, 3, 3), fletcher32=True)
+        f.create_dataset("gz_only", data=x, chunks=(7, 4, 3, 3), compression="gzip", compression_opts=9)
+        f.create_dataset("u2", data=np.arange(12, dtype=np.uint16).reshape(3, 4))
+        f["f8"].attrs["note"] = "attributes are skipped"
+        f.attrs["version"] = 3
+    # 7. structures the reader refuses by name: a version-4 (libver latest) chunk index, a compound type
+    with h5py.File(os.path.join(HERE, "refused.h5"), "w", libver="latest") as f:
+        f.create_dataset("chunked_v4", data=x, chunks=(2, 8, 3, 3))
+        f.create_dataset("compound", data=np.zeros(3, dtype=[("a", "<f4"), ("b", "<i4")]))
+        f.create_dataset("ok", data=np.arange(4, dtype=np.float32))
     print("h5py", h5py.__version__, "hdf5", h5py.version.hdf5_version, "->", sorted(os.listdir(HERE)))
 
 

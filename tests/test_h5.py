@@ -92,3 +92,20 @@ def test_feeds_the_stem_layout(h5):
     with h5.File(os.path.join(HERE, "features_like_reference.h5")) as f:
         batch = torch.from_numpy(h5.load_image_batch(f, [1, 2]))
     assert batch.shape == (2, C, H, W) and batch.dtype == torch.float32 and batch.is_contiguous()
+
+
+def test_other_types_filters_user_block_and_named_refusals(h5):
+    x = expected()
+    with h5.File(os.path.join(HERE, "types_and_filters.h5")) as f:          # 512-byte user block in front of the superblock
+        assert sorted(f.keys()) == ["checked", "f4_be", "f8", "gz_only", "u2"]
+        assert np.array_equal(f["checked"][...], x)                         # fletcher32-checked chunks
+        assert np.array_equal(f["gz_only"][...], x)                         # deflate without shuffle
+        assert f["f8"].dtype == np.float64 and np.array_equal(f["f8"][...], x.astype(np.float64)[:2])
+        assert f["f4_be"].dtype == np.dtype(">f4") and np.array_equal(f["f4_be"][...], x[:2])
+        assert np.array_equal(f["u2"][...], np.arange(12, dtype=np.uint16).reshape(3, 4))
+    with h5.File(os.path.join(HERE, "refused.h5")) as f:
+        assert np.array_equal(f["ok"][...], np.arange(4, dtype=np.float32))
+        with pytest.raises(NotImplementedError, match="layout"):            # version-4 chunk index (libver latest)
+            f["chunked_v4"]
+        with pytest.raises(NotImplementedError, match="datatype class 6"):  # compound type
+            f["compound"]
