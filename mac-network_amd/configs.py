@@ -39,8 +39,8 @@ def default_config(**over):
         outQuestion=False, outQuestionMul=False, outClassifierDims=[512], outputDropout=0.85,
         answerWordsNum=28,
         # question encoder (config.py:178-206, 262-270)
-        wrdEmbDim=300, encDim=512, encType="LSTM", encBi=True, encNumLayers=1, encVariationalDropout=False,
-        encProj=False, encInputDropout=0.85, qDropout=0.92, wrdEmbFixed=False,
+        wrdEmbDim=300, encDim=512, encType="LSTM", encBi=False, encNumLayers=1, encVariationalDropout=False,
+        encProj=False, encProjQAct="NON", encInputDropout=0.85, qDropout=0.92, wrdEmbFixed=False,
     )
     for k, v in over.items():
         if not hasattr(c, k):
@@ -49,7 +49,7 @@ def default_config(**over):
     return c
 
 
-_COMMON = dict(memoryVariationalDropout=True, relu="ELU", outQuestion=True, controlContextual=True,
+_COMMON = dict(memoryVariationalDropout=True, relu="ELU", outQuestion=True, controlContextual=True, encBi=True,
                readProjInputs=True, readMemConcatKB=True, readMemConcatProj=True, readMemProj=True,
                readCtrl=True, writeMemProj=True)
 FLAG_FILES = {

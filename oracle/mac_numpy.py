@@ -1,4 +1,5 @@
-"""TEST INFRASTRUCTURE -- not part of the product path.  PARITY UNPINNED (no reference-produced vectors exist).
+"""TEST INFRASTRUCTURE -- not part of the product path.  (Pinned through oracle/mac_oracle.py, which is checked against the
+reference's own code executed on tests/tf1_shim; this file is that oracle's independent cross-check.)
 
 Second, independent restatement of the reference's MAC cell: closed-form numpy fp64 forward for the
 five published flag files (configs/args.txt, args1-4.txt), written from the equations rather than

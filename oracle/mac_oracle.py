@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE -- not part of the product path.  PARITY UNPINNED (see below).
+"""TEST INFRASTRUCTURE -- not part of the product path.  PARITY PINNED to the reference's own code (see below).
 
 Op-for-op CPU restatement (PyTorch, fp32 or fp64) of the reference's MAC cell:
     /root/reference/mac_cell.py   MACCell.control :133-187, read :209-277, write :305-375,
@@ -17,15 +17,24 @@ the [B,N,2d] concat of ops.py:718, the `inp * W` product of ops.py:317, `att * K
 That makes this file both the checker for the HIP path and the "reference CPU path" timed by
 bench.py (`cpu_baseline.kind = "port"`).
 
-PARITY UNPINNED: the reference ships no tests, golden vectors or seeds, and
-TensorFlow 1.x cannot be imported in this environment, so nothing produced by the reference itself
-pins this restatement.  It is made trustworthy by (1) oracle/mac_numpy.py, an independent fp64
-closed-form restatement that must agree to fp32 round-off, (2) finite-difference checks of the
-autograd gradients, (3) hand-worked tiny cases in tests/golden/ -- all generated by us and labelled so.
+PARITY PINNED (since round 2).  The reference ships no tests, golden vectors or seeds and TensorFlow
+1.x cannot be imported here, so the pin is the reference's own code EXECUTED: /root/reference/{config,ops,mac_cell,model}.py
+are imported unmodified on an eager stand-in for the ~60 `tf.*` calls they make (tests/tf1_shim/tensorflow, torch fp64)
+and this file must reproduce them to 1e-12 -- states, attentions, logits, loss, predictions, every gradient, variable names
+and creation order, the random draws in order -- for the five flag files x eval/train, 40 further option sets, ~100 random
+option combinations (raise where the reference raises, with the same class), the stem and the question encoder
+(tests/test_reference_exec.py, tests/ref_exec.py; runs wherever /root/reference exists).  The same reference runs are
+committed as fixtures (tests/golden/reference/*.npz + the script that wrote them) so that the check travels to machines
+without the reference (tests/test_reference_golden.py on CPU, tests/test_gpu_reference_golden.py for the HIP path).
+What the stand-in restates rather than executes: the tf.* primitives themselves (matmul, softmax, dropout's
+x / keep * floor(keep + U), variable scoping incl. default-name uniquification, batch_norm, conv2d, BasicLSTMCell and the
+dynamic-rnn loop) -- each a few lines, checked against torch's own implementations where one exists.  Further
+self-consistency: oracle/mac_numpy.py (independent fp64 closed form), finite differences of the autograd gradients.
 
 Dropout: TF's `x / keep * floor(keep + U)`; the uniform draw is replaced by explicit 0/1 masks handed
 in through `mask_fn(site, step, shape)` (sites in oracle/dropout_hash.py).
 """
+import contextlib
 import math
 from contextlib import contextmanager
 from types import SimpleNamespace
@@ -86,8 +95,8 @@ def default_config(**over):
         outQuestion=False, outQuestionMul=False, outClassifierDims=[512], outputDropout=0.85,
         answerWordsNum=28,
         # question encoder (config.py:178-206, 262-270)
-        wrdEmbDim=300, encDim=512, encType="LSTM", encBi=True, encNumLayers=1, encVariationalDropout=False,
-        encProj=False, encInputDropout=0.85, qDropout=0.92, wrdEmbFixed=False,
+        wrdEmbDim=300, encDim=512, encType="LSTM", encBi=False, encNumLayers=1, encVariationalDropout=False,
+        encProj=False, encProjQAct="NON", encInputDropout=0.85, qDropout=0.92, wrdEmbFixed=False,
     )
     for k, v in over.items():
         if not hasattr(c, k):
@@ -96,7 +105,7 @@ def default_config(**over):
     return c
 
 
-_COMMON = dict(memoryVariationalDropout=True, relu="ELU", outQuestion=True, controlContextual=True,
+_COMMON = dict(memoryVariationalDropout=True, relu="ELU", outQuestion=True, controlContextual=True, encBi=True,
                readProjInputs=True, readMemConcatKB=True, readMemConcatProj=True, readMemProj=True,
                readCtrl=True, writeMemProj=True)
 FLAG_FILES = {
@@ -718,29 +727,45 @@ def stem_cnn(config, store, images, H, W, keep=1.0, masks=None):
     return feats.reshape(B, N, dims[-1])
 
 
+@_tf_shape_errors
 def question_encoder(config, store, questions, lengths, vocab, keep_input=1.0, keep_question=1.0, masks=None):
-    """qEmbeddingsOp (model.py:207-219) + encoder (model.py:279-307) -> ops.RNNLayer / biRNNLayer (ops.py:859-911,
-    938-950) with encType = LSTM, encBi, one layer, no variational dropout, encDim == ctrlDim (no projections).
+    """qEmbeddingsOp (model.py:207-219) + encoder (model.py:279-307) -> ops.RNNLayer -> biRNNLayer / fwRNNLayer (ops.py:798-950)
+    with encType = LSTM and no variational dropout; the output projections of model.py:785-787 (projWords = projQuestion =
+    encDim != ctrlDim or encProj) included.
     questions [B,S] int (0 = pad -> the zero row prepended at model.py:216; id i >= 1 -> emb[i-1]); lengths [B].
-    tf.nn.bidirectional_dynamic_rnn restated: the forward cell runs over positions 0..L-1, the backward cell over the
-    length-reversed question (array_ops.reverse_sequence) and its outputs are reversed back; past a question's end
-    dynamic_rnn emits zeros and copies the state through.  BasicLSTMCell (TF1 rnn_cell_impl): gates i, j, f, o =
-    split([x, h] @ kernel + bias); c' = c * sigmoid(f + 1) + sigmoid(i) * tanh(j); h' = tanh(c') * sigmoid(o).
-    masks: [input mask [B,S,E], question mask [B,2h]] when the keeps are < 1.
-    Returns questionCntxWords [B,S,2h], vecQuestions [B,2h]."""
+    --encBi: tf.nn.bidirectional_dynamic_rnn restated -- BasicLSTMCell(encDim / 2) per direction under
+    encoder/birnnLayer/bidirectional_rnn/{fw,bw}; the backward cell runs over the length-reversed question
+    (array_ops.reverse_sequence) and its outputs are reversed back.  Without it: tf.nn.dynamic_rnn of one BasicLSTMCell(encDim)
+    under encoder/rnnLayer/rnn.  Past a question's end dynamic_rnn emits zeros and copies the state through.
+    BasicLSTMCell (TF1 rnn_cell_impl): gates i, j, f, o = split([x, h] @ kernel + bias); c' = c * sigmoid(f + 1) +
+    sigmoid(i) * tanh(j); h' = tanh(c') * sigmoid(o).
+    masks: [input mask [B,S,E], question mask [B,encDim]] when the keeps are < 1.
+    Returns questionCntxWords [B,S,encDim or ctrlDim], vecQuestions [B,encDim or ctrlDim]."""
     ops = Ops(config, store)
     B, S = questions.shape
-    E, h = config.wrdEmbDim, config.encDim // 2
+    bi = bool(config.encBi)
+    if config.encType != "LSTM" or config.encVariationalDropout:
+        raise NotImplementedError("oracle: encType LSTM without variational dropout only")
+    E, h = config.wrdEmbDim, (config.encDim // 2 if bi else config.encDim)
     dt = store.dtype
     with store.scope("qEmbeddings"):
         emb = store.get("emb", (vocab, E), "normal")     # embInit: random rows (preprocess.py initEmbRandom), any init works here
     table = torch.cat([torch.zeros((1, E), dtype=dt), emb], dim=0)
     x = table[questions.long()]
+    scopes = ("birnnLayer", "bidirectional_rnn") if bi else ("rnnLayer", "rnn")
+    if config.encNumLayers > 1:
+        # model.py:295-298 builds every layer from `questions` under the same scope (RNNLayer's "rnnLayer<name>" scope closes
+        # before the layer is built, ops.py:938-950): the second layer asks for the first one's variables again
+        raise ValueError("Variable encoder/%s/%s/%sbasic_lstm_cell/kernel already exists, disallowed. Did you mean to set "
+                         "reuse=True in VarScope?" % (scopes[0], scopes[1], "fw/" if bi else ""))
     x = ops.dropout(x, keep_input, None if masks is None else masks[0])
     outs, finals = [], []
-    with store.scope("encoder"), store.scope("birnnLayer"), store.scope("bidirectional_rnn"):
-        for direction in ("fw", "bw"):
-            with store.scope(direction), store.scope("basic_lstm_cell"):
+    with store.scope("encoder"), store.scope(scopes[0]), store.scope(scopes[1]):
+        for direction in (("fw", "bw") if bi else ("",)):
+            with contextlib.ExitStack() as es:
+                if direction:
+                    es.enter_context(store.scope(direction))
+                es.enter_context(store.scope("basic_lstm_cell"))
                 kernel = store.get("kernel", (E + h, 4 * h), "xavier")     # glorot_uniform: TF's default for get_variable
                 bias = store.get("bias", (4 * h,), "zeros")
             hs = torch.zeros((B, h), dtype=dt)
@@ -748,7 +773,7 @@ def question_encoder(config, store, questions, lengths, vocab, keep_input=1.0, k
             out = [[None] * S for _ in range(B)]
             for tau in range(S):
                 active = (tau < lengths).to(dt).unsqueeze(1)                                  # [B,1]
-                pos = torch.full((B,), tau, dtype=torch.long) if direction == "fw" else (lengths.long() - 1 - tau).clamp(min=0)
+                pos = torch.full((B,), tau, dtype=torch.long) if direction != "bw" else (lengths.long() - 1 - tau).clamp(min=0)
                 xt = x[torch.arange(B), pos]                                                  # [B,E]
                 z = torch.cat([xt, hs], dim=1) @ kernel + bias
                 i, j, f, o = z.split(h, dim=1)
@@ -765,6 +790,10 @@ def question_encoder(config, store, questions, lengths, vocab, keep_input=1.0, k
     words = torch.cat(outs, dim=-1)
     vecQ = torch.cat(finals, dim=-1)
     vecQ = ops.dropout(vecQ, keep_question, None if masks is None else masks[1])
+    if config.encDim != config.ctrlDim or config.encProj:                  # model.py:785-787, 301-306
+        with store.scope("encoder"):
+            words = ops.linear(words, config.encDim, config.ctrlDim, name="projCW")
+            vecQ = ops.linear(vecQ, config.encDim, config.ctrlDim, act=config.encProjQAct, name="projQ")
     return words, vecQ
 
 

@@ -185,5 +185,6 @@ def run_reference_encoder(cfg, questions, lengths, emb, keep_input=1.0, keep_que
         tf.state.uniform_hook = lambda shape: _pop(q, shape)
     fake = SimpleNamespace(dropouts={"encInput": keep_input, "question": keep_question, "stateInput": 1.0}, batchSize=questions.shape[0])
     qs, _ = model.MACnet.qEmbeddingsOp(fake, tf.wrap(questions.clone()), emb.detach().to(dtype).clone())
-    words, vecQ = model.MACnet.encoder(fake, qs, tf.wrap(lengths.clone()))
+    proj = (cfg.encDim != cfg.ctrlDim) or cfg.encProj                                    # model.py:785-787, as MACnet.build calls it
+    words, vecQ = model.MACnet.encoder(fake, qs, tf.wrap(lengths.clone()), proj, proj, cfg.ctrlDim)
     return dict(words=words, vecQ=vecQ, variables=dict(tf.state.variables), draws=[u for _, u in tf.state.draws])

@@ -1,6 +1,7 @@
 """CPU: the oracle against itself -- two independent restatements, the scalar golden vectors,
-finite differences, and the invariants of SURVEY.md 8c.  (The reference ships no vectors: every
-fixture here is generated in this repo and labelled so; parity is "unpinned" by the reference.)"""
+finite differences, and the invariants of SURVEY.md 8c.  (The reference ships no vectors: every fixture HERE is
+generated in this repo and labelled so.  The pin to the reference itself is tests/test_reference_exec.py -- the reference's
+own code executed on tests/tf1_shim -- and its committed outputs, tests/test_reference_golden.py.)"""
 import glob
 import json
 import os

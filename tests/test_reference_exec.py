@@ -422,10 +422,31 @@ def test_oracle_stem_reproduces_the_reference(train, relu):
 # variable names, the input dropout, which final state is kept, the concat order -- against the oracle's question_encoder
 # (the cell and the dynamic-rnn loop are the shim's restatement of TF's; the oracle's LSTM is also pinned to torch.nn.LSTM)
 # ---------------------------------------------------------------------------------------------------------------
+ENC_VARIANTS = {
+    "bi": ["--encBi"],                                                   # the published flag files
+    "uni": [],                                                           # the parser's default: one forward LSTM(encDim)
+    "bi_proj": ["--encBi", "--encProj", "--encProjQAct", "TANH"],        # projCW / projQ (+ its second layer)
+    "uni_other_width": ["--ctrlDim", "12"],                              # encDim != ctrlDim projects as well (model.py:785)
+}
+
+
+def test_two_encoder_layers_raise_in_the_reference_and_the_oracle():
+    cfg = rx.parse_flags(None, *(rx.dims_flags(D, P, HID) + ["--encDim", "8", "--wrdEmbDim", "5", "--encBi", "--encNumLayers", "2"]))
+    q = torch.tensor([[1, 2, 0], [3, 0, 0]])
+    lengths = torch.tensor([2, 1], dtype=torch.int32)
+    emb = torch.randn(4, 5, dtype=torch.float64)
+    with pytest.raises(ValueError, match="already exists"):
+        rx.run_reference_encoder(cfg, q, lengths, emb)
+    ocfg = mo.default_config(encDim=8, wrdEmbDim=5, encBi=True, encNumLayers=2)
+    with pytest.raises(ValueError, match="already exists"):
+        mo.question_encoder(ocfg, mo.VarStore(generator=torch.Generator().manual_seed(0), dtype=torch.float64), q, lengths, 4)
+
+
+@pytest.mark.parametrize("variant", sorted(ENC_VARIANTS))
 @pytest.mark.parametrize("train", [False, True])
-def test_oracle_encoder_reproduces_the_reference(train):
+def test_oracle_encoder_reproduces_the_reference(train, variant):
     Bq, Sq, vocab, E, enc = 4, 6, 9, 5, 8
-    cfg = rx.parse_flags(None, *(rx.dims_flags(D, P, HID) + ["--encDim", str(enc), "--wrdEmbDim", str(E), "--encBi"]))
+    cfg = rx.parse_flags(None, *(rx.dims_flags(D, P, HID) + ["--encDim", str(enc), "--wrdEmbDim", str(E)] + ENC_VARIANTS[variant]))
     g = torch.Generator().manual_seed(3)
     lengths = torch.tensor([6, 1, 4, 3], dtype=torch.int32)
     questions = torch.randint(1, vocab + 1, (Bq, Sq), generator=g)
@@ -433,11 +454,11 @@ def test_oracle_encoder_reproduces_the_reference(train):
     emb = torch.randn(vocab, E, generator=g, dtype=torch.float64)
     ki, kq = (cfg.encInputDropout, cfg.qDropout) if train else (1.0, 1.0)
     ref = rx.run_reference_encoder(cfg, questions, lengths, emb, keep_input=ki, keep_question=kq, need_grad=True)
-    assert list(ref["variables"]) == ["qEmbeddings/emb", "encoder/birnnLayer/bidirectional_rnn/fw/basic_lstm_cell/kernel",
-                                      "encoder/birnnLayer/bidirectional_rnn/fw/basic_lstm_cell/bias",
-                                      "encoder/birnnLayer/bidirectional_rnn/bw/basic_lstm_cell/kernel",
-                                      "encoder/birnnLayer/bidirectional_rnn/bw/basic_lstm_cell/bias"]
-    ocfg = mo.default_config(encDim=enc, wrdEmbDim=E)
+    bi = "--encBi" in ENC_VARIANTS[variant]
+    cell_vars = (["encoder/birnnLayer/bidirectional_rnn/%s/basic_lstm_cell/%s" % (d_, v_) for d_ in ("fw", "bw") for v_ in ("kernel", "bias")]
+                 if bi else ["encoder/rnnLayer/rnn/basic_lstm_cell/kernel", "encoder/rnnLayer/rnn/basic_lstm_cell/bias"])
+    assert list(ref["variables"])[:1 + len(cell_vars)] == ["qEmbeddings/emb"] + cell_vars
+    ocfg = mo.default_config(encDim=enc, wrdEmbDim=E, encBi=bi, encProj=cfg.encProj, encProjQAct=cfg.encProjQAct, ctrlDim=cfg.ctrlDim)
     params = {k: v.detach().clone().requires_grad_(True) for k, v in ref["variables"].items()}
     vs = mo.VarStore(params=params, dtype=torch.float64)
     masks = None

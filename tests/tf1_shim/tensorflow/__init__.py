@@ -617,7 +617,11 @@ def reverse_sequence(x, seq_lengths, seq_axis=1, batch_axis=0, seq_dim=None, bat
 
 
 def _dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, scope=None, **_ignored):
-    """tf.nn.dynamic_rnn: past a sequence's end the output is zero and the state is copied through (rnn._rnn_step)."""
+    """tf.nn.dynamic_rnn: variables under `scope or "rnn"`; past a sequence's end the output is zero and the state is copied
+    through (rnn._rnn_step)."""
+    if scope is None:
+        with variable_scope("rnn"):
+            return _dynamic_rnn(cell, inputs, sequence_length, initial_state, scope="rnn")
     B, T = inputs.shape[0], inputs.shape[1]
     st = initial_state
     outs = []
@@ -638,10 +642,10 @@ def _bidirectional_dynamic_rnn(cell_fw, cell_bw, inputs, sequence_length=None, i
     length-reversed input and its outputs are reversed back."""
     with variable_scope("bidirectional_rnn"):
         with variable_scope("fw"):
-            out_fw, st_fw = _dynamic_rnn(cell_fw, inputs, sequence_length, initial_state_fw)
+            out_fw, st_fw = _dynamic_rnn(cell_fw, inputs, sequence_length, initial_state_fw, scope="fw")
         rev = reverse_sequence(inputs, sequence_length)
         with variable_scope("bw"):
-            tmp, st_bw = _dynamic_rnn(cell_bw, rev, sequence_length, initial_state_bw)
+            tmp, st_bw = _dynamic_rnn(cell_bw, rev, sequence_length, initial_state_bw, scope="bw")
         out_bw = reverse_sequence(tmp, sequence_length)
     return (out_fw, out_bw), (st_fw, st_bw)
 
