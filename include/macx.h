@@ -415,6 +415,19 @@ int macx_write_bwd(const macx_opts*, const macx_shapes*, const macx_dropout*, co
                    size_t saved_floats, float* ws, size_t ws_floats, const float* d_new_memory, const macx_param_grads*,
                    float* d_memory, float* d_info, float* d_control, void* stream);
 
+/* ---- embedding lookup on its own (model.py:207-219 qEmbeddingsOp + the input dropout of ops.py:812 / :880) --------------
+ *   macx_embed_lookup      x[r][0..E) = dropout(table[ids[r]]), table row 0 = zeros (padding), row i = emb[i - 1]; columns
+ *                          [E, ld) of x are written as zeros.  Dropout site SITE_ENC_INPUT on the stateless stream, element
+ *                          index (first_row + r) * E + c (first_row = b0 * S for a data-parallel shard); keep = 1: none.
+ *   macx_embed_lookup_bwd  d_emb[V][E] (written) = sum over the rows that looked a word up of dropout'(dx[r]); one workgroup
+ *                          per vocabulary row, fixed order, no atomics.
+ * The generic question encoder (mac-network_amd/encoder.py GenericQuestionEncoder) is built from these, macx_linear / macx_wgrad
+ * and the macx_op_* kernels. */
+int macx_embed_lookup(const int32_t* ids, const float* emb, int rows, int E, int ld, float keep, uint32_t seed,
+                      uint32_t first_row, float* x, void* stream);
+int macx_embed_lookup_bwd(const int32_t* ids, const float* dx, int rows, int E, int ld, int V, float keep, uint32_t seed,
+                          uint32_t first_row, float* d_emb, void* stream);
+
 /* ---- the ops.py primitives as single kernels (mac-network_amd/csrc/macx_ops.hip.h) -------------------------------
  * The building blocks of the GENERIC option path (mac-network_amd/generic.py): every legal option combination the fused
  * cell kernels above answer with MACX_EUNSUPPORTED runs as one kernel per reference op -- these, macx_linear / macx_h2_gemm

@@ -9,7 +9,7 @@ from .params import MACCellParams                   # noqa: F401
 from .generic import GenericMACCell, GenericParams  # noqa: F401
 from .output import GenericOutputClassifier, OutputClassifier   # noqa: F401
 from .stem import Stem                              # noqa: F401
-from .encoder import QuestionEncoder                # noqa: F401
+from .encoder import GenericQuestionEncoder, QuestionEncoder   # noqa: F401
 from .model import MACNet, MACNetCore               # noqa: F401
 
 __all__ = ["MACCell", "MACCellTuple", "MACCellParams", "OutputClassifier", "GenericOutputClassifier", "UnsupportedOptions", "freeze"]

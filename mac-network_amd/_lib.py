@@ -113,7 +113,7 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_images_to_nhwc", "macx_gemm_mode", "macx_h2_floats", "macx_h2_from_f32", "macx_h2_to_f32", "macx_h2_gemm",
            "macx_h2_pack_weight", "macx_h2_gemm_planes", "macx_op_act", "macx_op_act_bwd", "macx_op_binary", "macx_op_reduce",
            "macx_op_softmax", "macx_op_softmax_bwd", "macx_op_dropout", "macx_kb_attend_fwd", "macx_kb_attend_bwd",
-           "macx_kb_attend_bwd_ws_floats", "macx_answer_loss", "macx_workspace_bytes", "macx_control_attend_bwd",
+           "macx_kb_attend_bwd_ws_floats", "macx_answer_loss", "macx_workspace_bytes", "macx_embed_lookup", "macx_embed_lookup_bwd", "macx_control_attend_bwd",
            "macx_control_attend_bwd_ws_floats", "macx_read_fwd", "macx_read_bwd",
            "macx_write_fwd", "macx_write_bwd")
 
@@ -214,6 +214,8 @@ def lib():
                                C.c_void_p, C.c_size_t, C.c_void_p]
     L.macx_answer_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     P_, V_ = C.c_void_p, C.c_void_p
+    L.macx_embed_lookup.argtypes = [V_, V_, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, V_, V_]
+    L.macx_embed_lookup_bwd.argtypes = [V_, V_, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, V_, V_]
     L.macx_control_attend_bwd_ws_floats.restype = C.c_size_t
     L.macx_control_attend_bwd_ws_floats.argtypes = [P_]
     L.macx_control_attend_bwd.argtypes = [P_] + [V_] * 6 + [C.c_size_t] + [V_] * 5

@@ -1578,6 +1578,24 @@ int macx_control_attend_bwd(const macx_shapes* s, const float* d_control, const 
   return MACX_OK;
 }
 
+int macx_embed_lookup(const int32_t* ids, const float* emb, int rows, int E, int ld, float keep, uint32_t seed, uint32_t first_row,
+                      float* x, void* stream) {
+  if (!ids || !emb || !x || rows < 1 || E < 1 || ld < E) return MACX_EINVAL;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, ids, emb, rows, E, ld, first_row,
+                     make_drop(keep, seed, SITE_ENC_INPUT, 0), x);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
+int macx_embed_lookup_bwd(const int32_t* ids, const float* dx, int rows, int E, int ld, int V, float keep, uint32_t seed,
+                          uint32_t first_row, float* d_emb, void* stream) {
+  if (!ids || !dx || !d_emb || rows < 1 || E < 1 || ld < E || V < 1) return MACX_EINVAL;
+  hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, dx, rows, E, ld, first_row,
+                     make_drop(keep, seed, SITE_ENC_INPUT, 0), d_emb);
+  CK(hipGetLastError());
+  return MACX_OK;
+}
+
 int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first, size_t n, float* out, void* stream) {
   if (!out) return MACX_EINVAL;
   const DropSpec ds = make_drop(keep, seed, site, step);

@@ -129,6 +129,21 @@ def k_matmul(x, W, b, big):
     return out
 
 
+def k_embed(ids, emb, E, ld, keep, seed, first_row):
+    """rows of the zero-padded embedding table for `ids` [rows] int32, through the input dropout: [rows, ld] (columns >= E zero)."""
+    out = torch.empty((ids.numel(), ld), dtype=torch.float32, device=emb.device)
+    _lib.check(_L().macx_embed_lookup(_p(ids), _p(emb), ids.numel(), E, ld, keep, seed & 0xFFFFFFFF, first_row, _p(out), _st(emb)),
+               "macx_embed_lookup")
+    return out
+
+
+def k_embed_bwd(ids, dx, E, V, keep, seed, first_row):
+    d_emb = torch.empty((V, E), dtype=torch.float32, device=dx.device)
+    _lib.check(_L().macx_embed_lookup_bwd(_p(ids), _p(dx), ids.numel(), E, dx.shape[1], V, keep, seed & 0xFFFFFFFF, first_row,
+                                          _p(d_emb), _st(dx)), "macx_embed_lookup_bwd")
+    return d_emb
+
+
 def k_wgrad(x2, g2):
     """dW [K, n] = x2^T g2 (fixed-order split reduction)."""
     L = _L()
@@ -293,6 +308,26 @@ class _Linear(torch.autograd.Function):
         dW = k_wgrad(x2, g2) if ctx.needs_input_grad[1] else None
         db = k_reduce(R_ROWS, g2, g2.shape[0], 1, n) if ctx.has_b and ctx.needs_input_grad[2] else None
         return dx, dW, db
+
+
+class _Embed(torch.autograd.Function):
+    """tf.nn.embedding_lookup(concat([zeros(1, E), emb]), ids) + tf.nn.dropout (model.py:207-219, ops.py:812/880):
+    macx_embed_lookup forward, macx_embed_lookup_bwd (one workgroup per vocabulary row, fixed order) backward."""
+
+    @staticmethod
+    def forward(ctx, ids, emb, ld, keep, seed, first_row):
+        emb = _dev(emb, "emb")
+        _require_device(ids, "questions")
+        ids = ids.reshape(-1).to(torch.int32).contiguous()
+        ctx.save_for_backward(ids)
+        ctx.meta = (emb.shape[0], emb.shape[1], keep, seed, first_row)
+        return k_embed(ids, emb, emb.shape[1], ld, keep, seed, first_row)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        V, E, keep, seed, first_row = ctx.meta
+        return None, k_embed_bwd(ids, g.contiguous(), E, V, keep, seed, first_row), None, None, None, None
 
 
 # -------------------------------------------------------------------------------------------------------------------

@@ -64,8 +64,25 @@ def _torch_kernels(G):
     def wgrad(x2, g2):
         return x2.t() @ g2
 
+    def embed(ids, emb, E, ld, keep, seed, first_row):
+        table = torch.cat([torch.zeros(1, E), emb], dim=0)
+        x = table[ids.long()]
+        if keep < 1.0:
+            m = torch.as_tensor(dh.keep_mask(seed, 11, 0, keep, first_row * E, x.numel())).reshape(x.shape).to(x.dtype)
+            x = x * np.float32(1.0 / keep) * m
+        return torch.cat([x, torch.zeros(x.shape[0], ld - E)], dim=1)
+
+    def embed_bwd(ids, dx, E, V, keep, seed, first_row):
+        g = dx[:, :E]
+        if keep < 1.0:
+            m = torch.as_tensor(dh.keep_mask(seed, 11, 0, keep, first_row * E, g.numel())).reshape(g.shape).to(g.dtype)
+            g = g * np.float32(1.0 / keep) * m
+        out = torch.zeros(V + 1, E)
+        out.index_add_(0, ids.long(), g)
+        return out[1:]
+
     return dict(k_binary=binary, k_reduce=reduce, k_act=act, k_act_bwd=act_bwd, k_softmax=softmax, k_softmax_bwd=softmax_bwd,
-                k_dropout=dropout, k_matmul=matmul, k_wgrad=wgrad)
+                k_dropout=dropout, k_matmul=matmul, k_wgrad=wgrad, k_embed=embed, k_embed_bwd=embed_bwd)
 
 
 @pytest.fixture

@@ -88,11 +88,14 @@ def test_encoder_shard_draws_full_batch_masks(macx, dev):
 
 
 def test_encoder_rejects_unsupported(macx):
-    for over in (dict(encType="GRU"), dict(encBi=False), dict(encNumLayers=2), dict(encVariationalDropout=True), dict(encProj=True),
-                 dict(encDim=256)):
-        cfg = mo.flag_file_config("args", **over)
+    for over in (dict(encType="GRU"), dict(encVariationalDropout=True)):
         with pytest.raises(macx.UnsupportedOptions):
-            macx.QuestionEncoder(cfg, vocab=10)
+            macx.QuestionEncoder(mo.flag_file_config("args", **over), vocab=10)
+    with pytest.raises(ValueError, match="already exists"):             # what the reference raises for a second layer
+        macx.QuestionEncoder(mo.flag_file_config("args", encNumLayers=2), vocab=10)
+    # LSTM configurations without a fused kernel come back on the generic path
+    for over in (dict(encBi=False), dict(encProj=True), dict(encDim=256)):
+        assert type(macx.QuestionEncoder(mo.flag_file_config("args", **over), vocab=10)) is macx.GenericQuestionEncoder
 
 
 def test_full_tower_ids_to_logits_gradients(macx, dev):
@@ -143,3 +146,15 @@ def test_full_tower_ids_to_logits_gradients(macx, dev):
                 if not e < 3e-4:
                     bad[refname] = e
     assert not bad, bad
+
+
+@pytest.mark.parametrize("variant", ["uni", "uni_projected", "bi_proj_tanh", "uni_proj_prelu", "bi_other_width"])
+@pytest.mark.parametrize("train", [False, True])
+def test_generic_encoder_matches_oracle(macx, dev, variant, train):
+    """macx.QuestionEncoder on the LSTM configurations the fused kernels refuse (no --encBi = the parser's default; projCW /
+    projQ output projections): one HIP kernel per reference op (macx_embed_lookup, macx_linear, macx_op_*, macx_wgrad) against
+    the fp64 oracle with identical dropout masks -- outputs <= 1e-5, every gradient <= 2e-4."""
+    from test_generic_encoder_host import enc_cfg, run_pair, check
+    enc, words, vecQ, prm, lengths = run_pair(macx, enc_cfg(variant), train, dev=dev)
+    torch.cuda.synchronize()
+    check(enc, words, vecQ, prm, lengths, tol=1e-5, gtol=2e-4)
