@@ -121,6 +121,13 @@ class QuestionEncoder(torch.nn.Module):
             for f in _lib.ENC_FIELDS:
                 getattr(self, f).copy_(torch.as_tensor(d[REF_NAMES[f]]))
 
+    def embed(self, questions):
+        """embeddingsOp's `questionWords` (model.py:207-219, 783): the embedded question words [B,S,wrdEmbDim] WITHOUT the encoder's
+        input dropout -- what the cell attends over when --controlContextual is off (mac_cell.py:570)."""
+        from .generic import _Embed
+        B, S = questions.shape
+        return _Embed.apply(questions, self.emb, self.E, 1.0, 0, 0).reshape(B, S, self.E)
+
     def forward(self, questions, lengths, train=False, seed=None, b0=0, check_ids=True):
         """questions [B,S] int32 (0 = pad), lengths [B] int32 -> (questionCntxWords [B,S,2h], vecQuestions [B,2h])."""
         if not questions.is_cuda:
@@ -241,6 +248,15 @@ class GenericQuestionEncoder(torch.nn.Module):
         t = self.params.tensors()
         self.params.device = t[0].device if t else self.params.device
         return out
+
+    def embed(self, questions):
+        """embeddingsOp's `questionWords` (model.py:207-219, 783): the embedded question words [B,S,wrdEmbDim] without the input
+        dropout -- what the cell attends over when --controlContextual is off (mac_cell.py:570)."""
+        from .generic import _Embed
+        B, S = questions.shape
+        with self.params.scope("qEmbeddings"):
+            emb = self.params.get("emb", (self.vocab, self.E), "normal")
+        return _Embed.apply(questions, emb, self.E, 1.0, 0, 0).reshape(B, S, self.E)
 
     def forward(self, questions, lengths, train=False, seed=None, b0=0, check_ids=True):
         """questions [B,S] int (0 = pad), lengths [B] -> (questionCntxWords [B,S,w], vecQuestions [B,w]), w = ctrlDim when projected."""

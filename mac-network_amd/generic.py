@@ -389,6 +389,15 @@ class GenericParams(torch.nn.Module):
             raise ValueError("variable %s has shape %s, expected %s" % (key, tuple(v.shape), shape))
         return v
 
+    def _apply(self, fn, *a, **kw):
+        """.to(device) / .cuda() on this module or on any module that holds it: variables created later follow."""
+        out = super()._apply(fn, *a, **kw)
+        try:
+            self.device = fn(torch.empty(0)).device
+        except Exception:          # noqa: BLE001 -- a dtype-only conversion etc.: keep the device
+            pass
+        return out
+
     def _add(self, key, t):
         mangled = "v%d" % len(self.names)
         self.names[key] = mangled

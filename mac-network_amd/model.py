@@ -11,7 +11,7 @@ import torch
 
 from .cell import MACCell
 from .encoder import QuestionEncoder
-from .options import UnsupportedOptions, fresh_seed, get
+from .options import UnsupportedOptions, freeze, fresh_seed, get
 from .output import OutputClassifier, answer_loss_and_pred
 from .params import MACCellParams
 from .stem import Stem
@@ -23,7 +23,15 @@ class MACNetCore(torch.nn.Module):
         self.config = config
         self.netLength = int(get(config, "netLength"))
         self.stem = Stem(config, H=H, W=W, inDim=imageInDim, generator=generator)
-        self.cell = MACCellParams(config, self.netLength, generator=generator)
+        try:
+            freeze(config)
+            self.cell = MACCellParams(config, self.netLength, generator=generator)
+        except UnsupportedOptions:
+            # an option set of the generic path (the reference's default configuration among them): its variables appear
+            # under the reference's names the first time the cell runs (generic.GenericParams), so build the optimizer after
+            # one forward pass -- or load a checkpoint into `net.cell` first
+            from .generic import GenericParams
+            self.cell = GenericParams(generator=generator)
         self.out = OutputClassifier(config, answerWordsNum=answerWordsNum, generator=generator)
 
     def tensors(self):
@@ -67,4 +75,11 @@ class MACNet(MACNetCore):
     def forward(self, images, questions, questionLengths, train=False, seed=None, b0=0, check_ids=True):
         seed = fresh_seed(seed, train)
         words, vecQ = self.enc(questions, questionLengths, train=train, seed=seed, b0=b0, check_ids=check_ids)   # model.py:783-788
-        return super().forward(images, vecQ, words, questionLengths, train=train, seed=seed, b0=b0)
+        raw = None
+        if not get(self.config, "controlContextual"):
+            # mac_cell.py:570: the control unit attends over the embedded words themselves (embeddingsOp's output, no dropout)
+            raw = self.enc.embed(questions)
+            if raw.shape[-1] != get(self.config, "ctrlDim"):
+                raise ValueError("Dimensions must be equal: without --controlContextual the question words are wrdEmbDim = %d wide, "
+                                 "the control state ctrlDim = %d (mac_cell.py:154)" % (raw.shape[-1], get(self.config, "ctrlDim")))
+        return super().forward(images, vecQ, words, questionLengths, train=train, seed=seed, b0=b0, questionWords=raw)
