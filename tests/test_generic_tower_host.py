@@ -33,11 +33,17 @@ class _StemStandIn(torch.nn.Module):
 
 @pytest.mark.parametrize("contextual", [True, False])
 def test_tower_on_the_reference_default_configuration(macx, host_generic, contextual):
-    B, H, W, Cin, d, p, S, A, V = 3, 3, 2, 16, 128, 2, 5, 6, 9
+    run_tower(macx, contextual)
+
+
+def run_tower(macx, contextual, dev=None):
+    """dev=None: CPU stand-ins (host logic, stem replaced); a device: everything on the HIP kernels, the real stem included."""
+    B, H, W, d, p, S, A, V = 3, 3, 2, 128, 2, 5, 6, 9
+    Cin = 16 if dev is None else 128
     E = 7 if contextual else d      # without --controlContextual the cell attends over the raw embeddings: wrdEmbDim == ctrlDim needed
     cfg = mo.default_config(netLength=p, memDim=d, ctrlDim=d, attDim=d, encDim=d, wrdEmbDim=E, outClassifierDims=[128], answerWordsNum=A,
-                            controlContextual=contextual)
-    cfg.stemDim = 16
+                            controlContextual=contextual, relu="ELU" if dev is not None else "STD")
+    cfg.stemDim = 16 if dev is None else 128
     q, lengths = questions(B, S, V, 3)
     g = torch.Generator().manual_seed(2)
     img = torch.relu(torch.randn(B, H * W, Cin, generator=g))
@@ -50,21 +56,27 @@ def test_tower_on_the_reference_default_configuration(macx, host_generic, contex
     mo.output_classifier(cfg, vs0, m, vq)
     params = {k: v.clone() for k, v in vs0.params.items()}
 
-    stem = _StemStandIn(cfg, {k: v for k, v in params.items() if k.startswith("stem/")}, H, W)
-    real_stem = macx.model.Stem
-    macx.model.Stem = lambda *a, **k: stem                     # the constructor's own choices, without the HIP stem
-    try:
+    if dev is None:
+        stem = _StemStandIn(cfg, {k: v for k, v in params.items() if k.startswith("stem/")}, H, W)
+        real_stem = macx.model.Stem
+        macx.model.Stem = lambda *a, **k: stem                     # the constructor's own choices, without the HIP stem
+        try:
+            built = macx.MACNet(cfg, vocab=V, H=H, W=W, imageInDim=Cin, answerWordsNum=A)
+        finally:
+            macx.model.Stem = real_stem
+    else:
         built = macx.MACNet(cfg, vocab=V, H=H, W=W, imageInDim=Cin, answerWordsNum=A)
-    finally:
-        macx.model.Stem = real_stem
+        macx.checkpoint.load_reference(built.stem, {k: v for k, v in params.items() if k.startswith("stem/")})
     assert type(built.enc) is macx.GenericQuestionEncoder and type(built.out) is macx.GenericOutputClassifier
     assert type(built.cell) is macx.GenericParams and not built.cell.names          # lazily created
     built.enc.load_reference_dict(params)
     built.out.load_reference_dict(params)
     built.cell.load_reference_dict({k: v for k, v in params.items() if k.startswith("MACnetwork/")})
-    built = built.to(torch.device("cpu"))
-    assert built.cell.device == torch.device("cpu")                                  # ... and lazily created ones would follow
-    logits = built(img, q, lengths, train=False)
+    target = torch.device("cpu") if dev is None else dev
+    built = built.to(target)
+    assert built.cell.device == target                                               # ... and lazily created ones would follow
+    to = (lambda t: t.to(dev)) if dev is not None else (lambda t: t)
+    logits = built(to(img), to(q), to(lengths), train=False)
     prm = {k: v.double().clone().requires_grad_(True) for k, v in params.items()}
     vs = mo.VarStore(params=prm, dtype=torch.float64)
     w2, v2 = mo.question_encoder(cfg, vs, q, lengths, V)
@@ -73,7 +85,7 @@ def test_tower_on_the_reference_default_configuration(macx, host_generic, contex
     rl = mo.output_classifier(cfg, vs, m2, v2)
     assert max_abs(logits, rl) < 5e-5
     dl = torch.randn(logits.shape, generator=g)
-    (logits * dl).sum().backward()
+    (logits * to(dl)).sum().backward()
     (rl * dl.double()).sum().backward()
     seen = 0
     for mod in (built.enc.params, built.cell, built.out.params):

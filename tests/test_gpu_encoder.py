@@ -158,3 +158,12 @@ def test_generic_encoder_matches_oracle(macx, dev, variant, train):
     enc, words, vecQ, prm, lengths = run_pair(macx, enc_cfg(variant), train, dev=dev)
     torch.cuda.synchronize()
     check(enc, words, vecQ, prm, lengths, tol=1e-5, gtol=2e-4)
+
+
+@pytest.mark.parametrize("contextual", [True, False])
+def test_generic_tower_on_the_gpu(macx, dev, contextual):
+    """macx.MACNet on the reference's default option structure (generic encoder + generic cell + generic classifier around the
+    fused stem), with and without --controlContextual: ids -> logits and the gradients against the oracle chain."""
+    from test_generic_tower_host import run_tower
+    run_tower(macx, contextual, dev=dev)
+    torch.cuda.synchronize()
