@@ -721,7 +721,7 @@ def stem_cnn(config, store, images, H, W, keep=1.0, masks=None):
                 b = ops.getBias((dims[i + 1],))
                 m = None if masks is None else masks[i].reshape(B, H, W, dims[i])
                 inp = ops.dropout(feats, keep, m)
-                out = torch.nn.functional.conv2d(inp.permute(0, 3, 1, 2), kernel.permute(3, 2, 0, 1), padding=1)   # SAME, stride 1
+                out = torch.nn.functional.conv2d(inp.permute(0, 3, 1, 2), kernel.permute(3, 2, 0, 1).contiguous(), padding=1)   # SAME, stride 1
                 out = out.permute(0, 2, 3, 1) + b
                 feats = ops.act("RELU", out)
     return feats.reshape(B, N, dims[-1])

@@ -473,3 +473,58 @@ def test_oracle_encoder_reproduces_the_reference(train, variant):
     ((ref["words"] * w1).sum() + (ref["vecQ"] * w2).sum()).backward()
     for k, v in ref["variables"].items():
         assert float((params[k].grad - v.grad).abs().max()) <= 1e-12 * max(1.0, float(v.grad.abs().max())), k
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_stem_and_encoder_on_random_shapes_match_the_reference(seed):
+    """Random small shapes (one image, 1 x 1 grids, one-word questions, one-dimensional embeddings, either direction mode):
+    the oracle's stem and encoder against the reference's on the stand-in, values and every gradient."""
+    import random
+    rnd = random.Random(300 + seed)
+    for case in range(5):
+        # ---- stem
+        Bs, H, W, C, sd, od = rnd.randint(1, 3), rnd.randint(1, 5), rnd.randint(1, 5), rnd.randint(1, 9), rnd.randint(1, 9), rnd.randint(1, 9)
+        train = rnd.random() < 0.5
+        cfg = rx.parse_flags(None, *(rx.dims_flags(od, P, HID) + ["--stemDim", str(sd)]))
+        g = torch.Generator().manual_seed(seed * 10 + case)
+        images = torch.randn(Bs, H, W, C, generator=g, dtype=torch.float64)
+        keep = cfg.stemDropout if train else 1.0
+        ref = rx.run_reference_stem(cfg, images, keep=keep, need_grad=True)
+        ocfg = mo.default_config(memDim=od)
+        ocfg.stemDim = sd
+        params = {k: v.detach().clone().requires_grad_(True) for k, v in ref["variables"].items()}
+        masks = [torch.floor(keep + u).reshape(Bs, H * W, -1) for u in ref["draws"]] if train else None
+        kb = mo.stem_cnn(ocfg, mo.VarStore(params=params, dtype=torch.float64), images.reshape(Bs, H * W, C), H, W, keep=keep, masks=masks)
+        assert float((kb - ref["kb"]).abs().max()) <= 1e-11, ("stem", Bs, H, W, C, sd, od, train)
+        w = torch.randn(kb.shape, generator=g, dtype=torch.float64)
+        (kb * w).sum().backward()
+        (ref["kb"] * w).sum().backward()
+        for k, v in ref["variables"].items():
+            assert float((params[k].grad - v.grad).abs().max()) <= 1e-11 * max(1.0, float(v.grad.abs().max())), ("stem", k)
+        # ---- encoder
+        Bq, Sq, vocab, E, bi = rnd.randint(1, 4), rnd.randint(1, 6), rnd.randint(1, 7), rnd.randint(1, 6), rnd.random() < 0.5
+        enc = 2 * rnd.randint(1, 4)
+        ctrl = enc if rnd.random() < 0.6 else enc + 2
+        train = rnd.random() < 0.5
+        flags = ["--encDim", str(enc), "--wrdEmbDim", str(E), "--ctrlDim", str(ctrl)] + (["--encBi"] if bi else [])
+        cfg = rx.parse_flags(None, *(rx.dims_flags(D, P, HID) + flags))
+        lengths = torch.tensor([rnd.randint(1, Sq) for _ in range(Bq)], dtype=torch.int32)
+        qs = torch.tensor([[rnd.randint(1, vocab) if t < int(lengths[b]) else 0 for t in range(Sq)] for b in range(Bq)])
+        emb = torch.randn(vocab, E, generator=g, dtype=torch.float64)
+        ki, kq = (cfg.encInputDropout, cfg.qDropout) if train else (1.0, 1.0)
+        ref = rx.run_reference_encoder(cfg, qs, lengths, emb, keep_input=ki, keep_question=kq, need_grad=True)
+        ocfg = mo.default_config(encDim=enc, wrdEmbDim=E, encBi=bi, ctrlDim=ctrl)
+        params = {k: v.detach().clone().requires_grad_(True) for k, v in ref["variables"].items()}
+        masks = [torch.floor(ki + ref["draws"][0]), torch.floor(kq + ref["draws"][1])] if train else None
+        vs = mo.VarStore(params=params, dtype=torch.float64)
+        words, vecQ = mo.question_encoder(ocfg, vs, qs, lengths, vocab, keep_input=ki, keep_question=kq, masks=masks)
+        what = ("encoder", Bq, Sq, vocab, E, enc, ctrl, bi, train)
+        assert list(vs.params) == list(ref["variables"]), what
+        assert float((words - ref["words"]).abs().max()) <= 1e-11 and float((vecQ - ref["vecQ"]).abs().max()) <= 1e-11, what
+        w1 = torch.randn(words.shape, generator=g, dtype=torch.float64)
+        w2 = torch.randn(vecQ.shape, generator=g, dtype=torch.float64)
+        ((words * w1).sum() + (vecQ * w2).sum()).backward()
+        ((ref["words"] * w1).sum() + (ref["vecQ"] * w2).sum()).backward()
+        for k, v in ref["variables"].items():
+            if v.grad is not None:
+                assert float((params[k].grad - v.grad).abs().max()) <= 1e-11 * max(1.0, float(v.grad.abs().max())), (what, k)

@@ -544,7 +544,7 @@ def _conv2d(inp, filter=None, strides=None, padding="SAME", name=None):  # noqa:
     s = strides[1]
     if padding != "SAME" or s != 1 or kh % 2 == 0 or kw % 2 == 0:
         raise NotImplementedError("conv2d shim: SAME, stride 1, odd kernels only")
-    out = torch.nn.functional.conv2d(inp.permute(0, 3, 1, 2), filter.permute(3, 2, 0, 1), padding=(kh // 2, kw // 2))
+    out = torch.nn.functional.conv2d(inp.permute(0, 3, 1, 2), filter.permute(3, 2, 0, 1).contiguous(), padding=(kh // 2, kw // 2))
     return out.permute(0, 2, 3, 1)
 
 
