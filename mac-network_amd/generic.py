@@ -392,10 +392,15 @@ class GenericParams(torch.nn.Module):
     def _apply(self, fn, *a, **kw):
         """.to(device) / .cuda() on this module or on any module that holds it: variables created later follow."""
         out = super()._apply(fn, *a, **kw)
-        try:
-            self.device = fn(torch.empty(0)).device
-        except Exception:          # noqa: BLE001 -- a dtype-only conversion etc.: keep the device
-            pass
+        held = self.tensors()
+        if held:
+            self.device = held[0].device
+        else:
+            try:
+                probe = torch.empty(0, device=self.device) if self.device is not None else torch.empty(0)
+                self.device = fn(probe).device
+            except Exception:          # noqa: BLE001 -- keep the device
+                pass
         return out
 
     def _add(self, key, t):
