@@ -6,7 +6,7 @@ numpy restatement of the stateless dropout stream the HIP kernels use
 The reference draws its masks from TensorFlow's stateful RNG (ops.py:312, :674-679, :1054-1059;
 mac_cell.py:217, :463): `floor(keep + U[0,1))`.  That stream cannot be reproduced outside TF, so
 parity under dropout is defined on IDENTICAL MASKS: the oracle consumes masks produced here, the
-product regenerates the same bits in-kernel, and tests/test_dropout_stream.py checks the two
+product regenerates the same bits in-kernel, and tests/test_gpu_units.py::test_dropout_stream_matches_numpy checks the two
 implementations bit-for-bit.
 """
 import numpy as np
