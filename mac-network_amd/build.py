@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
             if fh.read().strip() == dig:
                 return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-I", os.path.join(ROOT, "include")]
+           "-Wno-pass-failed", "-Wno-inline-asm", "-I", os.path.join(ROOT, "include")]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH]
     if verbose:

@@ -14,6 +14,7 @@
 #include "macx_wgrad6.hip.h"
 #include "macx_h2.hip.h"
 #include "macx_gemm_h2.hip.h"
+#include "macx_chain_h2.hip.h"
 #include "macx_wgrad_h2.hip.h"
 #include "macx_small.hip.h"
 #include "macx_ops.hip.h"
@@ -51,6 +52,9 @@ struct ModeScope {
   ~ModeScope() { gemm_call_override() = saved; }
 };
 inline bool h2_mode() { return gemm_split_mode() == 2; }
+// the read unit's forward products as one kernel (macx_chain_h2.hip.h); macx_debug_set(4, 0) falls back to the four launches
+inline int& chain_mode() { static int m = 1; return m; }
+inline bool use_chain(int d) { return h2_mode() && chain_mode() && chain_fwd_supported(d); }
 inline int wfmt_plain() { return h2_mode() ? 3 : (gemm_split_mode() ? 1 : 0); }
 inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
 inline size_t wsize(size_t K, size_t n) { return K * n * 3 / 2; }     // covers format 1 (3/2) and format 3 (1 + the exponent)
@@ -138,8 +142,8 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
     L.seg[i] = take(counts[i]);
   }
   L.wx_p = take(wsize(d, d));
-  L.w1a_p = take(d * d);
-  L.w1b_p = take(d * d);
+  L.w1a_p = take(wsize(d, d));
+  L.w1b_p = take(wsize(d, d));
   L.w2_p = take(wsize(d, d));
   L.wy_p = take(d * d);
   L.wm_p = take((size_t)write_in_dim(o, s->d) * d);
@@ -523,8 +527,13 @@ int pack_forward_weights(const macx_opts* o, const macx_shapes* s, const macx_pa
     }
     if (units & U_READ) {
       pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);
-      pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, wfmt_ymix());
-      pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, wfmt_ymix());
+      if (use_chain(d)) {      // the chain kernel scales the A side by y: W1a and W1b are plain H2 weights there
+        pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, 3, saved + L.wmax + 2);
+        pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, 3, saved + L.wmax + 3);
+      } else {
+        pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, wfmt_ymix());
+        pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, wfmt_ymix());
+      }
       pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);
       pk.add(P->projY_W, d, 1, d, d, saved + L.wy_p);
     }
@@ -675,6 +684,36 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     int* qH1 = reinterpret_cast<int*>(saved + L.qmin_H1) + (size_t)i * L.qmin_stride;
     int* qKB = reinterpret_cast<int*>(saved + L.qmin_KBd) + (rdrop ? (size_t)i * L.qmin_stride : 0);
     uint8_t* att_bytes = rdrop ? reinterpret_cast<uint8_t*>(att_bits) : nullptr;
+    if (use_chain(d)) {
+      // KB -> X -> H1 -> I2 -> logits in one launch (macx_chain_h2.hip.h)
+      const size_t dd_ = (size_t)d * d;
+      auto wref = [&](size_t off) { return ChainW{reinterpret_cast<const char*>(saved + off), reinterpret_cast<const int*>(saved + off) + dd_}; };
+      ChainFwdP c;
+      memset(&c, 0, sizeof(c));
+      c.M = R; c.N = N; c.d = d;
+      // without read dropout the projected knowledge base is step-invariant: inference reads step 0's X back; a run that
+      // keeps its activations recomputes it into the step's own buffers, as the reference's graph does (ops.py:688)
+      c.mode = (rdrop || L.act_stride != 0 || i == 0) ? 0 : 1;
+      c.dbg = (kb_gemm_dbg() >> 12) & 31;
+      c.kb = in->knowledgeBase;
+      c.first = (uint32_t)((size_t)s->b0 * N * d);
+      c.thr1 = 1u << 24; c.inv1 = 1.0f; c.thr2 = 1u << 24; c.inv2 = 1.0f;
+      if (rdrop) {
+        const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
+        const DropSpec da = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
+        c.key1 = dk.key; c.thr1 = dk.thr24; c.inv1 = dk.inv_keep; c.bits1 = reinterpret_cast<uint8_t*>(kb_bits);
+        c.key2 = da.key; c.thr2 = da.thr24; c.inv2 = da.inv_keep; c.bytes2 = att_bytes;
+      }
+      if (rdrop || i == 0) { c.KBd = hKB; c.qmin_KBd = qKB; }
+      c.Wx = wref(L.wx_p); c.W1a = wref(L.w1a_p); c.W1b = wref(L.w1b_p); c.W2 = wref(L.w2_p);
+      c.bx = P->projX_b; c.b1 = P->memKbProj_b; c.b2 = P->memKbProj2_b;
+      c.act1 = o->read_mem_act; c.act2 = o->read_ctrl_act;
+      c.y = y; c.c = c_i; c.wk = P->kbLogits_w;
+      c.X = hX; c.qmin_X = qX;
+      if (keep) { c.H1 = hH1; c.qmin_H1 = qH1; c.I2 = hI2; }
+      c.logits = saved + L.logit_part;
+      CK(chain_fwd_launch(c, st));
+    } else {
     if (rdrop || i == 0) {
       H2FromP f;
       memset(&f, 0, sizeof(f));
@@ -712,6 +751,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     g.cvec = c_i; g.wvec = P->kbLogits_w; g.logit_part = saved + L.logit_part;
     g.e_bytes = att_bytes; g.out_qmin = nullptr;
     CK((kb_gemm_h2_launch<B_PLAIN, E_I2_LOGIT, false>(g, st)));
+    }
     (void)CB;
   } else {
   if (rdrop) {
@@ -749,7 +789,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   // attention over the knowledge base + summary (mac_cell.py:266-275)
   {
     KbAttP a;
-    a.B = B; a.N = N; a.d = d; a.nparts = d / (16 * kb_gemm_nw());
+    a.B = B; a.N = N; a.d = d; a.nparts = use_chain(d) ? 1 : d / (16 * kb_gemm_nw());
     a.logit_part = saved + L.logit_part; a.bias = P->kbLogits_b;
     a.kb = in->knowledgeBase;
     a.att = saved + L.seg[MACX_SEG_ATT_KB] + (size_t)i * B * N;
@@ -2288,6 +2328,7 @@ int macx_h2_gemm(const float* A, int B, int N, int K, const float* Wm, int n_out
 int macx_debug_set(int key, int value) {
   if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }
   if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
+  if (key == 4 && (value == 0 || value == 1)) { chain_mode() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

@@ -26,6 +26,8 @@ def macx():
         m._lib.lib().macx_gemm_mode(GEMM_MODES[os.environ["MACX_GEMM"]])
     if os.environ.get("MACX_DBG"):          # debugging aid: kernel-selection / timing bits of macx_debug_set(1, .)
         m._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
+    if os.environ.get("MACX_CHAIN"):        # 0: the read unit's forward products as four launches instead of the fused chain kernel
+        m._lib.lib().macx_debug_set(4, int(os.environ["MACX_CHAIN"]))
     return m
 
 
