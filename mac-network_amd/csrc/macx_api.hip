@@ -54,7 +54,7 @@ struct ModeScope {
 inline bool h2_mode() { return gemm_split_mode() == 2; }
 // the read unit's forward products as one kernel (macx_chain_h2.hip.h); macx_debug_set(4, 0) falls back to the four launches
 inline int& chain_mode() { static int m = 1; return m; }
-inline bool use_chain(int d) { return h2_mode() && chain_mode() && chain_fwd_supported(d); }
+inline bool use_chain(int d, int N) { return h2_mode() && chain_mode() && chain_supported(d, N); }
 inline int wfmt_plain() { return h2_mode() ? 3 : (gemm_split_mode() ? 1 : 0); }
 inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
 inline size_t wsize(size_t K, size_t n) { return K * n * 3 / 2; }     // covers format 1 (3/2) and format 3 (1 + the exponent)
@@ -252,6 +252,10 @@ struct BwdLayout {
   size_t dt, du;    // [B,d]
   size_t slab_w2, slab_wx, slab_w1a, slab_w1b;
   size_t ns_big, ngroup;
+  size_t db_rows;   // rows per step of db1_part / dbx_part
+  size_t dwk_rows;  // rows per step of dwk_part / db2_part
+  size_t dc_part, dls_part;   // chain kernel: per-row-group partials of dc / db_k of the current step
+  bool chain_sums;
   size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part, ctrl_dl;
   size_t tmpBd[4];  // [B,d] scratch
   size_t dccx;      // [p+1,B,d] gradient reaching cc_i from the NEXT step's contControl input (feedPrevAtt off)
@@ -276,7 +280,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   const size_t win = write_in_dim(o, s->d);
   size_t off = 0;
   auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
-  L.wxT_p = take(wsize(d, d)); L.w1aT_p = take(d * d); L.w1bT_p = take(d * d); L.w2T_p = take(wsize(d, d));
+  L.wxT_p = take(wsize(d, d)); L.w1aT_p = take(wsize(d, d)); L.w1bT_p = take(wsize(d, d)); L.w2T_p = take(wsize(d, d));
   L.wyT = take(d * d);
   L.wmT = take(win * d);
   L.wqT = take(d * d);
@@ -301,11 +305,17 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.slab_wx = take(L.ns_big * d * d);
   L.slab_w1a = take(p * L.ngroup * d * d);
   L.slab_w1b = take(p * L.ngroup * d * d);
-  const size_t nrb = nrb_of((int)N, (int)B, (int)d);
-  L.db2_part = take(p * B * d);
-  L.db1_part = take(p * B * nrb * d);
-  L.dbx_part = take(p * B * nrb * d);
-  L.dwk_part = take(p * B * d);
+  // column-sum partials of dI1 / dX: one row per GEMM workgroup row block, or per 64-row tile of the chain kernel
+  const size_t nrb = use_chain((int)d, (int)N) ? (B * N + 63) / 64 : B * nrb_of((int)N, (int)B, (int)d);
+  L.db_rows = nrb;
+  // dw_k / db2 partials: one row per question, or per 64-row tile when the chain kernel sums them (N >= 32)
+  L.chain_sums = use_chain((int)d, (int)N) && N >= 32;
+  L.dwk_rows = L.chain_sums ? (B * N + 63) / 64 : B;
+  L.db2_part = take(p * L.dwk_rows * d);
+  L.db1_part = take(p * nrb * d);
+  L.dbx_part = take(p * nrb * d);
+  L.dwk_part = take(p * L.dwk_rows * d);
+  if (L.chain_sums) { L.dc_part = take(L.dwk_rows * 3 * d); L.dls_part = take(L.dwk_rows * 3); }
   L.dbk_part = take(p * B);
   L.dwc_part = take(B * d);
   L.dbc_part = take(p * B);
@@ -527,7 +537,7 @@ int pack_forward_weights(const macx_opts* o, const macx_shapes* s, const macx_pa
     }
     if (units & U_READ) {
       pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);
-      if (use_chain(d)) {      // the chain kernel scales the A side by y: W1a and W1b are plain H2 weights there
+      if (use_chain(d, s->N)) {      // the chain kernel scales the A side by y: W1a and W1b are plain H2 weights there
         pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, 3, saved + L.wmax + 2);
         pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, 3, saved + L.wmax + 3);
       } else {
@@ -684,7 +694,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     int* qH1 = reinterpret_cast<int*>(saved + L.qmin_H1) + (size_t)i * L.qmin_stride;
     int* qKB = reinterpret_cast<int*>(saved + L.qmin_KBd) + (rdrop ? (size_t)i * L.qmin_stride : 0);
     uint8_t* att_bytes = rdrop ? reinterpret_cast<uint8_t*>(att_bits) : nullptr;
-    if (use_chain(d)) {
+    if (use_chain(d, s->N)) {
       // KB -> X -> H1 -> I2 -> logits in one launch (macx_chain_h2.hip.h)
       const size_t dd_ = (size_t)d * d;
       auto wref = [&](size_t off) { return ChainW{reinterpret_cast<const char*>(saved + off), reinterpret_cast<const int*>(saved + off) + dd_}; };
@@ -789,7 +799,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   // attention over the knowledge base + summary (mac_cell.py:266-275)
   {
     KbAttP a;
-    a.B = B; a.N = N; a.d = d; a.nparts = use_chain(d) ? 1 : d / (16 * kb_gemm_nw());
+    a.B = B; a.N = N; a.d = d; a.nparts = use_chain(d, s->N) ? 1 : d / (16 * kb_gemm_nw());
     a.logit_part = saved + L.logit_part; a.bias = P->kbLogits_b;
     a.kb = in->knowledgeBase;
     a.att = saved + L.seg[MACX_SEG_ATT_KB] + (size_t)i * B * N;
@@ -902,8 +912,13 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     Packer pk;
     if (units & U_READ) {
       pk.add(P->projX_W, 1, d, d, d, ws + W.wxT_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);            // Wx^T
-      pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, -1, -1, wfmt_ymix());       // W1a^T
-      pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, -1, -1, wfmt_ymix());  // W1b^T
+      if (use_chain(d, s->N)) {      // the chain kernel applies y to the accumulators: plain H2 weights
+        pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, -1, -1, 3, saved + L.wmax + 2);       // W1a^T
+        pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, -1, -1, 3, saved + L.wmax + 3);  // W1b^T
+      } else {
+        pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, -1, -1, wfmt_ymix());       // W1a^T
+        pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, -1, -1, wfmt_ymix());  // W1b^T
+      }
       pk.add(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);       // W2^T
       pk.add(P->projY_W, 1, d, d, d, ws + W.wyT);              // Wy^T
     }
@@ -1032,8 +1047,10 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       int* q_dI2 = reinterpret_cast<int*>(ws + W.qmin_dI2) + (size_t)i * B * CB;
       int* q_dI1 = reinterpret_cast<int*>(ws + W.qmin_dI1) + (size_t)i * B * CB;
       int* q_dX = reinterpret_cast<int*>(ws + W.qmin_dX) + (size_t)i * B * CB;
-      {
+      const bool chain = use_chain(d, s->N);
+      if (!(chain && W.chain_sums)) {
         ReadAttBwdH2P r;
+        r.dl = nullptr; r.no_out = chain ? 1 : 0;    // chain with tiny N: only dc / dw_k / db2 / db_k (dI2 comes from the chain kernel)
         r.B = B; r.N = N; r.d = d;
         r.att = att_kb + (size_t)i * B * N; r.da = ws + W.da; r.I2 = hI2; r.c = c_i; r.wk = P->kbLogits_w;
         r.act = o->read_ctrl_act;
@@ -1041,8 +1058,8 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         r.inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
         r.dI2 = hdI2;
         r.dc = DC + (size_t)(i + 1) * Bd;
-        r.dwk_part = ws + W.dwk_part + (size_t)i * Bd;
-        r.db2_part = ws + W.db2_part + (size_t)i * Bd;
+        r.dwk_part = ws + W.dwk_part + (size_t)i * W.dwk_rows * d;
+        r.db2_part = ws + W.db2_part + (size_t)i * W.dwk_rows * d;
         r.dbk_part = ws + W.dbk_part + (size_t)i * B;
         r.qmin = q_dI2;
         hipLaunchKernelGGL(read_att_bwd_h2_kernel, dim3(B, d / 128), dim3(RABH_THREADS), 0, st, r);
@@ -1053,6 +1070,36 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       g.B = B; g.N = N; g.K = d; g.Nout = d;
       g.dbg = kb_gemm_dbg() & (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128);      // phase-timing knobs (results are wrong under a non-zero mask)
       g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+      if (chain) {
+        // dl -> dI2 -> dI1 -> dX in one launch (macx_chain_h2.hip.h)
+        auto wref = [&](size_t off) { return ChainW{reinterpret_cast<const char*>(ws + off), reinterpret_cast<const int*>(ws + off) + dd}; };
+        ChainBwdP c;
+        memset(&c, 0, sizeof(c));
+        c.M = R; c.N = N; c.d = d;
+        c.dbg = (kb_gemm_dbg() >> 17) & 31;
+        c.att = att_kb + (size_t)i * B * N; c.da = ws + W.da;
+        c.I2 = hI2; c.c = c_i; c.wk = P->kbLogits_w; c.act2 = o->read_ctrl_act;
+        if (W.chain_sums) {
+          c.dwk_part = ws + W.dwk_part + (size_t)i * W.dwk_rows * d;
+          c.db2_part = ws + W.db2_part + (size_t)i * W.dwk_rows * d;
+          c.dc_part = ws + W.dc_part; c.dls_part = ws + W.dls_part;
+        }
+        c.bytes2 = rdrop ? reinterpret_cast<const uint8_t*>(saved + L.att_bits + (size_t)i * L.bits_stride) : nullptr;
+        c.inv2 = rdrop ? 1.0f / dp->keep_read : 1.0f;
+        c.dI2 = hdI2; c.qmin_dI2 = q_dI2;
+        c.W2T = wref(W.w2T_p); c.H1 = hH1; c.act1 = o->read_mem_act;
+        c.dI1 = hdI1; c.qmin_dI1 = q_dI1; c.db1_part = ws + W.db1_part + (size_t)i * W.db_rows * d;
+        c.W1aT = wref(W.w1aT_p); c.W1bT = wref(W.w1bT_p); c.y = y;
+        c.dX = hdX; c.qmin_dX = q_dX; c.dbx_part = ws + W.dbx_part + (size_t)i * W.db_rows * d;
+        CK(chain_bwd_launch(c, st));
+        if (W.chain_sums) {
+          DcReduceP q;
+          q.B = B; q.N = N; q.d = d; q.dc_part = ws + W.dc_part; q.dls_part = ws + W.dls_part;
+          q.dc = DC + (size_t)(i + 1) * Bd; q.dbk_part = ws + W.dbk_part + (size_t)i * B;
+          hipLaunchKernelGGL(dc_reduce_kernel, dim3(B), dim3(128), 0, st, q);
+          CK(hipGetLastError());
+        }
+      } else {
       // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
       g.A = hdI2;
       g.Wh = reinterpret_cast<const char*>(ws + W.w2T_p); g.w_exp = reinterpret_cast<const int*>(ws + W.w2T_p) + dd;
@@ -1065,6 +1112,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       g.out = hdX; g.out_qmin = q_dX;
       g.colsum_part = ws + W.dbx_part + (size_t)i * B * nrb * d;
       CK((kb_gemm_h2_launch<B_YMIX_COL, E_PLAIN, true>(g, st)));
+      }
       // S_b = X_b^T dI1_b -> dW1a / dW1b slabs and dy partials
       {
         SbH2P q;
@@ -1405,10 +1453,10 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   CK(slab_reduce_launch(ws + W.slab_wx, (int)W.ns_big, dd, GP->projX_W, 0, st));
   CK(slab_reduce_launch(ws + W.slab_w1a, (int)(p * W.ngroup), dd, GP->memKbProj_W, 0, st));
   CK(slab_reduce_launch(ws + W.slab_w1b, (int)(p * W.ngroup), dd, GP->memKbProj_W + dd, 0, st));
-  CK(rowsum(ws + W.db2_part, p * B, d, d, GP->memKbProj2_b, st));
-  CK(rowsum(ws + W.db1_part, p * B * nrb, d, d, GP->memKbProj_b, st));
-  CK(rowsum(ws + W.dbx_part, p * B * nrb, d, d, GP->projX_b, st));
-  CK(rowsum(ws + W.dwk_part, p * B, d, d, GP->kbLogits_w, st));
+  CK(rowsum(ws + W.db2_part, p * (int)W.dwk_rows, d, d, GP->memKbProj2_b, st));
+  CK(rowsum(ws + W.db1_part, p * (int)W.db_rows, d, d, GP->memKbProj_b, st));
+  CK(rowsum(ws + W.dbx_part, p * (int)W.db_rows, d, d, GP->projX_b, st));
+  CK(rowsum(ws + W.dwk_part, p * (int)W.dwk_rows, d, d, GP->kbLogits_w, st));
   CK(rowsum(ws + W.dbk_part, p * B, 1, 1, GP->kbLogits_b, st));
   return MACX_OK;
 }

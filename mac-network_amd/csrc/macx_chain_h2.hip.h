@@ -1,35 +1,44 @@
-// macx_chain_h2.hip.h -- the read unit's three knowledge-base products as ONE kernel (mac_cell.py:230-266, ops.py:668-725):
+// macx_chain_h2.hip.h -- the read unit's knowledge-base products chained inside ONE kernel per direction.
 //
+// forward (mac_cell.py:230-266, ops.py:668-725), chain_fwd_kernel:
 //     KBd = dropout(KB)                         ops.py:678
 //     X   = KBd Wx + bx                         ops.py:688            (stage 1)
 //     H1  = act([X*y, X] W1 + b1)               ops.py:703,718        (stage 2: X W1b, then (X*y) W1a on the same accumulators)
 //     I2  = H1 W2 + b2                          ops.py:326            (stage 3)
 //     l   = dropout(act(I2 * c)) . w_k          mac_cell.py:248-266
+// backward (SURVEY appendix A rows "logit" .. "mem-mul"), chain_bwd_kernel:
+//     dI2 = (dl w_k * mask * act'(I2 * c)) * c                        (stage B0, elementwise from the kept I2)
+//     dI1 = (dI2 W2^T) * act'(H1)                                     (stage B1)
+//     dX  = (dI1 W1a^T) * y + dI1 W1b^T                               (stage B2: two products on the same accumulators)
 //
-// A workgroup owns R = 16 NT consecutive rows of the [B*N, d] activation and ALL d columns of every stage, so a stage's output
+// A workgroup owns 64 consecutive rows of the [B*N, d] activation and ALL d columns of every stage, so a stage's output
 // never leaves the CU before it is the next stage's operand: it is written in place, as H2 planes, over the LDS tile the
-// stage just multiplied.  X, H1 and I2 still go to HBM once each (the backward pass reads them), as stores that drain behind
-// the next stage's matrix work; nothing is read back.  Against the four launches this replaces (h2_from_f32 + three
-// kb_gemm_h2) a step saves the HBM round trips of KBd, X and H1, three launch ramps and three store tails.
+// stage just multiplied.  Every tensor the other direction or a weight-gradient kernel needs still goes to HBM once, as
+// stores that drain behind the next stage's matrix work; nothing is read back.  Against the launches these replace
+// (h2_from_f32 + three kb_gemm_h2 forward, read_att_bwd_h2 + two kb_gemm_h2 backward) a step saves the HBM round trips of
+// the intermediates, the launch ramps and the store tails.
 //
 // How the pieces map onto a CU (8 waves, one workgroup per CU at d = 512: 128 KB of LDS):
-//   * rows are taken from the flat [B*N] axis, not per question: the question enters a row only through y (the A side, below),
-//     c and the dropout index, all of which are looked up per row -- so tiles never pad a question (B*N = 12544 = 196 x 64).
-//   * wave w owns columns [w d/8, (w+1) d/8) of the output for all R rows.  Weight fragments are therefore private to a wave:
-//     they go from L2 straight to registers in MFMA operand order (pack format 3 stores a lane's 8 k-values of one column as
-//     one 16-byte slot, 16 columns = 256 contiguous bytes), one K slice ahead of use, and never touch LDS.  The activation
-//     tile is shared by all waves and is LDS-resident for the whole stage: the K loop has NO barrier.
-//   * operands are swapped on the matrix pipe (D^T = W^T A^T): the weight slot is the MFMA's A operand and the activation
-//     slot its B operand -- the same two fragments -- so lane (i, g) ends up with FOUR CONSECUTIVE COLUMNS 4g..4g+3 of row
-//     i instead of four rows of one column.  Bias, activation, row maxima, the logit dot product and the hi/lo split all run
-//     on the accumulators where they lie, and half a slot (4 columns x fp16) leaves as one 8-byte store: no transpose through
-//     LDS, no row pass.
+//   * rows are taken from the flat [B*N] axis, not per question: the question enters a row only through y, c and the dropout
+//     index, all looked up per row -- tiles never pad a question (B*N = 12544 = 196 x 64).
+//   * a wave owns a block of 16-column tiles for its rows (d = 512: all 64 rows x 64 columns per wave).  Weight fragments go
+//     from L2 straight to registers in MFMA operand order (pack format 3 stores a lane's 8 k-values of one column as one
+//     16-byte slot, 16 columns = 256 contiguous bytes), one K slice ahead of use, and never touch LDS.  The activation tile
+//     is shared by all waves and LDS-resident for the whole stage: the K loop has NO barrier.
+//   * v_mfma_f32_16x16x32_f16 with the operands swapped (D^T = W^T A^T): the weight slot is the MFMA's A operand and the
+//     activation slot its B operand, so lane (i, g) ends up with FOUR CONSECUTIVE COLUMNS 4g .. 4g + 3 of row i of the tile
+//     instead of four rows of one column.  Bias, activation, row maxima, the logit dot product and the hi/lo split run on
+//     the accumulators where they lie, and half a slot (4 columns x fp16) leaves as one 8-byte store: no transpose through
+//     LDS, no row pass.  (Measured: the same loop on v_mfma_f32_32x32x16_f16 -- half the instructions, 4 accumulator tiles
+//     per wave instead of 16 -- ran 18.5 us against 16.5 us per product with no loads in the loop, 25 against 17 with them.)
 //   * one exponent per ROW (all d columns) instead of per (row, 128 columns): the workgroup sees the whole row, so a stage needs
 //     no per-K-block fold and no second accumulator set; the same exponent is written to each of the row's d/128 exponent
 //     bytes, which keeps the H2 tensors readable by every other kernel (macx_h2.hip.h).
-//   * y enters on the A side: stage 2 first accumulates X W1b, then the tile is rewritten in place as split(X * y_q) (fp32
-//     product, rounded once like the reference's X*y, own row exponents), the accumulators are brought to the new unit by an
-//     exact power of two, and (X*y) W1a is added -- K = 2d like the reference's concat, no per-question weight mixing.
+//   * y enters on the activation side.  Forward: stage 2 first accumulates X W1b, then the tile is rewritten in place as
+//     split(X * y_q) (fp32 product, rounded once like the reference's X*y, own row exponents), the accumulators are brought
+//     to the new unit by an exact power of two, and (X*y) W1a is added -- K = 2d like the reference's concat, no
+//     per-question weight mixing.  Backward: dI1 W1a^T is multiplied by y per output column on the accumulators, then
+//     dI1 W1b^T is added.
 #pragma once
 #include "macx_h2.hip.h"
 
@@ -40,10 +49,369 @@ struct ChainW {          // a weight matrix in pack format 3 (macx_h2.hip.h: pac
   const int* exp;        // device int: the stored fp16 are W * 2^exp
 };
 
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15); every lane of the row receives the same value (rotations
+// by 8, 4, 2, 1: the pairing is the same tree in every lane, and addition commutes)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov_f<0x128>(v);      // row_ror:8
+  v += dpp_mov_f<0x124>(v);      // row_ror:4
+  v += dpp_mov_f<0x122>(v);      // row_ror:2
+  v += dpp_mov_f<0x121>(v);      // row_ror:1
+  return v;
+}
+
+// sum over the 8 lanes 8 k .. 8 k + 7; every lane of the group receives the same value
+__device__ __forceinline__ float row8_sum(float v) {
+  v += dpp_mov_f<0x141>(v);      // row_half_mirror: i <-> 7 - i
+  v += dpp_mov_f<0x1B>(v);       // quad_perm [3,2,1,0]
+  v += dpp_mov_f<0xB1>(v);       // quad_perm [1,0,3,2]
+  return v;
+}
+
+template <int D_>
+struct ChainGeo {
+  static constexpr int D = D_, R = 64, KG = D / 8, CB = D / 128, KS = D / 32;
+  static constexpr int NWC = D >= 512 ? 8 : 4;       // waves along the columns
+  static constexpr int NWR = 8 / NWC;                // waves along the rows
+  static constexpr int CT = D / (16 * NWC);          // 16-column tiles per wave
+  static constexpr int RT = 4 / NWR;                 // 16-row tiles per wave
+  static constexpr int IT = KG / 8;                  // conversion passes: slot columns per lane (16 rows x 4 slot columns per wave step)
+  static constexpr size_t P_BYTES = (size_t)4 * R * D;
+  static constexpr int QS = 5;                       // backward: questions a tile can touch (N >= 16) -- their control vectors are staged in LDS
+  // P | sMax [8][R] | sPart [8][R] | sE [R] | sE2 [R] | sCol [2][D] | sW [D] | sC [QS][D] | sPf [8][64]
+  static constexpr size_t LDS = P_BYTES + (size_t)R * (8 + 8 + 1 + 1) * 4 + (size_t)(2 + 1 + QS) * D * 4 + 8 * 256;
+  static_assert(D % 128 == 0 && D >= 128 && D <= 512, "one workgroup holds 64 rows x D as H2 planes in LDS");
+};
+
+// what both kernels share: the tile in LDS, who owns what, the K loop, the row-exponent bookkeeping, the H2 emitters
+template <int D_>
+struct ChainCtx {
+  using G = ChainGeo<D_>;
+  static constexpr int D = G::D, R = G::R, KG = G::KG, CB = G::CB, KS = G::KS, NWC = G::NWC, NWR = G::NWR, CT = G::CT, RT = G::RT, IT = G::IT;
+  char* P;          // [2 planes][KG][R] x 16 B: the stage's activation operand
+  float* sMax;      // [8][R] partial row maxima
+  float* sPart;     // [8][R] partial row sums (attention logits)
+  int* sE;          // [R] exponents of the rows in P
+  int* sE2;         // [R] second exponent table
+  float* sCol;      // [2][D] column sums of the two row halves
+  float* sW;        // [D] backward: the logits weight
+  float* sC;        // [QS][D] backward: control vectors of the tile's questions
+  char* sPf;        // [8][256 B] landing zone of prefetch DMAs (never read)
+  int tid, lane, wave, li, lg;
+  int wr, wc, colbase, rowbase;
+  int M, N, nvalid;
+  size_t grow0;
+  int crow; size_t cgrow; bool cvalid;      // conversion passes: this lane's row
+
+  __device__ __forceinline__ void init(char* lds, int M_, int N_) {
+    P = lds;
+    sMax = reinterpret_cast<float*>(lds + G::P_BYTES);
+    sPart = sMax + 8 * R;
+    sE = reinterpret_cast<int*>(sPart + 8 * R);
+    sE2 = sE + R;
+    sCol = reinterpret_cast<float*>(sE2 + R);
+    sW = sCol + 2 * D;
+    sC = sW + D;
+    sPf = reinterpret_cast<char*>(sC + G::QS * D);
+    tid = threadIdx.x; lane = tid & 63;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    li = lane & 15; lg = lane >> 4;
+    wr = wave / NWC; wc = wave % NWC;
+    colbase = wc * 16 * CT; rowbase = wr * 16 * RT;
+    M = M_; N = N_;
+    grow0 = (size_t)blockIdx.x * R;
+    nvalid = (int)min((size_t)R, (size_t)M - grow0);
+    crow = (wave >> 1) * 16 + li;
+    cgrow = grow0 + crow;
+    cvalid = crow < nvalid;
+  }
+  __device__ __forceinline__ int ckg(int j) const { return ((wave & 1) * IT + j) * 4 + lg; }   // conversion passes: slot column j of this lane
+  __device__ __forceinline__ size_t qrow(size_t grow) const { return min((uint32_t)grow, (uint32_t)M - 1) / (uint32_t)N; }   // question of a row (rows < 2^31)
+
+  __device__ __forceinline__ int row_exponent(int row, int w0, int nw) const {
+    float m = sMax[w0 * R + row];
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, sMax[(w0 + w) * R + row]);
+    return h2_exponent(m);
+  }
+  // exponent of a row after an accumulator epilogue (partial maxima from the NWC waves of its row half) / a conversion pass
+  __device__ __forceinline__ int row_exponent_epi(int row) const { return row_exponent(row, (row / (16 * RT)) * NWC, NWC); }
+  __device__ __forceinline__ int row_exponent_conv(int row) const { return row_exponent(row, (row >> 4) * 2, 2); }
+  __device__ __forceinline__ int row_exponent_blk(int row) const { return row_exponent(row, 0, KG / 8); }
+  enum { PASS_CONV = 0, PASS_EPI = 1, PASS_BLK = 2 };
+  __device__ __forceinline__ int row_exponent_of(int row, int pass) const {
+    return pass == PASS_EPI ? row_exponent_epi(row) : (pass == PASS_BLK ? row_exponent_blk(row) : row_exponent_conv(row));
+  }
+
+  // per-row bookkeeping once sMax is complete: exponent table, exponent bytes, per-question minimum (wave 0 works)
+  __device__ __forceinline__ void publish_rows(int* eTab, int pass, const H2View& out, int* qmin) const {
+    if (tid < 64) {
+      const int r = tid;
+      const bool v = r < nvalid;
+      const int e = row_exponent_of(r, pass);
+      eTab[r] = e;
+      if (out.base && v) {
+        int8_t* ex = out.exps() + (grow0 + r) * CB;
+#pragma unroll
+        for (int k = 0; k < CB; ++k) ex[k] = (int8_t)e;
+      }
+      if (out.base && qmin) {
+        const int q0 = (int)((uint32_t)grow0 / (uint32_t)N), q1 = (int)(((uint32_t)grow0 + nvalid - 1) / (uint32_t)N);
+        const int qr = v ? (int)(((uint32_t)grow0 + r) / (uint32_t)N) : -1;
+        for (int qq = q0; qq <= q1; ++qq) {
+          int mn = (qr == qq) ? e : 127;
+#pragma unroll
+          for (int s = 32; s > 0; s >>= 1) mn = min(mn, __shfl_xor(mn, s, 64));
+          if (tid < CB) atomicMin(qmin + (size_t)qq * CB + tid, mn);
+        }
+      }
+    }
+  }
+  // conversion pass, second half: v[j][0..7] (fp32, this lane's slots) -> row exponents -> H2 slots in P (+ HBM)
+  __device__ __forceinline__ void convert_finish(float (&v)[IT][8], float m, int* eTab, const H2View& out, int* qmin) const {
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (lane < 16) sMax[wave * R + crow] = m;
+    __syncthreads();
+    const float s = h2_pow2(row_exponent_conv(crow));
+    const size_t Rp = out.Rp();
+    const size_t opb = out.plane_bytes();
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int kg = ckg(j);
+      float xs[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xs[q] = v[j][q] * s;
+      u32x4 hi, lo;
+      h2_split8(xs, hi, lo);
+      char* d = P + ((size_t)kg * R + crow) * 16;
+      *reinterpret_cast<u32x4*>(d) = hi;
+      *reinterpret_cast<u32x4*>(d + (size_t)KG * R * 16) = lo;
+      if (out.base && cvalid) {
+        char* g = out.base + ((size_t)kg * Rp + cgrow) * 16;
+        *reinterpret_cast<u32x4*>(g) = hi;
+        *reinterpret_cast<u32x4*>(g + opb) = lo;
+      }
+    }
+    publish_rows(eTab, PASS_CONV, out, qmin);
+    __syncthreads();
+  }
+  // ---- row-block conversion pass (backward stage B0): lane (r8 = lane & 7, kq = lane >> 3) of wave w < KG / 8 holds slot column
+  // 8 w + kq of the rows r8 + 8 s, s = 0..7 -- eight rows per lane, so sums over rows accumulate in registers, a wave's 8-lane
+  // groups read and write whole 128-byte lines, and a wave owns its columns for the whole tile.  v[s][0..7]: the slot of row
+  // block s.
+  __device__ __forceinline__ void convert_finish_blk(float (&v)[8][8], const H2View& out, int* eTab, int* qmin) const {
+    const int r8 = lane & 7, kq = lane >> 3;
+    const bool active = wave < KG / 8;
+    if (active) {
+#pragma unroll
+      for (int sb = 0; sb < 8; ++sb) {
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[sb][q]));
+        m = fmaxf(m, dpp_mov_f<0x128>(m));                 // lane ^ 8 (row_ror:8 within 16 lanes)
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (kq == 0) sMax[wave * R + 8 * sb + r8] = m;
+      }
+    }
+    __syncthreads();
+    if (active) {
+      const int kg = 8 * wave + kq;
+      const size_t Rp = out.Rp();
+      const size_t opb = out.plane_bytes();
+#pragma unroll
+      for (int sb = 0; sb < 8; ++sb) {
+        const int row = 8 * sb + r8;
+        const float s = h2_pow2(row_exponent_blk(row));
+        float xs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xs[q] = v[sb][q] * s;
+        u32x4 hi, lo;
+        h2_split8(xs, hi, lo);
+        char* d = P + ((size_t)kg * R + row) * 16;
+        *reinterpret_cast<u32x4*>(d) = hi;
+        *reinterpret_cast<u32x4*>(d + (size_t)KG * R * 16) = lo;
+        if (out.base && row < nvalid) {
+          char* g = out.base + ((size_t)kg * Rp + grow0 + row) * 16;
+          *reinterpret_cast<u32x4*>(g) = hi;
+          *reinterpret_cast<u32x4*>(g + opb) = lo;
+        }
+      }
+    }
+    publish_rows(eTab, PASS_BLK, out, qmin);
+    __syncthreads();
+  }
+
+  // an H2 tensor's rows of this tile -> P (a pure copy, lanes along rows) and its exponents -> eTab
+  __device__ __forceinline__ void load_tile(const H2View& src, int* eTab) const {
+    const size_t Rp = src.Rp();
+    for (int f = tid; f < 2 * KG * R; f += 512) {
+      const int r = f % R, s = f / R;                       // s = plane * KG + kg
+      const size_t gr = min(grow0 + r, (size_t)M - 1);
+      *reinterpret_cast<u32x4*>(P + (size_t)f * 16) = *reinterpret_cast<const u32x4*>(src.base + ((size_t)s * Rp + gr) * 16);
+    }
+    if (tid < R) eTab[tid] = (int)src.exps()[min(grow0 + tid, (size_t)M - 1) * CB];
+    __syncthreads();
+  }
+
+  // ---- the K loop of one product: acc[T][c] += W^T-slot x A-slot over all d (three fp16 terms, smallest first).
+  // KV: measurement variants (0 = the product): 1 no MFMA (the loads stay), 2 no weight loads inside the loop, 3 no loads
+  // at all inside the loop -- timing only, results are wrong
+  template <int KV>
+  __device__ __forceinline__ void kloop(f32x4 (&acc)[RT][CT], const char* W) const {
+    const char* wb = W + ((size_t)lg * D + colbase + li) * 16;
+    const char* pa = P + ((size_t)lg * R + rowbase + li) * 16;
+    // both operands of slice kt + 1 are requested before slice kt is multiplied: the weight slots from L2 (about one slice of
+    // matrix work away), the activation slots from LDS
+    u32x4 bq[2][2][CT], aq[2][2][RT];        // [set][plane][tile]
+    auto load_ab = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
+      if (!(KV >= 2 && in_loop)) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            bq[S][pl][c] = *reinterpret_cast<const u32x4*>(wb + ((size_t)(kt * 2 + pl) * 4 * D) * 16 + c * 256);
+      }
+      if (!(KV >= 3 && in_loop)) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int t = 0; t < RT; ++t)
+            aq[S][pl][t] = *reinterpret_cast<const u32x4*>(pa + ((size_t)(pl * KG + 4 * kt) * R + 16 * t) * 16);
+      }
+    };
+    auto mm = [&](auto set_c) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
+      if (KV == 1) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int c = 0; c < CT; ++c) asm volatile("" ::"v"(bq[S][pl][c]));
+#pragma unroll
+          for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(aq[S][pl][t]));
+        }
+        return;
+      }
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][0][c], aq[S][1][t], acc[t][c]);     // w_hi a_lo
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][1][c], aq[S][0][t], acc[t][c]);     // w_lo a_hi
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][0][c], aq[S][0][t], acc[t][c]);     // w_hi a_hi
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // the scheduler would sink a slice's loads to the end of the previous slice's products (shortest live range), i.e. to where
+    // they are needed: the order "request slice kt + 1, multiply slice kt" is pinned
+    load_ab(S0{}, 0, false);
+    if (KV >= 2) load_ab(S1{}, 1, false);
+#pragma unroll 1
+    for (int kt = 0; kt < KS; kt += 2) {
+      load_ab(S1{}, kt + 1, true);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S0{});
+      __builtin_amdgcn_sched_barrier(0);
+      load_ab(S0{}, min(kt + 2, KS - 2), true);    // (unconditional: behind a branch the wait-count pass drains every load at the join)
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S1{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __device__ __forceinline__ void zero_acc(f32x4 (&acc)[RT][CT]) const {
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- accumulator geometry: lane (li, lg) holds, for row tile t and column tile c, row rowbase + 16 t + li and the four
+  //      columns colbase + 16 c + 4 lg .. + 3 in acc[t][c][0..3]
+  __device__ __forceinline__ int arow(int t) const { return rowbase + 16 * t + li; }
+  __device__ __forceinline__ int acol(int c) const { return colbase + 16 * c + 4 * lg; }
+
+  // partial row maxima of the (finished) accumulator values -> sMax[wave]
+  __device__ __forceinline__ void rowmax(const f32x4 (&acc)[RT][CT]) const {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      float m = 0.f;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(acc[t][c][q]));
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if (lg == 0) sMax[wave * R + arow(t)] = m;
+    }
+  }
+  // after the barrier that completed sMax: split the accumulators, write them over P (to_p) and to `out`
+  __device__ __forceinline__ void emit(const f32x4 (&acc)[RT][CT], bool to_p, const H2View& out) const {
+    const size_t Rp = out.Rp();
+    const size_t opb = out.plane_bytes();
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int row = arow(t);
+      const float s = h2_pow2(row_exponent_epi(row));
+      const bool st = out.base && row < nvalid;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const f32x4 xv = acc[t][c] * s;
+        u32x2 hi, lo;
+        hi[0] = pk_f16(xv[0], xv[1]);
+        hi[1] = pk_f16(xv[2], xv[3]);
+        const f32x2_t b0 = unpk_f16(hi[0]), b1 = unpk_f16(hi[1]);
+        lo[0] = pk_f16(xv[0] - b0[0], xv[1] - b0[1]);
+        lo[1] = pk_f16(xv[2] - b1[0], xv[3] - b1[1]);
+        const int kg = (colbase >> 3) + 2 * c + (lg >> 1);
+        const int half = (lg & 1) * 8;
+        if (to_p) {
+          char* d = P + ((size_t)kg * R + row) * 16 + half;
+          *reinterpret_cast<u32x2*>(d) = hi;
+          *reinterpret_cast<u32x2*>(d + (size_t)KG * R * 16) = lo;
+        }
+        if (st) {
+          char* g = out.base + ((size_t)kg * Rp + grow0 + row) * 16 + half;
+          *reinterpret_cast<u32x2*>(g) = hi;
+          *reinterpret_cast<u32x2*>(g + opb) = lo;
+        }
+      }
+    }
+  }
+  // column sums of the accumulator values over the tile's rows -> part[D] (rows past the end hold zeros)
+  __device__ __forceinline__ void colsum(const f32x4 (&acc)[RT][CT], float* part) const {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float s = acc[0][c][q];
+#pragma unroll
+        for (int t = 1; t < RT; ++t) s += acc[t][c][q];
+        s = row16_sum(s);
+        if (li == 0) {
+          const int col = acol(c) + q;
+          if (NWR == 1) part[col] = s;
+          else sCol[wr * D + col] = s;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void colsum_finish(float* part) const {     // after a barrier; NWR == 2 only
+    if (NWR == 2)
+      for (int c = tid; c < D; c += 512) part[c] = sCol[c] + sCol[D + c];
+  }
+};
+
+// =========================================================================================================================
 struct ChainFwdP {
   int M, N, d;              // rows (B*N), rows per question, width
   int mode;                 // 0: KB -> X -> H1 -> I2 ; 1: X is read back (no read dropout: the projected KB is step-invariant)
-  int dbg;                  // timing knobs: 1 stop after stage 0, 2 after stage 1, 4 after stage 2 (results incomplete)
+  int dbg;                  // timing knobs: 1 stop after stage 0, 2 after stage 1, 4 after stage 2; dbg >> 3 = K-loop variant
   // stage 0
   const float* kb;          // [M][d] fp32, row-major
   uint32_t first;           // flat dropout index of element (0, 0): b0 * N * d
@@ -64,101 +432,14 @@ struct ChainFwdP {
   float* logits;            // [M] (without the bias b_k, which kb_attend adds)
 };
 
-template <int NT, int CT>
-constexpr size_t chain_fwd_lds_bytes() { return (size_t)4 * (16 * NT) * (128 * CT) + (size_t)(16 * NT) * (8 + 8 + 1 + 1) * 4; }
-
-// KV: measurement variants of the K loop (0 = the product): 1 no MFMA (the loads stay), 2 no weight loads inside the loop,
-// 3 no loads at all inside the loop -- timing only, results are wrong
-template <int NT, int CT, int KV = 0>
+template <int D_, int KV = 0>
 __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
-  constexpr int R = 16 * NT, D = 128 * CT, KG = D / 8, KT = D / 32, CB = D / 128;
-  constexpr int UPR = KG / 4;            // conversion units (16 rows x 4 slot columns) per row group
-  constexpr int IT = NT * UPR / 8;       // ... per wave
-  constexpr int WPR = 8 / NT;            // waves that share a row group in the conversion passes
-  static_assert(NT == 1 || NT == 2 || NT == 4, "row tiles per workgroup");
-  static_assert((NT * UPR) % 8 == 0 && UPR % IT == 0 && KT % 2 == 0, "conversion units divide among the waves");
+  using C = ChainCtx<D_>;
+  constexpr int D = C::D, R = C::R, KG = C::KG, CT = C::CT, RT = C::RT, IT = C::IT;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* const P = lds;                                             // [2 planes][KG][R] x 16 B: the stage's A operand
-  float* const sMax = reinterpret_cast<float*>(lds + (size_t)4 * R * D);   // [8][R] partial row maxima
-  float* const sPart = sMax + 8 * R;                                       // [8][R] partial attention logits
-  int* const sE = reinterpret_cast<int*>(sPart + 8 * R);                   // [R] exponents of the rows in P
-  int* const sE2 = sE + R;                                                 // [R] ... of the X*y tile
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lg = lane >> 4;
+  C x;
+  x.init(lds, p.M, p.N);
   const int M = p.M;
-  const size_t grow0 = (size_t)blockIdx.x * R;
-  const int nvalid = (int)min((size_t)R, (size_t)M - grow0);
-
-  // ---- conversion passes: lane (li, lg) of wave w handles row crow and slot columns ckg(j), j < IT
-  const int crow = (wave / WPR) * 16 + li;
-  const size_t cgrow = grow0 + crow;
-  const bool cvalid = crow < nvalid;
-  auto ckg = [&](int j) { return ((wave % WPR) * IT + j) * 4 + lg; };
-
-  // per-row bookkeeping after a pass produced partial maxima in sMax[w0 .. w0+nw)[R]: exponent table, exponent bytes, qmin
-  auto row_exponent = [&](int row, int w0, int nw) {
-    float m = sMax[w0 * R + row];
-    for (int w = 1; w < nw; ++w) m = fmaxf(m, sMax[(w0 + w) * R + row]);
-    return h2_exponent(m);
-  };
-  auto publish_rows = [&](int* eTab, int wpr, const H2View& out, int* qmin) {     // called by every thread; wave 0 works
-    if (tid < 64) {
-      const int r = tid;
-      const bool v = r < nvalid;
-      int e = 127;
-      if (r < R) {
-        e = row_exponent(r, wpr == 8 ? 0 : (r >> 4) * wpr, wpr);
-        eTab[r] = e;
-        if (out.base && v) {
-          int8_t* ex = out.exps() + (grow0 + r) * CB;
-#pragma unroll
-          for (int k = 0; k < CB; ++k) ex[k] = (int8_t)e;
-        }
-      }
-      if (out.base && qmin) {
-        const int q0 = (int)(grow0 / p.N), q1 = (int)((grow0 + nvalid - 1) / p.N);
-        const int qr = v ? (int)((grow0 + r) / p.N) : -1;
-        for (int qq = q0; qq <= q1; ++qq) {
-          int mn = (qr == qq) ? e : 127;
-#pragma unroll
-          for (int s = 32; s > 0; s >>= 1) mn = min(mn, __shfl_xor(mn, s, 64));
-          if (tid < CB) atomicMin(qmin + (size_t)qq * CB + tid, mn);
-        }
-      }
-    }
-  };
-  // v[j][0..7] (fp32, this lane's slots) -> row exponents -> H2 slots in P (+ HBM)
-  auto convert_finish = [&](float (&v)[IT][8], float m, int* eTab, const H2View& out, int* qmin) {
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    if (lane < 16) sMax[wave * R + crow] = m;
-    __syncthreads();
-    const int e = row_exponent(crow, (wave / WPR) * WPR, WPR);
-    const float s = h2_pow2(e);
-    const size_t Rp = out.Rp();
-    const size_t opb = out.plane_bytes();
-#pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      const int kg = ckg(j);
-      float xs[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) xs[q] = v[j][q] * s;
-      u32x4 hi, lo;
-      h2_split8(xs, hi, lo);
-      char* d = P + ((size_t)kg * R + crow) * 16;
-      *reinterpret_cast<u32x4*>(d) = hi;
-      *reinterpret_cast<u32x4*>(d + (size_t)KG * R * 16) = lo;
-      if (out.base && cvalid) {
-        char* g = out.base + ((size_t)kg * Rp + cgrow) * 16;
-        *reinterpret_cast<u32x4*>(g) = hi;
-        *reinterpret_cast<u32x4*>(g + opb) = lo;
-      }
-    }
-    publish_rows(eTab, WPR, out, qmin);
-    __syncthreads();
-  };
 
   // =====================================================================================================================
   // stage 0: the operand of the first product
@@ -169,17 +450,17 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
     const size_t Rp2 = (size_t)M + H2_PAD_ROWS;
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
-      const int kg = ckg(j);
+      const int kg = x.ckg(j);
       // (rows past the end read the last row and are zeroed: a branch around a load costs a full wait per load)
-      const float* src = p.kb + min(cgrow, (size_t)M - 1) * D + kg * 8;
+      const float* src = p.kb + min(x.cgrow, (size_t)M - 1) * D + kg * 8;
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { v[j][q] = cvalid ? a0[q] : 0.f; v[j][4 + q] = cvalid ? a1[q] : 0.f; }
+      for (int q = 0; q < 4; ++q) { v[j][q] = x.cvalid ? a0[q] : 0.f; v[j][4 + q] = x.cvalid ? a1[q] : 0.f; }
     }
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
-      const int kg = ckg(j);
-      const uint32_t e0 = p.first + (uint32_t)(cgrow * D + kg * 8);
+      const int kg = x.ckg(j);
+      const uint32_t e0 = p.first + (uint32_t)(x.cgrow * D + kg * 8);
       if (drop1) {
         uint32_t byte = 0;
 #pragma unroll
@@ -188,132 +469,39 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
           byte |= (keep ? 1u : 0u) << q;
           v[j][q] = keep ? v[j][q] * p.inv1 : 0.f;
         }
-        if (p.bits1 && cvalid) p.bits1[cgrow * KG + kg] = (uint8_t)byte;
+        if (p.bits1 && x.cvalid) p.bits1[x.cgrow * KG + kg] = (uint8_t)byte;
       }
-      if (drop2 && p.bytes2 && cvalid) {
+      if (drop2 && p.bytes2 && x.cvalid) {
         uint32_t byte = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) byte |= (keep_bit(e0 + q, p.key2, p.thr2) ? 1u : 0u) << q;
-        p.bytes2[(size_t)kg * Rp2 + cgrow] = (uint8_t)byte;
+        p.bytes2[(size_t)kg * Rp2 + x.cgrow] = (uint8_t)byte;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[j][q]));
     }
-    convert_finish(v, m, sE, p.KBd, p.qmin_KBd);
+    x.convert_finish(v, m, x.sE, p.KBd, p.qmin_KBd);
   } else {
-    // X as an earlier call left it: a pure copy, lanes along rows
-    const size_t Rp = p.X.Rp();
-    for (int f = tid; f < 2 * KG * R; f += 512) {
-      const int r = f % R, s = f / R;                       // s = plane * KG + kg
-      const size_t gr = min(grow0 + r, (size_t)M - 1);
-      *reinterpret_cast<u32x4*>(P + (size_t)f * 16) = *reinterpret_cast<const u32x4*>(p.X.base + ((size_t)s * Rp + gr) * 16);
-    }
-    if (tid < R) sE[tid] = (int)p.X.exps()[min(grow0 + tid, (size_t)M - 1) * CB];
-    __syncthreads();
+    x.load_tile(p.X, x.sE);
   }
   if (p.dbg & 1) return;
 
-  // =====================================================================================================================
-  // the K loop of one product: acc[t][c] += W^T-slot x A-slot over all d (three fp16 terms, smallest first)
-  f32x4 acc[NT][CT];
-  const int colbase = wave * (16 * CT);
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int c = 0; c < CT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  auto kloop = [&](const char* W) {
-    const char* wb = W + ((size_t)lg * D + colbase + li) * 16;
-    const char* pa = P + ((size_t)lg * R + li) * 16;
-    // both operands of slice kt + 1 are requested before slice kt is multiplied: the weight slots from L2 (about one slice of
-    // matrix work away), the activation slots from LDS (whose latency would otherwise be paid once per row tile)
-    u32x4 bq[2][2][CT], aq[2][2][NT];
-    auto load_ab = [&](auto set_c, int kt, bool in_loop) {
-      constexpr int S = decltype(set_c)::value;
-      if (!(KV >= 2 && in_loop)) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-          for (int c = 0; c < CT; ++c)
-            bq[S][pl][c] = *reinterpret_cast<const u32x4*>(wb + ((size_t)(kt * 2 + pl) * 4 * D) * 16 + c * 256);
-      }
-      if (!(KV >= 3 && in_loop)) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            aq[S][pl][t] = *reinterpret_cast<const u32x4*>(pa + ((size_t)(pl * KG + kt * 4) * R + t * 16) * 16);
-      }
-    };
-    auto mm = [&](auto set_c) {
-      constexpr int S = decltype(set_c)::value;
-      if (KV == 1) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-          for (int c = 0; c < CT; ++c) asm volatile("" ::"v"(bq[S][pl][c]));
-#pragma unroll
-          for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(aq[S][pl][t]));
-        }
-        return;
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][0][c], aq[S][1][t], acc[t][c]);     // w_hi a_lo
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][1][c], aq[S][0][t], acc[t][c]);     // w_lo a_hi
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][0][c], aq[S][0][t], acc[t][c]);     // w_hi a_hi
-      }
-    };
-    // the scheduler would sink a slice's loads to the end of the previous slice's products (shortest live range), i.e. to where
-    // they are needed: the order of "request slice kt + 1, multiply slice kt" is pinned
-    load_ab(S0{}, 0, false);
-    if (KV >= 2) load_ab(S1{}, 1, false);
-#pragma unroll 1
-    for (int kt = 0; kt < KT; kt += 2) {
-      load_ab(S1{}, kt + 1, true);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(S0{});
-      __builtin_amdgcn_sched_barrier(0);
-      load_ab(S0{}, min(kt + 2, KT - 2), true);    // (unconditional: behind a branch the wait-count pass drains every load at the join)
-      __builtin_amdgcn_sched_barrier(0);
-      mm(S1{});
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  // ---- epilogue on the accumulators: lane (li, lg) holds, for row tile t and column tile c, row 16 t + li and the four
-  //      columns colbase + 16 c + 4 lg .. + 3
-  // x = act(acc * 2^-(eA[row] + eW) + bias); returns with x in acc and the partial row maxima in sMax[wave]
-  auto bias_act = [&](auto act_c, const int* eTab, int eW, const float* bias) {
+  f32x4 acc[RT][CT];
+  // x = act(acc * 2^-(eA[row] + eW) + bias), left in acc
+  auto bias_act = [&](auto act_c, const int* eTab, int eW, const float* bias) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_c)::value;
-    f32x4 bv[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) bv[c] = *reinterpret_cast<const f32x4*>(bias + colbase + 16 * c + 4 * lg);
+    for (int c = 0; c < CT; ++c) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + x.acol(c));
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const float s = h2_unscale(eTab[16 * t + li], eW);
-      float m = 0.f;
+      for (int t = 0; t < RT; ++t) {
+        const float s = h2_unscale(eTab[x.arow(t)], eW);
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float x = act_apply(ACT, fmaf(acc[t][c][q], s, bv[c][q]));
-          acc[t][c][q] = x;
-          m = fmaxf(m, fabsf(x));
-        }
+        for (int q = 0; q < 4; ++q) acc[t][c][q] = act_apply(ACT, fmaf(acc[t][c][q], s, bv[q]));
       }
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      if (lg == 0) sMax[wave * R + 16 * t + li] = m;
     }
   };
-  auto bias_act_any = [&](int act, const int* eTab, int eW, const float* bias) {
+  auto bias_act_any = [&](int act, const int* eTab, int eW, const float* bias) __attribute__((always_inline)) {
     switch (act) {     // ONE switch per stage, not one per value (macx_gemm_h2.hip.h has the story)
       case ACT_TANH: bias_act(std::integral_constant<int, ACT_TANH>{}, eTab, eW, bias); break;
       case ACT_SIGMOID: bias_act(std::integral_constant<int, ACT_SIGMOID>{}, eTab, eW, bias); break;
@@ -322,130 +510,99 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
       default: bias_act(std::integral_constant<int, ACT_NON>{}, eTab, eW, bias); break;
     }
   };
-  // after the barrier that completed sMax: split the accumulators, write them over P (to_p) and to `out`
-  auto emit = [&](bool to_p, const H2View& out) {
-    const size_t Rp = out.Rp();
-    const size_t opb = out.plane_bytes();
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int row = 16 * t + li;
-      const float s = h2_pow2(row_exponent(row, 0, 8));
-      const bool st = out.base && row < nvalid;
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        const f32x4 x = acc[t][c] * s;
-        u32x2 hi, lo;
-        hi[0] = pk_f16(x[0], x[1]);
-        hi[1] = pk_f16(x[2], x[3]);
-        const f32x2_t b0 = unpk_f16(hi[0]), b1 = unpk_f16(hi[1]);
-        lo[0] = pk_f16(x[0] - b0[0], x[1] - b0[1]);
-        lo[1] = pk_f16(x[2] - b1[0], x[3] - b1[1]);
-        const int kg = (colbase >> 3) + 2 * c + (lg >> 1);
-        const int half = (lg & 1) * 8;
-        if (to_p) {
-          char* d = P + ((size_t)kg * R + row) * 16 + half;
-          *reinterpret_cast<u32x2*>(d) = hi;
-          *reinterpret_cast<u32x2*>(d + (size_t)KG * R * 16) = lo;
-        }
-        if (st) {
-          char* g = out.base + ((size_t)kg * Rp + grow0 + row) * 16 + half;
-          *reinterpret_cast<u32x2*>(g) = hi;
-          *reinterpret_cast<u32x2*>(g + opb) = lo;
-        }
-      }
-    }
-  };
 
   // =====================================================================================================================
   // stage 1: X = KBd Wx + bx
   if (p.mode == 0) {
-    zero_acc();
-    kloop(p.Wx.planes);
-    bias_act(std::integral_constant<int, ACT_NON>{}, sE, *p.Wx.exp, p.bx);
+    x.zero_acc(acc);
+    x.template kloop<KV>(acc, p.Wx.planes);
+    bias_act(std::integral_constant<int, ACT_NON>{}, x.sE, *p.Wx.exp, p.bx);
+    x.rowmax(acc);
     __syncthreads();                       // every wave is done reading P; sMax is complete
-    emit(true, p.X);
-    publish_rows(sE, 8, p.X, p.qmin_X);
+    x.emit(acc, true, p.X);
+    x.publish_rows(x.sE, C::PASS_EPI, p.X, p.qmin_X);
     __syncthreads();
   }
   if (p.dbg & 2) return;
 
   // =====================================================================================================================
   // stage 2: H1 = act(X W1b + (X * y) W1a + b1)
-  zero_acc();
-  kloop(p.W1b.planes);
+  x.zero_acc(acc);
+  x.template kloop<KV>(acc, p.W1b.planes);
   __syncthreads();                         // every wave is done reading X
   {
     float v[IT][8];
     float m = 0.f;
-    const float inv = h2_pow2(-sE[crow]);
-    const float* yq = p.y + (min(cgrow, (size_t)M - 1) / p.N) * D;
+    const float inv = h2_pow2(-x.sE[x.crow]);
+    const float* yq = p.y + x.qrow(x.cgrow) * D;
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
-      const int kg = ckg(j);
-      const char* s = P + ((size_t)kg * R + crow) * 16;
+      const int kg = x.ckg(j);
+      const char* s = x.P + ((size_t)kg * R + x.crow) * 16;
       const u32x4 hi = *reinterpret_cast<const u32x4*>(s), lo = *reinterpret_cast<const u32x4*>(s + (size_t)KG * R * 16);
-      float x[8];
-      h2_join8(hi, lo, inv, x);
+      float xv[8];
+      h2_join8(hi, lo, inv, xv);
       const f32x4 y0 = *reinterpret_cast<const f32x4*>(yq + kg * 8), y1 = *reinterpret_cast<const f32x4*>(yq + kg * 8 + 4);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        v[j][q] = x[q] * (q < 4 ? y0[q & 3] : y1[q & 3]);      // ops.py:703: the product the reference rounds to fp32
+        v[j][q] = xv[q] * (q < 4 ? y0[q & 3] : y1[q & 3]);      // ops.py:703: the product the reference rounds to fp32
         m = fmaxf(m, fabsf(v[j][q]));
       }
     }
-    convert_finish(v, m, sE2, H2View{nullptr, M, D}, nullptr);
+    x.convert_finish(v, m, x.sE2, H2View{nullptr, M, D}, nullptr);
   }
   {
     // accumulators: units 2^-(eX + e1b)  ->  2^-(eXy + e1a), exactly
     const int de = *p.W1a.exp - *p.W1b.exp;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int k = sE2[16 * t + li] - sE[16 * t + li] + de;
+    for (int t = 0; t < RT; ++t) {
+      const int k = x.sE2[x.arow(t)] - x.sE[x.arow(t)] + de;
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[t][c][q] = ldexpf(acc[t][c][q], k);
     }
   }
-  kloop(p.W1a.planes);
-  bias_act_any(p.act1, sE2, *p.W1a.exp, p.b1);
+  x.template kloop<KV>(acc, p.W1a.planes);
+  bias_act_any(p.act1, x.sE2, *p.W1a.exp, p.b1);
+  x.rowmax(acc);
   __syncthreads();
-  emit(true, p.H1);
-  publish_rows(sE, 8, p.H1, p.qmin_H1);
+  x.emit(acc, true, p.H1);
+  x.publish_rows(x.sE, C::PASS_EPI, p.H1, p.qmin_H1);
   __syncthreads();
   if (p.dbg & 4) return;
 
   // =====================================================================================================================
   // stage 3: I2 = H1 W2 + b2 ; logits = dropout(act(I2 * c)) . w_k
-  zero_acc();
-  kloop(p.W2.planes);
-  bias_act(std::integral_constant<int, ACT_NON>{}, sE, *p.W2.exp, p.b2);
+  x.zero_acc(acc);
+  x.template kloop<KV>(acc, p.W2.planes);
+  bias_act(std::integral_constant<int, ACT_NON>{}, x.sE, *p.W2.exp, p.b2);
+  x.rowmax(acc);
   {
     const bool drop2 = p.thr2 < (1u << 24);
-    auto logit_pass = [&](auto act_c) {
+    auto logit_pass = [&](auto act_c) __attribute__((always_inline)) {
       constexpr int ACT = decltype(act_c)::value;
-      f32x4 wv[CT];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) wv[c] = *reinterpret_cast<const f32x4*>(p.wk + colbase + 16 * c + 4 * lg);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const size_t gr = min(grow0 + 16 * t + li, (size_t)M - 1);
-        const float* cq = p.c + (gr / p.N) * D + colbase + 4 * lg;
+      for (int t = 0; t < RT; ++t) {
+        const size_t gr = min(x.grow0 + x.arow(t), (size_t)M - 1);
+        const float* cq = p.c + (size_t)((uint32_t)gr / (uint32_t)p.N) * D;
         float part = 0.f;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          const f32x4 cv = *reinterpret_cast<const f32x4*>(cq + 16 * c);
-          const uint32_t e0 = p.first + (uint32_t)(gr * D + colbase + 16 * c + 4 * lg);
+          const int col = x.acol(c);
+          const f32x4 cv = *reinterpret_cast<const f32x4*>(cq + col);
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(p.wk + col);
+          const uint32_t e0 = p.first + (uint32_t)(gr * D + col);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float g = act_apply(ACT, acc[t][c][q] * cv[q]);
             if (drop2) g = keep_bit(e0 + q, p.key2, p.thr2) ? g * p.inv2 : 0.f;
-            part = fmaf(g, wv[c][q], part);
+            part = fmaf(g, wv[q], part);
           }
         }
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
-        if (lg == 0) sPart[wave * R + 16 * t + li] = part;
+        if (x.lg == 0) x.sPart[x.wave * R + x.arow(t)] = part;
       }
     };
     switch (p.act2) {
@@ -457,42 +614,385 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
     }
   }
   __syncthreads();
-  emit(false, p.I2);
-  publish_rows(sE2, 8, p.I2, nullptr);
-  if (tid < nvalid) {
-    float s = sPart[tid];
+  x.emit(acc, false, p.I2);
+  x.publish_rows(x.sE2, C::PASS_EPI, p.I2, nullptr);
+  if (x.tid < x.nvalid) {
+    const int w0 = (x.tid / (16 * RT)) * C::NWC;
+    float s = x.sPart[w0 * R + x.tid];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) s += sPart[w * R + tid];          // fixed order
-    p.logits[grow0 + tid] = s;
+    for (int w = 1; w < C::NWC; ++w) s += x.sPart[(w0 + w) * R + x.tid];          // fixed order
+    p.logits[x.grow0 + x.tid] = s;
   }
 }
 
-template <int NT, int CT, int KV = 0>
+template <int D_, int KV = 0>
 inline hipError_t chain_fwd_launch_t(const ChainFwdP& p, hipStream_t st) {
-  auto kern = chain_fwd_kernel<NT, CT, KV>;
-  constexpr size_t lds = chain_fwd_lds_bytes<NT, CT>();
+  auto kern = chain_fwd_kernel<D_, KV>;
+  constexpr size_t lds = ChainGeo<D_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
-  const int R = 16 * NT;
-  hipLaunchKernelGGL(kern, dim3((p.M + R - 1) / R), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3((p.M + 63) / 64), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
-inline bool chain_fwd_supported(int d) { return d % 128 == 0 && d >= 128 && d <= 512; }
+inline bool chain_supported(int d, int N) { return d % 128 == 0 && d >= 128 && d <= 512 && N >= 16; }
 
 inline hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
   switch (p.d / 128) {
-    case 1: return chain_fwd_launch_t<4, 1>(p, st);
-    case 2: return chain_fwd_launch_t<4, 2>(p, st);
-    case 3: return chain_fwd_launch_t<4, 3>(p, st);
+    case 1: return chain_fwd_launch_t<128>(p, st);
+    case 2: return chain_fwd_launch_t<256>(p, st);
+    case 3: return chain_fwd_launch_t<384>(p, st);
     case 4:
       switch (p.dbg >> 3) {
-        case 1: return chain_fwd_launch_t<4, 4, 1>(p, st);
-        case 2: return chain_fwd_launch_t<4, 4, 2>(p, st);
-        case 3: return chain_fwd_launch_t<4, 4, 3>(p, st);
-        default: return chain_fwd_launch_t<4, 4>(p, st);
+        case 1: return chain_fwd_launch_t<512, 1>(p, st);
+        case 2: return chain_fwd_launch_t<512, 2>(p, st);
+        case 3: return chain_fwd_launch_t<512, 3>(p, st);
+        default: return chain_fwd_launch_t<512>(p, st);
       }
     default: return hipErrorInvalidValue;
+  }
+}
+
+
+// =========================================================================================================================
+struct ChainBwdP {
+  int M, N, d;
+  int dbg;                  // timing knobs: 1 stop after stage B0, 2 after B1; dbg >> 3 = K-loop variant
+  // stage B0: dI2 from the kept I2
+  const float* att;         // [B][N] knowledge-base attention of the step
+  const float* da;          // [B][N] dinfo . KB[n] (kb_att_da_kernel)
+  H2View I2;
+  const float* c;           // [B][d]
+  const float* wk;          // [d]
+  int act2;                 // readCtrlAct
+  const uint8_t* bytes2;    // keep bits of the attention dropout in slot order [d/8][M + pad]; null = keep all
+  float inv2;
+  H2View dI2; int* qmin_dI2;
+  // column sums of stage B0 per 64-row tile, summed over tiles by the caller in a fixed order; a tile may touch up to three
+  // questions (N >= 32), so what is per question has three segments.  All four null: not computed here
+  // (read_att_bwd_h2_kernel in its sums-only mode does it).
+  float* dwk_part;          // [tiles][d]     sum_rows dl * dropped(act(I2 * c))
+  float* db2_part;          // [tiles][d]     sum_rows dI2
+  float* dc_part;           // [tiles][3][d]  sum_rows dZ * I2, per question segment
+  float* dls_part;          // [tiles][3]     sum_rows dl, per question segment
+  // stage B1: dI1 = (dI2 W2^T) * act'(H1)
+  ChainW W2T;
+  H2View H1; int act1;      // readMemAct
+  H2View dI1; int* qmin_dI1;
+  float* db1_part;          // [tiles][d] column sums of dI1
+  // stage B2: dX = (dI1 W1a^T) * y + dI1 W1b^T
+  ChainW W1aT, W1bT;
+  const float* y;           // [B][d]
+  H2View dX; int* qmin_dX;
+  float* dbx_part;          // [tiles][d] column sums of dX
+};
+
+template <int D_, int KV = 0>
+__global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
+  using C = ChainCtx<D_>;
+  constexpr int D = C::D, R = C::R, KG = C::KG, CB = C::CB, CT = C::CT, RT = C::RT, IT = C::IT;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  C x;
+  x.init(lds, p.M, p.N);
+  const int M = p.M;
+
+  // =====================================================================================================================
+  // stage B0 (SURVEY appendix A rows "softmax", "logit", "ctrl-mul"):
+  //   dl = a (da - sum_j a_j da_j) ; dGd = dl w_k ; dG = dGd * mask / keep ; dZ = dG * act'(I2 * c) ; dI2 = dZ * c
+  // elementwise on this lane's slots of the kept I2; the sums over rows (dc, dw_k, db2, db_k) leave as per-row-group partials
+  {
+    const int q0 = (int)((uint32_t)x.grow0 / (uint32_t)p.N), q1 = (int)(((uint32_t)x.grow0 + x.nvalid - 1) / (uint32_t)p.N);
+    const int nq = q1 - q0 + 1;
+    float* sRed = x.sPart;              // [8]
+    float* sDot = x.sPart + 64;         // [nq <= 64]
+    for (int i = x.tid; i < D; i += 512) x.sW[i] = p.wk[i];
+    for (int i = x.tid; i < nq * D; i += 512) x.sC[i] = p.c[(size_t)q0 * D + i];        // nq <= QS: the caller guarantees N >= 16
+    for (int k = 0; k < nq; ++k) {       // sum_j a_j da_j of each question the tile touches (every tile of a question: same order, same value)
+      const float* aq = p.att + (size_t)(q0 + k) * p.N;
+      const float* dq = p.da + (size_t)(q0 + k) * p.N;
+      float part = 0.f;
+      for (int n = x.tid; n < p.N; n += 512) part += aq[n] * dq[n];
+      part = wave_sum(part);
+      if (x.lane == 0) sRed[x.wave] = part;
+      __syncthreads();
+      if (x.tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += sRed[w];
+        sDot[k] = t;
+      }
+      __syncthreads();
+    }
+    // row-block mapping (ChainCtx::convert_finish_blk): this lane's slot column and its eight rows
+    const int r8 = x.lane & 7, kq = x.lane >> 3;
+    const bool active = x.wave < KG / 8;
+    const int kg = active ? 8 * x.wave + kq : 0;
+    const size_t Rp = p.I2.Rp();
+    const size_t ipb = p.I2.plane_bytes();
+    const size_t tile = blockIdx.x;
+    const bool sums = p.dc_part != nullptr;
+    // (no keep bytes: any readable bytes stand in and are overridden -- a branch around a load costs a full wait per load)
+    const uint8_t* bytes_src = p.bytes2 ? p.bytes2 : reinterpret_cast<const uint8_t*>(p.I2.base);
+    const uint32_t bits_or = p.bytes2 ? 0u : 0xFFu;
+    float v[8][8];
+    // the kept I2 slots, the keep bytes and the rows' scalars are requested three row blocks ahead of their use (all eight at
+    // once would hold 100 registers more than the kernel has).  Rows past the end lie in the tensors' pad rows
+    // (H2_PAD_ROWS = 64 = one tile): readable, never used
+    u32x4 raw[8][2];
+    uint32_t bits[8];
+    float dlr[8], inv[8];
+    int seg[8];
+    const char* src0 = p.I2.base + ((size_t)kg * Rp + x.grow0 + r8) * 16;
+    const uint8_t* b0 = bytes_src + (size_t)kg * Rp + x.grow0 + r8;
+    const int8_t* e0 = p.I2.exps() + (x.grow0 + r8) * CB + (kg >> 4);
+    const uint32_t g0 = (uint32_t)x.grow0 + r8, last = (uint32_t)M - 1, un = (uint32_t)p.N;
+    const uint32_t qb1 = (uint32_t)(q0 + 1) * un, qb2 = qb1 + un;       // first rows of the next two questions
+    auto fetch = [&](auto sb_c) __attribute__((always_inline)) {
+      constexpr int sb = decltype(sb_c)::value;
+      raw[sb][0] = *reinterpret_cast<const u32x4*>(src0 + sb * 128);
+      raw[sb][1] = *reinterpret_cast<const u32x4*>(src0 + ipb + sb * 128);
+      bits[sb] = (uint32_t)b0[sb * 8];
+      inv[sb] = h2_pow2(-(int)e0[sb * 8 * CB]);
+      const uint32_t gr = min(g0 + 8 * sb, last);
+      seg[sb] = nq <= 3 ? (int)(gr >= qb1) + (int)(gr >= qb2) : (int)(gr / un) - q0;
+      const float dl_row = p.att[gr] * (p.da[gr] - sDot[seg[sb]]);
+      dlr[sb] = 8 * sb + r8 < x.nvalid ? dl_row : 0.f;
+    };
+    float a_dw[8], a_db[8], a_dc[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a_dw[e] = a_db[e] = a_dc[0][e] = a_dc[1][e] = a_dc[2][e] = 0.f;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(x.sW + kg * 8), w1 = *reinterpret_cast<const f32x4*>(x.sW + kg * 8 + 4);
+    auto block = [&](auto act_c, auto sb_c) __attribute__((always_inline)) {
+      constexpr int ACTC = decltype(act_c)::value;
+      const int ACT = ACTC >= 0 ? ACTC : p.act2;
+      constexpr int sb = decltype(sb_c)::value;
+      const float* cq = x.sC + (size_t)seg[sb] * D + kg * 8;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cq), c1 = *reinterpret_cast<const f32x4*>(cq + 4);
+      float i2[8];
+      h2_join8(raw[sb][0], raw[sb][1], inv[sb], i2);
+      const bool rv = 8 * sb + r8 < x.nvalid;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        i2[e] = rv ? i2[e] : 0.f;            // (pad rows hold anything, NaN included: select, do not multiply by zero)
+        const float cv = e < 4 ? c0[e & 3] : c1[e & 3], wv = e < 4 ? w0[e & 3] : w1[e & 3];
+        const float g = act_apply(ACT, i2[e] * cv);
+        const float f = (((bits[sb] | bits_or) >> e) & 1u) ? p.inv2 : 0.f;
+        const float dz = (dlr[sb] * wv) * f * act_grad_from_out(ACT, g);
+        const float ov = dz * cv;
+        v[sb][e] = ov;
+        a_dw[e] = fmaf(dlr[sb], g * f, a_dw[e]);              // dw_k += dl * dropped(G)
+        a_db[e] += ov;
+        const float t = dz * i2[e];                            // dc += dZ * I2, per question of the row
+        a_dc[0][e] += seg[sb] == 0 ? t : 0.f;
+        a_dc[1][e] += seg[sb] == 1 ? t : 0.f;
+        a_dc[2][e] += seg[sb] == 2 ? t : 0.f;
+      }
+    };
+    auto pass = [&](auto act_c) __attribute__((always_inline)) {
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2_ = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+      using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+      fetch(I0{}); fetch(I1{}); fetch(I2_{});
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(I3{}); block(act_c, I0{}); __builtin_amdgcn_sched_barrier(0);
+      fetch(I4{}); block(act_c, I1{}); __builtin_amdgcn_sched_barrier(0);
+      fetch(I5{}); block(act_c, I2_{}); __builtin_amdgcn_sched_barrier(0);
+      fetch(I6{}); block(act_c, I3{}); __builtin_amdgcn_sched_barrier(0);
+      fetch(I7{}); block(act_c, I4{}); __builtin_amdgcn_sched_barrier(0);
+      block(act_c, I5{}); __builtin_amdgcn_sched_barrier(0);
+      block(act_c, I6{}); __builtin_amdgcn_sched_barrier(0);
+      block(act_c, I7{});
+    };
+    // two instances only (ELU, what "RELU" means in the published configurations, and a per-value switch for the rest): five
+    // inlined copies of this body meet in one register allocation and spill ~250 registers
+    if (active) {
+      if (p.act2 == ACT_ELU) pass(std::integral_constant<int, ACT_ELU>{});
+      else pass(std::integral_constant<int, -1>{});
+    }
+    if (sums && active) {
+      // the wave owns these columns for the whole tile: sum the eight lanes that share a slot column, one lane stores
+      float* dw = p.dwk_part + tile * D + kg * 8;
+      float* db = p.db2_part + tile * D + kg * 8;
+      float* dc = p.dc_part + tile * 3 * D + kg * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        a_dw[e] = row8_sum(a_dw[e]);
+        a_db[e] = row8_sum(a_db[e]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < nq) a_dc[k][e] = row8_sum(a_dc[k][e]);
+      }
+      if (r8 == 0) {
+        *reinterpret_cast<f32x4*>(dw) = f32x4{a_dw[0], a_dw[1], a_dw[2], a_dw[3]};
+        *reinterpret_cast<f32x4*>(dw + 4) = f32x4{a_dw[4], a_dw[5], a_dw[6], a_dw[7]};
+        *reinterpret_cast<f32x4*>(db) = f32x4{a_db[0], a_db[1], a_db[2], a_db[3]};
+        *reinterpret_cast<f32x4*>(db + 4) = f32x4{a_db[4], a_db[5], a_db[6], a_db[7]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < nq) {
+            *reinterpret_cast<f32x4*>(dc + k * D) = f32x4{a_dc[k][0], a_dc[k][1], a_dc[k][2], a_dc[k][3]};
+            *reinterpret_cast<f32x4*>(dc + k * D + 4) = f32x4{a_dc[k][4], a_dc[k][5], a_dc[k][6], a_dc[k][7]};
+          }
+      }
+    }
+    if (sums && x.tid < 64) {          // db_k partials: sum of dl over the tile's rows, per question segment (fixed order)
+      const uint32_t gr = min((uint32_t)x.grow0 + x.tid, (uint32_t)M - 1);
+      const int sg = (int)(gr / (uint32_t)p.N) - q0;
+      const float dl = x.tid < x.nvalid ? p.att[gr] * (p.da[gr] - sDot[sg]) : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float t = wave_sum(sg == k ? dl : 0.f);
+        if (x.tid == 0) p.dls_part[tile * 3 + k] = t;
+      }
+    }
+    x.convert_finish_blk(v, p.dI2, x.sE, p.qmin_dI2);
+  }
+  if (p.dbg & 1) return;
+
+  f32x4 acc[RT][CT];
+  const size_t tile = blockIdx.x;
+  // =====================================================================================================================
+  // stage B1: dI1 = (dI2 W2^T) * act'(H1), act' from the kept activation OUTPUT
+  x.zero_acc(acc);
+  {
+    // the kept H1 rows of this tile are wanted by the epilogue below: pull their lines into L2 now (DMA into a scratch word:
+    // no register, nothing waits for it; older than every load of the K loop, so the loop's wait counts only over-wait)
+    const size_t Rp = p.H1.Rp();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int f = x.tid + 512 * k;                         // 2 planes x KG slot columns x 8 lines of 128 B
+      if (f < 2 * KG * 8) {
+        const char* src = p.H1.base + ((size_t)(f >> 3) * Rp + min(x.grow0, (size_t)M - 1)) * 16 + (f & 7) * 128;
+        dma4b(src, lds_addr_of(x.sPf) + x.wave * 256);
+      }
+    }
+  }
+  x.template kloop<KV>(acc, p.W2T.planes);
+  {
+    const int eW = *p.W2T.exp;
+    const size_t Rp = p.H1.Rp();
+    const size_t hpb = p.H1.plane_bytes();
+    auto pass = [&](auto act_c) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const size_t gr = min(x.grow0 + x.arow(t), (size_t)M - 1);
+        const float s = h2_unscale(x.sE[x.arow(t)], eW);
+        const int8_t* ex = p.H1.exps() + gr * CB;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const int kg = (x.colbase >> 3) + 2 * c + (x.lg >> 1);
+          const char* src = p.H1.base + ((size_t)kg * Rp + gr) * 16 + (x.lg & 1) * 8;
+          const u32x2 hh = *reinterpret_cast<const u32x2*>(src), hl = *reinterpret_cast<const u32x2*>(src + hpb);
+          float h[4];
+          h2_join4(hh, hl, h2_pow2(-(int)ex[kg >> 4]), h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[t][c][q] = acc[t][c][q] * s * act_grad_from_out(ACT, h[q]);
+        }
+      }
+    };
+    switch (p.act1) {
+      case ACT_TANH: pass(std::integral_constant<int, ACT_TANH>{}); break;
+      case ACT_SIGMOID: pass(std::integral_constant<int, ACT_SIGMOID>{}); break;
+      case ACT_ELU: pass(std::integral_constant<int, ACT_ELU>{}); break;
+      case ACT_RELU: pass(std::integral_constant<int, ACT_RELU>{}); break;
+      default: pass(std::integral_constant<int, ACT_NON>{}); break;
+    }
+  }
+  x.colsum(acc, p.db1_part + tile * D);
+  x.rowmax(acc);
+  __syncthreads();                         // every wave is done reading dI2; sMax (and sCol) complete
+  x.emit(acc, true, p.dI1);
+  x.publish_rows(x.sE, C::PASS_EPI, p.dI1, p.qmin_dI1);
+  x.colsum_finish(p.db1_part + tile * D);
+  __syncthreads();
+  if (p.dbg & 2) return;
+
+  // =====================================================================================================================
+  // stage B2: dX = (dI1 W1a^T) * y + dI1 W1b^T   (ops.py:703: d(x*y)/dx = y per column, per question)
+  x.zero_acc(acc);
+  x.template kloop<KV>(acc, p.W1aT.planes);
+  {
+    const int de = *p.W1bT.exp - *p.W1aT.exp;          // units 2^-(e + e1a) -> 2^-(e + e1b), exactly
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const float* yq = p.y + x.qrow(x.grow0 + x.arow(t)) * D;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(yq + x.acol(c));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][c][q] = ldexpf(acc[t][c][q] * yv[q], de);
+      }
+    }
+  }
+  x.template kloop<KV>(acc, p.W1bT.planes);
+  {
+    const int eW = *p.W1bT.exp;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const float s = h2_unscale(x.sE[x.arow(t)], eW);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[t][c] *= s;
+    }
+  }
+  x.colsum(acc, p.dbx_part + tile * D);
+  x.rowmax(acc);
+  __syncthreads();
+  x.emit(acc, false, p.dX);
+  x.publish_rows(x.sE2, C::PASS_EPI, p.dX, p.qmin_dX);
+  x.colsum_finish(p.dbx_part + tile * D);
+}
+
+template <int D_, int KV = 0>
+inline hipError_t chain_bwd_launch_t(const ChainBwdP& p, hipStream_t st) {
+  auto kern = chain_bwd_kernel<D_, KV>;
+  constexpr size_t lds = ChainGeo<D_>::LDS;
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((p.M + 63) / 64), dim3(512), lds, st, p);
+  return hipGetLastError();
+}
+
+inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
+  switch (p.d / 128) {
+    case 1: return chain_bwd_launch_t<128>(p, st);
+    case 2: return chain_bwd_launch_t<256>(p, st);
+    case 3: return chain_bwd_launch_t<384>(p, st);
+    case 4:
+      switch (p.dbg >> 3) {
+        case 1: return chain_bwd_launch_t<512, 1>(p, st);
+        case 3: return chain_bwd_launch_t<512, 3>(p, st);
+        default: return chain_bwd_launch_t<512>(p, st);
+      }
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// the per-question ends of stage B0's column sums: dc[q] += sum over the segments of the question's tiles, db_k partial
+struct DcReduceP {
+  int B, N, d;
+  const float* dc_part;     // [tiles][3][d]
+  const float* dls_part;    // [tiles][3]
+  float* dc;                // [B][d] accumulated in place
+  float* dbk_part;          // [B]
+};
+__global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
+  const int q = blockIdx.x;
+  const size_t r0 = (size_t)q * p.N, r1 = r0 + p.N - 1;
+  const int t0 = (int)(r0 >> 6), t1 = (int)(r1 >> 6);
+  for (int c4 = threadIdx.x * 4; c4 < p.d; c4 += 512) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int t = t0; t <= t1; ++t) {                       // fixed order
+      const int seg = q - (int)(((size_t)t << 6) / p.N);   // 0: the question that owns the tile's first row
+      s += *reinterpret_cast<const f32x4*>(p.dc_part + ((size_t)t * 3 + seg) * p.d + c4);
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(p.dc + (size_t)q * p.d + c4);
+    *dst = *dst + s;
+  }
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = t0; k <= t1; ++k) t += p.dls_part[(size_t)k * 3 + (q - (int)(((size_t)k << 6) / p.N))];
+    p.dbk_part[q] = t;
   }
 }
 

@@ -48,6 +48,8 @@ struct ReadAttBwdH2P {
   float* db2_part;       // [B][d]
   float* dbk_part;       // [B]
   int* qmin;             // [B][d/128] common (minimum) exponent of the question's dI2 rows, written
+  const float* dl;       // [B][N] softmax backward already done (kb_att_dl_kernel): att / da / dbk_part are not touched then
+  int no_out;            // 1: only the column sums dc / dwk_part / db2_part (dI2 comes from chain_bwd_kernel)
 };
 
 // One workgroup per (question, 128-column block), 16 waves: wave w owns slot column w (8 columns) and its lanes run along
@@ -66,6 +68,10 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NWV = RABH_THREADS / 64;
+  if (p.dl) {
+    for (int n = tid; n < p.N; n += RABH_THREADS) s_dl[n] = p.dl[(size_t)b * p.N + n];
+    __syncthreads();
+  } else {
   float dot = 0.f;
   for (int n = tid; n < p.N; n += RABH_THREADS) dot += p.att[(size_t)b * p.N + n] * p.da[(size_t)b * p.N + n];
   dot = wave_sum(dot);
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
 #pragma unroll
     for (int w = 0; w < NWV; ++w) t += s_red[w];
     p.dbk_part[b] = t;
+  }
   }
 
   const int kg = slab * 16 + wave;                       // this wave's slot column
@@ -143,6 +150,7 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
         }
         s_mx[wave][lrow] = m;
       }
+      if (p.no_out) continue;
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < RABH_CHUNK / 64; ++j) {
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
     case ACT_RELU: rows(std::integral_constant<int, ACT_RELU>{}); break;
     default: rows(std::integral_constant<int, ACT_NON>{}); break;
   }
-  if (wave == 0) {
+  if (wave == 0 && !p.no_out) {
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) emin = min(emin, __shfl_xor(emin, s, 64));
     if (lane == 0) p.qmin[(size_t)b * ocb + slab] = emin;
