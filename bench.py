@@ -134,6 +134,96 @@ def model_level(macx, dev, seed, steps=6):
             "flops_per_question_fwd_bwd": 3 * (P * flops_per_question_step() + stem_flops)}
 
 
+def run_bytes(macx, cfg, b, p):
+    """bytes of the two caller-owned buffers of one training run (forward `saved`, backward `ws`) at batch b, p steps"""
+    L = macx._lib.lib()
+    sh = macx._lib.MacxShapes(B=b, S=S, N=N, d=D, p=p, b0=0)
+    opts = macx.options.freeze(cfg)
+    return {"saved_bytes": 4 * int(L.macx_saved_floats(C.byref(opts), C.byref(sh), 1)),
+            "ws_bytes": 4 * int(L.macx_ws_floats(C.byref(opts), C.byref(sh), 1))}
+
+
+def fwd_only_p4(macx, dev, seed, p=4, steps=30):
+    """BASELINE configs[1]: synthetic CLEVR-shape (B=64, S=50, KB=14x14, d=512, p=4) FORWARD ONLY on one MI355X: evaluation
+    mode (no dropout), nothing kept for a backward pass."""
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
+    vq, words, lengths, kb = macx.configs.synthetic_inputs(B, S, N, D, seed=seed)
+    params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(seed)).to(dev)
+    vqd, wd, kbd, ld = vq.to(dev), words.to(dev), kb.to(dev), lengths.to(dev)
+
+    def fwd():
+        with torch.no_grad():
+            cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=ld, knowledgeBase=kbd,
+                                memoryDropout=1.0, readDropout=1.0, writeDropout=1.0, batchSize=B, train=False, config=cfg,
+                                params=params)
+            return cell.run().memory
+
+    for _ in range(6):
+        fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fwd()
+    torch.cuda.synchronize()
+    dt_eager = (time.perf_counter() - t0) / steps
+    # the same run replayed from one captured HIP graph (macx.CapturedForward): ~70 launches of 5-80 us each are host-bound when
+    # issued one ctypes call at a time; the batch is copied into the captured run's input tensors inside the timed region
+    cap = macx.CapturedForward(cfg, params, B, S, N)
+    ref = fwd()
+    got = cap(vqd, wd, ld, kbd)
+    torch.cuda.synchronize()
+    if not torch.equal(ref, got):
+        raise SystemExit("captured forward differs from the eager forward")
+    for _ in range(6):
+        cap(vqd, wd, ld, kbd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cap(vqd, wd, ld, kbd)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    units = 4 + 3 * (p - 1)            # knowledge-base products executed: step 0 all four, later steps reuse X
+    executed = 3.0 * units * 2.0 * B * N * D * D
+    return {"value": round(B / dt, 1), "unit": "questions/s", "ms_per_batch": round(dt * 1e3, 3), "steps": steps, "p": p, "batch": B,
+            "launch": "one captured HIP graph per batch (inputs copied in); eager ctypes launches: %.3f ms per batch = %.0f questions/s"
+                      % (dt_eager * 1e3, B / dt_eager),
+            "hoist": "evaluation has no read dropout, so the projected knowledge base X = KB Wx + bx is step-invariant: step 0 "
+                     "computes it, steps 1..p-1 read it back (the reference's graph recomputes it per step, ops.py:688)",
+            "reference_flops_per_question": p * flops_per_question_step(),
+            "roofline": {"bound": "mfma", "executed_tflops": round(executed / dt / 1e12, 1), "peak": PEAK_BF16_MFMA / 1e12,
+                         "frac": round(executed / dt / PEAK_BF16_MFMA, 4),
+                         "note": "whole forward pass (launch gaps and the [B,d] kernels included) over the fp16-pipe FLOPs it executes"}}
+
+
+def train_b128_p12(macx, dev, dist, seed, steps=8):
+    """BASELINE configs[2]: netLength 12, batch 128, fwd + bwd + global-norm clip + Adam + EMA (model.py:615-669) on one MI355X."""
+    b, p = 128, 12
+    step, params, _, _ = make_step(macx, dev, dist, 1, 0, b, p, seed)
+    opt = macx.optim.FlatAdamEMA(params.tensors(), lr=1e-4, clip_norm=8.0, ema_decay=0.999)
+
+    def one(i):
+        step(i)
+        opt.step()
+
+    for i in range(4):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(4 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
+    F = flops_per_question_step()
+    out = {"value": round(b / dt, 1), "unit": "questions/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "p": p, "batch": b,
+           "includes": "cell fwd + bwd (train-mode dropout) + clip + Adam + EMA over the cell's %d parameters"
+                       % sum(t.numel() for t in params.tensors()),
+           "whole_step_fp32_equiv_frac": round(b / dt * 3 * p * F / PEAK_FP32_MFMA, 4),
+           "executed_fp16_frac": round(b / dt * 3 * (3 * p * F) / PEAK_BF16_MFMA, 4)}
+    out.update(run_bytes(macx, cfg, b, p))
+    return out
+
+
 def time_steps(step, steps, warmup, prime, barrier, world, dev, dist):
     for i in range(prime + warmup):
         step(i)
@@ -175,7 +265,7 @@ def make_step(macx, dev, dist, world, rank, global_batch, p, seed):
     # flight it was seen to stall for seconds, so it gets the single all-reduce.  MACX_BENCH_BUCKET=single|overlap overrides.
     kind = os.environ.get("MACX_BENCH_BUCKET") or ("overlap" if dist.get_backend() == "nccl" else "single") if world > 1 else None
     if kind == "single":
-        bucket = macx.dp.GradBucket(params.tensors(), flat=params.grad_buffer())
+        bucket = macx.dp.GradBucket(params.tensors(), params=params)
         bucket.begin_step = lambda shard, glob: None
     else:
         bucket = macx.dp.OverlappedBuckets(params) if world > 1 else None
@@ -207,6 +297,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-level", action="store_true")
     ap.add_argument("--no-native", action="store_true", help="skip the comparison legs on the other two kernel families")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip BASELINE configs[1] (forward only, p=4) and configs[2] (B=128, Adam+EMA)")
     ap.add_argument("--no-extra-dp", action="store_true", help="N > 1: only the metric's (strong-scaling) configuration")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -215,12 +306,33 @@ def main():
     args = ap.parse_args()
 
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MAC cell has no CPU path")
     ndev = torch.cuda.device_count()
+    shared = os.environ.get("MACX_BENCH_BACKEND", "nccl") != "nccl"       # gloo: ranks may share one GPU (exercises the path only)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: become the launcher of N ranks, one process per GPU over RCCL -- the same command
+        # line the driver uses (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+        if ndev < args.gpus and not shared:
+            raise SystemExit("bench.py --gpus %d: this node has %d GPU(s) visible (RCCL needs one device per rank; "
+                             "MACX_BENCH_BACKEND=gloo lets ranks share a GPU to exercise the path)" % (args.gpus, ndev))
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d)"
+                         % (args.gpus, world, args.gpus, args.gpus))
+    if world > ndev and not shared:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, ndev))
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
     backend = None
@@ -289,7 +401,35 @@ def main():
         k_flops = 2.0 * Bp * N * D * D
         nrep = 32
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        chain_ms = None
         if mode == 2:
+            # the read unit's forward chain kernel (KB -> X -> H1 -> I2 -> logits, one launch per cell step): the library re-launches
+            # it between two HIP events on this stream (macx_read_chain_time), rotating the output buffers over the run's p steps
+            cfg_r = macx.configs.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
+            vq_r, w_r, len_r, _ = macx.configs.synthetic_inputs(Bp, S, N, D, seed=seed)
+            vqd_r, wd_r, ld_r = vq_r.to(dev), w_r.to(dev), len_r.to(dev)
+            cell_r = macx.MACCell(vecQuestions=vqd_r.detach(), questionWords=wd_r.detach(), questionCntxWords=wd_r.detach(),
+                                  questionLengths=ld_r, knowledgeBase=kbd.detach(), memoryDropout=cfg_r.memoryDropout,
+                                  readDropout=cfg_r.readDropout, writeDropout=cfg_r.writeDropout, batchSize=Bp, train=True,
+                                  config=cfg_r, params=params, seed=seed)
+            run = macx.cell._Run(cell_r, True)
+            run.begin()
+            run.step(0)
+            ms = C.c_float(0.0)
+            rc = L.macx_read_chain_time(*run._common()[:7], 0, 48, C.byref(ms), run.stream)
+            if rc == 0:
+                chain_ms = float(ms.value)
+            del run, cell_r
+        if chain_ms is not None:
+            k_ms = chain_ms
+            # reference op count of what the launch computes: projX 2 N d^2 + memKbProj 4 N d^2 (K = 2d) + memKbProj_2
+            # 2 N d^2 per question = 4 x 2 (B N) d^2
+            k_flops = 4 * 2.0 * Bp * N * D * D
+            c_ms = None
+            kname = ("chain_fwd_kernel<512> (read unit forward: dropout(KB) -> X -> H1 -> I2 -> attention logits in one launch; H2 tiles "
+                     "stay in LDS between the products; 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)")
+            terms, pipe = 3, "fp16 (v_mfma_f32_16x16x32_f16)"
+        elif mode == 2:
             # the library launches the kernel KREP times per call (C-side loop, read once from the environment) so that the
             # python / ctypes cost of a call -- tens of microseconds on some hosts, more than the kernel -- drops out of the
             # HIP-event interval
@@ -345,7 +485,7 @@ def main():
         peak = PEAK_BF16_MFMA if mode else PEAK_FP32_MFMA
         prof = {}
         try:   # per-launch HBM bytes (PMC) and in-step kernel averages (rocprofv3 --kernel-trace), written by tools/profile_round.sh
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline_inputs.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r03_roofline_inputs.json")))
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": kname,
@@ -356,7 +496,9 @@ def main():
                     "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": k_flops,
                     "algorithmic_tflops": round(alg / 1e12, 2),
                     "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("source"),
-                    "algorithmic_bytes_per_launch": 2 * Bp * N * D * 4 + D * D * 4,
+                    # chain kernel: the fp32 knowledge base in; dropout(KB), X, H1, I2 out as H2 (4 B per element) + keep bits; 4 weights
+                    "algorithmic_bytes_per_launch": ((1 + 4) * Bp * N * D * 4 + 2 * Bp * N * D // 8 + 4 * D * D * 4) if chain_ms is not None
+                                                    else 2 * Bp * N * D * 4 + D * D * 4,
                     "in_step_kernel_ms": prof.get("in_step_kernel_ms"),
                     # the whole step priced by the REFERENCE's op count (3 p F per question) against the f32-input MFMA
                     # peak, the arithmetic the metric is stated in
@@ -388,7 +530,8 @@ def main():
                           "global_batch": global_batch, "parallelism": "dp%d" % world,
                           "collective": None if world == 1 else "%s all-reduce of the flat gradient buffer (RCCL: in two buckets, the first overlapped with the last phase of the backward pass on a side stream), world size %d" % (
                               "RCCL (backend nccl)" if backend == "nccl" else backend, dist.get_world_size()),
-                          "flops_per_question_fwd_bwd": 3 * p * F},
+                          "flops_per_question_fwd_bwd": 3 * p * F,
+                          **run_bytes(macx, macx.configs.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D), bl, p)},
                "roofline": roofline}
         out.update(extra)
         if world == 1 and mode == 2 and not args.no_native:
@@ -402,6 +545,10 @@ def main():
                 del st3
             L.macx_gemm_mode(2)
             out["other_families"] = fam
+        if world == 1 and not args.no_extra_legs:
+            # BASELINE.json configs[1] and configs[2]
+            out["fwd_only_p4"] = fwd_only_p4(macx, dev, seed)
+            out["train_b128_p12_adam_ema"] = train_b128_p12(macx, dev, dist, seed)
         if world == 1 and not args.no_model_level:
             out["model_level"] = model_level(macx, dev, seed)
         if world == 1 and not args.no_cpu_baseline:

@@ -346,6 +346,14 @@ int macx_h2_gemm_planes(const float* hA, int B, int N, int K, const float* Wh, i
                         void* stream);
 int macx_h2_gemm(const float* A, int B, int N, int K, const float* W, int n_out, const float* bias, int act, float* out,
                  float* ws, size_t ws_floats, void* stream);
+/* bench / profiling hook (mode MACX_GEMM_H2, d <= 512, N >= 16): the kernel that runs the read unit's three knowledge-base
+ * products of one step -- dropout(KB) -> X -> H1 -> I2 -> attention logits (mac_cell.py:230-266, ops.py:668-725;
+ * mac-network_amd/csrc/macx_chain_h2.hip.h) -- re-launched `reps` times on `stream` between two HIP events; *ms_out = average
+ * milliseconds per launch.  `saved` comes from macx_cell_begin + macx_cell_step(.., step) with keep = 1; launch r writes the
+ * buffers of step (step + r) % p, so the run must not be differentiated afterwards.  MACX_EUNSUPPORTED when this shape /
+ * family does not run on that kernel. */
+int macx_read_chain_time(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*, const macx_inputs*,
+                         float* saved, size_t saved_floats, int step, int reps, float* ms_out, void* stream);
 /* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688) on the knowledge-base GEMM.
  * `W_packed` from macx_pack_weight(Wx, d, d, macx_gemm_mode(-1) ? MACX_PACK_BF16X3 : MACX_PACK_F32MFMA);
  * `drop_ws` >= B*N*d + B*N*d/32 floats of scratch for the dropped KB and its keep bits (may be NULL when keep_read == 1). */
@@ -467,7 +475,8 @@ int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint
  *            reads were observed), 8 epilogue without its global stores, 32 / 64 re-read K-slice 0 of A / of the weights
  *            (cache-hot), 128 weight-gradient contractions on the f32 TN kernel, 256 S_b kernel on the f32 kernel
  *   key 2  forced row tiles per GEMM workgroup (0 = automatic | 1 | 2 | 4 | 7 | 13)
- *   key 3  = macx_gemm_mode */
+ *   key 3  = macx_gemm_mode
+ *   key 4  0: the read unit's products as separate launches (A/B against the chain kernels of macx_chain_h2.hip.h); 1: default */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

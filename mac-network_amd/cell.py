@@ -109,13 +109,15 @@ class _Run:
         present = [f for f in self.params.fields if f in self._ptensors]
         sizes = [(self._ptensors[f].numel() + 3) & ~3 for f in present]          # 16-byte aligned views
         # the parameters' persistent flat gradient buffer (one fill instead of one per parameter; the views below become the
-        # parameters' .grad, so a flat all-reduce / optimizer needs no gather).  A second backward before the first one's
-        # gradients are consumed (gradient accumulation across calls) would overwrite them: such callers get a fresh buffer.
+        # parameters' .grad, so a flat all-reduce / optimizer needs no gather) -- only for a registered flat consumer and only
+        # once per step: a second cell run inside the same backward pass (micro-batches, two towers on one device), or a
+        # caller that keeps torch.autograd.grad results across calls, gets a buffer of its own.
         flat = None
-        if hasattr(self.params, "grad_buffer") and present == list(self.params.fields):
-            buf = self.params.grad_buffer()
-            if buf.numel() == sum(sizes) and all(getattr(self.params, f).grad is None for f in present):
-                flat = buf.zero_()
+        if hasattr(self.params, "claim_grad_buffer") and present == list(self.params.fields):
+            if all(getattr(self.params, f).grad is None for f in present):
+                buf = self.params.claim_grad_buffer()          # None: no flat consumer, or already handed out this step
+                if buf is not None and buf.numel() == sum(sizes):
+                    flat = buf
         if flat is None:
             flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         off = 0
@@ -194,6 +196,9 @@ class MACCell:
         try:
             freeze(config if config is not None else SimpleNamespace())
         except UnsupportedOptions:
+            if gemm is not None:
+                raise UnsupportedOptions("gemm=%r selects the kernel family of the FUSED read unit; this option set runs on the "
+                                         "generic one-kernel-per-op path, which has no such choice" % (gemm,))
             from .generic import GenericMACCell
             return GenericMACCell(*args, config=config, **kw)
         return super().__new__(cls)

@@ -58,6 +58,20 @@ def load_reference(net, d, use_ema=False, strict=True):
             if k.endswith(EMA_SUFFIX):
                 src[k[:-len(EMA_SUFFIX)]] = src[k]
     missing, bad = [], []
+    lazy = [m for m in _modules(net) if getattr(m, "lazy_scopes", None)]
+    for m in lazy:
+        # a module whose variables only appear on first use (generic.GenericParams before the first forward pass) has nothing to
+        # ask for yet: hand it every model variable stored under its scope, so that the first forward finds them instead of
+        # drawing fresh ones
+        scoped = {k: v for k, v in src.items() if k.startswith(tuple(m.lazy_scopes)) and not k.endswith(EMA_SUFFIX)
+                  and "/Adam" not in k and "/ExponentialMovingAverage" not in k}
+        have_now = set(m.to_reference_dict())
+        new = {k: v for k, v in scoped.items() if k not in have_now}
+        if new:
+            m.load_reference_dict(new)
+        if strict and not m.tensors():
+            raise KeyError("no variable under %s in the source: the lazily built module would start from random weights"
+                           % (m.lazy_scopes,))
     for m in _modules(net):
         want = m.to_reference_dict()
         for k, w in want.items():

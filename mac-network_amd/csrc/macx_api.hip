@@ -355,6 +355,54 @@ int check_impl(const macx_opts* o, const macx_shapes* s) {
   return MACX_OK;
 }
 
+// the parameter block of the read unit's forward chain kernel for step `i`; `ob`: the step whose X / H1 / I2 / KBd / keep-bit
+// buffers receive the outputs (= i in a run; the timing hook rotates it)
+ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                         const macx_inputs* in, float* saved, const SavedLayout& L, int keep, int i, int ob) {
+  const int B = s->B, N = s->N, d = s->d;
+  const int R = B * N;
+  const size_t Bd = (size_t)B * d, dd_ = (size_t)d * d;
+  const bool rdrop = dp->keep_read < 1.0f;
+  auto wref = [&](size_t off) { return ChainW{reinterpret_cast<const char*>(saved + off), reinterpret_cast<const int*>(saved + off) + dd_}; };
+  ChainFwdP c;
+  memset(&c, 0, sizeof(c));
+  c.M = R; c.N = N; c.d = d;
+  // without read dropout the projected knowledge base is step-invariant: inference reads step 0's X back; a run that
+  // keeps its activations recomputes it into the step's own buffers, as the reference's graph does (ops.py:688)
+  c.mode = (rdrop || L.act_stride != 0 || i == 0) ? 0 : 1;
+  c.dbg = (kb_gemm_dbg() >> 12) & 31;
+  c.kb = in->knowledgeBase;
+  c.first = (uint32_t)((size_t)s->b0 * N * d);
+  c.thr1 = 1u << 24; c.inv1 = 1.0f; c.thr2 = 1u << 24; c.inv2 = 1.0f;
+  if (rdrop) {
+    const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
+    const DropSpec da = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
+    c.key1 = dk.key; c.thr1 = dk.thr24; c.inv1 = dk.inv_keep;
+    c.bits1 = reinterpret_cast<uint8_t*>(saved + L.kb_bits + (size_t)ob * L.bits_stride);
+    c.key2 = da.key; c.thr2 = da.thr24; c.inv2 = da.inv_keep;
+    c.bytes2 = reinterpret_cast<uint8_t*>(saved + L.att_bits + (size_t)ob * L.bits_stride);
+  }
+  if (rdrop || i == 0) {
+    c.KBd = h2_view(rdrop ? saved + L.KBd + (size_t)ob * L.act_stride : saved + L.KBd, R, d);
+    c.qmin_KBd = reinterpret_cast<int*>(saved + L.qmin_KBd) + (rdrop ? (size_t)ob * L.qmin_stride : 0);
+  }
+  c.Wx = wref(L.wx_p); c.W1a = wref(L.w1a_p); c.W1b = wref(L.w1b_p); c.W2 = wref(L.w2_p);
+  c.bx = P->projX_b; c.b1 = P->memKbProj_b; c.b2 = P->memKbProj2_b;
+  c.act1 = o->read_mem_act; c.act2 = o->read_ctrl_act;
+  c.y = saved + L.y + (size_t)i * Bd;
+  c.c = saved + L.seg[MACX_SEG_CONTROLS] + (size_t)(i + 1) * Bd;
+  c.wk = P->kbLogits_w;
+  c.X = h2_view(saved + L.X + (size_t)ob * L.act_stride, R, d);
+  c.qmin_X = reinterpret_cast<int*>(saved + L.qmin_X) + (size_t)ob * L.qmin_stride;
+  if (keep) {
+    c.H1 = h2_view(saved + L.H1 + (size_t)ob * L.act_stride, R, d);
+    c.qmin_H1 = reinterpret_cast<int*>(saved + L.qmin_H1) + (size_t)ob * L.qmin_stride;
+    c.I2 = h2_view(saved + L.I2 + (size_t)ob * L.act_stride, R, d);
+  }
+  c.logits = saved + L.logit_part;
+  return c;
+}
+
 inline bool misaligned(const void* p) { return ((uintptr_t)p & 15) != 0; }
 
 hipError_t pack(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst, hipStream_t st) {
@@ -696,32 +744,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     uint8_t* att_bytes = rdrop ? reinterpret_cast<uint8_t*>(att_bits) : nullptr;
     if (use_chain(d, s->N)) {
       // KB -> X -> H1 -> I2 -> logits in one launch (macx_chain_h2.hip.h)
-      const size_t dd_ = (size_t)d * d;
-      auto wref = [&](size_t off) { return ChainW{reinterpret_cast<const char*>(saved + off), reinterpret_cast<const int*>(saved + off) + dd_}; };
-      ChainFwdP c;
-      memset(&c, 0, sizeof(c));
-      c.M = R; c.N = N; c.d = d;
-      // without read dropout the projected knowledge base is step-invariant: inference reads step 0's X back; a run that
-      // keeps its activations recomputes it into the step's own buffers, as the reference's graph does (ops.py:688)
-      c.mode = (rdrop || L.act_stride != 0 || i == 0) ? 0 : 1;
-      c.dbg = (kb_gemm_dbg() >> 12) & 31;
-      c.kb = in->knowledgeBase;
-      c.first = (uint32_t)((size_t)s->b0 * N * d);
-      c.thr1 = 1u << 24; c.inv1 = 1.0f; c.thr2 = 1u << 24; c.inv2 = 1.0f;
-      if (rdrop) {
-        const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
-        const DropSpec da = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
-        c.key1 = dk.key; c.thr1 = dk.thr24; c.inv1 = dk.inv_keep; c.bits1 = reinterpret_cast<uint8_t*>(kb_bits);
-        c.key2 = da.key; c.thr2 = da.thr24; c.inv2 = da.inv_keep; c.bytes2 = att_bytes;
-      }
-      if (rdrop || i == 0) { c.KBd = hKB; c.qmin_KBd = qKB; }
-      c.Wx = wref(L.wx_p); c.W1a = wref(L.w1a_p); c.W1b = wref(L.w1b_p); c.W2 = wref(L.w2_p);
-      c.bx = P->projX_b; c.b1 = P->memKbProj_b; c.b2 = P->memKbProj2_b;
-      c.act1 = o->read_mem_act; c.act2 = o->read_ctrl_act;
-      c.y = y; c.c = c_i; c.wk = P->kbLogits_w;
-      c.X = hX; c.qmin_X = qX;
-      if (keep) { c.H1 = hH1; c.qmin_H1 = qH1; c.I2 = hI2; }
-      c.logits = saved + L.logit_part;
+      const ChainFwdP c = make_chain_fwd(o, s, dp, P, in, saved, L, keep, i, i);
       CK(chain_fwd_launch(c, st));
     } else {
     if (rdrop || i == 0) {
@@ -2371,6 +2394,36 @@ int macx_h2_gemm(const float* A, int B, int N, int K, const float* Wm, int n_out
   CKI(macx_h2_pack_weight(Wm, K, n_out, 0, wp, stream));
   CKI(macx_h2_gemm_planes(hA, B, N, K, wp, n_out, bias, act, hO, stream));
   return macx_h2_to_f32(hO, B * N, n_out, out, stream);
+}
+
+/* bench / profiling hook: the read unit's forward chain kernel of `step`, re-launched `reps` times on `stream` between two HIP
+   events; *ms_out = average milliseconds per launch.  `saved` must come from macx_cell_begin + macx_cell_step(.., step) with
+   keep = 1 (the step's y and control exist then); the outputs of launch r go to the buffers of step (step + r) % p, so the run
+   must not be differentiated afterwards. */
+int macx_read_chain_time(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                         const macx_inputs* in, float* saved, size_t saved_floats, int step, int reps, float* ms_out,
+                         void* stream) {
+  ModeScope ms(o);
+  CKI(check_impl(o, s));
+  if (!dp || !P || !in || !saved || !ms_out || reps < 1 || step < 0 || step >= s->p) return MACX_EINVAL;
+  if (!use_chain(s->d, s->N)) return MACX_EUNSUPPORTED;
+  const SavedLayout L = make_saved(o, s, 1);
+  if (saved_floats < L.total) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  CK(chain_fwd_launch(make_chain_fwd(o, s, dp, P, in, saved, L, 1, step, step), st));      // untimed: code object, LDS attribute
+  CK(hipEventRecord(e0, st));
+  for (int r = 0; r < reps; ++r) CK(chain_fwd_launch(make_chain_fwd(o, s, dp, P, in, saved, L, 1, step, (step + r) % s->p), st));
+  CK(hipEventRecord(e1, st));
+  CK(hipEventSynchronize(e1));
+  float t = 0.f;
+  CK(hipEventElapsedTime(&t, e0, e1));
+  *ms_out = t / reps;
+  CK(hipEventDestroy(e0));
+  CK(hipEventDestroy(e1));
+  return MACX_OK;
 }
 
 int macx_debug_set(int key, int value) {

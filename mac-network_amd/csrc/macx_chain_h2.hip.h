@@ -81,8 +81,8 @@ struct ChainGeo {
   static constexpr int IT = KG / 8;                  // conversion passes: slot columns per lane (16 rows x 4 slot columns per wave step)
   static constexpr size_t P_BYTES = (size_t)4 * R * D;
   static constexpr int QS = 5;                       // backward: questions a tile can touch (N >= 16) -- their control vectors are staged in LDS
-  // P | sMax [8][R] | sPart [8][R] | sE [R] | sE2 [R] | sCol [2][D] | sW [D] | sC [QS][D] | sPf [8][64]
-  static constexpr size_t LDS = P_BYTES + (size_t)R * (8 + 8 + 1 + 1) * 4 + (size_t)(2 + 1 + QS) * D * 4 + 8 * 256;
+  // P | sMax [8][R] | sPart [8][R] | sE [R] | sE2 [R] | sCol [2][D] | sW [D] | sC [QS][D]
+  static constexpr size_t LDS = P_BYTES + (size_t)R * (8 + 8 + 1 + 1) * 4 + (size_t)(2 + 1 + QS) * D * 4;
   static_assert(D % 128 == 0 && D >= 128 && D <= 512, "one workgroup holds 64 rows x D as H2 planes in LDS");
 };
 
@@ -99,7 +99,6 @@ struct ChainCtx {
   float* sCol;      // [2][D] column sums of the two row halves
   float* sW;        // [D] backward: the logits weight
   float* sC;        // [QS][D] backward: control vectors of the tile's questions
-  char* sPf;        // [8][256 B] landing zone of prefetch DMAs (never read)
   int tid, lane, wave, li, lg;
   int wr, wc, colbase, rowbase;
   int M, N, nvalid;
@@ -115,7 +114,6 @@ struct ChainCtx {
     sCol = reinterpret_cast<float*>(sE2 + R);
     sW = sCol + 2 * D;
     sC = sW + D;
-    sPf = reinterpret_cast<char*>(sC + G::QS * D);
     tid = threadIdx.x; lane = tid & 63;
     wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     li = lane & 15; lg = lane >> 4;
@@ -658,6 +656,8 @@ inline hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
 struct ChainBwdP {
   int M, N, d;
   int dbg;                  // timing knobs: 1 stop after stage B0, 2 after B1; dbg >> 3 = K-loop variant
+                            // (tried: pulling the kept H1 rows toward L2 by DMA from inside the K loop of stage B1, whose
+                            // epilogue reads them -- no change, 4.399 vs 4.400 ms per step)
   // stage B0: dI2 from the kept I2
   const float* att;         // [B][N] knowledge-base attention of the step
   const float* da;          // [B][N] dinfo . KB[n] (kb_att_da_kernel)
@@ -854,19 +854,6 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   // =====================================================================================================================
   // stage B1: dI1 = (dI2 W2^T) * act'(H1), act' from the kept activation OUTPUT
   x.zero_acc(acc);
-  {
-    // the kept H1 rows of this tile are wanted by the epilogue below: pull their lines into L2 now (DMA into a scratch word:
-    // no register, nothing waits for it; older than every load of the K loop, so the loop's wait counts only over-wait)
-    const size_t Rp = p.H1.Rp();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int f = x.tid + 512 * k;                         // 2 planes x KG slot columns x 8 lines of 128 B
-      if (f < 2 * KG * 8) {
-        const char* src = p.H1.base + ((size_t)(f >> 3) * Rp + min(x.grow0, (size_t)M - 1)) * 16 + (f & 7) * 128;
-        dma4b(src, lds_addr_of(x.sPf) + x.wave * 256);
-      }
-    }
-  }
   x.template kloop<KV>(acc, p.W2T.planes);
   {
     const int eW = *p.W2T.exp;

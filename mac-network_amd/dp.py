@@ -28,7 +28,14 @@ class GradBucket:
     view of that buffer at its expected offset the all-reduce runs on it in place -- no gather copy; anything else (a
     gradient produced elsewhere, accumulated, or absent) falls back to one gather kernel into the buffer."""
 
-    def __init__(self, tensors, flat=None):
+    def __init__(self, tensors, flat=None, params=None):
+        """params: the MACCellParams whose grad_buffer() `flat` is -- registers this bucket as its flat consumer (the backward
+        pass then writes into the buffer, once per step) and releases the buffer again after every all-reduce."""
+        self.owner = params
+        if params is not None:
+            if flat is None:
+                flat = params.grad_buffer()
+            params.register_grad_buffer_user()
         self.tensors = list(tensors)
         self.sizes = [t.numel() for t in self.tensors]
         self.offsets, off = [], 0
@@ -68,7 +75,14 @@ class GradBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         for t, o, n in zip(self.tensors, self.offsets, self.sizes):            # gradients are views of the reduced buffer
             t.grad = self.flat[o:o + n].view_as(t)
+        self._release()
         return self.flat
+
+    def _release(self):
+        """The step's gradients are final: the next backward pass may take the persistent buffer again (the caller drops the
+        .grad views -- zero_grad / an optimizer step -- before it runs, as with any accumulate-free training loop)."""
+        if self.owner is not None:
+            self.owner.release_grad_buffer()
 
 
 class OverlappedBuckets(GradBucket):
@@ -89,7 +103,7 @@ class OverlappedBuckets(GradBucket):
     """
 
     def __init__(self, params, group=None):
-        super().__init__(params.tensors(), flat=params.grad_buffer())
+        super().__init__(params.tensors(), flat=params.grad_buffer(), params=params)
         self.early = params.early_floats()
         self.group = group
         self.weight = 1.0
@@ -143,4 +157,5 @@ class OverlappedBuckets(GradBucket):
         self.zero_copy_steps += 1
         for t, o, n in zip(self.tensors, self.offsets, self.sizes):
             t.grad = self.flat[o:o + n].view_as(t)
+        self._release()
         return self.flat

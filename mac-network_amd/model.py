@@ -32,6 +32,7 @@ class MACNetCore(torch.nn.Module):
             # one forward pass -- or load a checkpoint into `net.cell` first
             from .generic import GenericParams
             self.cell = GenericParams(generator=generator)
+            self.cell.lazy_scopes = ("MACnetwork/",)       # checkpoint.load_*: adopt every variable of the cell's scope
         self.out = OutputClassifier(config, answerWordsNum=answerWordsNum, generator=generator)
 
     def tensors(self):

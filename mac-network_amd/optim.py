@@ -17,14 +17,17 @@ class FlatAdamEMA:
         if not self.params or not self.params[0].is_cuda:
             raise RuntimeError("FlatAdamEMA needs parameters on the HIP device")
         self.sizes = [p.numel() for p in self.params]
-        n = sum(self.sizes)
+        # 16-byte aligned segments: the layout of MACCellParams.grad_buffer() and dp.GradBucket.flat, so that either can be
+        # handed to step(flat_grad=...) as it is (pad floats stay zero: gradient, moments and update)
+        self.offsets, n = [], 0
+        for k in self.sizes:
+            self.offsets.append(n)
+            n += (k + 3) & ~3
         dev = self.params[0].device
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p, k in zip(self.params, self.sizes):          # parameters become views of the flat buffer
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, k, off in zip(self.params, self.sizes, self.offsets):          # parameters become views of the flat buffer
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p.data)
-            off += k
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -37,11 +40,19 @@ class FlatAdamEMA:
         self.t = 0
 
     def step(self, flat_grad=None):
-        """flat_grad: an already flat gradient (e.g. GradBucket.flat after the all-reduce); otherwise the
-        .grad of every parameter is gathered with one torch.cat."""
+        """flat_grad: an already flat gradient in THIS layout -- the parameters in order, each segment padded to a multiple of
+        4 floats (dp.GradBucket.flat after the all-reduce, MACCellParams.grad_buffer() for a cell-only optimizer); a buffer of
+        any other size is rejected.  Without it the .grad of every parameter is gathered."""
         if flat_grad is None:
-            torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params], out=self.grad)
+            for p, k, off in zip(self.params, self.sizes, self.offsets):
+                if p.grad is None:
+                    self.grad[off:off + k].zero_()
+                else:
+                    self.grad[off:off + k].copy_(p.grad.reshape(-1))
             flat_grad = self.grad
+        elif flat_grad.numel() != self.flat.numel() or flat_grad.dtype != torch.float32:
+            raise ValueError("flat_grad holds %d floats, this optimizer's layout %d (segments padded to 4 floats, parameters in "
+                             "the order given at construction)" % (flat_grad.numel(), self.flat.numel()))
         self.t += 1
         L = _lib.lib()
         dev = self.flat.device
@@ -53,8 +64,4 @@ class FlatAdamEMA:
 
     def ema_state(self):
         """{index: tensor} views of the EMA shadow, shaped like the parameters (what emaSaver restores, main.py:711-729)."""
-        out, off = [], 0
-        for p, k in zip(self.params, self.sizes):
-            out.append(self.ema[off:off + k].view_as(p))
-            off += k
-        return out
+        return [self.ema[off:off + k].view_as(p) for p, k, off in zip(self.params, self.sizes, self.offsets)]

@@ -118,7 +118,9 @@ class MACCellParams(torch.nn.Module):
     def grad_buffer(self):
         """Persistent flat fp32 buffer the backward pass writes the parameter gradients into (16-byte aligned segments in
         `fields` order): the gradients autograd hands out are views of it, so a data-parallel all-reduce (macx.dp.GradBucket)
-        and a flat optimizer can run on it without a gather copy.  Allocated on first use, reused by every backward."""
+        or a flat optimizer over exactly these tensors (optim.FlatAdamEMA uses the same padded layout) can run on it without a
+        gather copy.  Allocated on first use; the backward pass only writes into it for a registered consumer
+        (register_grad_buffer_user), once per step."""
         dev = self.tensors()[0].device
         n = sum((t.numel() + 3) & ~3 for t in self.tensors())
         buf = getattr(self, "_grad_flat", None)
@@ -126,6 +128,24 @@ class MACCellParams(torch.nn.Module):
             buf = torch.zeros(n, dtype=torch.float32, device=dev)
             object.__setattr__(self, "_grad_flat", buf)
         return buf
+
+    def register_grad_buffer_user(self):
+        """A flat consumer (dp.GradBucket / OverlappedBuckets, a flat optimizer) announces itself: from now on the backward pass
+        writes into grad_buffer() -- once per step; the consumer calls release_grad_buffer() when it is done with the step's
+        gradients.  Without a registered consumer every backward pass gets a buffer of its own (two cell runs in one backward,
+        torch.autograd.grad results that must survive the next call)."""
+        object.__setattr__(self, "_grad_flat_registered", True)
+        object.__setattr__(self, "_grad_flat_busy", False)
+
+    def claim_grad_buffer(self):
+        """The persistent buffer, zeroed, if a consumer registered and this step's buffer has not been handed out yet; else None."""
+        if not getattr(self, "_grad_flat_registered", False) or getattr(self, "_grad_flat_busy", False):
+            return None
+        object.__setattr__(self, "_grad_flat_busy", True)
+        return self.grad_buffer().zero_()
+
+    def release_grad_buffer(self):
+        object.__setattr__(self, "_grad_flat_busy", False)
 
     def to_reference_dict(self):
         """{TF variable name: tensor} with the reference's shapes (scalar biases are 0-d)."""

@@ -156,6 +156,63 @@ def test_checkpoint_roundtrip_reference_names(tmp_path):
         macx.checkpoint.load_reference(net, bad)
 
 
+def test_checkpoint_reaches_a_lazily_built_cell(tmp_path):
+    """The reference's DEFAULT configuration runs on the generic path, whose cell variables only appear on first use: a
+    checkpoint loaded before the first forward pass must still land in the cell (it used to be skipped silently, and the first
+    forward then drew random weights), and a strict load from a source without cell variables must fail."""
+    import macx
+    from oracle import mac_oracle as mo
+    dcfg = mo.default_config(netLength=2, memDim=128, ctrlDim=128, attDim=128)
+    vq, words, lengths, kb = mo.synthetic_inputs(2, 5, 6, 128, seed=0)
+    vs = mo.VarStore(generator=torch.Generator().manual_seed(3))
+    mo.mac_network(dcfg, vs, vq, words, words, lengths, kb)                 # creates the cell's variables under their reference names
+    src = {"macModel/" + k + ":0": v for k, v in vs.params.items()}
+    assert any(k.startswith("macModel/MACnetwork/") for k in src)
+    net = macx.MACNetCore(dcfg, H=3, W=2, imageInDim=128, answerWordsNum=5, generator=torch.Generator().manual_seed(0))
+    assert isinstance(net.cell, macx.GenericParams) and not net.cell.tensors()
+    full = dict(macx.checkpoint.reference_state_dict(net))                  # stem + classifier of this net ...
+    full.update(src)                                                        # ... + the cell of the "checkpoint"
+    full["macModel/MACnetwork/initMem/Adam:0"] = torch.zeros(128)           # optimizer slots are not model variables
+    macx.checkpoint.load_reference(net, full)
+    got = net.cell.to_reference_dict()
+    assert set(got) == set(vs.params) and all(torch.equal(got[k], vs.params[k].to(torch.float32)) for k in got)
+    # the variables it now holds round-trip through a file
+    path = str(tmp_path / "lazy.npz")
+    macx.checkpoint.save_npz(path, net)
+    net2 = macx.MACNetCore(dcfg, H=3, W=2, imageInDim=128, answerWordsNum=5, generator=torch.Generator().manual_seed(1))
+    assert macx.checkpoint.load_npz(path, net2) == []
+    assert all(torch.equal(a, b) for a, b in zip(net.cell.tensors(), net2.cell.tensors()))
+    # strict: a source without a single cell variable is an error, not a silently random cell
+    net3 = macx.MACNetCore(dcfg, H=3, W=2, imageInDim=128, answerWordsNum=5, generator=torch.Generator().manual_seed(2))
+    with pytest.raises(KeyError):
+        macx.checkpoint.load_reference(net3, macx.checkpoint.reference_state_dict(net3))
+
+
+def test_flat_optimizer_shares_the_gradient_buffer_layout():
+    """FlatAdamEMA packs its parameters like MACCellParams.grad_buffer() / dp.GradBucket.flat (segments padded to 4 floats;
+    the scalar logits biases make tight packing differ), and rejects a flat gradient of any other size."""
+    import macx
+    cfg = macx.configs.flag_file_config("args", netLength=2, memDim=128, ctrlDim=128, attDim=128)
+    prm = macx.MACCellParams(cfg, 2)
+    sizes = [t.numel() for t in prm.tensors()]
+    assert any(n % 4 for n in sizes)
+    padded = sum((n + 3) & ~3 for n in sizes)
+    assert prm.grad_buffer().numel() == padded and padded != sum(sizes)
+    bucket = macx.dp.GradBucket(prm.tensors(), params=prm)
+    assert bucket.flat.data_ptr() == prm.grad_buffer().data_ptr()
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 3) & ~3
+    assert bucket.offsets == offs
+    # one backward pass per step may take the persistent buffer; a second one before the release gets its own
+    assert prm.claim_grad_buffer() is not None and prm.claim_grad_buffer() is None
+    prm.release_grad_buffer()
+    assert prm.claim_grad_buffer() is not None
+    # without a registered consumer nobody is handed the persistent buffer
+    assert macx.MACCellParams(cfg, 2).claim_grad_buffer() is None
+
+
 def test_product_configs_match_the_oracle_copies():
     """macx.configs (what bench.py / smoke() build workloads from) and the oracle's own copies describe the same flag files
     and draw the same synthetic inputs -- the measured path never imports oracle/."""

@@ -2,7 +2,7 @@
 # tools/knob_profile.sh "<mask> <mask> ..." [kernel-name regex]  (GPU box): per-kernel durations of the bench step under the
 # measurement knobs of macx_debug_set(1, mask) -- results are WRONG under a non-zero mask, only the timing means something.
 export TMPDIR=/tmp
-F="--steps 6 --warmup 2 --no-cpu-baseline --no-model-level --no-native"
+F="--steps 6 --warmup 2 --no-cpu-baseline --no-model-level --no-native --no-extra-legs"
 for m in $1; do
   rm -rf /tmp/knob_$m
   MACX_DBG=$m timeout 300 rocprofv3 --kernel-trace -d /tmp/knob_$m -o k -- python bench.py $F > /dev/null 2>&1

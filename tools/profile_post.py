@@ -51,18 +51,24 @@ def main(tag):
                 return k, d[k]
         return None, None
 
-    gk, gv = find(hb, r"kb_gemm_h2_kernel<13, 0, 0, false>")
+    gk, gv = find(hb, r"chain_fwd_kernel<512")
+    if not gv:
+        gk, gv = find(hb, r"kb_gemm_h2_kernel<13, 0, 0, false>")
     out = {"source": "tools/profile_round.sh %s: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of bench.py "
                      "(KiB per dispatch; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md HBM section), and --kernel-trace --stats" % tag}
     if gv:
         fetch, write = float(gv[fi]), float(gv[wi])
         out.update(kernel=gk, FETCH_SIZE_KiB=fetch, WRITE_SIZE_KiB=write, hbm_bytes_per_launch=int((2 * fetch + write) * 1024))
-    sk, sv = find(ks, r"kb_gemm_h2_kernelILi13ELi0ELi0ELb0")
+    sk, sv = find(ks, r"chain_fwd_kernelILi512ELi0")
+    if not sv:
+        sk, sv = find(ks, r"kb_gemm_h2_kernelILi13ELi0ELi0ELb0")
     if sv:
         out["in_step_kernel_ms"] = round(sv["avg_us"] / 1e3, 5)
     elem = B * N * D
     hbm = []
-    for pat, name, byts in ((r"h2_from_f32_kernel", "h2_from_f32_kernel (KB -> H2 through the read dropout, + keep bits/bytes)", elem * 8 + elem // 4),
+    for pat, name, byts in ((r"chain_bwd_kernelILi512ELi0", "chain_bwd_kernel<512> (I2, H1 H2 in; dI2, dI1, dX H2 out) -- MFMA-bound, listed for its HBM side",
+                             elem * 4 * 5),
+                            (r"h2_from_f32_kernel", "h2_from_f32_kernel (KB -> H2 through the read dropout, + keep bits/bytes)", elem * 8 + elem // 4),
                             (r"read_att_bwd_h2_kernel", "read_att_bwd_h2_kernel (I2 H2 in, dI2 H2 out)", elem * 8),
                             (r"kb_attend_kernel", "kb_attend_kernel (softmax over N + sum_n a KB)", elem * 4),
                             (r"kb_att_da_kernel", "kb_att_da_kernel (da = dr . KB)", elem * 4)):
@@ -77,4 +83,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03")

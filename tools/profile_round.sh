@@ -3,7 +3,7 @@
 # writes gpurun_out/<tag>_*: kernel-trace stats, four separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ, LDS/VALU) and the
 # roofline inputs bench.py reads (profiles/<tag>_roofline_inputs.json after `python tools/profile_post.py <tag>`, run locally).
 # Counter passes never share a run with --stats or any trace domain but the kernel trace.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
 B="python bench.py --no-cpu-baseline --no-model-level --no-native"
