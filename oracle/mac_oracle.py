@@ -132,6 +132,34 @@ def flag_file_config(name, **over):
 # -------------------------------------------------------------------------------------------------
 # variables: tf.variable_scope / tf.get_variable emulation with the reference's names
 # -------------------------------------------------------------------------------------------------
+class _ReluAtBoundary(torch.autograd.Function):
+    """max(x, 0) whose derivative is `mode` (0 or 1) where |x| <= eps * max|x|: plain ReLU jumps at 0, and a pre-activation
+    within round-off of zero falls on either side in an fp32 implementation.  Tests run the oracle under both modes and accept a
+    gradient between the two (tests/helpers.py: relu_boundary, hull_err); the forward value is torch.relu's."""
+
+    @staticmethod
+    def forward(ctx, x, mode, eps):
+        ctx.save_for_backward(x)
+        ctx.mode, ctx.eps = mode, eps
+        return torch.relu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        near = x.abs() <= ctx.eps * x.abs().max()
+        d = torch.where(near, torch.full_like(x, float(ctx.mode)), (x > 0).to(x.dtype))
+        return g * d, None, None
+
+
+RELU_BOUNDARY = None      # None: torch.relu; (mode, eps): _ReluAtBoundary -- set by tests only
+
+
+def relu_std(x):
+    if RELU_BOUNDARY is None:
+        return torch.relu(x)
+    return _ReluAtBoundary.apply(x, RELU_BOUNDARY[0], RELU_BOUNDARY[1])
+
+
 class VarStore:
     """name -> tensor.  Missing variables are created with the reference's initialisers
     (xavier-uniform for weights ops.py:20, zeros for biases ops.py:40, N(0,1) for state
@@ -286,7 +314,7 @@ class Ops:
             # config.reluAlpha's flag is commented out (config.py:221) -> AttributeError in the reference
             return torch.maximum(inp, self.config.reluAlpha * inp)
         if r == "STD":
-            return torch.relu(inp)
+            return relu_std(inp)
         # SELU: accepted by argparse (config.py:220) but no branch (ops.py:171-179): `output` unbound
         raise UnboundLocalError("local variable 'output' referenced before assignment")
 

@@ -55,3 +55,15 @@ def split_gemm(macx):
     L.macx_gemm_mode(1)
     yield
     L.macx_gemm_mode(default_gemm_mode())
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """observed parity errors of this session -> gpurun_out/parity_margins.json (see helpers.check_margin)"""
+    try:
+        import helpers
+        out = os.path.join(ROOT, "gpurun_out")
+        if helpers._MARGINS:
+            os.makedirs(out, exist_ok=True)
+            helpers.dump_margins(os.path.join(out, "parity_margins.json"))
+    except Exception:
+        pass
