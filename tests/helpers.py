@@ -52,7 +52,7 @@ def hull_err(got, a, b, floor=1e-6):
 class relu_boundary:
     """with relu_boundary(mode): the oracle's plain ReLU takes derivative `mode` (0 | 1) within eps of its jump"""
 
-    def __init__(self, mode, eps=1e-5):
+    def __init__(self, mode, eps=1e-6):
         self.v = (mode, eps)
 
     def __enter__(self):

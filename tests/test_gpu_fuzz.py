@@ -40,8 +40,7 @@ def test_fused_cell_matches_the_oracle_on_random_shapes_and_options(macx, dev, s
     control switches, variational or plain memory dropout, any keep values) and random shapes (odd batches, N from one
     cell to beyond a row tile, d in {128, 256}, 1-5 steps)."""
     import torch
-    import contextlib
-    from helpers import make_case, oracle_run, rel_err, hull_err, relu_boundary
+    from helpers import make_case, oracle_run, rel_err, relu_boundary
     from test_gpu_cell import build_cell, FWD_TOL, GRAD_TOL
     rnd = random.Random(7000 + seed)
     ran = 0
@@ -91,29 +90,39 @@ def test_fused_cell_matches_the_oracle_on_random_shapes_and_options(macx, dev, s
         ((state.memory * dmem.to(dev)).sum() + (state.control * dctl.to(dev)).sum()).backward()
         torch.cuda.synchronize()
         what = (seed, case, name, over, B, S, N, d, p, train)
-        # plain ReLU has a derivative jump at 0: a pre-activation within round-off of zero lands on the other side in fp32 than
+        # plain ReLU has a derivative jump at 0: a pre-activation within fp32 round-off of zero lands on the other side in fp32 than
         # in the fp64 oracle and moves ONE (row, column) of dI1 by its whole contribution (~5e-4 of the largest entry of dW1 /
-        # db1 / dWx / dKB; tests/case_probe.py).  The oracle therefore runs twice under --relu STD, with derivative 0 and with
-        # derivative 1 within 1e-5 of the jump, and a gradient must lie between the two (helpers.hull_err) to the SAME
-        # tolerance as everything else; where no pre-activation is near the jump the two runs coincide.
-        refs = []
-        for mode in ((0, 1) if cfg.relu == "STD" else (None,)):
-            ctx = relu_boundary(mode) if mode is not None else contextlib.nullcontext()
-            with ctx:
-                refs.append(oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=train, seed=5 + case,
-                                       need_grad=True, d_memory=dmem, d_control=dctl))
-        ref, ref1 = refs[0], refs[-1]
+        # db1 / dWx / dKB for one element; tests/case_probe.py) -- and a [B,N,d] pre-activation tensor has dozens of entries
+        # within 1e-6 of its largest magnitude around zero.  Under --relu STD the oracle therefore also runs with derivative 0
+        # and with derivative 1 at |pre-activation| <= 1e-6 max|pre-activation| (oracle._ReluAtBoundary): the distance between
+        # those two gradients is what the undecidable elements can contribute, and it is added to the tolerance of that tensor.
+        # Where no pre-activation is that close to the jump the two coincide and the tolerance is the usual one.
+        ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=train, seed=5 + case, need_grad=True,
+                         d_memory=dmem, d_control=dctl)
+        lohi = []
+        if cfg.relu == "STD":
+            for mode in (0, 1):
+                with relu_boundary(mode, 1e-6):
+                    lohi.append(oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=train, seed=5 + case,
+                                           need_grad=True, d_memory=dmem, d_control=dctl))
+
+        def undecidable(pick):
+            """relative size of what the masked elements contribute to the gradient `pick` selects from a run"""
+            if not lohi:
+                return 0.0
+            a, b = pick(lohi[0]), pick(lohi[1])
+            return 0.0 if a is None else rel_err(a, b)
         gtol = GRAD_TOL
         assert rel_err(state.memory, ref["memory"]) < FWD_TOL and rel_err(state.control, ref["control"]) < FWD_TOL, what
         for k, (got, nm) in enumerate(((vqd, "vecQ"), (wd, "words"), (kbd, "kb"))):
-            want, want1 = ref["inputs"][k], ref1["inputs"][k]
+            want = ref["inputs"][k]
             if want.grad is not None and float(want.grad.abs().max()) > 1e-9:
-                assert hull_err(got.grad, want.grad, want1.grad) < gtol, (what, nm)
+                assert rel_err(got.grad, want.grad) < gtol + undecidable(lambda r: r["inputs"][k].grad), (what, nm)
         names = macx.params.reference_names(cfg, p)
         for f in params.fields:
             gt = getattr(params, f).grad
             for refname, idx in names[f]:
-                rg, rg1 = ref["params"][refname].grad, ref1["params"][refname].grad
+                rg = ref["params"][refname].grad
                 got = gt if idx is None else gt[idx]
                 if rg is None:
                     assert float(got.abs().max()) == 0.0, (what, refname)
@@ -124,7 +133,7 @@ def test_fused_cell_matches_the_oracle_on_random_shapes_and_options(macx, dev, s
                     assert float(got.abs().max()) < 1e-6, (what, refname)
                     continue
                 floor = 5e-2 if refname.endswith("linearLayerlogits/biases/bias") else 1e-6
-                assert hull_err(got.reshape(rg.shape), rg, rg1, floor=floor) < gtol, (what, refname)
+                assert rel_err(got.reshape(rg.shape), rg, floor=floor) < gtol + undecidable(lambda r: r["params"][refname].grad), (what, refname)
         ran += 1
     assert ran >= 3
 
