@@ -1,6 +1,13 @@
 """TEST INFRASTRUCTURE.  fp64 restatement of the reference's training op (model.py:639-669):
 tf.clip_by_global_norm -> tf.train.AdamOptimizer (TF1 formulation with lr_t and epsilon-hat) ->
-tf.train.ExponentialMovingAverage.  PARITY UNPINNED (written from the TF1 documentation of those ops)."""
+tf.train.ExponentialMovingAverage (applied after the Adam update, the order an eager run of addTrainingOp gives).
+
+PINNED: MACnet.addOptimizerOp / computeGradients / addTrainingOp run unmodified on the eager TF-1.x stand-in
+(tests/ref_exec.run_reference_training) for five steps that straddle the clip threshold; this restatement, fed the gradients the
+reference computed, reproduces its variables, both Adam moments, the EMA shadows and the global norm to 1e-12
+(tests/test_reference_exec.py live, tests/test_reference_golden.py from tests/golden/reference/training_steps.npz).  The
+stand-in's AdamOptimizer / ExponentialMovingAverage are themselves restatements of TF's (training/adam.py, ApplyAdam,
+moving_averages.py) -- TensorFlow cannot be installed here."""
 import numpy as np
 
 

@@ -135,3 +135,23 @@ def hashed_reference_params(shapes, seed):
             lim = (6.0 / (shape[-2] + shape[-1])) ** 0.5
         out[name] = hashed_tensor(seed * 1000 + i, shape, lim)
     return out
+
+
+def load_training_fixture():
+    """tests/golden/reference/training_steps.npz (tests/golden/make_training_golden.py): the reference's own training op run
+    for a few steps.  Returns (hyper, names, init [name -> array], steps [dict(norm, g, p, m, v, e: name -> array)])."""
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference", "training_steps.npz")
+    z = np.load(path)
+    hyper = json.loads(bytes(z["hyper"]).decode())
+    names = json.loads(bytes(z["names"]).decode())
+    init = {n: z["init_%d" % i] for i, n in enumerate(names)}
+    steps = []
+    for t in range(hyper["steps"]):
+        steps.append(dict(norm=float(z["norm_%d" % t]),
+                          **{k: {n: z["%s_%d_%d" % (k, t, i)] for i, n in enumerate(names)} for k in "gpmve"}))
+    return hyper, names, init, steps
+
+
+def flat64(d, names):
+    return np.concatenate([np.asarray(d[n], dtype=np.float64).reshape(-1) for n in names])

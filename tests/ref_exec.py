@@ -188,3 +188,40 @@ def run_reference_encoder(cfg, questions, lengths, emb, keep_input=1.0, keep_que
     proj = (cfg.encDim != cfg.ctrlDim) or cfg.encProj                                    # model.py:785-787, as MACnet.build calls it
     words, vecQ = model.MACnet.encoder(fake, qs, tf.wrap(lengths.clone()), proj, proj, cfg.ctrlDim)
     return dict(words=words, vecQ=vecQ, variables=dict(tf.state.variables), draws=[u for _, u in tf.state.draws])
+
+
+def run_reference_training(cfg, vecQ, questionWords, questionCntxWords, lengths, kb, answers, steps, lr, preset=None, seed=0,
+                           dtype=torch.float64, answerWordsNum=7):
+    """`steps` training steps exactly as model.py strings them: MACnetwork -> outputOp -> classifier -> addAnswerLossOp
+    (evaluation-mode dropout: the optimizer is what is under test), then MACnet.addOptimizerOp (once) and, per step,
+    MACnet.computeGradients + MACnet.addTrainingOp (model.py:615-669) -- clip_by_global_norm, AdamOptimizer.apply_gradients
+    and ExponentialMovingAverage.apply as that code calls them, on the shim's restatement of those three TF classes.
+    Returns per step: the gradients the reference computed, the global norm, and the variables / Adam slots / EMA shadows
+    afterwards (name -> tensor, names without ':0')."""
+    M = load()
+    tf, model = M["tf"], M["model"]
+    tf.shim_reset(dtype=dtype, seed=seed, preset=preset, require_grad=True)
+    cfg.answerWordsNum = answerWordsNum
+    B = vecQ.shape[0]
+    fake = SimpleNamespace(dropouts={"memory": 1.0, "read": 1.0, "write": 1.0, "output": 1.0}, batchSize=B, train=True,
+                           batchNorm=None, answerLossList=[], correctNumList=[], answerAccList=[], lr=lr)
+    optimizer = model.MACnet.addOptimizerOp(fake)                       # model.py:616-620
+    ins = [tf.wrap(t.detach().to(dtype).clone()) for t in (vecQ, questionWords, questionCntxWords, kb)]
+    vq_, qw_, cw_, kb_ = ins
+    out = []
+    for step in range(steps):
+        with tf.variable_scope(tf.get_variable_scope(), reuse=(True if step > 0 else None)):
+            control, memory = model.MACnet.MACnetwork(fake, kb_, vq_, qw_, cw_, tf.wrap(lengths.clone()))
+            features, dim = model.MACnet.outputOp(fake, memory, vq_, None, None)
+            logits = model.MACnet.classifier(fake, features, dim)
+            loss, _ = model.MACnet.addAnswerLossOp(fake, logits, answers)
+        gv = model.MACnet.computeGradients(fake, optimizer, loss, None)                      # model.py:626-637
+        grads = {v.name[:-2]: (None if g is None else g.detach().clone()) for g, v in gv}
+        _, norm = model.MACnet.addTrainingOp(fake, optimizer, gv)                            # model.py:643-669
+        names = list(tf.state.variables)
+        out.append(dict(loss=float(loss), norm=float(norm), grads=grads,
+                        variables={k: tf.state.variables[k].detach().clone() for k in names},
+                        m={k: optimizer.m[k + ":0"].clone() for k in names if k + ":0" in optimizer.m},
+                        v={k: optimizer.v[k + ":0"].clone() for k in names if k + ":0" in optimizer.v},
+                        ema={k: tf.state.ema[k].clone() for k in names if k in tf.state.ema}))
+    return dict(steps=out, global_step=fake.globalStep.value, ema_names=sorted(fake.emaDict))

@@ -88,9 +88,31 @@ def test_adam_ema_step_matches_oracle(macx, dev, clip):
         assert abs(float(norm) - ref_norm) < 1e-4 * ref_norm
         got = torch.cat([p.detach().cpu().double().reshape(-1) for p in ps]).numpy()
         assert abs(got - ref_p).max() < 2e-6
-        assert abs(opt.ema.cpu().double().numpy() - ref_e).max() < 2e-6
+        ema = torch.cat([e.detach().cpu().double().reshape(-1) for e in opt.ema_state()]).numpy()
+        assert abs(ema - ref_e).max() < 2e-6
     # parameters are views of the flat buffer
     assert ps[0].data_ptr() == opt.flat.data_ptr()
+
+
+def test_adam_ema_step_follows_the_reference_training_op(macx, dev):
+    """macx_adam_ema_step (optim.FlatAdamEMA), fed the gradients the reference's computeGradients produced, against what the
+    reference's addTrainingOp (model.py:639-669) left in the variables, the EMA shadows and the norm -- five steps, clip active
+    on three (tests/golden/reference/training_steps.npz, generated by executing model.py)."""
+    from helpers import load_training_fixture
+    hyper, names, init, steps = load_training_fixture()
+    ps = [torch.nn.Parameter(torch.as_tensor(init[n], dtype=torch.float32).to(dev)) for n in names]
+    opt = macx.optim.FlatAdamEMA(ps, lr=hyper["lr"], beta1=hyper["beta1"], beta2=hyper["beta2"], eps=hyper["eps"],
+                                 clip_norm=hyper["clip"], ema_decay=hyper["decay"])
+    for t, s in enumerate(steps):
+        for p, n in zip(ps, names):
+            p.grad = torch.as_tensor(s["g"][n], dtype=torch.float32).to(dev).reshape(p.shape)
+        norm = opt.step()
+        torch.cuda.synchronize()
+        assert abs(float(norm) - s["norm"]) < 1e-5 * s["norm"]
+        for p, e, n in zip(ps, opt.ema_state(), names):
+            assert float((p.detach().cpu().double() - torch.as_tensor(s["p"][n]).reshape(p.shape)).abs().max()) < 2e-6, (t, n)
+            assert float((e.detach().cpu().double() - torch.as_tensor(s["e"][n]).reshape(e.shape)).abs().max()) < 2e-6, (t, n)
+        off = 0
 
 
 @pytest.mark.parametrize("B,A", [(64, 28), (5, 3), (130, 100), (2, 1)])

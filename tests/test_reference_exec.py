@@ -13,6 +13,7 @@ import numpy as np
 import os
 
 import pytest
+import sys
 import torch
 
 import ref_exec as rx
@@ -528,3 +529,28 @@ def test_stem_and_encoder_on_random_shapes_match_the_reference(seed):
         for k, v in ref["variables"].items():
             if v.grad is not None:
                 assert float((params[k].grad - v.grad).abs().max()) <= 1e-11 * max(1.0, float(v.grad.abs().max())), (what, k)
+
+
+def test_training_op_matches_the_optimizer_oracle_live():
+    """MACnet.addOptimizerOp / computeGradients / addTrainingOp (model.py:615-669) executed unmodified for five steps; the
+    committed fixture is exactly this run, and the optimizer oracle follows it step by step."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_training_golden as G
+    from helpers import load_training_fixture, flat64
+    from oracle import optim_oracle as oo
+    cfg, r = G.run()
+    hyper, names, init, steps = load_training_fixture()
+    assert list(r["steps"][0]["variables"]) == names and r["global_step"] == hyper["steps"]
+    assert r["ema_names"] == sorted(n + "/ExponentialMovingAverage" for n in names)       # emaDict (model.py:665)
+    tf = rx.load()["tf"]
+    p = flat64({n: tf.state.initial[n].numpy() for n in names}, names)
+    assert np.abs(p - flat64(init, names)).max() == 0
+    m, v, e = p * 0, p * 0, p.copy()
+    for t, (live, fx) in enumerate(zip(r["steps"], steps), start=1):
+        g = flat64({n: live["grads"][n].numpy() for n in names}, names)
+        assert np.abs(g - flat64(fx["g"], names)).max() < 1e-13
+        p, m, v, e, norm = oo.adam_ema_step(p, g, m, v, e, hyper["lr"], t, clip=hyper["clip"], decay=hyper["decay"])
+        assert abs(norm - live["norm"]) < 1e-12
+        for got, key in ((p, "variables"), (m, "m"), (v, "v"), (e, "ema")):
+            want = flat64({n: live[key][n].numpy() for n in names}, names)
+            assert np.abs(got - want).max() < 1e-12, (t, key)

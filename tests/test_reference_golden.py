@@ -75,3 +75,22 @@ def test_oracle_reproduces_reference_vectors(path):
     for k, t in ins.items():
         if "gin/" + k in z.files:
             close(t.grad, "gin/" + k)
+
+
+def test_optimizer_oracle_reproduces_the_reference_training_op():
+    """oracle/optim_oracle.adam_ema_step, fed the gradients MACnet.computeGradients produced, lands on the variables, Adam moments,
+    EMA shadows and global norm MACnet.addTrainingOp (model.py:639-669) left behind -- five steps, clip active on three."""
+    from helpers import load_training_fixture, flat64
+    from oracle import optim_oracle as oo
+    hyper, names, init, steps = load_training_fixture()
+    p = flat64(init, names)
+    m, v, e = p * 0, p * 0, p.copy()
+    clipped = 0
+    for t, s in enumerate(steps, start=1):
+        p, m, v, e, norm = oo.adam_ema_step(p, flat64(s["g"], names), m, v, e, hyper["lr"], t, beta1=hyper["beta1"], beta2=hyper["beta2"],
+                                            eps=hyper["eps"], clip=hyper["clip"], decay=hyper["decay"])
+        clipped += norm > hyper["clip"]
+        assert abs(norm - s["norm"]) < 1e-12 * s["norm"]
+        for got, key in ((p, "p"), (m, "m"), (v, "v"), (e, "e")):
+            assert np.abs(got - flat64(s[key], names)).max() < 1e-12, (t, key)
+    assert 0 < clipped < len(steps)

@@ -53,6 +53,9 @@ class _State:
         self.counts = {}             # full scope name -> times opened (default_name uniquification)
         self.draws = []              # [("uniform", tensor)] in call order
         self.uniform_hook = None     # shape -> tensor, replaces the generator when set
+        self.initial = {}            # full name -> the value the variable was initialised with (EMA shadows start there)
+        self.untrainable = {}        # name -> tf.Variable(..., trainable=False)
+        self.ema = {}                # variable name -> ExponentialMovingAverage shadow
 
 
 state = _State()
@@ -174,7 +177,7 @@ def uniform(shape):
 # variables and scopes
 # ------------------------------------------------------------------------------------------------
 def _cur_name():
-    return "/".join(n for n, _ in state.scope)
+    return "/".join(n for n, _ in state.scope if n)
 
 
 def _cur_reuse():
@@ -198,6 +201,11 @@ def variable_scope(name_or_scope, default_name=None, reuse=None, **_ignored):
         if default_name is None:
             raise ValueError("variable_scope: name_or_scope and default_name cannot both be None")
         name = _unique(default_name)
+    elif hasattr(name_or_scope, "name") and not isinstance(name_or_scope, str):
+        # a captured scope object (tf.get_variable_scope()): re-entered, not nested -- only the ROOT scope is ever passed here
+        if name_or_scope.name:
+            raise NotImplementedError("re-entering a non-root captured scope")
+        name = ""
     else:
         name = str(name_or_scope)
     state.scope.append((name, reuse))
@@ -293,7 +301,19 @@ def get_variable(name, shape=None, initializer=None, dtype=None, trainable=True,
     if state.require_grad and v.is_floating_point():
         v.requires_grad_(True)
     state.variables[full] = v
+    state.initial[full] = v.detach().clone()
     return v
+
+
+class Variable(object):
+    """tf.Variable(initial_value, dtype=, trainable=False, name=): the step counter of model.py:617 (eager: a python box)"""
+
+    def __init__(self, initial_value, dtype=None, trainable=True, name=None, **_ignored):
+        if trainable:
+            raise NotImplementedError("the reference only creates its globalStep this way (model.py:617)")
+        self.name = ((_cur_name() + "/") if _cur_name() else "") + (name or "Variable") + ":0"
+        self.value = initial_value
+        state.untrainable[self.name] = self
 
 
 def trainable_variables():
@@ -499,10 +519,107 @@ def cond(pred, true_fn, false_fn):
     return true_fn() if bool(pred) else false_fn()
 
 
-def clip_by_global_norm(t_list, clip_norm):
-    norm = torch.sqrt(sum((t.double() ** 2).sum() for t in t_list if t is not None))
-    scale = clip_norm / torch.maximum(norm, torch.tensor(float(clip_norm), dtype=torch.float64))
+def global_norm(t_list):
+    """clip_ops.global_norm: sqrt(sum_t ||t||_2^2) over the tensors that are not None"""
+    return _w(torch.sqrt(sum((t.double() ** 2).sum() for t in t_list if t is not None)))
+
+
+def clip_by_global_norm(t_list, clip_norm, use_norm=None):
+    """clip_ops.clip_by_global_norm: t * clip_norm / max(global_norm, clip_norm)"""
+    norm = global_norm(t_list) if use_norm is None else use_norm
+    scale = clip_norm / torch.maximum(norm.double(), torch.tensor(float(clip_norm), dtype=torch.float64))
     return [None if t is None else t * scale.to(t.dtype) for t in t_list], norm
+
+
+class GraphKeys(object):
+    UPDATE_OPS = "update_ops"
+
+
+def get_collection(key):
+    return []          # no tf.layers batch-norm update ops are ever registered by the reference's graph (it uses contrib's with updates_collections=None)
+
+
+@contextmanager
+def control_dependencies(ops_):
+    yield              # eager: every op has already run when its python call returns, in program order
+
+
+def group(*ops_, **_ignored):
+    return None
+
+
+# ------------------------------------------------------------------------------------------------
+# tf.train: what MACnet.addOptimizerOp / computeGradients / addTrainingOp (model.py:615-669) call.  Eager: an "op" runs when
+# it is built, so ONE pass through those three methods is one training step; optimizer slots live in the optimizer object
+# (created once, model.py:618) and EMA shadows in `state.ema` (a graph would create them once and update them per run).
+# ------------------------------------------------------------------------------------------------
+train = types.ModuleType("tensorflow.train")
+
+
+class _AdamOptimizer(object):
+    """tf.train.AdamOptimizer (training/adam.py + kernels/training_ops.cc ApplyAdam, TF 1.x):
+         lr_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power)        (the powers start at beta1, beta2)
+         m <- beta1 m + (1 - beta1) g ;  v <- beta2 v + (1 - beta2) g^2 ;  var <- var - lr_t m / (sqrt(v) + epsilon)
+       and, after every variable, beta1_power *= beta1, beta2_power *= beta2 (_finish)."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, **_ignored):
+        self.lr, self.beta1, self.beta2, self.eps = learning_rate, beta1, beta2, epsilon
+        self.beta1_power, self.beta2_power = beta1, beta2
+        self.m, self.v = {}, {}
+
+    def compute_gradients(self, loss, var_list=None, **_ignored):
+        vs = list(var_list) if var_list is not None else trainable_variables()
+        gs = torch.autograd.grad(loss, [v.value for v in vs], allow_unused=True, retain_graph=True)
+        return [(None if g is None else _w(g.detach()), v) for g, v in zip(gs, vs)]
+
+    def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+        lr = float(self.lr)
+        lr_t = lr * math.sqrt(1.0 - self.beta2_power) / (1.0 - self.beta1_power)
+        with torch.no_grad():
+            for g, v in grads_and_vars:
+                if g is None:
+                    continue
+                var = v.value
+                g = g.detach().to(var.dtype)
+                m = self.m.setdefault(v.name, torch.zeros_like(var))
+                vv = self.v.setdefault(v.name, torch.zeros_like(var))
+                m.mul_(self.beta1).add_(g, alpha=1.0 - self.beta1)
+                vv.mul_(self.beta2).addcmul_(g, g, value=1.0 - self.beta2)
+                var.data.sub_(lr_t * m / (vv.sqrt() + self.eps))
+        self.beta1_power *= self.beta1
+        self.beta2_power *= self.beta2
+        if global_step is not None:
+            global_step.value += 1
+        return "train_op"
+
+
+class _ExponentialMovingAverage(object):
+    """tf.train.ExponentialMovingAverage(decay).apply(vars): shadow <- shadow - (1 - decay) (shadow - var); a shadow starts at
+    its variable's INITIAL value (moving_averages.py: initialized_value())."""
+
+    def __init__(self, decay, num_updates=None, **_ignored):
+        if num_updates is not None:
+            raise NotImplementedError("model.py:658 passes the decay only")
+        self.decay = decay
+        self._vars = []
+
+    def apply(self, var_list=None):
+        self._vars = list(var_list) if var_list is not None else trainable_variables()
+        with torch.no_grad():
+            for v in self._vars:
+                key = v.name[:-2] if v.name.endswith(":0") else v.name
+                sh = state.ema.get(key)
+                if sh is None:
+                    sh = state.ema[key] = state.initial[key].clone()
+                sh.sub_((1.0 - self.decay) * (sh - v.value.detach()))
+        return "ema_op"
+
+    def variables_to_restore(self, moving_avg_variables=None):
+        return {(v.name[:-2] if v.name.endswith(":0") else v.name) + "/ExponentialMovingAverage": v for v in self._vars}
+
+
+train.AdamOptimizer = _AdamOptimizer
+train.ExponentialMovingAverage = _ExponentialMovingAverage
 
 
 # ------------------------------------------------------------------------------------------------
