@@ -2,7 +2,7 @@
 stanfordnlp/mac-network's mac_cell.py and the ops.py primitives they call) behind the
 reference's own MACCell interface.  Import with `importlib.import_module("mac-network_amd")`
 or through the `macx` alias module at the repo root."""
-from . import _lib, build, cell, checkpoint, configs, dp, encoder, generic, graph, h5, optim, options, output, params, stem, tf_bundle   # noqa: F401
+from . import _lib, build, cell, checkpoint, configs, dp, encoder, generic, graph, h5, optim, options, output, params, plan, stem, tf_bundle   # noqa: F401
 from .cell import MACCell, MACCellTuple             # noqa: F401
 from .options import UnsupportedOptions, freeze     # noqa: F401
 from .params import MACCellParams                   # noqa: F401

@@ -1,7 +1,10 @@
 """The GENERIC option path of the MAC cell: every legal option combination of mac_cell.py that the fused cell kernels
 (cell.py -> macx_cell_*) answer with UnsupportedOptions -- the reference's DEFAULT configuration, writeInputs != BOTH,
 readMemAttType BL / ADD, relu = PRM, writeConcatMul, controlProj, controlConcatWords, unsharedCells, mulBias, ... -- runs
-here as ONE HIP KERNEL PER REFERENCE OP, chained exactly as mac_cell.py:133-375, 420-480 chains ops.py.
+as one HIP kernel per primitive of a PLAN that plan.compile_cell derives from the option set once (plan.py: variable table in
+the reference's creation order + a flat operation list per zero_state / step, executed and differentiated by plan.run_segment).
+This module holds what the plan stands on: the kernel calls (k_*), the variable store under the reference's names, the cell
+class that feeds the plan's segments, and the few eager layer helpers the generic question encoder / output unit use.
 
 Every arithmetic step is a kernel of libmacx.so behind the C ABI (include/macx.h: macx_linear / macx_h2_gemm / macx_wgrad and
 the macx_op_* primitives); PyTorch owns the device memory, the stream, the concat / slice copies and the autograd tape that
@@ -389,6 +392,14 @@ class GenericParams(torch.nn.Module):
             raise ValueError("variable %s has shape %s, expected %s" % (key, tuple(v.shape), shape))
         return v
 
+    def ensure(self, full_name, shape, init):
+        """the variable `full_name` (a complete scope path), created with `init` unless it exists (a loaded checkpoint)"""
+        saved, self._stack = self._stack, []
+        try:
+            return self.get(full_name, shape, init)
+        finally:
+            self._stack = saved
+
     def _apply(self, fn, *a, **kw):
         """.to(device) / .cuda() on this module or on any module that holds it: variables created later follow."""
         out = super()._apply(fn, *a, **kw)
@@ -432,7 +443,8 @@ class GenericParams(torch.nn.Module):
 
 
 # -------------------------------------------------------------------------------------------------------------------
-# ops.py on the kernels
+# eager layer helpers for the generic question encoder and output unit (encoder.py, output.py): a dense layer of the
+# "linearLayer<name>" family and the activation table, on the autograd nodes above
 # -------------------------------------------------------------------------------------------------------------------
 class _Ops:
     def __init__(self, config, store):
@@ -449,149 +461,37 @@ class _Ops:
         with self.vs.scope("biases"):
             return self.vs.get("bias", shape, "zeros")
 
-    # ops.activations (ops.py:181-187) / ops.relu (ops.py:161-179)
     def act(self, name, x):
+        """config.py's activation names on macx_op_act; "RELU" is whatever --relu selects (ops.py:161-187)"""
         if name == "NON":
             return x
-        if name == "RELU":
-            r = self.g("relu")
-            if r == "PRM":
-                with self.vs.scope("prelu", default=True):
-                    alpha = self.vs.get("alpha", (x.shape[-1],), 0.25)
-                return _Act.apply(x, ACT_PRELU, alpha)
-            if r == "LKY":
-                raise AttributeError("'Config' object has no attribute 'reluAlpha'")
-            if r == "SELU":
-                raise UnboundLocalError("local variable 'output' referenced before assignment")
-            name = "ELU" if r == "ELU" else "RELU"
-        return _Act.apply(x, _lib.ACT[name], None)
+        flavour = self.g("relu") if name == "RELU" else None
+        if flavour == "PRM":
+            with self.vs.scope("prelu", default=True):
+                return _Act.apply(x, ACT_PRELU, self.vs.get("alpha", (x.shape[-1],), 0.25))
+        if flavour == "LKY":
+            raise AttributeError("'Config' object has no attribute 'reluAlpha'")
+        if flavour == "SELU":
+            raise UnboundLocalError("local variable 'output' referenced before assignment")
+        code = {None: name, "ELU": "ELU", "STD": "RELU"}[flavour]
+        return _Act.apply(x, _lib.ACT[code], None)
 
-    # tf.contrib.layers.batch_norm(updates_collections=None) on the last axis of a [B, c] tensor (mac_cell.py:370-373):
-    # batch statistics (biased variance) in training, moving averages in evaluation; eps = 0.001
-    def batch_norm(self, x, decay, center, scale, is_training, epsilon=0.001):
-        with self.vs.scope("BatchNorm", default=True):
-            c = x.shape[-1]
-            beta = self.vs.get("beta", (c,), "zeros") if center else None
-            gamma = self.vs.get("gamma", (c,), 1.0) if scale else None
-            mm = self.vs.get("moving_mean", (c,), "zeros")
-            mv = self.vs.get("moving_variance", (c,), 1.0)
-            B = x.shape[0]
-            ones_c = torch.ones(c, dtype=torch.float32, device=x.device)
-            eps = torch.full((1,), epsilon, dtype=torch.float32, device=x.device)
-            x = x.contiguous()
-            if is_training:
-                mean = _Binary.apply(_RowSum.apply(x), ones_c, OP_MUL, B_SAME, 1.0 / B)
-                cen = _Binary.apply(x, _Binary.apply(mean, ones_c, OP_MUL, B_SAME, -1.0), OP_ADD, B_CHANNEL, 1.0)
-                var = _Binary.apply(_RowSum.apply(_Binary.apply(cen, cen, OP_MUL, B_SAME, 1.0)), ones_c, OP_MUL, B_SAME, 1.0 / B)
-                with torch.no_grad():          # assign_moving_average: m -= (1 - decay) (m - stat), outside the gradient
-                    for mov, stat in ((mm, mean), (mv, var)):
-                        kept = k_binary(OP_MUL, B_SAME, mov.detach().contiguous(), ones_c, 1, c, decay)
-                        mov.copy_(k_binary(OP_ADD, B_SAME, kept, k_binary(OP_MUL, B_SAME, stat.detach().contiguous(), ones_c, 1, c, 1.0 - decay), 1, c))
-            else:
-                cen = _Binary.apply(x, _Binary.apply(mm.detach(), ones_c, OP_MUL, B_SAME, -1.0), OP_ADD, B_CHANNEL, 1.0)
-                var = mv.detach()
-            out = _Binary.apply(cen, _Act.apply(var, ACT_RSQRT_EPS, eps), OP_MUL, B_CHANNEL, 1.0)
-            if gamma is not None:
-                out = _Binary.apply(out, gamma, OP_MUL, B_CHANNEL, 1.0)
-            if beta is not None:
-                out = _Binary.apply(out, beta, OP_ADD, B_CHANNEL, 1.0)
-        return out
-
-    # ops.linear (ops.py:298-333)
-    def linear(self, inp, inDim, outDim, dropout=None, addBias=True, bias=0.0, act="NON", actLayer=True, name=""):
+    def linear(self, inp, inDim, outDim, dropout=None, act="NON", name=""):
+        """[.., inDim] -> [.., outDim] under "linearLayer<name>" (ops.py:298-333): input dropout, x W + b, activation and -- with an
+        activation -- the stacked "<name>_2" layer.  (Widths of 1 and constant bias offsets only occur inside the cell: plan.py.)"""
         with self.vs.scope("linearLayer" + name):
-            W = self.getWeight((inDim, outDim) if outDim > 1 else (inDim,))
-            b = self.getBias((outDim,) if outDim > 1 else ())
-            if dropout is not None:
-                inp = dropout(inp)
-            if outDim > 1:
-                bb = None
-                if addBias:
-                    bb = b if bias == 0.0 else _Binary.apply(b, torch.full_like(b, bias), OP_ADD, B_SAME, 1.0)
-                output = _Linear.apply(inp, W, bb)
-            else:
-                # ops.py:317: reduce_sum(inp * W, axis=-1)
-                output = _Reduce.apply(_Binary.apply(inp, W, OP_MUL, B_CHANNEL, 1.0), R_LAST)
-                if addBias:
-                    flat = output.reshape(-1, 1)
-                    output = _Binary.apply(flat, (b.reshape(1) + bias) if bias else b.reshape(1), OP_ADD, B_CHANNEL, 1.0).reshape(output.shape)
-            output = self.act(act, output)
-            if act != "NON" and actLayer:
-                output = self.linear(output, outDim, outDim, addBias=addBias, act="NON", actLayer=False, name=name + "_2")
-        return output
-
-    # ops.inter2logits / inter2att (ops.py:114-146)
-    def inter2logits(self, interactions, dim, dropout=None, name=""):
-        with self.vs.scope("inter2logits" + name):
-            return self.linear(interactions, dim, 1, dropout=dropout, name="logits")
-
-    def inter2att(self, interactions, dim, dropout=None, name=""):
-        with self.vs.scope("inter2att" + name):
-            return _Softmax.apply(self.inter2logits(interactions, dim, dropout=dropout), None)
-
-    # ops.att2Smry (ops.py:150)
-    @staticmethod
-    def att2Smry(attention, features):
-        B, N, d = features.shape
-        w = _Binary.apply(features.contiguous(), attention.reshape(-1), OP_MUL, B_ROW, 1.0)
-        return _Reduce.apply(w, R_MID)
-
-    @staticmethod
-    def bcast_mul(x, y):
-        """x [B,N,d] * y [B,d] (the extendY broadcast of ops.mul / ops.concat, ops.py:65-67, 693-695)."""
-        return _Binary.apply(x.contiguous(), y, OP_MUL, B_MID, 1.0)
-
-    # ops.mul (ops.py:668-725)
-    def mul(self, x, y, dim, proj=None, interMod="MUL", concat=None, extendY=True, name="", drops=None):
-        drops = drops or {}
-        with self.vs.scope("mul" + name):
-            origVals = {"x": x, "y": y, "dim": dim}
-            projVals = None
-            if proj is not None:
-                if drops.get("x") is not None:
-                    x = drops["x"](x)
-                if drops.get("y") is not None:
-                    y = drops["y"](y)
-                xName, yName = ("proj", "proj") if proj["shared"] else ("projX", "projY")
-                x = self.linear(x, dim, proj["dim"], name=xName)
-                y = self.linear(y, dim, proj["dim"], name=yName)
-                dim = proj["dim"]
-                projVals = {"x": x, "y": y, "dim": dim}
-                proj["x"], proj["y"] = x, y
-            mulBias = self.g("mulBias")
-            if interMod == "MUL":
-                if mulBias != 0.0:
-                    x = _Binary.apply(x.contiguous(), torch.full((x.shape[-1],), mulBias, device=x.device), OP_ADD, B_CHANNEL, 1.0)
-                    y = _Binary.apply(y.contiguous(), torch.full((y.shape[-1],), mulBias, device=y.device), OP_ADD, B_CHANNEL, 1.0)
-                output = self.bcast_mul(x, y) if extendY else _Binary.apply(x.contiguous(), y, OP_MUL, B_SAME, 1.0)
-            elif interMod == "DIAG":
-                raise UnboundLocalError("local variable 'output' referenced before assignment")
-            elif interMod == "BL":
-                W = self.getWeight((dim, dim))
-                b = self.getBias((dim,))
-                output = self.bcast_mul(_Linear.apply(x, W, None), y)
-                output = _Binary.apply(output, b, OP_ADD, B_CHANNEL, 1.0)
-            else:   # "ADD": tanh(x + y)
-                output = _Act.apply(_Binary.apply(x.contiguous(), y, OP_ADD, B_MID if extendY else B_SAME, 1.0), _lib.ACT["TANH"], None)
-            if concat is not None:
-                if concat.get("proj", False):
-                    if projVals is None:
-                        raise UnboundLocalError("local variable 'projVals' referenced before assignment")
-                    concatVals = projVals
-                else:
-                    concatVals = origVals
-                if concat.get("x", False):
-                    output = torch.cat([output, concatVals["x"]], dim=-1)
-                    dim += concatVals["dim"]
-        return output, dim
+            W, b = self.getWeight((inDim, outDim)), self.getBias((outDim,))
+            y = self.act(act, _Linear.apply(dropout(inp) if dropout is not None else inp, W, b))
+            return y if act == "NON" else self.linear(y, outDim, outDim, name=name + "_2")
 
 
 # -------------------------------------------------------------------------------------------------------------------
-# the cell (mac_cell.py:30-592)
+# the cell (the interface of mac_cell.py:30-592 over a compiled plan)
 # -------------------------------------------------------------------------------------------------------------------
 class GenericMACCell:
     """Same constructor / zero_state / __call__ / attribute surface as mac_cell.MACCell and macx.MACCell; built by
-    macx.MACCell(...) when the option set has no fused kernels."""
+    macx.MACCell(...) when the option set has no fused kernels.  zero_state and every step execute one segment of the plan
+    compiled from the option set (plan.compile_cell) -- one autograd node each."""
 
     generic = True
 
@@ -600,32 +500,28 @@ class GenericMACCell:
                  netLength=None, seed=None, b0=0):
         self.config = config if config is not None else SimpleNamespace()
         reject_like_reference(self.config)
-        g = self.g
-        for dname in ("memDim", "ctrlDim", "attDim"):
-            if g(dname) % 128:
-                raise UnsupportedOptions("the generic path needs %s %% 128 == 0" % dname)
+        bad = [k for k in ("memDim", "ctrlDim", "attDim") if self.g(k) % 128]
+        if bad:
+            raise UnsupportedOptions("the generic path needs %s %% 128 == 0" % bad[0])
         _L()                                           # fails loudly without libmacx.so
-        self.netLength = int(netLength if netLength is not None else g("netLength"))
-        self.vecQuestions = _dev(vecQuestions, "vecQuestions")
-        self.questionWords, self.questionCntxWords = questionWords, questionCntxWords
         _require_device(questionLengths, "questionLengths")
-        self.questionLengths = questionLengths.to(torch.int32).contiguous()
-        if self.questionLengths.shape != (self.vecQuestions.shape[0],):
+        lengths = questionLengths.to(torch.int32).contiguous()
+        if lengths.shape != (vecQuestions.shape[0],):
             raise ValueError("questionLengths must be [batchSize]")
-        self.knowledgeBase = _dev(knowledgeBase, "knowledgeBase")
-        self.train = bool(train)
-        self.dropouts = {"memory": float(memoryDropout) if train else 1.0, "read": float(readDropout) if train else 1.0,
-                         "write": float(writeDropout) if train else 1.0}
-        self.batchSize = int(batchSize)
-        self.reuse = reuse
+        self.train, self.batchSize, self.b0, self.reuse = bool(train), int(batchSize), int(b0), reuse
+        # the reference's attribute names (mac_cell.py:59-79), device-checked fp32 tensors
+        self.__dict__.update(vecQuestions=_dev(vecQuestions, "vecQuestions"), questionWords=questionWords,
+                             questionCntxWords=questionCntxWords, questionLengths=lengths,
+                             knowledgeBase=_dev(knowledgeBase, "knowledgeBase"))
+        rates = dict(memory=memoryDropout, read=readDropout, write=writeDropout)
+        self.dropouts = {k: (float(v) if self.train else 1.0) for k, v in rates.items()}      # evaluation feeds keep = 1 (model.py:118-125)
+        self.netLength = int(netLength if netLength is not None else self.g("netLength"))
         self.seed = fresh_seed(seed, self.train) & 0xFFFFFFFF
-        self.b0 = int(b0)
         dev = self.knowledgeBase.device
         self.params = params if params is not None else GenericParams(device=dev)
-        self.vs = self.params
-        self.ops = _Ops(self.config, self.params)
         self.none = torch.zeros((self.batchSize, 1), dtype=torch.float32, device=dev)
         self.iteration = 0
+        self._plan = self._exec = None
 
     def g(self, name):
         return get(self.config, name)
@@ -638,214 +534,58 @@ class GenericMACCell:
     def output_size(self):
         return 1
 
-    def _drop(self, site, keep, step=None):
-        """x -> tf.nn.dropout(x, keep) on the stateless stream; None when keep == 1 (the reference still builds the op)."""
-        if keep == 1.0:
-            return None
-        st = 0 if site == SITE_MEM_VAR else (self.iteration if step is None else step)
+    def plan(self):
+        """the compiled plan of this option set (first call: compiles it and creates the variables it names, in its order --
+        the reference's creation order -- unless a checkpoint already put them into `params`)"""
+        if self._plan is None:
+            from . import plan as _plan
+            self._plan = _plan.compile_cell(self.config, self.netLength)
+            for name, spec in self._plan.variables.items():
+                self.params.ensure(name, spec.shape, spec.init)
+        return self._plan
 
-        def f(x):
-            per_q = x.numel() // x.shape[0]
-            return _Dropout.apply(x, self.seed, site, st, keep, self.b0 * per_q)
-        return f
+    def _segment(self, seg, feeds):
+        from . import plan as _plan
+        if self._exec is None:
+            self._exec = _plan._Exec(self.seed, self.b0, self.dropouts, self.train, self.batchSize, self.knowledgeBase.device)
+        return _plan.run_segment(seg, self._exec, feeds, self.params)
 
-    # ---- control (mac_cell.py:133-187)
-    def control(self, controlInput, inWords, outWords, questionLengths, control, contControl=None, name=""):
-        g, ops = self.g, self.ops
-        with self.vs.scope("control" + name):
-            dim = g("ctrlDim")
-            newContControl = controlInput
-            if g("controlFeedPrev"):
-                newContControl = control if g("controlFeedPrevAtt") else contControl
-                if g("controlFeedInputs"):
-                    newContControl = torch.cat([newContControl, controlInput], dim=-1)
-                    dim += g("ctrlDim")
-                newContControl = ops.linear(newContControl, dim, g("ctrlDim"), act=g("controlContAct"), name="contControl")
-                dim = g("ctrlDim")
-            interactions = ops.bcast_mul(inWords, newContControl)
-            if g("controlConcatWords"):
-                interactions = torch.cat([interactions, inWords], dim=-1)
-                dim += g("ctrlDim")
-            if g("controlProj"):
-                interactions = ops.linear(interactions, dim, g("ctrlDim"), act=g("controlProjAct"))
-                dim = g("ctrlDim")
-            logits = ops.inter2logits(interactions, dim)
-            attention = _Softmax.apply(logits, questionLengths)      # softmax(expMask(logits, lengths)), mac_cell.py:176-177
-            self.attentions["question"].append(attention)
-            newControl = ops.att2Smry(attention, outWords)
-            if g("controlContinuous"):
-                newControl = newContControl
-        return newControl, newContControl
-
-    # ---- read (mac_cell.py:209-277)
-    def read(self, knowledgeBase, memory, control, name=""):
-        g, ops = self.g, self.ops
-        with self.vs.scope("read" + name):
-            dim = g("memDim")
-            if g("memoryVariationalDropout"):
-                if self.memDpMask is not None:
-                    memory = _Binary.apply(memory.contiguous(), self.memDpMask, OP_MUL, B_SAME, 1.0)
-            else:
-                dm = self._drop(SITE_MEM, self.dropouts["memory"])
-                memory = dm(memory) if dm else memory
-            proj = None
-            if g("readProjInputs"):
-                proj = {"dim": g("attDim"), "shared": g("readProjShared")}
-                dim = g("attDim")
-            concat = {"x": g("readMemConcatKB"), "proj": g("readMemConcatProj")}
-            drops = {"x": self._drop(SITE_READ_KB, self.dropouts["read"]),
-                     "y": self._drop(SITE_READ_MEM, self.dropouts["read"])} if proj else None
-            interactions, interDim = ops.mul(x=knowledgeBase, y=memory, dim=g("memDim"), proj=proj, concat=concat,
-                                             interMod=g("readMemAttType"), name="memInter", drops=drops)
-            projectedKB = proj.get("x") if proj else None
-            if g("readMemProj"):
-                interactions = ops.linear(interactions, interDim, dim, act=g("readMemAct"), name="memKbProj")
-            else:
-                dim = interDim
-            if g("readCtrl"):
-                if g("ctrlDim") != dim:
-                    raise NameError("name 'ctrlDim' is not defined")          # mac_cell.py:246
-                interactions, interDim = ops.mul(interactions, control, dim, interMod=g("readCtrlAttType"),
-                                                 concat={"x": g("readCtrlConcatInter")}, name="ctrlInter")
-                if g("readCtrlConcatKB"):
-                    if g("readCtrlConcatProj"):
-                        addedInp, addedDim = projectedKB, g("attDim")
-                    else:
-                        addedInp, addedDim = knowledgeBase, g("memDim")
-                    interactions = torch.cat([interactions, addedInp], dim=-1)
-                    dim += addedDim
-                interactions = ops.act(g("readCtrlAct"), interactions)
-            if interactions.shape[-1] != dim:
-                raise ValueError("Dimensions must be equal, but are %d and %d" % (interactions.shape[-1], dim))
-            attention = ops.inter2att(interactions, dim, dropout=self._drop(SITE_READ_ATT, self.dropouts["read"]))
-            self.attentions["kb"].append(attention)
-            if g("readSmryKBProj"):
-                knowledgeBase = projectedKB
-            information = ops.att2Smry(attention, knowledgeBase)
-        return information
-
-    # ---- write (mac_cell.py:305-375)
-    def write(self, memory, info, control, contControl=None, name=""):
-        g, ops = self.g, self.ops
-        with self.vs.scope("write" + name):
-            if g("writeInfoProj"):
-                info = ops.linear(info, g("memDim"), g("memDim"), name="info")
-            info = ops.act(g("writeInfoAct"), info)
-            if g("writeSelfAtt"):
-                selfControl = contControl if g("writeSelfAttMod") == "CONT" else control
-                selfControl = ops.linear(selfControl, g("ctrlDim"), g("ctrlDim"), name="ctrlProj")
-                interactions = ops.bcast_mul(self.controls, selfControl)
-                attention = ops.inter2att(interactions, g("ctrlDim"), name="selfAttention")
-                self.attentions["self"].append(attention)
-                selfSmry = ops.att2Smry(attention, self.memories)
-            newMemory, dim = memory, g("memDim")
-            if g("writeInputs") == "INFO":
-                newMemory = info
-            elif g("writeInputs") == "SUM":
-                newMemory = _Binary.apply(newMemory.contiguous(), info, OP_ADD, B_SAME, 1.0)
-            elif g("writeInputs") == "BOTH":
-                parts = [newMemory, info]
-                if g("writeConcatMul"):
-                    parts.append(_Binary.apply(newMemory.contiguous(), info, OP_MUL, B_SAME, 1.0))
-                newMemory, dim = torch.cat(parts, dim=-1), dim * len(parts)
-            if g("writeSelfAtt"):
-                newMemory = torch.cat([newMemory, selfSmry], dim=-1)
-                dim += g("memDim")
-            if g("writeMergeCtrl"):
-                newMemory = torch.cat([newMemory, control], dim=-1)
-                dim += g("memDim")
-            if g("writeMemProj") or (dim != g("memDim")):
-                newMemory = ops.linear(newMemory, dim, g("memDim"), name="newMemory")
-            newMemory = ops.act(g("writeMemAct"), newMemory)
-            if g("writeGate"):
-                gateDim = 1 if g("writeGateShared") else g("memDim")
-                if gateDim == 1:
-                    raise ValueError("Dimensions must be equal")              # [B,d] * [B] (ops.py:317, mac_cell.py:367)
-                z = ops.act("SIGMOID", ops.linear(control, g("ctrlDim"), gateDim, name="gate", bias=g("writeGateBias")))
-                self.attentions["gate"].append(z)
-                # newMemory * z + memory * (1 - z)
-                one_minus = _Binary.apply(_Binary.apply(z, torch.ones_like(z), OP_MUL, B_SAME, -1.0), torch.ones_like(z), OP_ADD, B_SAME, 1.0)
-                newMemory = _Binary.apply(_Binary.apply(newMemory.contiguous(), z, OP_MUL, B_SAME, 1.0),
-                                          _Binary.apply(memory.contiguous(), one_minus, OP_MUL, B_SAME, 1.0), OP_ADD, B_SAME, 1.0)
-            if g("memoryBN"):
-                newMemory = ops.batch_norm(newMemory, g("bnDecay"), g("bnCenter"), g("bnScale"), self.train)
-        return newMemory
-
-    @contextmanager
-    def _net_scope(self):
-        """model.py:441 wraps the cell in variable_scope("MACnetwork"); entered here unless the caller already did."""
-        if "MACnetwork" in self.vs._stack:
-            yield
-        else:
-            with self.vs.scope("MACnetwork"):
-                yield
-
-    # ---- one step (mac_cell.py:420-480)
-    def __call__(self, inputs, state, scope=None):
-        with self._net_scope():
-            return self._step(state, scope)
-
-    def _step(self, state, scope):
-        g, ops = self.g, self.ops
-        with self.vs.scope(scope or "MACCell"):
-            control, memory = state
-            inputNameU = "qInput%d" % self.iteration if g("controlInputUnshared") else "qInputU"
-            cellName = str(self.iteration) if g("unsharedCells") else ""
-            controlInput = ops.linear(self.vecQuestions, g("ctrlDim"), g("ctrlDim"), name="qInput")
-            controlInput = ops.act(g("controlInputAct"), controlInput)
-            controlInput = ops.linear(controlInput, g("ctrlDim"), g("ctrlDim"), name=inputNameU)
-            newControl, self.contControl = self.control(controlInput, self.inWords, self.outWords, self.questionLengths,
-                                                        control, self.contControl, name=cellName)
-            if g("controlWholeQ"):
-                newControl = self.vecQuestions
-            info = self.read(self.knowledgeBase, memory, newControl, name=cellName)
-            dw = self._drop(SITE_WRITE_INFO, self.dropouts["write"])
-            if dw:
-                info = dw(info)
-            newMemory = self.write(memory, info, newControl, self.contControl, name=cellName)
-            self.controls = torch.cat([self.controls, newControl.unsqueeze(1)], dim=1)
-            self.memories = torch.cat([self.memories, newMemory.unsqueeze(1)], dim=1)
-            self.infos = torch.cat([self.infos, info.unsqueeze(1)], dim=1)
-        return self.none, MACCellTuple(newControl, newMemory)
-
-    def initState(self, name, dim, initType, batchSize):
-        if initType == "PRM":
-            prm = self.vs.get(name, (dim,), "normal")
-            return _Binary.apply(torch.zeros((batchSize, dim), dtype=torch.float32, device=prm.device), prm, OP_ADD, B_CHANNEL, 1.0)
-        if initType == "ZERO":
-            return torch.zeros((batchSize, dim), dtype=torch.float32, device=self.knowledgeBase.device)
-        return self.vecQuestions
+    # histories as the reference exposes them: [B, steps + 1, d] (mac_cell.py:472-474, 549-551)
+    controls = property(lambda self: torch.stack(self._hist["control"], dim=1))
+    memories = property(lambda self: torch.stack(self._hist["memory"], dim=1))
+    infos = property(lambda self: torch.stack(self._hist["info"], dim=1))
 
     # ---- zero_state (mac_cell.py:539-592)
     def zero_state(self, batchSize=None, dtype=torch.float32):
-        with self._net_scope():
-            return self._zero_state(batchSize)
-
-    def _zero_state(self, batchSize):
-        g, ops = self.g, self.ops
-        batchSize = self.batchSize if batchSize is None else batchSize
+        if batchSize is not None and int(batchSize) != self.batchSize:
+            raise ValueError("zero_state(%d) on a cell built for batchSize %d" % (batchSize, self.batchSize))
+        words = _dev(self.questionCntxWords if self.g("controlContextual") else self.questionWords, "question words")
+        out = self._segment(self.plan().init, {"vecQuestions": self.vecQuestions, "words": words})
+        self._carry = {k: out[k] for k in ("in_words", "out_words", "mem_mask") if k in out}
+        self._carry["cont_control"] = out["control"]
+        self._hist = {"control": [out["control"]], "memory": [out["memory"]], "info": [out["memory"]]}
         self.attentions = {"kb": [], "question": [], "self": [], "gate": []}
-        initialControl = self.initState("initCtrl", g("ctrlDim"), g("initCtrl"), batchSize)
-        initialMemory = self.initState("initMem", g("memDim"), g("initMem"), batchSize)
-        self.controls = initialControl.unsqueeze(1)
-        self.memories = initialMemory.unsqueeze(1)
-        self.infos = initialMemory.unsqueeze(1)
-        self.contControl = initialControl
-        words = self.questionCntxWords if g("controlContextual") else self.questionWords
-        words = _dev(words, "question words")
-        self.inWords = self.outWords = words
-        if g("controlInWordsProj") or g("controlOutWordsProj"):
-            pWords = ops.linear(words, g("ctrlDim"), g("ctrlDim"), name="wordsProj")
-            self.inWords = pWords if g("controlInWordsProj") else words
-            self.outWords = pWords if g("controlOutWordsProj") else words
-        self.memDpMask = None
-        keep = self.dropouts["memory"]
-        if g("memoryVariationalDropout") and keep != 1.0:
-            # ops.generateVarDpMask / applyVarDpMask (ops.py:1054-1067): one mask per batch, x / keep * mask
-            ones = torch.ones((batchSize, g("memDim")), dtype=torch.float32, device=self.knowledgeBase.device)
-            self.memDpMask = _Dropout.apply(ones, self.seed, SITE_MEM_VAR, 0, keep, self.b0 * g("memDim"))
+        self.contControl = out["control"]
         self.iteration = 0
-        return MACCellTuple(initialControl, initialMemory)
+        return MACCellTuple(out["control"], out["memory"])
+
+    # ---- one step (mac_cell.py:420-480)
+    def __call__(self, inputs, state, scope=None):
+        if scope not in (None, "MACCell"):
+            raise UnsupportedOptions("the plan names the cell's variables under MACnetwork/MACCell (model.py:453-458 passes no scope)")
+        seg = self.plan().steps[int(self.iteration)]
+        have = {"vecQuestions": self.vecQuestions, "knowledgeBase": self.knowledgeBase, "lengths": self.questionLengths,
+                "control": state.control, "memory": state.memory, **self._carry}
+        if "controls" in seg.feeds:
+            have["controls"], have["memories"] = self.controls, self.memories
+        out = self._segment(seg, {k: have[k] for k in seg.feeds})
+        self._carry["cont_control"] = self.contControl = out["cont_control"]
+        for key, name in (("question", "att_question"), ("kb", "att_kb"), ("self", "att_self"), ("gate", "att_gate")):
+            if name in out:
+                self.attentions[key].append(out[name])
+        for key in ("control", "memory", "info"):
+            self._hist[key].append(out[key])
+        return self.none, MACCellTuple(out["control"], out["memory"])
 
     # ---- the loop of model.py:453-458
     def run(self):
