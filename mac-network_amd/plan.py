@@ -15,7 +15,7 @@ PyTorch owns memory, streams, concat / stack copies.  What the option values mea
 an option compiler emitting a dataflow plan, an interpreter with its own reverse sweep -- is not.
 """
 import collections
-from contextlib import contextmanager
+from contextlib import ExitStack, contextmanager
 
 import torch
 
@@ -195,19 +195,16 @@ class _Emitter:
     def join(self, parts):
         return parts[0] if len(parts) == 1 else self.emit(sum(self.w[q] for q in parts), "cat", *parts)
 
-    # -- d -> 1 scores, softmax (optionally behind the length mask), attention-weighted sum
-    def scores(self, x, width, tag="", drop=None):
-        with self.names("inter2logits" + tag):
-            return self.dense(x, width, 1, tag="logits", drop=drop)
-
+    # -- attention: d -> 1 scores ("inter2logits/linearLayerlogits", inside "inter2att<tag>" when the unit wraps it), softmax
+    #    (behind the length mask when `lengths` is fed), then the weights' sum over `values`
     def attend(self, x, width, values, tag="", drop=None, lengths=None, wrap=True):
-        if wrap:
-            with self.names("inter2att" + tag):
-                logits = self.scores(x, width, drop=drop)
-        else:
-            logits = self.scores(x, width, drop=drop)
-        att = self.emit(None, "softmax", logits, *([lengths] if lengths is not None else []))
-        return att, self.emit(self.w.get(values), "wsum", att, values)
+        path = (["inter2att" + tag] if wrap else []) + ["inter2logits"]
+        with ExitStack() as scopes:
+            for part in path:
+                scopes.enter_context(self.names(part))
+            scores = self.dense(x, width, 1, tag="logits", drop=drop)
+        weights = self.emit(None, "softmax", scores, *(() if lengths is None else (lengths,)))
+        return weights, self.emit(self.w.get(values), "wsum", weights, values)
 
     # -- the pairwise interaction of ops.mul (ops.py:668-725): optional projections of both sides (with their dropout sites),
     #    MUL / bilinear / additive combination, optional concat of an operand
