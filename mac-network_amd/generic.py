@@ -587,6 +587,40 @@ class GenericMACCell:
             self._hist[key].append(out[key])
         return self.none, MACCellTuple(out["control"], out["memory"])
 
+    # ---- the units on their own, with the reference's method signatures (mac_cell.py:133, 209, 305): each call compiles (once)
+    #      and runs the unit's segment of the plan for the current `iteration`; attentions are appended like in a step
+    def _unit(self, which, feeds):
+        from . import plan as _plan
+        key = (which, int(self.iteration))
+        cache = self.__dict__.setdefault("_unit_plans", {})
+        if key not in cache:
+            cache[key] = _plan.compile_unit(self.config, which, int(self.iteration))
+            for name, spec in cache[key].variables.items():
+                self.params.ensure(name, spec.shape, spec.init)
+        seg = cache[key].init
+        have = dict(feeds, lengths=self.questionLengths, **getattr(self, "_carry", {}))
+        if "controls" in seg.feeds:
+            have["controls"], have["memories"] = self.controls, self.memories
+        out = self._segment(seg, {k: have[k] for k in seg.feeds})
+        for k, name in (("question", "att_question"), ("kb", "att_kb"), ("self", "att_self"), ("gate", "att_gate")):
+            if name in out:
+                self.attentions[k].append(out[name])
+        return out
+
+    def control(self, controlInput, inWords, outWords, questionLengths, control, contControl=None, name=""):
+        out = self._unit("control", {"control_input": controlInput, "in_words": inWords, "out_words": outWords, "control": control,
+                                     "cont_control": contControl})
+        return out["control"], out["cont_control"]
+
+    def read(self, knowledgeBase, memory, control, name=""):
+        return self._unit("read", {"knowledgeBase": knowledgeBase, "memory": memory, "control": control})["info"]
+
+    def write(self, memory, info, control, contControl=None, name=""):
+        return self._unit("write", {"memory": memory, "info": info, "control": control, "cont_control": contControl})["memory"]
+
+    inWords = property(lambda self: self._carry["in_words"])
+    outWords = property(lambda self: self._carry["out_words"])
+
     # ---- the loop of model.py:453-458
     def run(self):
         state = self.zero_state(self.batchSize)

@@ -113,7 +113,8 @@ class CellPlan:
 class _Emitter:
     """layer-level vocabulary on top of Segment.emit; keeps the variable table, the scope names and every slot's last-axis width"""
 
-    FEED_WIDTH = {"knowledgeBase": "memDim", "memory": "memDim", "mem_mask": "memDim", "memories": "memDim", "control": "ctrlDim",
+    FEED_WIDTH = {"knowledgeBase": "memDim", "memory": "memDim", "mem_mask": "memDim", "memories": "memDim", "info": "memDim",
+                  "control": "ctrlDim", "control_input": "ctrlDim",
                   "cont_control": "ctrlDim", "controls": "ctrlDim", "vecQuestions": "ctrlDim", "words": "ctrlDim", "in_words": "ctrlDim",
                   "out_words": "ctrlDim"}
 
@@ -278,109 +279,145 @@ def compile_cell(config, netLength):
     for i in range(netLength):
         seg = e.begin(Segment("step%d" % i))
         plan.steps.append(seg)
-        suffix = str(i) if o("unsharedCells") else ""
         vq = e.feed("vecQuestions")
         with e.names("MACnetwork"), e.names("MACCell"):
             # question -> this step's control input (mac_cell.py:442-448)
             cin = e.activation(o("controlInputAct"), e.dense(vq, dc, dc, tag="qInput"))
             cin = e.dense(cin, dc, dc, tag=("qInput%d" % i) if o("controlInputUnshared") else "qInputU")
-
-            # ---- control unit (mac_cell.py:133-187)
-            with e.names("control" + suffix):
-                query, width = cin, dc
-                if o("controlFeedPrev"):
-                    parts = [e.feed("control") if o("controlFeedPrevAtt") else e.feed("cont_control")]
-                    if o("controlFeedInputs"):
-                        parts.append(cin)
-                    query = e.dense(e.join(parts), dc * len(parts), dc, tag="contControl", act=o("controlContAct"))
-                scored = e.pair("mul", e.feed("in_words"), query, "mid")
-                if o("controlConcatWords"):
-                    scored, width = e.join([scored, e.feed("in_words")]), width + dc
-                if o("controlProj"):
-                    scored, width = e.dense(scored, width, dc, act=o("controlProjAct")), dc
-                att_q, control = e.attend(scored, width, e.feed("out_words"), lengths=seg.feed("lengths"), wrap=False)
-                if o("controlContinuous"):
-                    control = query
+            control, query = _control_unit(e, i, cin)
             if o("controlWholeQ"):
                 control = vq
-            seg.results["att_question"], seg.results["cont_control"] = att_q, query
-
-            # ---- read unit (mac_cell.py:209-277)
-            with e.names("read" + suffix):
-                memory, kb = e.feed("memory"), e.feed("knowledgeBase")
-                if o("memoryVariationalDropout"):
-                    remembered = e.pair("mul", memory, e.feed("mem_mask"))
-                else:
-                    remembered = e.dropout(memory, ("mem", "memory", i))
-                project = {"width": da, "shared": o("readProjShared")} if o("readProjInputs") else None
-                width = da if project else dm
-                first = e.interact(kb, remembered, dm, "memInter", mode=o("readMemAttType"), project=project,
-                                   keep_x=o("readMemConcatKB"), keep_projected=o("readMemConcatProj"),
-                                   sites=(("read_kb", "read", i), ("read_mem", "read", i)))
-                found = first["value"]
-                if o("readMemProj"):
-                    found = e.dense(found, first["width"], width, tag="memKbProj", act=o("readMemAct"))
-                else:
-                    width = first["width"]
-                if o("readCtrl"):
-                    if dc != width:
-                        raise NameError("name 'ctrlDim' is not defined")                       # mac_cell.py:246
-                    found = e.interact(found, control, width, "ctrlInter", mode=o("readCtrlAttType"), keep_x=o("readCtrlConcatInter"))["value"]
-                    if o("readCtrlConcatKB"):
-                        extra, extra_w = (first.get("projected_x"), da) if o("readCtrlConcatProj") else (kb, dm)
-                        if extra is None:
-                            raise ValueError("None values not supported.")                    # tf.concat([..., None])
-                        found, width = e.join([found, extra]), width + extra_w
-                    found = e.activation(o("readCtrlAct"), found)
-                if e.w[found] != width:            # the logits layer is built for `width` inputs: TF's shape check
-                    raise ValueError("Dimensions must be equal, but are %d and %d" % (e.w[found], width))
-                source = kb
-                if o("readSmryKBProj"):
-                    source = first.get("projected_x")
-                    if source is None:
-                        raise ValueError("None values not supported.")                        # attention * None
-                att_kb, info = e.attend(found, width, source, drop=("read_att", "read", i))
-            seg.results["att_kb"] = att_kb
+            info = _read_unit(e, i, e.feed("knowledgeBase"), e.feed("memory"), control)
             info = e.dropout(info, ("write_info", "write", i))
             seg.results["info"] = info
-
-            # ---- write unit (mac_cell.py:305-375)
-            with e.names("write" + suffix):
-                if o("writeInfoProj"):
-                    info = e.dense(info, dm, dm, tag="info")
-                info = e.activation(o("writeInfoAct"), info)
-                recalled = None
-                if o("writeSelfAtt"):
-                    probe = e.dense(query if o("writeSelfAttMod") == "CONT" else control, dc, dc, tag="ctrlProj")
-                    att_s, recalled = e.attend(e.pair("mul", e.feed("controls"), probe, "mid"), dc, e.feed("memories"), tag="selfAttention")
-                    seg.results["att_self"] = att_s
-                how = o("writeInputs")
-                if how == "INFO":
-                    parts = [info]
-                elif how == "SUM":
-                    parts = [e.pair("add", memory, info)]
-                elif how == "BOTH":
-                    parts = [memory, info] + ([e.pair("mul", memory, info)] if o("writeConcatMul") else [])
-                else:
-                    parts = [memory]
-                if recalled is not None:
-                    parts.append(recalled)
-                if o("writeMergeCtrl"):
-                    parts.append(control)
-                new, width = e.join(parts), dm * len(parts)
-                if o("writeMemProj") or width != dm:
-                    new = e.dense(new, width, dm, tag="newMemory")
-                new = e.activation(o("writeMemAct"), new)
-                if o("writeGate"):
-                    if o("writeGateShared"):
-                        raise ValueError("Dimensions must be equal")                          # [B,d] * [B] (mac_cell.py:367)
-                    gate = e.emit(dm, "act", e.dense(control, dc, dm, tag="gate", const_bias=o("writeGateBias")), code=_lib.ACT["SIGMOID"])
-                    seg.results["att_gate"] = gate
-                    new = e.emit(dm, "blend", new, memory, gate)                              # new * z + memory * (1 - z)
-                if o("memoryBN"):
-                    new = _batch_norm(e, new, dm, o("bnDecay"), o("bnCenter"), o("bnScale"))
-            seg.results["control"], seg.results["memory"] = control, new
+            seg.results["control"], seg.results["memory"] = control, _write_unit(e, i, e.feed("memory"), info, control, query)
     return plan
+
+
+def compile_unit(config, unit, step=0):
+    """ONE unit of step `step` as a segment of its own (per-unit contract), named like the reference's methods:
+    "control" (controlInput, in_words, out_words, lengths, control, cont_control), "read" (knowledgeBase, memory, control),
+    "write" (memory, info, control, cont_control).  Variables are named as inside the full cell."""
+    plan = CellPlan()
+    e = _Emitter(config, plan)
+    seg = plan.init = e.begin(Segment(unit))
+    with e.names("MACnetwork"), e.names("MACCell"):
+        if unit == "control":
+            ctl, query = _control_unit(e, step, e.feed("control_input"))
+            seg.results["control"] = ctl
+            seg.results.move_to_end("control")
+        elif unit == "read":
+            seg.results["info"] = _read_unit(e, step, e.feed("knowledgeBase"), e.feed("memory"), e.feed("control"))
+        elif unit == "write":
+            seg.results["memory"] = _write_unit(e, step, e.feed("memory"), e.feed("info"), e.feed("control"), e.feed("cont_control"))
+        else:
+            raise KeyError(unit)
+    return plan
+
+
+def _control_unit(e, i, cin):
+    """mac_cell.py:133-187 -> (control, continuous control)"""
+    o, seg = e.opt, e.seg
+    dc = int(o("ctrlDim"))
+    with e.names("control" + (str(i) if o("unsharedCells") else "")):
+        query, width = cin, dc
+        if o("controlFeedPrev"):
+            parts = [e.feed("control") if o("controlFeedPrevAtt") else e.feed("cont_control")]
+            if o("controlFeedInputs"):
+                parts.append(cin)
+            query = e.dense(e.join(parts), dc * len(parts), dc, tag="contControl", act=o("controlContAct"))
+        scored = e.pair("mul", e.feed("in_words"), query, "mid")
+        if o("controlConcatWords"):
+            scored, width = e.join([scored, e.feed("in_words")]), width + dc
+        if o("controlProj"):
+            scored, width = e.dense(scored, width, dc, act=o("controlProjAct")), dc
+        att_q, control = e.attend(scored, width, e.feed("out_words"), lengths=seg.feed("lengths"), wrap=False)
+        if o("controlContinuous"):
+            control = query
+    seg.results["att_question"], seg.results["cont_control"] = att_q, query
+    return control, query
+
+
+def _read_unit(e, i, kb, memory, control):
+    """mac_cell.py:209-277 -> information"""
+    o, seg = e.opt, e.seg
+    dc, dm, da = int(o("ctrlDim")), int(o("memDim")), int(o("attDim"))
+    with e.names("read" + (str(i) if o("unsharedCells") else "")):
+        if o("memoryVariationalDropout"):
+            remembered = e.pair("mul", memory, e.feed("mem_mask"))
+        else:
+            remembered = e.dropout(memory, ("mem", "memory", i))
+        project = {"width": da, "shared": o("readProjShared")} if o("readProjInputs") else None
+        width = da if project else dm
+        first = e.interact(kb, remembered, dm, "memInter", mode=o("readMemAttType"), project=project,
+                           keep_x=o("readMemConcatKB"), keep_projected=o("readMemConcatProj"),
+                           sites=(("read_kb", "read", i), ("read_mem", "read", i)))
+        found = first["value"]
+        if o("readMemProj"):
+            found = e.dense(found, first["width"], width, tag="memKbProj", act=o("readMemAct"))
+        else:
+            width = first["width"]
+        if o("readCtrl"):
+            if dc != width:
+                raise NameError("name 'ctrlDim' is not defined")                       # mac_cell.py:246
+            found = e.interact(found, control, width, "ctrlInter", mode=o("readCtrlAttType"), keep_x=o("readCtrlConcatInter"))["value"]
+            if o("readCtrlConcatKB"):
+                extra, extra_w = (first.get("projected_x"), da) if o("readCtrlConcatProj") else (kb, dm)
+                if extra is None:
+                    raise ValueError("None values not supported.")                    # tf.concat([..., None])
+                found, width = e.join([found, extra]), width + extra_w
+            found = e.activation(o("readCtrlAct"), found)
+        if e.w[found] != width:            # the logits layer is built for `width` inputs: TF's shape check
+            raise ValueError("Dimensions must be equal, but are %d and %d" % (e.w[found], width))
+        source = kb
+        if o("readSmryKBProj"):
+            source = first.get("projected_x")
+            if source is None:
+                raise ValueError("None values not supported.")                        # attention * None
+        att_kb, info = e.attend(found, width, source, drop=("read_att", "read", i))
+    seg.results["att_kb"] = att_kb
+    return info
+
+
+def _write_unit(e, i, memory, info, control, query):
+    """mac_cell.py:305-375 -> new memory (`query`: this step's continuous control)"""
+    o, seg = e.opt, e.seg
+    dc, dm = int(o("ctrlDim")), int(o("memDim"))
+    with e.names("write" + (str(i) if o("unsharedCells") else "")):
+        if o("writeInfoProj"):
+            info = e.dense(info, dm, dm, tag="info")
+        info = e.activation(o("writeInfoAct"), info)
+        recalled = None
+        if o("writeSelfAtt"):
+            probe = e.dense(query if o("writeSelfAttMod") == "CONT" else control, dc, dc, tag="ctrlProj")
+            att_s, recalled = e.attend(e.pair("mul", e.feed("controls"), probe, "mid"), dc, e.feed("memories"), tag="selfAttention")
+            seg.results["att_self"] = att_s
+        how = o("writeInputs")
+        if how == "INFO":
+            parts = [info]
+        elif how == "SUM":
+            parts = [e.pair("add", memory, info)]
+        elif how == "BOTH":
+            parts = [memory, info] + ([e.pair("mul", memory, info)] if o("writeConcatMul") else [])
+        else:
+            parts = [memory]
+        if recalled is not None:
+            parts.append(recalled)
+        if o("writeMergeCtrl"):
+            parts.append(control)
+        new, width = e.join(parts), dm * len(parts)
+        if o("writeMemProj") or width != dm:
+            new = e.dense(new, width, dm, tag="newMemory")
+        new = e.activation(o("writeMemAct"), new)
+        if o("writeGate"):
+            if o("writeGateShared"):
+                raise ValueError("Dimensions must be equal")                          # [B,d] * [B] (mac_cell.py:367)
+            gate = e.emit(dm, "act", e.dense(control, dc, dm, tag="gate", const_bias=o("writeGateBias")), code=_lib.ACT["SIGMOID"])
+            seg.results["att_gate"] = gate
+            new = e.emit(dm, "blend", new, memory, gate)                              # new * z + memory * (1 - z)
+        if o("memoryBN"):
+            new = _batch_norm(e, new, dm, o("bnDecay"), o("bnCenter"), o("bnScale"))
+    return new
 
 
 def _batch_norm(e, x, c, decay, center, scale, eps=0.001):

@@ -241,3 +241,50 @@ def run_random_sets(macx, seed, dev=None):
             if want.grad is not None and float(want.grad.abs().max()) > 1e-6:
                 assert rel_err(got.grad, want.grad) < 2e-4 * k * kink, over
     assert built >= 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the units on their own (plan.compile_unit behind GenericMACCell.control / read / write), host logic
+# ---------------------------------------------------------------------------------------------------------------------
+def _unit_cells(macx, cfg, B, S, N, d, train):
+    vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, d, seed=13)
+    params = oracle_params(cfg, vq, words, lengths, kb)
+    keeps = (cfg.memoryDropout, cfg.readDropout, cfg.writeDropout) if train else (1.0, 1.0, 1.0)
+    op = {k: v.double().clone().requires_grad_(True) for k, v in params.items()}
+    vs = mo.VarStore(params=op, dtype=torch.float64)
+    ocell = mo.MACCellOracle(cfg, vs, vq.double(), words.double(), words.double(), lengths, kb.double(), keeps[0], keeps[1], keeps[2], B, train,
+                             mask_fn=mo.hash_mask_fn(5, keeps, b0=0) if train else None)
+    with vs.scope("MACnetwork"):
+        ocell.zero_state(B)
+    gp = macx.GenericParams().load_reference_dict(params)
+    hcell = macx.GenericMACCell(vq, words, words, lengths, kb, cfg.memoryDropout, cfg.readDropout, cfg.writeDropout, B, train,
+                                config=cfg, params=gp, seed=5, b0=0)
+    hcell.zero_state(B)
+    return ocell, vs, op, hcell, gp, kb, lengths
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_units_on_their_own_host_logic(macx, host_generic, train):
+    B, S, N, d = 3, 6, 12, 128
+    rand = lambda seed: torch.randn((B, d), generator=torch.Generator().manual_seed(seed))
+    cfg = mo.flag_file_config("args3", netLength=2, memDim=d, ctrlDim=d, attDim=d, controlProj=True, writeGate=True)
+    ocell, vs, op, hcell, gp, kb, lengths = _unit_cells(macx, cfg, B, S, N, d, train)
+    mem, ctl, cin, info, w = rand(1), rand(2), rand(3), rand(4), rand(5)
+    with vs.scope("MACnetwork"), vs.scope("MACCell"):
+        ref_c, ref_cc = ocell.control(cin.double(), ocell.inWords, ocell.outWords, lengths, ctl.double(), ctl.double())
+        ref_r = ocell.read(kb.double(), mem.double(), ctl.double())
+        ref_w = ocell.write(mem.double(), info.double(), ctl.double(), ctl.double())
+    ((ref_c + ref_cc + ref_r + ref_w) * w.double()).sum().backward()
+    got_c, got_cc = hcell.control(cin, hcell.inWords, hcell.outWords, hcell.questionLengths, ctl, ctl)
+    got_r = hcell.read(kb, mem, ctl)
+    got_w = hcell.write(mem, info, ctl, ctl)
+    ((got_c + got_cc + got_r + got_w) * w).sum().backward()
+    for a, b in ((got_c, ref_c), (got_cc, ref_cc), (got_r, ref_r), (got_w, ref_w)):
+        assert rel_err(a, b) < 1e-5
+    grads = gp.grads_by_name()
+    seen = 0
+    for k, v in op.items():
+        if v.grad is not None:
+            assert_grad(grads[k], v.grad, k)
+            seen += 1
+    assert seen > 10

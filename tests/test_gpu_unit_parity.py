@@ -58,8 +58,7 @@ def test_read_unit(macx, dev, name, over, train):
         info_ref = ocell.read(kbo, mo_, co_)
     (info_ref * w.double()).sum().backward()
     mh, ch, kbh = [t.to(dev).requires_grad_(True) for t in (mem, ctl, kb)]
-    with hcell._net_scope(), hcell.vs.scope("MACCell"):
-        info = hcell.read(kbh, mh, ch)
+    info = hcell.read(kbh, mh, ch)
     (info * w.to(dev)).sum().backward()
     torch.cuda.synchronize()
     assert rel_err(info, info_ref) < 1e-5
@@ -81,8 +80,7 @@ def test_write_unit(macx, dev, over):
         ref = ocell.write(a[0], a[1], a[2], a[2])
     (ref * w.double()).sum().backward()
     h = [t.to(dev).requires_grad_(True) for t in (mem, info, ctl)]
-    with hcell._net_scope(), hcell.vs.scope("MACCell"):
-        out = hcell.write(h[0], h[1], h[2], h[2])
+    out = hcell.write(h[0], h[1], h[2], h[2])
     (out * w.to(dev)).sum().backward()
     torch.cuda.synchronize()
     assert rel_err(out, ref) < 1e-5
@@ -103,8 +101,7 @@ def test_control_unit(macx, dev, name, over):
         ref, ref_cc = ocell.control(a[0], ocell.inWords, ocell.outWords, lengths, a[1], a[2])
     ((ref + ref_cc) * w.double()).sum().backward()
     h = [t.to(dev).requires_grad_(True) for t in (cin, ctl, cc)]
-    with hcell._net_scope(), hcell.vs.scope("MACCell"):
-        out, out_cc = hcell.control(h[0], hcell.inWords, hcell.outWords, hcell.questionLengths, h[1], h[2])
+    out, out_cc = hcell.control(h[0], hcell.inWords, hcell.outWords, hcell.questionLengths, h[1], h[2])
     ((out + out_cc) * w.to(dev)).sum().backward()
     torch.cuda.synchronize()
     assert rel_err(out, ref) < 1e-5 and rel_err(out_cc, ref_cc) < 1e-5
