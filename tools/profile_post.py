@@ -66,9 +66,7 @@ def main(tag):
         out["in_step_kernel_ms"] = round(sv["avg_us"] / 1e3, 5)
     elem = B * N * D
     hbm = []
-    for pat, name, byts in ((r"chain_bwd_kernelILi512ELi0", "chain_bwd_kernel<512> (I2, H1 H2 in; dI2, dI1, dX H2 out) -- MFMA-bound, listed for its HBM side",
-                             elem * 4 * 5),
-                            (r"h2_from_f32_kernel", "h2_from_f32_kernel (KB -> H2 through the read dropout, + keep bits/bytes)", elem * 8 + elem // 4),
+    for pat, name, byts in (                            (r"h2_from_f32_kernel", "h2_from_f32_kernel (KB -> H2 through the read dropout, + keep bits/bytes)", elem * 8 + elem // 4),
                             (r"read_att_bwd_h2_kernel", "read_att_bwd_h2_kernel (I2 H2 in, dI2 H2 out)", elem * 8),
                             (r"kb_attend_kernel", "kb_attend_kernel (softmax over N + sum_n a KB)", elem * 4),
                             (r"kb_att_da_kernel", "kb_att_da_kernel (da = dr . KB)", elem * 4)):
