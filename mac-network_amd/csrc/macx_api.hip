@@ -254,7 +254,7 @@ struct BwdLayout {
   size_t ns_big, ngroup;
   size_t db_rows;   // rows per step of db1_part / dbx_part
   size_t dwk_rows;  // rows per step of dwk_part / db2_part
-  size_t dc_part, dls_part;   // chain kernel: per-row-group partials of dc / db_k of the current step
+  size_t dc_part, dls_part;   // chain kernel: per-row-group partials of dc / db_k, [p][dwk_rows][3][d] and [p][dwk_rows][3]
   bool chain_sums;
   size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part, ctrl_dl;
   size_t tmpBd[4];  // [B,d] scratch
@@ -315,7 +315,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.db1_part = take(p * nrb * d);
   L.dbx_part = take(p * nrb * d);
   L.dwk_part = take(p * L.dwk_rows * d);
-  if (L.chain_sums) { L.dc_part = take(L.dwk_rows * 3 * d); L.dls_part = take(L.dwk_rows * 3); }
+  if (L.chain_sums) { L.dc_part = take(p * L.dwk_rows * 3 * d); L.dls_part = take(p * L.dwk_rows * 3); }
   L.dbk_part = take(p * B);
   L.dwc_part = take(B * d);
   L.dbc_part = take(p * B);
@@ -504,6 +504,26 @@ hipError_t rowsum(const float* src, int rows, int n, size_t ld, float* dst, hipS
   hipLaunchKernelGGL(rowsum_kernel, dim3((n + ROWSUM_COLS - 1) / ROWSUM_COLS, nz), dim3(1024), 0, st, src, rows, n, ld, dst, zsrc, zdst);
   return hipGetLastError();
 }
+// row sums collected while a pass is enqueued and launched together at its end (sources must stay untouched until then)
+struct RowsumBatch {
+  RowsumList L;
+  int n = 0, max_n = 0;
+  hipError_t add(const float* src, int rows, int cols, size_t ld, float* dst, hipStream_t st, int nz = 1, size_t zsrc = 0, size_t zdst = 0) {
+    if (!dst) return hipSuccess;
+    for (int z = 0; z < nz; ++z) {
+      if (n == ROWSUM_MAX) { hipError_t e = run(st); if (e != hipSuccess) return e; }
+      L.d[n++] = RowsumDesc{src + (size_t)z * zsrc, dst + (size_t)z * zdst, rows, cols, ld};
+      max_n = cols > max_n ? cols : max_n;
+    }
+    return hipSuccess;
+  }
+  hipError_t run(hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rowsum_list_kernel, dim3((max_n + ROWSUM_COLS - 1) / ROWSUM_COLS, n), dim3(1024), 0, st, L);
+    n = 0; max_n = 0;
+    return hipGetLastError();
+  }
+};
 hipError_t axpy(const float* x, size_t n, float* y, hipStream_t st) {
   hipLaunchKernelGGL(axpy_kernel, dim3(64), dim3(256), 0, st, x, n, y);
   return hipGetLastError();
@@ -682,6 +702,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   const float* m_prev = memories + (size_t)i * Bd;
   float* m_new = memories + (size_t)(i + 1) * Bd;
   float* md = saved + L.md + (size_t)i * Bd;
+  const bool md_fused = units == U_ALL && !o->write_gate;   // the write unit's linear also writes the next step's dropped memory
   float* y = saved + L.y + (size_t)i * Bd;
   float* X = saved + L.X + (size_t)i * L.act_stride;
   float* H1 = saved + L.H1 + (size_t)i * L.act_stride;
@@ -720,8 +741,11 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   const DropSpec dm = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
                                                     : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
   const DropSpec dry = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i);
-  hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md);
-  CK(hipGetLastError());
+  // (from step 1 on, the previous step's write unit left this step's dropped memory behind: md_fused below)
+  if (!(md_fused && i > 0)) {
+    hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md);
+    CK(hipGetLastError());
+  }
   {
     LinP l = lin_basic(md, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON, y, d);
     CK(small_linear_launch(l, 1, st));
@@ -862,6 +886,15 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     l.seg[1] = LinSeg{info, d, d, 0};
     l.Ktot = 2 * d;
     if (self_smry) { l.seg[2] = LinSeg{self_smry, d, d, 0}; l.Ktot = 3 * d; }
+    if (md_fused && i + 1 < s->p) {
+      // the new memory is the next step's read-unit input: its two dropouts (mac_cell.py:214-217, ops.py:679) ride this epilogue
+      l.use_drop = 2;
+      l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
+                                           : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i + 1);
+      l.d2 = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i + 1);
+      l.drop_row0 = (uint32_t)s->b0;
+      l.out_drop = saved + L.md + (size_t)(i + 1) * Bd; l.ld_od = d;
+    }
     CK(small_linear_launch(l, 1, st));
     if (o->write_gate) {
       // z = sigmoid(control Wg + bg + gateBias); m = newMemory * z + memory * (1 - z)   (mac_cell.py:358-367)
@@ -917,6 +950,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   if ((units & U_CONTROL) && (!GI->words || !GI->vecQuestions)) return MACX_EINVAL;
   if (units != U_ALL && (!ug || s->p != 1)) return MACX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  RowsumBatch rs;                     // bias-gradient row sums of this call: one launch at the end of each phase
   const SavedLayout L = make_saved(o, s, 1);
   const BwdLayout W = make_bwd(o, s);
   if (saved_floats < L.total || ws_floats < W.total) return MACX_ESMALL;
@@ -982,6 +1016,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const float* infos = saved + L.seg[MACX_SEG_INFOS];
   const float* att_kb = saved + L.seg[MACX_SEG_ATT_KB];
 
+  const bool dc_in_loop = (units & U_CONTROL) && o->control_feed_prev;
   for (int i = p - 1; i >= 0; --i) {
     const float* c_i = controls + (size_t)(i + 1) * Bd;
     const float* X = saved + L.X + (size_t)i * L.act_stride;
@@ -1105,7 +1140,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         if (W.chain_sums) {
           c.dwk_part = ws + W.dwk_part + (size_t)i * W.dwk_rows * d;
           c.db2_part = ws + W.db2_part + (size_t)i * W.dwk_rows * d;
-          c.dc_part = ws + W.dc_part; c.dls_part = ws + W.dls_part;
+          c.dc_part = ws + W.dc_part + (size_t)i * W.dwk_rows * 3 * d; c.dls_part = ws + W.dls_part + (size_t)i * W.dwk_rows * 3;
         }
         c.bytes2 = rdrop ? reinterpret_cast<const uint8_t*>(saved + L.att_bits + (size_t)i * L.bits_stride) : nullptr;
         c.inv2 = rdrop ? 1.0f / dp->keep_read : 1.0f;
@@ -1115,11 +1150,13 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         c.W1aT = wref(W.w1aT_p); c.W1bT = wref(W.w1bT_p); c.y = y;
         c.dX = hdX; c.qmin_dX = q_dX; c.dbx_part = ws + W.dbx_part + (size_t)i * W.db_rows * d;
         CK(chain_bwd_launch(c, st));
-        if (W.chain_sums) {
+        if (W.chain_sums && dc_in_loop) {       // the recurrent control unit differentiates through dL/dc_i inside this iteration
           DcReduceP q;
-          q.B = B; q.N = N; q.d = d; q.dc_part = ws + W.dc_part; q.dls_part = ws + W.dls_part;
+          q.B = B; q.N = N; q.d = d;
+          q.dc_part = ws + W.dc_part + (size_t)i * W.dwk_rows * 3 * d; q.dls_part = ws + W.dls_part + (size_t)i * W.dwk_rows * 3;
           q.dc = DC + (size_t)(i + 1) * Bd; q.dbk_part = ws + W.dbk_part + (size_t)i * B;
-          hipLaunchKernelGGL(dc_reduce_kernel, dim3(B), dim3(128), 0, st, q);
+          q.part_step = q.dls_step = q.dc_step = q.dbk_step = 0;
+          hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, 1), dim3(128), 0, st, q);
           CK(hipGetLastError());
         }
       } else {
@@ -1290,6 +1327,16 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       }
     }
   }
+  if ((units & U_READ) && h2_mode() && W.chain_sums && !dc_in_loop) {
+    // dL/dc_i += the read unit's part, db_k partials: every step's per-tile partials in one launch (nothing inside the loop
+    // read dL/dc_i: the control unit is not recurrent)
+    DcReduceP q;
+    q.B = B; q.N = N; q.d = d;
+    q.dc_part = ws + W.dc_part; q.dls_part = ws + W.dls_part; q.dc = DC + Bd; q.dbk_part = ws + W.dbk_part;
+    q.part_step = W.dwk_rows * 3 * d; q.dls_step = W.dwk_rows * 3; q.dc_step = Bd; q.dbk_step = B;
+    hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, p), dim3(128), 0, st, q);
+    CK(hipGetLastError());
+  }
 
   if (units == U_ALL) {
   if (o->write_self_att && !o->write_self_att_cont && !o->control_feed_prev) {
@@ -1300,8 +1347,8 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   }
   if (o->control_feed_prev) {
     // word-attention parameter partials were accumulated step by step
-    CK(rowsum(ws + W.dwc_part, B, d, d, GP->ctrlLogits_w, st));
-    CK(rowsum(ws + W.dbc_part, p * B, 1, 1, GP->ctrlLogits_b, st));
+    CK(rs.add(ws + W.dwc_part, B, d, d, GP->ctrlLogits_w, st));
+    CK(rs.add(ws + W.dbc_part, p * B, 1, 1, GP->ctrlLogits_b, st));
     // contControl weights: one contraction over all p*B rows per input segment
     const bool two = o->control_cont_act != MACX_ACT_NON;
     const float* prev_all = o->control_feed_prev_att ? controls : nullptr;   // rows of step i = c_{i-1} = controls[i]
@@ -1317,10 +1364,10 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     }
     if (o->control_feed_inputs)
       CKI(wgrad_impl(saved + L.cI, d, ws + W.dlin1, d, p * B, d, d, GP->contControl_W + dd, ws + W.small_slab, st));
-    CK(rowsum(ws + W.dlin1, p * B, d, d, GP->contControl_b, st));
+    CK(rs.add(ws + W.dlin1, p * B, d, d, GP->contControl_b, st));
     if (two) {
       CKI(wgrad_impl(saved + L.cc_h, d, ws + W.dcc, d, p * B, d, d, GP->contControl2_W, ws + W.small_slab, st));
-      CK(rowsum(ws + W.dcc, p * B, d, d, GP->contControl2_b, st));
+      CK(rs.add(ws + W.dcc, p * B, d, d, GP->contControl2_b, st));
     }
   }
   // ---- control unit backward.  Not recurrent: every control depends on the question only, so all
@@ -1339,8 +1386,8 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     hipLaunchKernelGGL(control_bwd_dl_kernel, dim3(B, p), dim3(256), 0, st, c);
     hipLaunchKernelGGL(control_bwd_apply_kernel, dim3(B, d / 64), dim3(256), 0, st, c);
     CK(hipGetLastError());
-    CK(rowsum(ws + W.dwc_part, B, d, d, GP->ctrlLogits_w, st));
-    CK(rowsum(ws + W.dbc_part, p * B, 1, 1, GP->ctrlLogits_b, st));
+    CK(rs.add(ws + W.dwc_part, B, d, d, GP->ctrlLogits_w, st));
+    CK(rs.add(ws + W.dbc_part, p * B, 1, 1, GP->ctrlLogits_b, st));
   }
   if (o->write_self_att) {
     // the self-attention control projection reads contControl (== controlInput here) or the control:
@@ -1351,14 +1398,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     if (o->write_self_att_cont && !o->control_feed_prev) CK(small_linear_launch(l, p, st));
     const float* src = o->write_self_att_cont ? saved + L.cc : controls + Bd;
     CKI(wgrad_impl(src, d, ws + W.dsc, d, p * B, d, d, GP->selfCtrl_W, ws + W.small_slab, st));
-    CK(rowsum(ws + W.dsc, p * B, d, d, GP->selfCtrl_b, st));
-    CK(rowsum(ws + W.dws_part, p * B, d, d, GP->selfLogits_w, st));
-    CK(rowsum(ws + W.dbs_part, p * B, 1, 1, GP->selfLogits_b, st));
+    CK(rs.add(ws + W.dsc, p * B, d, d, GP->selfCtrl_b, st));
+    CK(rs.add(ws + W.dws_part, p * B, d, d, GP->selfLogits_w, st));
+    CK(rs.add(ws + W.dbs_part, p * B, 1, 1, GP->selfLogits_b, st));
   }
   }   // U_ALL
   if (o->write_gate && (units & U_WRITE)) {
     CKI(wgrad_impl(controls + Bd, d, ws + W.dzpre, d, p * B, d, d, GP->gate_W, ws + W.small_slab, st));
-    CK(rowsum(ws + W.dzpre, p * B, d, d, GP->gate_b, st));
+    CK(rs.add(ws + W.dzpre, p * B, d, d, GP->gate_b, st));
   }
   if (units == U_ALL) {
   // ---- control inputs backward (mac_cell.py:442-448): dt = sum_i dcI_i WqU_i^T ; du = dt * act'(t)
@@ -1385,14 +1432,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       for (int i = 0; i < p; ++i)
         CKI(wgrad_impl(ctrl_t, d, ws + W.dcI + (size_t)i * Bd, d, B, d, d, GP->qInputU_W + (size_t)i * dd, ws + W.small_slab, st));
     }
-    CK(rowsum(ws + W.dcI, B, d, d, GP->qInputU_b, st, p, Bd, d));
+    CK(rs.add(ws + W.dcI, B, d, d, GP->qInputU_b, st, p, Bd, d));
   } else {
     hipLaunchKernelGGL(sum_parts_kernel, dim3(256), dim3(256), 0, st, (const float*)(ws + W.dcI), p, Bd, dcI_sum);
     CK(hipGetLastError());
     LinP ls = lin_basic(dcI_sum, d, d, B, ws + W.wqUT, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
     CK(small_linear_launch(ls, 1, st));
     CKI(wgrad_impl(ctrl_t, d, dcI_sum, d, B, d, d, GP->qInputU_W, ws + W.small_slab, st));
-    CK(rowsum(dcI_sum, B, d, d, GP->qInputU_b, st));
+    CK(rs.add(dcI_sum, B, d, d, GP->qInputU_b, st));
   }
   hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dt), ctrl_t, o->control_input_act, Bd,
                      ws + W.du);
@@ -1402,26 +1449,26 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     CK(small_linear_launch(l, 1, st));
   }
   CKI(wgrad_impl(in->vecQuestions, d, ws + W.du, d, B, d, d, GP->qInput_W, ws + W.small_slab, st));
-  CK(rowsum(ws + W.du, B, d, d, GP->qInput_b, st));
+  CK(rs.add(ws + W.du, B, d, d, GP->qInput_b, st));
 
   // ---- initial state (mac_cell.py:496-505)
-  if (o->init_mem == MACX_INIT_PRM) CK(rowsum(DM, B, d, d, GP->initMem, st));
+  if (o->init_mem == MACX_INIT_PRM) CK(rs.add(DM, B, d, d, GP->initMem, st));
   else if (o->init_mem == MACX_INIT_Q) CK(axpy(DM, Bd, GI->vecQuestions, st));
-  if (o->init_ctrl == MACX_INIT_PRM) CK(rowsum(DC, B, d, d, GP->initCtrl, st));
+  if (o->init_ctrl == MACX_INIT_PRM) CK(rs.add(DC, B, d, d, GP->initCtrl, st));
   else if (o->init_ctrl == MACX_INIT_Q) CK(axpy(DC, Bd, GI->vecQuestions, st));
 
   }   // U_ALL
   // ---- weight gradients of the [B,d] linears, one contraction over all p*B rows each
   if (units & U_READ) {
     CKI(wgrad_impl(saved + L.md, d, ws + W.DY, d, p * B, d, d, GP->projY_W, ws + W.small_slab, st));
-    CK(rowsum(ws + W.DY, p * B, d, d, GP->projY_b, st));
+    CK(rs.add(ws + W.DY, p * B, d, d, GP->projY_b, st));
   }
   if (units & U_WRITE) {
     CKI(wgrad_impl(memories, d, dwlin_all, d, p * B, d, d, GP->newMemory_W, ws + W.small_slab, st));
     CKI(wgrad_impl(infos, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + dd, ws + W.small_slab, st));
     if (o->write_self_att)
       CKI(wgrad_impl(saved + L.self_smry, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + 2 * dd, ws + W.small_slab, st));
-    CK(rowsum(dwlin_all, p * B, d, d, GP->newMemory_b, st));
+    CK(rs.add(dwlin_all, p * B, d, d, GP->newMemory_b, st));
   }
   if (units == U_READ) {
     // the read unit alone: dL/d(memory) = (dy Wy^T) through the two masks, dL/d(control) from the attention logits
@@ -1430,6 +1477,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   }
 
   }   // phase != 2
+  CK(rs.run(st));
   if (phase == 1 || !(units & U_READ)) return MACX_OK;
 
   // ---- read-unit weights: fixed-order reduction of the per-step slabs
@@ -1476,11 +1524,12 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   CK(slab_reduce_launch(ws + W.slab_wx, (int)W.ns_big, dd, GP->projX_W, 0, st));
   CK(slab_reduce_launch(ws + W.slab_w1a, (int)(p * W.ngroup), dd, GP->memKbProj_W, 0, st));
   CK(slab_reduce_launch(ws + W.slab_w1b, (int)(p * W.ngroup), dd, GP->memKbProj_W + dd, 0, st));
-  CK(rowsum(ws + W.db2_part, p * (int)W.dwk_rows, d, d, GP->memKbProj2_b, st));
-  CK(rowsum(ws + W.db1_part, p * (int)W.db_rows, d, d, GP->memKbProj_b, st));
-  CK(rowsum(ws + W.dbx_part, p * (int)W.db_rows, d, d, GP->projX_b, st));
-  CK(rowsum(ws + W.dwk_part, p * (int)W.dwk_rows, d, d, GP->kbLogits_w, st));
-  CK(rowsum(ws + W.dbk_part, p * B, 1, 1, GP->kbLogits_b, st));
+  CK(rs.add(ws + W.db2_part, p * (int)W.dwk_rows, d, d, GP->memKbProj2_b, st));
+  CK(rs.add(ws + W.db1_part, p * (int)W.db_rows, d, d, GP->memKbProj_b, st));
+  CK(rs.add(ws + W.dbx_part, p * (int)W.db_rows, d, d, GP->projX_b, st));
+  CK(rs.add(ws + W.dwk_part, p * (int)W.dwk_rows, d, d, GP->kbLogits_w, st));
+  CK(rs.add(ws + W.dbk_part, p * B, 1, 1, GP->kbLogits_b, st));
+  CK(rs.run(st));
   return MACX_OK;
 }
 }  // namespace

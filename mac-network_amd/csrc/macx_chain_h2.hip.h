@@ -71,6 +71,14 @@ __device__ __forceinline__ float row8_sum(float v) {
   return v;
 }
 
+// ELU inside the chain kernels: exp(x) - 1 on the negative side, without the cancellation-free polynomial of elu_f.  The
+// absolute error near zero (1 ulp of 1.0) is below what the value loses when it is stored as an H2 slot (2^-22 of the row
+// maximum) or summed into a logit, and the epilogues apply it to 64 values per lane.
+__device__ __forceinline__ float chain_act(int act, float x) {
+  if (act == ACT_ELU) return x > 0.0f ? x : __expf(x) - 1.0f;
+  return act_apply(act, x);
+}
+
 template <int D_>
 struct ChainGeo {
   static constexpr int D = D_, R = 64, KG = D / 8, CB = D / 128, KS = D / 32;
@@ -81,8 +89,10 @@ struct ChainGeo {
   static constexpr int IT = KG / 8;                  // conversion passes: slot columns per lane (16 rows x 4 slot columns per wave step)
   static constexpr size_t P_BYTES = (size_t)4 * R * D;
   static constexpr int QS = 5;                       // backward: questions a tile can touch (N >= 16) -- their control vectors are staged in LDS
-  // P | sMax [8][R] | sPart [8][R] | sE [R] | sE2 [R] | sCol [2][D] | sW [D] | sC [QS][D]
-  static constexpr size_t LDS = P_BYTES + (size_t)R * (8 + 8 + 1 + 1) * 4 + (size_t)(2 + 1 + QS) * D * 4;
+  static constexpr int BITS_LD = KG + 4;             // bytes per row of sBits (+4: rows 4 apart would share a bank)
+  // P | sMax [8][R] | sPart [8][R] | sE [R] | sE2 [R] | sCol [2][D] | sW [D] | sC [QS][D] | sBits [R][BITS_LD]
+  static constexpr size_t LDS = P_BYTES + (size_t)R * (8 + 8 + 1 + 1) * 4 + (size_t)(2 + 1 + QS) * D * 4 + (size_t)R * BITS_LD;
+  static_assert((R * BITS_LD) % 16 == 0, "LDS carve-outs stay 16-byte aligned");
   static_assert(D % 128 == 0 && D >= 128 && D <= 512, "one workgroup holds 64 rows x D as H2 planes in LDS");
 };
 
@@ -99,6 +109,7 @@ struct ChainCtx {
   float* sCol;      // [2][D] column sums of the two row halves
   float* sW;        // [D] backward: the logits weight
   float* sC;        // [QS][D] backward: control vectors of the tile's questions
+  uint8_t* sBits;   // [R][BITS_LD] forward: keep bits of the attention dropout (ops.py:312), one byte per 8 columns
   int tid, lane, wave, li, lg;
   int wr, wc, colbase, rowbase;
   int M, N, nvalid;
@@ -114,6 +125,7 @@ struct ChainCtx {
     sCol = reinterpret_cast<float*>(sE2 + R);
     sW = sCol + 2 * D;
     sC = sW + D;
+    sBits = reinterpret_cast<uint8_t*>(sC + G::QS * D);
     tid = threadIdx.x; lane = tid & 63;
     wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     li = lane & 15; lg = lane >> 4;
@@ -198,26 +210,45 @@ struct ChainCtx {
   }
   // ---- row-block conversion pass (backward stage B0): lane (r8 = lane & 7, kq = lane >> 3) of wave w < KG / 8 holds slot column
   // 8 w + kq of the rows r8 + 8 s, s = 0..7 -- eight rows per lane, so sums over rows accumulate in registers, a wave's 8-lane
-  // groups read and write whole 128-byte lines, and a wave owns its columns for the whole tile.  v[s][0..7]: the slot of row
-  // block s.
-  __device__ __forceinline__ void convert_finish_blk(float (&v)[8][8], const H2View& out, int* eTab, int* qmin) const {
+  // groups read and write whole 128-byte lines, and a wave owns its columns for the whole tile.
+  // The values are parked in P as fp32 while the pass runs (blk_park: slot (kg, row) = 32 bytes, the tile's fp32 image is
+  // exactly the size of its two fp16 planes) and only come back to registers here, once the pass's own accumulators are
+  // gone: holding all 64 through the pass cost 86 spilled registers.
+  __device__ __forceinline__ char* blk_slot(int kg, int row) const { return P + ((size_t)kg * R + row) * 32; }
+  __device__ __forceinline__ void blk_park(int kg, int row, const float (&o)[8]) const {
+    char* d = blk_slot(kg, row);
+    const int h = ((lane >> 3) & 1) * 16;            // lanes 8 apart would write the same banks: swap the slot's halves
+    *reinterpret_cast<f32x4*>(d + h) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(d + 16 - h) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+  // mx[s]: max |value| of this lane's slot of row block s
+  __device__ __forceinline__ void convert_finish_blk(const float (&mx)[8], const H2View& out, int* eTab, int* qmin) const {
     const int r8 = lane & 7, kq = lane >> 3;
     const bool active = wave < KG / 8;
+    const int kg = 8 * wave + kq;
     if (active) {
 #pragma unroll
       for (int sb = 0; sb < 8; ++sb) {
-        float m = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[sb][q]));
+        float m = mx[sb];
         m = fmaxf(m, dpp_mov_f<0x128>(m));                 // lane ^ 8 (row_ror:8 within 16 lanes)
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         if (kq == 0) sMax[wave * R + 8 * sb + r8] = m;
       }
     }
-    __syncthreads();
+    float v[8][8];
     if (active) {
-      const int kg = 8 * wave + kq;
+      const int h = (kq & 1) * 16;
+#pragma unroll
+      for (int sb = 0; sb < 8; ++sb) {
+        const char* d = blk_slot(kg, 8 * sb + r8);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(d + h), b = *reinterpret_cast<const f32x4*>(d + 16 - h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[sb][q] = a[q]; v[sb][4 + q] = b[q]; }
+      }
+    }
+    __syncthreads();                                       // sMax complete; every fp32 slot is in its owner's registers
+    if (active) {
       const size_t Rp = out.Rp();
       const size_t opb = out.plane_bytes();
 #pragma unroll
@@ -469,11 +500,13 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
         }
         if (p.bits1 && x.cvalid) p.bits1[x.cgrow * KG + kg] = (uint8_t)byte;
       }
-      if (drop2 && p.bytes2 && x.cvalid) {
+      if (drop2) {
+        // hashed once per element, here: the logits epilogue of stage 3 reads the bits back from LDS
         uint32_t byte = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) byte |= (keep_bit(e0 + q, p.key2, p.thr2) ? 1u : 0u) << q;
-        p.bytes2[(size_t)kg * Rp2 + x.cgrow] = (uint8_t)byte;
+        x.sBits[x.crow * C::G::BITS_LD + kg] = (uint8_t)byte;
+        if (p.bytes2 && x.cvalid) p.bytes2[(size_t)kg * Rp2 + x.cgrow] = (uint8_t)byte;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[j][q]));
@@ -495,7 +528,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
       for (int t = 0; t < RT; ++t) {
         const float s = h2_unscale(eTab[x.arow(t)], eW);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[t][c][q] = act_apply(ACT, fmaf(acc[t][c][q], s, bv[q]));
+        for (int q = 0; q < 4; ++q) acc[t][c][q] = chain_act(ACT, fmaf(acc[t][c][q], s, bv[q]));
       }
     }
   };
@@ -590,11 +623,11 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
           const int col = x.acol(c);
           const f32x4 cv = *reinterpret_cast<const f32x4*>(cq + col);
           const f32x4 wv = *reinterpret_cast<const f32x4*>(p.wk + col);
-          const uint32_t e0 = p.first + (uint32_t)(gr * D + col);
+          const uint32_t kb = drop2 ? (uint32_t)x.sBits[x.arow(t) * C::G::BITS_LD + (col >> 3)] >> (col & 4) : 0xFu;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float g = act_apply(ACT, acc[t][c][q] * cv[q]);
-            if (drop2) g = keep_bit(e0 + q, p.key2, p.thr2) ? g * p.inv2 : 0.f;
+            float g = chain_act(ACT, acc[t][c][q] * cv[q]);
+            if (drop2) g = ((kb >> q) & 1u) ? g * p.inv2 : 0.f;
             part = fmaf(g, wv[q], part);
           }
         }
@@ -687,7 +720,9 @@ struct ChainBwdP {
   float* dbx_part;          // [tiles][d] column sums of dX
 };
 
-template <int D_, int KV = 0>
+// A2: readCtrlAct as a compile-time constant (ACT_ELU, what "RELU" means in the published configurations) or -1 = decided per
+// value at run time.  Two kernels rather than two arms in one: the arms met in one register allocation (86 spilled registers).
+template <int D_, int KV = 0, int A2 = -1>
 __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   using C = ChainCtx<D_>;
   constexpr int D = C::D, R = C::R, KG = C::KG, CB = C::CB, CT = C::CT, RT = C::RT, IT = C::IT;
@@ -734,7 +769,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
     // (no keep bytes: any readable bytes stand in and are overridden -- a branch around a load costs a full wait per load)
     const uint8_t* bytes_src = p.bytes2 ? p.bytes2 : reinterpret_cast<const uint8_t*>(p.I2.base);
     const uint32_t bits_or = p.bytes2 ? 0u : 0xFFu;
-    float v[8][8];
+    float mx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // the kept I2 slots, the keep bytes and the rows' scalars are requested three row blocks ahead of their use (all eight at
     // once would hold 100 registers more than the kernel has).  Rows past the end lie in the tensors' pad rows
     // (H2_PAD_ROWS = 64 = one tile): readable, never used
@@ -771,15 +806,18 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       float i2[8];
       h2_join8(raw[sb][0], raw[sb][1], inv[sb], i2);
       const bool rv = 8 * sb + r8 < x.nvalid;
+      float o[8];
+      float m = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         i2[e] = rv ? i2[e] : 0.f;            // (pad rows hold anything, NaN included: select, do not multiply by zero)
         const float cv = e < 4 ? c0[e & 3] : c1[e & 3], wv = e < 4 ? w0[e & 3] : w1[e & 3];
-        const float g = act_apply(ACT, i2[e] * cv);
+        const float g = chain_act(ACT, i2[e] * cv);
         const float f = (((bits[sb] | bits_or) >> e) & 1u) ? p.inv2 : 0.f;
         const float dz = (dlr[sb] * wv) * f * act_grad_from_out(ACT, g);
         const float ov = dz * cv;
-        v[sb][e] = ov;
+        o[e] = ov;
+        m = fmaxf(m, fabsf(ov));
         a_dw[e] = fmaf(dlr[sb], g * f, a_dw[e]);              // dw_k += dl * dropped(G)
         a_db[e] += ov;
         const float t = dz * i2[e];                            // dc += dZ * I2, per question of the row
@@ -787,6 +825,8 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
         a_dc[1][e] += seg[sb] == 1 ? t : 0.f;
         a_dc[2][e] += seg[sb] == 2 ? t : 0.f;
       }
+      mx[sb] = m;
+      x.blk_park(kg, 8 * sb + r8, o);
     };
     auto pass = [&](auto act_c) __attribute__((always_inline)) {
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2_ = std::integral_constant<int, 2>;
@@ -803,12 +843,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       block(act_c, I6{}); __builtin_amdgcn_sched_barrier(0);
       block(act_c, I7{});
     };
-    // two instances only (ELU, what "RELU" means in the published configurations, and a per-value switch for the rest): five
-    // inlined copies of this body meet in one register allocation and spill ~250 registers
-    if (active) {
-      if (p.act2 == ACT_ELU) pass(std::integral_constant<int, ACT_ELU>{});
-      else pass(std::integral_constant<int, -1>{});
-    }
+    if (active) pass(std::integral_constant<int, A2>{});
     if (sums && active) {
       // the wave owns these columns for the whole tile: sum the eight lanes that share a slot column, one lane stores
       float* dw = p.dwk_part + tile * D + kg * 8;
@@ -845,7 +880,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
         if (x.tid == 0) p.dls_part[tile * 3 + k] = t;
       }
     }
-    x.convert_finish_blk(v, p.dI2, x.sE, p.qmin_dI2);
+    x.convert_finish_blk(mx, p.dI2, x.sE, p.qmin_dI2);
   }
   if (p.dbg & 1) return;
 
@@ -930,14 +965,19 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   x.colsum_finish(p.dbx_part + tile * D);
 }
 
-template <int D_, int KV = 0>
-inline hipError_t chain_bwd_launch_t(const ChainBwdP& p, hipStream_t st) {
-  auto kern = chain_bwd_kernel<D_, KV>;
+template <int D_, int KV, int A2>
+inline hipError_t chain_bwd_launch_a(const ChainBwdP& p, hipStream_t st) {
+  auto kern = chain_bwd_kernel<D_, KV, A2>;
   constexpr size_t lds = ChainGeo<D_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((p.M + 63) / 64), dim3(512), lds, st, p);
   return hipGetLastError();
+}
+
+template <int D_, int KV = 0>
+inline hipError_t chain_bwd_launch_t(const ChainBwdP& p, hipStream_t st) {
+  return p.act2 == ACT_ELU ? chain_bwd_launch_a<D_, KV, ACT_ELU>(p, st) : chain_bwd_launch_a<D_, KV, -1>(p, st);
 }
 
 inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
@@ -962,9 +1002,12 @@ struct DcReduceP {
   const float* dls_part;    // [tiles][3]
   float* dc;                // [B][d] accumulated in place
   float* dbk_part;          // [B]
+  size_t part_step, dls_step, dc_step, dbk_step;      // blockIdx.y = step: floats between the steps' buffers
 };
 __global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
   const int q = blockIdx.x;
+  p.dc_part += blockIdx.y * p.part_step; p.dls_part += blockIdx.y * p.dls_step;
+  p.dc += blockIdx.y * p.dc_step; p.dbk_part += blockIdx.y * p.dbk_step;
   const size_t r0 = (size_t)q * p.N, r1 = r0 + p.N - 1;
   const int t0 = (int)(r0 >> 6), t1 = (int)(r1 >> 6);
   for (int c4 = threadIdx.x * 4; c4 < p.d; c4 += 512) {

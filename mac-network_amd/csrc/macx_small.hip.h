@@ -163,6 +163,7 @@ struct LinP {
   // optional epilogue pieces (applied in this order after bias/act)
   const float* actgrad_src; int actgrad_act; int ld_ag; size_t zag;  // val *= act'(src)
   int use_drop; DropSpec d1, d2; uint32_t drop_row0;                // val *= f1*f2, idx=(drop_row0+r)*n_out+j
+  float* out_drop; int ld_od;       // use_drop == 2: `out` keeps val, out_drop receives val*f1*f2 (the next consumer's dropped copy)
   const float* addend; int ld_add; size_t zadd;                      // val += addend
   size_t rep_stride;
 };
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
   const int r = tid >> 2, cq = (tid & 3) * 4;
   const int row = r0 + r;
   if (r >= L_ROWS || row >= p.rows) return;
-  f32x4 val;
+  f32x4 val, vald = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 4; ++e) val[e] = ((red[0][r][cq + e] + red[1][r][cq + e]) + red[2][r][cq + e]) + red[3][r][cq + e];
   const int col = c0 + cq;
@@ -247,12 +248,14 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
       float f = 1.f;
       if (!keep_bit(idx, p.d1.key, p.d1.thr24)) f = 0.f; else f *= p.d1.inv_keep;
       if (!keep_bit(idx, p.d2.key, p.d2.thr24)) f = 0.f; else f *= p.d2.inv_keep;
-      v *= f;
+      if (p.use_drop == 2) vald[e] = v * f;
+      else v *= f;
     }
     if (p.addend) v += p.addend[(size_t)z * p.zadd + (size_t)row * p.ld_add + col + e];
     val[e] = v;
   }
   *reinterpret_cast<f32x4*>(p.out + (size_t)z * p.zout + (size_t)row * p.ldo + col) = val;
+  if (p.use_drop == 2) *reinterpret_cast<f32x4*>(p.out_drop + (size_t)row * p.ld_od + col) = vald;
 }
 
 inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
@@ -323,6 +326,36 @@ __global__ __launch_bounds__(1024) void rowsum_kernel(const float* __restrict__ 
 #pragma unroll
     for (int w = 1; w < 64; ++w) t += red[w][c];
     dst[i] = t;
+  }
+}
+
+// several row sums in one launch (blockIdx.y selects the descriptor): the backward pass ends in a dozen bias gradients, each
+// a launch of a few microseconds with nothing depending on it but the caller
+struct RowsumDesc { const float* src; float* dst; int rows, n; size_t ld; };
+constexpr int ROWSUM_MAX = 40;
+struct RowsumList { RowsumDesc d[ROWSUM_MAX]; };
+__global__ __launch_bounds__(1024) void rowsum_list_kernel(RowsumList L) {
+  __shared__ float red[64][ROWSUM_COLS + 1];
+  const RowsumDesc q = L.d[blockIdx.y];
+  if ((int)blockIdx.x * ROWSUM_COLS >= q.n) return;
+  const int c = threadIdx.x & (ROWSUM_COLS - 1), rg = threadIdx.x / ROWSUM_COLS;
+  const int i = blockIdx.x * ROWSUM_COLS + c;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < q.n) {           // the same order of additions as rowsum_kernel
+    int r = rg;
+    for (; r + 64 < q.rows; r += 128) {
+      s0 += q.src[(size_t)r * q.ld + i];
+      s1 += q.src[(size_t)(r + 64) * q.ld + i];
+    }
+    if (r < q.rows) s0 += q.src[(size_t)r * q.ld + i];
+  }
+  red[rg][c] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && i < q.n) {
+    float t = red[0][c];
+#pragma unroll
+    for (int w = 1; w < 64; ++w) t += red[w][c];
+    q.dst[i] = t;
   }
 }
 
