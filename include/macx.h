@@ -476,7 +476,9 @@ int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint
  *            (cache-hot), 128 weight-gradient contractions on the f32 TN kernel, 256 S_b kernel on the f32 kernel
  *   key 2  forced row tiles per GEMM workgroup (0 = automatic | 1 | 2 | 4 | 7 | 13)
  *   key 3  = macx_gemm_mode
- *   key 4  0: the read unit's products as separate launches (A/B against the chain kernels of macx_chain_h2.hip.h); 1: default */
+ *   key 4  0: the read unit's products as separate launches (A/B against the chain kernels of macx_chain_h2.hip.h); 1: default
+ *   key 5  0: the per-question contraction S_b = X_b^T dI1_b once per step (it then also delivers dy); 1 (default): dy from the
+ *          chain kernel, S_b of all steps in one launch at the end of the backward pass */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

@@ -55,6 +55,8 @@ inline bool h2_mode() { return gemm_split_mode() == 2; }
 // the read unit's forward products as one kernel (macx_chain_h2.hip.h); macx_debug_set(4, 0) falls back to the four launches
 inline int& chain_mode() { static int m = 1; return m; }
 inline bool use_chain(int d, int N) { return h2_mode() && chain_mode() && chain_supported(d, N); }
+// dy from the chain kernel and S_b of all steps as one deferred launch; macx_debug_set(5, 0): sb_h2 once per step, as before
+inline int& sb_defer_mode() { static int m = 1; return m; }
 inline int wfmt_plain() { return h2_mode() ? 3 : (gemm_split_mode() ? 1 : 0); }
 inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
 inline size_t wsize(size_t K, size_t n) { return K * n * 3 / 2; }     // covers format 1 (3/2) and format 3 (1 + the exponent)
@@ -255,7 +257,10 @@ struct BwdLayout {
   size_t db_rows;   // rows per step of db1_part / dbx_part
   size_t dwk_rows;  // rows per step of dwk_part / db2_part
   size_t dc_part, dls_part;   // chain kernel: per-row-group partials of dc / db_k, [p][dwk_rows][3][d] and [p][dwk_rows][3]
+  size_t dyc_part;            // chain kernel: per-row-group partials of dy, [dwk_rows][3][d]
   bool chain_sums;
+  bool sb_deferred;           // dy comes from the chain kernel: dI1 is kept per step and S_b of all steps is ONE launch at the end
+  size_t dI1_stride;          // floats between the steps' dI1 (0: one buffer)
   size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part, ctrl_dl;
   size_t tmpBd[4];  // [B,d] scratch
   size_t dccx;      // [p+1,B,d] gradient reaching cc_i from the NEXT step's contControl input (feedPrevAtt off)
@@ -287,7 +292,10 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.wqUT = take((o->control_input_unshared ? p : 1) * d * d);
   L.wccT = take(2 * d * d); L.wcc2T = take(d * d); L.wscT = take(d * d); L.wgT = take(d * d);
   L.act_floats = h2_mode() ? al4(h2_floats(B * N, d)) : B * N * d;
-  L.dI2 = take(p * L.act_floats); L.dI1 = take(L.act_floats); L.dX = take(p * L.act_floats); L.da = take(B * N);   // dI2, dX kept per step
+  L.chain_sums = use_chain((int)d, (int)N) && N >= 32;
+  L.sb_deferred = L.chain_sums && sb_defer_mode();
+  L.dI1_stride = L.sb_deferred ? L.act_floats : 0;
+  L.dI2 = take(p * L.act_floats); L.dI1 = take((L.sb_deferred ? p : 1) * L.act_floats); L.dX = take(p * L.act_floats); L.da = take(B * N);   // dI2, dX (dI1) kept per step
   L.DM = take((p + 1) * B * d);
   L.DC = take((p + 1) * B * d);
   L.dcI = take(p * B * d);
@@ -303,19 +311,18 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.ngroup = (B + sb_qpg((int)B, (int)N) - 1) / sb_qpg((int)B, (int)N);
   L.slab_w2 = take(L.ns_big * d * d);
   L.slab_wx = take(L.ns_big * d * d);
-  L.slab_w1a = take(p * L.ngroup * d * d);
-  L.slab_w1b = take(p * L.ngroup * d * d);
+  L.slab_w1a = take((L.sb_deferred ? 1 : p) * L.ngroup * d * d);
+  L.slab_w1b = take((L.sb_deferred ? 1 : p) * L.ngroup * d * d);
   // column-sum partials of dI1 / dX: one row per GEMM workgroup row block, or per 64-row tile of the chain kernel
   const size_t nrb = use_chain((int)d, (int)N) ? (B * N + 63) / 64 : B * nrb_of((int)N, (int)B, (int)d);
   L.db_rows = nrb;
   // dw_k / db2 partials: one row per question, or per 64-row tile when the chain kernel sums them (N >= 32)
-  L.chain_sums = use_chain((int)d, (int)N) && N >= 32;
   L.dwk_rows = L.chain_sums ? (B * N + 63) / 64 : B;
   L.db2_part = take(p * L.dwk_rows * d);
   L.db1_part = take(p * nrb * d);
   L.dbx_part = take(p * nrb * d);
   L.dwk_part = take(p * L.dwk_rows * d);
-  if (L.chain_sums) { L.dc_part = take(p * L.dwk_rows * 3 * d); L.dls_part = take(p * L.dwk_rows * 3); }
+  if (L.chain_sums) { L.dc_part = take(p * L.dwk_rows * 3 * d); L.dls_part = take(p * L.dwk_rows * 3); L.dyc_part = take(L.dwk_rows * 3 * d); }
   L.dbk_part = take(p * B);
   L.dwc_part = take(B * d);
   L.dbc_part = take(p * B);
@@ -1016,7 +1023,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const float* infos = saved + L.seg[MACX_SEG_INFOS];
   const float* att_kb = saved + L.seg[MACX_SEG_ATT_KB];
 
-  const bool dc_in_loop = (units & U_CONTROL) && o->control_feed_prev;
   for (int i = p - 1; i >= 0; --i) {
     const float* c_i = controls + (size_t)(i + 1) * Bd;
     const float* X = saved + L.X + (size_t)i * L.act_stride;
@@ -1101,7 +1107,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     if (h2_mode()) {
       const int R = B * N, CB = d / 128;
       const H2View hI2 = h2_view(I2, R, d), hH1 = h2_view(H1, R, d), hX = h2_view(X, R, d);
-      const H2View hdI2 = h2_view(dI2_i, R, d), hdI1 = h2_view(ws + W.dI1, R, d), hdX = h2_view(dX_i, R, d);
+      const H2View hdI2 = h2_view(dI2_i, R, d), hdI1 = h2_view(ws + W.dI1 + (size_t)i * W.dI1_stride, R, d), hdX = h2_view(dX_i, R, d);
       int* q_dI2 = reinterpret_cast<int*>(ws + W.qmin_dI2) + (size_t)i * B * CB;
       int* q_dI1 = reinterpret_cast<int*>(ws + W.qmin_dI1) + (size_t)i * B * CB;
       int* q_dX = reinterpret_cast<int*>(ws + W.qmin_dX) + (size_t)i * B * CB;
@@ -1149,13 +1155,16 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         c.dI1 = hdI1; c.qmin_dI1 = q_dI1; c.db1_part = ws + W.db1_part + (size_t)i * W.db_rows * d;
         c.W1aT = wref(W.w1aT_p); c.W1bT = wref(W.w1bT_p); c.y = y;
         c.dX = hdX; c.qmin_dX = q_dX; c.dbx_part = ws + W.dbx_part + (size_t)i * W.db_rows * d;
+        if (W.sb_deferred) { c.X = hX; c.dy_part = ws + W.dyc_part; }
         CK(chain_bwd_launch(c, st));
-        if (W.chain_sums && dc_in_loop) {       // the recurrent control unit differentiates through dL/dc_i inside this iteration
+        if (W.chain_sums) {
+          // the per-tile partials of this step: dL/dc_i += read-unit part, db_k partials, dy_i (the next launch needs dy_i)
           DcReduceP q;
+          memset(&q, 0, sizeof(q));
           q.B = B; q.N = N; q.d = d;
           q.dc_part = ws + W.dc_part + (size_t)i * W.dwk_rows * 3 * d; q.dls_part = ws + W.dls_part + (size_t)i * W.dwk_rows * 3;
           q.dc = DC + (size_t)(i + 1) * Bd; q.dbk_part = ws + W.dbk_part + (size_t)i * B;
-          q.part_step = q.dls_step = q.dc_step = q.dbk_step = 0;
+          if (W.sb_deferred) { q.dy_part = ws + W.dyc_part; q.dy = ws + W.DY + (size_t)i * Bd; }
           hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, 1), dim3(128), 0, st, q);
           CK(hipGetLastError());
         }
@@ -1173,9 +1182,11 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       g.colsum_part = ws + W.dbx_part + (size_t)i * B * nrb * d;
       CK((kb_gemm_h2_launch<B_YMIX_COL, E_PLAIN, true>(g, st)));
       }
-      // S_b = X_b^T dI1_b -> dW1a / dW1b slabs and dy partials
-      {
+      // S_b = X_b^T dI1_b -> dW1a / dW1b slabs and dy partials (deferred: one launch over all steps in phase 2, dy from the chain kernel)
+      if (!W.sb_deferred) {
         SbH2P q;
+        memset(&q, 0, sizeof(q));
+        q.nsteps = 1;
         q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B, N);
         q.X = hX; q.dI1 = hdI1;
         q.qminX = reinterpret_cast<const int*>(saved + L.qmin_X) + (size_t)i * L.qmin_stride; q.qminG = q_dI1;
@@ -1253,8 +1264,10 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     }
     // dy -> d(md) -> dL/d m_{i-1} = dwin[:, :d] + (dy Wy^T) * memmask * readmask
     float* DYi = ws + W.DY + (size_t)i * Bd;
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(256), dim3(256), 0, st, (const float*)(ws + W.dy_part), (h2_mode() ? SBH_CW / 2 : 2) * d / 128, Bd, DYi);
-    CK(hipGetLastError());
+    if (!(h2_mode() && W.sb_deferred)) {
+      hipLaunchKernelGGL(sum_parts_kernel, dim3(256), dim3(256), 0, st, (const float*)(ws + W.dy_part), (h2_mode() ? SBH_CW / 2 : 2) * d / 128, Bd, DYi);
+      CK(hipGetLastError());
+    }
     {
       // with self attention DM[i] already holds the parts later steps sent to this memory: accumulate
       const bool acc_prev = (units & U_WRITE) && (o->write_self_att || o->write_gate);
@@ -1327,17 +1340,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       }
     }
   }
-  if ((units & U_READ) && h2_mode() && W.chain_sums && !dc_in_loop) {
-    // dL/dc_i += the read unit's part, db_k partials: every step's per-tile partials in one launch (nothing inside the loop
-    // read dL/dc_i: the control unit is not recurrent)
-    DcReduceP q;
-    q.B = B; q.N = N; q.d = d;
-    q.dc_part = ws + W.dc_part; q.dls_part = ws + W.dls_part; q.dc = DC + Bd; q.dbk_part = ws + W.dbk_part;
-    q.part_step = W.dwk_rows * 3 * d; q.dls_step = W.dwk_rows * 3; q.dc_step = Bd; q.dbk_step = B;
-    hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, p), dim3(128), 0, st, q);
-    CK(hipGetLastError());
-  }
-
   if (units == U_ALL) {
   if (o->write_self_att && !o->write_self_att_cont && !o->control_feed_prev) {
     // selfControl = the NEW control: dL/dc_i += dsc_i Ws^T before the word attention is differentiated
@@ -1522,8 +1524,26 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   }
   CK(slab_reduce_launch(ws + W.slab_w2, (int)W.ns_big, dd, GP->memKbProj2_W, 0, st));
   CK(slab_reduce_launch(ws + W.slab_wx, (int)W.ns_big, dd, GP->projX_W, 0, st));
-  CK(slab_reduce_launch(ws + W.slab_w1a, (int)(p * W.ngroup), dd, GP->memKbProj_W, 0, st));
-  CK(slab_reduce_launch(ws + W.slab_w1b, (int)(p * W.ngroup), dd, GP->memKbProj_W + dd, 0, st));
+  if (h2_mode() && W.sb_deferred) {
+    // dW1a = sum_i sum_b diag(y_ib) S_ib, dW1b = sum_i sum_b S_ib, S_ib = X_ib^T dI1_ib: every step in one launch, the two
+    // accumulators of a workgroup run through all of them (macx_wgrad_h2.hip.h)
+    const int CB = d / 128;
+    SbH2P q;
+    memset(&q, 0, sizeof(q));
+    q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B, N);
+    q.X = h2_view(saved + L.X, B * N, d); q.dI1 = h2_view(ws + W.dI1, B * N, d);
+    q.qminX = reinterpret_cast<const int*>(saved + L.qmin_X); q.qminG = reinterpret_cast<const int*>(ws + W.qmin_dI1);
+    q.y = saved + L.y; q.W1a = P->memKbProj_W;
+    q.dW1a_part = ws + W.slab_w1a; q.dW1b_part = ws + W.slab_w1b; q.dy_part = nullptr;
+    q.nsteps = p;
+    q.x_step = L.act_stride * sizeof(float); q.g_step = W.dI1_stride * sizeof(float); q.y_step = Bd;
+    q.qx_step = L.qmin_stride; q.qg_step = (size_t)B * CB;
+    q.dbg = kb_gemm_dbg();
+    CK(sb_h2_launch(q, st));
+  }
+  const int nslab1 = (int)((h2_mode() && W.sb_deferred ? 1 : p) * W.ngroup);
+  CK(slab_reduce_launch(ws + W.slab_w1a, nslab1, dd, GP->memKbProj_W, 0, st));
+  CK(slab_reduce_launch(ws + W.slab_w1b, nslab1, dd, GP->memKbProj_W + dd, 0, st));
   CK(rs.add(ws + W.db2_part, p * (int)W.dwk_rows, d, d, GP->memKbProj2_b, st));
   CK(rs.add(ws + W.db1_part, p * (int)W.db_rows, d, d, GP->memKbProj_b, st));
   CK(rs.add(ws + W.dbx_part, p * (int)W.db_rows, d, d, GP->projX_b, st));
@@ -2479,6 +2499,7 @@ int macx_debug_set(int key, int value) {
   if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }
   if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
   if (key == 4 && (value == 0 || value == 1)) { chain_mode() = value; return MACX_OK; }
+  if (key == 5 && (value == 0 || value == 1)) { sb_defer_mode() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

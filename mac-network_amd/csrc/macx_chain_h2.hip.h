@@ -718,6 +718,11 @@ struct ChainBwdP {
   const float* y;           // [B][d]
   H2View dX; int* qmin_dX;
   float* dbx_part;          // [tiles][d] column sums of dX
+  // dy[q][k] = sum over the question's rows of (dI1 W1a^T)[r][k] * X[r][k]  (ops.py:703: d(x * y)/dy = x): the first product of
+  // stage B2 is exactly the left factor, so dy costs one read of the kept X tile -- and the per-question contraction
+  // S_b = X_b^T dI1_b that used to deliver it (sb_h2_kernel) leaves the recurrence and runs once, over all steps, at the end
+  H2View X;                 // the step's kept X
+  float* dy_part;           // [tiles][3][d] per question segment, like dc_part; null: not computed
 };
 
 // A2: readCtrlAct as a compile-time constant (ACT_ELU, what "RELU" means in the published configurations) or -1 = decided per
@@ -934,6 +939,57 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   // stage B2: dX = (dI1 W1a^T) * y + dI1 W1b^T   (ops.py:703: d(x*y)/dx = y per column, per question)
   x.zero_acc(acc);
   x.template kloop<KV>(acc, p.W1aT.planes);
+  if (p.dy_part) {
+    const int q0 = (int)((uint32_t)x.grow0 / (uint32_t)p.N), q1 = (int)(((uint32_t)x.grow0 + x.nvalid - 1) / (uint32_t)p.N);
+    const int nq = q1 - q0 + 1;                          // <= 3: the caller asks for this only when N >= 32
+    const uint32_t qb1 = (uint32_t)(q0 + 1) * (uint32_t)p.N, qb2 = qb1 + (uint32_t)p.N;
+    const int eW = *p.W1aT.exp;
+    const size_t Rp = p.X.Rp();
+    const size_t xpb = p.X.plane_bytes();
+    float sr[RT];
+    int sg[RT];
+    size_t gr[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      gr[t] = min(x.grow0 + x.arow(t), (size_t)M - 1);
+      sg[t] = (int)((uint32_t)gr[t] >= qb1) + (int)((uint32_t)gr[t] >= qb2);
+      sr[t] = h2_unscale(x.sE[x.arow(t)], eW);
+    }
+    float* stage = x.sW;                                 // [NWR][3][D] when the rows are split over two wave groups (sW and sC are idle)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const int kg = (x.colbase >> 3) + 2 * c + (x.lg >> 1);
+      float xv[RT][4];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const char* src = p.X.base + ((size_t)kg * Rp + gr[t]) * 16 + (x.lg & 1) * 8;
+        const u32x2 hh = *reinterpret_cast<const u32x2*>(src), hl = *reinterpret_cast<const u32x2*>(src + xpb);
+        h2_join4(hh, hl, h2_pow2(-(int)p.X.exps()[gr[t] * CB + (kg >> 4)]), xv[t]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float s3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          // (rows past the end read the last row again: select, their accumulators are zero but X need not be finite there)
+          const float v = x.arow(t) < x.nvalid ? acc[t][c][q] * sr[t] * xv[t][q] : 0.f;
+          s3[0] += sg[t] == 0 ? v : 0.f;
+          s3[1] += sg[t] == 1 ? v : 0.f;
+          s3[2] += sg[t] == 2 ? v : 0.f;
+        }
+        const int col = x.acol(c) + q;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < nq) {
+            const float sum = row16_sum(s3[k]);
+            if (x.li == 0) {
+              if (C::NWR == 1) p.dy_part[(tile * 3 + k) * D + col] = sum;
+              else stage[(x.wr * 3 + k) * D + col] = sum;
+            }
+          }
+      }
+    }
+  }
   {
     const int de = *p.W1bT.exp - *p.W1aT.exp;          // units 2^-(e + e1a) -> 2^-(e + e1b), exactly
 #pragma unroll
@@ -963,6 +1019,10 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   x.emit(acc, false, p.dX);
   x.publish_rows(x.sE2, C::PASS_EPI, p.dX, p.qmin_dX);
   x.colsum_finish(p.dbx_part + tile * D);
+  if (C::NWR == 2 && p.dy_part) {                       // the two row halves of the dy partials (staged before the last product)
+    const int nq = (int)(((uint32_t)x.grow0 + x.nvalid - 1) / (uint32_t)p.N) - (int)((uint32_t)x.grow0 / (uint32_t)p.N) + 1;
+    for (int i = x.tid; i < nq * D; i += 512) p.dy_part[tile * 3 * D + i] = x.sW[i] + x.sW[3 * D + i];
+  }
 }
 
 template <int D_, int KV, int A2>
@@ -1003,6 +1063,8 @@ struct DcReduceP {
   float* dc;                // [B][d] accumulated in place
   float* dbk_part;          // [B]
   size_t part_step, dls_step, dc_step, dbk_step;      // blockIdx.y = step: floats between the steps' buffers
+  const float* dy_part;     // [tiles][3][d] (chain_bwd_kernel stage B2) or null
+  float* dy;                // [B][d] written
 };
 __global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
   const int q = blockIdx.x;
@@ -1018,6 +1080,14 @@ __global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
     }
     f32x4* dst = reinterpret_cast<f32x4*>(p.dc + (size_t)q * p.d + c4);
     *dst = *dst + s;
+    if (p.dy_part) {
+      f32x4 sy = {0.f, 0.f, 0.f, 0.f};
+      for (int t = t0; t <= t1; ++t) {                     // fixed order
+        const int seg = q - (int)(((size_t)t << 6) / p.N);
+        sy += *reinterpret_cast<const f32x4*>(p.dy_part + ((size_t)t * 3 + seg) * p.d + c4);
+      }
+      *reinterpret_cast<f32x4*>(p.dy + (size_t)q * p.d + c4) = sy;
+    }
   }
   if (threadIdx.x == 0) {
     float t = 0.f;

@@ -491,7 +491,12 @@ struct SbH2P {
   const float* W1a;        // [d][d] row-major (k, j)
   float* dW1a_part;        // [ngroup][d][d]
   float* dW1b_part;
-  float* dy_part;          // [4*d/128][B][d]
+  float* dy_part;          // [4*d/128][B][d]; null: dy is not computed here (the chain kernel's stage B2 has it)
+  // all steps in one launch (the caller gets dy elsewhere, so nothing in the recurrence waits for S_b): the operands of step i
+  // lie x_step / g_step BYTES, y_step FLOATS and qx_step / qg_step INTS behind step 0's; the two accumulators run through
+  // every step and the slabs are written once
+  int nsteps;
+  size_t x_step, g_step, y_step, qx_step, qg_step;
   int dbg;                 // measurement knobs (macx_debug_set(1, mask)): 512 skip the per-question fold, 1024 skip fragments + MFMAs,
                            // 2048 skip the DMA issue
 };
@@ -502,11 +507,13 @@ constexpr int SBH_MAXROWS = 4096;          // rows of one workgroup's questions 
 constexpr int SBH_RING = 4;                // LDS stages: three stages of DMA in flight behind the one being multiplied
 constexpr int SBH_MAXQ = 32;               // questions per workgroup (their y_b[128] shares sit in LDS: 16 KB)
 
+template <bool DY>
 __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
   uint16_t* ftab = reinterpret_cast<uint16_t*>(lds + SBH_RING * SBH_STAGE);      // [questions][nchunk * 32] combined row factors (fp16)
   float* ytab = reinterpret_cast<float*>(lds + SBH_RING * SBH_STAGE + SBH_MAXROWS * 2);   // [questions][128] y_b of this tile's k rows
+  float* sctab = ytab + SBH_MAXQ * T_TILE;                // [questions] 2^-(EX + EG): the unit of a question's S_b
 
   const int nt = p.d / T_TILE;
   const int ntile = nt * nt;
@@ -529,6 +536,10 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   const size_t Rp = p.X.Rp();
   const size_t xpb = p.X.plane_bytes(), gpb = p.dI1.plane_bytes();
   const int xcb = p.X.cb(), gcb = p.dI1.cb();
+  // the current step's operands
+  H2View vX = p.X, vG = p.dI1;
+  const float* yS = p.y;
+  const int *qxS = p.qminX, *qgS = p.qminG;
   const int rows_q = nchunk * 32;                         // table rows per question (rows past N hold factor 0)
 
   // ---- staging: instruction u of a stage (u = 4 wave .. 4 wave + 3) fills column tile u & 7 of image u >> 3
@@ -546,17 +557,12 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
     for (int j = 0; j < 4; ++j) {
       const int u = wave * 4 + j;
       const int im = u >> 3, ct = u & 7;
-      const char* src = (im < 2 ? p.X.plane(0) + (im & 1) * xpb + ((size_t)(tk * 16 + 2 * ct + sl_kg) * Rp + row) * 16
-                                : p.dI1.plane(0) + (im & 1) * gpb + ((size_t)(tj * 16 + 2 * ct + sl_kg) * Rp + row) * 16);
+      const char* src = (im < 2 ? vX.base + (im & 1) * xpb + ((size_t)(tk * 16 + 2 * ct + sl_kg) * Rp + row) * 16
+                                : vG.base + (im & 1) * gpb + ((size_t)(tj * 16 + 2 * ct + sl_kg) * Rp + row) * 16);
       dma16b(src, st + im * WH_APL + ct * 1024);
     }
   };
-  if (total > 0) {                                        // in flight while the tables below are built
-    issue(0);
-    issue(1);
-    issue(2);
-  }
-
+  auto tables = [&]() __attribute__((always_inline)) {
   // ---- factor table
   for (int i = tid; i < nq * rows_q; i += 512) {
     const int qi = i / rows_q, n = i - qi * rows_q;
@@ -564,16 +570,16 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
     uint16_t f = 0;
     if (n < p.N) {
       const size_t row = (size_t)b * p.N + n;
-      const int k = (p.qminX[(size_t)b * xcb + tk] - (int)p.X.exps()[row * xcb + tk]) +
-                    (p.qminG[(size_t)b * gcb + tj] - (int)p.dI1.exps()[row * gcb + tj]);
+      const int k = (qxS[(size_t)b * xcb + tk] - (int)vX.exps()[row * xcb + tk]) +
+                    (qgS[(size_t)b * gcb + tj] - (int)vG.exps()[row * gcb + tj]);
       f = (uint16_t)(pk_pow2_f16(k) & 0xFFFFu);
     }
     ftab[i] = f;
   }
   for (int i = tid; i < nq * T_TILE; i += 512)
-    ytab[i] = p.y[(size_t)(b_begin + (i >> 7)) * p.d + tk * T_TILE + (i & 127)];
-  float* sctab = ytab + SBH_MAXQ * T_TILE;                // [questions] 2^-(EX + EG): the unit of a question's S_b
-  if (tid < nq) sctab[tid] = h2_unscale(p.qminX[(size_t)(b_begin + tid) * xcb + tk], p.qminG[(size_t)(b_begin + tid) * gcb + tj]);
+    ytab[i] = yS[(size_t)(b_begin + (i >> 7)) * p.d + tk * T_TILE + (i & 127)];
+  if (tid < nq) sctab[tid] = h2_unscale(qxS[(size_t)(b_begin + tid) * xcb + tk], qgS[(size_t)(b_begin + tid) * gcb + tj]);
+  };
 
   f32x4 accS[4][2], accA[4][2], accB[4][2];
 #pragma unroll
@@ -618,7 +624,7 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   // this wave's 64 x 32 share of W1a stays in registers for the whole kernel (32 per lane; the staging needs none) and y_b
   // comes from the LDS table: the per-question fold has no global load to wait for, so it does not drain the DMA queue
   float w1[4][4][2];
-  {
+  if (DY) {
     const float* wb = p.W1a + (size_t)(tk * T_TILE + wr * 64 + (lane >> 4) * 4) * p.d + tj * T_TILE + wc * 32 + (lane & 15);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -653,14 +659,26 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
           const float sv = accS[t][c][e] * sc;
           accB[t][c][e] += sv;
           accA[t][c][e] = fmaf(yk, sv, accA[t][c][e]);
-          dyp = fmaf(w1[t][e][c], sv, dyp);
+          if (DY) dyp = fmaf(w1[t][e][c], sv, dyp);
           accS[t][c][e] = 0.f;
         }
-        dyp = sum16_h2(dyp);
-        if ((lane & 15) == 0) p.dy_part[((size_t)(tj * 4 + wc) * p.B + b) * p.d + k] = dyp;
+        if (DY) {
+          dyp = sum16_h2(dyp);
+          if ((lane & 15) == 0) p.dy_part[((size_t)(tj * 4 + wc) * p.B + b) * p.d + k] = dyp;
+        }
       }
   };
 
+#pragma unroll 1
+  for (int step = 0; step < p.nsteps; ++step) {
+  vX.base = p.X.base + (size_t)step * p.x_step; vG.base = p.dI1.base + (size_t)step * p.g_step;
+  yS = p.y + (size_t)step * p.y_step; qxS = p.qminX + (size_t)step * p.qx_step; qgS = p.qminG + (size_t)step * p.qg_step;
+  if (total > 0) {                                        // in flight while the tables are built
+    issue(0);
+    issue(1);
+    issue(2);
+  }
+  tables();
   if (total > 0) {
     wait_vmcnt<8>();                                      // stage 0 has landed (stages 1, 2 may be in flight)
     __syncthreads();                                      // ... for every wave's share of it, and the factor table is complete
@@ -680,7 +698,8 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
     }
     wait_vmcnt<0>();                                      // the speculative stages past the end
   }
-  __syncthreads();                                        // ... of every wave: the ring is about to be reused
+  __syncthreads();                                        // ... of every wave: the ring and the tables are about to be reused
+  }   // step
 
   // ---- the two slabs leave through LDS: a wave's 64 x 32 share row-major in its own 9 KB of the (now idle) ring, read back
   //      as float4 so that a store instruction writes 8 rows x 128 contiguous bytes instead of 64-byte pieces
@@ -710,11 +729,13 @@ inline hipError_t sb_h2_launch(const SbH2P& p, hipStream_t st) {
   const int nchunk = (p.N + 31) >> 5;
   if (p.qpg * nchunk * 32 > SBH_MAXROWS || p.qpg > SBH_MAXQ) return hipErrorInvalidValue;
   constexpr size_t lds = SBH_RING * SBH_STAGE + SBH_MAXROWS * 2 + SBH_MAXQ * T_TILE * 4 + SBH_MAXQ * 4;
-  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2_kernel), lds);
+  if (p.nsteps < 1 || (p.nsteps > 1 && p.dy_part)) return hipErrorInvalidValue;    // dy is per step: its buffer is not
+  auto kern = p.dy_part ? sb_h2_kernel<true> : sb_h2_kernel<false>;
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   const int nt = p.d / T_TILE;
   const int ngroup = (p.B + p.qpg - 1) / p.qpg;
-  hipLaunchKernelGGL(sb_h2_kernel, dim3(nt * nt * ngroup), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(nt * nt * ngroup), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 

@@ -28,6 +28,8 @@ def macx():
         m._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
     if os.environ.get("MACX_CHAIN"):        # 0: the read unit's forward products as four launches instead of the fused chain kernel
         m._lib.lib().macx_debug_set(4, int(os.environ["MACX_CHAIN"]))
+    if os.environ.get("MACX_SB_DEFER"):     # 0: the S_b contraction once per step
+        m._lib.lib().macx_debug_set(5, int(os.environ["MACX_SB_DEFER"]))
     return m
 
 

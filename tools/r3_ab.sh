@@ -1,16 +1,16 @@
 #!/bin/bash
-# A/B of the fused read-chain kernel against the four launches it replaces: parity tests, then the bench step both ways
+# same-box A/B of a library knob on the bench step: AB_ENV="MACX_SB_DEFER=0" (the B side's environment)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_cell.py tests/test_gpu_reference_golden.py tests/test_gpu_unit_exports.py -x -q > gpurun_out/ab_pytest.log 2>&1
-echo "pytest rc=$?" ; tail -15 gpurun_out/ab_pytest.log
-FL="--steps 10 --warmup 2 --no-cpu-baseline --no-model-level --no-native --no-extra-legs"
-timeout 300 python bench.py $FL > gpurun_out/ab_chain.json 2> gpurun_out/ab_chain.err; echo "chain rc=$?"
-MACX_CHAIN=0 timeout 300 python bench.py $FL > gpurun_out/ab_nochain.json 2> gpurun_out/ab_nochain.err; echo "nochain rc=$?"
+FL="--steps 20 --warmup 3 --no-cpu-baseline --no-model-level --no-native --no-extra-legs"
+for rep in 1 2; do
+  timeout 300 python bench.py $FL > gpurun_out/ab_a$rep.json 2> gpurun_out/ab_a.err; echo "A rc=$?"
+  env $AB_ENV timeout 300 python bench.py $FL > gpurun_out/ab_b$rep.json 2> gpurun_out/ab_b.err; echo "B rc=$?"
+done
 python - <<'PY'
 import json
-for n in ("ab_chain", "ab_nochain"):
+for n in ("ab_a1", "ab_b1", "ab_a2", "ab_b2"):
     try:
         d = json.loads(open("gpurun_out/%s.json" % n).read().strip().splitlines()[-1])
         print(n, d["value"], d["ms_per_step"])
