@@ -356,6 +356,8 @@ def main():
         L.macx_debug_set(4, int(os.environ["MACX_CHAIN"]))
     if os.environ.get("MACX_SB_DEFER"):     # A/B only: 0 = sb_h2 once per step
         L.macx_debug_set(5, int(os.environ["MACX_SB_DEFER"]))
+    if os.environ.get("MACX_OVERLAP"):      # A/B only: 0 = no side queue
+        L.macx_debug_set(6, int(os.environ["MACX_OVERLAP"]))
     if os.environ.get("MACX_FORCE_RT"):     # tuning only: row tiles per GEMM workgroup
         L.macx_debug_set(2, int(os.environ["MACX_FORCE_RT"]))
     p = args.p

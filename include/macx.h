@@ -478,7 +478,10 @@ int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint
  *   key 3  = macx_gemm_mode
  *   key 4  0: the read unit's products as separate launches (A/B against the chain kernels of macx_chain_h2.hip.h); 1: default
  *   key 5  0: the per-question contraction S_b = X_b^T dI1_b once per step (it then also delivers dy); 1 (default): dy from the
- *          chain kernel, S_b of all steps in one launch at the end of the backward pass */
+ *          chain kernel, S_b of all steps in one launch at the end of the backward pass
+ *   key 6  0 (default): every launch on the caller's stream; 1..3: the backward pass's dKB contraction runs per step on an internal
+ *          queue (lowest / highest / middle priority), forked from and joined to the caller's stream by events (still
+ *          stream-ordered for the caller) -- measured slower, kept for the A/B */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

@@ -57,6 +57,31 @@ inline int& chain_mode() { static int m = 1; return m; }
 inline bool use_chain(int d, int N) { return h2_mode() && chain_mode() && chain_supported(d, N); }
 // dy from the chain kernel and S_b of all steps as one deferred launch; macx_debug_set(5, 0): sb_h2 once per step, as before
 inline int& sb_defer_mode() { static int m = 1; return m; }
+// A second queue for the backward pass's contractions that nothing in the recurrence waits for (dKB of a step: 27 us of
+// full-chip matrix work).  Between two chain kernels the caller's stream runs ~100 us of [B,d]-sized launches that leave the
+// chip almost idle; the side queue was meant to fill exactly that.  Fork and join are events on the caller's stream, so for the
+// caller everything is still ordered on `stream`.  MEASURED, same box: 4.44-4.47 ms per step with the side queue (lowest,
+// middle or highest priority alike) against 4.11 ms without -- the per-step dKB launches (read-modify-write of the gradient,
+// twelve ramps) cost more than the all-steps launch and hide nothing.  Off by default; macx_debug_set(6, 1..3) turns it on.
+inline int& overlap_mode() { static int m = 0; return m; }
+struct SideQueue { hipStream_t s; hipEvent_t fork, join; };
+inline SideQueue* side_queue() {
+  constexpr int MAXDEV = 64;
+  static SideQueue q[MAXDEV];
+  static int state[MAXDEV];           // 0 untried, 1 ready, -1 failed
+  if (!overlap_mode()) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  if (state[dev] == 0) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo: least priority
+    const bool ok = hipStreamCreateWithPriority(&q[dev].s, hipStreamNonBlocking, overlap_mode() == 2 ? hi : (overlap_mode() == 3 ? (lo + hi) / 2 : lo)) == hipSuccess &&
+                    hipEventCreateWithFlags(&q[dev].fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&q[dev].join, hipEventDisableTiming) == hipSuccess;
+    state[dev] = ok ? 1 : -1;
+  }
+  return state[dev] == 1 ? &q[dev] : nullptr;
+}
 inline int wfmt_plain() { return h2_mode() ? 3 : (gemm_split_mode() ? 1 : 0); }
 inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
 inline size_t wsize(size_t K, size_t n) { return K * n * 3 / 2; }     // covers format 1 (3/2) and format 3 (1 + the exponent)
@@ -1023,6 +1048,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const float* infos = saved + L.seg[MACX_SEG_INFOS];
   const float* att_kb = saved + L.seg[MACX_SEG_ATT_KB];
 
+  SideQueue* sq = ((units & U_READ) && h2_mode()) ? side_queue() : nullptr;
   for (int i = p - 1; i >= 0; --i) {
     const float* c_i = controls + (size_t)(i + 1) * Bd;
     const float* X = saved + L.X + (size_t)i * L.act_stride;
@@ -1197,21 +1223,30 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         q.dbg = kb_gemm_dbg();
         CK(sb_h2_launch(q, st));
       }
-      // dKB = sum_i (dX_i Wx^T) * kbmask_i + att_i (x) dinfo_i: ONE launch over all steps, after step 0 (below)
-      if (i == 0) {
-        g.A = h2_view(ws + W.dX, B * N, d); g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
+      // dKB = sum_i (dX_i Wx^T) * kbmask_i + att_i (x) dinfo_i: a launch per step on the side queue (it runs under the [B,d]
+      // launches that follow on the caller's stream), or ONE launch over all steps after step 0
+      if (sq || i == 0) {
+        const int i0 = sq ? i : 0;
+        g.A = h2_view(ws + W.dX + (size_t)i0 * W.act_floats, B * N, d); g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
         g.Wh = reinterpret_cast<const char*>(ws + W.wxT_p); g.w_exp = reinterpret_cast<const int*>(ws + W.wxT_p) + dd;
-        g.nsteps = p; g.a_step_bytes = W.act_floats * sizeof(float);
+        g.nsteps = sq ? 1 : p; g.a_step_bytes = W.act_floats * sizeof(float);
         g.out_f32 = GI->knowledgeBase; g.ldo = d;
         const bool wd = dp->keep_write < 1.0f;
         g.dr = wd ? ws + W.dinfo : ws + W.dwin + d; g.ld_dr = wd ? d : win; g.dr_step = wd ? Bd : (size_t)B * win;
         if (!(units & U_WRITE)) { g.dr = dinfo; g.ld_dr = d; g.dr_step = Bd; }
-        g.att = att_kb; g.att_step = (size_t)B * N;
-        g.e_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits) : nullptr;
+        else g.dr += (size_t)i0 * g.dr_step;
+        g.att = att_kb + (size_t)i0 * B * N; g.att_step = (size_t)B * N;
+        g.e_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits + (size_t)i0 * L.bits_stride) : nullptr;
         g.bits_step_words = L.bits_stride;
-        g.accumulate = 0;
+        g.accumulate = sq ? (i != p - 1) : 0;
         g.colsum_part = nullptr; g.out_qmin = nullptr; g.aux = H2View{nullptr, 0, 0};
-        CK((kb_gemm_h2_launch<B_PLAIN, E_DKB, false>(g, st)));
+        if (sq) {
+          CK(hipEventRecord(sq->fork, st));
+          CK(hipStreamWaitEvent(sq->s, sq->fork, 0));
+          CK((kb_gemm_h2_launch<B_PLAIN, E_DKB, false>(g, sq->s)));
+        } else {
+          CK((kb_gemm_h2_launch<B_PLAIN, E_DKB, false>(g, st)));
+        }
       }
     } else {
     {
@@ -1339,6 +1374,10 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         CK(hipMemsetAsync(ws + W.dcI + (size_t)i * Bd, 0, Bd * sizeof(float), st));
       }
     }
+  }
+  if (sq) {                        // join: everything the side queue was given is ordered before what follows on `stream`
+    CK(hipEventRecord(sq->join, sq->s));
+    CK(hipStreamWaitEvent(st, sq->join, 0));
   }
   if (units == U_ALL) {
   if (o->write_self_att && !o->write_self_att_cont && !o->control_feed_prev) {
@@ -2500,6 +2539,7 @@ int macx_debug_set(int key, int value) {
   if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
   if (key == 4 && (value == 0 || value == 1)) { chain_mode() = value; return MACX_OK; }
   if (key == 5 && (value == 0 || value == 1)) { sb_defer_mode() = value; return MACX_OK; }
+  if (key == 6 && value >= 0 && value <= 3) { overlap_mode() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

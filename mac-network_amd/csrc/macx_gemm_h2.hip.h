@@ -45,7 +45,7 @@ struct GemmH2P {
   const uint8_t* e_bytes;   // E_I2_LOGIT: keep bits of act(I2*c), one byte per slot, [Nout/8][Rp]; null = keep all
   const uint32_t* e_bits;   // E_DKB: keep bits of the knowledge base, row-major [B*N][ldo/32]; null = keep all
   float e_inv_keep;
-  int accumulate;           // E_DKB (unused by the multi-step form: the output is written once)
+  int accumulate;           // E_DKB: add to the output instead of writing it (one launch per step, steps after the first)
   // E_DKB runs ALL steps of the backward pass in one launch: the K loop walks `nsteps` A tensors (the kept dX_i, `a_step_bytes`
   // apart) against the same weight, the step's keep bits multiply each block sum as it is folded, and the epilogue adds
   // sum_i att_i (x) dinfo_i -- the caller's fp32 gradient is written once instead of read-modify-written every step
@@ -492,7 +492,10 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int it = tid + G_THREADS * i, lrow = it >> 5, c4 = (it & 31) * 4;
-      if (lrow < nvalid) *reinterpret_cast<f32x4*>(p.out_f32 + (grow0 + lrow) * (size_t)p.ldo + cb * G_BN + c4) = o[i];
+      if (lrow < nvalid) {
+        f32x4* dst = reinterpret_cast<f32x4*>(p.out_f32 + (grow0 + lrow) * (size_t)p.ldo + cb * G_BN + c4);
+        *dst = p.accumulate ? *dst + o[i] : o[i];
+      }
     }
     return;
   }
