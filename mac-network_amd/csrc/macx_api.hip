@@ -1808,7 +1808,7 @@ int macx_embed_lookup(const int32_t* ids, const float* emb, int rows, int E, int
 
 int macx_embed_lookup_bwd(const int32_t* ids, const float* dx, int rows, int E, int ld, int V, float keep, uint32_t seed,
                           uint32_t first_row, float* d_emb, void* stream) {
-  if (!ids || !dx || !d_emb || rows < 1 || E < 1 || ld < E || V < 1) return MACX_EINVAL;
+  if (!ids || !dx || !d_emb || rows < 1 || E < 1 || E > 1024 || ld < E || V < 1) return MACX_EINVAL;   // (embed_grad_kernel: 4 columns per thread)
   hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, dx, rows, E, ld, first_row,
                      make_drop(keep, seed, SITE_ENC_INPUT, 0), d_emb);
   CK(hipGetLastError());
@@ -2249,7 +2249,6 @@ struct EncLayout {
   size_t wx_p, wh_p;     // packed [2][Ep x 4h], [2][h x 4h]
   size_t Xp;             // [B*S][Ep]  dropped embedded words (columns E..Ep-1 zero)
   size_t Zx;             // [2][B*S][4h]
-  size_t R;              // [2][B][4h]
   size_t hs, cs;         // [2][S+1][B][h]
   size_t gates;          // [2][S][B][4h]
   size_t total;
@@ -2261,14 +2260,14 @@ EncLayout make_enc(const macx_enc_shapes* s) {
   auto take = [&](size_t n) { size_t r = off; off += al4(n); return r; };
   const size_t B = s->B, S = s->S, h = s->h, Ep = pad128(s->E), G = 4 * h;
   L.wx_p = take(2 * Ep * G); L.wh_p = take(2 * h * G);
-  L.Xp = take(B * S * Ep); L.Zx = take(2 * B * S * G); L.R = take(2 * B * G);
+  L.Xp = take(B * S * Ep); L.Zx = take(2 * B * S * G);
   L.hs = take(2 * (S + 1) * B * h); L.cs = take(2 * (S + 1) * B * h);
   L.gates = take(2 * S * B * G);
   L.total = off;
   return L;
 }
 struct EncBwdLayout {
-  size_t wxT_p, whT_p, dG, dZ, dh, dc, dh_pass, dXp, tmpW, slab, dq, total;
+  size_t wxT_p, whT_p, dG, dZ, dh, dc, dh_pass, dc2, dXp, tmpW, slab, dq, total;
 };
 EncBwdLayout make_enc_bwd(const macx_enc_shapes* s) {
   EncBwdLayout L;
@@ -2278,7 +2277,7 @@ EncBwdLayout make_enc_bwd(const macx_enc_shapes* s) {
   const size_t B = s->B, S = s->S, h = s->h, Ep = pad128(s->E), G = 4 * h;
   L.wxT_p = take(2 * G * Ep); L.whT_p = take(2 * G * h);
   L.dG = take(2 * S * B * G); L.dZ = take(2 * B * S * G);
-  L.dh = take(2 * B * h); L.dc = take(2 * B * h); L.dh_pass = take(2 * B * h);
+  L.dh = take(2 * B * h); L.dc = take(2 * B * h); L.dh_pass = take(2 * B * h); L.dc2 = take(2 * B * h);   // dh_pass: the second dh buffer
   L.dXp = take(B * S * Ep); L.tmpW = take(Ep * G);
   // split-reduction slabs of the two kernel-gradient contractions (input block [Ep, 4h], recurrent block [h, 4h]): the larger
   {
@@ -2291,7 +2290,7 @@ EncBwdLayout make_enc_bwd(const macx_enc_shapes* s) {
   return L;
 }
 int enc_check(const macx_enc_shapes* s) {
-  if (!s || s->B < 1 || s->S < 1 || s->V < 1 || s->E < 1 || s->h < 128 || s->h % 128) return MACX_EINVAL;
+  if (!s || s->B < 1 || s->S < 1 || s->V < 1 || s->E < 1 || s->E > 1024 || s->h < 128 || s->h % 128) return MACX_EINVAL;
   return MACX_OK;
 }
 }  // namespace
@@ -2330,16 +2329,11 @@ int macx_encoder_forward(const macx_enc_shapes* s, float keep_input, float keep_
   CK(hipMemsetAsync(saved + L.cs, 0, 2 * (size_t)(S + 1) * Bh * sizeof(float), st));
   CK(hipMemsetAsync(words, 0, (size_t)B * S * 2 * h * sizeof(float), st));
   for (int tau = 0; tau < S; ++tau) {
-    // R = h_prev Wh for both directions
-    {
-      LinP l = lin_basic(saved + L.hs + (size_t)tau * Bh, h, h, B, saved + L.wh_p, nullptr, G, MACX_ACT_NON, saved + L.R, G);
-      l.seg[0].zstride = (size_t)(S + 1) * Bh; l.zW = (size_t)h * G; l.zout = (size_t)B * G;
-      CK(small_linear_launch(l, 2, st));
-    }
-    LstmP c;
+    // R = h_prev Wh and the cell, both directions, one launch per time step
+    LstmStepP c;
     c.B = B; c.S = S; c.h = h; c.tau = tau; c.len = lengths;
-    c.R = saved + L.R; c.Zx = saved + L.Zx; c.hs = saved + L.hs; c.cs = saved + L.cs; c.gates = saved + L.gates; c.out = words;
-    hipLaunchKernelGGL(lstm_cell_kernel, dim3(128), dim3(256), 0, st, c);
+    c.Wh = saved + L.wh_p; c.Zx = saved + L.Zx; c.hs = saved + L.hs; c.cs = saved + L.cs; c.gates = saved + L.gates; c.out = words;
+    hipLaunchKernelGGL(lstm_step_kernel, dim3(h / 16, (B + 15) / 16, 2), dim3(256), 0, st, c);
     CK(hipGetLastError());
   }
   // vecQuestions = dropout(concat([h_fw_final, h_bw_final]))   (ops.py:905-906, model.py:292)
@@ -2378,18 +2372,22 @@ int macx_encoder_backward(const macx_enc_shapes* s, float keep_input, float keep
   for (int dir = 0; dir < 2; ++dir)
     CK(hipMemcpy2DAsync(ws + W.dh + (size_t)dir * Bh, (size_t)h * sizeof(float), ws + W.dq + dir * h, (size_t)2 * h * sizeof(float),
                         (size_t)h * sizeof(float), B, hipMemcpyDeviceToDevice, st));
-  for (int tau = S - 1; tau >= 0; --tau) {
-    LstmBwdP c;
-    c.B = B; c.S = S; c.h = h; c.tau = tau; c.len = lengths;
-    c.cs = saved + L.cs; c.gates = saved + L.gates; c.dout = d_words;
-    c.dh = ws + W.dh; c.dc = ws + W.dc; c.dG = ws + W.dG; c.dZ = ws + W.dZ; c.dh_pass = ws + W.dh_pass;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(128), dim3(256), 0, st, c);
-    CK(hipGetLastError());
-    // dh_prev = dG_tau Wh^T + (dh of the questions that had already ended)
-    LinP l = lin_basic(ws + W.dG + (size_t)tau * B * G, G, G, B, ws + W.whT_p, nullptr, h, MACX_ACT_NON, ws + W.dh, h);
-    l.seg[0].zstride = (size_t)S * B * G; l.zW = (size_t)G * h; l.zout = Bh;
-    l.addend = ws + W.dh_pass; l.ld_add = h; l.zadd = Bh;
-    CK(small_linear_launch(l, 2, st));
+  {
+    const size_t lds = lstm_step_bwd_lds(h);
+    CK(lds_attr_once(reinterpret_cast<const void*>(lstm_step_bwd_kernel), lds));
+    // the running dh / dc alternate between two buffers (a workgroup reads what its neighbours would otherwise overwrite)
+    float* dhb[2] = {ws + W.dh, ws + W.dh_pass};
+    float* dcb[2] = {ws + W.dc, ws + W.dc2};
+    int cur = 0;
+    for (int tau = S - 1; tau >= 0; --tau, cur ^= 1) {
+      LstmStepBwdP c;
+      c.B = B; c.S = S; c.h = h; c.tau = tau; c.len = lengths;
+      c.WhT = ws + W.whT_p; c.cs = saved + L.cs; c.gates = saved + L.gates; c.dout = d_words;
+      c.dh_in = dhb[cur]; c.dc_in = dcb[cur]; c.dh_out = dhb[cur ^ 1]; c.dc_out = dcb[cur ^ 1];
+      c.dG = ws + W.dG; c.dZ = ws + W.dZ;
+      hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(h / 16, (B + 15) / 16, 2), dim3(LSB_THREADS), lds, st, c);
+      CK(hipGetLastError());
+    }
   }
   for (int dir = 0; dir < 2; ++dir) {
     float* dK = dir ? Gr->bw_kernel : Gr->fw_kernel;

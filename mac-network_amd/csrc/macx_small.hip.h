@@ -1012,102 +1012,241 @@ __global__ void embed_gather_kernel(const int32_t* __restrict__ idx, const float
     x[i] = v;
   }
 }
-struct LstmP {
+// BasicLSTMCell (TF1): gates i, j, f, o ; c' = c * sigmoid(f + 1) + sigmoid(i) * tanh(j) ; h' = tanh(c') * sigmoid(o)
+// ---------------------------------------------------------------------------------------------
+// One LSTM time step of both directions in ONE launch: R = h_prev Wh on fp32 MFMA, then the cell.  The two launches this
+// replaces (small_linear + lstm_cell_kernel) were ~6 us each of pure latency, 100 dependent pairs per forward pass.
+// A workgroup owns 16 questions x 16 hidden units of one direction and therefore all four gates of its units: four waves
+// split the reduction over h, an LDS combine in fixed order, then one (question, unit) per thread.
+// Grid (h / 16, ceil(B / 16), 2).
+// ---------------------------------------------------------------------------------------------
+struct LstmStepP {
   int B, S, h, tau;
   const int32_t* len;      // [B]
-  const float* R;          // [2][B][4h]    h_prev Wh + b   (this step)
-  const float* Zx;         // [2][B*S][4h]  x Wx            (all positions)
-  float* hs; float* cs;    // [2][S+1][B][h] each: state BEFORE step tau at index tau
-  float* gates;            // [2][S][B][4h] gate activations i, j, f, o (saved for backward)
-  float* out;              // [B][S][2h]    outputs (zero-initialised)
+  const float* Wh;         // [2] packed [h/16][4][4h][4] (pack format 0)
+  const float* Zx;         // [2][B*S][4h]  x Wx + b  (all positions)
+  float* hs; float* cs;    // [2][S+1][B][h]
+  float* gates;            // [2][S][B][4h]
+  float* out;              // [B][S][2h]
 };
-// BasicLSTMCell (TF1): gates i, j, f, o ; c' = c * sigmoid(f + 1) + sigmoid(i) * tanh(j) ; h' = tanh(c') * sigmoid(o)
-__global__ void lstm_cell_kernel(LstmP p) {
-  const int n = 2 * p.B * p.h;
-  const size_t Bh = (size_t)p.B * p.h;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int dir = i / (p.B * p.h);
-    const int r = i - dir * p.B * p.h;
-    const int b = r / p.h, u = r - b * p.h;
-    const int L = min(max(p.len[b], 0), p.S);      // never index past the padded question (host validates too)
-    const bool active = p.tau < L;
-    const int pos = dir == 0 ? p.tau : L - 1 - p.tau;
-    const size_t s0 = (size_t)(dir * (p.S + 1) + p.tau) * Bh + r, s1 = s0 + Bh;
-    const float hp = p.hs[s0], cp = p.cs[s0];
-    float hn = hp, cn = cp;
-    float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f;
-    if (active) {
-      const float* R = p.R + ((size_t)dir * p.B + b) * 4 * p.h;
-      const float* Z = p.Zx + ((size_t)dir * p.B * p.S + (size_t)b * p.S + pos) * 4 * p.h;
-      gi = 1.0f / (1.0f + expf(-(R[u] + Z[u])));
-      gj = tanhf(R[p.h + u] + Z[p.h + u]);
-      gf = 1.0f / (1.0f + expf(-(R[2 * p.h + u] + Z[2 * p.h + u] + 1.0f)));
-      go = 1.0f / (1.0f + expf(-(R[3 * p.h + u] + Z[3 * p.h + u])));
-      cn = cp * gf + gi * gj;
-      hn = tanhf(cn) * go;
-      p.out[((size_t)b * p.S + pos) * 2 * p.h + dir * p.h + u] = hn;
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
+  __shared__ float red[4][4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int u0 = blockIdx.x * 16, r0 = blockIdx.y * 16, dir = blockIdx.z;
+  const int h = p.h, G = 4 * h;
+  const size_t Bh = (size_t)p.B * h;
+  const float* hp = p.hs + (size_t)(dir * (p.S + 1) + p.tau) * Bh;
+  const float* Wd = p.Wh + (size_t)dir * h * G;
+  const int rowc = min(r0 + li, p.B - 1);
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nQ = h >> 4;
+  constexpr int PF = 4;                     // k groups in flight per wave (h = 256: the wave's whole share)
+  for (int Q0 = wave; Q0 < nQ; Q0 += 4 * PF) {
+    f32x4 af[PF], bf[PF][4];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int Q = min(Q0 + 4 * u, nQ - 1);
+      af[u] = *reinterpret_cast<const f32x4*>(hp + (size_t)rowc * h + Q * 16 + lg * 4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bf[u][g] = *reinterpret_cast<const f32x4*>(Wd + ((size_t)(Q * 4 + lg) * G + g * h + u0 + li) * 4);
     }
-    p.hs[s1] = hn;
-    p.cs[s1] = cn;
-    float* g = p.gates + ((size_t)(dir * p.S + p.tau) * p.B + b) * 4 * p.h;
-    g[u] = gi; g[p.h + u] = gj; g[2 * p.h + u] = gf; g[3 * p.h + u] = go;
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (Q0 + 4 * u < nQ) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][e], bf[u][g][e], acc[g], 0, 0, 0);
+      }
   }
+  // accumulator map: unit = lane & 15, question = (lane >> 4) * 4 + e
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][g][lg * 4 + e][li] = acc[g][e];
+  __syncthreads();
+  const int row = tid >> 4, uu = tid & 15;
+  const int b = r0 + row, u = u0 + uu;
+  if (b >= p.B) return;
+  float R[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) R[g] = ((red[0][g][row][uu] + red[1][g][row][uu]) + red[2][g][row][uu]) + red[3][g][row][uu];
+  const int L = min(max(p.len[b], 0), p.S);      // never index past the padded question (host validates too)
+  const bool active = p.tau < L;
+  const int pos = dir == 0 ? p.tau : L - 1 - p.tau;
+  const size_t s0 = (size_t)(dir * (p.S + 1) + p.tau) * Bh + (size_t)b * h + u, s1 = s0 + Bh;
+  const float hpv = p.hs[s0], cp = p.cs[s0];
+  float hn = hpv, cn = cp;
+  float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f;
+  if (active) {
+    const float* Z = p.Zx + ((size_t)dir * p.B * p.S + (size_t)b * p.S + pos) * G;
+    gi = 1.0f / (1.0f + expf(-(R[0] + Z[u])));
+    gj = tanhf(R[1] + Z[h + u]);
+    gf = 1.0f / (1.0f + expf(-(R[2] + Z[2 * h + u] + 1.0f)));
+    go = 1.0f / (1.0f + expf(-(R[3] + Z[3 * h + u])));
+    cn = cp * gf + gi * gj;
+    hn = tanhf(cn) * go;
+    p.out[((size_t)b * p.S + pos) * 2 * h + dir * h + u] = hn;
+  }
+  p.hs[s1] = hn;
+  p.cs[s1] = cn;
+  float* gp = p.gates + ((size_t)(dir * p.S + p.tau) * p.B + b) * G;
+  gp[u] = gi; gp[h + u] = gj; gp[2 * h + u] = gf; gp[3 * h + u] = go;
 }
-struct LstmBwdP {
+
+// The backward step likewise: gate gradients of the workgroup's 16 questions (all 4h columns, recomputed by each of the h / 16
+// workgroups that share the questions -- elementwise work, cheaper than a launch), then dh_prev = dG Wh^T for the workgroup's
+// 16 units from the LDS tile.  The running dh / dc are double-buffered by the parity of tau (a workgroup reads what its
+// neighbours would otherwise be overwriting); the workgroup with blockIdx.x == 0 writes dc, dG and dZ.
+struct LstmStepBwdP {
   int B, S, h, tau;
   const int32_t* len;
-  const float* cs;         // saved cell states [2][S+1][B][h]
-  const float* gates;      // saved gate activations
-  const float* dout;       // [B][S][2h]  gradient wrt the outputs
-  float* dh; float* dc;    // [2][B][h]   running state gradients (in/out)
-  float* dG;               // [2][S][B][4h]  gate pre-activation gradients, dense over (tau, b)
-  float* dZ;               // [2][B*S][4h]   the same, scattered to word positions (zero-initialised)
-  float* dh_pass;          // [2][B][h]   part of dh that bypasses the recurrent linear (inactive rows)
+  const float* WhT;        // [2] packed [4h/16][4][h][4] (pack format 0 of Wh^T)
+  const float* cs;         // [2][S+1][B][h]
+  const float* gates;      // [2][S][B][4h]
+  const float* dout;       // [B][S][2h]
+  const float* dh_in; const float* dc_in;     // [2][B][h] running state gradients after step tau + 1
+  float* dh_out; float* dc_out;               // ... after this step
+  float* dG;               // [2][S][B][4h]
+  float* dZ;               // [2][B*S][4h] (zero-initialised)
 };
-__global__ void lstm_cell_bwd_kernel(LstmBwdP p) {
-  const int n = 2 * p.B * p.h;
-  const size_t Bh = (size_t)p.B * p.h;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int dir = i / (p.B * p.h);
-    const int r = i - dir * p.B * p.h;
-    const int b = r / p.h, u = r - b * p.h;
-    const int L = min(max(p.len[b], 0), p.S);      // never index past the padded question (host validates too)
-    const bool active = p.tau < L;
-    const int pos = dir == 0 ? p.tau : L - 1 - p.tau;
-    float* g = p.dG + ((size_t)(dir * p.S + p.tau) * p.B + b) * 4 * p.h;
-    float dh = p.dh[i], dc = p.dc[i];
-    float di = 0.f, dj = 0.f, df = 0.f, dO = 0.f, pass = dh;
-    if (active) {
-      const float* ga = p.gates + ((size_t)(dir * p.S + p.tau) * p.B + b) * 4 * p.h;
-      const float gi = ga[u], gj = ga[p.h + u], gf = ga[2 * p.h + u], go = ga[3 * p.h + u];
-      const float cp = p.cs[(size_t)(dir * (p.S + 1) + p.tau) * Bh + r];
-      const float cn = p.cs[(size_t)(dir * (p.S + 1) + p.tau + 1) * Bh + r];
-      dh += p.dout[((size_t)b * p.S + pos) * 2 * p.h + dir * p.h + u];
-      const float tc = tanhf(cn);
-      dO = dh * tc * go * (1.0f - go);
-      const float dct = dc + dh * go * (1.0f - tc * tc);
-      di = dct * gj * gi * (1.0f - gi);
-      dj = dct * gi * (1.0f - gj * gj);
-      df = dct * cp * gf * (1.0f - gf);
-      dc = dct * gf;
-      pass = 0.f;
-      float* z = p.dZ + ((size_t)dir * p.B * p.S + (size_t)b * p.S + pos) * 4 * p.h;
-      z[u] = di; z[p.h + u] = dj; z[2 * p.h + u] = df; z[3 * p.h + u] = dO;
+constexpr int LSB_THREADS = 1024;      // 16 waves: the elementwise part is h / 64 (question, unit) pairs per thread, the product 4 k groups per wave at h = 256
+__global__ __launch_bounds__(LSB_THREADS) void lstm_step_bwd_kernel(LstmStepBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  const int h = p.h, G = 4 * h;
+  float* sG = lsm;                          // [16][G + 4] gate gradients of the workgroup's questions
+  float* sPass = sG + 16 * (G + 4);         // [16][16] dh that bypasses the recurrent product (questions that have ended)
+  float* red = sPass + 256;                 // [16 waves][16][17]
+  const int ldg = G + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int u0 = blockIdx.x * 16, r0 = blockIdx.y * 16, dir = blockIdx.z;
+  const size_t Bh = (size_t)p.B * h;
+  const bool writer = blockIdx.x == 0;
+  // ---- the cell's backward for 16 questions x h units
+#pragma unroll 4
+  for (int it = tid; it < 16 * h; it += LSB_THREADS) {
+    const int row = it / h, u = it - row * h;
+    const int b = r0 + row;
+    float di = 0.f, dj = 0.f, df = 0.f, dO = 0.f, pass = 0.f, dc = 0.f;
+    if (b < p.B) {
+      const size_t i = (size_t)dir * Bh + (size_t)b * h + u;
+      const int L = min(max(p.len[b], 0), p.S);
+      const bool active = p.tau < L;
+      const int pos = dir == 0 ? p.tau : L - 1 - p.tau;
+      float dh = p.dh_in[i];
+      dc = p.dc_in[i];
+      pass = dh;
+      if (active) {
+        const float* ga = p.gates + ((size_t)(dir * p.S + p.tau) * p.B + b) * G;
+        const float gi = ga[u], gj = ga[h + u], gf = ga[2 * h + u], go = ga[3 * h + u];
+        const size_t r = (size_t)b * h + u;
+        const float cp = p.cs[(size_t)(dir * (p.S + 1) + p.tau) * Bh + r];
+        const float cn = p.cs[(size_t)(dir * (p.S + 1) + p.tau + 1) * Bh + r];
+        dh += p.dout[((size_t)b * p.S + pos) * 2 * h + dir * h + u];
+        const float tc = tanhf(cn);
+        dO = dh * tc * go * (1.0f - go);
+        const float dct = dc + dh * go * (1.0f - tc * tc);
+        di = dct * gj * gi * (1.0f - gi);
+        dj = dct * gi * (1.0f - gj * gj);
+        df = dct * cp * gf * (1.0f - gf);
+        dc = dct * gf;
+        pass = 0.f;
+        if (writer) {
+          float* z = p.dZ + ((size_t)dir * p.B * p.S + (size_t)b * p.S + pos) * G;
+          z[u] = di; z[h + u] = dj; z[2 * h + u] = df; z[3 * h + u] = dO;
+        }
+      }
+      if (writer) {
+        float* g = p.dG + ((size_t)(dir * p.S + p.tau) * p.B + b) * G;
+        g[u] = di; g[h + u] = dj; g[2 * h + u] = df; g[3 * h + u] = dO;
+        p.dc_out[i] = dc;
+      }
     }
-    g[u] = di; g[p.h + u] = dj; g[2 * p.h + u] = df; g[3 * p.h + u] = dO;
-    p.dc[i] = dc;
-    p.dh_pass[i] = pass;
+    float* sg = sG + row * ldg;
+    sg[u] = di; sg[h + u] = dj; sg[2 * h + u] = df; sg[3 * h + u] = dO;
+    if (u >= u0 && u < u0 + 16) sPass[row * 16 + (u - u0)] = pass;
   }
+  __syncthreads();
+  // ---- dh_prev[16 questions][16 units] = dG[16][4h] WhT[4h][units]
+  const float* Wd = p.WhT + (size_t)dir * G * h;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nQ = G >> 4;
+  constexpr int PF = 4, NW = LSB_THREADS / 64;
+  for (int Q0 = wave; Q0 < nQ; Q0 += NW * PF) {
+    f32x4 af[PF], bf[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int Q = min(Q0 + NW * u, nQ - 1);
+      af[u] = *reinterpret_cast<const f32x4*>(sG + li * ldg + Q * 16 + lg * 4);
+      bf[u] = *reinterpret_cast<const f32x4*>(Wd + ((size_t)(Q * 4 + lg) * h + u0 + li) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (Q0 + NW * u < nQ) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][e], bf[u][e], acc, 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[(wave * 16 + lg * 4 + e) * 17 + li] = acc[e];
+  __syncthreads();
+  if (tid >= 256) return;
+  const int row = tid >> 4, uu = tid & 15;
+  const int b = r0 + row;
+  if (b >= p.B) return;
+  float v = red[row * 17 + uu];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) v += red[(w * 16 + row) * 17 + uu];        // fixed order
+  p.dh_out[(size_t)dir * Bh + (size_t)b * h + u0 + uu] = v + sPass[row * 16 + uu];
 }
-// d emb[v-1][c] = sum over tokens == v of dropmask * dx[r][c]   (one workgroup per vocabulary row: no atomics)
+inline size_t lstm_step_bwd_lds(int h) { return ((size_t)16 * (4 * h + 4) + 256 + (LSB_THREADS / 64) * 16 * 17) * sizeof(float); }
+
+// d emb[v-1][c] = sum over tokens == v of dropmask * dx[r][c]   (one workgroup per vocabulary row: no atomics).
+// The rows that hold token v are found 256 at a time by all threads (ballot + ordered compaction into LDS), then summed in
+// ascending row order: the scan is rows / 256 short passes instead of `rows` sequential compares per thread.
 __global__ __launch_bounds__(256) void embed_grad_kernel(const int32_t* __restrict__ idx, const float* __restrict__ dx, int rows, int E, int Ep,
                                                         uint32_t row0, DropSpec ds, float* demb) {
+  __shared__ int list[256];
+  __shared__ int wcount[4];
   const int v = blockIdx.x + 1;
-  for (int c = threadIdx.x; c < E; c += 256) {
-    float acc = 0.f;
-    for (int r = 0; r < rows; ++r)
-      if (idx[r] == v) acc += drop_apply(dx[(size_t)r * Ep + c], (uint32_t)((row0 + r) * E + c), ds);
-    demb[(size_t)(v - 1) * E + c] = acc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int CMAX = 4;                           // columns per thread held in registers: E <= 1024
+  float acc[CMAX];
+#pragma unroll
+  for (int k = 0; k < CMAX; ++k) acc[k] = 0.f;
+  for (int r0 = 0; r0 < rows; r0 += 256) {
+    const int r = r0 + tid;
+    const bool m = r < rows && idx[r] == v;
+    const unsigned long long mask = __ballot(m);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wcount[wave] = __popcll(mask);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { base += w < wave ? wcount[w] : 0; total += wcount[w]; }
+    if (m) list[base + before] = r;
+    __syncthreads();
+    for (int k = 0; k < total; ++k) {                // ascending rows
+      const int rr = list[k];
+#pragma unroll
+      for (int j = 0; j < CMAX; ++j) {
+        const int c = tid + 256 * j;
+        if (c < E) acc[j] += drop_apply(dx[(size_t)rr * Ep + c], (uint32_t)((row0 + rr) * E + c), ds);
+      }
+    }
+    __syncthreads();                                 // list / wcount are rewritten by the next pass
+  }
+#pragma unroll
+  for (int j = 0; j < CMAX; ++j) {
+    const int c = tid + 256 * j;
+    if (c < E) demb[(size_t)(v - 1) * E + c] = acc[j];
   }
 }
 
