@@ -284,6 +284,7 @@ struct BwdLayout {
   size_t dc_part, dls_part;   // chain kernel: per-row-group partials of dc / db_k, [p][dwk_rows][3][d] and [p][dwk_rows][3]
   size_t dyc_part;            // chain kernel: per-row-group partials of dy, [dwk_rows][3][d]
   bool chain_sums;
+  bool dy_in_linear;          // ... and its per-tile partials are summed by the dy linear itself (small_linear PART form)
   bool sb_deferred;           // dy comes from the chain kernel: dI1 is kept per step and S_b of all steps is ONE launch at the end
   size_t dI1_stride;          // floats between the steps' dI1 (0: one buffer)
   size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part, ctrl_dl;
@@ -320,6 +321,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.chain_sums = use_chain((int)d, (int)N) && N >= 32;
   L.sb_deferred = L.chain_sums && sb_defer_mode();
   L.dI1_stride = L.sb_deferred ? L.act_floats : 0;
+  L.dy_in_linear = L.sb_deferred && B <= 128 && (N + 62) / 64 + 1 <= (size_t)LIN_PART_TILES;
   L.dI2 = take(p * L.act_floats); L.dI1 = take((L.sb_deferred ? p : 1) * L.act_floats); L.dX = take(p * L.act_floats); L.da = take(B * N);   // dI2, dX (dI1) kept per step
   L.DM = take((p + 1) * B * d);
   L.DC = take((p + 1) * B * d);
@@ -459,8 +461,12 @@ struct Packer {
 
 // ---- H2 helpers (macx_h2.hip.h) -------------------------------------------------------------------------------
 // min over n entries of [n][cb] minimum-exponent arrays -> out[cb]
-__global__ void qmin_reduce_kernel(const int* q, int n, int cb, int* out) {
+struct QminList { const int* q[4]; int n[4]; int* out[4]; };     // blockIdx.x selects one of up to four reductions
+__global__ void qmin_reduce_kernel(QminList L, int cb) {
   __shared__ int red[8][4];
+  const int* q = L.q[blockIdx.x];
+  const int n = L.n[blockIdx.x];
+  int* out = L.out[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int k = 0; k < cb; ++k) {
     int m = 127;
@@ -476,9 +482,15 @@ __global__ void qmin_reduce_kernel(const int* q, int n, int cb, int* out) {
     out[threadIdx.x] = min(m, 126);       // an all-zero tensor family keeps exponent 0 rows: 127 never reaches a kernel
   }
 }
-hipError_t qmin_reduce(const int* q, int n, int cb, int* out, hipStream_t st) {
-  hipLaunchKernelGGL(qmin_reduce_kernel, dim3(1), dim3(256), 0, st, q, n, cb, out);
+hipError_t qmin_reduce_list(const QminList& L, int count, int cb, hipStream_t st) {
+  hipLaunchKernelGGL(qmin_reduce_kernel, dim3(count), dim3(256), 0, st, L, cb);
   return hipGetLastError();
+}
+hipError_t qmin_reduce(const int* q, int n, int cb, int* out, hipStream_t st) {
+  QminList L;
+  memset(&L, 0, sizeof(L));
+  L.q[0] = q; L.n[0] = n; L.out[0] = out;
+  return qmin_reduce_list(L, 1, cb, st);
 }
 hipError_t h2_from_f32(const H2FromP& f, hipStream_t st) {
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(h2_from_f32_kernel), H2C_LDS);
@@ -1049,6 +1061,9 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const float* att_kb = saved + L.seg[MACX_SEG_ATT_KB];
 
   SideQueue* sq = ((units & U_READ) && h2_mode()) ? side_queue() : nullptr;
+  // the recurrent control unit differentiates through dL/dc_i inside iteration i; otherwise every step's dc / db_k partials are
+  // reduced in one launch after the loop
+  const bool dc_in_loop = (units & U_CONTROL) && o->control_feed_prev;
   for (int i = p - 1; i >= 0; --i) {
     const float* c_i = controls + (size_t)(i + 1) * Bd;
     const float* X = saved + L.X + (size_t)i * L.act_stride;
@@ -1183,14 +1198,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         c.dX = hdX; c.qmin_dX = q_dX; c.dbx_part = ws + W.dbx_part + (size_t)i * W.db_rows * d;
         if (W.sb_deferred) { c.X = hX; c.dy_part = ws + W.dyc_part; }
         CK(chain_bwd_launch(c, st));
-        if (W.chain_sums) {
+        if (W.chain_sums && (dc_in_loop || (W.sb_deferred && !W.dy_in_linear))) {
           // the per-tile partials of this step: dL/dc_i += read-unit part, db_k partials, dy_i (the next launch needs dy_i)
           DcReduceP q;
           memset(&q, 0, sizeof(q));
           q.B = B; q.N = N; q.d = d;
           q.dc_part = ws + W.dc_part + (size_t)i * W.dwk_rows * 3 * d; q.dls_part = ws + W.dls_part + (size_t)i * W.dwk_rows * 3;
           q.dc = DC + (size_t)(i + 1) * Bd; q.dbk_part = ws + W.dbk_part + (size_t)i * B;
-          if (W.sb_deferred) { q.dy_part = ws + W.dyc_part; q.dy = ws + W.DY + (size_t)i * Bd; }
+          if (W.sb_deferred && !W.dy_in_linear) { q.dy_part = ws + W.dyc_part; q.dy = ws + W.DY + (size_t)i * Bd; }
           hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, 1), dim3(128), 0, st, q);
           CK(hipGetLastError());
         }
@@ -1313,7 +1328,12 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       l.d2 = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i);
       l.drop_row0 = (uint32_t)s->b0;
       if (units & U_WRITE) { l.addend = dwin; l.ld_add = win; }
-      CK(small_linear_launch(l, 1, st));
+      if (h2_mode() && W.dy_in_linear) {
+        l.part = ws + W.dyc_part; l.part_N = N; l.part_sum = DYi;
+        CK(small_linear_part_launch(l, st));
+      } else {
+        CK(small_linear_launch(l, 1, st));
+      }
       if (acc_prev) {
         CK(axpy(ws + W.tmpBd[0], Bd, dm_prev, st));
         if (o->write_gate) CK(axpy(ws + W.tmpBd[3], Bd, dm_prev, st));   // dm * (1 - z)
@@ -1374,6 +1394,15 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         CK(hipMemsetAsync(ws + W.dcI + (size_t)i * Bd, 0, Bd * sizeof(float), st));
       }
     }
+  }
+  if ((units & U_READ) && h2_mode() && W.chain_sums && !(dc_in_loop || (W.sb_deferred && !W.dy_in_linear))) {
+    DcReduceP q;
+    memset(&q, 0, sizeof(q));
+    q.B = B; q.N = N; q.d = d;
+    q.dc_part = ws + W.dc_part; q.dls_part = ws + W.dls_part; q.dc = DC + Bd; q.dbk_part = ws + W.dbk_part;
+    q.part_step = W.dwk_rows * 3 * d; q.dls_step = W.dwk_rows * 3; q.dc_step = Bd; q.dbk_step = B;
+    hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, p), dim3(128), 0, st, q);
+    CK(hipGetLastError());
   }
   if (sq) {                        // join: everything the side queue was given is ordered before what follows on `stream`
     CK(hipEventRecord(sq->join, sq->s));
@@ -1527,10 +1556,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   if (h2_mode()) {
     const int CB = d / 128;
     int* ecom = reinterpret_cast<int*>(ws + W.ecom);       // [H1 | dI2 | KBd | dX][8]
-    CK(qmin_reduce(reinterpret_cast<const int*>(saved + L.qmin_H1), p * B, CB, ecom, st));
-    CK(qmin_reduce(reinterpret_cast<const int*>(ws + W.qmin_dI2), p * B, CB, ecom + 8, st));
-    CK(qmin_reduce(reinterpret_cast<const int*>(saved + L.qmin_KBd), (rdrop ? p : 1) * B, CB, ecom + 16, st));
-    CK(qmin_reduce(reinterpret_cast<const int*>(ws + W.qmin_dX), p * B, CB, ecom + 24, st));
+    {
+      QminList ql;
+      ql.q[0] = reinterpret_cast<const int*>(saved + L.qmin_H1); ql.n[0] = p * B; ql.out[0] = ecom;
+      ql.q[1] = reinterpret_cast<const int*>(ws + W.qmin_dI2); ql.n[1] = p * B; ql.out[1] = ecom + 8;
+      ql.q[2] = reinterpret_cast<const int*>(saved + L.qmin_KBd); ql.n[2] = (rdrop ? p : 1) * B; ql.out[2] = ecom + 16;
+      ql.q[3] = reinterpret_cast<const int*>(ws + W.qmin_dX); ql.n[3] = p * B; ql.out[3] = ecom + 24;
+      CK(qmin_reduce_list(ql, 4, CB, st));
+    }
     TnH2P t;
     memset(&t, 0, sizeof(t));
     t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(t.M, t.nsplit);
@@ -1561,8 +1594,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     t.part = ws + W.slab_wx;
     CK(wgrad_any(t, st));
   }
-  CK(slab_reduce_launch(ws + W.slab_w2, (int)W.ns_big, dd, GP->memKbProj2_W, 0, st));
-  CK(slab_reduce_launch(ws + W.slab_wx, (int)W.ns_big, dd, GP->projX_W, 0, st));
+
   if (h2_mode() && W.sb_deferred) {
     // dW1a = sum_i sum_b diag(y_ib) S_ib, dW1b = sum_i sum_b S_ib, S_ib = X_ib^T dI1_ib: every step in one launch, the two
     // accumulators of a workgroup run through all of them (macx_wgrad_h2.hip.h)
@@ -1581,8 +1613,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     CK(sb_h2_launch(q, st));
   }
   const int nslab1 = (int)((h2_mode() && W.sb_deferred ? 1 : p) * W.ngroup);
-  CK(slab_reduce_launch(ws + W.slab_w1a, nslab1, dd, GP->memKbProj_W, 0, st));
-  CK(slab_reduce_launch(ws + W.slab_w1b, nslab1, dd, GP->memKbProj_W + dd, 0, st));
+  {
+    SlabList sl;
+    sl.d[0] = SlabDesc{ws + W.slab_w2, (int)W.ns_big, dd / 4, GP->memKbProj2_W, 0};
+    sl.d[1] = SlabDesc{ws + W.slab_wx, (int)W.ns_big, dd / 4, GP->projX_W, 0};
+    sl.d[2] = SlabDesc{ws + W.slab_w1a, nslab1, dd / 4, GP->memKbProj_W, 0};
+    sl.d[3] = SlabDesc{ws + W.slab_w1b, nslab1, dd / 4, GP->memKbProj_W + dd, 0};
+    CK(slab_reduce_list_launch(sl, 4, dd, st));
+  }
   CK(rs.add(ws + W.db2_part, p * (int)W.dwk_rows, d, d, GP->memKbProj2_b, st));
   CK(rs.add(ws + W.db1_part, p * (int)W.db_rows, d, d, GP->memKbProj_b, st));
   CK(rs.add(ws + W.dbx_part, p * (int)W.db_rows, d, d, GP->projX_b, st));

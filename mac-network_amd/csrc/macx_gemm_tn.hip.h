@@ -361,6 +361,37 @@ __global__ void slab_reduce_kernel(const float* __restrict__ part, int nslab, si
   }
 }
 
+// several reductions in one launch (blockIdx.y selects one): the read unit's four weight gradients end this way
+struct SlabDesc { const float* part; int nslab; size_t n4; float* dst; int accumulate; };
+struct SlabList { SlabDesc d[8]; };
+__global__ void slab_reduce_list_kernel(SlabList L) {
+  const SlabDesc q = L.d[blockIdx.y];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q.n4; i += stride) {
+    // (the order of slab_reduce_kernel)
+    const f32x4* src = reinterpret_cast<const f32x4*>(q.part) + i;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int k = 0;
+    for (; k + 8 <= q.nslab; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * q.n4];
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+      a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
+    }
+    for (; k < q.nslab; ++k) a0 += src[(size_t)k * q.n4];
+    f32x4 s = (a0 + a1) + (a2 + a3);
+    if (q.accumulate) s += reinterpret_cast<const f32x4*>(q.dst)[i];
+    reinterpret_cast<f32x4*>(q.dst)[i] = s;
+  }
+}
+inline hipError_t slab_reduce_list_launch(const SlabList& L, int n, size_t max_n, hipStream_t st) {
+  int grid = (int)((max_n / 4 + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(slab_reduce_list_kernel, dim3(grid, n), dim3(256), 0, st, L);
+  return hipGetLastError();
+}
+
 inline hipError_t slab_reduce_launch(const float* part, int nslab, size_t n, float* dst, int accumulate, hipStream_t st) {
   const size_t n4 = n / 4;
   int grid = (int)((n4 + 255) / 256);

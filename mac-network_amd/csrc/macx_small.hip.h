@@ -166,11 +166,16 @@ struct LinP {
   float* out_drop; int ld_od;       // use_drop == 2: `out` keeps val, out_drop receives val*f1*f2 (the next consumer's dropped copy)
   const float* addend; int ld_add; size_t zadd;                      // val += addend
   size_t rep_stride;
+  // PART form (small_linear_part_launch): the input row of question b is the sum of the chain kernel's per-tile partials
+  // part[tile][3][Ktot] over the 64-row tiles the question's `part_N` rows touch (macx_chain_h2.hip.h, dy_part) -- the reduction
+  // that would otherwise be a launch of its own in front of this one.  Column block 0 also writes the summed rows to part_sum.
+  const float* part; int part_N; float* part_sum;
 };
+constexpr int LIN_PART_TILES = 6;     // tiles a question may touch in the PART form: N <= 320
 
 // RTL row tiles of 16 per workgroup: 4 for tall inputs; 1 for the [B,d] chain (B <= 128 rows), where 64-row workgroups
 // would leave a 32-workgroup grid on a 256-CU chip and the launch is pure latency.
-template <int RTL>
+template <int RTL, bool PART = false>
 __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
   constexpr int L_ROWS = 16 * RTL;
   __shared__ float red[4][L_ROWS][20];
@@ -192,9 +197,43 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
   const int nQ = p.Ktot >> 4;
   // Operands are L2-resident and the chain is latency-bound: fetch the fragments of 8 k-groups
   // (40 x 16 B per lane in flight) before touching the matrix pipe.
-  constexpr int PF = 8;
+  constexpr int PF = PART ? 4 : 8;
+  // PART: the partial rows of this lane's question (fixed order: ascending tiles, as dc_reduce_kernel sums them)
+  const float* pbase[LIN_PART_TILES];
+  bool pvalid[LIN_PART_TILES];
+  if (PART) {
+    const uint32_t first = (uint32_t)rowc[0] * (uint32_t)p.part_N;
+    const int t0 = (int)(first >> 6), t1 = (int)((first + p.part_N - 1) >> 6);
+#pragma unroll
+    for (int j = 0; j < LIN_PART_TILES; ++j) {
+      const int tt = min(t0 + j, t1);
+      const int seg = rowc[0] - (int)(((uint32_t)tt << 6) / (uint32_t)p.part_N);
+      pbase[j] = p.part + ((size_t)tt * 3 + seg) * p.Ktot + lg * 4;
+      pvalid[j] = t0 + j <= t1;
+    }
+  }
   for (int Q0 = wave; Q0 < nQ; Q0 += 4 * PF) {
     f32x4 bf[PF], af[PF][RTL];
+    if (PART) {
+      f32x4 pv[PF][LIN_PART_TILES];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int Q = min(Q0 + 4 * u, nQ - 1);
+        bf[u] = *reinterpret_cast<const f32x4*>(Wz + (size_t)Q * 4 * p.n_out * 4);
+#pragma unroll
+        for (int j = 0; j < LIN_PART_TILES; ++j) pv[u][j] = *reinterpret_cast<const f32x4*>(pbase[j] + Q * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        f32x4 sum = pv[u][0];
+#pragma unroll
+        for (int j = 1; j < LIN_PART_TILES; ++j) sum += pvalid[j] ? pv[u][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        af[u][0] = sum;
+        const int Q = Q0 + 4 * u;
+        if (blockIdx.x == 0 && Q < nQ && r0 + li < p.rows)
+          *reinterpret_cast<f32x4*>(p.part_sum + (size_t)(r0 + li) * p.Ktot + Q * 16 + lg * 4) = sum;
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int Q = min(Q0 + 4 * u, nQ - 1);
@@ -212,6 +251,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
       bf[u] = *reinterpret_cast<const f32x4*>(Wz + (size_t)Q * 4 * p.n_out * 4);
 #pragma unroll
       for (int t = 0; t < RTL; ++t) af[u][t] = *reinterpret_cast<const f32x4*>(xs + (size_t)rowc[t] * ld);
+    }
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -258,6 +298,11 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
   if (p.use_drop == 2) *reinterpret_cast<f32x4*>(p.out_drop + (size_t)row * p.ld_od + col) = vald;
 }
 
+inline hipError_t small_linear_part_launch(const LinP& p, hipStream_t st) {
+  if (!p.part || !p.part_sum || p.rows > 128 || (p.part_N + 62) / 64 + 1 > LIN_PART_TILES) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((small_linear_kernel<1, true>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
 inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
   if (p.rows <= 128) {
     hipLaunchKernelGGL(small_linear_kernel<1>, dim3(p.n_out / 16, (p.rows + 15) / 16, nz), dim3(256), 0, st, p);
