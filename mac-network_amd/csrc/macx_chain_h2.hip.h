@@ -491,20 +491,18 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
       const int kg = x.ckg(j);
       const uint32_t e0 = p.first + (uint32_t)(x.cgrow * D + kg * 8);
       if (drop1) {
-        uint32_t byte = 0;
+        uint32_t byte = 0;             // (e0 is even: the width is a multiple of 128)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const bool keep = keep_bit(e0 + q, p.key1, p.thr1);
-          byte |= (keep ? 1u : 0u) << q;
-          v[j][q] = keep ? v[j][q] * p.inv1 : 0.f;
-        }
+        for (int q = 0; q < 8; q += 2) byte |= keep_pair(e0 + q, p.key1, p.thr1) << q;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[j][q] = ((byte >> q) & 1u) ? v[j][q] * p.inv1 : 0.f;
         if (p.bits1 && x.cvalid) p.bits1[x.cgrow * KG + kg] = (uint8_t)byte;
       }
       if (drop2) {
         // hashed once per element, here: the logits epilogue of stage 3 reads the bits back from LDS
         uint32_t byte = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) byte |= (keep_bit(e0 + q, p.key2, p.thr2) ? 1u : 0u) << q;
+        for (int q = 0; q < 8; q += 2) byte |= keep_pair(e0 + q, p.key2, p.thr2) << q;
         x.sBits[x.crow * C::G::BITS_LD + kg] = (uint8_t)byte;
         if (p.bytes2 && x.cvalid) p.bytes2[(size_t)kg * Rp2 + x.cgrow] = (uint8_t)byte;
       }

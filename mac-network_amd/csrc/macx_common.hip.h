@@ -39,7 +39,7 @@ inline hipError_t lds_attr_once(const void* fn, size_t bytes) {
 // instead of storing [B,N,d] masks, and a data-parallel shard sees exactly the masks the
 // full-batch run would have used (the element index is built from the GLOBAL question index).
 //
-//   bits(idx, key) = fmix(idx ^ key);   keep  <=>  (bits >> 8) < thr24,   thr24 = floor(keep * 2^24)
+//   h = fmix((idx >> 1) ^ key);  bits = idx odd ? h >> 16 : h & 0xFFFF;   keep  <=>  (bits << 8) < thr24,   thr24 = floor(keep * 2^24)
 //
 // oracle/dropout_hash.py restates the same function in numpy; tests compare the two bit-exactly.
 // ---------------------------------------------------------------------------------------------
@@ -57,8 +57,17 @@ __host__ __device__ __forceinline__ uint32_t site_key(uint32_t seed, uint32_t si
   return hash_mix(hash_mix(seed ^ 0xA511E9B3u) ^ hash_mix(site * 0x632BE5ABu + step * 0x2545F491u + 0x1B873593u));
 }
 
+// One 32-bit hash decides TWO neighbouring elements (16 bits each): the hash is the price of a dropout site inside the fused
+// kernels (2 x 64 per thread in front of the chain kernel's first product), and 2^-16 is resolution enough for a keep
+// probability.
 __host__ __device__ __forceinline__ bool keep_bit(uint32_t idx, uint32_t key, uint32_t thr24) {
-  return (hash_mix(idx ^ key) >> 8) < thr24;
+  const uint32_t h = hash_mix((idx >> 1) ^ key);
+  return (((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) << 8) < thr24;
+}
+// elements idx (even) and idx + 1 from one hash: bit 0 / bit 1 of the result
+__host__ __device__ __forceinline__ uint32_t keep_pair(uint32_t idx_even, uint32_t key, uint32_t thr24) {
+  const uint32_t h = hash_mix((idx_even >> 1) ^ key);
+  return (((h & 0xFFFFu) << 8) < thr24 ? 1u : 0u) | (((h >> 16) << 8) < thr24 ? 2u : 0u);
 }
 
 // dropout sites inside the cell (the numbers are part of the mask definition)

@@ -47,8 +47,9 @@ def threshold24(keep):
 def keep_mask(seed, site, step, keep, first, n):
     """0/1 float32 mask for flat element indices first .. first+n-1 of a dropout site."""
     idx = (np.arange(n, dtype=np.uint64) + np.uint64(first)) & _M32
-    bits = hash_mix(idx ^ np.uint64(site_key(seed, site, step)))
-    return ((bits >> np.uint64(8)) < np.uint64(threshold24(keep))).astype(np.float32)
+    h = hash_mix((idx >> np.uint64(1)) ^ np.uint64(site_key(seed, site, step)))      # one hash per pair of elements
+    bits = np.where((idx & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    return ((bits << np.uint64(8)) < np.uint64(threshold24(keep))).astype(np.float32)
 
 
 def mask_for(seed, site, step, keep, shape, b0=0):
