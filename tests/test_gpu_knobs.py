@@ -1,0 +1,42 @@
+"""-m gpu: the A/B knobs of macx_debug_set select different kernels for the same mathematics -- every route must give the
+gradients of the default one (summation orders differ, so not bit-for-bit):
+  key 4 = 0   the read unit as per-product launches instead of the chain kernels
+  key 5 = 0   S_b = X_b^T dI1_b once per step (delivering dy) instead of dy from the chain kernel + one deferred launch
+  key 6 = 1   the per-step dKB contraction on the internal side queue (fork / join by events) with accumulation in HBM"""
+import pytest
+import torch
+
+from helpers import make_case, rel_err
+from test_gpu_cell import build_cell
+
+pytestmark = pytest.mark.gpu
+
+
+def run(macx, dev, name, B, S, N, d, p):
+    cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
+    cell, params, (vqd, wd, kbd) = build_cell(macx, dev, cfg, vq, words, lengths, kb, True, seed=11, requires_grad=True)
+    state = cell.run()
+    gm = torch.randn(B, d, generator=torch.Generator().manual_seed(3)).to(dev)
+    (state.memory * gm).sum().backward()
+    torch.cuda.synchronize()
+    out = {"memory": state.memory.detach().clone(), "d_kb": kbd.grad.clone(), "d_words": wd.grad.clone(), "d_vq": vqd.grad.clone()}
+    for f in params.fields:
+        out["d_" + f] = getattr(params, f).grad.clone()
+    return out
+
+
+@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1)])
+@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 5, 9, 196, 128, 3), ("args1", 4, 9, 49, 256, 4)])
+def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
+    lib = macx._lib.lib()
+    defaults = {4: 1, 5: 1, 6: 0}
+    ref = run(macx, dev, name, B, S, N, d, p)
+    assert lib.macx_debug_set(key, value) == 0
+    try:
+        got = run(macx, dev, name, B, S, N, d, p)
+    finally:
+        assert lib.macx_debug_set(key, defaults[key]) == 0
+    for k in ref:
+        # (the logits bias shifts every logit of a softmax alike: its gradient is round-off around zero)
+        floor = 5e-2 if k.endswith("Logits_b") else 1e-6
+        assert rel_err(got[k], ref[k], floor=floor) < 2e-5, k
