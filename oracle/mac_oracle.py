@@ -154,10 +154,12 @@ class _ReluAtBoundary(torch.autograd.Function):
 RELU_BOUNDARY = None      # None: torch.relu; (mode, eps): _ReluAtBoundary -- set by tests only
 
 
-def relu_std(x):
+def relu_std(x, flip=False):
+    """flip: the derivative at the jump is taken from the OTHER side (PReLU = relu(x) - alpha relu(-x): its two one-sided
+    derivatives are 1 and alpha, so the second term runs with the opposite mode)"""
     if RELU_BOUNDARY is None:
         return torch.relu(x)
-    return _ReluAtBoundary.apply(x, RELU_BOUNDARY[0], RELU_BOUNDARY[1])
+    return _ReluAtBoundary.apply(x, RELU_BOUNDARY[0] ^ int(flip), RELU_BOUNDARY[1])
 
 
 class VarStore:
@@ -307,7 +309,7 @@ class Ops:
         if r == "PRM":
             with self.vs.scope("prelu", default=True):
                 alpha = self.vs.get("alpha", (inp.shape[-1],), 0.25)
-            return torch.relu(inp) - alpha * torch.relu(-inp)
+            return relu_std(inp) - alpha * relu_std(-inp, flip=True)
         if r == "ELU":
             return torch.nn.functional.elu(inp)
         if r == "LKY":

@@ -225,9 +225,24 @@ def run_random_sets(macx, seed, dev=None):
         k = 5.0 if cfg.memoryBN else 1.0
         # ReLU / PReLU have a derivative jump at 0: a pre-activation within round-off of zero lands on the other side in fp32
         # than in the fp64 oracle and moves one (row, column) of the read unit's gradients by its whole contribution (seen on
-        # the GPU at 1e-3 of the largest entry, identical in two kernel families, absent with ELU) -- gradients of such
-        # option sets get a tolerance that admits a flipped element
-        kink = 100.0 if cfg.relu in ("STD", "PRM") else 1.0          # (24 knowledge-base rows here: one element is 1/24 of a column)
+        # the GPU at 1e-3 of the largest entry, identical in two kernel families, absent with ELU).  For such option sets the
+        # oracle also runs with derivative 0 and with derivative 1 (PReLU: alpha and 1) wherever |pre-activation| <= 4e-6 of the
+        # tensor's largest: the distance between those two gradients is what the undecidable elements can contribute to a
+        # tensor, and it is added to that tensor's tolerance (as tests/test_gpu_fuzz.py does for the fused cell); where no
+        # pre-activation is that close to the jump the two coincide and the tolerance is the usual one
+        lohi = []
+        if cfg.relu in ("STD", "PRM"):
+            from helpers import relu_boundary
+            for mode in (0, 1):
+                with relu_boundary(mode, 4e-6):
+                    lohi.append(oracle_run(cfg, params, vq, words, lengths, kb, train=train, seed=91, b0=1, need_grad=True, d_memory=dM,
+                                           d_control=dC))
+
+        def undecidable(pick):
+            if not lohi:
+                return 0.0
+            a, b = pick(lohi[0]), pick(lohi[1])
+            return 0.0 if a is None or b is None else rel_err(a, b)
         # (absolute floor: writeInputs=MEM under batch norm normalises identical rows -- the memory is round-off around zero)
         assert list(gp.names) == list(params), over
         assert rel_err(state.memory, ref["memory"], floor=1e-3) < 2e-5 * k and rel_err(state.control, ref["control"], floor=1e-3) < 2e-5 * k, over
@@ -236,10 +251,10 @@ def run_random_sets(macx, seed, dev=None):
             if v.grad is None:
                 assert grads[name] is None or float(grads[name].abs().max()) == 0.0, (over, name)
             elif float(v.grad.abs().max()) > 1e-6:
-                assert_grad(grads[name], v.grad, name, 2e-4 * k * kink)
-        for got, want in zip((vqd, wd, kbd), ref["inputs"]):
+                assert_grad(grads[name], v.grad, name, 2e-4 * k + undecidable(lambda r, name=name: r["params"][name].grad))
+        for j, (got, want) in enumerate(zip((vqd, wd, kbd), ref["inputs"])):
             if want.grad is not None and float(want.grad.abs().max()) > 1e-6:
-                assert rel_err(got.grad, want.grad) < 2e-4 * k * kink, over
+                assert rel_err(got.grad, want.grad) < 2e-4 * k + undecidable(lambda r, j=j: r["inputs"][j].grad), over
     assert built >= 2
 
 
