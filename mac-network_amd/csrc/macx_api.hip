@@ -321,7 +321,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.chain_sums = use_chain((int)d, (int)N) && N >= 32;
   L.sb_deferred = L.chain_sums && sb_defer_mode();
   L.dI1_stride = L.sb_deferred ? L.act_floats : 0;
-  L.dy_in_linear = L.sb_deferred && B <= 128 && (N + 62) / 64 + 1 <= (size_t)LIN_PART_TILES;
+  L.dy_in_linear = L.sb_deferred && B <= 128 && ((N - 2) >> chain_tile_shift((int)d, B * N)) + 2 <= (size_t)LIN_PART_TILES;
   L.dI2 = take(p * L.act_floats); L.dI1 = take((L.sb_deferred ? p : 1) * L.act_floats); L.dX = take(p * L.act_floats); L.da = take(B * N);   // dI2, dX (dI1) kept per step
   L.DM = take((p + 1) * B * d);
   L.DC = take((p + 1) * B * d);
@@ -341,10 +341,10 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.slab_w1a = take((L.sb_deferred ? 1 : p) * L.ngroup * d * d);
   L.slab_w1b = take((L.sb_deferred ? 1 : p) * L.ngroup * d * d);
   // column-sum partials of dI1 / dX: one row per GEMM workgroup row block, or per 64-row tile of the chain kernel
-  const size_t nrb = use_chain((int)d, (int)N) ? (B * N + 63) / 64 : B * nrb_of((int)N, (int)B, (int)d);
+  const size_t nrb = use_chain((int)d, (int)N) ? chain_tiles((int)d, B * N) : B * nrb_of((int)N, (int)B, (int)d);
   L.db_rows = nrb;
   // dw_k / db2 partials: one row per question, or per 64-row tile when the chain kernel sums them (N >= 32)
-  L.dwk_rows = L.chain_sums ? (B * N + 63) / 64 : B;
+  L.dwk_rows = L.chain_sums ? chain_tiles((int)d, B * N) : B;
   L.db2_part = take(p * L.dwk_rows * d);
   L.db1_part = take(p * nrb * d);
   L.dbx_part = take(p * nrb * d);
@@ -1205,6 +1205,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
           q.B = B; q.N = N; q.d = d;
           q.dc_part = ws + W.dc_part + (size_t)i * W.dwk_rows * 3 * d; q.dls_part = ws + W.dls_part + (size_t)i * W.dwk_rows * 3;
           q.dc = DC + (size_t)(i + 1) * Bd; q.dbk_part = ws + W.dbk_part + (size_t)i * B;
+          q.tile_shift = chain_tile_shift(d, (size_t)B * N);
           if (W.sb_deferred && !W.dy_in_linear) { q.dy_part = ws + W.dyc_part; q.dy = ws + W.DY + (size_t)i * Bd; }
           hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, 1), dim3(128), 0, st, q);
           CK(hipGetLastError());
@@ -1329,7 +1330,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       l.drop_row0 = (uint32_t)s->b0;
       if (units & U_WRITE) { l.addend = dwin; l.ld_add = win; }
       if (h2_mode() && W.dy_in_linear) {
-        l.part = ws + W.dyc_part; l.part_N = N; l.part_sum = DYi;
+        l.part = ws + W.dyc_part; l.part_N = N; l.part_sum = DYi; l.part_shift = chain_tile_shift(d, (size_t)B * N);
         CK(small_linear_part_launch(l, st));
       } else {
         CK(small_linear_launch(l, 1, st));
@@ -1401,6 +1402,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     q.B = B; q.N = N; q.d = d;
     q.dc_part = ws + W.dc_part; q.dls_part = ws + W.dls_part; q.dc = DC + Bd; q.dbk_part = ws + W.dbk_part;
     q.part_step = W.dwk_rows * 3 * d; q.dls_step = W.dwk_rows * 3; q.dc_step = Bd; q.dbk_step = B;
+    q.tile_shift = chain_tile_shift(d, (size_t)B * N);
     hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, p), dim3(128), 0, st, q);
     CK(hipGetLastError());
   }

@@ -79,14 +79,22 @@ __device__ __forceinline__ float chain_act(int act, float x) {
   return act_apply(act, x);
 }
 
-template <int D_>
+// R_: rows of a tile.  64 whenever that gives the chip enough tiles; 32 / 16 for small batches (a data-parallel shard of the
+// metric's 64 questions): a launch lasts as long as ONE tile takes, so with 25 tiles of 64 rows on 256 CUs the kernel ran as
+// long as with 196 -- shorter tiles put the rows on more CUs (the weights then stream from L2 once per 16 or 32 rows instead
+// of once per 64: the K loop turns L2-bound, at about half its time).
+template <int D_, int R_ = 64>
 struct ChainGeo {
-  static constexpr int D = D_, R = 64, KG = D / 8, CB = D / 128, KS = D / 32;
+  static constexpr int D = D_, R = R_, KG = D / 8, CB = D / 128, KS = D / 32;
   static constexpr int NWC = D >= 512 ? 8 : 4;       // waves along the columns
   static constexpr int NWR = 8 / NWC;                // waves along the rows
   static constexpr int CT = D / (16 * NWC);          // 16-column tiles per wave
-  static constexpr int RT = 4 / NWR;                 // 16-row tiles per wave
-  static constexpr int IT = KG / 8;                  // conversion passes: slot columns per lane (16 rows x 4 slot columns per wave step)
+  static constexpr int RT = R / (16 * NWR);          // 16-row tiles per wave
+  static constexpr int NRG = R / 16;                 // 16-row groups of the tile
+  static constexpr int WPG = 8 / NRG;                // conversion passes: waves that share a row group
+  static constexpr int IT = KG / (4 * WPG);          // ... slot columns per lane (16 rows x 4 slot columns per wave step)
+  static constexpr int SB = R / 8;                   // backward stage B0: 8-row blocks per lane
+  static_assert(R == 64 || ((R == 32 || R == 16) && NWR == 1), "short tiles: every wave holds all rows (d = 512)");
   static constexpr size_t P_BYTES = (size_t)4 * R * D;
   static constexpr int QS = 5;                       // backward: questions a tile can touch (N >= 16) -- their control vectors are staged in LDS
   static constexpr int BITS_LD = KG + 4;             // bytes per row of sBits (+4: rows 4 apart would share a bank)
@@ -97,10 +105,11 @@ struct ChainGeo {
 };
 
 // what both kernels share: the tile in LDS, who owns what, the K loop, the row-exponent bookkeeping, the H2 emitters
-template <int D_>
+template <int D_, int R_ = 64>
 struct ChainCtx {
-  using G = ChainGeo<D_>;
-  static constexpr int D = G::D, R = G::R, KG = G::KG, CB = G::CB, KS = G::KS, NWC = G::NWC, NWR = G::NWR, CT = G::CT, RT = G::RT, IT = G::IT;
+  using G = ChainGeo<D_, R_>;
+  static constexpr int D = G::D, R = G::R, KG = G::KG, CB = G::CB, KS = G::KS, NWC = G::NWC, NWR = G::NWR, CT = G::CT, RT = G::RT, IT = G::IT,
+                       WPG = G::WPG, SB = G::SB;
   char* P;          // [2 planes][KG][R] x 16 B: the stage's activation operand
   float* sMax;      // [8][R] partial row maxima
   float* sPart;     // [8][R] partial row sums (attention logits)
@@ -134,11 +143,11 @@ struct ChainCtx {
     M = M_; N = N_;
     grow0 = (size_t)blockIdx.x * R;
     nvalid = (int)min((size_t)R, (size_t)M - grow0);
-    crow = (wave >> 1) * 16 + li;
+    crow = (wave / WPG) * 16 + li;
     cgrow = grow0 + crow;
     cvalid = crow < nvalid;
   }
-  __device__ __forceinline__ int ckg(int j) const { return ((wave & 1) * IT + j) * 4 + lg; }   // conversion passes: slot column j of this lane
+  __device__ __forceinline__ int ckg(int j) const { return ((wave % WPG) * IT + j) * 4 + lg; }   // conversion passes: slot column j of this lane
   __device__ __forceinline__ size_t qrow(size_t grow) const { return min((uint32_t)grow, (uint32_t)M - 1) / (uint32_t)N; }   // question of a row (rows < 2^31)
 
   __device__ __forceinline__ int row_exponent(int row, int w0, int nw) const {
@@ -148,7 +157,7 @@ struct ChainCtx {
   }
   // exponent of a row after an accumulator epilogue (partial maxima from the NWC waves of its row half) / a conversion pass
   __device__ __forceinline__ int row_exponent_epi(int row) const { return row_exponent(row, (row / (16 * RT)) * NWC, NWC); }
-  __device__ __forceinline__ int row_exponent_conv(int row) const { return row_exponent(row, (row >> 4) * 2, 2); }
+  __device__ __forceinline__ int row_exponent_conv(int row) const { return row_exponent(row, (row >> 4) * WPG, WPG); }
   __device__ __forceinline__ int row_exponent_blk(int row) const { return row_exponent(row, 0, KG / 8); }
   enum { PASS_CONV = 0, PASS_EPI = 1, PASS_BLK = 2 };
   __device__ __forceinline__ int row_exponent_of(int row, int pass) const {
@@ -158,10 +167,10 @@ struct ChainCtx {
   // per-row bookkeeping once sMax is complete: exponent table, exponent bytes, per-question minimum (wave 0 works)
   __device__ __forceinline__ void publish_rows(int* eTab, int pass, const H2View& out, int* qmin) const {
     if (tid < 64) {
-      const int r = tid;
-      const bool v = r < nvalid;
+      const int r = min(tid, R - 1);                // (lanes past a short tile: no row, they only take part in the shuffles)
+      const bool v = tid < nvalid;
       const int e = row_exponent_of(r, pass);
-      eTab[r] = e;
+      if (tid < R) eTab[r] = e;
       if (out.base && v) {
         int8_t* ex = out.exps() + (grow0 + r) * CB;
 #pragma unroll
@@ -228,7 +237,7 @@ struct ChainCtx {
     const int kg = 8 * wave + kq;
     if (active) {
 #pragma unroll
-      for (int sb = 0; sb < 8; ++sb) {
+      for (int sb = 0; sb < SB; ++sb) {
         float m = mx[sb];
         m = fmaxf(m, dpp_mov_f<0x128>(m));                 // lane ^ 8 (row_ror:8 within 16 lanes)
         m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -240,7 +249,7 @@ struct ChainCtx {
     if (active) {
       const int h = (kq & 1) * 16;
 #pragma unroll
-      for (int sb = 0; sb < 8; ++sb) {
+      for (int sb = 0; sb < SB; ++sb) {
         const char* d = blk_slot(kg, 8 * sb + r8);
         const f32x4 a = *reinterpret_cast<const f32x4*>(d + h), b = *reinterpret_cast<const f32x4*>(d + 16 - h);
 #pragma unroll
@@ -252,7 +261,7 @@ struct ChainCtx {
       const size_t Rp = out.Rp();
       const size_t opb = out.plane_bytes();
 #pragma unroll
-      for (int sb = 0; sb < 8; ++sb) {
+      for (int sb = 0; sb < SB; ++sb) {
         const int row = 8 * sb + r8;
         const float s = h2_pow2(row_exponent_blk(row));
         float xs[8];
@@ -461,9 +470,9 @@ struct ChainFwdP {
   float* logits;            // [M] (without the bias b_k, which kb_attend adds)
 };
 
-template <int D_, int KV = 0>
+template <int D_, int KV = 0, int R_ = 64>
 __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
-  using C = ChainCtx<D_>;
+  using C = ChainCtx<D_, R_>;
   constexpr int D = C::D, R = C::R, KG = C::KG, CT = C::CT, RT = C::RT, IT = C::IT;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   C x;
@@ -654,17 +663,25 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   }
 }
 
-template <int D_, int KV = 0>
+template <int D_, int KV = 0, int R_ = 64>
 inline hipError_t chain_fwd_launch_t(const ChainFwdP& p, hipStream_t st) {
-  auto kern = chain_fwd_kernel<D_, KV>;
-  constexpr size_t lds = ChainGeo<D_>::LDS;
+  auto kern = chain_fwd_kernel<D_, KV, R_>;
+  constexpr size_t lds = ChainGeo<D_, R_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((p.M + 63) / 64), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
 inline bool chain_supported(int d, int N) { return d % 128 == 0 && d >= 128 && d <= 512 && N >= 16; }
+// rows per tile: the tallest tile that still leaves the chip one tile per CU (short tiles exist for d = 512 only)
+inline int chain_tile_rows(int d, size_t M) {
+  if (d != 512) return 64;
+  if ((M + 31) / 32 > 256) return 64;
+  return (M + 15) / 16 > 256 ? 32 : 16;
+}
+inline int chain_tile_shift(int d, size_t M) { const int r = chain_tile_rows(d, M); return r == 64 ? 6 : (r == 32 ? 5 : 4); }
+inline size_t chain_tiles(int d, size_t M) { const size_t r = (size_t)chain_tile_rows(d, M); return (M + r - 1) / r; }
 
 inline hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
   switch (p.d / 128) {
@@ -672,6 +689,11 @@ inline hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
     case 2: return chain_fwd_launch_t<256>(p, st);
     case 3: return chain_fwd_launch_t<384>(p, st);
     case 4:
+      switch (chain_tile_rows(p.d, (size_t)p.M)) {
+        case 16: return chain_fwd_launch_t<512, 0, 16>(p, st);
+        case 32: return chain_fwd_launch_t<512, 0, 32>(p, st);
+        default: break;
+      }
       switch (p.dbg >> 3) {
         case 1: return chain_fwd_launch_t<512, 1>(p, st);
         case 2: return chain_fwd_launch_t<512, 2>(p, st);
@@ -725,9 +747,9 @@ struct ChainBwdP {
 
 // A2: readCtrlAct as a compile-time constant (ACT_ELU, what "RELU" means in the published configurations) or -1 = decided per
 // value at run time.  Two kernels rather than two arms in one: the arms met in one register allocation (86 spilled registers).
-template <int D_, int KV = 0, int A2 = -1>
+template <int D_, int KV = 0, int A2 = -1, int R_ = 64>
 __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
-  using C = ChainCtx<D_>;
+  using C = ChainCtx<D_, R_>;
   constexpr int D = C::D, R = C::R, KG = C::KG, CB = C::CB, CT = C::CT, RT = C::RT, IT = C::IT;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   C x;
@@ -832,19 +854,22 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       x.blk_park(kg, 8 * sb + r8, o);
     };
     auto pass = [&](auto act_c) __attribute__((always_inline)) {
-      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2_ = std::integral_constant<int, 2>;
-      using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
-      using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
-      fetch(I0{}); fetch(I1{}); fetch(I2_{});
+      constexpr int SBc = C::SB;                       // 8-row blocks of the tile: 8, 4 or 2
+      fetch(std::integral_constant<int, 0>{});
+      if constexpr (SBc > 1) fetch(std::integral_constant<int, 1>{});
+      if constexpr (SBc > 2) fetch(std::integral_constant<int, 2>{});
       __builtin_amdgcn_sched_barrier(0);
-      fetch(I3{}); block(act_c, I0{}); __builtin_amdgcn_sched_barrier(0);
-      fetch(I4{}); block(act_c, I1{}); __builtin_amdgcn_sched_barrier(0);
-      fetch(I5{}); block(act_c, I2_{}); __builtin_amdgcn_sched_barrier(0);
-      fetch(I6{}); block(act_c, I3{}); __builtin_amdgcn_sched_barrier(0);
-      fetch(I7{}); block(act_c, I4{}); __builtin_amdgcn_sched_barrier(0);
-      block(act_c, I5{}); __builtin_amdgcn_sched_barrier(0);
-      block(act_c, I6{}); __builtin_amdgcn_sched_barrier(0);
-      block(act_c, I7{});
+      auto step = [&](auto sb_c) __attribute__((always_inline)) {
+        constexpr int sb = decltype(sb_c)::value;
+        if constexpr (sb < SBc) {
+          if constexpr (sb + 3 < SBc) fetch(std::integral_constant<int, sb + 3>{});
+          block(act_c, sb_c);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
     };
     if (active) pass(std::integral_constant<int, A2>{});
     if (sums && active) {
@@ -1023,19 +1048,19 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   }
 }
 
-template <int D_, int KV, int A2>
+template <int D_, int KV, int A2, int R_ = 64>
 inline hipError_t chain_bwd_launch_a(const ChainBwdP& p, hipStream_t st) {
-  auto kern = chain_bwd_kernel<D_, KV, A2>;
-  constexpr size_t lds = ChainGeo<D_>::LDS;
+  auto kern = chain_bwd_kernel<D_, KV, A2, R_>;
+  constexpr size_t lds = ChainGeo<D_, R_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((p.M + 63) / 64), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
-template <int D_, int KV = 0>
+template <int D_, int KV = 0, int R_ = 64>
 inline hipError_t chain_bwd_launch_t(const ChainBwdP& p, hipStream_t st) {
-  return p.act2 == ACT_ELU ? chain_bwd_launch_a<D_, KV, ACT_ELU>(p, st) : chain_bwd_launch_a<D_, KV, -1>(p, st);
+  return p.act2 == ACT_ELU ? chain_bwd_launch_a<D_, KV, ACT_ELU, R_>(p, st) : chain_bwd_launch_a<D_, KV, -1, R_>(p, st);
 }
 
 inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
@@ -1044,6 +1069,11 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
     case 2: return chain_bwd_launch_t<256>(p, st);
     case 3: return chain_bwd_launch_t<384>(p, st);
     case 4:
+      switch (chain_tile_rows(p.d, (size_t)p.M)) {
+        case 16: return chain_bwd_launch_t<512, 0, 16>(p, st);
+        case 32: return chain_bwd_launch_t<512, 0, 32>(p, st);
+        default: break;
+      }
       switch (p.dbg >> 3) {
         case 1: return chain_bwd_launch_t<512, 1>(p, st);
         case 3: return chain_bwd_launch_t<512, 3>(p, st);
@@ -1063,17 +1093,19 @@ struct DcReduceP {
   size_t part_step, dls_step, dc_step, dbk_step;      // blockIdx.y = step: floats between the steps' buffers
   const float* dy_part;     // [tiles][3][d] (chain_bwd_kernel stage B2) or null
   float* dy;                // [B][d] written
+  int tile_shift;           // log2 of the rows per tile (chain_tile_shift)
 };
 __global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
   const int q = blockIdx.x;
   p.dc_part += blockIdx.y * p.part_step; p.dls_part += blockIdx.y * p.dls_step;
   p.dc += blockIdx.y * p.dc_step; p.dbk_part += blockIdx.y * p.dbk_step;
   const size_t r0 = (size_t)q * p.N, r1 = r0 + p.N - 1;
-  const int t0 = (int)(r0 >> 6), t1 = (int)(r1 >> 6);
+  const int ts = p.tile_shift;
+  const int t0 = (int)(r0 >> ts), t1 = (int)(r1 >> ts);
   for (int c4 = threadIdx.x * 4; c4 < p.d; c4 += 512) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int t = t0; t <= t1; ++t) {                       // fixed order
-      const int seg = q - (int)(((size_t)t << 6) / p.N);   // 0: the question that owns the tile's first row
+      const int seg = q - (int)(((size_t)t << ts) / p.N);   // 0: the question that owns the tile's first row
       s += *reinterpret_cast<const f32x4*>(p.dc_part + ((size_t)t * 3 + seg) * p.d + c4);
     }
     f32x4* dst = reinterpret_cast<f32x4*>(p.dc + (size_t)q * p.d + c4);
@@ -1081,7 +1113,7 @@ __global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
     if (p.dy_part) {
       f32x4 sy = {0.f, 0.f, 0.f, 0.f};
       for (int t = t0; t <= t1; ++t) {                     // fixed order
-        const int seg = q - (int)(((size_t)t << 6) / p.N);
+        const int seg = q - (int)(((size_t)t << ts) / p.N);
         sy += *reinterpret_cast<const f32x4*>(p.dy_part + ((size_t)t * 3 + seg) * p.d + c4);
       }
       *reinterpret_cast<f32x4*>(p.dy + (size_t)q * p.d + c4) = sy;
@@ -1089,7 +1121,7 @@ __global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
   }
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int k = t0; k <= t1; ++k) t += p.dls_part[(size_t)k * 3 + (q - (int)(((size_t)k << 6) / p.N))];
+    for (int k = t0; k <= t1; ++k) t += p.dls_part[(size_t)k * 3 + (q - (int)(((size_t)k << ts) / p.N))];
     p.dbk_part[q] = t;
   }
 }

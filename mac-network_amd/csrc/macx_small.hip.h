@@ -169,7 +169,7 @@ struct LinP {
   // PART form (small_linear_part_launch): the input row of question b is the sum of the chain kernel's per-tile partials
   // part[tile][3][Ktot] over the 64-row tiles the question's `part_N` rows touch (macx_chain_h2.hip.h, dy_part) -- the reduction
   // that would otherwise be a launch of its own in front of this one.  Column block 0 also writes the summed rows to part_sum.
-  const float* part; int part_N; float* part_sum;
+  const float* part; int part_N; float* part_sum; int part_shift;      // part_shift: log2 of the rows per tile
 };
 constexpr int LIN_PART_TILES = 6;     // tiles a question may touch in the PART form: N <= 320
 
@@ -203,11 +203,11 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
   bool pvalid[LIN_PART_TILES];
   if (PART) {
     const uint32_t first = (uint32_t)rowc[0] * (uint32_t)p.part_N;
-    const int t0 = (int)(first >> 6), t1 = (int)((first + p.part_N - 1) >> 6);
+    const int t0 = (int)(first >> p.part_shift), t1 = (int)((first + p.part_N - 1) >> p.part_shift);
 #pragma unroll
     for (int j = 0; j < LIN_PART_TILES; ++j) {
       const int tt = min(t0 + j, t1);
-      const int seg = rowc[0] - (int)(((uint32_t)tt << 6) / (uint32_t)p.part_N);
+      const int seg = rowc[0] - (int)(((uint32_t)tt << p.part_shift) / (uint32_t)p.part_N);
       pbase[j] = p.part + ((size_t)tt * 3 + seg) * p.Ktot + lg * 4;
       pvalid[j] = t0 + j <= t1;
     }
@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
 }
 
 inline hipError_t small_linear_part_launch(const LinP& p, hipStream_t st) {
-  if (!p.part || !p.part_sum || p.rows > 128 || (p.part_N + 62) / 64 + 1 > LIN_PART_TILES) return hipErrorInvalidValue;
+  if (!p.part || !p.part_sum || p.rows > 128 || p.part_shift < 4 || p.part_shift > 6 ||
+      ((p.part_N - 2) >> p.part_shift) + 2 > LIN_PART_TILES) return hipErrorInvalidValue;
   hipLaunchKernelGGL((small_linear_kernel<1, true>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(256), 0, st, p);
   return hipGetLastError();
 }

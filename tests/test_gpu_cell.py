@@ -40,6 +40,8 @@ def build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=0, b0=0, requ
     ("args4", 4, 9, 49, 128, 3, True),
     ("args4", 3, 9, 196, 128, 2, False),
     ("args1", 4, 9, 49, 128, 4, True),
+    ("args", 3, 9, 196, 512, 2, True),        # d = 512, 588 rows: the chain kernels' 16-row tiles
+    ("args", 24, 9, 196, 512, 2, True),       # 4704 rows: 32-row tiles
 ])
 def test_forward_stepwise_matches_oracle(macx, dev, name, B, S, N, d, p, train):
     cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
@@ -80,6 +82,9 @@ def test_forward_stepwise_matches_oracle(macx, dev, name, B, S, N, d, p, train):
     ("args1", 2, 7, 30, 128, 3, False),
     ("args", 2, 7, 30, 128, 18, True),        # more than 16 steps: the deferred dKB launch adds att (x) dinfo in two chunks
     ("args", 2, 5, 20, 128, 1, True),         # a single step
+    ("args", 3, 9, 196, 512, 2, True),        # d = 512, 588 rows: the chain kernels' 16-row tiles (14 tiles per question: dy through dc_reduce)
+    ("args", 24, 7, 196, 512, 2, True),       # 4704 rows: 32-row tiles (dy partials summed by the linear)
+    ("args1", 5, 7, 49, 512, 3, True),        # 245 rows, recurrent control: dc inside the loop
 ])
 def test_backward_matches_oracle_autograd(macx, dev, name, B, S, N, d, p, train):
     cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
