@@ -1099,29 +1099,28 @@ __global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
   const int q = blockIdx.x;
   p.dc_part += blockIdx.y * p.part_step; p.dls_part += blockIdx.y * p.dls_step;
   p.dc += blockIdx.y * p.dc_step; p.dbk_part += blockIdx.y * p.dbk_step;
-  const size_t r0 = (size_t)q * p.N, r1 = r0 + p.N - 1;
+  const uint32_t r0 = (uint32_t)q * (uint32_t)p.N, r1 = r0 + (uint32_t)p.N - 1;      // (rows < 2^31: 32-bit divisions, no 64-bit software routine)
   const int ts = p.tile_shift;
   const int t0 = (int)(r0 >> ts), t1 = (int)(r1 >> ts);
+  auto seg_of = [&](int t) { return q - (int)(((uint32_t)t << ts) / (uint32_t)p.N); };   // 0: the question that owns the tile's first row
   for (int c4 = threadIdx.x * 4; c4 < p.d; c4 += 512) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int t = t0; t <= t1; ++t) {                       // fixed order
-      const int seg = q - (int)(((size_t)t << ts) / p.N);   // 0: the question that owns the tile's first row
-      s += *reinterpret_cast<const f32x4*>(p.dc_part + ((size_t)t * 3 + seg) * p.d + c4);
-    }
+#pragma unroll 4
+    for (int t = t0; t <= t1; ++t)                          // fixed order
+      s += *reinterpret_cast<const f32x4*>(p.dc_part + ((size_t)t * 3 + seg_of(t)) * p.d + c4);
     f32x4* dst = reinterpret_cast<f32x4*>(p.dc + (size_t)q * p.d + c4);
     *dst = *dst + s;
     if (p.dy_part) {
       f32x4 sy = {0.f, 0.f, 0.f, 0.f};
-      for (int t = t0; t <= t1; ++t) {                     // fixed order
-        const int seg = q - (int)(((size_t)t << ts) / p.N);
-        sy += *reinterpret_cast<const f32x4*>(p.dy_part + ((size_t)t * 3 + seg) * p.d + c4);
-      }
+#pragma unroll 4
+      for (int t = t0; t <= t1; ++t)                        // fixed order
+        sy += *reinterpret_cast<const f32x4*>(p.dy_part + ((size_t)t * 3 + seg_of(t)) * p.d + c4);
       *reinterpret_cast<f32x4*>(p.dy + (size_t)q * p.d + c4) = sy;
     }
   }
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int k = t0; k <= t1; ++k) t += p.dls_part[(size_t)k * 3 + (q - (int)(((size_t)k << ts) / p.N))];
+    for (int k = t0; k <= t1; ++k) t += p.dls_part[(size_t)k * 3 + seg_of(k)];
     p.dbk_part[q] = t;
   }
 }
