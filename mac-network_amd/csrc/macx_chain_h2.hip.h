@@ -10,8 +10,10 @@
 //     dI2 = (dl w_k * mask * act'(I2 * c)) * c                        (stage B0, elementwise from the kept I2)
 //     dI1 = (dI2 W2^T) * act'(H1)                                     (stage B1)
 //     dX  = (dI1 W1a^T) * y + dI1 W1b^T                               (stage B2: two products on the same accumulators)
+//     dy  = sum_rows (dI1 W1a^T) * X                                  (stage B2, between its two products: per-tile partials)
 //
-// A workgroup owns 64 consecutive rows of the [B*N, d] activation and ALL d columns of every stage, so a stage's output
+// A workgroup owns 64 (for small row counts 32 or 16: ChainGeo) consecutive rows of the [B*N, d] activation and ALL d
+// columns of every stage, so a stage's output
 // never leaves the CU before it is the next stage's operand: it is written in place, as H2 planes, over the LDS tile the
 // stage just multiplied.  Every tensor the other direction or a weight-gradient kernel needs still goes to HBM once, as
 // stores that drain behind the next stage's matrix work; nothing is read back.  Against the launches these replace
