@@ -343,15 +343,25 @@ __device__ __forceinline__ void pack_h2_weight(const float* src, int ld_k, int l
   const int e = h2_weight_exponent(*maxabs);
   const float s = h2_pow2(e);
   const size_t nslot = (size_t)(K >> 3) * Nout;
+  const bool vec8 = ld_k == 1 && (ld_j & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
   char* d0 = reinterpret_cast<char*>(dst);
   for (size_t i = tid_global; i < nslot; i += nthreads) {
     const int j = (int)(i % Nout);
     const int kg = (int)(i / Nout);
     float x[8];
+    if (vec8 && kg * 8 + 8 <= k_src && j < n_src) {
+      // transposed source: the slot's eight k values are contiguous -- two 16-byte loads instead of eight scalar ones whose
+      // lanes sit a whole row apart
+      const float* sp = src + (size_t)kg * 8 + (size_t)j * ld_j;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int k = kg * 8 + q;
-      x[q] = (k < k_src && j < n_src) ? src[(size_t)k * ld_k + (size_t)j * ld_j] * s : 0.f;
+      for (int q = 0; q < 4; ++q) { x[q] = a[q] * s; x[4 + q] = b[q] * s; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = kg * 8 + q;
+        x[q] = (k < k_src && j < n_src) ? src[(size_t)k * ld_k + (size_t)j * ld_j] * s : 0.f;
+      }
     }
     u32x4 hi, lo;
     h2_split8(x, hi, lo);

@@ -42,15 +42,29 @@ __global__ void pack_weights_kernel(PackList L) {
                    (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
     return;
   }
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    if (q.fmt == 0) {
-      const int e = i & 3;
-      const size_t t = i >> 2;
-      const int j = t % q.Nout;
+  if (q.fmt == 0) {
+    // one thread per group of four consecutive k of a column: one 16-byte store (and, for a transposed source, one 16-byte load)
+    const bool vec4 = q.ld_k == 1 && (q.ld_j & 3) == 0 && (reinterpret_cast<uintptr_t>(q.src) & 15) == 0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total / 4; t += (size_t)gridDim.x * blockDim.x) {
+      const int j = (int)(t % q.Nout);
       const size_t qg = t / q.Nout;
-      const int k = 16 * (int)(qg >> 2) + 4 * (int)(qg & 3) + e;
-      q.dst[i] = (k < q.k_src && j < q.n_src) ? q.src[(size_t)k * q.ld_k + (size_t)j * q.ld_j] : 0.f;
-    } else {
+      const int k0 = 16 * (int)(qg >> 2) + 4 * (int)(qg & 3);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (j < q.n_src) {
+        if (vec4 && k0 + 4 <= q.k_src) {
+          v = *reinterpret_cast<const f32x4*>(q.src + (size_t)k0 + (size_t)j * q.ld_j);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + e < q.k_src) v[e] = q.src[(size_t)(k0 + e) * q.ld_k + (size_t)j * q.ld_j];
+        }
+      }
+      reinterpret_cast<f32x4*>(q.dst)[t] = v;
+    }
+    return;
+  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    {
       const int kk = i & 31;
       const size_t t = i >> 5;
       const int j = t % q.Nout;
@@ -650,6 +664,14 @@ __global__ __launch_bounds__(KA_THREADS) void kb_attend_kernel(KbAttP p) {
   __shared__ f32x4 s_acc[NRG][32];
   const int b = blockIdx.x, slab = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the knowledge-base rows of the summary pass do not depend on the softmax: the first KA_PRE of this thread's rows are
+  // requested now and arrive while the three reductions below run (N <= 256: all of them)
+  constexpr int KA_PRE = 8;
+  const int rg = tid >> 5, c4 = tid & 31;
+  const float* kb = p.kb + (size_t)b * p.N * p.d + slab * 128 + c4 * 4;
+  f32x4 pv[KA_PRE];
+#pragma unroll
+  for (int i = 0; i < KA_PRE; ++i) pv[i] = *reinterpret_cast<const f32x4*>(kb + (size_t)min(rg + i * NRG, p.N - 1) * p.d);
   float m = -INFINITY;
   for (int n = tid; n < p.N; n += KA_THREADS) {
     float l = p.bias[0];
@@ -682,11 +704,14 @@ __global__ __launch_bounds__(KA_THREADS) void kb_attend_kernel(KbAttP p) {
     if (slab == 0) p.att[(size_t)b * p.N + n] = a;
   }
   __syncthreads();
-  // summary: NRG row groups x 32 float4 columns
-  const int rg = tid >> 5, c4 = tid & 31;
-  const float* kb = p.kb + (size_t)b * p.N * p.d + slab * 128 + c4 * 4;
+  // summary: NRG row groups x 32 float4 columns (ascending rows per thread)
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int n = rg; n < p.N; n += NRG) {
+#pragma unroll
+  for (int i = 0; i < KA_PRE; ++i) {
+    const int n = rg + i * NRG;
+    if (n < p.N) acc += pv[i] * s_att[n];
+  }
+  for (int n = rg + KA_PRE * NRG; n < p.N; n += NRG) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(kb + (size_t)n * p.d);
     const float a = s_att[n];
     acc += v * a;
