@@ -185,8 +185,10 @@ def fwd_only_p4(macx, dev, seed, p=4, steps=30):
     units = 4 + 3 * (p - 1)            # knowledge-base products executed: step 0 all four, later steps reuse X
     executed = 3.0 * units * 2.0 * B * N * D * D
     return {"value": round(B / dt, 1), "unit": "questions/s", "ms_per_batch": round(dt * 1e3, 3), "steps": steps, "p": p, "batch": B,
-            "launch": "one captured HIP graph per batch (inputs copied in); eager ctypes launches: %.3f ms per batch = %.0f questions/s"
-                      % (dt_eager * 1e3, B / dt_eager),
+            "launch": ("one captured HIP graph per batch (inputs copied in)" if cap.captured else
+                       "EAGER launches: this process's graph replays failed CapturedForward's self-check (mac-network_amd/graph.py)")
+                      + "; eager ctypes launches: %.3f ms per batch = %.0f questions/s" % (dt_eager * 1e3, B / dt_eager),
+            "graph_replay": bool(cap.captured),
             "hoist": "evaluation has no read dropout, so the projected knowledge base X = KB Wx + bx is step-invariant: step 0 "
                      "computes it, steps 1..p-1 read it back (the reference's graph recomputes it per step, ops.py:688)",
             "reference_flops_per_question": p * flops_per_question_step(),

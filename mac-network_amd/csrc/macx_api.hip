@@ -212,7 +212,7 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.bits_stride = keep ? bits_floats : 0;
   L.kb_bits = take(pk * bits_floats);
   L.att_bits = take(pk * bits_floats);
-  L.wmax = take(8);
+  L.wmax = take(8 + 4 * 64);          // the four maxima (+ 4 spare), then absmax4's per-workgroup partials
   L.qmin_stride = keep ? B * (d / 128) : 0;
   L.qmin_X = take(3 * pk * B * (d / 128));
   L.qmin_H1 = L.qmin_X + pk * B * (d / 128);
@@ -499,15 +499,18 @@ hipError_t h2_from_f32(const H2FromP& f, hipStream_t st) {
   hipLaunchKernelGGL(h2_from_f32_kernel, dim3(f.B * nrb, f.C / 128), dim3(H2C_THREADS), H2C_LDS, st, f);
   return hipGetLastError();
 }
+// out[0..3] = max |.| of four tensors; part: 4 * ABSMAX_BLOCKS floats of scratch, or null (one workgroup per tensor: slower)
+constexpr int ABSMAX_BLOCKS = 64;
 hipError_t absmax4(const float* a, size_t na, const float* b, size_t nb, const float* c, size_t nc, const float* d_, size_t nd,
-                   float* out, hipStream_t st) {
+                   float* out, float* part, hipStream_t st) {
   AbsMaxList L;
   memset(&L, 0, sizeof(L));
   L.src[0] = a; L.n[0] = na; L.src[1] = b; L.n[1] = nb; L.src[2] = c; L.n[2] = nc; L.src[3] = d_; L.n[3] = nd;
-  L.out = out;
-  hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(float), st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(absmax_kernel, dim3(64, 4), dim3(256), 0, st, L);
+  L.out = out; L.part = part;
+  hipLaunchKernelGGL(absmax_kernel, dim3(part ? ABSMAX_BLOCKS : 1, 4), dim3(256), 0, st, L);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !part) return e;
+  hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)part, ABSMAX_BLOCKS, out);
   return hipGetLastError();
 }
 
@@ -643,7 +646,8 @@ int pack_forward_weights(const macx_opts* o, const macx_shapes* s, const macx_pa
     if (h2_mode() && (units & U_READ)) {
       // per-matrix maxima -> weight exponents (plain weights) and the bound of the question-mixed tile (W1a, W1b)
       const size_t dd_ = (size_t)d * d;
-      CK(absmax4(P->projX_W, dd_, P->memKbProj2_W, dd_, P->memKbProj_W, dd_, P->memKbProj_W + dd_, dd_, saved + L.wmax, st));
+      CK(absmax4(P->projX_W, dd_, P->memKbProj2_W, dd_, P->memKbProj_W, dd_, P->memKbProj_W + dd_, dd_, saved + L.wmax,
+                 saved + L.wmax + 8, st));
       // minimum-exponent arrays are filled with atomicMin by the producers of X / H1 / KBd
       CK(hipMemsetAsync(saved + L.qmin_X, 0x7F, 3 * (size_t)(keep ? p : 1) * B * (d / 128) * sizeof(int), st));
     }
@@ -2504,7 +2508,7 @@ int macx_h2_pack_weight(const float* Wm, int K, int n_out, int transpose, float*
   if (!Wm || !out || K < 128 || K % 128 || n_out < 128 || n_out % 128 || misaligned(Wm) || misaligned(out)) return MACX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   float* wmax = out + al4((size_t)K * n_out + 4);
-  CK(absmax4(Wm, (size_t)K * n_out, Wm, 1, Wm, 1, Wm, 1, wmax, st));
+  CK(absmax4(Wm, (size_t)K * n_out, Wm, 1, Wm, 1, Wm, 1, wmax, nullptr, st));
   Packer pk;
   if (transpose) pk.add(Wm, 1, K, K, n_out, out, -1, -1, 3, wmax);
   else pk.add(Wm, n_out, 1, K, n_out, out, -1, -1, 3, wmax);

@@ -316,10 +316,12 @@ __global__ void h2_min_exp_kernel(const char* base, size_t stride_bytes, int nt,
 }
 
 // ---- weights -------------------------------------------------------------------------------------------------
-// max |W| of up to 8 matrices in one launch: blockIdx.y selects the matrix, gridDim.x workgroups share it and combine with an
-// integer atomicMax on the bit pattern (non-negative floats order like their bit patterns: order-independent, deterministic;
-// NaN entries are skipped by fmaxf).  out[] must be zeroed by the caller.
-struct AbsMaxList { const float* src[8]; size_t n[8]; float* out; };
+// max |W| of up to 8 matrices: blockIdx.y selects the matrix, gridDim.x workgroups share it.  With more than one workgroup per
+// matrix each writes its partial maximum and absmax_finish_kernel combines them -- plain stores all the way: the earlier form
+// (a 16-byte memset + an integer atomicMax per workgroup) made the exponent of every packed weight depend on the memset having
+// landed before the first atomic, and replayed HIP graphs were seen to give finite but 1e-2-wrong runs in a fraction of the
+// processes (mac-network_amd/graph.py).  NaN entries are skipped by fmaxf.
+struct AbsMaxList { const float* src[8]; size_t n[8]; float* out; float* part; };   // part: [8][gridDim.x], or null when gridDim.x == 1
 __global__ __launch_bounds__(256) void absmax_kernel(AbsMaxList L) {
   __shared__ float red[4];
   const float* s = L.src[blockIdx.y];
@@ -331,8 +333,17 @@ __global__ __launch_bounds__(256) void absmax_kernel(AbsMaxList L) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const float t = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    atomicMax(reinterpret_cast<int*>(L.out) + blockIdx.y, __float_as_int(t));
+    if (gridDim.x == 1) L.out[blockIdx.y] = t;
+    else L.part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
   }
+}
+// out[mat] = max over part[mat][0..nblk): one wave per matrix (blockDim = 64 * nmat <= 512)
+__global__ void absmax_finish_kernel(const float* __restrict__ part, int nblk, float* out) {
+  const int mat = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float m = 0.f;
+  for (int i = lane; i < nblk; i += 64) m = fmaxf(m, part[(size_t)mat * nblk + i]);
+  m = wave_max(m);
+  if (lane == 0) out[mat] = m;
 }
 // pack format 3: W (or W^T) as H2 weight planes  dst[kt][plane][g][Nout] x 16 B  (8 consecutive k of one column),
 // scaled by the per-matrix exponent derived from *maxabs; the exponent is stored as an int after the planes.

@@ -12,7 +12,18 @@ tensors and replays it per batch.
 
 Evaluation only (no dropout, nothing kept for a backward pass); parameters are read at replay time, so an optimizer step or
 a checkpoint load between calls is seen.  Changing a parameter's storage (`.to()`, `.data = `) needs a new capture.
+
+A capture checks itself before it is used (`verify=True`): three replays on random inputs must reproduce the eager run bit
+for bit; a process whose replays do not falls back to eager launches (`captured` is False, a warning says so): slower where
+the host is slow, never wrong.  The check exists because of a bug it would have caught: until the end of round 3 the
+per-matrix maximum behind every packed weight's exponent was a 16-byte memset followed by integer atomicMax, and in about
+one process in ten (one in three for the smallest shapes) the replayed graph ran the two out of order from its second
+replay on -- maximum 0, exponent 0, weights split at the wrong scale, results finite and 1e-2 off, deterministically for
+that process, while eager launches of the same kernels stayed bit-identical.  `absmax4` now writes per-workgroup partials
+and a second kernel combines them (no memset, no atomics); tools/graph_replay_probe.py is the probe that found it.
 """
+import warnings
+
 import torch
 
 from .cell import MACCell
@@ -20,7 +31,7 @@ from .options import get
 
 
 class CapturedForward:
-    def __init__(self, config, params, B, S, N, device=None, netLength=None, warmup=2):
+    def __init__(self, config, params, B, S, N, device=None, netLength=None, warmup=2, verify=True):
         dev = torch.device(device) if device is not None else params.tensors()[0].device
         if dev.type != "cuda":
             raise RuntimeError("CapturedForward needs the HIP device: the MAC cell has no CPU path")
@@ -44,6 +55,26 @@ class CapturedForward:
             state = self.cell.run()
             self.memory, self.control = state.memory, state.control
         self.attentions = self.cell.attentions
+        self.captured = True
+        if verify and not self._replays_match_eager():
+            self.captured = False
+            warnings.warn("CapturedForward: replays of the captured run do not reproduce the eager run in this process; "
+                          "falling back to eager launches", RuntimeWarning)
+
+    def _replays_match_eager(self, replays=3):
+        g = torch.Generator().manual_seed(20240519)
+        dev = self.knowledgeBase.device
+        self.vecQuestions.copy_(torch.randn(self.vecQuestions.shape, generator=g).to(dev))
+        self.words.copy_(torch.randn(self.words.shape, generator=g).to(dev))
+        self.knowledgeBase.copy_(torch.randn(self.knowledgeBase.shape, generator=g).to(dev))
+        with torch.no_grad():
+            want = self._cell().run().memory.clone()
+        ok = True
+        for _ in range(replays):
+            self.graph.replay()
+            ok = ok and bool(torch.equal(self.memory, want))
+        torch.cuda.synchronize(dev)
+        return ok
 
     def _cell(self):
         return MACCell(vecQuestions=self.vecQuestions, questionWords=self.words, questionCntxWords=self.words,
@@ -59,7 +90,14 @@ class CapturedForward:
         self.knowledgeBase.copy_(knowledgeBase)
 
     def replay(self):
-        self.graph.replay()
+        if self.captured:
+            self.graph.replay()
+        else:                                    # (see the module docstring)
+            with torch.no_grad():
+                self.cell = self._cell()
+                state = self.cell.run()
+            self.memory, self.control = state.memory, state.control
+            self.attentions = self.cell.attentions
         return self.memory
 
     def __call__(self, vecQuestions, words, lengths, knowledgeBase):
