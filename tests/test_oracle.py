@@ -241,3 +241,20 @@ def test_question_encoder_restatement_matches_torch_lstm():
     out, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=5)
     assert (out - w).abs().max() < 1e-12 and (torch.cat([hn[0], hn[1]], 1) - v).abs().max() < 1e-12
     assert float(w[0, 3:].abs().max()) == 0.0 and float(w[2, 1:].abs().max()) == 0.0
+
+
+def test_prelu_boundary_modes_take_the_two_one_sided_derivatives():
+    """relu_boundary(mode): PReLU = relu(x) - alpha relu(-x) takes derivative alpha (mode 0) or 1 (mode 1) at the jump and the
+    usual one-sided derivatives away from it; with no boundary mode it is torch's (derivative of relu at 0 = 0 on both terms)."""
+    from helpers import relu_boundary
+    cfg = mo.default_config(relu="PRM")
+    x0 = torch.tensor([[-2.0, 0.0, 1e-9, 3.0]], dtype=torch.float64)
+    for mode, at_jump in ((0, 0.25), (1, 1.0)):
+        vs = mo.VarStore(generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+        ops = mo.Ops(cfg, vs)
+        x = x0.clone().requires_grad_(True)
+        with relu_boundary(mode, 1e-6):
+            y = ops.relu(x)
+        y.sum().backward()
+        assert torch.allclose(x.grad, torch.tensor([[0.25, at_jump, at_jump, 1.0]], dtype=torch.float64))
+        assert torch.allclose(y.detach(), torch.tensor([[-0.5, 0.0, 1e-9, 3.0]], dtype=torch.float64))
