@@ -356,6 +356,8 @@ def main():
         L.macx_gemm_mode({"native": 0, "split": 1, "h2": 2}[os.environ["MACX_GEMM"]])
     if os.environ.get("MACX_CHAIN"):        # A/B only: 0 = the read unit's forward products as four launches
         L.macx_debug_set(4, int(os.environ["MACX_CHAIN"]))
+    if os.environ.get("MACX_CHAIN_KV"):     # A/B only: K-loop variant of the chain kernels
+        L.macx_debug_set(7, int(os.environ["MACX_CHAIN_KV"]))
     if os.environ.get("MACX_SB_DEFER"):     # A/B only: 0 = sb_h2 once per step
         L.macx_debug_set(5, int(os.environ["MACX_SB_DEFER"]))
     if os.environ.get("MACX_OVERLAP"):      # A/B only: 0 = no side queue

@@ -63,6 +63,12 @@ inline int& sb_defer_mode() { static int m = 1; return m; }
 // caller everything is still ordered on `stream`.  MEASURED, same box: 4.44-4.47 ms per step with the side queue (lowest,
 // middle or highest priority alike) against 4.11 ms without -- the per-step dKB launches (read-modify-write of the gradient,
 // twelve ramps) cost more than the all-steps launch and hide nothing.  Off by default; macx_debug_set(6, 1..3) turns it on.
+// Mode 4 (round 4) is a different use of the same queue: the chain kernels occupy 196 of the chip's 256 CUs (one 64-row tile
+// per workgroup, one workgroup per CU), so a RIGHT-SIZED grid -- 56 workgroups, seven per XCD next to the chain kernel's 24-25 --
+// runs beside them on CUs that would idle: the dW2 = sum_i H1_i^T dI2_i contraction of step i (its operands are complete when
+// chain_bwd of step i ends) is launched there while the caller's stream goes on with step i - 1, accumulating into one set of
+// slabs; phase 2 then has one all-steps weight-gradient launch less.  (Modes 1-3 failed because a 244-workgroup launch does
+// not run BESIDE a chain kernel but in front of it: every CU holds one workgroup of either.)
 inline int& overlap_mode() { static int m = 0; return m; }
 struct SideQueue { hipStream_t s; hipEvent_t fork, join; };
 inline SideQueue* side_queue() {
@@ -301,6 +307,8 @@ struct BwdLayout {
   size_t qmin_dI2, qmin_dI1, qmin_dX;   // h2: [p][B][d/128] ints
   size_t ecom;                       // h2: 4 x [d/128] ints, common exponents of H1 / dI2 / KBd / dX over all steps
   size_t wg_ftab;                    // h2: [d/128][d/128][Mpad] fp16 row factors of the deferred weight-gradient contractions
+  // per-step dW2 on the side queue (overlap mode 4): common exponents [p][2][8], row factors [p][d/128][d/128][Mpad(B N)], splits
+  size_t ecom_s, ftab_s, ftab_s_stride, side_ns;
   size_t total;
 };
 
@@ -371,6 +379,16 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.qmin_dX = L.qmin_dI1 + p * B * (d / 128);
   L.ecom = take(4 * 8);
   L.wg_ftab = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
+  L.ecom_s = take(p * 16);
+  L.ftab_s_stride = h2_mode() ? al4((d / 128) * (d / 128) * wgrad_h2_mpad(B * N) / 2 + 4) : 4;
+  L.ftab_s = take(p * L.ftab_s_stride);
+  {
+    // workgroups the chain kernel leaves free, a multiple of 8 (one XCD takes block b % 8): splits = free / output tiles
+    const size_t tiles = chain_supported((int)d, (int)N) ? chain_tiles((int)d, B * N) : 256;
+    const size_t free_wg = tiles < 256 ? ((256 - tiles) / 8) * 8 : 0;
+    L.side_ns = h2_mode() ? free_wg / wgrad_h2_tiles((int)d, (int)d) : 0;
+    if (L.side_ns > L.ns_big) L.side_ns = L.ns_big;
+  }
   L.total = off;
   return L;
 }
@@ -1010,6 +1028,12 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const int nrb = nrb_of(N, B, d);
   const bool rdrop = dp->keep_read < 1.0f;
 
+  SideQueue* sq_any = ((units & U_READ) && h2_mode()) ? side_queue() : nullptr;
+  SideQueue* sq = (sq_any && overlap_mode() != 4) ? sq_any : nullptr;                     // modes 1-3: dKB of a step
+  // mode 4: dW2 of a step beside the chain kernels (only where there is room beside them and every step is kept)
+  const bool w2_side = sq_any && overlap_mode() == 4 && units == U_ALL && use_chain(d, N) && W.side_ns >= 1;
+  SideQueue* sq_w2 = (w2_side && phase != 2) ? sq_any : nullptr;
+
   if (phase != 2) {
   // ---- weights in the layouts the backward kernels read
   const int nU = o->control_input_unshared ? p : 1;
@@ -1064,7 +1088,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const float* infos = saved + L.seg[MACX_SEG_INFOS];
   const float* att_kb = saved + L.seg[MACX_SEG_ATT_KB];
 
-  SideQueue* sq = ((units & U_READ) && h2_mode()) ? side_queue() : nullptr;
   // the recurrent control unit differentiates through dL/dc_i inside iteration i; otherwise every step's dc / db_k partials are
   // reduced in one launch after the loop
   const bool dc_in_loop = (units & U_CONTROL) && o->control_feed_prev;
@@ -1202,6 +1225,28 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         c.dX = hdX; c.qmin_dX = q_dX; c.dbx_part = ws + W.dbx_part + (size_t)i * W.db_rows * d;
         if (W.sb_deferred) { c.X = hX; c.dy_part = ws + W.dyc_part; }
         CK(chain_bwd_launch(c, st));
+        if (sq_w2) {
+          // dW2 += H1_i^T dI2_i on the side queue (macx_wgrad_h2.hip.h), its own common exponents and row factors per step
+          hipStream_t s2 = sq_w2->s;
+          CK(hipEventRecord(sq_w2->fork, st));
+          CK(hipStreamWaitEvent(s2, sq_w2->fork, 0));
+          int* ecs = reinterpret_cast<int*>(ws + W.ecom_s) + (size_t)i * 16;
+          QminList ql;
+          memset(&ql, 0, sizeof(ql));
+          ql.q[0] = reinterpret_cast<const int*>(saved + L.qmin_H1) + (size_t)i * L.qmin_stride; ql.n[0] = B; ql.out[0] = ecs;
+          ql.q[1] = q_dI2; ql.n[1] = B; ql.out[1] = ecs + 8;
+          CK(qmin_reduce_list(ql, 2, CB, s2));
+          TnH2P t;
+          memset(&t, 0, sizeof(t));
+          t.M = R; t.Kd = d; t.Jd = d; t.nsplit = (int)W.side_ns; t.rows_per_split = rows_per_split(t.M, t.nsplit);
+          t.R = R;
+          t.A = reinterpret_cast<const char*>(H1); t.G = reinterpret_cast<const char*>(dI2_i);
+          t.ecomA = ecs; t.ecomG = ecs + 8;
+          t.ftab = reinterpret_cast<uint16_t*>(ws + W.ftab_s + (size_t)i * W.ftab_s_stride);
+          t.part = ws + W.slab_w2;
+          t.accumulate = (i != p - 1);
+          CK(wgrad_h2_launch(t, s2));
+        }
         if (W.chain_sums && (dc_in_loop || (W.sb_deferred && !W.dy_in_linear))) {
           // the per-tile partials of this step: dL/dc_i += read-unit part, db_k partials, dy_i (the next launch needs dy_i)
           DcReduceP q;
@@ -1410,9 +1455,9 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, p), dim3(128), 0, st, q);
     CK(hipGetLastError());
   }
-  if (sq) {                        // join: everything the side queue was given is ordered before what follows on `stream`
-    CK(hipEventRecord(sq->join, sq->s));
-    CK(hipStreamWaitEvent(st, sq->join, 0));
+  if (sq || sq_w2) {               // join: everything the side queue was given is ordered before what follows on `stream`
+    CK(hipEventRecord(sq_any->join, sq_any->s));
+    CK(hipStreamWaitEvent(st, sq_any->join, 0));
   }
   if (units == U_ALL) {
   if (o->write_self_att && !o->write_self_att_cont && !o->control_feed_prev) {
@@ -1580,7 +1625,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     t.ftab = reinterpret_cast<uint16_t*>(ws + W.wg_ftab);
     t.dbg = kb_gemm_dbg();
     t.part = ws + W.slab_w2;
-    CK(wgrad_h2_launch(t, st));
+    if (!w2_side) CK(wgrad_h2_launch(t, st));
     t.A = reinterpret_cast<const char*>(saved + L.KBd);
     t.a_mod = rdrop ? 0 : B * N;                              // no dropout: the same (converted) KB every step
     t.G = reinterpret_cast<const char*>(ws + W.dX);
@@ -1621,7 +1666,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const int nslab1 = (int)((h2_mode() && W.sb_deferred ? 1 : p) * W.ngroup);
   {
     SlabList sl;
-    sl.d[0] = SlabDesc{ws + W.slab_w2, (int)W.ns_big, dd / 4, GP->memKbProj2_W, 0};
+    sl.d[0] = SlabDesc{ws + W.slab_w2, (int)((h2_mode() && w2_side) ? W.side_ns : W.ns_big), dd / 4, GP->memKbProj2_W, 0};
     sl.d[1] = SlabDesc{ws + W.slab_wx, (int)W.ns_big, dd / 4, GP->projX_W, 0};
     sl.d[2] = SlabDesc{ws + W.slab_w1a, nslab1, dd / 4, GP->memKbProj_W, 0};
     sl.d[3] = SlabDesc{ws + W.slab_w1b, nslab1, dd / 4, GP->memKbProj_W + dd, 0};
@@ -2581,7 +2626,8 @@ int macx_debug_set(int key, int value) {
   if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
   if (key == 4 && (value == 0 || value == 1)) { chain_mode() = value; return MACX_OK; }
   if (key == 5 && (value == 0 || value == 1)) { sb_defer_mode() = value; return MACX_OK; }
-  if (key == 6 && value >= 0 && value <= 3) { overlap_mode() = value; return MACX_OK; }
+  if (key == 6 && value >= 0 && value <= 4) { overlap_mode() = value; return MACX_OK; }
+  if (key == 7 && value >= -1 && value <= 63) { chain_kv() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

@@ -85,18 +85,28 @@ __device__ __forceinline__ float chain_act(int act, float x) {
 // metric's 64 questions): a launch lasts as long as ONE tile takes, so with 25 tiles of 64 rows on 256 CUs the kernel ran as
 // long as with 196 -- shorter tiles put the rows on more CUs (the weights then stream from L2 once per 16 or 32 rows instead
 // of once per 64: the K loop turns L2-bound, at about half its time).
-template <int D_, int R_ = 64>
+template <int D_, int R_ = 64, int MF_ = 0>
 struct ChainGeo {
   static constexpr int D = D_, R = R_, KG = D / 8, CB = D / 128, KS = D / 32;
+  // MF: the matrix instruction.  0: v_mfma_f32_16x16x32_f16 (16 accumulator tiles of 16 x 16 per wave at d = 512); 1:
+  // v_mfma_f32_32x32x16_f16 (4 tiles of 32 x 32, two instructions per 32-wide K slice) -- the 32 x 32 form issues at the
+  // pipe's full rate (MI355X_MICROARCH.md: 32 cycles per 32768 FLOP against ~19.5 per 16384 measured for 16x16x32).
+  static constexpr int MF = MF_;
+  static constexpr int TM = MF ? 32 : 16;            // edge of the instruction's output tile
   static constexpr int NWC = D >= 512 ? 8 : 4;       // waves along the columns
   static constexpr int NWR = 8 / NWC;                // waves along the rows
-  static constexpr int CT = D / (16 * NWC);          // 16-column tiles per wave
-  static constexpr int RT = R / (16 * NWR);          // 16-row tiles per wave
+  static constexpr int CW = D / NWC;                 // columns per wave
+  static constexpr int RPW = R / NWR;                // rows per wave
+  static constexpr int RT = RPW / TM;                // row tiles per wave
+  // accumulators are addressed as f32x4 acc[RT][CT]: four consecutive columns of one row per entry.  16 x 16: one entry per
+  // 16-column tile; 32 x 32: the instruction leaves a lane four such groups per tile (columns 8 b + 4 (lane >> 5) .. + 3)
+  static constexpr int CT = MF ? CW / 8 : CW / 16;
   static constexpr int NRG = R / 16;                 // 16-row groups of the tile
   static constexpr int WPG = 8 / NRG;                // conversion passes: waves that share a row group
   static constexpr int IT = KG / (4 * WPG);          // ... slot columns per lane (16 rows x 4 slot columns per wave step)
   static constexpr int SB = R / 8;                   // backward stage B0: 8-row blocks per lane
   static_assert(R == 64 || ((R == 32 || R == 16) && NWR == 1), "short tiles: every wave holds all rows (d = 512)");
+  static_assert(!MF || (RPW % 32 == 0 && CW % 32 == 0 && RT * (CW / 32) >= 4), "32 x 32 tiles: at least four independent accumulators per wave");
   static constexpr size_t P_BYTES = (size_t)4 * R * D;
   static constexpr int QS = 5;                       // backward: questions a tile can touch (N >= 16) -- their control vectors are staged in LDS
   static constexpr int BITS_LD = KG + 4;             // bytes per row of sBits (+4: rows 4 apart would share a bank)
@@ -107,11 +117,11 @@ struct ChainGeo {
 };
 
 // what both kernels share: the tile in LDS, who owns what, the K loop, the row-exponent bookkeeping, the H2 emitters
-template <int D_, int R_ = 64>
+template <int D_, int R_ = 64, int MF_ = 0>
 struct ChainCtx {
-  using G = ChainGeo<D_, R_>;
+  using G = ChainGeo<D_, R_, MF_>;
   static constexpr int D = G::D, R = G::R, KG = G::KG, CB = G::CB, KS = G::KS, NWC = G::NWC, NWR = G::NWR, CT = G::CT, RT = G::RT, IT = G::IT,
-                       WPG = G::WPG, SB = G::SB;
+                       WPG = G::WPG, SB = G::SB, MF = G::MF, TM = G::TM, CW = G::CW, RPW = G::RPW;
   char* P;          // [2 planes][KG][R] x 16 B: the stage's activation operand
   float* sMax;      // [8][R] partial row maxima
   float* sPart;     // [8][R] partial row sums (attention logits)
@@ -122,6 +132,7 @@ struct ChainCtx {
   float* sC;        // [QS][D] backward: control vectors of the tile's questions
   uint8_t* sBits;   // [R][BITS_LD] forward: keep bits of the attention dropout (ops.py:312), one byte per 8 columns
   int tid, lane, wave, li, lg;
+  int ar, ah;       // accumulator geometry: this lane's row within an output tile, and which group of four columns it holds
   int wr, wc, colbase, rowbase;
   int M, N, nvalid;
   size_t grow0;
@@ -140,8 +151,9 @@ struct ChainCtx {
     tid = threadIdx.x; lane = tid & 63;
     wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     li = lane & 15; lg = lane >> 4;
+    ar = MF ? (lane & 31) : li; ah = MF ? (lane >> 5) : lg;
     wr = wave / NWC; wc = wave % NWC;
-    colbase = wc * 16 * CT; rowbase = wr * 16 * RT;
+    colbase = wc * CW; rowbase = wr * RPW;
     M = M_; N = N_;
     grow0 = (size_t)blockIdx.x * R;
     nvalid = (int)min((size_t)R, (size_t)M - grow0);
@@ -158,7 +170,7 @@ struct ChainCtx {
     return h2_exponent(m);
   }
   // exponent of a row after an accumulator epilogue (partial maxima from the NWC waves of its row half) / a conversion pass
-  __device__ __forceinline__ int row_exponent_epi(int row) const { return row_exponent(row, (row / (16 * RT)) * NWC, NWC); }
+  __device__ __forceinline__ int row_exponent_epi(int row) const { return row_exponent(row, (row / RPW) * NWC, NWC); }
   __device__ __forceinline__ int row_exponent_conv(int row) const { return row_exponent(row, (row >> 4) * WPG, WPG); }
   __device__ __forceinline__ int row_exponent_blk(int row) const { return row_exponent(row, 0, KG / 8); }
   enum { PASS_CONV = 0, PASS_EPI = 1, PASS_BLK = 2 };
@@ -298,25 +310,39 @@ struct ChainCtx {
   }
 
   // ---- the K loop of one product: acc[T][c] += W^T-slot x A-slot over all d (three fp16 terms, smallest first).
-  // KV: measurement variants (0 = the product): 1 no MFMA (the loads stay), 2 no weight loads inside the loop, 3 no loads
-  // at all inside the loop -- timing only, results are wrong
+  // KV is a bit mask.  KV & 3: measurement variants (0 = the product): 1 no MFMA (the loads stay), 2 no weight loads inside the
+  // loop, 3 no loads at all inside the loop -- timing only, results are wrong.  KV & 4: the activation fragments of the next
+  // slice are requested in the MIDDLE of the current slice's products instead of in front of them (their s_waitcnt
+  // lgkmcnt(0) then finds them long complete; requested in front, the wait sits between the request and the first
+  // product).  KV & 8: static priority for the second-dispatched half of the workgroup (chain kernels set it once, at entry).
+  // KV & 16: the 32 x 32 x 16 instruction (MF, a property of the context).
   template <int KV>
   __device__ __forceinline__ void kloop(f32x4 (&acc)[RT][CT], const char* W) const {
+    if constexpr (MF) kloop32<KV>(acc, W);
+    else kloop16<KV>(acc, W);
+  }
+  template <int KV>
+  __device__ __forceinline__ void kloop16(f32x4 (&acc)[RT][CT], const char* W) const {
+    constexpr int KM = KV & 3;
+    constexpr bool MID = (KV & 4) != 0 && RT >= 2;
     const char* wb = W + ((size_t)lg * D + colbase + li) * 16;
     const char* pa = P + ((size_t)lg * R + rowbase + li) * 16;
     // both operands of slice kt + 1 are requested before slice kt is multiplied: the weight slots from L2 (about one slice of
     // matrix work away), the activation slots from LDS
     u32x4 bq[2][2][CT], aq[2][2][RT];        // [set][plane][tile]
-    auto load_ab = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
+    auto load_b = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
       constexpr int S = decltype(set_c)::value;
-      if (!(KV >= 2 && in_loop)) {
+      if (!(KM >= 2 && in_loop)) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
           for (int c = 0; c < CT; ++c)
             bq[S][pl][c] = *reinterpret_cast<const u32x4*>(wb + ((size_t)(kt * 2 + pl) * 4 * D) * 16 + c * 256);
       }
-      if (!(KV >= 3 && in_loop)) {
+    };
+    auto load_a = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
+      if (!(KM >= 3 && in_loop)) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
@@ -324,9 +350,9 @@ struct ChainCtx {
             aq[S][pl][t] = *reinterpret_cast<const u32x4*>(pa + ((size_t)(pl * KG + 4 * kt) * R + 16 * t) * 16);
       }
     };
-    auto mm = [&](auto set_c) __attribute__((always_inline)) {
+    auto mm = [&](auto set_c, int t0, int t1) __attribute__((always_inline)) {
       constexpr int S = decltype(set_c)::value;
-      if (KV == 1) {
+      if (KM == 1) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -336,8 +362,23 @@ struct ChainCtx {
         }
         return;
       }
+      if (KV & 32) {      // term-major: every accumulator of the range once per term (16 instead of 4 instructions between two on the same one)
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
+        for (int t = t0; t < t1; ++t)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][0][c], aq[S][1][t], acc[t][c]);
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][1][c], aq[S][0][t], acc[t][c]);
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][0][c], aq[S][0][t], acc[t][c]);
+        return;
+      }
+#pragma unroll
+      for (int t = t0; t < t1; ++t) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][0][c], aq[S][1][t], acc[t][c]);     // w_hi a_lo
 #pragma unroll
@@ -350,19 +391,134 @@ struct ChainCtx {
     using S1 = std::integral_constant<int, 1>;
     // the scheduler would sink a slice's loads to the end of the previous slice's products (shortest live range), i.e. to where
     // they are needed: the order "request slice kt + 1, multiply slice kt" is pinned
-    load_ab(S0{}, 0, false);
-    if (KV >= 2) load_ab(S1{}, 1, false);
+    load_b(S0{}, 0, false); load_a(S0{}, 0, false);
+    if (KM >= 2) { load_b(S1{}, 1, false); load_a(S1{}, 1, false); }
+    auto half_step = [&](auto cur, auto nxt, int kn) __attribute__((always_inline)) {
+      load_b(nxt, kn, true);
+      if (!MID) load_a(nxt, kn, true);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MID) {
+        mm(cur, 0, RT / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(nxt, kn, true);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(cur, RT / 2, RT);
+      } else {
+        mm(cur, 0, RT);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
 #pragma unroll 1
     for (int kt = 0; kt < KS; kt += 2) {
-      load_ab(S1{}, kt + 1, true);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(S0{});
-      __builtin_amdgcn_sched_barrier(0);
-      load_ab(S0{}, min(kt + 2, KS - 2), true);    // (unconditional: behind a branch the wait-count pass drains every load at the join)
-      __builtin_amdgcn_sched_barrier(0);
-      mm(S1{});
-      __builtin_amdgcn_sched_barrier(0);
+      half_step(S0{}, S1{}, kt + 1);
+      half_step(S1{}, S0{}, min(kt + 2, KS - 2));   // (unconditional: behind a branch the wait-count pass drains every load at the join)
     }
+  }
+  // the same product on v_mfma_f32_32x32x16_f16: a wave's RPW x CW block is RT x CW/32 tiles of 32 x 32, a 32-wide K slice is
+  // two instructions per tile and term (k groups 0-1 and 2-3 of the slice; lane = (row or column l & 31, k group l >> 5)).
+  // Same operand swap as the 16 x 16 form (D^T = W^T A^T): lane l ends up with row l & 31 of the tile and the columns
+  // 8 b + 4 (l >> 5) + q, b = 0..3 -- four groups of four consecutive columns, i.e. half a slot each -- which is exactly what
+  // acc[t][4 c32 + b][q] names, so every epilogue is shared with the 16 x 16 form through arow / acol / akg / ahalf.
+  // Every tile is visited once per term and k half: the same accumulator is four instructions (128 cycles) apart.
+  template <int KV>
+  __device__ __forceinline__ void kloop32(f32x4 (&acc)[RT][CT], const char* W) const {
+    constexpr int KM = KV & 3;
+    constexpr bool MID = (KV & 4) != 0;
+    constexpr int C32 = CW / 32;
+    const char* wb = W + ((size_t)ah * D + colbase + ar) * 16;
+    const char* pa = P + ((size_t)ah * R + rowbase + ar) * 16;
+    // (whole-vector shuffles: element-wise inserts into an array of 16-wide vectors are not promoted to registers)
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x16 A[RT][C32];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int c = 0; c < C32; ++c) {
+        const f32x8 lo = __builtin_shufflevector(acc[t][4 * c], acc[t][4 * c + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const f32x8 hi = __builtin_shufflevector(acc[t][4 * c + 2], acc[t][4 * c + 3], 0, 1, 2, 3, 4, 5, 6, 7);
+        A[t][c] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+      }
+    u32x4 bq[2][2][C32][2], aq[2][2][RT][2];        // [set][plane][tile][k half]
+    auto load_b = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
+      if (!(KM >= 2 && in_loop)) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int c = 0; c < C32; ++c)
+              bq[S][pl][c][kk] = *reinterpret_cast<const u32x4*>(wb + ((size_t)((kt * 2 + pl) * 4 + 2 * kk) * D) * 16 + c * 512);
+      }
+    };
+    auto load_a = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
+      if (!(KM >= 3 && in_loop)) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+              aq[S][pl][t][kk] = *reinterpret_cast<const u32x4*>(pa + ((size_t)(pl * KG + 4 * kt + 2 * kk) * R + 32 * t) * 16);
+      }
+    };
+    auto mm = [&](auto set_c, int kk) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
+      if (KM == 1) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int c = 0; c < C32; ++c) asm volatile("" ::"v"(bq[S][pl][c][kk]));
+#pragma unroll
+          for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(aq[S][pl][t][kk]));
+        }
+        return;
+      }
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < C32; ++c) A[t][c] = mfma32_f16(bq[S][0][c][kk], aq[S][1][t][kk], A[t][c]);     // w_hi a_lo
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < C32; ++c) A[t][c] = mfma32_f16(bq[S][1][c][kk], aq[S][0][t][kk], A[t][c]);     // w_lo a_hi
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < C32; ++c) A[t][c] = mfma32_f16(bq[S][0][c][kk], aq[S][0][t][kk], A[t][c]);     // w_hi a_hi
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_b(S0{}, 0, false); load_a(S0{}, 0, false);
+    if (KM >= 2) { load_b(S1{}, 1, false); load_a(S1{}, 1, false); }
+    auto half_step = [&](auto cur, auto nxt, int kn) __attribute__((always_inline)) {
+      load_b(nxt, kn, true);
+      if (!MID) load_a(nxt, kn, true);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(cur, 0);
+      if (MID) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(nxt, kn, true);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mm(cur, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < KS; kt += 2) {
+      half_step(S0{}, S1{}, kt + 1);
+      half_step(S1{}, S0{}, min(kt + 2, KS - 2));
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int c = 0; c < C32; ++c) {
+        acc[t][4 * c + 0] = __builtin_shufflevector(A[t][c], A[t][c], 0, 1, 2, 3);
+        acc[t][4 * c + 1] = __builtin_shufflevector(A[t][c], A[t][c], 4, 5, 6, 7);
+        acc[t][4 * c + 2] = __builtin_shufflevector(A[t][c], A[t][c], 8, 9, 10, 11);
+        acc[t][4 * c + 3] = __builtin_shufflevector(A[t][c], A[t][c], 12, 13, 14, 15);
+      }
   }
   __device__ __forceinline__ void zero_acc(f32x4 (&acc)[RT][CT]) const {
 #pragma unroll
@@ -371,10 +527,29 @@ struct ChainCtx {
       for (int c = 0; c < CT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- accumulator geometry: lane (li, lg) holds, for row tile t and column tile c, row rowbase + 16 t + li and the four
-  //      columns colbase + 16 c + 4 lg .. + 3 in acc[t][c][0..3]
-  __device__ __forceinline__ int arow(int t) const { return rowbase + 16 * t + li; }
-  __device__ __forceinline__ int acol(int c) const { return colbase + 16 * c + 4 * lg; }
+  // ---- accumulator geometry: lane (ar, ah) holds, for row tile t and column group c, row rowbase + TM t + ar and the four
+  //      columns acol(c) .. + 3 in acc[t][c][0..3] (16 x 16: ar = lane & 15, ah = lane >> 4, one group per 16-column tile;
+  //      32 x 32: ar = lane & 31, ah = lane >> 5, four groups per 32-column tile).  A group is half of the slot akg(c).
+  __device__ __forceinline__ int arow(int t) const { return rowbase + TM * t + ar; }
+  __device__ __forceinline__ int acol(int c) const { return colbase + (MF ? 8 * c + 4 * ah : 16 * c + 4 * ah); }
+  __device__ __forceinline__ int akg(int c) const { return (colbase >> 3) + (MF ? c : 2 * c + (ah >> 1)); }
+  __device__ __forceinline__ int ahalf() const { return (MF ? ah : (ah & 1)) * 8; }
+  // reductions over the lanes that hold the same row (different column groups) / the same columns (different rows)
+  __device__ __forceinline__ float rowred_max(float m) const {
+    if (!MF) m = fmaxf(m, __shfl_xor(m, 16, 64));
+    return fmaxf(m, __shfl_xor(m, 32, 64));
+  }
+  __device__ __forceinline__ float rowred_sum(float v) const {
+    if (!MF) v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+  }
+  __device__ __forceinline__ float colred_sum(float v) const {
+    v = row16_sum(v);
+    if (MF) v += __shfl_xor(v, 16, 64);
+    return v;
+  }
+  __device__ __forceinline__ bool row_writer() const { return ah == 0; }     // one lane per row
+  __device__ __forceinline__ bool col_writer() const { return ar == 0; }     // one lane per column group
 
   // partial row maxima of the (finished) accumulator values -> sMax[wave]
   __device__ __forceinline__ void rowmax(const f32x4 (&acc)[RT][CT]) const {
@@ -385,9 +560,8 @@ struct ChainCtx {
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(acc[t][c][q]));
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      if (lg == 0) sMax[wave * R + arow(t)] = m;
+      m = rowred_max(m);
+      if (row_writer()) sMax[wave * R + arow(t)] = m;
     }
   }
   // after the barrier that completed sMax: split the accumulators, write them over P (to_p) and to `out`
@@ -408,8 +582,8 @@ struct ChainCtx {
         const f32x2_t b0 = unpk_f16(hi[0]), b1 = unpk_f16(hi[1]);
         lo[0] = pk_f16(xv[0] - b0[0], xv[1] - b0[1]);
         lo[1] = pk_f16(xv[2] - b1[0], xv[3] - b1[1]);
-        const int kg = (colbase >> 3) + 2 * c + (lg >> 1);
-        const int half = (lg & 1) * 8;
+        const int kg = akg(c);
+        const int half = ahalf();
         if (to_p) {
           char* d = P + ((size_t)kg * R + row) * 16 + half;
           *reinterpret_cast<u32x2*>(d) = hi;
@@ -432,8 +606,8 @@ struct ChainCtx {
         float s = acc[0][c][q];
 #pragma unroll
         for (int t = 1; t < RT; ++t) s += acc[t][c][q];
-        s = row16_sum(s);
-        if (li == 0) {
+        s = colred_sum(s);
+        if (col_writer()) {
           const int col = acol(c) + q;
           if (NWR == 1) part[col] = s;
           else sCol[wr * D + col] = s;
@@ -474,12 +648,13 @@ struct ChainFwdP {
 
 template <int D_, int KV = 0, int R_ = 64>
 __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
-  using C = ChainCtx<D_, R_>;
+  using C = ChainCtx<D_, R_, (KV >> 4) & 1>;
   constexpr int D = C::D, R = C::R, KG = C::KG, CT = C::CT, RT = C::RT, IT = C::IT;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   C x;
   x.init(lds, p.M, p.N);
   const int M = p.M;
+  if ((KV & 8) && x.wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched wave of each SIMD loses every arbitration otherwise
 
   // =====================================================================================================================
   // stage 0: the operand of the first product
@@ -640,9 +815,8 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
             part = fmaf(g, wv[q], part);
           }
         }
-        part += __shfl_xor(part, 16, 64);
-        part += __shfl_xor(part, 32, 64);
-        if (x.lg == 0) x.sPart[x.wave * R + x.arow(t)] = part;
+        part = x.rowred_sum(part);
+        if (x.row_writer()) x.sPart[x.wave * R + x.arow(t)] = part;
       }
     };
     switch (p.act2) {
@@ -657,7 +831,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   x.emit(acc, false, p.I2);
   x.publish_rows(x.sE2, C::PASS_EPI, p.I2, nullptr);
   if (x.tid < x.nvalid) {
-    const int w0 = (x.tid / (16 * RT)) * C::NWC;
+    const int w0 = (x.tid / C::RPW) * C::NWC;
     float s = x.sPart[w0 * R + x.tid];
 #pragma unroll
     for (int w = 1; w < C::NWC; ++w) s += x.sPart[(w0 + w) * R + x.tid];          // fixed order
@@ -668,13 +842,17 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
 template <int D_, int KV = 0, int R_ = 64>
 inline hipError_t chain_fwd_launch_t(const ChainFwdP& p, hipStream_t st) {
   auto kern = chain_fwd_kernel<D_, KV, R_>;
-  constexpr size_t lds = ChainGeo<D_, R_>::LDS;
+  constexpr size_t lds = ChainGeo<D_, R_>::LDS;      // (the same for both matrix instructions)
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
+// K-loop variant of the d = 512, 64-row chain kernels (ChainCtx::kloop: 4 = activation reads in mid-slice, 8 = static priority,
+// 16 = the 32 x 32 x 16 instruction, and their sums); -1 = the default.  macx_debug_set(7, v): A/B measurements in one process
+constexpr int CHAIN_KV_DEFAULT = 4;
+inline int& chain_kv() { static int v = -1; return v; }
 inline bool chain_supported(int d, int N) { return d % 128 == 0 && d >= 128 && d <= 512 && N >= 16; }
 // rows per tile: the tallest tile that still leaves the chip one tile per CU (short tiles exist for d = 512 only)
 inline int chain_tile_rows(int d, size_t M) {
@@ -700,7 +878,13 @@ inline hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
         case 1: return chain_fwd_launch_t<512, 1>(p, st);
         case 2: return chain_fwd_launch_t<512, 2>(p, st);
         case 3: return chain_fwd_launch_t<512, 3>(p, st);
-        default: return chain_fwd_launch_t<512>(p, st);
+        default: break;
+      }
+      switch (chain_kv()) {
+        case 0: return chain_fwd_launch_t<512, 0>(p, st);
+        case 4: return chain_fwd_launch_t<512, 4>(p, st);
+        case 20: return chain_fwd_launch_t<512, 20>(p, st);
+        default: return chain_fwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
       }
     default: return hipErrorInvalidValue;
   }
@@ -751,12 +935,13 @@ struct ChainBwdP {
 // value at run time.  Two kernels rather than two arms in one: the arms met in one register allocation (86 spilled registers).
 template <int D_, int KV = 0, int A2 = -1, int R_ = 64>
 __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
-  using C = ChainCtx<D_, R_>;
+  using C = ChainCtx<D_, R_, (KV >> 4) & 1>;
   constexpr int D = C::D, R = C::R, KG = C::KG, CB = C::CB, CT = C::CT, RT = C::RT, IT = C::IT;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   C x;
   x.init(lds, p.M, p.N);
   const int M = p.M;
+  if ((KV & 8) && x.wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   // =====================================================================================================================
   // stage B0 (SURVEY appendix A rows "softmax", "logit", "ctrl-mul"):
@@ -765,23 +950,35 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   {
     const int q0 = (int)((uint32_t)x.grow0 / (uint32_t)p.N), q1 = (int)(((uint32_t)x.grow0 + x.nvalid - 1) / (uint32_t)p.N);
     const int nq = q1 - q0 + 1;
-    float* sRed = x.sPart;              // [8]
-    float* sDot = x.sPart + 64;         // [nq <= 64]
+    float* sRed = x.sPart;              // [QS][8]
+    float* sDot = x.sPart + 64;         // [nq <= QS]
     for (int i = x.tid; i < D; i += 512) x.sW[i] = p.wk[i];
     for (int i = x.tid; i < nq * D; i += 512) x.sC[i] = p.c[(size_t)q0 * D + i];        // nq <= QS: the caller guarantees N >= 16
-    for (int k = 0; k < nq; ++k) {       // sum_j a_j da_j of each question the tile touches (every tile of a question: same order, same value)
-      const float* aq = p.att + (size_t)(q0 + k) * p.N;
-      const float* dq = p.da + (size_t)(q0 + k) * p.N;
-      float part = 0.f;
-      for (int n = x.tid; n < p.N; n += 512) part += aq[n] * dq[n];
-      part = wave_sum(part);
-      if (x.lane == 0) sRed[x.wave] = part;
+    {
+      // sum_j a_j da_j of each question the tile touches (every tile of a question: same order, same value).  All questions in
+      // one pass: their loads are in flight together and the workgroup meets twice, not twice per question
+      float part[C::G::QS];
+#pragma unroll
+      for (int k = 0; k < C::G::QS; ++k) {
+        part[k] = 0.f;
+        if (k < nq) {
+          const float* aq = p.att + (size_t)(q0 + k) * p.N;
+          const float* dq = p.da + (size_t)(q0 + k) * p.N;
+          for (int n = x.tid; n < p.N; n += 512) part[k] += aq[n] * dq[n];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < C::G::QS; ++k)
+        if (k < nq) {
+          const float t = wave_sum(part[k]);
+          if (x.lane == 0) sRed[k * 8 + x.wave] = t;
+        }
       __syncthreads();
-      if (x.tid == 0) {
+      if (x.tid < nq) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) t += sRed[w];
-        sDot[k] = t;
+        for (int w = 0; w < 8; ++w) t += sRed[x.tid * 8 + w];
+        sDot[x.tid] = t;
       }
       __syncthreads();
     }
@@ -933,8 +1130,8 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
         const int8_t* ex = p.H1.exps() + gr * CB;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          const int kg = (x.colbase >> 3) + 2 * c + (x.lg >> 1);
-          const char* src = p.H1.base + ((size_t)kg * Rp + gr) * 16 + (x.lg & 1) * 8;
+          const int kg = x.akg(c);
+          const char* src = p.H1.base + ((size_t)kg * Rp + gr) * 16 + x.ahalf();
           const u32x2 hh = *reinterpret_cast<const u32x2*>(src), hl = *reinterpret_cast<const u32x2*>(src + hpb);
           float h[4];
           h2_join4(hh, hl, h2_pow2(-(int)ex[kg >> 4]), h);
@@ -983,11 +1180,11 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
     float* stage = x.sW;                                 // [NWR][3][D] when the rows are split over two wave groups (sW and sC are idle)
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-      const int kg = (x.colbase >> 3) + 2 * c + (x.lg >> 1);
+      const int kg = x.akg(c);
       float xv[RT][4];
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
-        const char* src = p.X.base + ((size_t)kg * Rp + gr[t]) * 16 + (x.lg & 1) * 8;
+        const char* src = p.X.base + ((size_t)kg * Rp + gr[t]) * 16 + x.ahalf();
         const u32x2 hh = *reinterpret_cast<const u32x2*>(src), hl = *reinterpret_cast<const u32x2*>(src + xpb);
         h2_join4(hh, hl, h2_pow2(-(int)p.X.exps()[gr[t] * CB + (kg >> 4)]), xv[t]);
       }
@@ -1006,8 +1203,8 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           if (k < nq) {
-            const float sum = row16_sum(s3[k]);
-            if (x.li == 0) {
+            const float sum = x.colred_sum(s3[k]);
+            if (x.col_writer()) {
               if (C::NWR == 1) p.dy_part[(tile * 3 + k) * D + col] = sum;
               else stage[(x.wr * 3 + k) * D + col] = sum;
             }
@@ -1053,7 +1250,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
 template <int D_, int KV, int A2, int R_ = 64>
 inline hipError_t chain_bwd_launch_a(const ChainBwdP& p, hipStream_t st) {
   auto kern = chain_bwd_kernel<D_, KV, A2, R_>;
-  constexpr size_t lds = ChainGeo<D_, R_>::LDS;
+  constexpr size_t lds = ChainGeo<D_, R_>::LDS;      // (the same for both matrix instructions)
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
@@ -1079,7 +1276,13 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
       switch (p.dbg >> 3) {
         case 1: return chain_bwd_launch_t<512, 1>(p, st);
         case 3: return chain_bwd_launch_t<512, 3>(p, st);
-        default: return chain_bwd_launch_t<512>(p, st);
+        default: break;
+      }
+      switch (chain_kv()) {
+        case 0: return chain_bwd_launch_t<512, 0>(p, st);
+        case 4: return chain_bwd_launch_t<512, 4>(p, st);
+        case 20: return chain_bwd_launch_t<512, 20>(p, st);
+        default: return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
       }
     default: return hipErrorInvalidValue;
   }

@@ -128,6 +128,11 @@ __device__ __forceinline__ void dma4b(const char* g, uint32_t lds_wave_addr) {  
 __device__ __forceinline__ f32x4 mfma_f16(const u32x4 a, const u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
+// v_mfma_f32_32x32x16_f16: lane l supplies row / column l & 31 and the k values 8 (l >> 5) .. + 7 of a 16-wide slice; the
+// result D[i][j]: lane l holds j = l & 31 and i = 8 (reg >> 2) + 4 (l >> 5) + (reg & 3)
+__device__ __forceinline__ f32x16 mfma32_f16(const u32x4 a, const u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Workgroup tile -> H2.  A workgroup that holds `rows` x 128 finished values (one question's rows, one 128-column

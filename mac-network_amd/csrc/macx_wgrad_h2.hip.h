@@ -243,6 +243,7 @@ struct TnH2P {
   uint16_t* ftab;        // [Kd/128][Jd/128][Mpad] combined row factors, Mpad = wgrad_h2_mpad(M)
   float* part;           // [nsplit][Kd][Jd]
   int dbg;               // measurement knobs (macx_debug_set(1, mask)): 1024 skip fragments + MFMAs, 2048 skip the in-loop DMA
+  int accumulate;        // 1: part += (a launch per step into one set of slabs, launches ordered on one stream)
 };
 __host__ __device__ inline size_t wgrad_h2_mpad(size_t M) { return (M + 63) & ~(size_t)31; }       // a stage starting below M stays inside
 
@@ -436,7 +437,10 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
 #pragma unroll
     for (int i = 0; i < 32 / RPI; ++i) {
       const int r = i * RPI + lane / LPR, c4 = (lane % LPR) * 4;
-      *reinterpret_cast<f32x4*>(out + (size_t)(tp * 16 + r) * p.Jd + c4) = *reinterpret_cast<const f32x4*>(tw + r * LDW + c4);
+      f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)(tp * 16 + r) * p.Jd + c4);
+      f32x4 val = *reinterpret_cast<const f32x4*>(tw + r * LDW + c4);
+      if (p.accumulate) val += *dst;
+      *dst = val;
     }
   }
 }
