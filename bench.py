@@ -197,6 +197,47 @@ def fwd_only_p4(macx, dev, seed, p=4, steps=30):
                          "note": "whole forward pass (launch gaps and the [B,d] kernels included) over the fp16-pipe FLOPs it executes"}}
 
 
+def train_step_graph(macx, dev, seed, steps=20):
+    """The metric's step (B=64, p=12, fwd+bwd, train-mode dropout) replayed from ONE captured HIP graph (macx.CapturedTrainStep):
+    what the step costs when the host is out of the loop.  The masks of a replay are those of the captured seed (the seed is a
+    kernel parameter), so this is a measurement leg, not a training loop."""
+    cfg = macx.configs.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
+    vq, words, lengths, kb = macx.configs.synthetic_inputs(B, S, N, D, seed=seed)
+    params = macx.MACCellParams(cfg, P, generator=torch.Generator().manual_seed(seed)).to(dev)
+    cap = macx.CapturedTrainStep(cfg, params, B, S, N, seed=seed)
+    gm = (torch.randn(B, D, generator=torch.Generator().manual_seed(1)) / B).to(dev)
+    cap.load(vq.to(dev), words.to(dev), lengths.to(dev), kb.to(dev), gm)
+    for _ in range(4):
+        cap.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cap.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(B / dt, 1), "unit": "questions/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "graph_replay": bool(cap.captured),
+            "launch": ("one captured HIP graph per step (forward + full backward; verified bit for bit against the eager step, all "
+                       "gradients, three replays)" if cap.captured else
+                       "EAGER launches: this process's replays failed CapturedTrainStep's self-check (mac-network_amd/graph.py)")}
+
+
+def latest_roofline_inputs():
+    """profiles/latest_roofline_inputs.json if present, else the newest profiles/rNN_roofline_inputs.json (tools/profile_post.py
+    writes both): per-launch HBM bytes (PMC) and in-step kernel averages of the dominant kernel"""
+    import glob
+    d = os.path.join(ROOT, "profiles")
+    cands = [os.path.join(d, "latest_roofline_inputs.json")] + sorted(glob.glob(os.path.join(d, "r[0-9][0-9]_roofline_inputs.json")), reverse=True)
+    for c in cands:
+        try:
+            out = json.load(open(c))
+            out.setdefault("file", os.path.relpath(c, ROOT))
+            return out
+        except Exception:
+            continue
+    return {}
+
+
 def train_b128_p12(macx, dev, dist, seed, steps=8):
     """BASELINE configs[2]: netLength 12, batch 128, fwd + bwd + global-norm clip + Adam + EMA (model.py:615-669) on one MI355X."""
     b, p = 128, 12
@@ -300,6 +341,8 @@ def main():
     ap.add_argument("--no-model-level", action="store_true")
     ap.add_argument("--no-native", action="store_true", help="skip the comparison legs on the other two kernel families")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip BASELINE configs[1] (forward only, p=4) and configs[2] (B=128, Adam+EMA)")
+    ap.add_argument("--no-probe", action="store_true", help="profiling runs (tools/profile_round.sh): only the timed steps, no roofline "
+                    "probe launches of the dominant kernel behind them -- its in-step average in a kernel trace then counts the step's launches only")
     ap.add_argument("--no-extra-dp", action="store_true", help="N > 1: only the metric's (strong-scaling) configuration")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -394,7 +437,11 @@ def main():
             del st2
             torch.cuda.empty_cache()
 
-    if rank == 0:
+    if rank == 0 and args.no_probe:
+        print(json.dumps({"metric": "questions/sec fwd+bwd (B=64,d=512,p=12,KB=14x14x1024) at 1/2/4/8 MI355X", "value": round(qps, 2),
+                          "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(ms_per_step, 3), "roofline": None, "note": "--no-probe: profiling run"}), flush=True)
+    elif rank == 0:
         ptr = lambda t: C.c_void_p(t.data_ptr())
         mode = L.macx_gemm_mode(-1)
         st = None
@@ -491,11 +538,8 @@ def main():
             terms, pipe = (6, "bf16 (v_mfma_f32_16x16x32_bf16)") if mode == 1 else (1, "f32 (v_mfma_f32_16x16x4_f32)")
         alg = k_flops / (k_ms * 1e-3)
         peak = PEAK_BF16_MFMA if mode else PEAK_FP32_MFMA
-        prof = {}
-        try:   # per-launch HBM bytes (PMC) and in-step kernel averages (rocprofv3 --kernel-trace), written by tools/profile_round.sh
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r03_roofline_inputs.json")))
-        except Exception:
-            pass
+        # per-launch HBM bytes (PMC) and in-step kernel averages (rocprofv3 --kernel-trace), written by tools/profile_round.sh
+        prof = latest_roofline_inputs()
         roofline = {"bound": "mfma", "kernel": kname,
                     # achieved = the FLOPs the matrix pipe EXECUTES for this launch (terms x the algorithmic 2 (B N) d^2) per second,
                     # priced against the dense peak of the pipe they execute on
@@ -503,7 +547,11 @@ def main():
                     "frac": round(terms * alg / peak, 4), "pipe": pipe, "mfma_terms_per_product": terms,
                     "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": k_flops,
                     "algorithmic_tflops": round(alg / 1e12, 2),
-                    "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("source"),
+                    "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("source"), "profile_file": prof.get("file"),
+                    # what the pipe sustains on THIS instruction with random fp16 operands, all 256 CUs, nothing else in the loop
+                    # (tools/probes/mfma_probe.hip, profiles/r04_mfma_probe.txt): the matrix pipe's rate is data-dependent -- the chip
+                    # clocks to its power budget -- 2440 TF on zero operands, 1880 TF on random ones; `peak` stays the guide's dense figure
+                    "pipe_rate_random_operands_tflops": 1880.0 if mode == 2 else None,
                     # chain kernel: the fp32 knowledge base in; dropout(KB), X, H1, I2 out as H2 (4 B per element) + keep bits; 4 weights
                     "algorithmic_bytes_per_launch": ((1 + 4) * Bp * N * D * 4 + 2 * Bp * N * D // 8 + 4 * D * D * 4) if chain_ms is not None
                                                     else 2 * Bp * N * D * 4 + D * D * 4,
@@ -557,6 +605,7 @@ def main():
             # BASELINE.json configs[1] and configs[2]
             out["fwd_only_p4"] = fwd_only_p4(macx, dev, seed)
             out["train_b128_p12_adam_ema"] = train_b128_p12(macx, dev, dist, seed)
+            out["train_step_graph"] = train_step_graph(macx, dev, seed)
         if world == 1 and not args.no_model_level:
             out["model_level"] = model_level(macx, dev, seed)
         if world == 1 and not args.no_cpu_baseline:

@@ -156,8 +156,6 @@ struct SavedLayout {
   size_t act_stride;                // floats per kept step of X / H1 / I2 / KBd if keep else 0
   size_t act_floats;                // floats of one such tensor (B*N*d, or the H2 size in h2 mode)
   size_t wmax;                      // h2: max |W| of projX, memKbProj2, W1a, W1b (4 floats)
-  size_t qmin_X, qmin_H1, qmin_KBd; // h2: [pk][B][d/128] ints, minimum exponent of each question's rows
-  size_t qmin_stride;               // ints per kept step (0 when activations are not kept)
   size_t total;
 };
 
@@ -219,10 +217,6 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.kb_bits = take(pk * bits_floats);
   L.att_bits = take(pk * bits_floats);
   L.wmax = take(8 + 4 * 64);          // the four maxima (+ 4 spare), then absmax4's per-workgroup partials
-  L.qmin_stride = keep ? B * (d / 128) : 0;
-  L.qmin_X = take(3 * pk * B * (d / 128));
-  L.qmin_H1 = L.qmin_X + pk * B * (d / 128);
-  L.qmin_KBd = L.qmin_H1 + pk * B * (d / 128);
   L.total = off;
   return L;
 }
@@ -304,10 +298,9 @@ struct BwdLayout {
   size_t small_slab;
   size_t tmp_dd;    // [d,d] scratch
   size_t act_floats;                 // floats of one [B,N,d] activation (H2 size in h2 mode)
-  size_t qmin_dI2, qmin_dI1, qmin_dX;   // h2: [p][B][d/128] ints
-  size_t ecom;                       // h2: 4 x [d/128] ints, common exponents of H1 / dI2 / KBd / dX over all steps
+  size_t ecom;                       // h2: [4][EMIN_NB][8] ints, partial minima of the row exponents of H1 / dI2 / KBd / dX over all steps
   size_t wg_ftab;                    // h2: [d/128][d/128][Mpad] fp16 row factors of the deferred weight-gradient contractions
-  // per-step dW2 on the side queue (overlap mode 4): common exponents [p][2][8], row factors [p][d/128][d/128][Mpad(B N)], splits
+  // per-step dW2 on the side queue (overlap mode 4): exponent minima [p][2][EMIN_NB][8], row factors [p][d/128][d/128][Mpad(B N)], splits
   size_t ecom_s, ftab_s, ftab_s_stride, side_ns;
   size_t total;
 };
@@ -374,12 +367,9 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   }
   L.small_slab = take(small);
   L.tmp_dd = take(d * d);
-  L.qmin_dI2 = take(3 * p * B * (d / 128));
-  L.qmin_dI1 = L.qmin_dI2 + p * B * (d / 128);
-  L.qmin_dX = L.qmin_dI1 + p * B * (d / 128);
-  L.ecom = take(4 * 8);
+  L.ecom = take(4 * EMIN_NB * 8);
   L.wg_ftab = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
-  L.ecom_s = take(p * 16);
+  L.ecom_s = take(p * 2 * EMIN_NB * 8);
   L.ftab_s_stride = h2_mode() ? al4((d / 128) * (d / 128) * wgrad_h2_mpad(B * N) / 2 + 4) : 4;
   L.ftab_s = take(p * L.ftab_s_stride);
   {
@@ -436,7 +426,6 @@ ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dr
   }
   if (rdrop || i == 0) {
     c.KBd = h2_view(rdrop ? saved + L.KBd + (size_t)ob * L.act_stride : saved + L.KBd, R, d);
-    c.qmin_KBd = reinterpret_cast<int*>(saved + L.qmin_KBd) + (rdrop ? (size_t)ob * L.qmin_stride : 0);
   }
   c.Wx = wref(L.wx_p); c.W1a = wref(L.w1a_p); c.W1b = wref(L.w1b_p); c.W2 = wref(L.w2_p);
   c.bx = P->projX_b; c.b1 = P->memKbProj_b; c.b2 = P->memKbProj2_b;
@@ -445,10 +434,8 @@ ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dr
   c.c = saved + L.seg[MACX_SEG_CONTROLS] + (size_t)(i + 1) * Bd;
   c.wk = P->kbLogits_w;
   c.X = h2_view(saved + L.X + (size_t)ob * L.act_stride, R, d);
-  c.qmin_X = reinterpret_cast<int*>(saved + L.qmin_X) + (size_t)ob * L.qmin_stride;
   if (keep) {
     c.H1 = h2_view(saved + L.H1 + (size_t)ob * L.act_stride, R, d);
-    c.qmin_H1 = reinterpret_cast<int*>(saved + L.qmin_H1) + (size_t)ob * L.qmin_stride;
     c.I2 = h2_view(saved + L.I2 + (size_t)ob * L.act_stride, R, d);
   }
   c.logits = saved + L.logit_part;
@@ -479,36 +466,10 @@ struct Packer {
 
 // ---- H2 helpers (macx_h2.hip.h) -------------------------------------------------------------------------------
 // min over n entries of [n][cb] minimum-exponent arrays -> out[cb]
-struct QminList { const int* q[4]; int n[4]; int* out[4]; };     // blockIdx.x selects one of up to four reductions
-__global__ void qmin_reduce_kernel(QminList L, int cb) {
-  __shared__ int red[8][4];
-  const int* q = L.q[blockIdx.x];
-  const int n = L.n[blockIdx.x];
-  int* out = L.out[blockIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = 0; k < cb; ++k) {
-    int m = 127;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) m = min(m, q[(size_t)i * cb + k]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
-    if (lane == 0) red[k][wave] = m;
-  }
-  __syncthreads();
-  if (threadIdx.x < cb) {
-    int m = red[threadIdx.x][0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = min(m, red[threadIdx.x][w]);
-    out[threadIdx.x] = min(m, 126);       // an all-zero tensor family keeps exponent 0 rows: 127 never reaches a kernel
-  }
-}
-hipError_t qmin_reduce_list(const QminList& L, int count, int cb, hipStream_t st) {
-  hipLaunchKernelGGL(qmin_reduce_kernel, dim3(count), dim3(256), 0, st, L, cb);
+// minimum row exponents of up to four families of H2 tensors -> per-workgroup partials (macx_h2.hip.h: h2_emin_list_kernel)
+hipError_t emin_list(const EminList& L, int count, hipStream_t st) {
+  hipLaunchKernelGGL(h2_emin_list_kernel, dim3(EMIN_NB, count), dim3(256), 0, st, L);
   return hipGetLastError();
-}
-hipError_t qmin_reduce(const int* q, int n, int cb, int* out, hipStream_t st) {
-  QminList L;
-  memset(&L, 0, sizeof(L));
-  L.q[0] = q; L.n[0] = n; L.out[0] = out;
-  return qmin_reduce_list(L, 1, cb, st);
 }
 hipError_t h2_from_f32(const H2FromP& f, hipStream_t st) {
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(h2_from_f32_kernel), H2C_LDS);
@@ -666,8 +627,6 @@ int pack_forward_weights(const macx_opts* o, const macx_shapes* s, const macx_pa
       const size_t dd_ = (size_t)d * d;
       CK(absmax4(P->projX_W, dd_, P->memKbProj2_W, dd_, P->memKbProj_W, dd_, P->memKbProj_W + dd_, dd_, saved + L.wmax,
                  saved + L.wmax + 8, st));
-      // minimum-exponent arrays are filled with atomicMin by the producers of X / H1 / KBd
-      CK(hipMemsetAsync(saved + L.qmin_X, 0x7F, 3 * (size_t)(keep ? p : 1) * B * (d / 128) * sizeof(int), st));
     }
     if (units & U_READ) {
       pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);
@@ -828,9 +787,6 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     const int R = B * N, CB = d / 128;
     const H2View hX = h2_view(X, R, d), hH1 = h2_view(H1, R, d), hI2 = h2_view(I2, R, d);
     const H2View hKB = h2_view(rdrop ? KBd : saved + L.KBd, R, d);
-    int* qX = reinterpret_cast<int*>(saved + L.qmin_X) + (size_t)i * L.qmin_stride;
-    int* qH1 = reinterpret_cast<int*>(saved + L.qmin_H1) + (size_t)i * L.qmin_stride;
-    int* qKB = reinterpret_cast<int*>(saved + L.qmin_KBd) + (rdrop ? (size_t)i * L.qmin_stride : 0);
     uint8_t* att_bytes = rdrop ? reinterpret_cast<uint8_t*>(att_bits) : nullptr;
     if (use_chain(d, s->N)) {
       // KB -> X -> H1 -> I2 -> logits in one launch (macx_chain_h2.hip.h)
@@ -849,7 +805,6 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
         f.key = dk.key; f.thr24 = dk.thr24; f.inv_keep = dk.inv_keep; f.bits = kb_bits;
         f.key2 = da.key; f.thr24_2 = da.thr24; f.bytes2 = att_bytes;
       }
-      f.qmin = qKB;
       CK(h2_from_f32(f, st));
     }
     GemmH2P g;
@@ -860,19 +815,19 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     // X = dropout(KB) Wx + bx  (ops.py:678,688)
     g.A = hKB;
     g.Wh = reinterpret_cast<const char*>(saved + L.wx_p); g.w_exp = reinterpret_cast<const int*>(saved + L.wx_p) + (size_t)d * d;
-    g.out = hX; g.bias = P->projX_b; g.act = MACX_ACT_NON; g.out_qmin = qX;
+    g.out = hX; g.bias = P->projX_b; g.act = MACX_ACT_NON;
     if (rdrop || L.act_stride != 0 || i == 0) CK((kb_gemm_h2_launch<B_PLAIN, E_BIAS_ACT, false>(g, st)));
     // H1 = act( X (diag(y) W1a + W1b) + b1 )   (ops.py:703,718; mac_cell.py:237)
     g.A = hX; g.Wh = nullptr; g.w_exp = nullptr;
     g.Wt = saved + L.w1a_p; g.Wt2 = saved + L.w1b_p; g.w_max = saved + L.wmax + 2; g.y = y; g.ldy = d;
-    g.out = hH1; g.bias = P->memKbProj_b; g.act = o->read_mem_act; g.out_qmin = qH1;
+    g.out = hH1; g.bias = P->memKbProj_b; g.act = o->read_mem_act;
     CK((kb_gemm_h2_launch<B_YMIX_ROW, E_BIAS_ACT, false>(g, st)));
     // I2 = H1 W2 + b2 ; logits = dropout(act(I2 * c)) . w_k   (ops.py:326; mac_cell.py:248,262,266)
     g.A = hH1; g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
     g.Wh = reinterpret_cast<const char*>(saved + L.w2_p); g.w_exp = reinterpret_cast<const int*>(saved + L.w2_p) + (size_t)d * d;
     g.out = hI2; g.bias = P->memKbProj2_b; g.act = o->read_ctrl_act;
     g.cvec = c_i; g.wvec = P->kbLogits_w; g.logit_part = saved + L.logit_part;
-    g.e_bytes = att_bytes; g.out_qmin = nullptr;
+    g.e_bytes = att_bytes;
     CK((kb_gemm_h2_launch<B_PLAIN, E_I2_LOGIT, false>(g, st)));
     }
     (void)CB;
@@ -1068,7 +1023,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     CK(pk.run(st));
   }
 
-  if (h2_mode()) CK(hipMemsetAsync(ws + W.qmin_dI2, 0x7F, 3 * (size_t)p * B * (d / 128) * sizeof(int), st));
   float* DM = ws + W.DM;
   float* DC = ws + W.DC;
   // dL/d(newMemory linear output) for all steps; with writeMemAct = NON it IS dL/dm_{1..p}
@@ -1176,9 +1130,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       const int R = B * N, CB = d / 128;
       const H2View hI2 = h2_view(I2, R, d), hH1 = h2_view(H1, R, d), hX = h2_view(X, R, d);
       const H2View hdI2 = h2_view(dI2_i, R, d), hdI1 = h2_view(ws + W.dI1 + (size_t)i * W.dI1_stride, R, d), hdX = h2_view(dX_i, R, d);
-      int* q_dI2 = reinterpret_cast<int*>(ws + W.qmin_dI2) + (size_t)i * B * CB;
-      int* q_dI1 = reinterpret_cast<int*>(ws + W.qmin_dI1) + (size_t)i * B * CB;
-      int* q_dX = reinterpret_cast<int*>(ws + W.qmin_dX) + (size_t)i * B * CB;
       const bool chain = use_chain(d, s->N);
       if (!(chain && W.chain_sums)) {
         ReadAttBwdH2P r;
@@ -1193,7 +1144,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         r.dwk_part = ws + W.dwk_part + (size_t)i * W.dwk_rows * d;
         r.db2_part = ws + W.db2_part + (size_t)i * W.dwk_rows * d;
         r.dbk_part = ws + W.dbk_part + (size_t)i * B;
-        r.qmin = q_dI2;
         hipLaunchKernelGGL(read_att_bwd_h2_kernel, dim3(B, d / 128), dim3(RABH_THREADS), 0, st, r);
         CK(hipGetLastError());
       }
@@ -1218,11 +1168,11 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         }
         c.bytes2 = rdrop ? reinterpret_cast<const uint8_t*>(saved + L.att_bits + (size_t)i * L.bits_stride) : nullptr;
         c.inv2 = rdrop ? 1.0f / dp->keep_read : 1.0f;
-        c.dI2 = hdI2; c.qmin_dI2 = q_dI2;
+        c.dI2 = hdI2;
         c.W2T = wref(W.w2T_p); c.H1 = hH1; c.act1 = o->read_mem_act;
-        c.dI1 = hdI1; c.qmin_dI1 = q_dI1; c.db1_part = ws + W.db1_part + (size_t)i * W.db_rows * d;
+        c.dI1 = hdI1; c.db1_part = ws + W.db1_part + (size_t)i * W.db_rows * d;
         c.W1aT = wref(W.w1aT_p); c.W1bT = wref(W.w1bT_p); c.y = y;
-        c.dX = hdX; c.qmin_dX = q_dX; c.dbx_part = ws + W.dbx_part + (size_t)i * W.db_rows * d;
+        c.dX = hdX; c.dbx_part = ws + W.dbx_part + (size_t)i * W.db_rows * d;
         if (W.sb_deferred) { c.X = hX; c.dy_part = ws + W.dyc_part; }
         CK(chain_bwd_launch(c, st));
         if (sq_w2) {
@@ -1230,18 +1180,19 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
           hipStream_t s2 = sq_w2->s;
           CK(hipEventRecord(sq_w2->fork, st));
           CK(hipStreamWaitEvent(s2, sq_w2->fork, 0));
-          int* ecs = reinterpret_cast<int*>(ws + W.ecom_s) + (size_t)i * 16;
-          QminList ql;
-          memset(&ql, 0, sizeof(ql));
-          ql.q[0] = reinterpret_cast<const int*>(saved + L.qmin_H1) + (size_t)i * L.qmin_stride; ql.n[0] = B; ql.out[0] = ecs;
-          ql.q[1] = q_dI2; ql.n[1] = B; ql.out[1] = ecs + 8;
-          CK(qmin_reduce_list(ql, 2, CB, s2));
+          int* ecs = reinterpret_cast<int*>(ws + W.ecom_s) + (size_t)i * 2 * EMIN_NB * 8;
+          EminList el;
+          memset(&el, 0, sizeof(el));
+          el.R = R; el.C = d; el.part = ecs;
+          el.base[0] = reinterpret_cast<const char*>(H1); el.nt[0] = 1;
+          el.base[1] = reinterpret_cast<const char*>(dI2_i); el.nt[1] = 1;
+          CK(emin_list(el, 2, s2));
           TnH2P t;
           memset(&t, 0, sizeof(t));
           t.M = R; t.Kd = d; t.Jd = d; t.nsplit = (int)W.side_ns; t.rows_per_split = rows_per_split(t.M, t.nsplit);
           t.R = R;
           t.A = reinterpret_cast<const char*>(H1); t.G = reinterpret_cast<const char*>(dI2_i);
-          t.ecomA = ecs; t.ecomG = ecs + 8;
+          t.ecomA = ecs; t.ecomG = ecs + EMIN_NB * 8; t.ecom_nb = EMIN_NB;
           t.ftab = reinterpret_cast<uint16_t*>(ws + W.ftab_s + (size_t)i * W.ftab_s_stride);
           t.part = ws + W.slab_w2;
           t.accumulate = (i != p - 1);
@@ -1263,13 +1214,13 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
       g.A = hdI2;
       g.Wh = reinterpret_cast<const char*>(ws + W.w2T_p); g.w_exp = reinterpret_cast<const int*>(ws + W.w2T_p) + dd;
-      g.out = hdI1; g.aux = hH1; g.act = o->read_mem_act; g.out_qmin = q_dI1;
+      g.out = hdI1; g.aux = hH1; g.act = o->read_mem_act;
       g.colsum_part = ws + W.db1_part + (size_t)i * B * nrb * d;
       CK((kb_gemm_h2_launch<B_PLAIN, E_MUL_DACT, true>(g, st)));
       // dX = dI1 (diag(y) W1a + W1b)^T ; dbx partials
       g.A = hdI1; g.Wh = nullptr; g.w_exp = nullptr;
       g.Wt = ws + W.w1aT_p; g.Wt2 = ws + W.w1bT_p; g.w_max = saved + L.wmax + 2; g.y = y; g.ldy = d;
-      g.out = hdX; g.out_qmin = q_dX;
+      g.out = hdX;
       g.colsum_part = ws + W.dbx_part + (size_t)i * B * nrb * d;
       CK((kb_gemm_h2_launch<B_YMIX_COL, E_PLAIN, true>(g, st)));
       }
@@ -1280,7 +1231,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         q.nsteps = 1;
         q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B, N);
         q.X = hX; q.dI1 = hdI1;
-        q.qminX = reinterpret_cast<const int*>(saved + L.qmin_X) + (size_t)i * L.qmin_stride; q.qminG = q_dI1;
         q.y = y; q.W1a = P->memKbProj_W;
         q.dW1a_part = ws + W.slab_w1a + (size_t)i * W.ngroup * dd;
         q.dW1b_part = ws + W.slab_w1b + (size_t)i * W.ngroup * dd;
@@ -1304,7 +1254,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         g.e_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits + (size_t)i0 * L.bits_stride) : nullptr;
         g.bits_step_words = L.bits_stride;
         g.accumulate = sq ? (i != p - 1) : 0;
-        g.colsum_part = nullptr; g.out_qmin = nullptr; g.aux = H2View{nullptr, 0, 0};
+        g.colsum_part = nullptr; g.aux = H2View{nullptr, 0, 0};
         if (sq) {
           CK(hipEventRecord(sq->fork, st));
           CK(hipStreamWaitEvent(sq->s, sq->fork, 0));
@@ -1606,14 +1556,17 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   // p*B*N rows (the per-step operands are kept; 288 GB of HBM makes that the cheap choice)
   if (h2_mode()) {
     const int CB = d / 128;
-    int* ecom = reinterpret_cast<int*>(ws + W.ecom);       // [H1 | dI2 | KBd | dX][8]
+    int* ecom = reinterpret_cast<int*>(ws + W.ecom);       // [H1 | dI2 | KBd | dX][EMIN_NB][8]
+    constexpr int ES = EMIN_NB * 8;
     {
-      QminList ql;
-      ql.q[0] = reinterpret_cast<const int*>(saved + L.qmin_H1); ql.n[0] = p * B; ql.out[0] = ecom;
-      ql.q[1] = reinterpret_cast<const int*>(ws + W.qmin_dI2); ql.n[1] = p * B; ql.out[1] = ecom + 8;
-      ql.q[2] = reinterpret_cast<const int*>(saved + L.qmin_KBd); ql.n[2] = (rdrop ? p : 1) * B; ql.out[2] = ecom + 16;
-      ql.q[3] = reinterpret_cast<const int*>(ws + W.qmin_dX); ql.n[3] = p * B; ql.out[3] = ecom + 24;
-      CK(qmin_reduce_list(ql, 4, CB, st));
+      EminList el;
+      memset(&el, 0, sizeof(el));
+      el.R = B * N; el.C = d; el.part = ecom;
+      el.base[0] = reinterpret_cast<const char*>(saved + L.H1); el.stride[0] = L.act_stride * sizeof(float); el.nt[0] = p;
+      el.base[1] = reinterpret_cast<const char*>(ws + W.dI2); el.stride[1] = W.act_floats * sizeof(float); el.nt[1] = p;
+      el.base[2] = reinterpret_cast<const char*>(saved + L.KBd); el.stride[2] = L.act_stride * sizeof(float); el.nt[2] = rdrop ? p : 1;
+      el.base[3] = reinterpret_cast<const char*>(ws + W.dX); el.stride[3] = W.act_floats * sizeof(float); el.nt[3] = p;
+      CK(emin_list(el, 4, st));
     }
     TnH2P t;
     memset(&t, 0, sizeof(t));
@@ -1621,7 +1574,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     t.R = B * N;
     t.A = reinterpret_cast<const char*>(saved + L.H1); t.a_stride = L.act_stride * sizeof(float); t.a_mod = 0;
     t.G = reinterpret_cast<const char*>(ws + W.dI2); t.g_stride = W.act_floats * sizeof(float);
-    t.ecomA = ecom; t.ecomG = ecom + 8;
+    t.ecomA = ecom; t.ecomG = ecom + ES; t.ecom_nb = EMIN_NB;
     t.ftab = reinterpret_cast<uint16_t*>(ws + W.wg_ftab);
     t.dbg = kb_gemm_dbg();
     t.part = ws + W.slab_w2;
@@ -1629,7 +1582,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     t.A = reinterpret_cast<const char*>(saved + L.KBd);
     t.a_mod = rdrop ? 0 : B * N;                              // no dropout: the same (converted) KB every step
     t.G = reinterpret_cast<const char*>(ws + W.dX);
-    t.ecomA = ecom + 16; t.ecomG = ecom + 24;
+    t.ecomA = ecom + 2 * ES; t.ecomG = ecom + 3 * ES;
     t.part = ws + W.slab_wx;
     CK(wgrad_h2_launch(t, st));
   } else {
@@ -1654,12 +1607,10 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     memset(&q, 0, sizeof(q));
     q.B = B; q.N = N; q.d = d; q.qpg = sb_qpg(B, N);
     q.X = h2_view(saved + L.X, B * N, d); q.dI1 = h2_view(ws + W.dI1, B * N, d);
-    q.qminX = reinterpret_cast<const int*>(saved + L.qmin_X); q.qminG = reinterpret_cast<const int*>(ws + W.qmin_dI1);
     q.y = saved + L.y; q.W1a = P->memKbProj_W;
     q.dW1a_part = ws + W.slab_w1a; q.dW1b_part = ws + W.slab_w1b; q.dy_part = nullptr;
     q.nsteps = p;
     q.x_step = L.act_stride * sizeof(float); q.g_step = W.dI1_stride * sizeof(float); q.y_step = Bd;
-    q.qx_step = L.qmin_stride; q.qg_step = (size_t)B * CB;
     q.dbg = kb_gemm_dbg();
     CK(sb_h2_launch(q, st));
   }

@@ -178,10 +178,12 @@ struct ChainCtx {
     return pass == PASS_EPI ? row_exponent_epi(row) : (pass == PASS_BLK ? row_exponent_blk(row) : row_exponent_conv(row));
   }
 
-  // per-row bookkeeping once sMax is complete: exponent table, exponent bytes, per-question minimum (wave 0 works)
-  __device__ __forceinline__ void publish_rows(int* eTab, int pass, const H2View& out, int* qmin) const {
+  // per-row bookkeeping once sMax is complete: exponent table and exponent bytes (wave 0 works).  (What a contraction over rows
+  // needs besides -- the minimum exponent of a question's / of all rows -- its consumers take from these bytes themselves:
+  // h2_emin_list_kernel, sb_h2_kernel.)
+  __device__ __forceinline__ void publish_rows(int* eTab, int pass, const H2View& out) const {
     if (tid < 64) {
-      const int r = min(tid, R - 1);                // (lanes past a short tile: no row, they only take part in the shuffles)
+      const int r = min(tid, R - 1);                // (lanes past a short tile: no row)
       const bool v = tid < nvalid;
       const int e = row_exponent_of(r, pass);
       if (tid < R) eTab[r] = e;
@@ -190,20 +192,10 @@ struct ChainCtx {
 #pragma unroll
         for (int k = 0; k < CB; ++k) ex[k] = (int8_t)e;
       }
-      if (out.base && qmin) {
-        const int q0 = (int)((uint32_t)grow0 / (uint32_t)N), q1 = (int)(((uint32_t)grow0 + nvalid - 1) / (uint32_t)N);
-        const int qr = v ? (int)(((uint32_t)grow0 + r) / (uint32_t)N) : -1;
-        for (int qq = q0; qq <= q1; ++qq) {
-          int mn = (qr == qq) ? e : 127;
-#pragma unroll
-          for (int s = 32; s > 0; s >>= 1) mn = min(mn, __shfl_xor(mn, s, 64));
-          if (tid < CB) atomicMin(qmin + (size_t)qq * CB + tid, mn);
-        }
-      }
     }
   }
   // conversion pass, second half: v[j][0..7] (fp32, this lane's slots) -> row exponents -> H2 slots in P (+ HBM)
-  __device__ __forceinline__ void convert_finish(float (&v)[IT][8], float m, int* eTab, const H2View& out, int* qmin) const {
+  __device__ __forceinline__ void convert_finish(float (&v)[IT][8], float m, int* eTab, const H2View& out) const {
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     if (lane < 16) sMax[wave * R + crow] = m;
@@ -228,7 +220,7 @@ struct ChainCtx {
         *reinterpret_cast<u32x4*>(g + opb) = lo;
       }
     }
-    publish_rows(eTab, PASS_CONV, out, qmin);
+    publish_rows(eTab, PASS_CONV, out);
     __syncthreads();
   }
   // ---- row-block conversion pass (backward stage B0): lane (r8 = lane & 7, kq = lane >> 3) of wave w < KG / 8 holds slot column
@@ -245,7 +237,7 @@ struct ChainCtx {
     *reinterpret_cast<f32x4*>(d + 16 - h) = f32x4{o[4], o[5], o[6], o[7]};
   }
   // mx[s]: max |value| of this lane's slot of row block s
-  __device__ __forceinline__ void convert_finish_blk(const float (&mx)[8], const H2View& out, int* eTab, int* qmin) const {
+  __device__ __forceinline__ void convert_finish_blk(const float (&mx)[8], const H2View& out, int* eTab) const {
     const int r8 = lane & 7, kq = lane >> 3;
     const bool active = wave < KG / 8;
     const int kg = 8 * wave + kq;
@@ -293,7 +285,7 @@ struct ChainCtx {
         }
       }
     }
-    publish_rows(eTab, PASS_BLK, out, qmin);
+    publish_rows(eTab, PASS_BLK, out);
     __syncthreads();
   }
 
@@ -633,15 +625,15 @@ struct ChainFwdP {
   uint8_t* bits1;           // its keep bits, row-major, one byte per 8 columns [M][d/8] (= uint32 words [M][d/32]); may be null
   uint32_t key2, thr2; float inv2;      // ops.py:312 site on act(I2 * c)
   uint8_t* bytes2;          // its keep bits in slot order [d/8][M + pad]; may be null
-  H2View KBd; int* qmin_KBd;            // base null: not written
+  H2View KBd;               // base null: not written
   ChainW Wx, W1a, W1b, W2;
   const float *bx, *b1, *b2;
   int act1, act2;           // readMemAct (on H1), readCtrlAct (on I2 * c)
   const float* y;           // [B][d]
   const float* c;           // [B][d]
   const float* wk;          // [d]
-  H2View X; int* qmin_X;    // written in mode 0, read in mode 1
-  H2View H1; int* qmin_H1;  // base null: not written (inference)
+  H2View X;                 // written in mode 0, read in mode 1
+  H2View H1;                // base null: not written (inference)
   H2View I2;                // base null: not written
   float* logits;            // [M] (without the bias b_k, which kb_attend adds)
 };
@@ -695,7 +687,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[j][q]));
     }
-    x.convert_finish(v, m, x.sE, p.KBd, p.qmin_KBd);
+    x.convert_finish(v, m, x.sE, p.KBd);
   } else {
     x.load_tile(p.X, x.sE);
   }
@@ -735,7 +727,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
     x.rowmax(acc);
     __syncthreads();                       // every wave is done reading P; sMax is complete
     x.emit(acc, true, p.X);
-    x.publish_rows(x.sE, C::PASS_EPI, p.X, p.qmin_X);
+    x.publish_rows(x.sE, C::PASS_EPI, p.X);
     __syncthreads();
   }
   if (p.dbg & 2) return;
@@ -764,7 +756,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
         m = fmaxf(m, fabsf(v[j][q]));
       }
     }
-    x.convert_finish(v, m, x.sE2, H2View{nullptr, M, D}, nullptr);
+    x.convert_finish(v, m, x.sE2, H2View{nullptr, M, D});
   }
   {
     // accumulators: units 2^-(eX + e1b)  ->  2^-(eXy + e1a), exactly
@@ -783,7 +775,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   x.rowmax(acc);
   __syncthreads();
   x.emit(acc, true, p.H1);
-  x.publish_rows(x.sE, C::PASS_EPI, p.H1, p.qmin_H1);
+  x.publish_rows(x.sE, C::PASS_EPI, p.H1);
   __syncthreads();
   if (p.dbg & 4) return;
 
@@ -829,7 +821,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   }
   __syncthreads();
   x.emit(acc, false, p.I2);
-  x.publish_rows(x.sE2, C::PASS_EPI, p.I2, nullptr);
+  x.publish_rows(x.sE2, C::PASS_EPI, p.I2);
   if (x.tid < x.nvalid) {
     const int w0 = (x.tid / C::RPW) * C::NWC;
     float s = x.sPart[w0 * R + x.tid];
@@ -906,7 +898,7 @@ struct ChainBwdP {
   int act2;                 // readCtrlAct
   const uint8_t* bytes2;    // keep bits of the attention dropout in slot order [d/8][M + pad]; null = keep all
   float inv2;
-  H2View dI2; int* qmin_dI2;
+  H2View dI2;
   // column sums of stage B0 per 64-row tile, summed over tiles by the caller in a fixed order; a tile may touch up to three
   // questions (N >= 32), so what is per question has three segments.  All four null: not computed here
   // (read_att_bwd_h2_kernel in its sums-only mode does it).
@@ -917,12 +909,12 @@ struct ChainBwdP {
   // stage B1: dI1 = (dI2 W2^T) * act'(H1)
   ChainW W2T;
   H2View H1; int act1;      // readMemAct
-  H2View dI1; int* qmin_dI1;
+  H2View dI1;
   float* db1_part;          // [tiles][d] column sums of dI1
   // stage B2: dX = (dI1 W1a^T) * y + dI1 W1b^T
   ChainW W1aT, W1bT;
   const float* y;           // [B][d]
-  H2View dX; int* qmin_dX;
+  H2View dX;
   float* dbx_part;          // [tiles][d] column sums of dX
   // dy[q][k] = sum over the question's rows of (dI1 W1a^T)[r][k] * X[r][k]  (ops.py:703: d(x * y)/dy = x): the first product of
   // stage B2 is exactly the left factor, so dy costs one read of the kept X tile -- and the per-question contraction
@@ -1107,7 +1099,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
         if (x.tid == 0) p.dls_part[tile * 3 + k] = t;
       }
     }
-    x.convert_finish_blk(mx, p.dI2, x.sE, p.qmin_dI2);
+    x.convert_finish_blk(mx, p.dI2, x.sE);
   }
   if (p.dbg & 1) return;
 
@@ -1152,7 +1144,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   x.rowmax(acc);
   __syncthreads();                         // every wave is done reading dI2; sMax (and sCol) complete
   x.emit(acc, true, p.dI1);
-  x.publish_rows(x.sE, C::PASS_EPI, p.dI1, p.qmin_dI1);
+  x.publish_rows(x.sE, C::PASS_EPI, p.dI1);
   x.colsum_finish(p.db1_part + tile * D);
   __syncthreads();
   if (p.dbg & 2) return;
@@ -1239,7 +1231,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   x.rowmax(acc);
   __syncthreads();
   x.emit(acc, false, p.dX);
-  x.publish_rows(x.sE2, C::PASS_EPI, p.dX, p.qmin_dX);
+  x.publish_rows(x.sE2, C::PASS_EPI, p.dX);
   x.colsum_finish(p.dbx_part + tile * D);
   if (C::NWR == 2 && p.dy_part) {                       // the two row halves of the dy partials (staged before the last product)
     const int nq = (int)(((uint32_t)x.grow0 + x.nvalid - 1) / (uint32_t)p.N) - (int)((uint32_t)x.grow0 / (uint32_t)p.N) + 1;

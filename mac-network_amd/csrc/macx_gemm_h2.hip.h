@@ -52,7 +52,6 @@ struct GemmH2P {
   int nsteps; size_t a_step_bytes;
   size_t bits_step_words;   // uint32 words between the keep bits of consecutive steps
   size_t att_step, dr_step; // floats between att_i / dinfo_i of consecutive steps
-  int* out_qmin;            // [B][Nout/128] minimum exponent of each question's output rows, atomicMin (caller presets 127)
   int dbg;                  // measurement knobs (macx_debug_set(1, mask)): 1 skip the epilogue, 32 skip the in-loop staging,
                             // 64 skip the fragment reads + MFMAs, 256 return at once, 512 return in front of the K loop
 };
@@ -591,19 +590,6 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
       for (int k = 1; k < 16; ++k) s += Px[k * ROWS + tid];          // fixed order
       p.logit_part[(size_t)cb * p.B * p.N + grow0 + tid] = s;
     }
-  }
-  if (p.out_qmin && tid < 64) {
-    // (reads rexp after the barrier below would cost another barrier: recompute from Mx, which is complete here)
-    int mn = 127;
-    for (int r = tid; r < nvalid; r += 64) {
-      float m = Mx[r];
-#pragma unroll
-      for (int k = 1; k < 16; ++k) m = fmaxf(m, Mx[k * ROWS + r]);
-      mn = min(mn, h2_exponent(m));
-    }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) mn = min(mn, __shfl_xor(mn, s, 64));
-    if (tid == 0) atomicMin(p.out_qmin + (size_t)b * p.out.cb() + cb, mn);
   }
   if (COLSUM) {
     const int c4 = tid & 31, rg = tid >> 5;

@@ -144,7 +144,7 @@ __device__ __forceinline__ f32x16 mfma32_f16(const u32x4 a, const u32x4 b, f32x1
 // ---------------------------------------------------------------------------------------------------------------
 template <int NT, int MAXROWS>
 __device__ __forceinline__ void h2_store_tile(const float* T, int ldt, int rows, const H2View& o, size_t row0, int cb,
-                                              float* scratch, int* qmin_out = nullptr) {
+                                              float* scratch) {
   constexpr int RP = (MAXROWS + 63) & ~63;
   constexpr int ITEMS = (16 * RP + NT - 1) / NT;
   const int tid = threadIdx.x;
@@ -173,13 +173,6 @@ __device__ __forceinline__ void h2_store_tile(const float* T, int ldt, int rows,
     reinterpret_cast<int*>(rmax)[16 * rows + tid] = e;
   }
   __syncthreads();
-  if (qmin_out && tid < 64) {       // minimum exponent of the tile's rows (several row blocks of one question: atomicMin)
-    int m = 127;
-    for (int r = tid; r < rows; r += 64) m = min(m, reinterpret_cast<const int*>(rmax)[16 * rows + r]);
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) m = min(m, __shfl_xor(m, s, 64));
-    if (tid == 0) atomicMin(qmin_out, m);
-  }
   const int* rexp = reinterpret_cast<const int*>(rmax) + 16 * rows;
   char* p0 = o.plane(0);
   const size_t pb = o.plane_bytes();
@@ -223,7 +216,6 @@ struct H2FromP {
   uint32_t* bits;                        // site 1 keep bits, row-major [B*N][C/32]; may be null
   uint32_t key2, thr24_2;                // site 2
   uint8_t* bytes2;                       // site 2 keep bytes, slot order [C/8][Rp]; may be null
-  int* qmin;                             // [B][C/128] minimum exponent per question, atomicMin (caller presets 127); may be null
 };
 
 __global__ __launch_bounds__(H2C_THREADS) void h2_from_f32_kernel(H2FromP p) {
@@ -259,7 +251,7 @@ __global__ __launch_bounds__(H2C_THREADS) void h2_from_f32_kernel(H2FromP p) {
     *reinterpret_cast<f32x4*>(T + lrow * H2C_LDT + c4 * 4) = v;
   }
   __syncthreads();
-  h2_store_tile<H2C_THREADS, H2C_ROWS>(T, H2C_LDT, rows, p.out, grow0, cb, scratch, p.qmin ? p.qmin + (size_t)b * p.out.cb() + cb : nullptr);
+  h2_store_tile<H2C_THREADS, H2C_ROWS>(T, H2C_LDT, rows, p.out, grow0, cb, scratch);
   if (p.bytes2) {
     const size_t Rp = p.out.Rp();
     static_assert((H2C_ROWS & (H2C_ROWS - 1)) == 0, "row index by mask");
@@ -291,18 +283,24 @@ __global__ void h2_to_f32_kernel(H2View in, float* out) {
   }
 }
 
-// min over the rows of `nt` H2 tensors (consecutive, `stride_bytes` apart) of the exponents, per 128-column block: the
-// common exponent a contraction over rows brings every row to.  out[cb] must be preset to 127.
-__global__ void h2_min_exp_kernel(const char* base, size_t stride_bytes, int nt, int R, int C, int* out) {
-  __shared__ int red[8][16];
-  const int ncb = C >> 7;
+// Minimum over the rows of the exponents of up to four FAMILIES of H2 tensors (a family: `nt` tensors `stride` bytes apart), per
+// 128-column block: the common exponent a contraction over rows brings every row to.  Plain stores only: workgroup x of family
+// y writes its partial minima to part[(y * gridDim.x + x) * 8 + k]; a consumer takes the minimum over the gridDim.x partials
+// (h2_emin_final).  The rounds before ran these minima as an atomicMin into an array preset by a memset; under HIP-graph replay
+// that pair was seen to run out of order, so no kernel of this library orders itself against a memset any more.
+constexpr int EMIN_NB = 32;
+struct EminList { const char* base[4]; size_t stride[4]; int nt[4]; int R, C; int* part; };
+__global__ __launch_bounds__(256) void h2_emin_list_kernel(EminList L) {
+  __shared__ int red[8][4];
+  const int f = blockIdx.y;
+  const int ncb = L.C >> 7;
   int m[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) m[k] = 127;
-  for (int t = blockIdx.y; t < nt; t += gridDim.y) {
-    const H2View v{const_cast<char*>(base) + (size_t)t * stride_bytes, R, C};
+  for (int t = 0; t < L.nt[f]; ++t) {
+    const H2View v{const_cast<char*>(L.base[f]) + (size_t)t * L.stride[f], L.R, L.C};
     const int8_t* e = v.exps();
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x)
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < L.R; r += gridDim.x * 256)
       for (int k = 0; k < ncb; ++k) m[k] = min(m[k], (int)e[(size_t)r * ncb + k]);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -313,11 +311,18 @@ __global__ void h2_min_exp_kernel(const char* base, size_t stride_bytes, int nt,
     if (lane == 0) red[k][wave] = x;
   }
   __syncthreads();
-  if (threadIdx.x < ncb) {
-    int x = red[threadIdx.x][0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) x = min(x, red[threadIdx.x][w]);
-    atomicMin(out + threadIdx.x, x);            // integer min: order-independent, deterministic
+  if (threadIdx.x < 8) {
+    int x = 127;
+    if ((int)threadIdx.x < ncb) x = min(min(red[threadIdx.x][0], red[threadIdx.x][1]), min(red[threadIdx.x][2], red[threadIdx.x][3]));
+    L.part[((size_t)f * gridDim.x + blockIdx.x) * 8 + threadIdx.x] = x;
   }
+}
+// the family's common exponent of column block k from its nb partials (an all-zero family keeps exponent-0 rows: 127 never
+// reaches a kernel)
+__device__ __forceinline__ int h2_emin_final(const int* part, int nb, int k) {
+  int m = 127;
+  for (int b = 0; b < nb; ++b) m = min(m, part[(size_t)b * 8 + k]);
+  return min(m, 126);
 }
 
 // ---- weights -------------------------------------------------------------------------------------------------

@@ -47,7 +47,6 @@ struct ReadAttBwdH2P {
   float* dwk_part;       // [B][d]
   float* db2_part;       // [B][d]
   float* dbk_part;       // [B]
-  int* qmin;             // [B][d/128] common (minimum) exponent of the question's dI2 rows, written
   const float* dl;       // [B][N] softmax backward already done (kb_att_dl_kernel): att / da / dbk_part are not touched then
   int no_out;            // 1: only the column sums dc / dwk_part / db2_part (dI2 comes from chain_bwd_kernel)
 };
@@ -115,7 +114,6 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
   float a_dc[8], a_dw[8], a_db[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) a_dc[e] = a_dw[e] = a_db[e] = 0.f;
-  int emin = 127;
 
   // (the activation is selected by ONE switch around the row loop, not per value: see the row pass of kb_gemm_h2_kernel)
   auto rows = [&](auto act_c) {
@@ -171,7 +169,6 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
           *reinterpret_cast<u32x4*>(dst) = hi;
           *reinterpret_cast<u32x4*>(dst + opb) = lo;
           if (wave == 0) p.dI2.exps()[row * ocb + slab] = (int8_t)ex;
-          emin = min(emin, ex);
         }
       }
       __syncthreads();                    // s_mx is reused by the next pass
@@ -183,11 +180,6 @@ __global__ __launch_bounds__(RABH_THREADS) void read_att_bwd_h2_kernel(ReadAttBw
     case ACT_ELU: rows(std::integral_constant<int, ACT_ELU>{}); break;
     case ACT_RELU: rows(std::integral_constant<int, ACT_RELU>{}); break;
     default: rows(std::integral_constant<int, ACT_NON>{}); break;
-  }
-  if (wave == 0 && !p.no_out) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) emin = min(emin, __shfl_xor(emin, s, 64));
-    if (lane == 0) p.qmin[(size_t)b * ocb + slab] = emin;
   }
   // column sums: this wave's 8 columns, summed over its lanes' rows
 #pragma unroll
@@ -238,8 +230,9 @@ struct TnH2P {
   int R;                 // rows per H2 tensor
   const char* A; size_t a_stride; int a_mod;     // a_mod > 0: A row of reduction row m is m % a_mod of tensor 0
   const char* G; size_t g_stride;
-  const int* ecomA;      // [Kd/128] common exponents (qmin_reduce)
-  const int* ecomG;      // [Jd/128]
+  const int* ecomA;      // [ecom_nb][8] partial minima of A's row exponents per 128-column block (h2_emin_list_kernel)
+  const int* ecomG;      // [ecom_nb][8] ... of G's
+  int ecom_nb;
   uint16_t* ftab;        // [Kd/128][Jd/128][Mpad] combined row factors, Mpad = wgrad_h2_mpad(M)
   float* part;           // [nsplit][Kd][Jd]
   int dbg;               // measurement knobs (macx_debug_set(1, mask)): 1024 skip fragments + MFMAs, 2048 skip the in-loop DMA
@@ -264,6 +257,12 @@ template <int KW, int JW> constexpr int wh_ring() { return KW + JW == 4 ? 2 : (K
 
 // one thread per reduction row: the fp16 factor of every (A block, G block) pair
 __global__ __launch_bounds__(256) void wgrad_h2_factors_kernel(TnH2P p) {
+  __shared__ int sE[2][8];
+  if (threadIdx.x < 16) {
+    const int w = threadIdx.x >> 3, k = threadIdx.x & 7;
+    sE[w][k] = h2_emin_final(w ? p.ecomG : p.ecomA, p.ecom_nb, k);
+  }
+  __syncthreads();
   const size_t mpad = wgrad_h2_mpad((size_t)p.M);
   const size_t m = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= mpad) return;
@@ -278,9 +277,9 @@ __global__ __launch_bounds__(256) void wgrad_h2_factors_kernel(TnH2P p) {
   const int8_t* ea = reinterpret_cast<const int8_t*>(p.A + (p.a_mod ? 0 : (size_t)ti * p.a_stride) + 2 * a0.plane_bytes()) + (size_t)ar * acb;
   const int8_t* eg = reinterpret_cast<const int8_t*>(p.G + (size_t)ti * p.g_stride + 2 * g0.plane_bytes()) + (size_t)rr * gcb;
   for (int k = 0; k < acb; ++k) {
-    const int da = p.ecomA[k] - (int)ea[k];
+    const int da = sE[0][k] - (int)ea[k];
     for (int j = 0; j < gcb; ++j)
-      p.ftab[((size_t)k * gcb + j) * mpad + m] = (uint16_t)(pk_pow2_f16(da + p.ecomG[j] - (int)eg[j]) & 0xFFFFu);
+      p.ftab[((size_t)k * gcb + j) * mpad + m] = (uint16_t)(pk_pow2_f16(da + sE[1][j] - (int)eg[j]) & 0xFFFFu);
   }
 }
 
@@ -421,7 +420,7 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
 
   // ---- the slab leaves through LDS, 32 rows of the wave's share at a time (row-major in the wave's own corner of the idle
   //      ring, read back as float4): a store instruction writes whole 128 / 256-byte row segments instead of 64-byte pieces
-  const float sc = h2_unscale(p.ecomA[tk * KW + aq], p.ecomG[tj * JW + gq]);
+  const float sc = h2_unscale(h2_emin_final(p.ecomA, p.ecom_nb, tk * KW + aq), h2_emin_final(p.ecomG, p.ecom_nb, tj * JW + gq));
   float* out = p.part + (size_t)split * p.Kd * p.Jd + (size_t)(tk * KT + wr * 16 * NR) * p.Jd + tj * JT + wc * 32 * JW;
   constexpr int CW = 32 * JW, LDW = CW + 4;
   constexpr int LPR = CW / 4, RPI = 64 / LPR;             // lanes per row, rows per store instruction
@@ -489,18 +488,18 @@ struct SbH2P {
   int qpg;
   H2View X;                // [B*N][d]
   H2View dI1;              // [B*N][d]
-  const int* qminX;        // [B][d/128] common exponent of each question's rows (written by the producer of X)
-  const int* qminG;        // [B][d/128] ... of dI1
+  // (the common exponents of a question's rows -- the minimum of their exponent bytes, per operand and 128-column block -- are
+  // found by the kernel itself while it builds its factor table)
   const float* y;          // [B][d]
   const float* W1a;        // [d][d] row-major (k, j)
   float* dW1a_part;        // [ngroup][d][d]
   float* dW1b_part;
   float* dy_part;          // [4*d/128][B][d]; null: dy is not computed here (the chain kernel's stage B2 has it)
   // all steps in one launch (the caller gets dy elsewhere, so nothing in the recurrence waits for S_b): the operands of step i
-  // lie x_step / g_step BYTES, y_step FLOATS and qx_step / qg_step INTS behind step 0's; the two accumulators run through
-  // every step and the slabs are written once
+  // lie x_step / g_step BYTES and y_step FLOATS behind step 0's; the two accumulators run through every step and the slabs
+  // are written once
   int nsteps;
-  size_t x_step, g_step, y_step, qx_step, qg_step;
+  size_t x_step, g_step, y_step;
   int dbg;                 // measurement knobs (macx_debug_set(1, mask)): 512 skip the per-question fold, 1024 skip fragments + MFMAs,
                            // 2048 skip the DMA issue
 };
@@ -518,6 +517,7 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   uint16_t* ftab = reinterpret_cast<uint16_t*>(lds + SBH_RING * SBH_STAGE);      // [questions][nchunk * 32] combined row factors (fp16)
   float* ytab = reinterpret_cast<float*>(lds + SBH_RING * SBH_STAGE + SBH_MAXROWS * 2);   // [questions][128] y_b of this tile's k rows
   float* sctab = ytab + SBH_MAXQ * T_TILE;                // [questions] 2^-(EX + EG): the unit of a question's S_b
+  int* qmn = reinterpret_cast<int*>(sctab + SBH_MAXQ);    // [2][questions] minimum exponent of the question's X / dI1 rows (this tile's blocks)
 
   const int nt = p.d / T_TILE;
   const int ntile = nt * nt;
@@ -543,7 +543,6 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   // the current step's operands
   H2View vX = p.X, vG = p.dI1;
   const float* yS = p.y;
-  const int *qxS = p.qminX, *qgS = p.qminG;
   const int rows_q = nchunk * 32;                         // table rows per question (rows past N hold factor 0)
 
   // ---- staging: instruction u of a stage (u = 4 wave .. 4 wave + 3) fills column tile u & 7 of image u >> 3
@@ -567,22 +566,42 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
     }
   };
   auto tables = [&]() __attribute__((always_inline)) {
-  // ---- factor table
+  // ---- the questions' common exponents: integer minima through LDS (order-independent), one LDS atomic per wave, question and
+  //      operand -- then the factor table
+  if (tid < 2 * SBH_MAXQ) qmn[tid] = 127;
+  __syncthreads();
+  for (int i0 = 0; i0 < nq * rows_q; i0 += 512) {
+    const int i = i0 + tid;
+    const int qi = i / rows_q, n = i - qi * rows_q;
+    int ex = 127, eg = 127;
+    if (i < nq * rows_q && n < p.N) {
+      const size_t row = (size_t)(b_begin + qi) * p.N + n;
+      ex = (int)vX.exps()[row * xcb + tk];
+      eg = (int)vG.exps()[row * gcb + tj];
+    }
+    const int q_lo = min(i0 + (tid & ~63), nq * rows_q - 1) / rows_q, q_hi = min(i0 + (tid | 63), nq * rows_q - 1) / rows_q;   // questions of this wave's rows
+    for (int q = q_lo; q <= q_hi; ++q) {
+      int mx = qi == q ? ex : 127, mg = qi == q ? eg : 127;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mx = min(mx, __shfl_xor(mx, o, 64)); mg = min(mg, __shfl_xor(mg, o, 64)); }
+      if (lane == 0) { atomicMin(qmn + q, mx); atomicMin(qmn + SBH_MAXQ + q, mg); }
+    }
+  }
+  __syncthreads();
   for (int i = tid; i < nq * rows_q; i += 512) {
     const int qi = i / rows_q, n = i - qi * rows_q;
     const int b = b_begin + qi;
     uint16_t f = 0;
     if (n < p.N) {
       const size_t row = (size_t)b * p.N + n;
-      const int k = (qxS[(size_t)b * xcb + tk] - (int)vX.exps()[row * xcb + tk]) +
-                    (qgS[(size_t)b * gcb + tj] - (int)vG.exps()[row * gcb + tj]);
+      const int k = (min(qmn[qi], 126) - (int)vX.exps()[row * xcb + tk]) + (min(qmn[SBH_MAXQ + qi], 126) - (int)vG.exps()[row * gcb + tj]);
       f = (uint16_t)(pk_pow2_f16(k) & 0xFFFFu);
     }
     ftab[i] = f;
   }
   for (int i = tid; i < nq * T_TILE; i += 512)
     ytab[i] = yS[(size_t)(b_begin + (i >> 7)) * p.d + tk * T_TILE + (i & 127)];
-  if (tid < nq) sctab[tid] = h2_unscale(qxS[(size_t)(b_begin + tid) * xcb + tk], qgS[(size_t)(b_begin + tid) * gcb + tj]);
+  if (tid < nq) sctab[tid] = h2_unscale(min(qmn[tid], 126), min(qmn[SBH_MAXQ + tid], 126));
   };
 
   f32x4 accS[4][2], accA[4][2], accB[4][2];
@@ -676,7 +695,7 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
 #pragma unroll 1
   for (int step = 0; step < p.nsteps; ++step) {
   vX.base = p.X.base + (size_t)step * p.x_step; vG.base = p.dI1.base + (size_t)step * p.g_step;
-  yS = p.y + (size_t)step * p.y_step; qxS = p.qminX + (size_t)step * p.qx_step; qgS = p.qminG + (size_t)step * p.qg_step;
+  yS = p.y + (size_t)step * p.y_step;
   if (total > 0) {                                        // in flight while the tables are built
     issue(0);
     issue(1);
@@ -732,7 +751,7 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
 inline hipError_t sb_h2_launch(const SbH2P& p, hipStream_t st) {
   const int nchunk = (p.N + 31) >> 5;
   if (p.qpg * nchunk * 32 > SBH_MAXROWS || p.qpg > SBH_MAXQ) return hipErrorInvalidValue;
-  constexpr size_t lds = SBH_RING * SBH_STAGE + SBH_MAXROWS * 2 + SBH_MAXQ * T_TILE * 4 + SBH_MAXQ * 4;
+  constexpr size_t lds = SBH_RING * SBH_STAGE + SBH_MAXROWS * 2 + SBH_MAXQ * T_TILE * 4 + SBH_MAXQ * 4 + 2 * SBH_MAXQ * 4;
   if (p.nsteps < 1 || (p.nsteps > 1 && p.dy_part)) return hipErrorInvalidValue;    // dy is per step: its buffer is not
   auto kern = p.dy_part ? sb_h2_kernel<true> : sb_h2_kernel<false>;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);

@@ -103,3 +103,105 @@ class CapturedForward:
     def __call__(self, vecQuestions, words, lengths, knowledgeBase):
         self.load(vecQuestions, words, lengths, knowledgeBase)
         return self.replay()
+
+
+class CapturedTrainStep:
+    """Forward + backward of the cell (train-mode dropout, every gradient) replayed from ONE captured HIP graph.
+
+        step = macx.CapturedTrainStep(cfg, params, B=64, S=50, N=196, seed=1234)
+        step.load(vecQuestions, words, lengths, knowledgeBase, d_memory)     # or write into step.knowledgeBase etc.
+        step.replay()                        # params' .grad, step.knowledgeBase.grad, step.words.grad, step.vecQuestions.grad
+        memory = step.memory                 # [B, d] final memory of the run
+
+    About 140 launches per step (p = 12) plus what autograd adds around them; a host that cannot issue them faster than the
+    GPU retires them (gpurun boxes differ by 7x in host speed) sets the pace of the eager step, a replay does not depend on it.
+    Nothing in the step orders itself against a memset any more (round 4: the minimum-exponent arrays behind the deferred
+    contractions were the last memset-then-atomicMin pair), which is what makes the backward pass capturable.
+
+    LIMIT -- the dropout masks are a function of (seed, site, step, element) and the seed travels BY VALUE in the kernel
+    parameters: every replay draws the masks of the captured seed.  That is exact for measurement and for a fixed-mask
+    evaluation of gradients; a training loop that wants fresh masks per step re-captures (or runs eagerly).  Lifting it needs
+    the seed in device memory, read by the dozen kernels that hash -- not done.
+
+    `verify=True` replays three times against the eager step on random inputs and falls back to eager launches when a replay
+    differs in any gradient (`captured` False, a warning says so)."""
+
+    def __init__(self, config, params, B, S, N, seed=0, device=None, netLength=None, b0=0, warmup=2, verify=True):
+        dev = torch.device(device) if device is not None else params.tensors()[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("CapturedTrainStep needs the HIP device: the MAC cell has no CPU path")
+        d = int(get(config, "memDim"))
+        self.config, self.params, self.seed, self.b0 = config, params, int(seed), int(b0)
+        self.netLength = int(netLength if netLength is not None else get(config, "netLength"))
+        self.vecQuestions = torch.zeros(B, d, device=dev, requires_grad=True)
+        self.words = torch.zeros(B, S, d, device=dev, requires_grad=True)
+        self.lengths = torch.full((B,), S, dtype=torch.int32, device=dev)
+        self.knowledgeBase = torch.zeros(B, N, d, device=dev, requires_grad=True)
+        self.d_memory = torch.zeros(B, d, device=dev)
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._eager()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._clear_grads()
+        with torch.cuda.graph(self.graph):
+            self.memory = self._eager()
+        self.captured = True
+        if verify and not self._replays_match_eager():
+            self.captured = False
+            warnings.warn("CapturedTrainStep: replays of the captured step do not reproduce the eager step in this process; "
+                          "falling back to eager launches", RuntimeWarning)
+
+    def _leaves(self):
+        return [self.vecQuestions, self.words, self.knowledgeBase] + list(self.params.tensors())
+
+    def _clear_grads(self):
+        for t in self._leaves():
+            t.grad = None
+
+    def _eager(self):
+        self._clear_grads()
+        cell = MACCell(vecQuestions=self.vecQuestions, questionWords=self.words, questionCntxWords=self.words,
+                       questionLengths=self.lengths, knowledgeBase=self.knowledgeBase,
+                       memoryDropout=float(get(self.config, "memoryDropout")), readDropout=float(get(self.config, "readDropout")),
+                       writeDropout=float(get(self.config, "writeDropout")), batchSize=self.vecQuestions.shape[0], train=True,
+                       config=self.config, params=self.params, netLength=self.netLength, seed=self.seed, b0=self.b0)
+        state = cell.run()
+        torch.autograd.backward([state.memory], [self.d_memory])
+        return state.memory.detach()
+
+    def _replays_match_eager(self, replays=3):
+        g = torch.Generator().manual_seed(20240520)
+        dev = self.knowledgeBase.device
+        with torch.no_grad():
+            for t in (self.vecQuestions, self.words, self.knowledgeBase, self.d_memory):
+                t.copy_(torch.randn(t.shape, generator=g).to(dev))
+        captured_grads = [t.grad for t in self._leaves()]        # the tensors the graph writes
+        mem = self._eager().clone()
+        want = [t.grad.clone() for t in self._leaves()]
+        for t, gcap in zip(self._leaves(), captured_grads):
+            t.grad = gcap
+        ok = True
+        for _ in range(replays):
+            self.graph.replay()
+            ok = ok and bool(torch.equal(self.memory, mem)) and all(torch.equal(t.grad, w) for t, w in zip(self._leaves(), want))
+        torch.cuda.synchronize(dev)
+        return ok
+
+    def load(self, vecQuestions, words, lengths, knowledgeBase, d_memory):
+        with torch.no_grad():
+            self.vecQuestions.copy_(vecQuestions)
+            self.words.copy_(words)
+            self.lengths.copy_(lengths)
+            self.knowledgeBase.copy_(knowledgeBase)
+            self.d_memory.copy_(d_memory)
+
+    def replay(self):
+        if self.captured:
+            self.graph.replay()
+        else:
+            self.memory = self._eager()
+        return self.memory

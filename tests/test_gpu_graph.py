@@ -47,3 +47,39 @@ def test_eager_fallback_behind_the_same_interface(macx, dev):
     torch.cuda.synchronize()
     assert torch.equal(ref, got)
     assert all(torch.equal(a, b) for a, b in zip(cell.attentions["kb"], cap.attentions["kb"]))
+
+
+def test_captured_train_step_equals_eager(macx, dev):
+    """forward + backward from one captured HIP graph: final memory and EVERY gradient bit for bit the eager step's, over
+    several replays and after new inputs (nothing in the step orders itself against a memset any more)"""
+    B, S, N, d, p = 6, 7, 40, 128, 3
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=d, ctrlDim=d, attDim=d)
+    params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(0)).to(dev)
+    step = macx.CapturedTrainStep(cfg, params, B, S, N, seed=77)
+    assert step.captured, "the capture's self-check failed in this process"
+    for seed in (1, 2):
+        vq, words, lengths, kb = [t.to(dev) for t in macx.configs.synthetic_inputs(B, S, N, d, seed=seed)]
+        gm = torch.randn(B, d, generator=torch.Generator().manual_seed(seed)).to(dev)
+        step.load(vq, words, lengths, kb, gm)
+        for _ in range(2):
+            mem = step.replay().clone()
+            got = [t.grad.clone() for t in step._leaves()]
+            # the eager step on the same static tensors (replays write into the captured .grad tensors: keep and restore them)
+            keep = [t.grad for t in step._leaves()]
+            ref_mem = step._eager().clone()
+            ref = [t.grad.clone() for t in step._leaves()]
+            for t, g in zip(step._leaves(), keep):
+                t.grad = g
+            torch.cuda.synchronize()
+            assert torch.equal(mem, ref_mem)
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b)
+
+
+def test_captured_train_step_metric_shape(macx, dev):
+    """... at the metric's shape (B = 64, N = 196, d = 512, p = 12): the chain kernels' 64-row tiles, the deferred contractions"""
+    B, S, N, d, p = 64, 50, 196, 512, 12
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=d, ctrlDim=d, attDim=d)
+    params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(0)).to(dev)
+    step = macx.CapturedTrainStep(cfg, params, B, S, N, seed=5)         # verify=True: three replays against the eager step
+    assert step.captured

@@ -3,7 +3,9 @@
 copies the kernel-stats / PMC summaries / bench line and derives profiles/<tag>_roofline_inputs.json -- per-launch HBM bytes
 of the dominant kernel (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes, KiB per dispatch) and the in-step average
 durations + GB/s of the HBM-bound kernels -- which bench.py reports as roofline.traffic / roofline.hbm_kernels.
-    python tools/profile_post.py r02"""
+    python tools/profile_post.py r02
+The kernel-trace / PMC passes run bench.py with --no-probe, so the in-step average of the dominant kernel counts the step's own
+launches only (round 3's folded the roofline probe's 50 launches in)."""
 import json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,7 +61,7 @@ def main(tag):
     if gv:
         fetch, write = float(gv[fi]), float(gv[wi])
         out.update(kernel=gk, FETCH_SIZE_KiB=fetch, WRITE_SIZE_KiB=write, hbm_bytes_per_launch=int((2 * fetch + write) * 1024))
-    sk, sv = find(ks, r"chain_fwd_kernelILi512ELi0")
+    sk, sv = find(ks, r"chain_fwd_kernelILi512ELi\d+ELi64")
     if not sv:
         sk, sv = find(ks, r"kb_gemm_h2_kernelILi13ELi0ELi0ELb0")
     if sv:
@@ -76,7 +78,9 @@ def main(tag):
                         "achieved": round(byts / (v["avg_us"] * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(byts / (v["avg_us"] * 1e-6) / 8e12, 4)})
     out["hbm_kernels"] = hbm
+    out["file"] = "profiles/%s_roofline_inputs.json" % tag
     json.dump(out, open(os.path.join(P, "%s_roofline_inputs.json" % tag), "w"), indent=1)
+    json.dump(out, open(os.path.join(P, "latest_roofline_inputs.json"), "w"), indent=1)      # what bench.py reads
     print(json.dumps(out, indent=1)[:1500])
 
 

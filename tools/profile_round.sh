@@ -3,10 +3,10 @@
 # writes gpurun_out/<tag>_*: kernel-trace stats, four separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ, LDS/VALU) and the
 # roofline inputs bench.py reads (profiles/<tag>_roofline_inputs.json after `python tools/profile_post.py <tag>`, run locally).
 # Counter passes never share a run with --stats or any trace domain but the kernel trace.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
-B="python bench.py --no-cpu-baseline --no-model-level --no-native --no-extra-legs"
+B="python bench.py --no-cpu-baseline --no-model-level --no-native --no-extra-legs --no-probe"
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_k -o r -- $B --steps 5 --warmup 2 > $O/${TAG}_k.log 2>&1
 python tools/rocpd_stats.py $O/${TAG}_k/r_results.db > $O/${TAG}_kernel_stats.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_f -o f -- $B --steps 1 --warmup 0 > $O/${TAG}_f.log 2>&1
