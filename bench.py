@@ -134,6 +134,70 @@ def model_level(macx, dev, seed, steps=6):
             "flops_per_question_fwd_bwd": 3 * (P * flops_per_question_step() + stem_flops)}
 
 
+def model_level_dp(macx, dev, dist, world, rank, global_batch, seed, steps=5):
+    """The whole tower data-parallel (model.py:775-826): every rank runs encoder + stem + cell + classifier on its tower slice of
+    `global_batch` questions, the 57 MB flat gradient is exchanged in two buckets (macx.dp.TowerBuckets: the classifier's and the
+    cell's early gradients from the cell's phase-1 hook, the rest after backward), then clip + Adam + EMA on the reduced buffer
+    (clip after the exchange, model.py:645-650)."""
+    lo, hi = macx.dp.tower_slice(global_batch, rank, world)
+    bl = hi - lo
+    cfg = macx.configs.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
+    VOCAB = 90
+    net = macx.MACNet(cfg, vocab=VOCAB, generator=torch.Generator().manual_seed(seed)).to(dev)
+    bucket = macx.dp.TowerBuckets(net)
+    opt = macx.optim.FlatAdamEMA(bucket.tensors(), lr=1e-4, clip_norm=8.0, ema_decay=0.999)
+    g = torch.Generator().manual_seed(seed + rank)
+    _, _, lengths, _ = macx.configs.synthetic_inputs(bl, S, 1, 8, seed=seed + rank)
+    img = torch.relu(torch.randn(bl, N, 1024, generator=g)).to(dev)
+    qs = torch.randint(1, VOCAB + 1, (bl, S), generator=g, dtype=torch.int32)
+    qs = (qs * (torch.arange(S).unsqueeze(0) < lengths.unsqueeze(1)).to(torch.int32)).to(dev)
+    lengths = lengths.to(dev)
+    ans = torch.randint(0, 28, (bl,), generator=g).to(dev)
+
+    def one(i):
+        for t in net.tensors():
+            t.grad = None
+        logits = net(img, qs, lengths, train=True, seed=seed + i, b0=lo, check_ids=False)
+        loss, _ = net.loss_and_pred(logits, ans)
+        bucket.begin_step(bl, global_batch)
+        loss.backward()
+        bucket.allreduce_(bl, global_batch)
+        opt.step(flat_grad=bucket.flat)
+
+    for i in range(3):
+        one(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(3 + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    # the exchange on its own: the whole flat buffer, nothing to overlap with
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ar_ms = None
+    if world > 1:
+        dist.all_reduce(bucket.flat)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            dist.all_reduce(bucket.flat)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 3
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return {"value": round(global_batch * steps / dt, 2), "unit": "questions/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "global_batch": global_batch, "shard_on_rank0": bl, "gradient_bytes": 4 * int(bucket.flat.numel()),
+            "early_bucket_bytes": 4 * int(bucket.early), "overlapped_steps": int(bucket.overlapped_steps),
+            "allreduce_alone_ms": None if ar_ms is None else round(ar_ms, 3),
+            "includes": "encoder + stem + cell (p=%d) + classifier fwd+bwd, two-bucket all-reduce, clip + Adam + EMA" % P}
+
+
 def run_bytes(macx, cfg, b, p):
     """bytes of the two caller-owned buffers of one training run (forward `saved`, backward `ws`) at batch b, p steps"""
     L = macx._lib.lib()
@@ -195,6 +259,45 @@ def fwd_only_p4(macx, dev, seed, p=4, steps=30):
             "roofline": {"bound": "mfma", "executed_tflops": round(executed / dt / 1e12, 1), "peak": PEAK_BF16_MFMA / 1e12,
                          "frac": round(executed / dt / PEAK_BF16_MFMA, 4),
                          "note": "whole forward pass (launch gaps and the [B,d] kernels included) over the fp16-pipe FLOPs it executes"}}
+
+
+def gqa_shape_p4(macx, dev, seed, flag_file, steps=8):
+    """BASELINE configs[4]: GQA-shape knowledge base 7 x 7 x 2048 -> stem (2048 -> 512 -> 512) -> MAC cell with N = 49, p = 4 and
+    the write unit of configs/args3.txt (self-attention) / args4.txt (self-attention + memory gate), fwd + bwd, B = 64."""
+    p, Ng, H, W, Cin = 4, 49, 7, 7, 2048
+    cfg = macx.configs.flag_file_config(flag_file, netLength=p, memDim=D, ctrlDim=D, attDim=D)
+    stem = macx.Stem(cfg, H=H, W=W, inDim=Cin, generator=torch.Generator().manual_seed(seed)).to(dev)
+    params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(seed)).to(dev)
+    vq, words, lengths, _ = macx.configs.synthetic_inputs(B, S, 1, D, seed=seed)
+    vqd, wd = [t.to(dev).requires_grad_(True) for t in (vq, words)]
+    ld = lengths.to(dev)
+    img = torch.relu(torch.randn(B, Ng, Cin, generator=torch.Generator().manual_seed(seed))).to(dev)
+    gmem = (torch.randn(B, D, generator=torch.Generator().manual_seed(1)) / B).to(dev)
+    leaves = [vqd, wd] + stem.tensors() + params.tensors()
+
+    def one(i):
+        for t in leaves:
+            t.grad = None
+        kb = stem(img, train=True, seed=seed + i)
+        cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=ld, knowledgeBase=kb,
+                            memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout, writeDropout=cfg.writeDropout,
+                            batchSize=B, train=True, config=cfg, params=params, seed=seed + i)
+        torch.autograd.backward([cell.run().memory], [gmem])
+
+    for i in range(3):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(3 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    cell_flops = 3.0 * p * flops_per_question_step(n=Ng)
+    stem_flops = 3.0 * 2.0 * 9 * Ng * (Cin * 512 + 512 * 512)
+    return {"value": round(B / dt, 1), "unit": "questions/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "p": p, "batch": B,
+            "includes": "stem 7x7x%d -> 512 -> 512 + MAC cell (configs/%s.txt, N=%d, p=%d), fwd+bwd, train-mode dropout" % (Cin, flag_file, Ng, p),
+            "reference_flops_per_question": cell_flops + stem_flops,
+            "fp32_equiv_tflops": round(B / dt * (cell_flops + stem_flops) / 1e12, 1)}
 
 
 def train_step_graph(macx, dev, seed, steps=20):
@@ -436,6 +539,8 @@ def main():
                           "ms_per_step": round(d2 / n2 * 1e3, 3), "steps": n2, "scaling": "weak"}
             del st2
             torch.cuda.empty_cache()
+        extra["model_level_dp"] = model_level_dp(macx, dev, dist, world, rank, global_batch, seed)
+        torch.cuda.empty_cache()
 
     if rank == 0 and args.no_probe:
         print(json.dumps({"metric": "questions/sec fwd+bwd (B=64,d=512,p=12,KB=14x14x1024) at 1/2/4/8 MI355X", "value": round(qps, 2),
@@ -606,6 +711,8 @@ def main():
             out["fwd_only_p4"] = fwd_only_p4(macx, dev, seed)
             out["train_b128_p12_adam_ema"] = train_b128_p12(macx, dev, dist, seed)
             out["train_step_graph"] = train_step_graph(macx, dev, seed)
+            out["gqa_shape_p4_args3"] = gqa_shape_p4(macx, dev, seed, "args3")
+            out["gqa_shape_p4_args4"] = gqa_shape_p4(macx, dev, seed, "args4")
         if world == 1 and not args.no_model_level:
             out["model_level"] = model_level(macx, dev, seed)
         if world == 1 and not args.no_cpu_baseline:

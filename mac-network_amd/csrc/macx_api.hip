@@ -1848,8 +1848,8 @@ int macx_embed_lookup(const int32_t* ids, const float* emb, int rows, int E, int
 
 int macx_embed_lookup_bwd(const int32_t* ids, const float* dx, int rows, int E, int ld, int V, float keep, uint32_t seed,
                           uint32_t first_row, float* d_emb, void* stream) {
-  if (!ids || !dx || !d_emb || rows < 1 || E < 1 || E > 1024 || ld < E || V < 1) return MACX_EINVAL;   // (embed_grad_kernel: 4 columns per thread)
-  hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, dx, rows, E, ld, first_row,
+  if (!ids || !dx || !d_emb || rows < 1 || E < 1 || ld < E || V < 1) return MACX_EINVAL;
+  hipLaunchKernelGGL(embed_grad_kernel, dim3(V, (E + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, ids, dx, rows, E, ld, first_row,
                      make_drop(keep, seed, SITE_ENC_INPUT, 0), d_emb);
   CK(hipGetLastError());
   return MACX_OK;
@@ -2330,7 +2330,7 @@ EncBwdLayout make_enc_bwd(const macx_enc_shapes* s) {
   return L;
 }
 int enc_check(const macx_enc_shapes* s) {
-  if (!s || s->B < 1 || s->S < 1 || s->V < 1 || s->E < 1 || s->E > 1024 || s->h < 128 || s->h % 128) return MACX_EINVAL;
+  if (!s || s->B < 1 || s->S < 1 || s->V < 1 || s->E < 1 || s->h < 128 || s->h % 128) return MACX_EINVAL;
   return MACX_OK;
 }
 }  // namespace
@@ -2446,7 +2446,7 @@ int macx_encoder_backward(const macx_enc_shapes* s, float keep_input, float keep
     l.Ktot = 2 * G;
     CK(small_linear_launch(l, 1, st));
   }
-  hipLaunchKernelGGL(embed_grad_kernel, dim3(s->V), dim3(256), 0, st, questions, (const float*)(ws + W.dXp), B * S, E, Ep,
+  hipLaunchKernelGGL(embed_grad_kernel, dim3(s->V, (E + 1023) / 1024), dim3(256), 0, st, questions, (const float*)(ws + W.dXp), B * S, E, Ep,
                      (uint32_t)s->b0 * (uint32_t)S, make_drop(keep_input, seed, SITE_ENC_INPUT, 0), Gr->emb);
   CK(hipGetLastError());
   return MACX_OK;

@@ -1288,7 +1288,8 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const int32_t* __restri
   __shared__ int wcount[4];
   const int v = blockIdx.x + 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int CMAX = 4;                           // columns per thread held in registers: E <= 1024
+  constexpr int CMAX = 4;                           // columns per thread held in registers: blockIdx.y selects a chunk of 1024 columns
+  const int c0 = blockIdx.y * 1024;
   float acc[CMAX];
 #pragma unroll
   for (int k = 0; k < CMAX; ++k) acc[k] = 0.f;
@@ -1308,7 +1309,7 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const int32_t* __restri
       const int rr = list[k];
 #pragma unroll
       for (int j = 0; j < CMAX; ++j) {
-        const int c = tid + 256 * j;
+        const int c = c0 + tid + 256 * j;
         if (c < E) acc[j] += drop_apply(dx[(size_t)rr * Ep + c], (uint32_t)((row0 + rr) * E + c), ds);
       }
     }
@@ -1316,7 +1317,7 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const int32_t* __restri
   }
 #pragma unroll
   for (int j = 0; j < CMAX; ++j) {
-    const int c = tid + 256 * j;
+    const int c = c0 + tid + 256 * j;
     if (c < E) demb[(size_t)(v - 1) * E + c] = acc[j];
   }
 }

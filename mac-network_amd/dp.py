@@ -159,3 +159,125 @@ class OverlappedBuckets(GradBucket):
             t.grad = self.flat[o:o + n].view_as(t)
         self._release()
         return self.flat
+
+
+class TowerBuckets:
+    """Data parallelism for the WHOLE tower the reference builds per GPU (model.py:775-826: embeddings, question encoder, stem,
+    MAC cell, output unit + classifier -- 57 MB of fp32 gradients at p = 12), two buckets over ONE flat buffer:
+
+        [ output unit + classifier | cell, early fields | cell, late fields | stem | question encoder ]
+          `--------- early bucket ---------'             `------------ late bucket -------------'
+
+    Backward order decides the split: the classifier's gradients exist before the cell's backward pass starts and the cell's
+    early fields are final after its phase 1 (macx_cell_backward_phase), so that range is all-reduced on a side stream from the
+    cell's phase-1 hook while phase 2 -- and then the stem's and the encoder's backward passes, which need the cell's input
+    gradients -- still run; the rest follows after backward().  The cell's gradient buffer IS its range of the flat buffer
+    (MACCellParams.grad_buffer() is pointed at it), the other modules' gradients are gathered into theirs.  Clipping comes
+    after the exchange, as in model.py:645-650: hand `flat` to optim.FlatAdamEMA(bucket.tensors()).step(flat_grad=bucket.flat).
+
+        bucket = TowerBuckets(net); opt = FlatAdamEMA(bucket.tensors(), ...)
+        bucket.begin_step(shard, global_batch); loss.backward(); bucket.allreduce_(shard, global_batch); opt.step(bucket.flat)
+    """
+
+    def __init__(self, net, group=None):
+        self.net, self.group = net, group
+        cell = net.cell
+        if not hasattr(cell, "early_floats"):
+            raise TypeError("TowerBuckets needs the fused cell's parameters (MACCellParams); a generic-path cell is exchanged with "
+                            "GradBucket(net.tensors())")
+        enc = list(net.enc.tensors()) if hasattr(net, "enc") else []
+        groups = [list(net.out.tensors()), list(cell.tensors()), list(net.stem.tensors()), enc]
+        self._tensors = [t for g in groups for t in g]
+        self.sizes = [t.numel() for t in self._tensors]
+        self.offsets, off = [], 0
+        for n in self.sizes:
+            self.offsets.append(off)
+            off += (n + 3) & ~3
+        dev = self._tensors[0].device
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        n_out = len(groups[0])
+        self.cell_lo = self.offsets[n_out]
+        cell_floats = sum((t.numel() + 3) & ~3 for t in groups[1])
+        self.cell_hi = self.cell_lo + cell_floats
+        # the cell's backward pass writes straight into its range
+        object.__setattr__(cell, "_grad_flat", self.flat[self.cell_lo:self.cell_hi])
+        cell.register_grad_buffer_user()
+        cell.after_backward_phase1 = self._phase1
+        self.early = self.cell_lo + cell.early_floats()
+        self.n_out = n_out
+        self.n_cell = len(groups[1])
+        self.weight = 1.0
+        self._early_work, self._early_started = None, False
+        self.side = torch.cuda.Stream(device=dev) if self.flat.is_cuda else None
+        self.overlapped_steps = 0
+        self.allreduce_ms = None
+
+    def tensors(self):
+        """the parameters in the flat buffer's order (what optim.FlatAdamEMA must be built over to take `flat` as it is)"""
+        return list(self._tensors)
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def begin_step(self, shard_size, global_size):
+        self.weight = float(shard_size) / float(global_size)
+        self._early_started, self._early_work = False, None
+
+    def _gather(self, lo, hi):
+        for t, o, n in zip(self._tensors[lo:hi], self.offsets[lo:hi], self.sizes[lo:hi]):
+            dst = self.flat[o:o + n]
+            if t.grad is None:
+                dst.zero_()
+            elif t.grad.data_ptr() != dst.data_ptr():
+                dst.copy_(t.grad.reshape(-1))
+
+    def _phase1(self, flat):
+        if flat.data_ptr() != self.flat.data_ptr() + 4 * self.cell_lo:
+            return                                    # this backward pass got a buffer of its own: everything goes late
+        if any(t.grad is None for t in self._tensors[:self.n_out]):
+            return                                    # the classifier's gradients are not there yet (unusual graph): all late
+        self._gather(0, self.n_out)
+        if not self._active():
+            self._early_started = True
+            return
+        part = self.flat[:self.early]
+        cur = torch.cuda.current_stream(self.flat.device) if self.side is not None else None
+        if self.side is not None:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                if self.weight != 1.0:
+                    part.mul_(self.weight)
+                self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            if self.weight != 1.0:
+                part.mul_(self.weight)
+            self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._early_started = True
+
+    def allreduce_(self, shard_size, global_size):
+        w = float(shard_size) / float(global_size)
+        cell_ok = all(t.grad is not None and t.grad.data_ptr() == self.flat.data_ptr() + 4 * o
+                      for t, o in zip(self._tensors[self.n_out:self.n_out + self.n_cell], self.offsets[self.n_out:self.n_out + self.n_cell]))
+        early_done = self._early_started and w == self.weight and cell_ok
+        if self._early_started and not early_done:
+            raise RuntimeError("the early bucket is already in flight but the cell's gradients are not views of the flat buffer")
+        lo = self.early if early_done else 0
+        if not early_done:
+            self._gather(0, self.n_out + self.n_cell)
+        self._gather(self.n_out + self.n_cell, len(self._tensors))
+        late = self.flat[lo:]
+        if w != 1.0:
+            late.mul_(w)
+        if self._active():
+            dist.all_reduce(late, op=dist.ReduceOp.SUM, group=self.group)
+            if self._early_work is not None:
+                self._early_work.wait()
+        if self.side is not None and early_done:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+        if early_done:
+            self.overlapped_steps += 1
+        self._early_started = False
+        for t, o, n in zip(self._tensors, self.offsets, self.sizes):
+            t.grad = self.flat[o:o + n].view_as(t)
+        self.net.cell.release_grad_buffer()
+        return self.flat

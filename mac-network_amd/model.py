@@ -27,12 +27,16 @@ class MACNetCore(torch.nn.Module):
             freeze(config)
             self.cell = MACCellParams(config, self.netLength, generator=generator)
         except UnsupportedOptions:
-            # an option set of the generic path (the reference's default configuration among them): its variables appear
-            # under the reference's names the first time the cell runs (generic.GenericParams), so build the optimizer after
-            # one forward pass -- or load a checkpoint into `net.cell` first
+            # an option set of the generic path (the reference's default configuration among them).  The option set and the
+            # net length are known here, so the plan is compiled now and every variable it names is created now, in the plan's
+            # (= TensorFlow's creation) order: tensors(), the optimizer's layout and a checkpoint load (missing / extra / shape
+            # checks of checkpoint.load_reference) see exactly the variables the cell will use -- nothing is adopted by scope and
+            # nothing is drawn at random behind a loaded checkpoint's back on the first forward pass
+            from . import plan as _plan
             from .generic import GenericParams
             self.cell = GenericParams(generator=generator)
-            self.cell.lazy_scopes = ("MACnetwork/",)       # checkpoint.load_*: adopt every variable of the cell's scope
+            for name, spec in _plan.compile_cell(config, self.netLength).variables.items():
+                self.cell.ensure(name, spec.shape, spec.init)
         self.out = OutputClassifier(config, answerWordsNum=answerWordsNum, generator=generator)
 
     def tensors(self):

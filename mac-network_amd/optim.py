@@ -12,7 +12,14 @@ from . import _lib
 
 
 class FlatAdamEMA:
-    def __init__(self, params, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, clip_norm=8.0, ema_decay=0.999):
+    def __init__(self, params, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, clip_norm=8.0, ema_decay=0.999, grad_owner=None):
+        """grad_owner: the MACCellParams whose grad_buffer() will be handed to step(flat_grad=...) by a cell-only training loop
+        with no data-parallel bucket in between -- this optimizer then is the buffer's flat consumer: it registers (the backward
+        pass writes into the persistent buffer only for a registered consumer) and releases the buffer at the end of every
+        step.  With a dp.GradBucket / OverlappedBuckets / TowerBuckets the bucket is the consumer: leave this None."""
+        self.grad_owner = grad_owner
+        if grad_owner is not None:
+            grad_owner.register_grad_buffer_user()
         self.params = [p for p in params]
         if not self.params or not self.params[0].is_cuda:
             raise RuntimeError("FlatAdamEMA needs parameters on the HIP device")
@@ -41,8 +48,13 @@ class FlatAdamEMA:
 
     def step(self, flat_grad=None):
         """flat_grad: an already flat gradient in THIS layout -- the parameters in order, each segment padded to a multiple of
-        4 floats (dp.GradBucket.flat after the all-reduce, MACCellParams.grad_buffer() for a cell-only optimizer); a buffer of
-        any other size is rejected.  Without it the .grad of every parameter is gathered."""
+        4 floats: dp.GradBucket.flat / TowerBuckets.flat after the all-reduce, or MACCellParams.grad_buffer() for a cell-only
+        optimizer built with grad_owner= (without a registered consumer the backward pass does not write into that buffer: a
+        stale or zero gradient would be stepped on -- refused below).  A buffer of any other size is rejected.  Without
+        flat_grad the .grad of every parameter is gathered."""
+        if flat_grad is not None and self.grad_owner is None and getattr(flat_grad, "_macx_cell_grad_buffer", False):
+            raise ValueError("this is a MACCellParams.grad_buffer(): build the optimizer with grad_owner=params so that the backward "
+                             "pass writes into it")
         if flat_grad is None:
             for p, k, off in zip(self.params, self.sizes, self.offsets):
                 if p.grad is None:
@@ -60,6 +72,8 @@ class FlatAdamEMA:
         _lib.check(L.macx_adam_ema_step(self.flat.numel(), p_(self.flat), p_(flat_grad), p_(self.m), p_(self.v), p_(self.ema), self.lr,
                                         self.beta1, self.beta2, self.eps, self.t, self.clip_norm, self.ema_decay, p_(self.ws),
                                         p_(self.norm), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "macx_adam_ema_step")
+        if self.grad_owner is not None:
+            self.grad_owner.release_grad_buffer()          # the step's gradients are consumed: the next backward may claim the buffer
         return self.norm
 
     def ema_state(self):

@@ -118,14 +118,15 @@ class MACCellParams(torch.nn.Module):
     def grad_buffer(self):
         """Persistent flat fp32 buffer the backward pass writes the parameter gradients into (16-byte aligned segments in
         `fields` order): the gradients autograd hands out are views of it, so a data-parallel all-reduce (macx.dp.GradBucket)
-        or a flat optimizer over exactly these tensors (optim.FlatAdamEMA uses the same padded layout) can run on it without a
-        gather copy.  Allocated on first use; the backward pass only writes into it for a registered consumer
-        (register_grad_buffer_user), once per step."""
+        or a flat optimizer over exactly these tensors (optim.FlatAdamEMA(..., grad_owner=params) uses the same padded layout)
+        can run on it without a gather copy.  Allocated on first use; the backward pass only writes into it for a registered
+        consumer (register_grad_buffer_user), once per step, until the consumer releases it (release_grad_buffer)."""
         dev = self.tensors()[0].device
         n = sum((t.numel() + 3) & ~3 for t in self.tensors())
         buf = getattr(self, "_grad_flat", None)
         if buf is None or buf.numel() != n or buf.device != dev:
             buf = torch.zeros(n, dtype=torch.float32, device=dev)
+            buf._macx_cell_grad_buffer = True          # optim.FlatAdamEMA.step refuses it from an optimizer that is not its consumer
             object.__setattr__(self, "_grad_flat", buf)
         return buf
 

@@ -89,7 +89,10 @@ def u_from_mask(mask, keep):
     return m * (1.0 - keep / 2.0) + (1.0 - m) * ((1.0 - keep) / 2.0)
 
 
-def hip_case(name, p, B=2, S=6, N=20, D=128, HID=64, ANS=28, seed=31):
+def hip_case(name, p, B=2, S=6, N=20, D=128, HID=64, ANS=28, seed=31, compact=False, tag=None):
+    """compact: a full-width case (d = 512, N = 196 -- the chain kernels' 64-row-tile geometry) kept small: the inputs are NOT
+    stored (the test regenerates them from the seed: configs.synthetic_inputs is oracle.synthetic_inputs; two checksums are),
+    and every large gradient travels as its sums along each axis."""
     cfg = rx.parse_flags(name + ".txt", *rx.dims_flags(D, p, HID))
     vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, D, seed=seed, dtype=torch.float32)
     g = torch.Generator().manual_seed(seed + 1)
@@ -121,31 +124,39 @@ def hip_case(name, p, B=2, S=6, N=20, D=128, HID=64, ANS=28, seed=31):
     z = pack_run(ref, cfg, keeps, output_keep, True, answers)
     for k in [k for k in z if k.startswith("draw_")]:
         del z[k]
-    z.update(vecQ=vq.numpy(), words=words.numpy(), lengths=lengths.numpy(), kb=kb.numpy(),
-             shape=np.array([B, S, N, D, p, HID, ANS, seed], dtype=np.int64),
+    if compact:
+        z.update(lengths=lengths.numpy(), input_checksums=np.array([float(kb.double().sum()), float(kb.double().abs().sum()),
+                                                                    float(words.double().sum()), float(vq.double().sum())]))
+    else:
+        z.update(vecQ=vq.numpy(), words=words.numpy(), lengths=lengths.numpy(), kb=kb.numpy())
+    z.update(shape=np.array([B, S, N, D, p, HID, ANS, seed], dtype=np.int64),
              var_shapes=np.frombuffer(json.dumps({k: list(s) for k, s in shapes.items()}).encode(), dtype=np.uint8))
     for k, v in ref["variables"].items():
         gk = v.grad
         if gk is None:
             continue
-        if gk.dim() == 2 and gk.numel() > 4096 and "memKbProj_2" not in k and "newMemory" not in k:
+        if gk.dim() == 2 and gk.numel() > 4096 and (compact or ("memKbProj_2" not in k and "newMemory" not in k)):
             z["gsum0/" + k] = np64(gk.sum(0)).astype(np.float32)      # column sums and row sums of the big matrices
             z["gsum1/" + k] = np64(gk.sum(1)).astype(np.float32)
         else:
             z["grad/" + k] = np64(gk).astype(np.float32)
     for k, t in ref["inputs"].items():
         if t.grad is not None and k != "questionWords":
-            z["gin/" + k] = np64(t.grad).astype(np.float32)
+            if compact and t.grad.dim() == 3:
+                z["ginsum1/" + k] = np64(t.grad.sum(1)).astype(np.float32)
+                z["ginsum2/" + k] = np64(t.grad.sum(2)).astype(np.float32)
+            else:
+                z["gin/" + k] = np64(t.grad).astype(np.float32)
     for k in ("controls", "memories", "infos"):
         z[k] = z[k].astype(np.float32)
-    np.savez_compressed(os.path.join(OUT, "hip_%s_p%d.npz" % (name, p)), **z)
+    np.savez_compressed(os.path.join(OUT, "hip_%s_p%d.npz" % (tag or name, p)), **z)
 
 
 def main():
     assert rx.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
     for f in os.listdir(OUT):
-        if f.endswith(".npz"):
+        if f.endswith(".npz") and (f.startswith("oracle_") or f.startswith("hip_")):      # (training_steps.npz: make_training_golden.py)
             os.remove(os.path.join(OUT, f))
     for name in T.FLAG_FILES:
         for train in (False, True):
@@ -155,6 +166,8 @@ def main():
     for name in T.FLAG_FILES:
         hip_case(name, 4)
     hip_case("args", 12)
+    # the chain kernels' d = 512 geometry (64-row tiles over 8 x 196 rows = 24.5 tiles) against the executed reference directly
+    hip_case("args", 4, B=8, S=9, N=196, D=512, HID=64, seed=37, compact=True, tag="args_d512")
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote %d files, %.1f KB" % (len(os.listdir(OUT)), total / 1024))
 

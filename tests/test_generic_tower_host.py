@@ -68,13 +68,15 @@ def run_tower(macx, contextual, dev=None):
         built = macx.MACNet(cfg, vocab=V, H=H, W=W, imageInDim=Cin, answerWordsNum=A)
         macx.checkpoint.load_reference(built.stem, {k: v for k, v in params.items() if k.startswith("stem/")})
     assert type(built.enc) is macx.GenericQuestionEncoder and type(built.out) is macx.GenericOutputClassifier
-    assert type(built.cell) is macx.GenericParams and not built.cell.names          # lazily created
+    # the cell's plan is compiled at construction: its variables exist, under the reference's names and in its creation order
+    assert type(built.cell) is macx.GenericParams
+    assert list(built.cell.names) == [k for k in params if k.startswith("MACnetwork/")]
     built.enc.load_reference_dict(params)
     built.out.load_reference_dict(params)
     built.cell.load_reference_dict({k: v for k, v in params.items() if k.startswith("MACnetwork/")})
     target = torch.device("cpu") if dev is None else dev
     built = built.to(target)
-    assert built.cell.device == target                                               # ... and lazily created ones would follow
+    assert built.cell.device == target
     to = (lambda t: t.to(dev)) if dev is not None else (lambda t: t)
     logits = built(to(img), to(q), to(lengths), train=False)
     prm = {k: v.double().clone().requires_grad_(True) for k, v in params.items()}

@@ -72,3 +72,98 @@ def test_two_ranks_drive_the_hip_cell_and_match_the_full_batch(dev):
     assert ret["phase_split"] == 0.0, "phase 1 + phase 2 of the backward pass differ from the single call"
     assert ret["overlapped"] == 1, "the early bucket did not start from the phase-1 hook"
     assert ret["worst"] < 2e-5, dict(ret["errs"])
+
+
+# ---- the whole tower (model.py:775-826): encoder + stem + cell + classifier through macx.dp.TowerBuckets
+def _tower(macx, dev):
+    import helpers as _h  # noqa: F401
+    B, H, W, Cin, d, p, S, A, V, E = 5, 4, 3, 128, 256, 2, 6, 7, 12, 20
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=d, ctrlDim=d, attDim=d, encDim=d, wrdEmbDim=E, outClassifierDims=[32],
+                                        answerWordsNum=A)
+    cfg.stemDim = 128
+    net = macx.MACNet(cfg, vocab=V, H=H, W=W, imageInDim=Cin, answerWordsNum=A, generator=torch.Generator().manual_seed(4)).to(dev)
+    g = torch.Generator().manual_seed(6)
+    img = torch.relu(torch.randn(B, H * W, Cin, generator=g))
+    lengths = torch.randint(2, S + 1, (B,), generator=g, dtype=torch.int32)
+    lengths[0] = S
+    q = torch.randint(1, V + 1, (B, S), generator=g, dtype=torch.int32)
+    q = q * (torch.arange(S).unsqueeze(0) < lengths.unsqueeze(1)).to(torch.int32)
+    ans = torch.randint(0, A, (B,), generator=g)
+    return net, (img, q, lengths, ans), B
+
+
+def _tower_step(net, data, dev, lo, hi, Bg, bucket=None):
+    img, q, lengths, ans = data
+    for t in net.tensors():
+        t.grad = None
+    logits = net(img[lo:hi].to(dev), q[lo:hi].to(dev), lengths[lo:hi].to(dev), train=True, seed=21, b0=lo)
+    loss, _ = net.loss_and_pred(logits, ans[lo:hi].to(dev))          # mean over the shard (model.py:596)
+    if bucket is not None:
+        bucket.begin_step(hi - lo, Bg)
+    loss.backward()
+    if bucket is not None:
+        bucket.allreduce_(hi - lo, Bg)
+    torch.cuda.synchronize()
+    return [t.grad.detach().cpu().clone() for t in net.tensors()]
+
+
+def _tower_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import macx
+    dev = torch.device("cuda:0")
+    net, data, Bg = _tower(macx, dev)
+    bucket = macx.dp.TowerBuckets(net)
+    lo, hi = macx.dp.tower_slice(Bg, rank, world)
+    got = _tower_step(net, data, dev, lo, hi, Bg, bucket)
+    if rank == 0:
+        overlapped = bucket.overlapped_steps
+        flat_ok = all(t.grad.data_ptr() == bucket.flat.data_ptr() + 4 * o for t, o in zip(bucket.tensors(), bucket.offsets))
+        net.cell.after_backward_phase1 = None
+        full = _tower_step(net, data, dev, 0, Bg, Bg)
+        errs = [float((a - b).abs().max() / max(float(b.abs().max()), 1e-2)) for a, b in zip(got, full)]
+        ret["worst"], ret["overlapped"], ret["flat_ok"] = max(errs), overlapped, flat_ok
+        ret["n"] = len(errs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_whole_tower_matches_the_full_batch(dev):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_tower_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["overlapped"] == 1, "the early bucket (classifier + the cell's early fields) did not start from the phase-1 hook"
+    assert ret["flat_ok"], "after the exchange every gradient must be a view of the tower's flat buffer"
+    assert ret["worst"] < 3e-5, dict(ret)
+
+
+def test_flat_optimizer_on_the_cells_gradient_buffer(macx, dev):
+    """optim.FlatAdamEMA(..., grad_owner=params).step(flat_grad=params.grad_buffer()) == the gather path over two steps; without
+    grad_owner the buffer is refused (the backward pass would not have written into it)."""
+    B, S, N, d, p = 4, 6, 33, 128, 2
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=d, ctrlDim=d, attDim=d)
+    vq, words, lengths, kb = [t.to(dev) for t in macx.configs.synthetic_inputs(B, S, N, d, seed=3)]
+
+    def train(flat):
+        params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(7)).to(dev)
+        opt = macx.optim.FlatAdamEMA(params.tensors(), lr=1e-2, grad_owner=params if flat else None)
+        for i in range(2):
+            for t in params.tensors():
+                t.grad = None
+            cell = macx.MACCell(vq, words, words, lengths, kb, cfg.memoryDropout, cfg.readDropout, cfg.writeDropout, B, True,
+                                config=cfg, params=params, seed=5 + i)
+            cell.run().memory.square().sum().backward()
+            opt.step(flat_grad=params.grad_buffer() if flat else None)
+        torch.cuda.synchronize()
+        return opt.flat.clone(), params
+
+    a, _ = train(False)
+    b, prm = train(True)
+    assert torch.equal(a, b)
+    other = macx.optim.FlatAdamEMA(macx.MACCellParams(cfg, p).to(dev).tensors())
+    with pytest.raises(ValueError):
+        other.step(flat_grad=prm.grad_buffer())

@@ -21,7 +21,8 @@ FILES = sorted(glob.glob(os.path.join(HERE, "golden", "reference", "hip_*.npz"))
 
 
 def test_fixtures_present():
-    assert len(FILES) >= 6
+    assert len(FILES) >= 7
+    assert any(f.endswith("hip_args_d512_p4.npz") for f in FILES)       # full width: the chain kernels' 64-row tiles
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[4:-4] for f in FILES])
@@ -38,7 +39,16 @@ def test_hip_path_reproduces_reference_vectors(macx, dev, path):
     with torch.no_grad():
         for f, name in macx.output.REF_NAMES.items():
             getattr(out, f).copy_(ref_params[name].to(dev))
-    vq, words, kb = [torch.from_numpy(z[k]).to(dev).requires_grad_(True) for k in ("vecQ", "words", "kb")]
+    if "kb" in z.files:
+        vq, words, kb = [torch.from_numpy(z[k]).to(dev).requires_grad_(True) for k in ("vecQ", "words", "kb")]
+    else:
+        # a compact full-width fixture: inputs regenerated from the seed (the generator of the fixture used the same function)
+        vq_c, words_c, len_c, kb_c = macx.configs.synthetic_inputs(B, S, N, D, seed=seed)
+        assert np.array_equal(len_c.numpy(), z["lengths"])
+        cs = z["input_checksums"]
+        got_cs = [float(kb_c.double().sum()), float(kb_c.double().abs().sum()), float(words_c.double().sum()), float(vq_c.double().sum())]
+        assert np.allclose(got_cs, cs, rtol=1e-9, atol=1e-6), (got_cs, cs)
+        vq, words, kb = [t.to(dev).requires_grad_(True) for t in (vq_c, words_c, kb_c)]
     lengths = torch.from_numpy(z["lengths"]).to(dev)
     cell = macx.MACCell(vecQuestions=vq, questionWords=words, questionCntxWords=words, questionLengths=lengths,
                         knowledgeBase=kb, memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout,
@@ -66,7 +76,10 @@ def test_hip_path_reproduces_reference_vectors(macx, dev, path):
             assert max_abs(cell.attentions[key][i], ref("att_%s_%d" % (key, i))) < 2e-6, (key, i)
     bad = {}
     for k, t in (("gin/vecQ", vq), ("gin/questionCntxWords", words), ("gin/kb", kb)):
-        e = rel_err(t.grad, ref(k))
+        if k in z.files:
+            e = rel_err(t.grad, ref(k))
+        else:
+            e = max(rel_err(t.grad.sum(1), ref("ginsum1/" + k[4:])), rel_err(t.grad.sum(2), ref("ginsum2/" + k[4:])))
         if not e < 2e-4:
             bad[k] = e
     got = {}

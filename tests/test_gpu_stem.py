@@ -52,6 +52,15 @@ def test_stem_clevr_shape_fp32(macx, dev):
         assert rel_err(getattr(stem, f).grad, prm[name].grad) < 1e-3, f
 
 
+def test_stem_gqa_shape(macx, dev):
+    """BASELINE configs[4]: GQA-shape features 7 x 7 x 2048 -> 512 -> 512 (model.py:791, config.py:433), training mode, B = 8:
+    the K loop of the first convolution walks 9 taps x 2048 channels = 18432."""
+    stem, kb, ref, prm = run_case(macx, dev, 8, 7, 7, 2048, 512, 512, True, dtype=torch.float64)
+    assert rel_err(kb, ref) < 2e-5
+    for f, name in macx.stem.REF_NAMES.items():
+        assert rel_err(getattr(stem, f).grad, prm[name].grad) < 2e-4, f
+
+
 def test_core_graph_stem_cell_classifier_gradients(macx, dev):
     """images -> stem -> MAC cell x p -> classifier -> CE: logits and every parameter gradient against the
     oracle chain (stem_cnn -> mac_network -> output_classifier), identical dropout masks."""

@@ -45,15 +45,16 @@ def test_check_and_sizing_without_gpu(macx):
     assert L.macx_gemm_mode(-1) == 2
     keep = L.macx_saved_floats(C.byref(o1), C.byref(s), 1)
     nokeep = L.macx_saved_floats(C.byref(o1), C.byref(s), 0)
-    # X, H1, I2, dropped KB (fp32) + the two 1-bit dropout masks, kept for 11 more steps (+ the per-question exponents)
-    assert keep - nokeep == 11 * 64 * 196 * 512 * 4 + 11 * 2 * (64 * 196 * 512 // 32) + 11 * 3 * 64 * 4
+    # X, H1, I2, dropped KB (fp32) + the two 1-bit dropout masks, kept for 11 more steps (no per-question exponent arrays any
+    # more: the consumers take the minima from the tensors' exponent bytes, round 4)
+    assert keep - nokeep == 11 * 64 * 196 * 512 * 4 + 11 * 2 * (64 * 196 * 512 // 32)
     assert L.macx_gemm_mode(-1) == 2
     # the default family keeps the same tensors as H2: 4 bytes per element as well (+ exponents and 64 pad rows each)
     keep = L.macx_saved_floats(C.byref(o), C.byref(s), 1)
     nokeep = L.macx_saved_floats(C.byref(o), C.byref(s), 0)
     h2 = L.macx_h2_floats(64 * 196, 512)
     assert 64 * 196 * 512 < h2 < 1.01 * 64 * 196 * 512
-    assert 11 * 4 * h2 < keep - nokeep < 11 * 4 * h2 + 11 * 2 * (64 * 196 + 64) * 64 // 4 + 11 * 3 * 64 * 4 + 64
+    assert 11 * 4 * h2 < keep - nokeep < 11 * 4 * h2 + 11 * 2 * (64 * 196 + 64) * 64 // 4 + 64
     off, cnt = C.c_size_t(), C.c_size_t()
     assert L.macx_saved_segment(C.byref(o), C.byref(s), 1, macx._lib.SEG["att_kb"], C.byref(off), C.byref(cnt)) == 0
     assert cnt.value == 12 * 64 * 196
@@ -169,7 +170,9 @@ def test_checkpoint_reaches_a_lazily_built_cell(tmp_path):
     src = {"macModel/" + k + ":0": v for k, v in vs.params.items()}
     assert any(k.startswith("macModel/MACnetwork/") for k in src)
     net = macx.MACNetCore(dcfg, H=3, W=2, imageInDim=128, answerWordsNum=5, generator=torch.Generator().manual_seed(0))
-    assert isinstance(net.cell, macx.GenericParams) and not net.cell.tensors()
+    # the plan is compiled at construction: the cell holds exactly the variables the reference's graph creates, in its order
+    assert isinstance(net.cell, macx.GenericParams)
+    assert list(net.cell.to_reference_dict()) == list(vs.params)
     full = dict(macx.checkpoint.reference_state_dict(net))                  # stem + classifier of this net ...
     full.update(src)                                                        # ... + the cell of the "checkpoint"
     full["macModel/MACnetwork/initMem/Adam:0"] = torch.zeros(128)           # optimizer slots are not model variables
@@ -182,10 +185,20 @@ def test_checkpoint_reaches_a_lazily_built_cell(tmp_path):
     net2 = macx.MACNetCore(dcfg, H=3, W=2, imageInDim=128, answerWordsNum=5, generator=torch.Generator().manual_seed(1))
     assert macx.checkpoint.load_npz(path, net2) == []
     assert all(torch.equal(a, b) for a, b in zip(net.cell.tensors(), net2.cell.tensors()))
-    # strict: a source without a single cell variable is an error, not a silently random cell
+    # strict: a source that lacks ONE variable the plan needs is an error (it used to be drawn at random on the first forward) ...
     net3 = macx.MACNetCore(dcfg, H=3, W=2, imageInDim=128, answerWordsNum=5, generator=torch.Generator().manual_seed(2))
-    with pytest.raises(KeyError):
-        macx.checkpoint.load_reference(net3, macx.checkpoint.reference_state_dict(net3))
+    one_short = dict(full)
+    dropped = "macModel/" + list(vs.params)[-1] + ":0"
+    del one_short[dropped]
+    with pytest.raises(KeyError, match="missing variables"):
+        macx.checkpoint.load_reference(net3, one_short)
+    assert macx.checkpoint.load_reference(net3, one_short, strict=False) == [dropped[len("macModel/"):-2]]
+    # ... and a variable of a DIFFERENT option set stored under the cell's scope is ignored: it does not become a Parameter
+    extra = dict(full)
+    extra["macModel/MACnetwork/MACCell/write/linearLayergate/weights/weight:0"] = torch.zeros(128, 128)
+    net4 = macx.MACNetCore(dcfg, H=3, W=2, imageInDim=128, answerWordsNum=5, generator=torch.Generator().manual_seed(2))
+    macx.checkpoint.load_reference(net4, extra)
+    assert list(net4.cell.to_reference_dict()) == list(vs.params)
 
 
 def test_flat_optimizer_shares_the_gradient_buffer_layout():
