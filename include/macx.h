@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MACX_ABI_VERSION 2
+#define MACX_ABI_VERSION 3
 
 enum {
   MACX_OK = 0,
@@ -78,6 +78,10 @@ typedef struct macx_shapes {
   int32_t d;     /* memDim == ctrlDim == attDim (config.py:294-296); multiple of 128           */
   int32_t p;     /* netLength (config.py:292)                                                  */
   int32_t b0;    /* global index of question 0: data-parallel shard offset (model.py:139-149)  */
+  int32_t d_logical; /* 0 (or d): the cell is d wide.  Else: the caller runs a d_logical-wide cell (config.py:294-296 takes
+                      * any width) zero-padded to d columns -- weights, biases, inputs -- and the dropout element indices are
+                      * taken at the LOGICAL width ((row * d_logical + column): the masks of the unpadded cell); d_logical % 8
+                      * == 0, d - 128 < d_logical < d.  The padded columns of every state and gradient are exact zeros. */
 } macx_shapes;
 
 /* Dropout of one cell run.  keep == 1 (evaluation, model.py:118-125) is the exact identity. */

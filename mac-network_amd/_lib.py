@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MACX_OK, MACX_EINVAL, MACX_EUNSUPPORTED, MACX_EREJECTED, MACX_ESMALL = 0, -1, -2, -3, -4
 ACT = {"NON": 0, "TANH": 1, "SIGMOID": 2, "ELU": 3, "RELU": 4}
@@ -26,7 +26,7 @@ class MacxOpts(C.Structure):
 
 
 class MacxShapes(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("B", "S", "N", "d", "p", "b0")]
+    _fields_ = [(n, C.c_int32) for n in ("B", "S", "N", "d", "p", "b0", "d_logical")]
 
 
 class MacxDropout(C.Structure):

@@ -51,7 +51,7 @@ class _Run:
         self.opts = cell.opts
         B, S, d = cell.words.shape
         N = cell.knowledgeBase.shape[1]
-        self.shapes = _lib.MacxShapes(B=B, S=S, N=N, d=d, p=cell.netLength, b0=cell.b0)
+        self.shapes = _lib.MacxShapes(B=B, S=S, N=N, d=d, p=cell.netLength, b0=cell.b0, d_logical=int(getattr(cell, "d_logical", 0)))
         _lib.check(self.L.macx_check(C.byref(self.opts), C.byref(self.shapes)), "macx_check")
         self.drop = _lib.MacxDropout(keep_memory=cell.dropouts["memory"], keep_read=cell.dropouts["read"],
                                      keep_write=cell.dropouts["write"], seed=cell.seed & 0xFFFFFFFF)
@@ -193,6 +193,9 @@ class MACCell:
         what the reference raises."""
         from types import SimpleNamespace
         from .options import UnsupportedOptions
+        if cls is MACCell and config is not None and _needs_padding(config):
+            # a width the kernels' 128-column granule does not divide (config.py:294-296 takes any): the same cell, zero-padded
+            return PaddedMACCell(*args, config=config, gemm=gemm, **kw)
         try:
             freeze(config if config is not None else SimpleNamespace())
         except UnsupportedOptions:
@@ -205,8 +208,9 @@ class MACCell:
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
-                 netLength=None, seed=None, b0=0, gemm=None):
+                 netLength=None, seed=None, b0=0, gemm=None, d_logical=0):
         from types import SimpleNamespace
+        self.d_logical = int(d_logical)        # > 0: this is the zero-padded image of a d_logical-wide cell (PaddedMACCell)
         self.config = config if config is not None else SimpleNamespace()
         self.opts = freeze(self.config, gemm)     # raises for rejected / unsupported option sets
         self.netLength = int(netLength if netLength is not None else get(self.config, "netLength"))
@@ -333,3 +337,103 @@ class MACCell:
         if control is None:
             control, memory = self._controls_all[self.netLength], self._memories_all[self.netLength]
         return MACCellTuple(control, memory)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# widths that are not multiples of 128 (config.py:294-296 takes any int): the same cell, zero-padded
+# ---------------------------------------------------------------------------------------------------------------------------
+def _needs_padding(config):
+    d = int(get(config, "memDim"))
+    return d % 128 != 0 and d % 8 == 0 and int(get(config, "ctrlDim")) == d and int(get(config, "attDim")) == d
+
+
+def _pad_last(t, n):
+    return torch.nn.functional.pad(t, (0, n - t.shape[-1]))
+
+
+def _pad_blocks(t, d, dp):
+    """[k * d, d] (k row blocks, one per concatenated input: ops.concat, ops.py:65-78) -> [k * dp, dp], each block padded on its own"""
+    k = t.shape[0] // d
+    return torch.nn.functional.pad(t.reshape(k, d, d), (0, dp - d, 0, dp - d)).reshape(k * dp, dp)
+
+
+class _PaddedParams:
+    """The zero-padded image of a MACCellParams: same fields, every width d -> dp.  The padded tensors are autograd results of
+    the logical parameters (torch.nn.functional.pad), so gradients arrive at the logical tensors, sliced, on their own."""
+
+    def __init__(self, params, d, dp):
+        self.fields = list(params.fields)
+        self.p = params.p
+        for f in self.fields:
+            t = getattr(params, f)
+            if t.dim() == 1:
+                v = t if t.shape[0] == 1 else _pad_last(t, dp)                       # scalar logit biases stay
+            elif f in ("memKbProj_W", "newMemory_W", "contControl_W"):
+                v = _pad_blocks(t, d, dp)
+            elif t.dim() == 2 and t.shape[0] != d:                                   # [nU, d] stacked biases
+                v = _pad_last(t, dp)
+            elif t.dim() == 2:
+                v = torch.nn.functional.pad(t, (0, dp - d, 0, dp - d))
+            else:                                                                    # [nU, d, d]
+                v = torch.nn.functional.pad(t, (0, dp - d, 0, dp - d))
+            setattr(self, f, v)
+
+    def tensors(self):
+        return [getattr(self, f) for f in self.fields]
+
+
+class PaddedMACCell:
+    """MACCell for memDim == ctrlDim == attDim == d with d % 128 != 0 (d % 8 == 0): the cell runs dp = ceil(d / 128) * 128 wide
+    on zero-padded weights, biases and inputs (macx_shapes.d_logical = d).  Padded columns stay exact zeros through every
+    linear layer (zero weights, zero bias), activation (act(0) = 0; the gate's sigmoid(0) = 0.5 mixes two zeros), attention
+    logit (zero terms of a dot product) and gradient, and the kernels take the dropout element index at the LOGICAL width, so
+    states, attentions and gradients are those of the unpadded cell with the unpadded cell's masks.  Same interface as MACCell;
+    states and histories come back d wide."""
+
+    def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
+                 memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
+                 netLength=None, seed=None, b0=0, gemm=None):
+        import copy
+        self.config = config
+        d = self.d = int(get(config, "memDim"))
+        dp = self.dp = (d + 127) // 128 * 128
+        self.netLength = int(netLength if netLength is not None else get(config, "netLength"))
+        self.params = params if params is not None else MACCellParams(config, self.netLength, device=knowledgeBase.device)
+        wide = copy.copy(config)
+        wide.memDim = wide.ctrlDim = wide.attDim = dp
+        pad = lambda t: _pad_last(t, dp)
+        words_p = pad(questionWords)
+        cntx_p = words_p if questionCntxWords is questionWords else pad(questionCntxWords)
+        self.inner = MACCell(pad(vecQuestions), words_p, cntx_p, questionLengths, pad(knowledgeBase), memoryDropout, readDropout,
+                             writeDropout, batchSize, train, reuse, config=wide, params=_PaddedParams(self.params, d, dp),
+                             netLength=self.netLength, seed=seed, b0=b0, gemm=gemm, d_logical=d)
+        self.none = self.inner.none
+        self.batchSize, self.train, self.seed, self.b0 = self.inner.batchSize, self.inner.train, self.inner.seed, self.inner.b0
+
+    iteration = property(lambda self: self.inner.iteration, lambda self, v: setattr(self.inner, "iteration", v))
+    attentions = property(lambda self: self.inner.attentions)
+
+    @property
+    def state_size(self):
+        return MACCellTuple(self.d, self.d)
+
+    @property
+    def output_size(self):
+        return 1
+
+    def _cut(self, state):
+        return MACCellTuple(state.control[..., :self.d], state.memory[..., :self.d])
+
+    def zero_state(self, batchSize=None, dtype=torch.float32):
+        return self._cut(self.inner.zero_state(batchSize, dtype))
+
+    def __call__(self, inputs, state, scope=None):
+        out, st = self.inner(inputs, state, scope)
+        return out, self._cut(st)
+
+    def run(self):
+        return self._cut(self.inner.run())
+
+    controls = property(lambda self: self.inner.controls[..., :self.d])
+    memories = property(lambda self: self.inner.memories[..., :self.d])
+    infos = property(lambda self: self.inner.infos[..., :self.d])

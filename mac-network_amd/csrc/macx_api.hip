@@ -383,11 +383,19 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   return L;
 }
 
+// row stride of the dropout element index: the logical width of a zero-padded cell, else the width
+inline int dlog_of(const macx_shapes* s) { return (s->d_logical > 0 && s->d_logical < s->d) ? s->d_logical : s->d; }
+
 int check_impl(const macx_opts* o, const macx_shapes* s) {
   if (!o || !s) return MACX_EINVAL;
   if (o->abi_version != MACX_ABI_VERSION) return MACX_EINVAL;
   if (s->B < 1 || s->S < 1 || s->N < 1 || s->p < 1 || s->d < 128) return MACX_EINVAL;
   if (s->d % 128 != 0 || s->d > 1024) return MACX_EINVAL;
+  if (s->d_logical != 0 && s->d_logical != s->d) {
+    // a zero-padded cell: the dropout index is taken at the logical width (sites of the H2 kernel family only)
+    if (s->d_logical % 8 != 0 || s->d_logical <= s->d - 128 || s->d_logical > s->d) return MACX_EINVAL;
+    if (!h2_mode()) return MACX_EUNSUPPORTED;
+  }
   if (s->S > C_MAXS || s->N > K_MAXN || s->p > CB_MAXZ) return MACX_EINVAL;
   if ((size_t)(s->b0 + s->B) * s->N * s->d >= (1ull << 32)) return MACX_EINVAL;  // 32-bit dropout index
   if (o->write_inputs != MACX_WRITE_BOTH) return MACX_EUNSUPPORTED;
@@ -414,7 +422,8 @@ ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dr
   c.mode = (rdrop || L.act_stride != 0 || i == 0) ? 0 : 1;
   c.dbg = (kb_gemm_dbg() >> 12) & 31;
   c.kb = in->knowledgeBase;
-  c.first = (uint32_t)((size_t)s->b0 * N * d);
+  c.dlog = dlog_of(s);
+  c.first = (uint32_t)((size_t)s->b0 * N * c.dlog);
   c.thr1 = 1u << 24; c.inv1 = 1.0f; c.thr2 = 1u << 24; c.inv2 = 1.0f;
   if (rdrop) {
     const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
@@ -768,7 +777,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   const DropSpec dry = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i);
   // (from step 1 on, the previous step's write unit left this step's dropped memory behind: md_fused below)
   if (!(md_fused && i > 0)) {
-    hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md);
+    hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md, dlog_of(s));
     CK(hipGetLastError());
   }
   {
@@ -797,7 +806,8 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
       H2FromP f;
       memset(&f, 0, sizeof(f));
       f.src = in->knowledgeBase; f.B = B; f.N = N; f.C = d; f.out = hKB;
-      f.first = (uint32_t)((size_t)s->b0 * N * d);
+      f.ldrop = dlog_of(s);
+      f.first = (uint32_t)((size_t)s->b0 * N * f.ldrop);
       f.thr24 = 1u << 24; f.inv_keep = 1.0f; f.thr24_2 = 1u << 24;
       if (rdrop) {
         const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
@@ -880,7 +890,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   // write dropout (mac_cell.py:461-463); self.infos keeps the dropped value (mac_cell.py:474)
   if (wdrop) {
     const DropSpec dw = make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i);
-    hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)info_raw, B, d, (uint32_t)s->b0, dw, no_drop(), info);
+    hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)info_raw, B, d, (uint32_t)s->b0, dw, no_drop(), info, dlog_of(s));
     CK(hipGetLastError());
   }
   // ---- write unit (mac_cell.py:305-375), writeInputs = BOTH: act(concat([memory, info (, selfSmry)]) W + b)
@@ -909,7 +919,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     if (self_smry) { l.seg[2] = LinSeg{self_smry, d, d, 0}; l.Ktot = 3 * d; }
     if (md_fused && i + 1 < s->p) {
       // the new memory is the next step's read-unit input: its two dropouts (mac_cell.py:214-217, ops.py:679) ride this epilogue
-      l.use_drop = 2;
+      l.use_drop = 2; l.drop_ld = dlog_of(s);
       l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
                                            : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i + 1);
       l.d2 = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i + 1);
@@ -1092,7 +1102,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     ld_dinfo = win;
     if (dp->keep_write < 1.0f) {
       hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)dwin, win, d, B, d, (uint32_t)s->b0,
-                         make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i), ws + W.dinfo + (size_t)i * Bd);
+                         make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i), ws + W.dinfo + (size_t)i * Bd, dlog_of(s));
       CK(hipGetLastError());
       dinfo = ws + W.dinfo + (size_t)i * Bd;
       ld_dinfo = d;
@@ -1322,7 +1332,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       // with self attention DM[i] already holds the parts later steps sent to this memory: accumulate
       const bool acc_prev = (units & U_WRITE) && (o->write_self_att || o->write_gate);
       LinP l = lin_basic(DYi, d, d, B, ws + W.wyT, nullptr, d, MACX_ACT_NON, acc_prev ? ws + W.tmpBd[0] : dm_prev, d);
-      l.use_drop = 1;
+      l.use_drop = 1; l.drop_ld = dlog_of(s);
       l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
                                            : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
       l.d2 = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i);

@@ -620,7 +620,8 @@ struct ChainFwdP {
   int dbg;                  // timing knobs: 1 stop after stage 0, 2 after stage 1, 4 after stage 2; dbg >> 3 = K-loop variant
   // stage 0
   const float* kb;          // [M][d] fp32, row-major
-  uint32_t first;           // flat dropout index of element (0, 0): b0 * N * d
+  uint32_t first;           // flat dropout index of element (0, 0): b0 * N * dlog
+  int dlog;                 // row stride of the dropout index: the logical width of a zero-padded cell (macx_shapes.d_logical), else d
   uint32_t key1, thr1; float inv1;      // ops.py:678 site (thr = 1 << 24: keep everything)
   uint8_t* bits1;           // its keep bits, row-major, one byte per 8 columns [M][d/8] (= uint32 words [M][d/32]); may be null
   uint32_t key2, thr2; float inv2;      // ops.py:312 site on act(I2 * c)
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
       const int kg = x.ckg(j);
-      const uint32_t e0 = p.first + (uint32_t)(x.cgrow * D + kg * 8);
+      const uint32_t e0 = p.first + (uint32_t)(x.cgrow * (size_t)p.dlog + kg * 8);
       if (drop1) {
         uint32_t byte = 0;             // (e0 is even: the width is a multiple of 128)
 #pragma unroll

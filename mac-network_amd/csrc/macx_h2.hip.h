@@ -211,7 +211,8 @@ constexpr size_t H2C_LDS = (size_t)H2C_ROWS * H2C_LDT * 4 + (size_t)17 * H2C_ROW
 struct H2FromP {
   const float* src; int B, N, C;
   H2View out;
-  uint32_t first;                        // flat index of element (0,0,0): b0 * N * C
+  uint32_t first;                        // flat dropout index of element (0,0,0): b0 * N * ldrop
+  int ldrop;                             // row stride of the dropout index (the logical width of a zero-padded tensor); 0 = C
   uint32_t key, thr24; float inv_keep;   // site 1 (thr24 = 1 << 24: keep everything)
   uint32_t* bits;                        // site 1 keep bits, row-major [B*N][C/32]; may be null
   uint32_t key2, thr24_2;                // site 2
@@ -229,14 +230,16 @@ __global__ __launch_bounds__(H2C_THREADS) void h2_from_f32_kernel(H2FromP p) {
   const size_t grow0 = (size_t)b * p.N + row0;
   const int tid = threadIdx.x, c4 = tid & 31, rg = tid >> 5;
   const bool drop = p.thr24 < (1u << 24);
+  const int ldrop = p.ldrop > 0 ? p.ldrop : p.C;
   for (int lrow = rg; lrow < rows; lrow += H2C_THREADS / 32) {
     const size_t e0 = (grow0 + lrow) * p.C + cb * 128 + c4 * 4;
+    const uint32_t d0 = (uint32_t)((grow0 + lrow) * (size_t)ldrop + cb * 128 + c4 * 4);
     f32x4 v = *reinterpret_cast<const f32x4*>(p.src + e0);
     if (drop) {
       uint32_t nib = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool keep = keep_bit(p.first + (uint32_t)e0 + e, p.key, p.thr24);
+        const bool keep = keep_bit(p.first + d0 + e, p.key, p.thr24);
         nib |= (keep ? 1u : 0u) << e;
         v[e] = keep ? v[e] * p.inv_keep : 0.f;
       }
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(H2C_THREADS) void h2_from_f32_kernel(H2FromP p) {
     for (int it = tid; it < 16 * H2C_ROWS; it += H2C_THREADS) {
       const int kgl = it / H2C_ROWS, lrow = it & (H2C_ROWS - 1);
       if (lrow < rows) {
-        const uint32_t e0 = p.first + (uint32_t)((grow0 + lrow) * p.C + cb * 128 + kgl * 8);
+        const uint32_t e0 = p.first + (uint32_t)((grow0 + lrow) * (size_t)ldrop + cb * 128 + kgl * 8);
         uint32_t byte = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) byte |= (keep_bit(e0 + e, p.key2, p.thr24_2) ? 1u : 0u) << e;

@@ -176,7 +176,8 @@ struct LinP {
   float* out; int ldo; size_t zout;
   // optional epilogue pieces (applied in this order after bias/act)
   const float* actgrad_src; int actgrad_act; int ld_ag; size_t zag;  // val *= act'(src)
-  int use_drop; DropSpec d1, d2; uint32_t drop_row0;                // val *= f1*f2, idx=(drop_row0+r)*n_out+j
+  int use_drop; DropSpec d1, d2; uint32_t drop_row0;                // val *= f1*f2, idx=(drop_row0+r)*drop_ld+j
+  int drop_ld;                      // row stride of the dropout index: the logical width of a zero-padded cell; 0 = n_out
   float* out_drop; int ld_od;       // use_drop == 2: `out` keeps val, out_drop receives val*f1*f2 (the next consumer's dropped copy)
   const float* addend; int ld_add; size_t zadd;                      // val += addend
   size_t rep_stride;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
     v = act_apply(p.act, v);
     if (p.actgrad_src) v *= act_grad_from_out(p.actgrad_act, p.actgrad_src[(size_t)z * p.zag + (size_t)row * p.ld_ag + col + e]);
     if (p.use_drop) {
-      const uint32_t idx = (p.drop_row0 + row) * (uint32_t)p.n_out + col + e;
+      const uint32_t idx = (p.drop_row0 + row) * (uint32_t)(p.drop_ld > 0 ? p.drop_ld : p.n_out) + col + e;
       float f = 1.f;
       if (!keep_bit(idx, p.d1.key, p.d1.thr24)) f = 0.f; else f *= p.d1.inv_keep;
       if (!keep_bit(idx, p.d2.key, p.d2.thr24)) f = 0.f; else f *= p.d2.inv_keep;
@@ -330,11 +331,14 @@ inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // elementwise helpers on [B,d]
 // ---------------------------------------------------------------------------------------------
-// out = x * f1 * f2 with two dropout streams indexed (row0+r)*d + j   (mac_cell.py:214-217 then ops.py:679)
-__global__ void drop2_kernel(const float* __restrict__ x, int rows, int d, uint32_t row0, DropSpec d1, DropSpec d2, float* out) {
+// out = x * f1 * f2 with two dropout streams indexed (row0+r)*dl + j   (mac_cell.py:214-217 then ops.py:679); dl: the logical
+// width of a zero-padded cell (macx_shapes.d_logical), 0 = d
+__global__ void drop2_kernel(const float* __restrict__ x, int rows, int d, uint32_t row0, DropSpec d1, DropSpec d2, float* out, int dl = 0) {
   const int n = rows * d;
+  if (dl <= 0) dl = d;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t idx = row0 * (uint32_t)d + i;
+    const int r = i / d, j = i - r * d;
+    const uint32_t idx = (row0 + (uint32_t)r) * (uint32_t)dl + (uint32_t)j;
     float v = x[i];
     v = drop_apply(v, idx, d1);
     v = drop_apply(v, idx, d2);
@@ -421,11 +425,12 @@ __global__ __launch_bounds__(1024) void rowsum_list_kernel(RowsumList L) {
 
 // dst[r][j] = src[r*ld_src + col0 + j] * dropfactor((row0+r)*d + j)
 __global__ void copy_cols_drop_kernel(const float* __restrict__ src, int ld_src, int col0, int rows, int d, uint32_t row0,
-                                      DropSpec ds, float* dst) {
+                                      DropSpec ds, float* dst, int dl = 0) {
   const int n = rows * d;
+  if (dl <= 0) dl = d;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int r = i / d, j = i - r * d;
-    dst[i] = drop_apply(src[(size_t)r * ld_src + col0 + j], row0 * (uint32_t)d + i, ds);
+    dst[i] = drop_apply(src[(size_t)r * ld_src + col0 + j], (row0 + (uint32_t)r) * (uint32_t)dl + (uint32_t)j, ds);
   }
 }
 

@@ -25,11 +25,25 @@ def test_extreme_shapes_match_the_oracle(macx, dev, name, B, S, N, d, p, train):
     parity(macx, dev, name, B, S, N, d, p, train)
 
 
-@pytest.mark.parametrize("over", [dict(S=257), dict(N=1025), dict(p=33), dict(d=1152), dict(d=192), dict(B=0)])
+@pytest.mark.parametrize("name,B,S,N,d,p,train", [
+    ("args", 3, 6, 49, 144, 2, True),          # 144 -> 256 columns: chain kernels at d = 256, dropout indices at the logical width
+    ("args", 5, 7, 196, 400, 3, True),         # 400 -> 512: the d = 512 tile geometry (980 rows: 16-row tiles)
+    ("args4", 2, 6, 20, 200, 2, True),         # self-attention + gate (sigmoid(0) = 0.5 in the padded columns, times zeros)
+    ("args1", 2, 5, 33, 72, 2, False),         # narrower than one granule, recurrent control, evaluation
+])
+def test_widths_that_are_not_multiples_of_128(macx, dev, name, B, S, N, d, p, train):
+    """config.py:294-296 takes any width: a cell whose width is a multiple of 8 runs zero-padded to the kernels' 128-column
+    granule (macx.cell.PaddedMACCell, macx_shapes.d_logical) with the UNPADDED cell's dropout masks -- states and every
+    gradient against the fp64 oracle at the logical width."""
+    parity(macx, dev, name, B, S, N, d, p, train)
+
+
+@pytest.mark.parametrize("over", [dict(S=257), dict(N=1025), dict(p=33), dict(d=1152), dict(d=192), dict(B=0), dict(d=256, d_logical=100),
+                                  dict(d=256, d_logical=132)])
 def test_first_size_past_each_limit_is_rejected(macx, over):
     cfg, *_ = make_case("args", 2, 4, 8, 128, 2)
     opts = macx.options.freeze(cfg)
-    kw = dict(B=2, S=4, N=8, d=128, p=2, b0=0)
+    kw = dict(B=2, S=4, N=8, d=128, p=2, b0=0, d_logical=0)
     kw.update(over)
     sh = macx._lib.MacxShapes(**kw)
     L = macx._lib.lib()
