@@ -57,6 +57,8 @@ inline int& chain_mode() { static int m = 1; return m; }
 inline bool use_chain(int d, int N) { return h2_mode() && chain_mode() && chain_supported(d, N); }
 // dy from the chain kernel and S_b of all steps as one deferred launch; macx_debug_set(5, 0): sb_h2 once per step, as before
 inline int& sb_defer_mode() { static int m = 1; return m; }
+// the deferred S_b contraction on 128 x 256 tiles with summation by parts (sb_h2w_kernel); macx_debug_set(8, 0): the 128 x 128 kernel
+inline int& sb_wide_mode() { static int m = 1; return m; }
 // A second queue for the backward pass's contractions that nothing in the recurrence waits for (dKB of a step: 27 us of
 // full-chip matrix work).  Between two chain kernels the caller's stream runs ~100 us of [B,d]-sized launches that leave the
 // chip almost idle; the side queue was meant to fill exactly that.  Fork and join are events on the caller's stream, so for the
@@ -279,6 +281,8 @@ struct BwdLayout {
   size_t dt, du;    // [B,d]
   size_t slab_w2, slab_wx, slab_w1a, slab_w1b;
   size_t ns_big, ngroup;
+  bool sb_wide;               // the deferred S_b contraction runs on sb_h2w_kernel (128 x 256 tiles, summation by parts)
+  int sb_qpg;                 // questions per workgroup group of the S_b kernel in use
   size_t db_rows;   // rows per step of db1_part / dbx_part
   size_t dwk_rows;  // rows per step of dwk_part / db2_part
   size_t dc_part, dls_part;   // chain kernel: per-row-group partials of dc / db_k, [p][dwk_rows][3][d] and [p][dwk_rows][3]
@@ -336,7 +340,9 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dmd = take(B * d);
   L.dt = take(B * d); L.du = take(B * d);
   L.ns_big = wgrad_big_splits((int)(p * B * N), (int)d, (int)d);
-  L.ngroup = (B + sb_qpg((int)B, (int)N) - 1) / sb_qpg((int)B, (int)N);
+  L.sb_wide = L.sb_deferred && h2_mode() && sb_wide_mode() && sb_h2_wide_ok((int)B, (int)N, (int)d);
+  L.sb_qpg = L.sb_wide ? sb_h2_wide_qpg((int)B, (int)N, (int)d) : sb_qpg((int)B, (int)N);
+  L.ngroup = (B + L.sb_qpg - 1) / L.sb_qpg;
   L.slab_w2 = take(L.ns_big * d * d);
   L.slab_wx = take(L.ns_big * d * d);
   L.slab_w1a = take((L.sb_deferred ? 1 : p) * L.ngroup * d * d);
@@ -1622,7 +1628,8 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     q.nsteps = p;
     q.x_step = L.act_stride * sizeof(float); q.g_step = W.dI1_stride * sizeof(float); q.y_step = Bd;
     q.dbg = kb_gemm_dbg();
-    CK(sb_h2_launch(q, st));
+    q.qpg = W.sb_qpg;
+    CK(W.sb_wide ? sb_h2w_launch(q, st) : sb_h2_launch(q, st));
   }
   const int nslab1 = (int)((h2_mode() && W.sb_deferred ? 1 : p) * W.ngroup);
   {
@@ -2589,6 +2596,7 @@ int macx_debug_set(int key, int value) {
   if (key == 5 && (value == 0 || value == 1)) { sb_defer_mode() = value; return MACX_OK; }
   if (key == 6 && value >= 0 && value <= 4) { overlap_mode() = value; return MACX_OK; }
   if (key == 7 && value >= -1 && value <= 63) { chain_kv() = value; return MACX_OK; }
+  if (key == 8 && (value == 0 || value == 1)) { sb_wide_mode() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

@@ -120,6 +120,13 @@ __device__ __forceinline__ void dma16b(const char* g, uint32_t lds_wave_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
 }
 
+// ... with the global address as a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: several DMA instructions
+// of a stage that differ only in their base (plane, column tile) share ONE offset register instead of a 64-bit address each
+__device__ __forceinline__ void dma16b_s(const char* sbase, uint32_t voff, uint32_t lds_wave_addr) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane(lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(l) : "memory", "m0");
+}
+
 __device__ __forceinline__ void dma4b(const char* g, uint32_t lds_wave_addr) {      // 64 lanes x 4 B, lane-linear
   const uint32_t l = __builtin_amdgcn_readfirstlane(lds_wave_addr);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l) : "memory", "m0");

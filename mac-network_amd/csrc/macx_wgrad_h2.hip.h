@@ -748,6 +748,278 @@ __global__ __launch_bounds__(512) void sb_h2_kernel(SbH2P p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same contraction on a 128 x 256 output tile (round 4).  The 128 x 128 kernel above issues one transpose read per MFMA
+// (each wave re-reads its 4 X fragments for only 2 dI1 column tiles): 17.9 M LDS instructions for 16.5 M MFMAs at the
+// metric's shape -- it runs at the LDS's pace, 0.69 PF against wgrad_h2_kernel's 1.04.  A wave tile of 64 x 64 halves the
+// X re-reads (0.67 reads per MFMA), but three accumulator sets of that size (S_b, dW1a, dW1b: 192 registers) do not fit.
+// They are not needed: with T_k = S_1 + .. + S_k (the questions and steps of this workgroup in processing order)
+//     dW1b = T_K,      dW1a = sum_k diag(y_k) S_k = sum_k diag(y_k - y_{k+1}) T_k      (y_{K+1} = 0; summation by parts)
+// so ONE running accumulator that is never cleared serves both, and the fold at a question's end is
+//     dW1a += (y_k - y_{k+1}) * T_k                       (two sets: 128 registers).
+// T_k is kept in the current question's unit 2^-(EX_k + EG_k) and moved to the next question's with an exact power of two
+// when the next question starts -- which is also when y_{k+1} is at hand (the LDS table of the step's questions), so the
+// fold of question k runs at the start of question k + 1.  Rounding: a fold rounds at 2^-24 |T_k| instead of 2^-24 |S_k|;
+// |T_k| grows like sqrt(k) |S| over the <= 2 questions x p steps of a workgroup.
+// No dy (that is per question and needs S_b itself): the deferred all-steps launch only.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SBW_STAGE = 2 * WH_APL + 4 * WH_APL;     // X hi, X lo (128 columns) | dI1 hi, dI1 lo (256 columns): 48 KB
+constexpr int SBW_RING = 3;
+constexpr int SBW_MAXQ = 4;                            // questions per workgroup
+constexpr int SBW_MAXROWS = 1024;                      // factor-table rows (SBW_MAXQ questions of <= 256 rows)
+
+__global__ __launch_bounds__(512) void sb_h2w_kernel(SbH2P p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+  uint16_t* ftab = reinterpret_cast<uint16_t*>(lds + SBW_RING * SBW_STAGE);                  // [questions][nchunk * 32]
+  float* ytab = reinterpret_cast<float*>(lds + SBW_RING * SBW_STAGE + SBW_MAXROWS * 2);      // [questions][128]
+  int* qmn = reinterpret_cast<int*>(ytab + SBW_MAXQ * T_TILE);                               // [2][questions] EX | EG of the step's questions
+  float* yold = reinterpret_cast<float*>(qmn + 3 * SBW_MAXQ);                                // [2][128] y of the question before (ytab is rebuilt per step)
+
+  const int ntk = p.d / T_TILE, ntj = p.d / (2 * T_TILE);
+  const int ntile = ntk * ntj;
+  const int nblk = gridDim.x;
+  int v = blockIdx.x;
+  if ((nblk & 7) == 0) v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int group = v / ntile;
+  const int tile = v % ntile;
+  const int tk = tile / ntj, tj = tile % ntj;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;                // 64 rows (k) x 64 columns (j) of the 128 x 256 tile
+  const int gq = wc >> 1;                                 // the 128-column block of dI1 this wave's columns lie in
+
+  const int nchunk = (p.N + 31) >> 5;
+  const int b_begin = group * p.qpg;
+  const int b_end = min(p.B, b_begin + p.qpg);
+  const int nq = b_end - b_begin;
+  const int total = nq * nchunk;
+  const size_t Rp = p.X.Rp();
+  const size_t xpb = p.X.plane_bytes(), gpb = p.dI1.plane_bytes();
+  const int xcb = p.X.cb(), gcb = p.dI1.cb();
+  H2View vX = p.X, vG = p.dI1;
+  const float* yS = p.y;
+  const int rows_q = nchunk * 32;
+
+  // ---- staging: 48 column tiles of 16 per stage (X: 2 planes x 8, dI1: 2 planes x 16).  Wave w copies X tiles 2 w, 2 w + 1
+  //      and dI1 tiles 4 w .. 4 w + 3 (tile = plane * tiles-per-plane + column tile); every one of its six instructions is a
+  //      wave-uniform base + the SAME per-lane offset (slot of row sl_m, column group sl_kg of the tile): one address register
+  const int sl_half = lane >> 5, sl_row = (lane & 31) >> 1, sl_kg = lane & 1;
+  const int sl_m = sl_half * 16 + sl_row;
+  const uint32_t lds0 = lds_addr_of(lds);
+  auto issue = [&](int s_raw) __attribute__((always_inline)) {
+    const int s = min(s_raw, total - 1);
+    const int qi = s / nchunk, ch = s - qi * nchunk;
+    const int n = min(ch * 32 + sl_m, p.N - 1);
+    const uint32_t voff = (uint32_t)(((size_t)sl_kg * Rp + (size_t)(b_begin + qi) * p.N + n) * 16);
+    const uint32_t st = lds0 + (uint32_t)((s_raw % SBW_RING) * SBW_STAGE);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int u = wave * 2 + j, pl = u >> 3, ct = u & 7;
+      dma16b_s(vX.base + pl * xpb + (size_t)(tk * 16 + 2 * ct) * Rp * 16, voff, st + pl * WH_APL + ct * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = wave * 4 + j, pl = u >> 4, ct = u & 15;
+      dma16b_s(vG.base + pl * gpb + (size_t)(tj * 32 + 2 * ct) * Rp * 16, voff, st + 2 * WH_APL + pl * 2 * WH_APL + ct * 1024);
+    }
+  };
+  // per step: the questions' common exponents (integer minima through LDS), the combined row factors (one table per dI1
+  // column block of the tile: the chain kernels give a row ONE exponent, other producers one per 128 columns), y, units
+  auto tables = [&]() __attribute__((always_inline)) {
+    if (tid < 3 * SBW_MAXQ) qmn[tid] = 127;
+    __syncthreads();
+    for (int i0 = 0; i0 < nq * rows_q; i0 += 512) {
+      const int i = i0 + tid;
+      const int qi = i / rows_q, n = i - qi * rows_q;
+      int ex = 127, eg0 = 127, eg1 = 127;
+      if (i < nq * rows_q && n < p.N) {
+        const size_t row = (size_t)(b_begin + qi) * p.N + n;
+        ex = (int)vX.exps()[row * xcb + tk];
+        eg0 = (int)vG.exps()[row * gcb + 2 * tj];
+        eg1 = (int)vG.exps()[row * gcb + 2 * tj + 1];
+      }
+      const int q_lo = min(i0 + (tid & ~63), nq * rows_q - 1) / rows_q, q_hi = min(i0 + (tid | 63), nq * rows_q - 1) / rows_q;
+      for (int q = q_lo; q <= q_hi; ++q) {
+        int mx = qi == q ? ex : 127, mg = qi == q ? min(eg0, eg1) : 127;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mx = min(mx, __shfl_xor(mx, o, 64)); mg = min(mg, __shfl_xor(mg, o, 64)); }
+        if (lane == 0) { atomicMin(qmn + q, mx); atomicMin(qmn + SBW_MAXQ + q, mg); }
+      }
+    }
+    __syncthreads();
+    // the two column blocks of dI1 share ONE common exponent (their minimum): one accumulator unit per question
+    for (int i = tid; i < 2 * nq * rows_q; i += 512) {
+      const int blk = i / (nq * rows_q), r = i - blk * nq * rows_q;
+      const int qi = r / rows_q, n = r - qi * rows_q;
+      uint16_t f = 0;
+      if (n < p.N) {
+        const size_t row = (size_t)(b_begin + qi) * p.N + n;
+        const int k = (min(qmn[qi], 126) - (int)vX.exps()[row * xcb + tk]) + (min(qmn[SBW_MAXQ + qi], 126) - (int)vG.exps()[row * gcb + 2 * tj + blk]);
+        f = (uint16_t)(pk_pow2_f16(k) & 0xFFFFu);
+      }
+      ftab[blk * (SBW_MAXROWS / 2) + r] = f;
+    }
+    for (int i = tid; i < nq * T_TILE; i += 512)
+      ytab[i] = yS[(size_t)(b_begin + (i >> 7)) * p.d + tk * T_TILE + (i & 127)];
+  };
+
+  f32x4 accT[4][4], accA[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accT[t][c] = accA[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto frag = [&](const char* tile) __attribute__((always_inline)) {
+    const u32x2 lo = tr_read(tile + lane * 8), hi = tr_read(tile + 512 + lane * 8);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
+  auto compute = [&](int buf, int qi, int ch) __attribute__((always_inline)) {
+    const char* sa = lds + buf * SBW_STAGE + (wr * 4) * 1024;
+    const char* sg = lds + buf * SBW_STAGE + 2 * WH_APL + (wc * 4) * 1024;
+    const uint16_t* ft = ftab + gq * (SBW_MAXROWS / 2) + qi * rows_q + ch * 32 + (lane >> 4) * 4;
+    const u32x2 f0 = *reinterpret_cast<const u32x2*>(ft), f1 = *reinterpret_cast<const u32x2*>(ft + 16);
+    u32x4 gf[2][4];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u32x4 w = frag(sg + pl * 2 * WH_APL + c * 1024);
+        w[0] = pk_mul_f16(w[0], f0[0]); w[1] = pk_mul_f16(w[1], f0[1]);
+        w[2] = pk_mul_f16(w[2], f1[0]); w[3] = pk_mul_f16(w[3], f1[1]);
+        gf[pl][c] = w;
+      }
+#pragma unroll
+    for (int ap = 1; ap >= 0; --ap) {                     // smallest terms first: X_lo x dI1_hi ; X_hi x {dI1_lo, dI1_hi}
+      u32x4 af[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[t] = frag(sa + ap * WH_APL + t * 1024);
+#pragma unroll
+      for (int bp = 1 - ap; bp >= 0; --bp)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) accT[t][c] = mfma_f16(af[t], gf[bp][c], accT[t][c]);
+    }
+  };
+  // the fold of the question that just ended, run when the next one (its y in `ynext`, its unit exponent `e_next`) starts:
+  //   dW1a += (y_k - y_next) * T_k * 2^-e_k ;  T_k (unit 2^-e_k) -> unit 2^-e_next
+  // (y of the question before lives in LDS, two buffers taken in turn: a question is at least one stage -- one barrier -- long,
+  // so the buffer a fold reads was written a barrier ago and is overwritten two questions later)
+  int ex_prev = 0, eg_prev = 0, ybuf = 0;
+  bool pending = false;
+  auto keep_y = [&](const float* ynext) __attribute__((always_inline)) {
+    if (tid < T_TILE) yold[(ybuf ^ 1) * T_TILE + tid] = ynext ? ynext[tid] : 0.f;
+    ybuf ^= 1;
+  };
+  auto fold = [&](const float* ynext, int ex_next, int eg_next) __attribute__((always_inline)) {
+    const float sc = h2_unscale(ex_prev, eg_prev);
+    const float mv = h2_pow2(max(min((ex_next + eg_next) - (ex_prev + eg_prev), 126), -126));
+    const float* yp = yold + ybuf * T_TILE;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k0 = wr * 64 + t * 16 + (lane >> 4) * 4;
+      f32x4 yn = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ynext) yn = *reinterpret_cast<const f32x4*>(ynext + k0);
+      const f32x4 yo = *reinterpret_cast<const f32x4*>(yp + k0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dy = (yo[e] - yn[e]) * sc;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          accA[t][c][e] = fmaf(dy, accT[t][c][e], accA[t][c][e]);
+          accT[t][c][e] *= mv;
+        }
+      }
+    }
+    keep_y(ynext);
+    ex_prev = ex_next; eg_prev = eg_next;
+  };
+
+#pragma unroll 1
+  for (int step = 0; step < p.nsteps; ++step) {
+    vX.base = p.X.base + (size_t)step * p.x_step; vG.base = p.dI1.base + (size_t)step * p.g_step;
+    yS = p.y + (size_t)step * p.y_step;
+    if (total > 0) { issue(0); issue(1); }
+    tables();
+    if (total > 0) {
+      wait_vmcnt<6>();                                      // stage 0 has landed (stage 1 may be in flight)
+      __syncthreads();                                      // ... every wave's share of it; the tables are complete
+      int qi = 0, qch = 0;
+#pragma unroll 1
+      for (int s = 0; s < total; ++s) {
+        if (!(p.dbg & 2048)) issue(s + 2);                  // ring slot (s + 2) % 3 was last read in iteration s - 1
+        if (qch == 0) {
+          // a question starts: the fold of the one before it (none in front of the very first), or just its y and unit
+          const float* yn = ytab + qi * T_TILE;
+          const int exn = min(qmn[qi], 126), egn = min(qmn[SBW_MAXQ + qi], 126);
+          if (pending) {
+            if (!(p.dbg & 512)) fold(yn, exn, egn);
+          } else {
+            keep_y(yn);
+            ex_prev = exn; eg_prev = egn;
+            pending = true;
+          }
+        }
+        if (!(p.dbg & 1024)) compute(s % SBW_RING, qi, qch);
+        wait_vmcnt<6>();                                    // stage s + 1 has landed; stage s + 2 stays in flight
+        if (++qch == nchunk) { qch = 0; ++qi; }
+        __syncthreads();
+      }
+      wait_vmcnt<0>();
+    }
+    __syncthreads();                                        // the ring and the tables are about to be reused
+  }
+  if (pending && !(p.dbg & 512)) fold(nullptr, ex_prev, eg_prev);     // y_{K+1} = 0; T stays in its unit
+  const float scT = h2_unscale(ex_prev, eg_prev);
+
+  // ---- the two slabs leave through LDS (a wave's 64 x 64 share row-major in its own 17 KB of the idle ring)
+  float* oa = p.dW1a_part + (size_t)group * p.d * p.d;
+  float* ob = p.dW1b_part + (size_t)group * p.d * p.d;
+  constexpr int LDW = 68;
+  float* tw = reinterpret_cast<float*>(lds) + wave * (64 * LDW);
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          tw[(t * 16 + (lane >> 4) * 4 + e) * LDW + c * 16 + (lane & 15)] = which ? accT[t][c][e] * scT : accA[t][c][e];
+    float* o = (which ? ob : oa) + (size_t)(tk * T_TILE + wr * 64) * p.d + tj * 2 * T_TILE + wc * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = i * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+      *reinterpret_cast<f32x4*>(o + (size_t)r * p.d + c4) = *reinterpret_cast<const f32x4*>(tw + r * LDW + c4);
+    }
+  }
+}
+
+inline bool sb_h2_wide_ok(int B, int N, int d) { return d % 256 == 0 && B >= 1 && N >= 1 && ((N + 31) / 32) * 32 <= SBW_MAXROWS / 2; }
+// questions per workgroup of the wide kernel: tiles x groups ~ 256 workgroups
+inline int sb_h2_wide_qpg(int B, int N, int d) {
+  const int tiles = (d / 128) * (d / 256);
+  int groups = 256 / tiles;
+  if (groups < 1) groups = 1;
+  int qpg = (B + groups - 1) / groups;
+  const int rows_q = ((N + 31) / 32) * 32;
+  const int cap = min(SBW_MAXQ, (SBW_MAXROWS / 2) / rows_q);
+  if (qpg > cap) qpg = cap;
+  return qpg < 1 ? 1 : qpg;
+}
+inline hipError_t sb_h2w_launch(const SbH2P& p, hipStream_t st) {
+  const int nchunk = (p.N + 31) >> 5;
+  if (p.qpg < 1 || p.qpg > SBW_MAXQ || p.qpg * nchunk * 32 > SBW_MAXROWS / 2 || p.d % 256 || p.dy_part || p.nsteps < 1) return hipErrorInvalidValue;
+  constexpr size_t lds = (size_t)SBW_RING * SBW_STAGE + SBW_MAXROWS * 2 + SBW_MAXQ * T_TILE * 4 + 3 * SBW_MAXQ * 4 + 2 * T_TILE * 4;
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2w_kernel), lds);
+  if (e != hipSuccess) return e;
+  const int ngroup = (p.B + p.qpg - 1) / p.qpg;
+  hipLaunchKernelGGL(sb_h2w_kernel, dim3((p.d / 128) * (p.d / 256) * ngroup), dim3(512), lds, st, p);
+  return hipGetLastError();
+}
+
 inline hipError_t sb_h2_launch(const SbH2P& p, hipStream_t st) {
   const int nchunk = (p.N + 31) >> 5;
   if (p.qpg * nchunk * 32 > SBH_MAXROWS || p.qpg > SBH_MAXQ) return hipErrorInvalidValue;
