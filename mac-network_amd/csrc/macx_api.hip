@@ -12,6 +12,7 @@
 #include "macx_gemm6.hip.h"
 #include "macx_gemm_tn.hip.h"
 #include "macx_wgrad6.hip.h"
+#include "macx_gemm3h.hip.h"
 #include "macx_h2.hip.h"
 #include "macx_gemm_h2.hip.h"
 #include "macx_chain_h2.hip.h"
@@ -467,12 +468,16 @@ struct Packer {
   PackList L;
   int n = 0;
   void add(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst, int k_src = -1, int n_src = -1, int fmt = 0,
-           const float* maxabs = nullptr) {
-    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout, k_src < 0 ? K : k_src, n_src < 0 ? Nout : n_src, fmt, maxabs};
+           const float* maxabs = nullptr, float* exp_dst = nullptr) {
+    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout, k_src < 0 ? K : k_src, n_src < 0 ? Nout : n_src, fmt, maxabs, exp_dst};
   }
   hipError_t run(hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(64, n), dim3(256), 0, st, L);
+    size_t big = 0;
+    for (int i = 0; i < n; ++i) big = std::max(big, (size_t)L.d[i].K * L.d[i].Nout);
+    // (grid-stride kernels: 64 workgroups per matrix cover the cell's d x d weights in two passes; the stem's 9 Cin x Cout
+    // kernels are 18 - 36 times larger and took 60 - 90 us on that grid)
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(big > ((size_t)1 << 20) ? 512 : 64, n), dim3(256), 0, st, L);
     n = 0;
     return hipGetLastError();
   }
@@ -505,6 +510,16 @@ hipError_t absmax4(const float* a, size_t na, const float* b, size_t nb, const f
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !part) return e;
   hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)part, ABSMAX_BLOCKS, out);
+  return hipGetLastError();
+}
+
+// out[0] = max |.| of one large tensor (n % 4 == 0); part: AMAX_BIG_BLOCKS floats of scratch
+constexpr int AMAX_BIG_BLOCKS = 512;
+hipError_t absmax_big(const float* a, size_t n, float* out, float* part, hipStream_t st) {
+  hipLaunchKernelGGL(absmax_vec_kernel, dim3(AMAX_BIG_BLOCKS), dim3(256), 0, st, a, n / 4, part);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)part, AMAX_BIG_BLOCKS, out);
   return hipGetLastError();
 }
 
@@ -2134,6 +2149,7 @@ struct StemLayout {
   size_t X1;             // [B][N][Cmid]   act(conv0)
   size_t in1p;           // [B][Np][Cmid]  dropped, halo-padded X1
   size_t bits1;          // [B*N*Cmid/32]  keep bits of the layer-1 input dropout
+  size_t amax;           // 3h family: largest magnitudes [kernel0, kernel1, in0p, in1p] (+ 4 spare), then scratch for the absmax passes
   size_t total;
 };
 struct StemGeo { int N, wp, np; };
@@ -2148,6 +2164,7 @@ StemLayout make_stem(const macx_stem_shapes* s) {
   L.k0_p = take(wsize(9 * Ci, Cm)); L.k1_p = take(wsize(9 * Cm, Co));
   L.in0p = take(B * g.np * Ci); L.X1 = take(B * g.N * Cm); L.in1p = take(B * g.np * Cm);
   L.bits1 = take(B * g.N * Cm / 32 + 8);
+  L.amax = take(8 + 4 * AMAX_BIG_BLOCKS);
   L.total = off;
   return L;
 }
@@ -2167,6 +2184,7 @@ struct StemBwdLayout {
   size_t dY2, dY2p, dY1; // [B][N][Cout], [B][Np][Cout], [B][N][Cmid]
   size_t slab0, slab1;   // weight-gradient partial slabs
   int ns0, ns1;
+  size_t amax;           // 3h family: largest magnitudes [dY2, dY1] (+ 6 spare), then scratch
   size_t total;
 };
 StemBwdLayout make_stem_bwd(const macx_stem_shapes* s) {
@@ -2182,6 +2200,7 @@ StemBwdLayout make_stem_bwd(const macx_stem_shapes* s) {
   L.ns1 = conv_splits((int)(9 * Cm / T_TILE * (Co / T_TILE)), (int)(B * g.N));
   L.slab0 = take((size_t)L.ns0 * 9 * Ci * Cm);
   L.slab1 = take((size_t)L.ns1 * 9 * Cm * Co);
+  L.amax = take(8 + 2 * AMAX_BIG_BLOCKS);
   L.total = off;
   return L;
 }
@@ -2206,7 +2225,7 @@ void conv_gemm_params(GemmP& g, const macx_stem_shapes* s, const StemGeo& geo, c
   g.ldo = nout; g.e_inv_keep = 1.0f;
 }
 int conv_wgrad(const macx_stem_shapes* s, const StemGeo& geo, const float* Apad, int cin, const float* G, int cout, int ns, float* slab,
-               float* out, hipStream_t st) {
+               float* out, hipStream_t st, const float* a_max = nullptr, const float* g_max = nullptr) {
   TnP t;
   memset(&t, 0, sizeof(t));
   t.M = s->B * geo.N; t.Kd = 9 * cin; t.Jd = cout; t.nsplit = ns; t.rows_per_split = rows_per_split(t.M, ns);
@@ -2215,7 +2234,9 @@ int conv_wgrad(const macx_stem_shapes* s, const StemGeo& geo, const float* Apad,
   t.magic_n = (uint32_t)(((1ull << 32) + geo.N - 1) / geo.N);
   t.magic_w = (uint32_t)(((1ull << 32) + s->W - 1) / s->W);
   t.part = (ns == 1) ? out : slab;
-  CK(wgrad_any(t, st));
+  t.a_maxabs = a_max; t.g_maxabs = g_max;
+  if (a_max && g_max) CK(wgrad3h_launch(t, st));      // three fp16 terms (macx_gemm3h.hip.h)
+  else CK(wgrad_any(t, st));
   if (ns > 1) CK(slab_reduce_launch(slab, ns, (size_t)t.Kd * t.Jd, out, 0, st));
   return 0;
 }
@@ -2233,10 +2254,22 @@ int macx_stem_forward(const macx_stem_shapes* s, int act, float keep, uint32_t s
   hipStream_t st = (hipStream_t)stream;
   const StemGeo geo = stem_geo(s);
   const int Ci = s->Cin, Cm = s->Cmid, Co = s->Cout;
+  // the default (H2) family runs the stem on three fp16 MFMA terms with one exponent per operand tensor (macx_gemm3h.hip.h);
+  // the other two families keep the six-term bf16 split / the f32 MFMA
+  const bool h3 = h2_mode();
+  float* amax = saved + L.amax;
   Packer pk;
+  if (h3) {
+    CK(absmax_big(P->kernel0, (size_t)9 * Ci * Cm, amax + 0, amax + 8, st));
+    CK(absmax_big(P->kernel1, (size_t)9 * Cm * Co, amax + 1, amax + 8 + AMAX_BIG_BLOCKS, st));
+    pk.add(P->kernel0, Cm, 1, 9 * Ci, Cm, saved + L.k0_p, -1, -1, 3, amax + 0);
+    pk.add(P->kernel1, Co, 1, 9 * Cm, Co, saved + L.k1_p, -1, -1, 3, amax + 1);
+  } else {
   pk.add(P->kernel0, Cm, 1, 9 * Ci, Cm, saved + L.k0_p, -1, -1, wfmt_plain_f32ops());     // HWIO flattened = [9*Cin][Cmid] row-major
   pk.add(P->kernel1, Co, 1, 9 * Cm, Co, saved + L.k1_p, -1, -1, wfmt_plain_f32ops());
+  }
   CK(pk.run(st));
+  float* ascr = amax + 8 + 2 * AMAX_BIG_BLOCKS;
   PadP q0{s->B, geo.N, s->W, geo.wp, geo.np, Ci};
   PadP q1{s->B, geo.N, s->W, geo.wp, geo.np, Cm};
   // cnn_0: dropout -> conv3x3 SAME -> + b -> act   (ops.py:400-411)
@@ -2244,12 +2277,22 @@ int macx_stem_forward(const macx_stem_shapes* s, int act, float keep, uint32_t s
   GemmP g;
   conv_gemm_params(g, s, geo, saved + L.in0p, Ci, Cm, +1);
   g.Wp = saved + L.k0_p; g.out = saved + L.X1; g.bias = P->bias0; g.act = act;
+  if (h3) {
+    CK(absmax_big(saved + L.in0p, (size_t)s->B * geo.np * Ci, amax + 2, ascr, st));
+    g.a_maxabs = amax + 2;
+    CK((kb_gemm3h_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  } else
   CK((kb_gemm<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
   // cnn_1
   CK(launch_pad_drop(saved + L.X1, q1, keep, seed, SITE_STEM1, (uint32_t)((size_t)s->b0 * geo.N * Cm), saved + L.in1p,
                      reinterpret_cast<uint32_t*>(saved + L.bits1), st));
   conv_gemm_params(g, s, geo, saved + L.in1p, Cm, Co, +1);
   g.Wp = saved + L.k1_p; g.out = kb; g.bias = P->bias1; g.act = act;
+  if (h3) {
+    CK(absmax_big(saved + L.in1p, (size_t)s->B * geo.np * Cm, amax + 3, ascr + AMAX_BIG_BLOCKS, st));
+    g.a_maxabs = amax + 3;
+    CK((kb_gemm3h_launch<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
+  } else
   CK((kb_gemm<A_PLAIN, B_PLAIN, E_BIAS_ACT, false>(g, st)));
   return MACX_OK;
 }
@@ -2266,12 +2309,20 @@ int macx_stem_backward(const macx_stem_shapes* s, int act, float keep, uint32_t 
   const StemGeo geo = stem_geo(s);
   const int Ci = s->Cin, Cm = s->Cmid, Co = s->Cout, M = s->B * geo.N;
   (void)seed;
+  const bool h3 = h2_mode();
+  const float* fmax = saved + L.amax;                    // [kernel0, kernel1, in0p, in1p] from the forward pass
+  float* bmax = ws + W.amax;
   // backward-data weights of cnn_1: B[(tap, co)][ci] = K1[tap][ci][co]
   {
     Packer pk;
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < 9; ++tap) {
+      if (h3)      // nine per-tap transposes back to back = ONE [9 Cout][Cmid] matrix of format 3, one exponent behind the last
+        pk.add(P->kernel1 + (size_t)tap * Cm * Co, 1, Co, Co, Cm, ws + W.k1T_p + (size_t)tap * Co * Cm, -1, -1, 3, fmax + 1,
+               ws + W.k1T_p + (size_t)9 * Co * Cm);
+      else
       pk.add(P->kernel1 + (size_t)tap * Cm * Co, 1, Co, Co, Cm, ws + W.k1T_p + (size_t)tap * (gemm_split_mode() ? wsize(Co, Cm) : (size_t)Co * Cm), -1, -1,
              wfmt_plain_f32ops());
+    }
     CK(pk.run(st));
   }
   // dY2 = d_kb * act'(kb)
@@ -2279,15 +2330,21 @@ int macx_stem_backward(const macx_stem_shapes* s, int act, float keep, uint32_t 
   hipLaunchKernelGGL(pad_mul_actgrad_kernel, dim3(2048), dim3(256), 0, st, d_kb, kb, act, q2, ws + W.dY2, ws + W.dY2p);
   CK(hipGetLastError());
   CK(rowsum(ws + W.dY2, M, Co, Co, G->bias1, st));
-  CKI(conv_wgrad(s, geo, saved + L.in1p, Cm, ws + W.dY2, Co, W.ns1, ws + W.slab1, G->kernel1, st));
+  if (h3) CK(absmax_big(ws + W.dY2, (size_t)M * Co, bmax + 0, bmax + 8, st));
+  CKI(conv_wgrad(s, geo, saved + L.in1p, Cm, ws + W.dY2, Co, W.ns1, ws + W.slab1, G->kernel1, st, h3 ? fmax + 3 : nullptr, h3 ? bmax + 0 : nullptr));
   // dY1 = convT(dY2) * dropmask1 * act'(X1): gather with the opposite tap offsets
   GemmP g;
   conv_gemm_params(g, s, geo, ws + W.dY2p, Co, Cm, -1);
   g.Wp = ws + W.k1T_p; g.out = ws + W.dY1; g.aux = saved + L.X1; g.act = act;
   if (keep < 1.0f) { g.e_bits = reinterpret_cast<const uint32_t*>(saved + L.bits1); g.e_inv_keep = 1.0f / keep; }
+  if (h3) {
+    g.a_maxabs = bmax + 0;                              // the padded copy holds the same values
+    CK((kb_gemm3h_launch<A_PLAIN, B_PLAIN, E_MUL_DACT, false>(g, st)));
+  } else
   CK((kb_gemm<A_PLAIN, B_PLAIN, E_MUL_DACT, false>(g, st)));
   CK(rowsum(ws + W.dY1, M, Cm, Cm, G->bias0, st));
-  CKI(conv_wgrad(s, geo, saved + L.in0p, Ci, ws + W.dY1, Cm, W.ns0, ws + W.slab0, G->kernel0, st));
+  if (h3) CK(absmax_big(ws + W.dY1, (size_t)M * Cm, bmax + 1, bmax + 8 + AMAX_BIG_BLOCKS, st));
+  CKI(conv_wgrad(s, geo, saved + L.in0p, Ci, ws + W.dY1, Cm, W.ns0, ws + W.slab0, G->kernel0, st, h3 ? fmax + 2 : nullptr, h3 ? bmax + 1 : nullptr));
   return MACX_OK;
 }
 

@@ -83,6 +83,7 @@ struct GemmP {
   float e_inv_keep;
   int accumulate;         // E_DKB: 1 -> out += , 0 -> out =
   int dbg;                // measurement knobs (macx_debug_set(1, mask)): 1 skip epilogue, 2 skip in-loop staging, 4 write-through stores (unsafe, see epilogue), 8 no epilogue stores
+  const float* a_maxabs;  // kb_gemm3h_kernel: largest magnitude of A (device float)
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

@@ -32,6 +32,7 @@ struct TnP {
   uint32_t magic_n, magic_w;   // ceil(2^32 / conv_n), ceil(2^32 / conv_w)
   int nz; size_t zG, zpart;   // nz > 1: blockIdx.y selects one of nz independent contractions sharing A (G += z*zG, part += z*zpart); split kernel only
   int dbg;               // timing experiments (macx_debug_set(1, mask)): 16 no MFMAs, 32 no in-loop loads, 64 no in-loop split/store
+  const float* a_maxabs; const float* g_maxabs;   // wgrad3h_kernel: largest magnitude of A / of G (device floats)
 };
 
 // 8 waves: waves 0-3 and 4-7 each cover the 128x128 tile as 2x2 sub-tiles of 64x64 and take

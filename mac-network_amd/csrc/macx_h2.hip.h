@@ -357,6 +357,19 @@ __global__ __launch_bounds__(256) void absmax_kernel(AbsMaxList L) {
     else L.part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
   }
 }
+// ... of ONE large tensor (n % 4 == 0, 16-byte aligned): 16-byte loads, gridDim.x partials for absmax_finish_kernel
+__global__ __launch_bounds__(256) void absmax_vec_kernel(const float* __restrict__ s, size_t n4, float* part) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(s)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 // out[mat] = max over part[mat][0..nblk): one wave per matrix (blockDim = 64 * nmat <= 512)
 __global__ void absmax_finish_kernel(const float* __restrict__ part, int nblk, float* out) {
   const int mat = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -370,7 +383,8 @@ __global__ void absmax_finish_kernel(const float* __restrict__ part, int nblk, f
 constexpr int H2_WE_LO = -20, H2_WE_HI = 36;
 __device__ __forceinline__ int h2_weight_exponent(float maxabs) { return min(max(h2_exponent(maxabs), H2_WE_LO), H2_WE_HI); }
 __device__ __forceinline__ void pack_h2_weight(const float* src, int ld_k, int ld_j, int K, int Nout, int k_src, int n_src,
-                                               const float* maxabs, float* dst, size_t tid_global, size_t nthreads) {
+                                               const float* maxabs, float* dst, size_t tid_global, size_t nthreads,
+                                               float* exp_dst = nullptr) {
   const int e = h2_weight_exponent(*maxabs);
   const float s = h2_pow2(e);
   const size_t nslot = (size_t)(K >> 3) * Nout;
@@ -401,7 +415,9 @@ __device__ __forceinline__ void pack_h2_weight(const float* src, int ld_k, int l
     *reinterpret_cast<u32x4*>(d) = hi;
     *reinterpret_cast<u32x4*>(d + (size_t)4 * Nout * 16) = lo;
   }
-  if (tid_global == 0) reinterpret_cast<int*>(dst)[(size_t)K * Nout] = e;
+  // (exp_dst: several row blocks packed back to back as ONE matrix -- the per-tap transposes of a convolution's backward-data
+  // weights -- share one exponent behind the last of them)
+  if (tid_global == 0) *reinterpret_cast<int*>(exp_dst ? exp_dst : dst + (size_t)K * Nout) = e;
 }
 
 }  // namespace macx

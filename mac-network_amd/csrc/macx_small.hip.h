@@ -31,7 +31,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int 
 //   fmt 1: dst[kt][plane][j][32] bf16 -- the exact 3-way bf16 split of W (macx_gemm6.hip.h, B_PLAIN); K*Nout*3/2 floats
 //   fmt 2: dst[kt][j][32] fp32 k-major tiles (macx_gemm6.hip.h, B_YMIX_*: mixed in fp32, split while staging)
 //   fmt 3: H2 weight planes dst[kt][plane][g][Nout] x 16 B fp16 + the matrix exponent (macx_h2.hip.h, macx_gemm_h2.hip.h)
-struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; int fmt; const float* maxabs; };   // zero fill for k >= k_src or j >= n_src
+struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; int fmt; const float* maxabs; float* exp_dst; };   // zero fill for k >= k_src or j >= n_src; exp_dst: where format 3 leaves its exponent (null: behind the planes)
 constexpr int PACK_MAX = 40;
 struct PackList { PackDesc d[PACK_MAX]; };
 __global__ void pack_weights_kernel(PackList L) {
@@ -39,7 +39,7 @@ __global__ void pack_weights_kernel(PackList L) {
   const size_t total = (size_t)q.K * q.Nout;
   if (q.fmt == 3) {
     pack_h2_weight(q.src, q.ld_k, q.ld_j, q.K, q.Nout, q.k_src, q.n_src, q.maxabs, q.dst,
-                   (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+                   (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, q.exp_dst);
     return;
   }
   if (q.fmt == 0) {

@@ -1,13 +1,12 @@
 #!/bin/bash
-# one GPU call: sequential (key 9 = 0) vs pipelined forward (1): bitwise parity, ms/step, then the tests that compare the
-# one-call path with the stepwise path and the oracle
+# one GPU call: the stem on the 3-term fp16 family: parity tests, timing (tools/microbench.py --stem), kernel stats, tower tests
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
 mkdir -p $O
-timeout 600 python tools/kv_sweep.py 0 1 --key 9 --steps 20 --rounds 3 > $O/pipe_sweep.log 2>&1; echo "sweep rc=$?"
-grep -v "^ref" $O/pipe_sweep.log | tail -10
-timeout 900 python -m pytest tests/test_gpu_cell.py tests/test_gpu_configs.py tests/test_gpu_graph.py tests/test_gpu_dp.py -x -q > $O/pipe_pytest.log 2>&1; echo "pytest rc=$?"
-tail -4 $O/pipe_pytest.log
-timeout 300 python bench.py --no-cpu-baseline --no-model-level --no-native --no-extra-legs > $O/pipe_bench.json 2> $O/pipe_bench.err; echo "bench rc=$?"
-python -c "
-import json; d=json.load(open('$O/pipe_bench.json')); print(d['value'], d['ms_per_step'])"
+timeout 900 python -m pytest tests/test_gpu_stem.py -x -q > $O/stem_pytest.log 2>&1; echo "stem pytest rc=$?"; tail -5 $O/stem_pytest.log
+timeout 300 python tools/microbench.py --stem > $O/stem_micro.log 2>&1; tail -6 $O/stem_micro.log
+MACX_GEMM=split timeout 300 python tools/microbench.py --stem > $O/stem_micro_split.log 2>&1; tail -3 $O/stem_micro_split.log
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kv_k -o r -- python tools/microbench.py --stem > $O/stem_k.log 2>&1
+python tools/rocpd_stats.py $O/kv_k/r_results.db > $O/stem_kernel_stats.txt; rm -rf $O/kv_k
+head -14 $O/stem_kernel_stats.txt | cut -c1-90,100-160
+timeout 900 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_dp.py tests/test_gpu_output.py -x -q > $O/stem_pytest2.log 2>&1; echo "tower pytest rc=$?"; tail -3 $O/stem_pytest2.log
