@@ -464,6 +464,35 @@ hipError_t pack(const float* src, int ld_k, int ld_j, int K, int Nout, float* ds
   hipLaunchKernelGGL(pack_weight_kernel, dim3(256), dim3(256), 0, st, src, ld_k, ld_j, K, Nout, dst);
   return hipGetLastError();
 }
+// ---- device-side fills and copies as KERNELS.  No hipMemsetAsync / hipMemcpyAsync anywhere in this library: under HIP-graph
+// replay (ROCm 7.2) a memset node was seen to run out of order with the kernel nodes around it -- in round 3 behind the packed
+// weights' maxima, in round 4 behind dL/dc of a captured training step (the control unit's gradients differed from the eager
+// step's in three of four fresh processes, every replay alike; tools/graph_train_probe_verify.py) -- while kernel nodes keep
+// their order.  Sizes in bytes, multiples of 4.
+__global__ void fill_u32_kernel(uint32_t* dst, size_t n, uint32_t v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+__global__ void copy2d_u32_kernel(uint32_t* dst, size_t dpitch, const uint32_t* __restrict__ src, size_t spitch, size_t width, size_t rows) {
+  const size_t n = width * rows;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / width, c = i - r * width;
+    dst[r * dpitch + c] = src[r * spitch + c];
+  }
+}
+inline unsigned fill_grid(size_t n) { return (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (n + 1023) / 1024)); }
+inline hipError_t dev_zero(void* dst, size_t bytes, hipStream_t st) {
+  if (!bytes) return hipSuccess;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_grid(bytes / 4)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(dst), bytes / 4, 0u);
+  return hipGetLastError();
+}
+inline hipError_t dev_copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, hipStream_t st) {
+  if (!width || !rows) return hipSuccess;
+  hipLaunchKernelGGL(copy2d_u32_kernel, dim3(fill_grid(width / 4 * rows)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(dst), dpitch / 4,
+                     reinterpret_cast<const uint32_t*>(src), spitch / 4, width / 4, rows);
+  return hipGetLastError();
+}
+inline hipError_t dev_copy(void* dst, const void* src, size_t bytes, hipStream_t st) { return dev_copy2d(dst, bytes, src, bytes, bytes, 1, st); }
+
 struct Packer {
   PackList L;
   int n = 0;
@@ -1058,14 +1087,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   float* DC = ws + W.DC;
   // dL/d(newMemory linear output) for all steps; with writeMemAct = NON it IS dL/dm_{1..p}
   float* dwlin_all = (o->write_mem_act == MACX_ACT_NON && !o->write_gate) ? DM + Bd : ws + W.dwlin;
-  CK(hipMemsetAsync(DM, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
-  CK(hipMemsetAsync(DC, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
-  if (d_memory) CK(hipMemcpyAsync(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (d_control) CK(hipMemcpyAsync(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(dev_zero(DM, (size_t)(p + 1) * Bd * sizeof(float), st));
+  CK(dev_zero(DC, (size_t)(p + 1) * Bd * sizeof(float), st));
+  if (d_memory) CK(dev_copy(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), st));
+  if (d_control) CK(dev_copy(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), st));
   if ((units & U_CONTROL) && o->control_feed_prev) {
-    CK(hipMemsetAsync(GI->words, 0, (size_t)B * S * d * sizeof(float), st));
-    CK(hipMemsetAsync(ws + W.dwc_part, 0, Bd * sizeof(float), st));
-    CK(hipMemsetAsync(ws + W.dccx, 0, (size_t)(p + 1) * Bd * sizeof(float), st));
+    CK(dev_zero(GI->words, (size_t)B * S * d * sizeof(float), st));
+    CK(dev_zero(ws + W.dwc_part, Bd * sizeof(float), st));
+    CK(dev_zero(ws + W.dccx, (size_t)(p + 1) * Bd * sizeof(float), st));
   }
 
   const float* controls = saved + L.seg[MACX_SEG_CONTROLS];
@@ -1146,10 +1175,10 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     if (!(units & U_READ)) {
       // the write unit alone: dL/d(memory) = dwin[:, :d] (+ dm (1 - z) under the gate), dL/d(info), dL/d(control) (the gate's)
       const size_t pitch = (size_t)win * sizeof(float), wbytes = (size_t)d * sizeof(float);
-      CK(hipMemcpy2DAsync(ug->d_memory, wbytes, dwin, pitch, wbytes, B, hipMemcpyDeviceToDevice, st));
+      CK(dev_copy2d(ug->d_memory, wbytes, dwin, pitch, wbytes, B, st));
       if (o->write_gate) CK(axpy(ws + W.tmpBd[3], Bd, ug->d_memory, st));
-      CK(hipMemcpy2DAsync(ug->d_info_out, wbytes, dinfo, (size_t)ld_dinfo * sizeof(float), wbytes, B, hipMemcpyDeviceToDevice, st));
-      CK(hipMemcpyAsync(ug->d_control, DC + (size_t)(i + 1) * Bd, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+      CK(dev_copy2d(ug->d_info_out, wbytes, dinfo, (size_t)ld_dinfo * sizeof(float), wbytes, B, st));
+      CK(dev_copy(ug->d_control, DC + (size_t)(i + 1) * Bd, Bd * sizeof(float), st));
       continue;
     }
 
@@ -1407,7 +1436,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         l2.actgrad_src = saved + L.cc_h + (size_t)i * Bd; l2.actgrad_act = o->control_cont_act; l2.ld_ag = d;
         CK(small_linear_launch(l2, 1, st));
       } else {
-        CK(hipMemcpyAsync(dlin1, dcc_i, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+        CK(dev_copy(dlin1, dcc_i, Bd * sizeof(float), st));
       }
       // dx = dlin1 Wc^T = [d prev | d cI_i]
       LinP lx = lin_basic(dlin1, d, d, B, ws + W.wccT, nullptr, cin, MACX_ACT_NON, ws + W.dxc, cin);
@@ -1422,7 +1451,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
                            ws + W.dcI + (size_t)i * Bd);
         CK(hipGetLastError());
       } else {
-        CK(hipMemsetAsync(ws + W.dcI + (size_t)i * Bd, 0, Bd * sizeof(float), st));
+        CK(dev_zero(ws + W.dcI + (size_t)i * Bd, Bd * sizeof(float), st));
       }
     }
   }
@@ -1574,8 +1603,8 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   }
   if (units == U_READ) {
     // the read unit alone: dL/d(memory) = (dy Wy^T) through the two masks, dL/d(control) from the attention logits
-    CK(hipMemcpyAsync(ug->d_memory, DM, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
-    CK(hipMemcpyAsync(ug->d_control, DC + Bd, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+    CK(dev_copy(ug->d_memory, DM, Bd * sizeof(float), st));
+    CK(dev_copy(ug->d_control, DC + Bd, Bd * sizeof(float), st));
   }
 
   }   // phase != 2
@@ -1710,15 +1739,15 @@ int macx_read_fwd(const macx_opts* o, const macx_shapes* s, const macx_dropout* 
   if (saved_floats < L.total) return MACX_ESMALL;
   const size_t Bd = (size_t)s->B * s->d;
   CKI(pack_forward_weights(o, s, P, saved, L, 1, U_READ, st));
-  CK(hipMemcpyAsync(saved + L.seg[MACX_SEG_MEMORIES], memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  CK(hipMemcpyAsync(saved + L.seg[MACX_SEG_CONTROLS] + Bd, control, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(dev_copy(saved + L.seg[MACX_SEG_MEMORIES], memory, Bd * sizeof(float), st));
+  CK(dev_copy(saved + L.seg[MACX_SEG_CONTROLS] + Bd, control, Bd * sizeof(float), st));
   macx_inputs in;
   memset(&in, 0, sizeof(in));
   in.knowledgeBase = knowledgeBase;
   CKI(cell_step_impl(o, s, dp, P, &in, saved, saved_floats, 1, 0, U_READ, stream));
   const float* info_raw = dp->keep_write < 1.0f ? saved + L.info_raw : saved + L.seg[MACX_SEG_INFOS];
-  CK(hipMemcpyAsync(info, info_raw, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  CK(hipMemcpyAsync(att, saved + L.seg[MACX_SEG_ATT_KB], (size_t)s->B * s->N * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(dev_copy(info, info_raw, Bd * sizeof(float), st));
+  CK(dev_copy(att, saved + L.seg[MACX_SEG_ATT_KB], (size_t)s->B * s->N * sizeof(float), st));
   return MACX_OK;
 }
 
@@ -1753,13 +1782,13 @@ int macx_write_fwd(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   const size_t Bd = (size_t)s->B * s->d;
   CKI(pack_forward_weights(o, s, P, saved, L, 1, U_WRITE, st));
   float* info_raw = dp->keep_write < 1.0f ? saved + L.info_raw : saved + L.seg[MACX_SEG_INFOS];
-  CK(hipMemcpyAsync(saved + L.seg[MACX_SEG_MEMORIES], memory, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  CK(hipMemcpyAsync(info_raw, info, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  CK(hipMemcpyAsync(saved + L.seg[MACX_SEG_CONTROLS] + Bd, control, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(dev_copy(saved + L.seg[MACX_SEG_MEMORIES], memory, Bd * sizeof(float), st));
+  CK(dev_copy(info_raw, info, Bd * sizeof(float), st));
+  CK(dev_copy(saved + L.seg[MACX_SEG_CONTROLS] + Bd, control, Bd * sizeof(float), st));
   macx_inputs in;
   memset(&in, 0, sizeof(in));
   CKI(cell_step_impl(o, s, dp, P, &in, saved, saved_floats, 1, 0, U_WRITE, stream));
-  CK(hipMemcpyAsync(new_memory, saved + L.seg[MACX_SEG_MEMORIES] + Bd, Bd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CK(dev_copy(new_memory, saved + L.seg[MACX_SEG_MEMORIES] + Bd, Bd * sizeof(float), st));
   return MACX_OK;
 }
 
@@ -2073,10 +2102,8 @@ int macx_output_forward(const macx_out_shapes* s, int act, float keep, uint32_t 
   // classifier (model.py:547-576 -> ops.FCLayer ops.py:349-359): dropout on every layer input, act between layers
   const DropSpec d0 = make_drop(keep, seed, SITE_OUT_FC0, 0), d1 = make_drop(keep, seed, SITE_OUT_FC1, 0);
   // the concat is built in place: columns [0,d) memory, [d,2d) eq, with the layer-input mask indexed over [B, 2d]
-  CK(hipMemcpy2DAsync(saved + L.x0, (size_t)in * sizeof(float), memory, (size_t)d * sizeof(float), (size_t)d * sizeof(float), B,
-                      hipMemcpyDeviceToDevice, st));
-  CK(hipMemcpy2DAsync(saved + L.x0 + d, (size_t)in * sizeof(float), saved + L.eq, (size_t)d * sizeof(float), (size_t)d * sizeof(float), B,
-                      hipMemcpyDeviceToDevice, st));
+  CK(dev_copy2d(saved + L.x0, (size_t)in * sizeof(float), memory, (size_t)d * sizeof(float), (size_t)d * sizeof(float), B, st));
+  CK(dev_copy2d(saved + L.x0 + d, (size_t)in * sizeof(float), saved + L.eq, (size_t)d * sizeof(float), (size_t)d * sizeof(float), B, st));
   hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)(saved + L.x0), B, in, (uint32_t)s->b0, d0, no_drop(),
                      saved + L.x0);
   LinP f0 = lin_basic(saved + L.x0, in, in, B, saved + L.w0_p, P->fc0_b, H, act, saved + L.h, H);
@@ -2085,7 +2112,7 @@ int macx_output_forward(const macx_out_shapes* s, int act, float keep, uint32_t 
                      saved + L.x1);
   CK(hipGetLastError());
   // fc_1: bias padded with zeros by reading through a guarded copy
-  CK(hipMemsetAsync(saved + L.logits_pad, 0, (size_t)B * Ap * sizeof(float), st));
+  CK(dev_zero(saved + L.logits_pad, (size_t)B * Ap * sizeof(float), st));
   LinP f1 = lin_basic(saved + L.x1, H, H, B, saved + L.w1_p, nullptr, Ap, MACX_ACT_NON, saved + L.logits_pad, Ap);
   CK(small_linear_launch(f1, 1, st));
   hipLaunchKernelGGL(crop_cols_kernel, dim3(16), dim3(256), 0, st, (const float*)(saved + L.logits_pad), Ap, B, A, logits);
@@ -2439,9 +2466,9 @@ int macx_encoder_forward(const macx_enc_shapes* s, float keep_input, float keep_
                        saved + L.Zx + (size_t)dir * B * S * G, G);
     CK(small_linear_launch(l, 1, st));
   }
-  CK(hipMemsetAsync(saved + L.hs, 0, 2 * (size_t)(S + 1) * Bh * sizeof(float), st));
-  CK(hipMemsetAsync(saved + L.cs, 0, 2 * (size_t)(S + 1) * Bh * sizeof(float), st));
-  CK(hipMemsetAsync(words, 0, (size_t)B * S * 2 * h * sizeof(float), st));
+  CK(dev_zero(saved + L.hs, 2 * (size_t)(S + 1) * Bh * sizeof(float), st));
+  CK(dev_zero(saved + L.cs, 2 * (size_t)(S + 1) * Bh * sizeof(float), st));
+  CK(dev_zero(words, (size_t)B * S * 2 * h * sizeof(float), st));
   for (int tau = 0; tau < S; ++tau) {
     // R = h_prev Wh and the cell, both directions, one launch per time step
     LstmStepP c;
@@ -2452,8 +2479,8 @@ int macx_encoder_forward(const macx_enc_shapes* s, float keep_input, float keep_
   }
   // vecQuestions = dropout(concat([h_fw_final, h_bw_final]))   (ops.py:905-906, model.py:292)
   for (int dir = 0; dir < 2; ++dir)
-    CK(hipMemcpy2DAsync(vecQ + dir * h, (size_t)2 * h * sizeof(float), saved + L.hs + ((size_t)dir * (S + 1) + S) * Bh,
-                        (size_t)h * sizeof(float), (size_t)h * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+    CK(dev_copy2d(vecQ + dir * h, (size_t)2 * h * sizeof(float), saved + L.hs + ((size_t)dir * (S + 1) + S) * Bh,
+                        (size_t)h * sizeof(float), (size_t)h * sizeof(float), B, st));
   hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)vecQ, B, 2 * h, (uint32_t)s->b0,
                      make_drop(keep_question, seed, SITE_QUESTION, 0), no_drop(), vecQ);
   CK(hipGetLastError());
@@ -2478,14 +2505,14 @@ int macx_encoder_backward(const macx_enc_shapes* s, float keep_input, float keep
     pk.add(K + (size_t)E * G, 1, G, G, h, ws + W.whT_p + (size_t)dir * G * h);   // Wh^T: [4h] -> [h]
   }
   CK(pk.run(st));
-  CK(hipMemsetAsync(ws + W.dZ, 0, 2 * (size_t)B * S * G * sizeof(float), st));
-  CK(hipMemsetAsync(ws + W.dc, 0, 2 * Bh * sizeof(float), st));
+  CK(dev_zero(ws + W.dZ, 2 * (size_t)B * S * G * sizeof(float), st));
+  CK(dev_zero(ws + W.dc, 2 * Bh * sizeof(float), st));
   // d(final states) = d_vecQ through the question dropout, split per direction
   hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, d_vecQ, B, 2 * h, (uint32_t)s->b0,
                      make_drop(keep_question, seed, SITE_QUESTION, 0), no_drop(), ws + W.dq);
   for (int dir = 0; dir < 2; ++dir)
-    CK(hipMemcpy2DAsync(ws + W.dh + (size_t)dir * Bh, (size_t)h * sizeof(float), ws + W.dq + dir * h, (size_t)2 * h * sizeof(float),
-                        (size_t)h * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+    CK(dev_copy2d(ws + W.dh + (size_t)dir * Bh, (size_t)h * sizeof(float), ws + W.dq + dir * h, (size_t)2 * h * sizeof(float),
+                        (size_t)h * sizeof(float), B, st));
   {
     const size_t lds = lstm_step_bwd_lds(h);
     CK(lds_attr_once(reinterpret_cast<const void*>(lstm_step_bwd_kernel), lds));
@@ -2507,7 +2534,7 @@ int macx_encoder_backward(const macx_enc_shapes* s, float keep_input, float keep
     float* dK = dir ? Gr->bw_kernel : Gr->fw_kernel;
     // input block of the kernel: X^T dZ (rows [0,E) of the padded product)
     CKI(wgrad_impl(saved + L.Xp, Ep, ws + W.dZ + (size_t)dir * B * S * G, G, B * S, Ep, G, ws + W.tmpW, ws + W.slab, st));
-    CK(hipMemcpyAsync(dK, ws + W.tmpW, (size_t)E * G * sizeof(float), hipMemcpyDeviceToDevice, st));
+    CK(dev_copy(dK, ws + W.tmpW, (size_t)E * G * sizeof(float), st));
     // recurrent block: sum_tau h_prev(tau)^T dG_tau  -- one contraction over S*B rows
     CKI(wgrad_impl(saved + L.hs + (size_t)dir * (S + 1) * Bh, h, ws + W.dG + (size_t)dir * S * B * G, G, S * B, h, G,
                    dK + (size_t)E * G, ws + W.slab, st));

@@ -185,10 +185,16 @@ class CapturedTrainStep:
         for t, gcap in zip(self._leaves(), captured_grads):
             t.grad = gcap
         ok = True
-        for _ in range(replays):
+        self.verify_report = []              # (replay, index into [memory] + leaves) of every tensor that differed
+        for r in range(replays):
             self.graph.replay()
-            ok = ok and bool(torch.equal(self.memory, mem)) and all(torch.equal(t.grad, w) for t, w in zip(self._leaves(), want))
+            if not torch.equal(self.memory, mem):
+                self.verify_report.append((r, 0))
+            for i, (t, w) in enumerate(zip(self._leaves(), want)):
+                if not torch.equal(t.grad, w):
+                    self.verify_report.append((r, i + 1))
         torch.cuda.synchronize(dev)
+        ok = not self.verify_report
         return ok
 
     def load(self, vecQuestions, words, lengths, knowledgeBase, d_memory):

@@ -32,6 +32,8 @@ def macx():
         m._lib.lib().macx_debug_set(5, int(os.environ["MACX_SB_DEFER"]))
     if os.environ.get("MACX_CHAIN_KV"):     # K-loop variant of the chain kernels (macx_chain_h2.hip.h: ChainCtx::kloop)
         m._lib.lib().macx_debug_set(7, int(os.environ["MACX_CHAIN_KV"]))
+    if os.environ.get("MACX_SB_WIDE"):      # 0: the deferred S_b contraction on the 128 x 128 kernel
+        m._lib.lib().macx_debug_set(8, int(os.environ["MACX_SB_WIDE"]))
     if os.environ.get("MACX_OVERLAP"):      # 0: no side queue in the backward pass
         m._lib.lib().macx_debug_set(6, int(os.environ["MACX_OVERLAP"]))
     return m
