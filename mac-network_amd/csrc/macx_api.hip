@@ -300,7 +300,7 @@ struct BwdLayout {
   size_t dzpre;     // [p,B,d] gate pre-activation gradient
   size_t dsc;       // [p,B,d] gradient of the projected control of the self attention
   size_t dws_part, dbs_part;   // [p,B,d], [p,B]
-  size_t small_slab;
+  size_t small_slab, small_slab_stride;
   size_t tmp_dd;    // [d,d] scratch
   size_t act_floats;                 // floats of one [B,N,d] activation (H2 size in h2 mode)
   size_t ecom;                       // h2: [4][EMIN_NB][8] ints, partial minima of the row exponents of H1 / dI2 / KBd / dX over all steps
@@ -372,7 +372,8 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
     const int ns = wgrad_splits((int)(p * B), (int)d, (int)d);
     small = (size_t)ns * d * d;
   }
-  L.small_slab = take(small);
+  L.small_slab_stride = al4(small);
+  L.small_slab = take(8 * L.small_slab_stride);        // SmallWgradBatch: one slab set per batched contraction
   L.tmp_dd = take(d * d);
   L.ecom = take(4 * EMIN_NB * 8);
   L.wg_ftab = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
@@ -627,6 +628,42 @@ int wgrad_impl(const float* A, int lda, const float* G, int ldg, int M, int Kd, 
   if (t.nsplit > 1) CK(slab_reduce_launch(ws, t.nsplit, (size_t)Kd * Jd, out, 0, st));
   return 0;
 }
+
+// The weight gradients of the [B,d]-sized linears (768 reduction rows each at p = 12: 17 us of latency per launch + a slab
+// reduction) collected and run as ONE contraction launch + ONE slab reduction (wgrad6_list_kernel).  An entry that does not fit
+// the batch (other tile geometry, the f32 kernel family, more than 8) runs on its own at once.
+struct SmallWgradBatch {
+  TnList L; SlabList S;
+  int n = 0, nred = 0, jw = 0;
+  size_t max_n = 0;
+  float* slab; size_t slab_stride;
+  SmallWgradBatch(float* slab_, size_t stride) : slab(slab_), slab_stride(stride) { memset(&L, 0, sizeof(L)); memset(&S, 0, sizeof(S)); }
+  int add(const float* A, int lda, const float* G, int ldg, int M, int Kd, int Jd, float* out, hipStream_t st) {
+    const bool ok = gemm_split_mode() && !(kb_gemm_dbg() & 128) && n < 8 && (jw == 0 || jw == wgrad6_jw(Jd));
+    if (!ok) return wgrad_impl(A, lda, G, ldg, M, Kd, Jd, out, slab + (size_t)7 * slab_stride, st);
+    jw = wgrad6_jw(Jd);
+    TnP& t = L.d[n];
+    t.M = M; t.Kd = Kd; t.Jd = Jd;
+    t.nsplit = wgrad_splits(M, Kd, Jd);
+    t.rows_per_split = rows_per_split(M, t.nsplit);
+    t.A = A; t.lda = lda; t.a_mod = M; t.G = G; t.ldg = ldg;
+    t.part = (t.nsplit == 1) ? out : slab + (size_t)n * slab_stride;
+    L.nblk[n] = (Kd / T_TILE) * (Jd / (jw * T_TILE)) * t.nsplit;
+    if (t.nsplit > 1) {
+      S.d[nred++] = SlabDesc{t.part, t.nsplit, (size_t)Kd * Jd / 4, out, 0};
+      max_n = std::max(max_n, (size_t)Kd * Jd);
+    }
+    ++n;
+    return 0;
+  }
+  int run(hipStream_t st) {
+    if (n == 0) return 0;
+    CK(jw == 2 ? wgrad6_list_launch_t<2>(L, n, st) : wgrad6_list_launch_t<1>(L, n, st));
+    if (nred) CK(slab_reduce_list_launch(S, nred, max_n, st));
+    n = nred = 0;
+    return 0;
+  }
+};
 
 }  // namespace
 
@@ -1035,6 +1072,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const SavedLayout L = make_saved(o, s, 1);
   const BwdLayout W = make_bwd(o, s);
   if (saved_floats < L.total || ws_floats < W.total) return MACX_ESMALL;
+  SmallWgradBatch wb(ws + W.small_slab, W.small_slab_stride);       // weight gradients of the [B,d] linears: one launch at the end of phase 1
   const int B = s->B, N = s->N, d = s->d, p = s->p, S = s->S;
   const size_t Bd = (size_t)B * d;
   const size_t BNd = (size_t)B * N * d;
@@ -1087,8 +1125,12 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   float* DC = ws + W.DC;
   // dL/d(newMemory linear output) for all steps; with writeMemAct = NON it IS dL/dm_{1..p}
   float* dwlin_all = (o->write_mem_act == MACX_ACT_NON && !o->write_gate) ? DM + Bd : ws + W.dwlin;
-  CK(dev_zero(DM, (size_t)(p + 1) * Bd * sizeof(float), st));
-  CK(dev_zero(DC, (size_t)(p + 1) * Bd * sizeof(float), st));
+  if (DC == DM + (size_t)(p + 1) * Bd) {                 // (adjacent in the workspace: one fill)
+    CK(dev_zero(DM, 2 * (size_t)(p + 1) * Bd * sizeof(float), st));
+  } else {
+    CK(dev_zero(DM, (size_t)(p + 1) * Bd * sizeof(float), st));
+    CK(dev_zero(DC, (size_t)(p + 1) * Bd * sizeof(float), st));
+  }
   if (d_memory) CK(dev_copy(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), st));
   if (d_control) CK(dev_copy(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), st));
   if ((units & U_CONTROL) && o->control_feed_prev) {
@@ -1528,14 +1570,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     l.seg[0].zstride = Bd; l.zout = Bd; l.addend = dst; l.ld_add = d; l.zadd = Bd;
     if (o->write_self_att_cont && !o->control_feed_prev) CK(small_linear_launch(l, p, st));
     const float* src = o->write_self_att_cont ? saved + L.cc : controls + Bd;
-    CKI(wgrad_impl(src, d, ws + W.dsc, d, p * B, d, d, GP->selfCtrl_W, ws + W.small_slab, st));
+    CKI(wb.add(src, d, ws + W.dsc, d, p * B, d, d, GP->selfCtrl_W, st));
     CK(rs.add(ws + W.dsc, p * B, d, d, GP->selfCtrl_b, st));
     CK(rs.add(ws + W.dws_part, p * B, d, d, GP->selfLogits_w, st));
     CK(rs.add(ws + W.dbs_part, p * B, 1, 1, GP->selfLogits_b, st));
   }
   }   // U_ALL
   if (o->write_gate && (units & U_WRITE)) {
-    CKI(wgrad_impl(controls + Bd, d, ws + W.dzpre, d, p * B, d, d, GP->gate_W, ws + W.small_slab, st));
+    CKI(wb.add(controls + Bd, d, ws + W.dzpre, d, p * B, d, d, GP->gate_W, st));
     CK(rs.add(ws + W.dzpre, p * B, d, d, GP->gate_b, st));
   }
   if (units == U_ALL) {
@@ -1579,7 +1621,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     LinP l = lin_basic(ws + W.du, d, d, B, ws + W.wqT, nullptr, d, MACX_ACT_NON, GI->vecQuestions, d);
     CK(small_linear_launch(l, 1, st));
   }
-  CKI(wgrad_impl(in->vecQuestions, d, ws + W.du, d, B, d, d, GP->qInput_W, ws + W.small_slab, st));
+  CKI(wb.add(in->vecQuestions, d, ws + W.du, d, B, d, d, GP->qInput_W, st));
   CK(rs.add(ws + W.du, B, d, d, GP->qInput_b, st));
 
   // ---- initial state (mac_cell.py:496-505)
@@ -1591,14 +1633,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   }   // U_ALL
   // ---- weight gradients of the [B,d] linears, one contraction over all p*B rows each
   if (units & U_READ) {
-    CKI(wgrad_impl(saved + L.md, d, ws + W.DY, d, p * B, d, d, GP->projY_W, ws + W.small_slab, st));
+    CKI(wb.add(saved + L.md, d, ws + W.DY, d, p * B, d, d, GP->projY_W, st));
     CK(rs.add(ws + W.DY, p * B, d, d, GP->projY_b, st));
   }
   if (units & U_WRITE) {
-    CKI(wgrad_impl(memories, d, dwlin_all, d, p * B, d, d, GP->newMemory_W, ws + W.small_slab, st));
-    CKI(wgrad_impl(infos, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + dd, ws + W.small_slab, st));
+    CKI(wb.add(memories, d, dwlin_all, d, p * B, d, d, GP->newMemory_W, st));
+    CKI(wb.add(infos, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + dd, st));
     if (o->write_self_att)
-      CKI(wgrad_impl(saved + L.self_smry, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + 2 * dd, ws + W.small_slab, st));
+      CKI(wb.add(saved + L.self_smry, d, dwlin_all, d, p * B, d, d, GP->newMemory_W + 2 * dd, st));
     CK(rs.add(dwlin_all, p * B, d, d, GP->newMemory_b, st));
   }
   if (units == U_READ) {
@@ -1607,6 +1649,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     CK(dev_copy(ug->d_control, DC + Bd, Bd * sizeof(float), st));
   }
 
+  CKI(wb.run(st));
   }   // phase != 2
   CK(rs.run(st));
   if (phase == 1 || !(units & U_READ)) return MACX_OK;

@@ -26,7 +26,7 @@ template <int JW>
 constexpr int w6_stage_bytes() { return W6_OPER + 3 * 4 * (JW * 128 * 16 + 32); }
 
 template <bool CONV, int JW>
-__global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
+__device__ __forceinline__ void wgrad6_body(const TnP& p, const int zidx, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
   constexpr int JT = JW * T_TILE;                   // output tile width
@@ -37,9 +37,8 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
   const int ntj = p.Jd / JT;
   const int ntk = p.Kd / T_TILE;
   const int ntile = ntj * ntk;
-  const int nblk = gridDim.x;
-  int v = blockIdx.x;
-  if ((nblk & 7) == 0) v = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  int v = bid;
+  if ((nblk & 7) == 0) v = (bid & 7) * (nblk >> 3) + (bid >> 3);
   const int split = v / ntile;
   const int tile = v % ntile;
   const int tk = tile / ntj, tj = tile % ntj;
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
     }
     const int mg = wave;
     const float* baseA = p.A + a_col0 + 2 * lane;
-    const float* baseG = p.G + (size_t)blockIdx.y * p.zG + tj * JT + 2 * JW * lane;
+    const float* baseG = p.G + (size_t)zidx * p.zG + tj * JT + 2 * JW * lane;
     int amod_row = (m_begin + mg * 8) % p.a_mod;   // A row of reduction row m is m % a_mod, kept incrementally
     f32x2_t ra[3][8];
     gvec rg[3][8];
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
       __syncthreads();
     }
     // 16x16 accumulator map: col = lane & 15 (j), row = (lane >> 4) * 4 + reg (k)
-    float* out = p.part + (size_t)blockIdx.y * p.zpart + (size_t)split * p.Kd * p.Jd;
+    float* out = p.part + (size_t)zidx * p.zpart + (size_t)split * p.Kd * p.Jd;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -186,6 +185,20 @@ __global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) {
           out[(size_t)k * p.Jd + j] = acc[t][c][e];
         }
   }
+}
+
+template <bool CONV, int JW>
+__global__ __launch_bounds__(512) void wgrad6_kernel(TnP p) { wgrad6_body<CONV, JW>(p, blockIdx.y, blockIdx.x, gridDim.x); }
+
+// several independent contractions of the same tile geometry in ONE launch (the [B,d]-sized linears' weight gradients at the end
+// of a backward pass: 768 reduction rows each, a launch of their own was 17 us of latency + a slab reduction): blockIdx.y
+// selects the contraction, workgroups past a contraction's own count leave at once
+struct TnList { TnP d[8]; int nblk[8]; };
+template <int JW>
+__global__ __launch_bounds__(512) void wgrad6_list_kernel(TnList L) {
+  const int n = L.nblk[blockIdx.y];
+  if ((int)blockIdx.x >= n) return;
+  wgrad6_body<false, JW>(L.d[blockIdx.y], 0, blockIdx.x, n);
 }
 
 inline int wgrad6_jw(int Jd) { return (Jd % 256 == 0) ? 2 : 1; }
@@ -203,6 +216,17 @@ inline hipError_t wgrad6_launch_t(const TnP& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int JW>
+inline hipError_t wgrad6_list_launch_t(const TnList& L, int count, hipStream_t st) {
+  auto kern = wgrad6_list_kernel<JW>;
+  constexpr size_t lds = 2 * w6_stage_bytes<JW>();
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
+  if (e != hipSuccess) return e;
+  int gx = 1;
+  for (int i = 0; i < count; ++i) gx = L.nblk[i] > gx ? L.nblk[i] : gx;
+  hipLaunchKernelGGL(kern, dim3(gx, count), dim3(512), lds, st, L);
+  return hipGetLastError();
+}
 inline hipError_t wgrad6_launch(const TnP& p, hipStream_t st) {
   if (wgrad6_jw(p.Jd) == 2) return p.conv_taps ? wgrad6_launch_t<true, 2>(p, st) : wgrad6_launch_t<false, 2>(p, st);
   return p.conv_taps ? wgrad6_launch_t<true, 1>(p, st) : wgrad6_launch_t<false, 1>(p, st);
