@@ -15,12 +15,16 @@ a checkpoint load between calls is seen.  Changing a parameter's storage (`.to()
 
 A capture checks itself before it is used (`verify=True`): three replays on random inputs must reproduce the eager run bit
 for bit; a process whose replays do not falls back to eager launches (`captured` is False, a warning says so): slower where
-the host is slow, never wrong.  The check exists because of a bug it would have caught: until the end of round 3 the
-per-matrix maximum behind every packed weight's exponent was a 16-byte memset followed by integer atomicMax, and in about
-one process in ten (one in three for the smallest shapes) the replayed graph ran the two out of order from its second
+the host is slow, never wrong.  The check exists because of a bug it would have caught.  Until the end of round 3 the
+per-matrix maximum behind every packed weight's exponent was a 16-byte hipMemsetAsync followed by integer atomicMax, and in
+about one process in ten (one in three for the smallest shapes) the replayed graph ran the two out of order from its second
 replay on -- maximum 0, exponent 0, weights split at the wrong scale, results finite and 1e-2 off, deterministically for
-that process, while eager launches of the same kernels stayed bit-identical.  `absmax4` now writes per-workgroup partials
-and a second kernel combines them (no memset, no atomics); tools/graph_replay_probe.py is the probe that found it.
+that process, while eager launches of the same kernels stayed bit-identical.  Round 3 removed that one pair; round 4 found
+the general rule behind it (tools/graph_train_probe_verify.py, profiles/r04_graph_train_verify_8_processes.txt): under
+ROCm 7.2 a captured hipMemsetAsync / hipMemcpyAsync becomes a memset / memcpy NODE, and replay does not keep such nodes in
+stream order with the kernel nodes around them.  The library therefore issues no memset or memcpy at all any more -- every
+fill and copy on the step's path is a kernel (`dev_zero` / `dev_copy` / `dev_copy2d` in macx_api.hip) -- and reductions that
+used to start from a memset write per-workgroup partials that a later kernel combines.
 """
 import warnings
 
@@ -115,8 +119,8 @@ class CapturedTrainStep:
 
     About 140 launches per step (p = 12) plus what autograd adds around them; a host that cannot issue them faster than the
     GPU retires them (gpurun boxes differ by 7x in host speed) sets the pace of the eager step, a replay does not depend on it.
-    Nothing in the step orders itself against a memset any more (round 4: the minimum-exponent arrays behind the deferred
-    contractions were the last memset-then-atomicMin pair), which is what makes the backward pass capturable.
+    The library issues no memset / memcpy node (module docstring; the minimum-exponent arrays behind the deferred contractions
+    were the last memset-then-atomicMin pair), which is what makes the backward pass capturable.
 
     LIMIT -- the dropout masks are a function of (seed, site, step, element) and the seed travels BY VALUE in the kernel
     parameters: every replay draws the masks of the captured seed.  That is exact for measurement and for a fixed-mask
