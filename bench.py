@@ -302,24 +302,24 @@ def gqa_shape_p4(macx, dev, seed, flag_file, steps=8):
 
 def train_step_graph(macx, dev, seed, steps=20):
     """The metric's step (B=64, p=12, fwd+bwd, train-mode dropout) replayed from ONE captured HIP graph (macx.CapturedTrainStep):
-    what the step costs when the host is out of the loop.  The masks of a replay are those of the captured seed (the seed is a
-    kernel parameter), so this is a measurement leg, not a training loop."""
+    what the step costs when the host is out of the loop.  Every replay draws fresh dropout masks, as a training loop does: the
+    seed is baked into the capture, the run's mask word (macx_dropout.mask_word, device memory) is rewritten per replay."""
     cfg = macx.configs.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
     vq, words, lengths, kb = macx.configs.synthetic_inputs(B, S, N, D, seed=seed)
     params = macx.MACCellParams(cfg, P, generator=torch.Generator().manual_seed(seed)).to(dev)
     cap = macx.CapturedTrainStep(cfg, params, B, S, N, seed=seed)
     gm = (torch.randn(B, D, generator=torch.Generator().manual_seed(1)) / B).to(dev)
     cap.load(vq.to(dev), words.to(dev), lengths.to(dev), kb.to(dev), gm)
-    for _ in range(4):
-        cap.replay()
+    for it in range(4):
+        cap.replay(iteration=it)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        cap.replay()
+    for it in range(steps):
+        cap.replay(iteration=4 + it)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(B / dt, 1), "unit": "questions/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
-            "graph_replay": bool(cap.captured),
+            "graph_replay": bool(cap.captured), "masks": "fresh per replay (mask word rewritten in device memory, one 4-byte fill per step)",
             "launch": ("one captured HIP graph per step (forward + full backward; verified bit for bit against the eager step, all "
                        "gradients, three replays)" if cap.captured else
                        "EAGER launches: this process's replays failed CapturedTrainStep's self-check (mac-network_amd/graph.py)")}

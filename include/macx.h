@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MACX_ABI_VERSION 3
+#define MACX_ABI_VERSION 4
 
 enum {
   MACX_OK = 0,
@@ -88,6 +88,15 @@ typedef struct macx_shapes {
 typedef struct macx_dropout {
   float keep_memory, keep_read, keep_write;   /* config.py:213-215                              */
   uint32_t seed;                              /* stateless mask stream, see macx_dropout_mask  */
+  const uint32_t* mask_word;                  /* NULL, or ONE 32-bit word in DEVICE memory that every dropout site of the run
+                                               * XORs into its key when the kernel RUNS (not when it is enqueued):
+                                               *   mask(seed, word, site, step, i) = stream keyed site_key(seed, site, step) ^ word.
+                                               * The seed travels by value in kernel arguments, so a captured HIP graph would
+                                               * replay the masks of the captured seed for ever; the word is read on every
+                                               * replay, so ONE capture of a training step draws fresh masks per replay
+                                               * (write the word between replays -- e.g. a hash of the iteration number).
+                                               * Forward and backward of one run must see the same word.  NULL == word 0 ==
+                                               * the masks of ABI <= 3. */
 } macx_dropout;
 
 /* Parameters, keyed by the reference's variable names under macModel/MACnetwork/ (SURVEY 8b).
@@ -377,6 +386,9 @@ int macx_control_attend_bwd(const macx_shapes*, const float* d_control, const fl
  * `first` (test hook for the stateless stream; site numbers in macx_common.hip.h). */
 int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
                       size_t n, float* out, void* stream);
+/* ... under a run's mask word (macx_dropout.mask_word: device pointer or NULL) */
+int macx_dropout_mask_w(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
+                        size_t n, const uint32_t* mask_word, float* out, void* stream);
 /* weight-gradient contraction out[k][j] = sum_m A[m][k] G[m][j]  (fixed-order split reduction).
  * `ws` >= nsplit*Kd*Jd floats where nsplit = macx_wgrad_splits(M, Kd, Jd). */
 int macx_wgrad_splits(int M, int Kd, int Jd);
@@ -471,6 +483,9 @@ int macx_op_softmax(const float* x, const int32_t* lengths, int rows_per_len, si
 int macx_op_softmax_bwd(const float* a, const float* da, size_t rows, int n, float* dx, void* stream);
 int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
                     float* out, void* stream);
+/* ... under a run's mask word (macx_dropout.mask_word: device pointer or NULL) */
+int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
+                      const uint32_t* mask_word, float* out, void* stream);
 
 /* tuning hook for A/B measurements (never needed for correct results):
  *   key 0  waves per workgroup of the NATIVE knowledge-base GEMM (4 | 8)

@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MACX_OK, MACX_EINVAL, MACX_EUNSUPPORTED, MACX_EREJECTED, MACX_ESMALL = 0, -1, -2, -3, -4
 ACT = {"NON": 0, "TANH": 1, "SIGMOID": 2, "ELU": 3, "RELU": 4}
@@ -30,7 +30,8 @@ class MacxShapes(C.Structure):
 
 
 class MacxDropout(C.Structure):
-    _fields_ = [("keep_memory", C.c_float), ("keep_read", C.c_float), ("keep_write", C.c_float), ("seed", C.c_uint32)]
+    _fields_ = [("keep_memory", C.c_float), ("keep_read", C.c_float), ("keep_write", C.c_float), ("seed", C.c_uint32),
+                ("mask_word", C.c_void_p)]
 
 
 PARAM_FIELDS = (
@@ -105,14 +106,14 @@ class MacxInputGrads(C.Structure):
 EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats", "macx_ws_floats",
            "macx_saved_segment", "macx_cell_begin", "macx_cell_step", "macx_cell_forward", "macx_cell_backward",
            "macx_cell_backward_phase",
-           "macx_linear", "macx_pack_weight", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_wgrad_splits",
+           "macx_linear", "macx_pack_weight", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_dropout_mask_w", "macx_wgrad_splits",
            "macx_wgrad", "macx_debug_set", "macx_output_saved_floats", "macx_output_ws_floats",
            "macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
            "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward",
            "macx_encoder_saved_floats", "macx_encoder_ws_floats", "macx_encoder_forward", "macx_encoder_backward",
            "macx_images_to_nhwc", "macx_gemm_mode", "macx_h2_floats", "macx_h2_from_f32", "macx_h2_to_f32", "macx_h2_gemm",
            "macx_h2_pack_weight", "macx_h2_gemm_planes", "macx_op_act", "macx_op_act_bwd", "macx_op_binary", "macx_op_reduce",
-           "macx_op_softmax", "macx_op_softmax_bwd", "macx_op_dropout", "macx_kb_attend_fwd", "macx_kb_attend_bwd",
+           "macx_op_softmax", "macx_op_softmax_bwd", "macx_op_dropout", "macx_op_dropout_w", "macx_kb_attend_fwd", "macx_kb_attend_bwd",
            "macx_kb_attend_bwd_ws_floats", "macx_answer_loss", "macx_workspace_bytes", "macx_embed_lookup", "macx_embed_lookup_bwd", "macx_control_attend_bwd",
            "macx_control_attend_bwd_ws_floats", "macx_read_fwd", "macx_read_bwd",
            "macx_write_fwd", "macx_write_bwd", "macx_read_chain_time")
@@ -166,6 +167,8 @@ def lib():
     L.macx_control_attend.argtypes = [P(MacxShapes)] + [C.c_void_p] * 8
     L.macx_dropout_mask.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_void_p,
                                     C.c_void_p]
+    L.macx_dropout_mask_w.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
     L.macx_debug_set.argtypes = [C.c_int, C.c_int]
     L.macx_read_chain_time.argtypes = [P(MacxOpts), P(MacxShapes), P(MacxDropout), P(MacxParams), P(MacxInputs), C.c_void_p, C.c_size_t,
                                        C.c_int, C.c_int, P(C.c_float), C.c_void_p]
@@ -238,6 +241,8 @@ def lib():
     L.macx_op_softmax_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     L.macx_op_dropout.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p,
                                   C.c_void_p]
+    L.macx_op_dropout_w.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
     for n in EXPORTS:
         if n.endswith("_floats"):
             getattr(L, n).restype = C.c_size_t

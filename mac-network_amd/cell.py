@@ -41,6 +41,17 @@ def _f32c(t, name):
     return t.contiguous()
 
 
+def _mask_word(t, like):
+    """macx_dropout.mask_word: one 32-bit word in device memory (an int32 / uint32 tensor with one element), or None."""
+    if t is None:
+        return None
+    if not torch.is_tensor(t) or t.numel() != 1 or t.dtype not in (torch.int32, torch.uint32) or not t.is_cuda:
+        raise TypeError("mask_word must be a 1-element int32 tensor on the HIP device (the kernels read it when they run)")
+    if t.device != like.device:
+        raise ValueError("mask_word lives on %s, the cell on %s" % (t.device, like.device))
+    return t
+
+
 class _Run:
     """One cell run: shapes, frozen options, buffers, and the ctypes structs that describe them."""
 
@@ -54,7 +65,8 @@ class _Run:
         self.shapes = _lib.MacxShapes(B=B, S=S, N=N, d=d, p=cell.netLength, b0=cell.b0, d_logical=int(getattr(cell, "d_logical", 0)))
         _lib.check(self.L.macx_check(C.byref(self.opts), C.byref(self.shapes)), "macx_check")
         self.drop = _lib.MacxDropout(keep_memory=cell.dropouts["memory"], keep_read=cell.dropouts["read"],
-                                     keep_write=cell.dropouts["write"], seed=cell.seed & 0xFFFFFFFF)
+                                     keep_write=cell.dropouts["write"], seed=cell.seed & 0xFFFFFFFF,
+                                     mask_word=cell.mask_word.data_ptr() if cell.mask_word is not None else None)
         dev = cell.knowledgeBase.device
         self.saved_floats = self.L.macx_saved_floats(C.byref(self.opts), C.byref(self.shapes), self.keep)
         self.saved = torch.empty(self.saved_floats, dtype=torch.float32, device=dev)
@@ -184,6 +196,9 @@ class MACCell:
     config   object with the reference's flag names (default: the reference defaults)
     params   MACCellParams (default: freshly initialised like tf.get_variable would)
     seed     dropout stream seed;  b0  global index of this shard's first question (data parallel)
+    mask_word  None, or a 1-element int32 tensor on the device: every dropout site XORs it into its key WHEN THE KERNELS RUN
+             (macx.h, macx_dropout.mask_word).  The seed is baked into a captured HIP graph, this word is not: write a new
+             value between replays and one capture draws fresh masks per step (graph.CapturedTrainStep).  None == word 0.
     gemm     kernel family of the knowledge-base GEMMs of THIS cell: "h2" | "split" | "native" (None: the process default)
     """
 
@@ -208,8 +223,9 @@ class MACCell:
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
-                 netLength=None, seed=None, b0=0, gemm=None, d_logical=0):
+                 netLength=None, seed=None, b0=0, gemm=None, d_logical=0, mask_word=None):
         from types import SimpleNamespace
+        self.mask_word = _mask_word(mask_word, knowledgeBase)
         self.d_logical = int(d_logical)        # > 0: this is the zero-padded image of a d_logical-wide cell (PaddedMACCell)
         self.config = config if config is not None else SimpleNamespace()
         self.opts = freeze(self.config, gemm)     # raises for rejected / unsupported option sets
@@ -392,7 +408,7 @@ class PaddedMACCell:
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
-                 netLength=None, seed=None, b0=0, gemm=None):
+                 netLength=None, seed=None, b0=0, gemm=None, mask_word=None):
         import copy
         self.config = config
         d = self.d = int(get(config, "memDim"))
@@ -406,7 +422,7 @@ class PaddedMACCell:
         cntx_p = words_p if questionCntxWords is questionWords else pad(questionCntxWords)
         self.inner = MACCell(pad(vecQuestions), words_p, cntx_p, questionLengths, pad(knowledgeBase), memoryDropout, readDropout,
                              writeDropout, batchSize, train, reuse, config=wide, params=_PaddedParams(self.params, d, dp),
-                             netLength=self.netLength, seed=seed, b0=b0, gemm=gemm, d_logical=d)
+                             netLength=self.netLength, seed=seed, b0=b0, gemm=gemm, d_logical=d, mask_word=mask_word)
         self.none = self.inner.none
         self.batchSize, self.train, self.seed, self.b0 = self.inner.batchSize, self.inner.train, self.inner.seed, self.inner.b0
 

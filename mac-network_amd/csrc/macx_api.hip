@@ -107,6 +107,7 @@ inline int wfmt_plain_f32ops() { return gemm_split_mode() ? 1 : 0; }
 
 inline DropSpec make_drop(float keep, uint32_t seed, uint32_t site, uint32_t step) {
   DropSpec s;
+  s.word = nullptr;
   s.key = site_key(seed, site, step);
   if (keep >= 1.0f) {
     s.thr24 = 1u << 24;
@@ -117,8 +118,15 @@ inline DropSpec make_drop(float keep, uint32_t seed, uint32_t site, uint32_t ste
   }
   return s;
 }
+// a site of the cell: the run's mask word (macx_dropout.mask_word, device memory, may be null) rides along
+inline DropSpec make_drop(float keep, const macx_dropout* dp, uint32_t site, uint32_t step) {
+  DropSpec s = make_drop(keep, dp->seed, site, step);
+  s.word = dp->mask_word;
+  return s;
+}
 inline DropSpec no_drop() {
   DropSpec s;
+  s.word = nullptr;
   s.key = 0;
   s.thr24 = 1u << 24;
   s.inv_keep = 1.0f;
@@ -434,11 +442,12 @@ ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dr
   c.first = (uint32_t)((size_t)s->b0 * N * c.dlog);
   c.thr1 = 1u << 24; c.inv1 = 1.0f; c.thr2 = 1u << 24; c.inv2 = 1.0f;
   if (rdrop) {
-    const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
-    const DropSpec da = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
+    const DropSpec dk = make_drop(dp->keep_read, dp, SITE_READ_KB, i);
+    const DropSpec da = make_drop(dp->keep_read, dp, SITE_READ_ATT, i);
     c.key1 = dk.key; c.thr1 = dk.thr24; c.inv1 = dk.inv_keep;
     c.bits1 = reinterpret_cast<uint8_t*>(saved + L.kb_bits + (size_t)ob * L.bits_stride);
     c.key2 = da.key; c.thr2 = da.thr24; c.inv2 = da.inv_keep;
+    c.word = dp->mask_word;
     c.bytes2 = reinterpret_cast<uint8_t*>(saved + L.att_bits + (size_t)ob * L.bits_stride);
   }
   if (rdrop || i == 0) {
@@ -859,9 +868,9 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   // ---- read unit (mac_cell.py:209-277)
   if (units & U_READ) {
   // memory dropout (mac_cell.py:214-217) then the read-dropout of ops.mul's y input (ops.py:679)
-  const DropSpec dm = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
-                                                    : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
-  const DropSpec dry = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i);
+  const DropSpec dm = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp, SITE_MEM_VAR, 0)
+                                                    : make_drop(dp->keep_memory, dp, SITE_MEM, i);
+  const DropSpec dry = make_drop(dp->keep_read, dp, SITE_READ_MEM, i);
   // (from step 1 on, the previous step's write unit left this step's dropped memory behind: md_fused below)
   if (!(md_fused && i > 0)) {
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md, dlog_of(s));
@@ -897,10 +906,11 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
       f.first = (uint32_t)((size_t)s->b0 * N * f.ldrop);
       f.thr24 = 1u << 24; f.inv_keep = 1.0f; f.thr24_2 = 1u << 24;
       if (rdrop) {
-        const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
-        const DropSpec da = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);
+        const DropSpec dk = make_drop(dp->keep_read, dp, SITE_READ_KB, i);
+        const DropSpec da = make_drop(dp->keep_read, dp, SITE_READ_ATT, i);
         f.key = dk.key; f.thr24 = dk.thr24; f.inv_keep = dk.inv_keep; f.bits = kb_bits;
         f.key2 = da.key; f.thr24_2 = da.thr24; f.bytes2 = att_bytes;
+        f.word = dp->mask_word;
       }
       CK(h2_from_f32(f, st));
     }
@@ -931,10 +941,10 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   } else {
   if (rdrop) {
     const uint32_t first = (uint32_t)((size_t)s->b0 * N * d);
-    const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, i);
-    const DropSpec da = make_drop(dp->keep_read, dp->seed, SITE_READ_ATT, i);     // same keep probability, own stream
+    const DropSpec dk = make_drop(dp->keep_read, dp, SITE_READ_KB, i);
+    const DropSpec da = make_drop(dp->keep_read, dp, SITE_READ_ATT, i);     // same keep probability, own stream
     hipLaunchKernelGGL(kb_dropout_kernel, dim3(2048), dim3(256), 0, st, in->knowledgeBase, (size_t)B * N * d / 4, dk.key, dk.thr24,
-                       dk.inv_keep, first, KBd, kb_bits, da.key, att_bits);
+                       dk.inv_keep, first, KBd, kb_bits, da.key, att_bits, dp->mask_word);
     CK(hipGetLastError());
   }
   GemmP g;
@@ -976,7 +986,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   if (!(units & U_WRITE)) return MACX_OK;
   // write dropout (mac_cell.py:461-463); self.infos keeps the dropped value (mac_cell.py:474)
   if (wdrop) {
-    const DropSpec dw = make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i);
+    const DropSpec dw = make_drop(dp->keep_write, dp, SITE_WRITE_INFO, i);
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, (const float*)info_raw, B, d, (uint32_t)s->b0, dw, no_drop(), info, dlog_of(s));
     CK(hipGetLastError());
   }
@@ -1007,9 +1017,9 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     if (md_fused && i + 1 < s->p) {
       // the new memory is the next step's read-unit input: its two dropouts (mac_cell.py:214-217, ops.py:679) ride this epilogue
       l.use_drop = 2; l.drop_ld = dlog_of(s);
-      l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
-                                           : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i + 1);
-      l.d2 = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i + 1);
+      l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp, SITE_MEM_VAR, 0)
+                                           : make_drop(dp->keep_memory, dp, SITE_MEM, i + 1);
+      l.d2 = make_drop(dp->keep_read, dp, SITE_READ_MEM, i + 1);
       l.drop_row0 = (uint32_t)s->b0;
       l.out_drop = saved + L.md + (size_t)(i + 1) * Bd; l.ld_od = d;
     }
@@ -1194,7 +1204,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     ld_dinfo = win;
     if (dp->keep_write < 1.0f) {
       hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)dwin, win, d, B, d, (uint32_t)s->b0,
-                         make_drop(dp->keep_write, dp->seed, SITE_WRITE_INFO, i), ws + W.dinfo + (size_t)i * Bd, dlog_of(s));
+                         make_drop(dp->keep_write, dp, SITE_WRITE_INFO, i), ws + W.dinfo + (size_t)i * Bd, dlog_of(s));
       CK(hipGetLastError());
       dinfo = ws + W.dinfo + (size_t)i * Bd;
       ld_dinfo = d;
@@ -1425,9 +1435,9 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       const bool acc_prev = (units & U_WRITE) && (o->write_self_att || o->write_gate);
       LinP l = lin_basic(DYi, d, d, B, ws + W.wyT, nullptr, d, MACX_ACT_NON, acc_prev ? ws + W.tmpBd[0] : dm_prev, d);
       l.use_drop = 1; l.drop_ld = dlog_of(s);
-      l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp->seed, SITE_MEM_VAR, 0)
-                                           : make_drop(dp->keep_memory, dp->seed, SITE_MEM, i);
-      l.d2 = make_drop(dp->keep_read, dp->seed, SITE_READ_MEM, i);
+      l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp, SITE_MEM_VAR, 0)
+                                           : make_drop(dp->keep_memory, dp, SITE_MEM, i);
+      l.d2 = make_drop(dp->keep_read, dp, SITE_READ_MEM, i);
       l.drop_row0 = (uint32_t)s->b0;
       if (units & U_WRITE) { l.addend = dwin; l.ld_add = win; }
       if (h2_mode() && W.dy_in_linear) {
@@ -1889,9 +1899,10 @@ int macx_kb_project(const macx_shapes* s, const macx_dropout* dp, int step, cons
     if (!bits_ws) return MACX_EINVAL;
     // scratch: [B*N*d] dropped KB, then [B*N*d/32] keep bits
     const size_t n = (size_t)s->B * s->N * d;
-    const DropSpec dk = make_drop(dp->keep_read, dp->seed, SITE_READ_KB, step);
+    const DropSpec dk = make_drop(dp->keep_read, dp, SITE_READ_KB, step);
     hipLaunchKernelGGL(kb_dropout_kernel, dim3(2048), dim3(256), 0, st, kb, n / 4, dk.key, dk.thr24, dk.inv_keep,
-                       (uint32_t)((size_t)s->b0 * s->N * d), bits_ws, reinterpret_cast<uint32_t*>(bits_ws + n), 0u, (uint32_t*)nullptr);
+                       (uint32_t)((size_t)s->b0 * s->N * d), bits_ws, reinterpret_cast<uint32_t*>(bits_ws + n), 0u, (uint32_t*)nullptr,
+                       dk.word);
     CK(hipGetLastError());
     g.A = bits_ws;
   }
@@ -1959,12 +1970,16 @@ int macx_embed_lookup_bwd(const int32_t* ids, const float* dx, int rows, int E, 
   return MACX_OK;
 }
 
-int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first, size_t n, float* out, void* stream) {
+int macx_dropout_mask_w(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first, size_t n, const uint32_t* mask_word,
+                        float* out, void* stream) {
   if (!out) return MACX_EINVAL;
   const DropSpec ds = make_drop(keep, seed, site, step);
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, ds.key, ds.thr24, first, n, out);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, ds.key, ds.thr24, first, n, out, mask_word);
   CK(hipGetLastError());
   return MACX_OK;
+}
+int macx_dropout_mask(uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first, size_t n, float* out, void* stream) {
+  return macx_dropout_mask_w(seed, site, step, keep, first, n, nullptr, out, stream);
 }
 
 // ---- answer loss + prediction (model.py:593-612): SURVEY 8f row 2 -------------------------------------------------
@@ -2067,14 +2082,19 @@ int macx_op_softmax_bwd(const float* a, const float* da, size_t rows, int n, flo
   CK(hipGetLastError());
   return MACX_OK;
 }
-int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first, float* out,
-                    void* stream) {
+int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
+                      const uint32_t* mask_word, float* out, void* stream) {
   if (!x || !out || !(keep > 0.f) || keep > 1.f) return MACX_EINVAL;
   if (n == 0) return MACX_OK;
   const DropSpec ds = make_drop(keep, seed, site, step);
-  hipLaunchKernelGGL(op_dropout_kernel, dim3(op_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, first, ds.key, ds.thr24, ds.inv_keep, out);
+  hipLaunchKernelGGL(op_dropout_kernel, dim3(op_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, first, ds.key, ds.thr24, ds.inv_keep, out,
+                     mask_word);
   CK(hipGetLastError());
   return MACX_OK;
+}
+int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first, float* out,
+                    void* stream) {
+  return macx_op_dropout_w(x, n, seed, site, step, keep, first, nullptr, out, stream);
 }
 
 // =================================================================================================

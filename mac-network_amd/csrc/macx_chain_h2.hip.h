@@ -625,6 +625,7 @@ struct ChainFwdP {
   uint32_t key1, thr1; float inv1;      // ops.py:678 site (thr = 1 << 24: keep everything)
   uint8_t* bits1;           // its keep bits, row-major, one byte per 8 columns [M][d/8] (= uint32 words [M][d/32]); may be null
   uint32_t key2, thr2; float inv2;      // ops.py:312 site on act(I2 * c)
+  const uint32_t* word;                 // macx_dropout.mask_word (device, may be null): XORed into both keys when the kernel runs
   uint8_t* bytes2;          // its keep bits in slot order [d/8][M + pad]; may be null
   H2View KBd;               // base null: not written
   ChainW Wx, W1a, W1b, W2;
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
     float v[IT][8];
     float m = 0.f;
     const bool drop1 = p.thr1 < (1u << 24), drop2 = p.thr2 < (1u << 24);
+    const uint32_t key1 = run_key(p.key1, p.word), key2 = run_key(p.key2, p.word);
     const size_t Rp2 = (size_t)M + H2_PAD_ROWS;
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
       if (drop1) {
         uint32_t byte = 0;             // (e0 is even: the width is a multiple of 128)
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) byte |= keep_pair(e0 + q, p.key1, p.thr1) << q;
+        for (int q = 0; q < 8; q += 2) byte |= keep_pair(e0 + q, key1, p.thr1) << q;
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[j][q] = ((byte >> q) & 1u) ? v[j][q] * p.inv1 : 0.f;
         if (p.bits1 && x.cvalid) p.bits1[x.cgrow * KG + kg] = (uint8_t)byte;
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
         // hashed once per element, here: the logits epilogue of stage 3 reads the bits back from LDS
         uint32_t byte = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) byte |= keep_pair(e0 + q, p.key2, p.thr2) << q;
+        for (int q = 0; q < 8; q += 2) byte |= keep_pair(e0 + q, key2, p.thr2) << q;
         x.sBits[x.crow * C::G::BITS_LD + kg] = (uint8_t)byte;
         if (p.bytes2 && x.cvalid) p.bytes2[(size_t)kg * Rp2 + x.cgrow] = (uint8_t)byte;
       }

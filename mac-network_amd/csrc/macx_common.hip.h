@@ -90,8 +90,16 @@ struct DropSpec {
   uint32_t key;      // site_key(seed, site, step)
   uint32_t thr24;    // floor(keep * 2^24); 1<<24 means keep everything
   float inv_keep;    // 1/keep
+  const uint32_t* word;   // macx_dropout.mask_word: one device word XORed into the key when the kernel RUNS (null = 0)
 };
 
+// The key a kernel hashes with: the host's site key, XOR the run's mask word read from device memory.  A captured graph bakes
+// `key` (a kernel argument) but reads the word on every replay, so one capture draws fresh masks per replay (macx.h, macx_dropout).
+__device__ __forceinline__ uint32_t run_key(uint32_t key, const uint32_t* word) { return word ? key ^ *word : key; }
+__device__ __forceinline__ uint32_t run_key(const DropSpec& d) { return run_key(d.key, d.word); }
+
+// (callers that apply a spec to many elements resolve the key once: drop_resolve)
+__device__ __forceinline__ DropSpec drop_resolve(DropSpec d) { d.key = run_key(d); d.word = nullptr; return d; }
 __device__ __forceinline__ float drop_apply(float v, uint32_t idx, const DropSpec& d) {
   return keep_bit(idx, d.key, d.thr24) ? v * d.inv_keep : 0.0f;
 }

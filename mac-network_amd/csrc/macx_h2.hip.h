@@ -223,6 +223,7 @@ struct H2FromP {
   uint32_t key, thr24; float inv_keep;   // site 1 (thr24 = 1 << 24: keep everything)
   uint32_t* bits;                        // site 1 keep bits, row-major [B*N][C/32]; may be null
   uint32_t key2, thr24_2;                // site 2
+  const uint32_t* word;                  // macx_dropout.mask_word (device, may be null): XORed into both keys at run time
   uint8_t* bytes2;                       // site 2 keep bytes, slot order [C/8][Rp]; may be null
 };
 
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(H2C_THREADS) void h2_from_f32_kernel(H2FromP p) {
   const int tid = threadIdx.x, c4 = tid & 31, rg = tid >> 5;
   const bool drop = p.thr24 < (1u << 24);
   const int ldrop = p.ldrop > 0 ? p.ldrop : p.C;
+  const uint32_t key = run_key(p.key, p.word), key2 = run_key(p.key2, p.word);
   for (int lrow = rg; lrow < rows; lrow += H2C_THREADS / 32) {
     const size_t e0 = (grow0 + lrow) * p.C + cb * 128 + c4 * 4;
     const uint32_t d0 = (uint32_t)((grow0 + lrow) * (size_t)ldrop + cb * 128 + c4 * 4);
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(H2C_THREADS) void h2_from_f32_kernel(H2FromP p) {
       uint32_t nib = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool keep = keep_bit(p.first + d0 + e, p.key, p.thr24);
+        const bool keep = keep_bit(p.first + d0 + e, key, p.thr24);
         nib |= (keep ? 1u : 0u) << e;
         v[e] = keep ? v[e] * p.inv_keep : 0.f;
       }
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(H2C_THREADS) void h2_from_f32_kernel(H2FromP p) {
         const uint32_t e0 = p.first + (uint32_t)((grow0 + lrow) * (size_t)ldrop + cb * 128 + kgl * 8);
         uint32_t byte = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) byte |= (keep_bit(e0 + e, p.key2, p.thr24_2) ? 1u : 0u) << e;
+        for (int e = 0; e < 8; ++e) byte |= (keep_bit(e0 + e, key2, p.thr24_2) ? 1u : 0u) << e;
         p.bytes2[(size_t)(cb * 16 + kgl) * Rp + grow0 + lrow] = (uint8_t)byte;
       }
     }

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void op_softmax_bwd_kernel(const float* a, con
 
 // ---- dropout from the stateless stream -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void op_dropout_kernel(const float* x, size_t n, uint32_t first, uint32_t key, uint32_t thr24, float inv_keep,
-                                                         float* out) {
+                                                         float* out, const uint32_t* word = nullptr) {
+  key = run_key(key, word);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
     out[i] = keep_bit((uint32_t)(first + i), key, thr24) ? x[i] * inv_keep : 0.f;
 }

@@ -92,7 +92,9 @@ __global__ void pack_weights_kernel(PackList L) {
 // bits (1 per element) the backward pass needs.  16 B per lane; 8 lanes assemble one 32-bit word.
 __global__ __launch_bounds__(256) void kb_dropout_kernel(const float* __restrict__ kb, size_t n4, uint32_t key, uint32_t thr24,
                                                         float inv_keep, uint32_t first, float* out, uint32_t* bits, uint32_t key2,
-                                                        uint32_t* bits2) {
+                                                        uint32_t* bits2, const uint32_t* word = nullptr) {
+  key = run_key(key, word);
+  key2 = run_key(key2, word);
   // bits2 (optional): keep bits of a second dropout site over the same index range (the read unit's attention dropout,
   // ops.py:312 via :142) -- the pass is HBM-bound, the second hash is free and saves a launch per step
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(256) void kb_dropout_kernel(const float* __restrict
 }
 
 // keep bits of a dropout site: word w holds elements first + 32w .. first + 32w + 31 (bit i = element i)
-__global__ void mask_bits_kernel(uint32_t key, uint32_t thr24, uint32_t first, size_t nwords, uint32_t* out) {
+__global__ void mask_bits_kernel(uint32_t key, uint32_t thr24, uint32_t first, size_t nwords, uint32_t* out, const uint32_t* word = nullptr) {
+  key = run_key(key, word);
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (size_t)gridDim.x * blockDim.x) {
     const uint32_t base = first + (uint32_t)(w << 5);
     uint32_t bits = 0;
@@ -301,8 +304,8 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
     if (p.use_drop) {
       const uint32_t idx = (p.drop_row0 + row) * (uint32_t)(p.drop_ld > 0 ? p.drop_ld : p.n_out) + col + e;
       float f = 1.f;
-      if (!keep_bit(idx, p.d1.key, p.d1.thr24)) f = 0.f; else f *= p.d1.inv_keep;
-      if (!keep_bit(idx, p.d2.key, p.d2.thr24)) f = 0.f; else f *= p.d2.inv_keep;
+      if (!keep_bit(idx, run_key(p.d1), p.d1.thr24)) f = 0.f; else f *= p.d1.inv_keep;
+      if (!keep_bit(idx, run_key(p.d2), p.d2.thr24)) f = 0.f; else f *= p.d2.inv_keep;
       if (p.use_drop == 2) vald[e] = v * f;
       else v *= f;
     }
@@ -334,6 +337,8 @@ inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
 // out = x * f1 * f2 with two dropout streams indexed (row0+r)*dl + j   (mac_cell.py:214-217 then ops.py:679); dl: the logical
 // width of a zero-padded cell (macx_shapes.d_logical), 0 = d
 __global__ void drop2_kernel(const float* __restrict__ x, int rows, int d, uint32_t row0, DropSpec d1, DropSpec d2, float* out, int dl = 0) {
+  d1 = drop_resolve(d1);
+  d2 = drop_resolve(d2);
   const int n = rows * d;
   if (dl <= 0) dl = d;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -357,7 +362,8 @@ __global__ void init_state_kernel(int mode, const float* __restrict__ prm, const
   }
 }
 
-__global__ void dropout_mask_kernel(uint32_t key, uint32_t thr24, uint32_t first, size_t n, float* out) {
+__global__ void dropout_mask_kernel(uint32_t key, uint32_t thr24, uint32_t first, size_t n, float* out, const uint32_t* word = nullptr) {
+  key = run_key(key, word);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     out[i] = keep_bit(first + (uint32_t)i, key, thr24) ? 1.f : 0.f;
 }
@@ -426,6 +432,7 @@ __global__ __launch_bounds__(1024) void rowsum_list_kernel(RowsumList L) {
 // dst[r][j] = src[r*ld_src + col0 + j] * dropfactor((row0+r)*d + j)
 __global__ void copy_cols_drop_kernel(const float* __restrict__ src, int ld_src, int col0, int rows, int d, uint32_t row0,
                                       DropSpec ds, float* dst, int dl = 0) {
+  ds = drop_resolve(ds);
   const int n = rows * d;
   if (dl <= 0) dl = d;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

@@ -107,9 +107,11 @@ def k_softmax_bwd(a, g):
     return dx
 
 
-def k_dropout(x, seed, site, step, keep, first):
+def k_dropout(x, seed, site, step, keep, first, mask_word=None):
+    """mask_word: macx_dropout.mask_word (1-element int32 device tensor XORed into the site key when the kernel runs) or None"""
     out = torch.empty_like(x)
-    _lib.check(_L().macx_op_dropout(_p(x), x.numel(), seed, site, step, keep, first, _p(out), _st(x)), "macx_op_dropout")
+    _lib.check(_L().macx_op_dropout_w(_p(x), x.numel(), seed, site, step, keep, first, _p(mask_word) if mask_word is not None else None,
+                                      _p(out), _st(x)), "macx_op_dropout")
     return out
 
 
@@ -497,7 +499,9 @@ class GenericMACCell:
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
-                 netLength=None, seed=None, b0=0):
+                 netLength=None, seed=None, b0=0, mask_word=None):
+        from .cell import _mask_word
+        self.mask_word = _mask_word(mask_word, knowledgeBase)
         self.config = config if config is not None else SimpleNamespace()
         reject_like_reference(self.config)
         bad = [k for k in ("memDim", "ctrlDim", "attDim") if self.g(k) % 128]
@@ -547,7 +551,8 @@ class GenericMACCell:
     def _segment(self, seg, feeds):
         from . import plan as _plan
         if self._exec is None:
-            self._exec = _plan._Exec(self.seed, self.b0, self.dropouts, self.train, self.batchSize, self.knowledgeBase.device)
+            self._exec = _plan._Exec(self.seed, self.b0, self.dropouts, self.train, self.batchSize, self.knowledgeBase.device,
+                                     mask_word=self.mask_word)
         return _plan.run_segment(seg, self._exec, feeds, self.params)
 
     # histories as the reference exposes them: [B, steps + 1, d] (mac_cell.py:472-474, 549-551)

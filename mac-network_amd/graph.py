@@ -34,6 +34,18 @@ from .cell import MACCell
 from .options import get
 
 
+def mix32(x):
+    """the 32-bit finaliser the dropout stream hashes with (macx_common.hip.h, hash_mix): iteration number -> mask word"""
+    h = (x + 0x7F4A7C15) & 0xFFFFFFFF
+    h = (h * 0x9E3779B1) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x85EBCA77) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE3D) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
 class CapturedForward:
     def __init__(self, config, params, B, S, N, device=None, netLength=None, warmup=2, verify=True):
         dev = torch.device(device) if device is not None else params.tensors()[0].device
@@ -122,10 +134,16 @@ class CapturedTrainStep:
     The library issues no memset / memcpy node (module docstring; the minimum-exponent arrays behind the deferred contractions
     were the last memset-then-atomicMin pair), which is what makes the backward pass capturable.
 
-    LIMIT -- the dropout masks are a function of (seed, site, step, element) and the seed travels BY VALUE in the kernel
-    parameters: every replay draws the masks of the captured seed.  That is exact for measurement and for a fixed-mask
-    evaluation of gradients; a training loop that wants fresh masks per step re-captures (or runs eagerly).  Lifting it needs
-    the seed in device memory, read by the dozen kernels that hash -- not done.
+    Fresh masks per replay -- the dropout masks are a function of (seed, site, step, element) and the seed travels BY VALUE in
+    the kernel arguments, so a capture bakes it.  The run therefore also carries one 32-bit word in DEVICE memory
+    (`macx_dropout.mask_word`, `step.mask_word`) that every dropout site XORs into its key when the kernel RUNS:
+
+        for it in range(steps):
+            step.load(...)
+            step.replay(iteration=it)        # word = mix32(it): the masks of (seed, word); same word => same masks
+
+    `replay()` without an argument keeps the word it has (0 after construction: the masks of the plain seed), which is what
+    measurement wants.  The eager step behind `_eager()` reads the same word, so verification compares like with like.
 
     `verify=True` replays three times against the eager step on random inputs and falls back to eager launches when a replay
     differs in any gradient (`captured` False, a warning says so)."""
@@ -142,6 +160,7 @@ class CapturedTrainStep:
         self.lengths = torch.full((B,), S, dtype=torch.int32, device=dev)
         self.knowledgeBase = torch.zeros(B, N, d, device=dev, requires_grad=True)
         self.d_memory = torch.zeros(B, d, device=dev)
+        self.mask_word = torch.zeros(1, dtype=torch.int32, device=dev)        # macx_dropout.mask_word of every run of this step
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -172,14 +191,21 @@ class CapturedTrainStep:
                        questionLengths=self.lengths, knowledgeBase=self.knowledgeBase,
                        memoryDropout=float(get(self.config, "memoryDropout")), readDropout=float(get(self.config, "readDropout")),
                        writeDropout=float(get(self.config, "writeDropout")), batchSize=self.vecQuestions.shape[0], train=True,
-                       config=self.config, params=self.params, netLength=self.netLength, seed=self.seed, b0=self.b0)
+                       config=self.config, params=self.params, netLength=self.netLength, seed=self.seed, b0=self.b0,
+                       mask_word=self.mask_word)
         state = cell.run()
         torch.autograd.backward([state.memory], [self.d_memory])
         return state.memory.detach()
 
+    def set_mask_word(self, word):
+        """the raw 32-bit word the next replays XOR into every dropout key (0: the masks of the plain seed)"""
+        word &= 0xFFFFFFFF
+        self.mask_word.fill_(word - (1 << 32) if word >= (1 << 31) else word)
+
     def _replays_match_eager(self, replays=3):
         g = torch.Generator().manual_seed(20240520)
         dev = self.knowledgeBase.device
+        self.set_mask_word(0x5bd1e995)          # a non-trivial word: the check covers the device-read path as well
         with torch.no_grad():
             for t in (self.vecQuestions, self.words, self.knowledgeBase, self.d_memory):
                 t.copy_(torch.randn(t.shape, generator=g).to(dev))
@@ -198,6 +224,7 @@ class CapturedTrainStep:
                 if not torch.equal(t.grad, w):
                     self.verify_report.append((r, i + 1))
         torch.cuda.synchronize(dev)
+        self.set_mask_word(0)
         ok = not self.verify_report
         return ok
 
@@ -209,7 +236,10 @@ class CapturedTrainStep:
             self.knowledgeBase.copy_(knowledgeBase)
             self.d_memory.copy_(d_memory)
 
-    def replay(self):
+    def replay(self, iteration=None):
+        """iteration: None keeps the current mask word; an int draws the masks of word mix32(iteration)"""
+        if iteration is not None:
+            self.set_mask_word(mix32(int(iteration)))
         if self.captured:
             self.graph.replay()
         else:

@@ -447,8 +447,9 @@ def _ones_like(t):
 class _Exec:
     """the per-run context of a segment execution: dropout stream, mode, batch"""
 
-    def __init__(self, seed, b0, keeps, train, batch, device):
+    def __init__(self, seed, b0, keeps, train, batch, device, mask_word=None):
         self.seed, self.b0, self.keeps, self.train, self.batch, self.device = seed, b0, keeps, train, batch, device
+        self.mask_word = mask_word                 # macx_dropout.mask_word of the run (device tensor) or None
 
     # ---- forward rules: (node, inputs) -> output (+ what backward wants, stashed per node)
     def fwd(self, nd, x, stash):
@@ -492,7 +493,7 @@ class _Exec:
             if self.keeps[a["keep"]] == 1.0:
                 return x[0]
             p = x[0].contiguous()
-            return G.k_dropout(p, self.seed, a["site"], a["step"], self.keeps[a["keep"]], self.b0 * (p.numel() // p.shape[0]))
+            return G.k_dropout(p, self.seed, a["site"], a["step"], self.keeps[a["keep"]], self.b0 * (p.numel() // p.shape[0]), self.mask_word)
         if op == "cat":
             return torch.cat(list(x), dim=-1)
         if op == "rows":                      # a [c] variable as the B rows of a [B, c] state
@@ -581,7 +582,7 @@ class _Exec:
         if op == "drop":
             if self.keeps[a["keep"]] == 1.0:
                 return [g]
-            return [G.k_dropout(g, self.seed, a["site"], a["step"], self.keeps[a["keep"]], self.b0 * (g.numel() // g.shape[0]))]
+            return [G.k_dropout(g, self.seed, a["site"], a["step"], self.keeps[a["keep"]], self.b0 * (g.numel() // g.shape[0]), self.mask_word)]
         if op == "cat":
             out, at = [], 0
             for t, w in zip(x, want):

@@ -44,17 +44,19 @@ def threshold24(keep):
     return int(np.floor(np.float64(np.float32(keep)) * 16777216.0))
 
 
-def keep_mask(seed, site, step, keep, first, n):
-    """0/1 float32 mask for flat element indices first .. first+n-1 of a dropout site."""
+def keep_mask(seed, site, step, keep, first, n, word=0):
+    """0/1 float32 mask for flat element indices first .. first+n-1 of a dropout site.  word: the run's mask word
+    (include/macx.h, macx_dropout.mask_word -- XORed into the site key; 0 = the plain seed's masks)."""
     idx = (np.arange(n, dtype=np.uint64) + np.uint64(first)) & _M32
-    h = hash_mix((idx >> np.uint64(1)) ^ np.uint64(site_key(seed, site, step)))      # one hash per pair of elements
+    key = np.uint64((site_key(seed, site, step) ^ (int(word) & 0xFFFFFFFF)) & 0xFFFFFFFF)
+    h = hash_mix((idx >> np.uint64(1)) ^ key)      # one hash per pair of elements
     bits = np.where((idx & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
     return ((bits << np.uint64(8)) < np.uint64(threshold24(keep))).astype(np.float32)
 
 
-def mask_for(seed, site, step, keep, shape, b0=0):
+def mask_for(seed, site, step, keep, shape, b0=0, word=0):
     """Mask of a [B, ...] tensor whose flat index starts at global question b0."""
     shape = tuple(int(x) for x in shape)
     per_q = int(np.prod(shape[1:])) if len(shape) > 1 else 1
     n = int(np.prod(shape))
-    return keep_mask(seed, site, step, keep, b0 * per_q, n).reshape(shape)
+    return keep_mask(seed, site, step, keep, b0 * per_q, n, word).reshape(shape)

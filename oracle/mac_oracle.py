@@ -685,14 +685,15 @@ class MACCellOracle:
         return (initialControl, initialMemory)
 
 
-def hash_mask_fn(seed, keeps, b0=0):
-    """mask_fn backed by the stateless stream (oracle/dropout_hash.py), keyed like the HIP path."""
+def hash_mask_fn(seed, keeps, b0=0, word=0):
+    """mask_fn backed by the stateless stream (oracle/dropout_hash.py), keyed like the HIP path (word: the run's mask word,
+    include/macx.h macx_dropout.mask_word)."""
     site_keep = {dh.SITE_MEM_VAR: keeps[0], dh.SITE_MEM: keeps[0], dh.SITE_READ_KB: keeps[1],
                  dh.SITE_READ_MEM: keeps[1], dh.SITE_READ_ATT: keeps[1], dh.SITE_WRITE_INFO: keeps[2]}
 
     def fn(site, step, shape):
         st = 0 if site == dh.SITE_MEM_VAR else step
-        return dh.mask_for(seed, site, st, site_keep[site], shape, b0=b0)
+        return dh.mask_for(seed, site, st, site_keep[site], shape, b0=b0, word=word)
 
     return fn
 

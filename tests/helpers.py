@@ -14,13 +14,13 @@ def make_case(config_name, B, S, N, d, p, seed=1234, **over):
 
 
 def oracle_run(cfg, ref_params, vq, words, lengths, kb, train=False, seed=0, b0=0, dtype=torch.float64, need_grad=False,
-               d_memory=None, d_control=None):
+               d_memory=None, d_control=None, word=0):
     """Oracle forward (+ backward).  ref_params: {reference variable name: tensor}."""
     params = {k: v.detach().cpu().to(dtype).clone().requires_grad_(need_grad) for k, v in ref_params.items()}
     vs = mo.VarStore(params=params, dtype=dtype)
     vq_, words_, kb_ = [t.detach().cpu().to(dtype).clone().requires_grad_(need_grad) for t in (vq, words, kb)]
     keeps = (cfg.memoryDropout, cfg.readDropout, cfg.writeDropout) if train else (1.0, 1.0, 1.0)
-    mask_fn = mo.hash_mask_fn(seed, keeps, b0=b0) if train else None
+    mask_fn = mo.hash_mask_fn(seed, keeps, b0=b0, word=word) if train else None
     c, m, cell = mo.mac_network(cfg, vs, vq_, words_, words_, lengths.cpu(), kb_, train=train, mask_fn=mask_fn, keeps=keeps)
     out = dict(control=c, memory=m, cell=cell, params=params, inputs=(vq_, words_, kb_))
     if need_grad:

@@ -54,8 +54,9 @@ def _torch_kernels(G):
     def softmax_bwd(a, g):
         return a * (g - (a * g).sum(-1, keepdim=True))
 
-    def dropout(x, seed, site, step, keep, first):
-        m = torch.as_tensor(dh.keep_mask(seed, site, step, keep, first, x.numel())).reshape(x.shape).to(x.dtype)
+    def dropout(x, seed, site, step, keep, first, mask_word=None):
+        word = int(mask_word.item()) & 0xFFFFFFFF if mask_word is not None else 0
+        m = torch.as_tensor(dh.keep_mask(seed, site, step, keep, first, x.numel(), word=word)).reshape(x.shape).to(x.dtype)
         return x * np.float32(1.0 / keep) * m
 
     def matmul(x, W, b, big):

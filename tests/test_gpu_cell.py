@@ -116,6 +116,55 @@ def test_backward_matches_oracle_autograd(macx, dev, name, B, S, N, d, p, train)
     assert not bad, bad
 
 
+@pytest.mark.parametrize("name,B,S,N,d,p,gemm", [
+    ("args", 3, 9, 49, 128, 3, None),          # the H2 family below the chain kernels' width
+    ("args", 3, 9, 196, 512, 2, None),         # the chain kernels
+    ("args4", 3, 9, 49, 128, 3, "split"),      # kb_dropout_kernel + the write unit's sites
+    ("args1", 3, 9, 49, 128, 3, "native"),
+])
+def test_mask_word_matches_oracle(macx, dev, name, B, S, N, d, p, gemm):
+    """macx_dropout.mask_word: one device word XORed into every site key when the kernels run.  Forward, every gradient
+    against the oracle on the masks of (seed, word); word 0 is bit for bit the run without a word."""
+    cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p, writeDropout=0.9)
+    word = 0xC0FFEE11
+    wt = torch.tensor([word - (1 << 32)], dtype=torch.int32, device=dev)
+
+    def run(mask_word):
+        params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(5)).to(dev)
+        vqd, wd, kbd = [t.to(dev).requires_grad_(True) for t in (vq, words, kb)]
+        cell = macx.MACCell(vqd, wd, wd, lengths.to(dev), kbd, cfg.memoryDropout, cfg.readDropout, cfg.writeDropout, B, True,
+                            config=cfg, params=params, seed=5, gemm=gemm, mask_word=mask_word)
+        state = cell.run()
+        (state.memory * dmem.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        return state, params, (vqd, wd, kbd)
+
+    dmem = torch.randn(B, d, generator=torch.Generator().manual_seed(9)) / B
+    state, params, (vqd, wd, kbd) = run(wt)
+    ref = oracle_run(cfg, params.to_reference_dict(), vq, words, lengths, kb, train=True, seed=5, need_grad=True, d_memory=dmem, word=word)
+    assert rel_err(state.memory, ref["memory"]) < FWD_TOL
+    rvq, rwords, rkb = ref["inputs"]
+    assert rel_err(kbd.grad, rkb.grad) < GRAD_TOL and rel_err(wd.grad, rwords.grad) < GRAD_TOL and rel_err(vqd.grad, rvq.grad) < GRAD_TOL
+    names = macx.params.reference_names(cfg, p)
+    bad = {}
+    for f in params.fields:
+        for refname, idx in names[f]:
+            rg = ref["params"][refname].grad
+            gt = getattr(params, f).grad
+            got = gt if idx is None else gt[idx]
+            e = rel_err(got.reshape(rg.shape), rg, floor=5e-2 if refname.endswith("linearLayerlogits/biases/bias") else 1e-6)
+            if not e < GRAD_TOL:
+                bad[refname] = e
+    assert not bad, bad
+    # a different stream than the plain seed's ...
+    plain, pparams, (_, _, pkb) = run(None)
+    assert not torch.equal(plain.memory, state.memory)
+    # ... and word 0 IS the plain seed's stream
+    zero, zparams, (_, _, zkb) = run(torch.zeros(1, dtype=torch.int32, device=dev))
+    assert torch.equal(zero.memory, plain.memory) and torch.equal(zkb.grad, pkb.grad)
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(zparams.tensors(), pparams.tensors()))
+
+
 def test_stepwise_final_state_carries_gradient(macx, dev):
     """The model.py:453-458 loop, unchanged, trains: the last step's state has the autograd edge."""
     cfg, vq, words, lengths, kb = make_case("args", 2, 6, 49, 128, 2)

@@ -130,6 +130,31 @@ def test_generic_path_matches_oracle(macx, dev, variant, train):
         assert rel_err(got.grad, want.grad) < GRAD_TOL * slack, name
 
 
+def test_generic_path_under_a_mask_word(macx, dev):
+    """macx_dropout.mask_word on the one-kernel-per-op path (macx_op_dropout_w): the masks of (seed, word), forward and backward"""
+    B, S, N, d, p = 3, 7, 20, 128, 2
+    cfg = make_cfg("no_var_dropout", d, p)          # plain memory dropout: a site of its own per step
+    vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, d, seed=11)
+    params = oracle_params(cfg, vq, words, lengths, kb)
+    dM = torch.randn(B, d, generator=torch.Generator().manual_seed(3))
+    word = 0x1234ABCD
+    ref = oracle_run(cfg, params, vq, words, lengths, kb, train=True, seed=91, b0=1, need_grad=True, d_memory=dM, word=word)
+    gp = macx.GenericParams(device=dev).load_reference_dict(params)
+    vqd, wd, kbd = [t.to(dev).requires_grad_(True) for t in (vq, words, kb)]
+    cell = macx.GenericMACCell(vqd, wd, wd, lengths.to(dev), kbd, cfg.memoryDropout, cfg.readDropout, cfg.writeDropout, B, True,
+                               config=cfg, params=gp, seed=91, b0=1, mask_word=torch.tensor([word], dtype=torch.int32, device=dev))
+    state = cell.zero_state(B)
+    for i in range(p):
+        cell.iteration = i
+        _, state = cell(cell.none, state)
+    (state.memory * dM.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel_err(state.memory, ref["memory"]) < FWD_TOL
+    assert rel_err(kbd.grad, ref["inputs"][2].grad) < GRAD_TOL
+    plain = oracle_run(cfg, params, vq, words, lengths, kb, train=True, seed=91, b0=1)
+    assert rel_err(state.memory, plain["memory"]) > 1e-3          # not the plain seed's masks
+
+
 def test_dispatch_between_the_fused_and_the_generic_path(macx, dev):
     vq, words, lengths, kb = [t.to(dev) for t in mo.synthetic_inputs(2, 5, 14, 128)]
     mk = lambda cfg: macx.MACCell(vq, words, words, lengths, kb, 0.85, 0.85, 1.0, 2, False, config=cfg)

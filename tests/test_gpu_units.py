@@ -27,6 +27,14 @@ def test_dropout_stream_matches_numpy(macx, dev):
         assert np.array_equal(out.cpu().numpy(), ref)
         if keep < 1:
             assert abs(ref.mean() - keep) < 0.01
+        # under a run's mask word (macx_dropout.mask_word): read from device memory when the kernel runs
+        for word in (0, 0x9E3779B9, 0xFFFFFFFF):
+            wt = torch.tensor([word - (1 << 32) if word >= (1 << 31) else word], dtype=torch.int32, device=dev)
+            macx._lib.check(L.macx_dropout_mask_w(seed, site, step, keep, first, n, _p(wt), _p(out), None), "mask_w")
+            torch.cuda.synchronize()
+            refw = dh.keep_mask(seed, site, step, keep, first, n, word=word)
+            assert np.array_equal(out.cpu().numpy(), refw)
+            assert (word == 0) == np.array_equal(refw, ref) or keep >= 1
 
 
 @pytest.mark.parametrize("rows,k1,k2,nout,act", [(64, 512, 0, 512, "NON"), (64, 512, 512, 512, "TANH"),

@@ -175,6 +175,11 @@ def test_dropout_stream_statistics_and_shard_consistency():
     assert np.array_equal(shard, m[4:])
     assert not np.array_equal(dh.mask_for(1234, dh.SITE_READ_KB, 4, 0.85, (8, 49, 64)), m)
     assert dh.mask_for(1, dh.SITE_MEM_VAR, 0, 1.0, (3, 5)).min() == 1.0
+    # the run's mask word (include/macx.h, macx_dropout.mask_word): XORed into the site key; 0 = the plain stream
+    assert np.array_equal(dh.mask_for(1234, dh.SITE_READ_KB, 3, 0.85, (8, 49, 64), word=0), m)
+    w = dh.mask_for(1234, dh.SITE_READ_KB, 3, 0.85, (8, 49, 64), word=0xDEADBEEF)
+    assert not np.array_equal(w, m) and abs(w.mean() - 0.85) < 0.01
+    assert dh.site_key(1234, dh.SITE_READ_KB, 3) ^ 0xDEADBEEF == dh.site_key(1234, dh.SITE_READ_KB, 3) ^ 0xDEADBEEF
 
 
 @pytest.mark.parametrize("over,exc", [
