@@ -100,7 +100,10 @@ def model_level(macx, dev, seed, steps=6):
     cfg = macx.configs.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
     VOCAB = 90                                                    # CLEVR question vocabulary size (preprocess.py)
     net = macx.MACNet(cfg, vocab=VOCAB, generator=torch.Generator().manual_seed(seed)).to(dev)
-    opt = macx.optim.FlatAdamEMA(net.tensors(), lr=1e-4, clip_norm=8.0, ema_decay=0.999)
+    # the tower's flat gradient buffer (what the data-parallel step exchanges): the cell's backward pass writes straight into its
+    # range and the optimizer reads the buffer as it is -- no per-tensor gather of the cell's 26 gradients in front of the step
+    bucket = macx.dp.TowerBuckets(net)
+    opt = macx.optim.FlatAdamEMA(bucket.tensors(), lr=1e-4, clip_norm=8.0, ema_decay=0.999)
     g = torch.Generator().manual_seed(seed)
     _, _, lengths, _ = macx.configs.synthetic_inputs(B, S, 1, 8, seed=seed)
     img = torch.relu(torch.randn(B, N, 1024, generator=g)).to(dev)
@@ -114,8 +117,10 @@ def model_level(macx, dev, seed, steps=6):
             t.grad = None
         logits = net(img, qs, lengths, train=True, seed=seed + i, check_ids=False)
         loss, _ = net.loss_and_pred(logits, ans)
+        bucket.begin_step(B, B)
         loss.backward()
-        opt.step()
+        bucket.allreduce_(B, B)              # one process: gathers the other modules' gradients into the buffer, exchanges nothing
+        opt.step(flat_grad=bucket.flat)
         return loss
 
     for i in range(3):

@@ -25,7 +25,8 @@ constexpr int kb_gemm3h_lds_bytes() {
   constexpr int ROWS = RT * 16;
   constexpr int stage = 2 * 4 * (ROWS * 16 + GS_PAD3) + 2 * 4 * (128 * 16 + GS_PAD3);
   constexpr int epi = (ROWS * (128 + 4) + 256 * 8) * 4;
-  return 2 * stage > epi ? 2 * stage : epi;
+  constexpr int loop = 2 * stage + 2 * 512 * 16;   // two stages + the scratch slots (both planes) of threads without a slot
+  return loop > epi ? loop : epi;
 }
 
 template <int RT, int AP, int BP, int EP, bool COLSUM>
@@ -44,6 +45,8 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
   constexpr int A_SLOTS = ROWS * 4;                  // 16-byte slots (8 k of one row) per A plane and stage
   constexpr int A_IT = (A_SLOTS + G_THREADS - 1) / G_THREADS;
   constexpr int HT = (RT + 1) / 2;                   // row tiles of the upper wave half (the lower one has RT - HT)
+  constexpr int SCRATCH = 2 * STAGE;                 // 512 x 16 B behind the two stages: where threads without a slot store
+  constexpr int VPM = (A_IT * 44 + 6 * HT - 1) / (6 * HT) + 1;      // vector instructions placed behind each product
   char* lds = reinterpret_cast<char*>(smem);
 
   const int nblk = gridDim.x;
@@ -83,9 +86,14 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
   // ds_write_b128 / ds_read_b128 lane groups of gfx950 then hit 16 distinct 4-bank slots, i.e. NO bank conflicts on either
   // side with an unpadded k-group stride (the PMC pass of the first layout showed half of the LDS-active cycles were
   // conflict cycles), and a lane's two float4 loads are 32 contiguous bytes of a row (a wave touches 16 full 128-B lines).
-  f32x4 ra[A_IT][2];
-  uint32_t rbits[A_IT];
-  u32x4 rb[2];               // B_PLAIN: raw plane bytes
+  // TWO register sets: the slice that is split and stored while the matrix pipe works on the current one was loaded a whole
+  // half-iteration earlier, the loads issued now are for the slice after it (round 4: with one set the split ran after the
+  // products of every slice, all waves at once -- the pipe idled 40 % of the loop, tools/stem_knobs.py)
+  f32x4 ra[2][A_IT][2];
+  uint32_t rbits[2][A_IT];
+  u32x4 rb[2][2];            // B_PLAIN: raw plane bytes
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
   const bool conv = p.conv_taps > 0;
   const float* Abase = p.A + (size_t)b * (p.a_qstride ? p.a_qstride : (size_t)p.N * p.lda);
@@ -93,24 +101,29 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
   const int sg = lane >> 4;                 // k-group of this thread's slots (A and B)
   int a_off[A_IT];
   int a_row[A_IT];
-  int a_lrow[A_IT];
-  bool a_ok[A_IT], a_in[A_IT];
+  int a_dst[A_IT], a_buf[A_IT], a_pl[A_IT]; // LDS byte offset of the slot inside a stage, the stage stride, the plane stride -- a thread
+                                            // past the last slot stores into scratch bytes behind the stages instead (stage stride 0)
+  bool a_ok[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int f = tid + G_THREADS * i;
     const int lrow = (f >> 6) * 16 + (lane & 15);
     const int n = row0 + lrow;
-    a_lrow[i] = lrow;
-    a_in[i] = f < A_SLOTS;
-    a_ok[i] = a_in[i] && (n < row_end);
+    const bool in = f < A_SLOTS;
+    a_ok[i] = in && (n < row_end);
     const int nc = min(n, p.N - 1);
     a_row[i] = nc;
     const int srow = conv ? (nc / p.conv_w + 1) * p.conv_wp + (nc % p.conv_w) + 1 : nc;
     a_off[i] = srow * p.lda + sg * 8;
+    a_dst[i] = in ? sg * A_GS + lrow * 16 : SCRATCH + tid * 16;      // no predicated store: the loop body stays ONE basic block
+    a_buf[i] = in ? STAGE : 0;
+    a_pl[i] = in ? A_PLANE : 512 * 16;
   }
   const int bcol = (lane & 15) + 16 * (tid >> 6);      // this thread's column of the 128-column weight tile
 
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](auto set_c, int kt_raw) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    int kt = min(kt_raw, nk - 1);          // past the end: re-read the last slice (stored to a buffer nobody multiplies)
     int koff = kt << 5;
     if (conv) {
       const int per = p.conv_cin >> 5;
@@ -121,47 +134,48 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
     if (p.dbg & 32) koff = 0;       // timing experiments: 32 = every slice re-reads slice 0 of A (L1/L2-hot), 64 = of B
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      ra[i][0] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff);
-      ra[i][1] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff + 4);
-      if (AP == A_DROP) rbits[i] = Bitbase[a_row[i] * (p.lda >> 5) + kt];
+      ra[SET][i][0] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff);
+      ra[SET][i][1] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff + 4);
+      if (AP == A_DROP) rbits[SET][i] = Bitbase[a_row[i] * (p.lda >> 5) + kt];
     }
     if (p.dbg & 64) kt = 0;
     if (BP == B_PLAIN) {
       // pack format 3: [kt][plane][k group][Nout] x 16 B fp16; the thread copies its slot (column bcol, k group sg) of both planes
       const char* src = reinterpret_cast<const char*>(p.Wp) + ((((size_t)kt * 2) * 4 + sg) * p.Nout + (size_t)cb * G_BN + bcol) * 16;
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) rb[pl] = *reinterpret_cast<const u32x4*>(src + (size_t)pl * 4 * p.Nout * 16);
+      for (int pl = 0; pl < 2; ++pl) rb[SET][pl] = *reinterpret_cast<const u32x4*>(src + (size_t)pl * 4 * p.Nout * 16);
     }
   };
 
-  auto store_tiles = [&](int buf, int kt) {
+  auto store_tiles = [&](auto set_c, int buf) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
     char* dA = lds + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       float x[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float vv = ra[i][e >> 2][e & 3];
-        if (AP == A_DROP) vv = ((rbits[i] >> (sg * 8 + e)) & 1u) ? vv * p.a_inv_keep : 0.f;
+        float vv = ra[SET][i][e >> 2][e & 3];
+        if (AP == A_DROP) vv = ((rbits[SET][i] >> (sg * 8 + e)) & 1u) ? vv * p.a_inv_keep : 0.f;
         x[e] = a_ok[i] ? vv * a_scale : 0.f;
       }
       u32x4 s0, s1;
       h2_split8(x, s0, s1);
-      if (a_in[i]) {
-        char* d = dA + sg * A_GS + a_lrow[i] * 16;
-        *reinterpret_cast<u32x4*>(d) = s0;
-        *reinterpret_cast<u32x4*>(d + A_PLANE) = s1;
-      }
+      char* d = lds + buf * a_buf[i] + a_dst[i];
+      *reinterpret_cast<u32x4*>(d) = s0;
+      *reinterpret_cast<u32x4*>(d + a_pl[i]) = s1;
     }
     char* dB = dA + 2 * A_PLANE + sg * B_GS + bcol * 16;
     if (BP == B_PLAIN) {
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(dB + pl * B_PLANE) = rb[pl];
+      for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(dB + pl * B_PLANE) = rb[SET][pl];
     }
   };
 
-  // lane (i = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7 of row / column i for BOTH operands
-  auto compute = [&](int buf) {
+  // lane (i = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7 of row / column i for BOTH operands.  Every wave multiplies HT
+  // row tiles: the lower half's last one lies past its rows when RT is odd (its accumulators are never stored) -- a branch
+  // around it would cut the loop body into blocks the scheduler cannot interleave.
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sA = lds + buf * STAGE + (lane >> 4) * A_GS + (t0 * 16 + (lane & 15)) * 16;
     const char* sB = lds + buf * STAGE + 2 * A_PLANE + (lane >> 4) * B_GS + (cgp * 32 + (lane & 15)) * 16;
     u32x4 bf[2][2];
@@ -174,33 +188,49 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
     for (int ap = 1; ap >= 0; --ap) {
       u32x4 af[HT];
 #pragma unroll
-      for (int t = 0; t < HT; ++t)
-        if (t < HT - 1 || t < my_nt) af[t] = *reinterpret_cast<const u32x4*>(sA + ap * A_PLANE + t * 16 * 16);
+      for (int t = 0; t < HT; ++t) af[t] = *reinterpret_cast<const u32x4*>(sA + ap * A_PLANE + t * 16 * 16);
 #pragma unroll
       for (int bp = 1 - ap; bp >= 0; --bp) {
 #pragma unroll
-        for (int t = 0; t < HT - 1; ++t) {
+        for (int t = 0; t < HT; ++t) {
           acc[t][0] = mfma_f16(af[t], bf[bp][0], acc[t][0]);
           acc[t][1] = mfma_f16(af[t], bf[bp][1], acc[t][1]);
-        }
-        if (HT - 1 < my_nt) {
-          acc[HT - 1][0] = mfma_f16(af[HT - 1], bf[bp][0], acc[HT - 1][0]);
-          acc[HT - 1][1] = mfma_f16(af[HT - 1], bf[bp][1], acc[HT - 1][1]);
         }
       }
     }
   };
+  // the matrix pipe's instructions with the split of the next slice between them (one of 6 HT products, then a share of the
+  // vector work): both come from the same wave, the pipe runs the product while the wave issues the split
+  auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 6 * HT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x2, VPM, 0);
+    }
+  };
 
-  load_tiles(0);
-  store_tiles(0, 0);
-  __syncthreads();
   const bool stage = !(p.dbg & 2);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = stage ? (kt & 1) : 0;
-    if (stage && kt + 1 < nk) load_tiles(kt + 1);
-    compute(cur);
-    if (stage && kt + 1 < nk) store_tiles(cur ^ 1, kt + 1);
-    __syncthreads();
+  load_tiles(S0{}, 0);
+  store_tiles(S0{}, 0);
+  load_tiles(S1{}, 1);
+  __syncthreads();
+  if (stage) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      // buffer 0 holds slice kt, set 1 slice kt + 1 (in flight since the previous half)
+      load_tiles(S0{}, kt + 2);
+      compute(0);
+      store_tiles(S1{}, 1);
+      interleave();
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      load_tiles(S1{}, kt + 3);
+      compute(1);
+      store_tiles(S0{}, 0);
+      interleave();
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) compute(0);          // timing experiment: the products alone
   }
   if (p.dbg & 1) {
     if (acc[0][0][0] == 123.456f) p.out[0] = acc[HT - 1][1][3];

@@ -1128,6 +1128,16 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
   for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nQ = h >> 4;
   constexpr int PF = 4;                     // k groups in flight per wave (h = 256: the wave's whole share)
+  // what the cell needs behind the product -- this thread's (question, unit): length, previous state, the input projection's
+  // four gate columns -- is requested BEFORE the product, so that its round trip does not start behind the barrier
+  const int crow = tid >> 4, cuu = tid & 15;
+  const int cb = min(r0 + crow, p.B - 1), cu = u0 + cuu;
+  const int cL = min(max(p.len[cb], 0), p.S);      // never index past the padded question (host validates too)
+  const int cpos = dir == 0 ? p.tau : max(cL - 1 - p.tau, 0);
+  const size_t cs0 = (size_t)(dir * (p.S + 1) + p.tau) * Bh + (size_t)cb * h + cu;
+  const float hpv_pre = p.hs[cs0], cp_pre = p.cs[cs0];
+  const float* Zpre = p.Zx + ((size_t)dir * p.B * p.S + (size_t)cb * p.S + cpos) * G;
+  const float z0 = Zpre[cu], z1 = Zpre[h + cu], z2 = Zpre[2 * h + cu], z3 = Zpre[3 * h + cu];
   for (int Q0 = wave; Q0 < nQ; Q0 += 4 * PF) {
     f32x4 af[PF], bf[PF][4];
 #pragma unroll
@@ -1159,19 +1169,18 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
   float R[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) R[g] = ((red[0][g][row][uu] + red[1][g][row][uu]) + red[2][g][row][uu]) + red[3][g][row][uu];
-  const int L = min(max(p.len[b], 0), p.S);      // never index past the padded question (host validates too)
+  const int L = cL;
   const bool active = p.tau < L;
-  const int pos = dir == 0 ? p.tau : L - 1 - p.tau;
-  const size_t s0 = (size_t)(dir * (p.S + 1) + p.tau) * Bh + (size_t)b * h + u, s1 = s0 + Bh;
-  const float hpv = p.hs[s0], cp = p.cs[s0];
+  const int pos = cpos;
+  const size_t s0 = cs0, s1 = s0 + Bh;
+  const float hpv = hpv_pre, cp = cp_pre;
   float hn = hpv, cn = cp;
   float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f;
   if (active) {
-    const float* Z = p.Zx + ((size_t)dir * p.B * p.S + (size_t)b * p.S + pos) * G;
-    gi = 1.0f / (1.0f + expf(-(R[0] + Z[u])));
-    gj = tanhf(R[1] + Z[h + u]);
-    gf = 1.0f / (1.0f + expf(-(R[2] + Z[2 * h + u] + 1.0f)));
-    go = 1.0f / (1.0f + expf(-(R[3] + Z[3 * h + u])));
+    gi = 1.0f / (1.0f + expf(-(R[0] + z0)));
+    gj = tanhf(R[1] + z1);
+    gf = 1.0f / (1.0f + expf(-(R[2] + z2 + 1.0f)));
+    go = 1.0f / (1.0f + expf(-(R[3] + z3)));
     cn = cp * gf + gi * gj;
     hn = tanhf(cn) * go;
     p.out[((size_t)b * p.S + pos) * 2 * h + dir * h + u] = hn;
@@ -1211,8 +1220,16 @@ __global__ __launch_bounds__(LSB_THREADS) void lstm_step_bwd_kernel(LstmStepBwdP
   const int li = lane & 15, lg = lane >> 4;
   const int u0 = blockIdx.x * 16, r0 = blockIdx.y * 16, dir = blockIdx.z;
   const size_t Bh = (size_t)p.B * h;
-  const bool writer = blockIdx.x == 0;
-  // ---- the cell's backward for 16 questions x h units
+  // the recurrent weights of this wave's k groups first: their L2 round trip runs under the cell's backward instead of
+  // behind the barrier (the launch is latency, 100 of them in a row)
+  const float* Wd = p.WhT + (size_t)dir * G * h;
+  const int nQ = G >> 4;
+  constexpr int PF = 4, NW = LSB_THREADS / 64;
+  f32x4 bf0[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) bf0[u] = *reinterpret_cast<const f32x4*>(Wd + ((size_t)(min(wave + NW * u, nQ - 1) * 4 + lg) * h + u0 + li) * 4);
+  // ---- the cell's backward for 16 questions x h units.  Every workgroup of a question block computes all of it (its
+  //      product needs all 4h gate gradients) and WRITES the columns of its own 16 units: dc, dG, dZ
 #pragma unroll 4
   for (int it = tid; it < 16 * h; it += LSB_THREADS) {
     const int row = it / h, u = it - row * h;
@@ -1241,12 +1258,12 @@ __global__ __launch_bounds__(LSB_THREADS) void lstm_step_bwd_kernel(LstmStepBwdP
         df = dct * cp * gf * (1.0f - gf);
         dc = dct * gf;
         pass = 0.f;
-        if (writer) {
+        if (u >= u0 && u < u0 + 16) {
           float* z = p.dZ + ((size_t)dir * p.B * p.S + (size_t)b * p.S + pos) * G;
           z[u] = di; z[h + u] = dj; z[2 * h + u] = df; z[3 * h + u] = dO;
         }
       }
-      if (writer) {
+      if (u >= u0 && u < u0 + 16) {
         float* g = p.dG + ((size_t)(dir * p.S + p.tau) * p.B + b) * G;
         g[u] = di; g[h + u] = dj; g[2 * h + u] = df; g[3 * h + u] = dO;
         p.dc_out[i] = dc;
@@ -1258,17 +1275,14 @@ __global__ __launch_bounds__(LSB_THREADS) void lstm_step_bwd_kernel(LstmStepBwdP
   }
   __syncthreads();
   // ---- dh_prev[16 questions][16 units] = dG[16][4h] WhT[4h][units]
-  const float* Wd = p.WhT + (size_t)dir * G * h;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int nQ = G >> 4;
-  constexpr int PF = 4, NW = LSB_THREADS / 64;
   for (int Q0 = wave; Q0 < nQ; Q0 += NW * PF) {
     f32x4 af[PF], bf[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int Q = min(Q0 + NW * u, nQ - 1);
       af[u] = *reinterpret_cast<const f32x4*>(sG + li * ldg + Q * 16 + lg * 4);
-      bf[u] = *reinterpret_cast<const f32x4*>(Wd + ((size_t)(Q * 4 + lg) * h + u0 + li) * 4);
+      bf[u] = Q0 == wave ? bf0[u] : *reinterpret_cast<const f32x4*>(Wd + ((size_t)(Q * 4 + lg) * h + u0 + li) * 4);
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u)
