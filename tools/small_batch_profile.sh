@@ -3,7 +3,7 @@
 # durations vs wall time per step (the difference is launch gaps), the longest kernels.
 export TMPDIR=/tmp
 b=${1:-8}
-F="--steps 20 --warmup 5 --no-cpu-baseline --no-model-level --no-native --per-gpu-batch $b"
+F="--steps 20 --warmup 5 --no-cpu-baseline --no-model-level --no-native --no-extra-legs --no-probe --per-gpu-batch $b"
 python bench.py $F 2>/dev/null | grep -a "^{" | sed -E "s/.*\"ms_per_step\": ([0-9.]+).*/wall ms per step (no profiler): \1/"
 rm -rf /tmp/sb_$b
 timeout 300 rocprofv3 --kernel-trace -d /tmp/sb_$b -o k -- python bench.py $F > /dev/null 2>&1
