@@ -124,13 +124,9 @@ def model_level(macx, dev, seed, steps=6):
         return loss
 
     for i in range(3):
-        one(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = one(3 + i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+        loss = one(i)
+    dt = best_block(one, steps, first=3)
+    loss = one(3 + 3 * steps)
     stem_flops = 2.0 * 9 * N * (1024 * 512 + 512 * 512)          # forward, per question
     return {"value": round(B / dt, 2), "unit": "questions/s", "ms_per_step": round(dt * 1e3, 3),
             "includes": "question encoder (emb + biLSTM) + stem CNN + MAC cell (p=%d) + output unit/classifier + CE loss, "
@@ -229,12 +225,7 @@ def fwd_only_p4(macx, dev, seed, p=4, steps=30):
 
     for _ in range(6):
         fwd()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fwd()
-    torch.cuda.synchronize()
-    dt_eager = (time.perf_counter() - t0) / steps
+    dt_eager = best_block(lambda i: fwd(), steps)
     # the same run replayed from one captured HIP graph (macx.CapturedForward): ~70 launches of 5-80 us each are host-bound when
     # issued one ctypes call at a time; the batch is copied into the captured run's input tensors inside the timed region
     cap = macx.CapturedForward(cfg, params, B, S, N)
@@ -245,12 +236,7 @@ def fwd_only_p4(macx, dev, seed, p=4, steps=30):
         raise SystemExit("captured forward differs from the eager forward")
     for _ in range(6):
         cap(vqd, wd, ld, kbd)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        cap(vqd, wd, ld, kbd)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = best_block(lambda i: cap(vqd, wd, ld, kbd), steps)
     units = 4 + 3 * (p - 1)            # knowledge-base products executed: step 0 all four, later steps reuse X
     executed = 3.0 * units * 2.0 * B * N * D * D
     return {"value": round(B / dt, 1), "unit": "questions/s", "ms_per_batch": round(dt * 1e3, 3), "steps": steps, "p": p, "batch": B,
@@ -291,12 +277,7 @@ def gqa_shape_p4(macx, dev, seed, flag_file, steps=8):
 
     for i in range(3):
         one(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        one(3 + i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = best_block(one, steps, first=3)
     cell_flops = 3.0 * p * flops_per_question_step(n=Ng)
     stem_flops = 3.0 * 2.0 * 9 * Ng * (Cin * 512 + 512 * 512)
     return {"value": round(B / dt, 1), "unit": "questions/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "p": p, "batch": B,
@@ -358,12 +339,7 @@ def train_b128_p12(macx, dev, dist, seed, steps=8):
 
     for i in range(4):
         one(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        one(4 + i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = best_block(one, steps, first=4)
     cfg = macx.configs.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
     F = flops_per_question_step()
     out = {"value": round(b / dt, 1), "unit": "questions/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "p": p, "batch": b,
@@ -373,6 +349,22 @@ def train_b128_p12(macx, dev, dist, seed, steps=8):
            "executed_fp16_frac": round(b / dt * 3 * (3 * p * F) / PEAK_BF16_MFMA, 4)}
     out.update(run_bytes(macx, cfg, b, p))
     return out
+
+
+def best_block(one, steps, first=0, blocks=3):
+    """seconds per step: the fastest of `blocks` timed blocks of `steps` steps (side legs only -- boxes of the pool have bursts of
+    host-side interference that double or triple an eager leg for seconds at a time; the metric's own timing is K steps, once)"""
+    best, i = None, first
+    for _ in range(blocks):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one(i)
+            i += 1
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        best = dt if best is None else min(best, dt)
+    return best
 
 
 def mode_is_h2(L):
@@ -781,6 +773,8 @@ def main():
                "roofline": roofline}
         out.update(extra)
         out["launch"] = launch_mode
+        out["side_legs_timing"] = ("every leg below the metric (other_families, fwd_only_p4, train_b128_p12_adam_ema, gqa_shape_*, model_level) reports "
+                                   "the fastest of 3 timed blocks of its `steps` steps; the metric itself is timed once: K steps")
         if eager_leg is not None:
             out["eager_step"] = eager_leg
             out["settle"] = settle_log
@@ -792,7 +786,9 @@ def main():
             for name, m in (("split_bf16_6term", 1), ("native_f32_mfma", 0)):
                 L.macx_gemm_mode(m)
                 st3, _, _, _ = make_step(macx, dev, dist, 1, 0, global_batch, p, seed)
-                d3 = time_steps(st3, 5, 1, 2, barrier, 1, dev, dist)
+                for i in range(3):
+                    st3(i)
+                d3 = best_block(st3, 5, first=3) * 5
                 fam[name] = {"value": round(global_batch * 5 / d3, 2), "unit": "questions/s", "ms_per_step": round(d3 / 5 * 1e3, 3), "steps": 5}
                 del st3
             L.macx_gemm_mode(2)

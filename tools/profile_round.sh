@@ -6,7 +6,7 @@
 TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
-B="python bench.py --no-cpu-baseline --no-model-level --no-native --no-extra-legs --no-probe"
+B="python bench.py --no-cpu-baseline --no-model-level --no-native --no-extra-legs --no-probe --eager"   # --eager: the step as launches (same kernels as a replay; no settle blocks in the trace)
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_k -o r -- $B --steps 5 --warmup 2 > $O/${TAG}_k.log 2>&1
 python tools/rocpd_stats.py $O/${TAG}_k/r_results.db > $O/${TAG}_kernel_stats.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_f -o f -- $B --steps 1 --warmup 0 > $O/${TAG}_f.log 2>&1
