@@ -209,7 +209,15 @@ class MACCell:
         from types import SimpleNamespace
         from .options import UnsupportedOptions
         if cls is MACCell and config is not None and _needs_padding(config):
-            # a width the kernels' 128-column granule does not divide (config.py:294-296 takes any): the same cell, zero-padded
+            # a width the kernels' 128-column granule does not divide (config.py:294-296 takes any): the same cell, zero-padded --
+            # as a whole for the option sets with fused kernels, inside each product on the generic path
+            try:
+                freeze(config)
+            except UnsupportedOptions:
+                if gemm is not None:
+                    raise
+                from .generic import GenericMACCell
+                return GenericMACCell(*args, config=config, **kw)
             return PaddedMACCell(*args, config=config, gemm=gemm, **kw)
         try:
             freeze(config if config is not None else SimpleNamespace())

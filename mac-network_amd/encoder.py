@@ -74,6 +74,8 @@ def _check_fused(config):
         raise UnsupportedOptions("encoder: output projections (encProj / encDim != ctrlDim) have no fused HIP path")
     if g("ansEmbMod", "NON") == "SHARED":
         raise UnsupportedOptions("encoder: shared question/answer embeddings have no HIP path")
+    if (int(g("encDim", 512)) // 2) % 128 or int(g("encDim", 512)) % 2:
+        raise UnsupportedOptions("encoder: the fused kernels need 128 k units per direction (the generic path takes any multiple of 4)")
 
 
 class QuestionEncoder(torch.nn.Module):
@@ -156,7 +158,8 @@ class GenericQuestionEncoder(torch.nn.Module):
     per-step slices / stack / concat, the reverse-sequence gather and the autograd tape.  Variables under the reference's
     names (encoder/rnnLayer/rnn/basic_lstm_cell/kernel, ... / birnnLayer/bidirectional_rnn/{fw,bw}/..., linearLayerprojCW, ...).
     --encNumLayers > 1 raises what the reference raises (its layers collide on one variable scope); other cell types,
-    variational dropout and shared answer embeddings are refused.  Hidden width per direction: a multiple of 128."""
+    variational dropout and shared answer embeddings are refused.  Hidden width per direction: any multiple of 4 (the products
+    zero-pad their operands to the kernels' 128-column granule, generic.k_matmul)."""
 
     def __init__(self, config, vocab, embInit=None, generator=None, device=None):
         super().__init__()
@@ -181,8 +184,9 @@ class GenericQuestionEncoder(torch.nn.Module):
         self.vocab, self.E = int(vocab), int(g("wrdEmbDim"))
         self.enc, self.ctrl = int(g("encDim")), int(g("ctrlDim"))
         self.hh = self.enc // 2 if self.bi else self.enc
-        if self.hh % 128:
-            raise UnsupportedOptions("encoder: the LSTM width per direction must be a multiple of 128 (got %d)" % self.hh)
+        if self.hh % 4:
+            raise UnsupportedOptions("encoder: the LSTM width per direction must be a multiple of 4 (got %d): 16-byte rows; widths "
+                                     "off the product kernels' 128-column granule run zero-padded inside them" % self.hh)
         self.proj = g("encProj") or self.enc != self.ctrl
         self.proj_act = g("encProjQAct")
         self.keep_in, self.keep_q = float(g("encInputDropout")), float(g("qDropout"))

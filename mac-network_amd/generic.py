@@ -115,11 +115,24 @@ def k_dropout(x, seed, site, step, keep, first, mask_word=None):
     return out
 
 
+def _pad128(v):
+    return (v + 127) // 128 * 128
+
+
 def k_matmul(x, W, b, big):
-    """x [rows, K] @ W [K, n] (+ b): the knowledge-base GEMM for [B, N, .] operands (big = (B, N)), macx_linear otherwise."""
+    """x [rows, K] @ W [K, n] (+ b): the knowledge-base GEMM for [B, N, .] operands (big = (B, N)), macx_linear otherwise.
+    Layer widths the kernels' 128-column granule does not divide (config.py:294-296 and every *Dim option take any integer) run
+    zero-padded: zero rows of W meet zero columns of x, the padded output columns are dropped."""
     L = _L()
     rows, K = x.shape
     n = W.shape[1]
+    Kp, np_ = _pad128(K), _pad128(n)
+    if Kp != K or np_ != n:
+        pad = torch.nn.functional.pad
+        xp = pad(x, (0, Kp - K)).contiguous() if Kp != K else x
+        Wp = pad(W, (0, np_ - n, 0, Kp - K)).contiguous()
+        bp = pad(b, (0, np_ - n)).contiguous() if b is not None else None
+        return k_matmul(xp, Wp, bp, big)[:, :n].contiguous()
     out = torch.empty((rows, n), dtype=torch.float32, device=x.device)
     bias = b if b is not None else torch.zeros(n, dtype=torch.float32, device=x.device)
     if big is not None:
@@ -154,6 +167,10 @@ def k_wgrad(x2, g2):
     L = _L()
     rows, K = x2.shape
     n = g2.shape[1]
+    Kp, np_ = _pad128(K), _pad128(n)
+    if Kp != K or np_ != n:                       # widths off the 128-column granule: zero-padded operands, the padding dropped
+        pad = torch.nn.functional.pad
+        return k_wgrad(pad(x2, (0, Kp - K)).contiguous(), pad(g2, (0, np_ - n)).contiguous())[:K, :n].contiguous()
     dW = torch.empty((K, n), dtype=torch.float32, device=g2.device)
     ws = torch.empty(L.macx_wgrad_splits(rows, K, n) * K * n, dtype=torch.float32, device=g2.device)
     _lib.check(L.macx_wgrad(_p(x2), K, _p(g2), n, rows, K, n, _p(dW), _p(ws), _st(g2)), "macx_wgrad")
@@ -296,8 +313,6 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, W, b):
         x, W = _dev(x), _dev(W)
         K, n = W.shape
-        if K % 128 or n % 128:
-            raise UnsupportedOptions("the generic path needs layer widths that are multiples of 128 (got %d -> %d)" % (K, n))
         x2 = x.reshape(-1, K)
         big = (x.shape[0], x.shape[1]) if (x.dim() == 3 and x.shape[1] <= 1024) else None
         ctx.big, ctx.xshape, ctx.has_b = big, tuple(x.shape), b is not None
@@ -504,9 +519,10 @@ class GenericMACCell:
         self.mask_word = _mask_word(mask_word, knowledgeBase)
         self.config = config if config is not None else SimpleNamespace()
         reject_like_reference(self.config)
-        bad = [k for k in ("memDim", "ctrlDim", "attDim") if self.g(k) % 128]
+        bad = [k for k in ("memDim", "ctrlDim", "attDim") if self.g(k) % 4]
         if bad:
-            raise UnsupportedOptions("the generic path needs %s %% 128 == 0" % bad[0])
+            raise UnsupportedOptions("the generic path needs %s %% 4 == 0 (16-byte rows; widths off the 128-column granule of the "
+                                     "product kernels run zero-padded inside them)" % bad[0])
         _L()                                           # fails loudly without libmacx.so
         _require_device(questionLengths, "questionLengths")
         lengths = questionLengths.to(torch.int32).contiguous()

@@ -457,8 +457,6 @@ class _Exec:
         if op == "linear":
             inp, W, b = x[0].contiguous(), x[1], (x[2] if len(x) > 2 else None)
             K, n = W.shape
-            if K % 128 or n % 128:
-                raise UnsupportedOptions("the generic path needs layer widths that are multiples of 128 (got %d -> %d)" % (K, n))
             big = (inp.shape[0], inp.shape[1]) if (inp.dim() == 3 and inp.shape[1] <= 1024) else None
             if b is not None and a["const"] != 0.0:
                 b = G.k_binary(G.OP_ADD, G.B_SAME, b.contiguous(), torch.full_like(b, a["const"]), 1, b.shape[-1])

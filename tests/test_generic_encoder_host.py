@@ -16,6 +16,8 @@ ENC_VARIANTS = {
     "bi_proj_tanh": dict(encBi=True, encDim=256, ctrlDim=256, encProj=True, encProjQAct="TANH"),
     "uni_proj_prelu": dict(encBi=False, encDim=128, ctrlDim=128, encProj=True, encProjQAct="RELU", relu="PRM"),
     "bi_other_width": dict(encBi=True, encDim=256, ctrlDim=128),
+    "bi_off_granule": dict(encBi=True, encDim=144, ctrlDim=144),        # 72 units per direction: off the kernels' 128-column granule
+    "uni_off_granule": dict(encBi=False, encDim=100, ctrlDim=200),
 }
 
 
@@ -92,8 +94,12 @@ def test_generic_encoder_dispatch_and_rejections(macx, host_generic):
         macx.QuestionEncoder(mo.default_config(encDim=128, ctrlDim=128, encNumLayers=2), vocab=5)
     with pytest.raises(macx.UnsupportedOptions):
         macx.QuestionEncoder(mo.default_config(encType="GRU"), vocab=5)
-    with pytest.raises(macx.UnsupportedOptions, match="128"):
-        macx.QuestionEncoder(mo.default_config(encDim=64, ctrlDim=64), vocab=5)
+    # widths off the kernels' 128-column granule: accepted on the generic path (round 4), also for the flag files' configuration
+    assert type(macx.QuestionEncoder(mo.default_config(encDim=64, ctrlDim=64), vocab=5)) is macx.GenericQuestionEncoder
+    assert type(macx.QuestionEncoder(mo.flag_file_config("args", encDim=144, ctrlDim=144, memDim=144, attDim=144, wrdEmbDim=8), vocab=5)) \
+        is macx.GenericQuestionEncoder
+    with pytest.raises(macx.UnsupportedOptions, match="multiple of 4"):
+        macx.QuestionEncoder(mo.default_config(encDim=66, ctrlDim=66), vocab=5)
     fixed = macx.QuestionEncoder(mo.default_config(encDim=128, ctrlDim=128, wrdEmbDim=8, wrdEmbFixed=True), vocab=5)
     assert not fixed.params.table[fixed.params.names["qEmbeddings/emb"]].requires_grad
 

@@ -154,9 +154,13 @@ def test_generic_path_rejections(macx, host_generic):
         mk(readMemAttType="DIAG")
     with pytest.raises(UnboundLocalError):
         mk(relu="SELU", writeMemAct="RELU").run()
+    # widths off the kernels' 128-column granule are accepted (zero-padded inside the products, round 4) ...
+    macx.GenericMACCell(vq[:, :64], words[:, :, :64], words[:, :, :64], lengths, kb[:, :, :64], 1.0, 1.0, 1.0, 2, False,
+                        config=mo.default_config(netLength=1, memDim=64, ctrlDim=64, attDim=64))
+    # ... rows that are not whole 16-byte units are not
     with pytest.raises(macx.UnsupportedOptions):
-        macx.GenericMACCell(vq[:, :64], words[:, :, :64], words[:, :, :64], lengths, kb[:, :, :64], 1.0, 1.0, 1.0, 2, False,
-                     config=mo.default_config(netLength=1, memDim=64, ctrlDim=64, attDim=64))
+        macx.GenericMACCell(vq[:, :66], words[:, :, :66], words[:, :, :66], lengths, kb[:, :, :66], 1.0, 1.0, 1.0, 2, False,
+                            config=mo.default_config(netLength=1, memDim=66, ctrlDim=66, attDim=66))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

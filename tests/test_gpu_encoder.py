@@ -148,7 +148,8 @@ def test_full_tower_ids_to_logits_gradients(macx, dev):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("variant", ["uni", "uni_projected", "bi_proj_tanh", "uni_proj_prelu", "bi_other_width"])
+@pytest.mark.parametrize("variant", ["uni", "uni_projected", "bi_proj_tanh", "uni_proj_prelu", "bi_other_width", "bi_off_granule",
+                                     "uni_off_granule"])
 @pytest.mark.parametrize("train", [False, True])
 def test_generic_encoder_matches_oracle(macx, dev, variant, train):
     """macx.QuestionEncoder on the LSTM configurations the fused kernels refuse (no --encBi = the parser's default; projCW /

@@ -130,6 +130,43 @@ def test_generic_path_matches_oracle(macx, dev, variant, train):
         assert rel_err(got.grad, want.grad) < GRAD_TOL * slack, name
 
 
+@pytest.mark.parametrize("variant,d,train", [("defaults", 144, True), ("read_bilinear", 72, True), ("write_sum", 200, False),
+                                             ("control_proj", 100, True)])
+def test_generic_path_at_widths_off_the_128_granule(macx, dev, variant, d, train):
+    """config.py:294-296 takes any width: on the one-kernel-per-op path the products zero-pad their operands to the kernels'
+    128-column granule (generic.k_matmul / k_wgrad) and every other op works at the logical width -- states, attentions and all
+    gradients against the fp64 oracle; macx.MACCell dispatches such a configuration here."""
+    B, S, N, p = 3, 7, 20, 2
+    cfg = make_cfg(variant, d, p)
+    vq, words, lengths, kb = mo.synthetic_inputs(B, S, N, d, seed=11)
+    params = oracle_params(cfg, vq, words, lengths, kb)
+    dM = torch.randn(B, d, generator=torch.Generator().manual_seed(3))
+    ref = oracle_run(cfg, params, vq, words, lengths, kb, train=train, seed=91, b0=1, need_grad=True, d_memory=dM)
+    gp = macx.GenericParams(device=dev).load_reference_dict(params)
+    vqd, wd, kbd = [t.to(dev).requires_grad_(True) for t in (vq, words, kb)]
+    cell = macx.MACCell(vqd, wd, wd, lengths.to(dev), kbd, cfg.memoryDropout, cfg.readDropout, cfg.writeDropout, B, train,
+                        config=cfg, params=gp, seed=91, b0=1)
+    assert getattr(cell, "generic", False), "a width off the granule with a non-fused option set belongs on the generic path"
+    state = cell.zero_state(B)
+    for i in range(p):
+        cell.iteration = i
+        _, state = cell(cell.none, state)
+    (state.memory * dM.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert state.memory.shape == (B, d)
+    assert rel_err(state.memory, ref["memory"]) < FWD_TOL and rel_err(state.control, ref["control"]) < FWD_TOL
+    for a, b in zip(cell.attentions["kb"], ref["cell"].attentions["kb"]):
+        assert max_abs(a, b) < 2e-6
+    grads = gp.grads_by_name()
+    for k, v in ref["params"].items():
+        if v.grad is not None:
+            assert grads[k] is not None, k
+            assert_grad(grads[k], v.grad, k)
+    for name, got, want in zip(("vecQuestions", "words", "knowledgeBase"), (vqd, wd, kbd), ref["inputs"]):
+        if want.grad is not None:
+            assert rel_err(got.grad, want.grad) < GRAD_TOL, name
+
+
 def test_generic_path_under_a_mask_word(macx, dev):
     """macx_dropout.mask_word on the one-kernel-per-op path (macx_op_dropout_w): the masks of (seed, word), forward and backward"""
     B, S, N, d, p = 3, 7, 20, 128, 2
