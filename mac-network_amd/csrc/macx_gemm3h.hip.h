@@ -23,7 +23,7 @@ constexpr int GS_PAD3 = 0;
 template <int RT>
 constexpr int kb_gemm3h_lds_bytes() {
   constexpr int ROWS = RT * 16;
-  constexpr int stage = 2 * 4 * (ROWS * 16 + GS_PAD3) + 2 * 4 * (128 * 16 + GS_PAD3);
+  constexpr int stage = 2 * 4 * (ROWS * 16 + GS_PAD3);
   constexpr int epi = (ROWS * (128 + 4) + 256 * 8) * 4;
   constexpr int loop = 2 * stage + 2 * 512 * 16;   // two stages + the scratch slots (both planes) of threads without a slot
   return loop > epi ? loop : epi;
@@ -38,10 +38,8 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
   constexpr int G_LDT = G_BN + 4;
   constexpr int ROWS = RT * 16;
   constexpr int A_GS = ROWS * 16 + GS_PAD3;           // bytes between k-groups of an A plane
-  constexpr int B_GS = G_BN * 16 + GS_PAD3;
   constexpr int A_PLANE = 4 * A_GS;                  // bytes
-  constexpr int B_PLANE = 4 * B_GS;
-  constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+  constexpr int STAGE = 2 * A_PLANE;                 // the weights go from L2 to registers (load_b)
   constexpr int A_SLOTS = ROWS * 4;                  // 16-byte slots (8 k of one row) per A plane and stage
   constexpr int A_IT = (A_SLOTS + G_THREADS - 1) / G_THREADS;
   constexpr int HT = (RT + 1) / 2;                   // row tiles of the upper wave half (the lower one has RT - HT)
@@ -91,7 +89,10 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
   // products of every slice, all waves at once -- the pipe idled 40 % of the loop, tools/stem_knobs.py)
   f32x4 ra[2][A_IT][2];
   uint32_t rbits[2][A_IT];
-  u32x4 rb[2][2];            // B_PLAIN: raw plane bytes
+  // The weights never touch LDS: pack format 3 stores them as the matrix pipe reads them (16 B = 8 k of one column per plane
+  // and k group), so a lane loads ITS operand fragments of the next slice straight from L2 into registers while the current
+  // slice multiplies -- no staging stores, no LDS reads for B, and the LDS pipe (85 % busy with both operands) is left to A.
+  u32x4 wb[2][2][2];         // [set][plane][column tile]
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
@@ -119,7 +120,6 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
     a_buf[i] = in ? STAGE : 0;
     a_pl[i] = in ? A_PLANE : 512 * 16;
   }
-  const int bcol = (lane & 15) + 16 * (tid >> 6);      // this thread's column of the 128-column weight tile
 
   auto load_tiles = [&](auto set_c, int kt_raw) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
@@ -138,13 +138,17 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
       ra[SET][i][1] = *reinterpret_cast<const f32x4*>(Abase + a_off[i] + koff + 4);
       if (AP == A_DROP) rbits[SET][i] = Bitbase[a_row[i] * (p.lda >> 5) + kt];
     }
+  };
+  auto load_b = [&](auto set_c, int kt_raw) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    int kt = min(kt_raw, nk - 1);
     if (p.dbg & 64) kt = 0;
-    if (BP == B_PLAIN) {
-      // pack format 3: [kt][plane][k group][Nout] x 16 B fp16; the thread copies its slot (column bcol, k group sg) of both planes
-      const char* src = reinterpret_cast<const char*>(p.Wp) + ((((size_t)kt * 2) * 4 + sg) * p.Nout + (size_t)cb * G_BN + bcol) * 16;
+    // pack format 3: [kt][plane][k group][Nout] x 16 B fp16; lane (i = lane & 15, g = lane >> 4) holds k = 8 g .. 8 g + 7 of column i
+    const char* src = reinterpret_cast<const char*>(p.Wp) + ((((size_t)kt * 2) * 4 + sg) * p.Nout + (size_t)cb * G_BN + cgp * 32 + (lane & 15)) * 16;
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) rb[SET][pl] = *reinterpret_cast<const u32x4*>(src + (size_t)pl * 4 * p.Nout * 16);
-    }
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) wb[SET][pl][c] = *reinterpret_cast<const u32x4*>(src + ((size_t)pl * 4 * p.Nout + c * 16) * 16);
   };
 
   auto store_tiles = [&](auto set_c, int buf) __attribute__((always_inline)) {
@@ -165,24 +169,20 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
       *reinterpret_cast<u32x4*>(d) = s0;
       *reinterpret_cast<u32x4*>(d + a_pl[i]) = s1;
     }
-    char* dB = dA + 2 * A_PLANE + sg * B_GS + bcol * 16;
-    if (BP == B_PLAIN) {
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4*>(dB + pl * B_PLANE) = rb[SET][pl];
-    }
+    (void)dA;
   };
 
   // lane (i = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7 of row / column i for BOTH operands.  Every wave multiplies HT
   // row tiles: the lower half's last one lies past its rows when RT is odd (its accumulators are never stored) -- a branch
   // around it would cut the loop body into blocks the scheduler cannot interleave.
-  auto compute = [&](int buf) __attribute__((always_inline)) {
+  auto compute = [&](int buf, auto set_c) __attribute__((always_inline)) {
+    constexpr int BSET = decltype(set_c)::value;
     const char* sA = lds + buf * STAGE + (lane >> 4) * A_GS + (t0 * 16 + (lane & 15)) * 16;
-    const char* sB = lds + buf * STAGE + 2 * A_PLANE + (lane >> 4) * B_GS + (cgp * 32 + (lane & 15)) * 16;
     u32x4 bf[2][2];
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) bf[pl][c] = *reinterpret_cast<const u32x4*>(sB + pl * B_PLANE + c * 16 * 16);
+      for (int c = 0; c < 2; ++c) bf[pl][c] = wb[BSET][pl][c];
     // term order: smallest products first into the accumulator:  A_lo x B_hi ; A_hi x {B_lo, B_hi}
 #pragma unroll
     for (int ap = 1; ap >= 0; --ap) {
@@ -211,26 +211,29 @@ __global__ __launch_bounds__(512) void kb_gemm3h_kernel(GemmP p) {
 
   const bool stage = !(p.dbg & 2);
   load_tiles(S0{}, 0);
+  load_b(S0{}, 0);
   store_tiles(S0{}, 0);
   load_tiles(S1{}, 1);
   __syncthreads();
   if (stage) {
     for (int kt = 0; kt < nk; kt += 2) {
-      // buffer 0 holds slice kt, set 1 slice kt + 1 (in flight since the previous half)
+      // buffer 0 holds slice kt of A, weight set 0 slice kt; A set 1 holds slice kt + 1 (in flight since the previous half)
       load_tiles(S0{}, kt + 2);
-      compute(0);
+      load_b(S1{}, kt + 1);
+      compute(0, S0{});
       store_tiles(S1{}, 1);
       interleave();
       __syncthreads();
       if (kt + 1 >= nk) break;
       load_tiles(S1{}, kt + 3);
-      compute(1);
+      load_b(S0{}, kt + 2);
+      compute(1, S1{});
       store_tiles(S0{}, 0);
       interleave();
       __syncthreads();
     }
   } else {
-    for (int kt = 0; kt < nk; ++kt) compute(0);          // timing experiment: the products alone
+    for (int kt = 0; kt < nk; ++kt) compute(0, S0{});          // timing experiment: the products alone
   }
   if (p.dbg & 1) {
     if (acc[0][0][0] == 123.456f) p.out[0] = acc[HT - 1][1][3];
