@@ -418,6 +418,12 @@ class PaddedMACCell:
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
                  netLength=None, seed=None, b0=0, gemm=None, mask_word=None):
         import copy
+        from .options import UnsupportedOptions
+        # the dropout index at the logical width (macx_shapes.d_logical) is implemented by the H2 kernel family: the padded cell runs
+        # on it whatever the process default is; asking for another family is refused, not silently overridden
+        if gemm not in (None, "h2"):
+            raise UnsupportedOptions("gemm=%r: a cell whose width is not a multiple of 128 runs zero-padded on the H2 kernel family only" % (gemm,))
+        gemm = "h2"
         self.config = config
         d = self.d = int(get(config, "memDim"))
         dp = self.dp = (d + 127) // 128 * 128

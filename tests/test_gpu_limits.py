@@ -38,6 +38,24 @@ def test_widths_that_are_not_multiples_of_128(macx, dev, name, B, S, N, d, p, tr
     parity(macx, dev, name, B, S, N, d, p, train)
 
 
+def test_padded_cell_runs_on_the_h2_family_whatever_the_default(macx, dev):
+    """the logical-width dropout index lives in the H2 kernels: a padded cell selects that family for itself (process default
+    split / native included) and refuses an explicit other one"""
+    cfg, vq, words, lengths, kb = make_case("args", 2, 5, 20, 144, 2)
+    L = macx._lib.lib()
+    before = L.macx_gemm_mode(-1)
+    try:
+        L.macx_gemm_mode(1)                       # process default: the 6-term bf16 split
+        vqd, wd, kbd = [t.to(dev) for t in (vq, words, kb)]
+        mk = lambda **kw: macx.MACCell(vqd, wd, wd, lengths.to(dev), kbd, 0.85, 0.85, 1.0, 2, True, config=cfg, seed=3, **kw)
+        cell = mk()
+        assert cell.run().memory.shape == (2, 144)
+        with pytest.raises(macx.UnsupportedOptions):
+            mk(gemm="split")
+    finally:
+        L.macx_gemm_mode(before)
+
+
 @pytest.mark.parametrize("over", [dict(S=257), dict(N=1025), dict(p=33), dict(d=1152), dict(d=192), dict(B=0), dict(d=256, d_logical=100),
                                   dict(d=256, d_logical=132)])
 def test_first_size_past_each_limit_is_rejected(macx, over):
