@@ -240,3 +240,42 @@ def test_product_configs_match_the_oracle_copies():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
     body = src[src.index("def main():"):]
     assert "oracle" not in body.replace("cpu_baseline", "")     # only the cpu_baseline leg touches the oracle
+
+
+def test_mix32_is_the_dropout_streams_finaliser(macx):
+    """graph.mix32 (iteration number -> mask word of a captured training step) is hash_mix of macx_common.hip.h / oracle/dropout_hash.py"""
+    from oracle import dropout_hash as dh
+    from macx.graph import mix32
+    for x in (0, 1, 2, 12345, 0xFFFFFFFF, 0x80000000):
+        assert mix32(x) == int(dh.hash_mix((x + 0x7F4A7C15) & 0xFFFFFFFF))
+    assert len({mix32(i) for i in range(1000)}) == 1000
+
+
+def test_bench_settle_and_best_block_logic(monkeypatch):
+    """bench.settle stops when two replay blocks agree within 2 % and the eager block is within 8 % of them, or after max_s;
+    bench.best_block reports the fastest block (pure host logic: time and the device are faked)"""
+    import bench
+    clock = {"t": 0.0}
+    monkeypatch.setattr(bench.time, "perf_counter", lambda: clock["t"])
+    monkeypatch.setattr(bench.torch.cuda, "synchronize", lambda *a, **k: None)
+    costs = {"g": [4.0e-3] * 100, "e": [6.0e-3, 5.0e-3, 4.1e-3] + [4.1e-3] * 100}
+    calls = {"g": 0, "e": 0}
+
+    def mk(kind):
+        def step(i):
+            clock["t"] += costs[kind][calls[kind] // 20]
+            calls[kind] += 1
+        return step
+
+    out = bench.settle(mk("g"), mk("e"), 30.0)
+    assert out["quiet"] and out["n_blocks"] == 3 and out["blocks_replay_eager_ms"][-1] == (4.0, 4.1)
+    # a box that never gets quiet: gives up after max_s
+    calls.update(g=0, e=0)
+    costs["e"] = [9.0e-3] * 1000
+    out = bench.settle(mk("g"), mk("e"), 1.0)
+    assert not out["quiet"] and out["seconds"] >= 1.0
+    # best_block: the fastest of three blocks
+    seq = iter([5e-3] * 4 + [3e-3] * 4 + [4e-3] * 4)
+    def one(i):
+        clock["t"] += next(seq)
+    assert abs(bench.best_block(one, 4) - 3e-3) < 1e-12
