@@ -25,6 +25,9 @@ ROCm 7.2 a captured hipMemsetAsync / hipMemcpyAsync becomes a memset / memcpy NO
 stream order with the kernel nodes around them.  The library therefore issues no memset or memcpy at all any more -- every
 fill and copy on the step's path is a kernel (`dev_zero` / `dev_copy` / `dev_copy2d` in macx_api.hip) -- and reductions that
 used to start from a memset write per-workgroup partials that a later kernel combines.
+(What torch adds around the library inside a capture is not under its control: the two `.clone()`s of the final state are
+device-to-device copy nodes.  They deliver `memory`, which the self-check compares on every verification replay, and they have
+never been seen out of order -- but they are the reason the check stays on by default.)
 """
 import warnings
 
