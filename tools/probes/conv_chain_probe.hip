@@ -115,21 +115,28 @@ __global__ __launch_bounds__(512) void conv_chain_kernel(ConvP p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto slice = [&](int buf, int q, auto set_c) __attribute__((always_inline)) {
+  // the activation fragments of a slice, from LDS: [set][plane][16-row tile]
+  u32x4 aq[2][2][4];
+  auto load_a = [&](auto set_c, int buf, int q) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
     const char* sA = lds + buf * BUF + ((q * 4 + lg) * ROWS + li) * 16;
-    // smallest terms first: A_lo x B_hi ; A_hi x {B_lo, B_hi}
 #pragma unroll
-    for (int ap = 1; ap >= 0; --ap) {
-      u32x4 af[4];
+    for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const u32x4*>(sA + ap * (KG * ROWS * 16) + t * 256);
+      for (int t = 0; t < 4; ++t) aq[SET][pl][t] = *reinterpret_cast<const u32x4*>(sA + pl * (KG * ROWS * 16) + t * 256);
+  };
+  // the products of one slice, operands swapped as in the chain kernels (D^T = W^T A^T: a lane ends up with FOUR CONSECUTIVE
+  // COLUMNS of one row, a 16-byte store), smallest terms first
+  auto mm = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
 #pragma unroll
-      for (int bp = 1 - ap; bp >= 0; --bp)
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+      for (int c = 0; c < 4; ++c) acc[t][c] = mfma_f16(wb[SET][0][c], aq[SET][1][t], acc[t][c]);     // w_hi a_lo
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[t][c] = mfma_f16(af[t], wb[SET][bp][c], acc[t][c]);
+      for (int c = 0; c < 4; ++c) acc[t][c] = mfma_f16(wb[SET][1][c], aq[SET][0][t], acc[t][c]);     // w_lo a_hi
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[t][c] = mfma_f16(wb[SET][0][c], aq[SET][0][t], acc[t][c]);     // w_hi a_hi
     }
   };
 
@@ -137,16 +144,27 @@ __global__ __launch_bounds__(512) void conv_chain_kernel(ConvP p) {
   load_w(S0{}, 0);
   store_chunk(0);
   __syncthreads();
+  // The order "request slice q + 1, multiply slice q" is PINNED (sched_barrier): left alone, the scheduler sinks a slice's loads to
+  // the end of the previous slice's products -- shortest live range -- i.e. to where they are needed, and the L2 round trip of the
+  // weights is exposed in every slice (the first version of this probe: 0.61 PF).
+#pragma unroll 1
   for (int ch = 0; ch < nchunk; ++ch) {
     const int buf = ch & 1;
     load_chunk(ch + 1);                         // in flight under this chunk's 8 slices
+    load_a(S0{}, buf, 0);
     const int ks0 = ch * (KC / 32);
 #pragma unroll
     for (int q = 0; q < KC / 32; q += 2) {
       load_w(S1{}, ks0 + q + 1);
-      slice(buf, q, S0{});
-      load_w(S0{}, ks0 + q + 2);
-      slice(buf, q + 1, S1{});
+      load_a(S1{}, buf, q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S0{});
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(S0{}, ks0 + q + 2);                // (q + 2 == 8: slice 0 of the next chunk)
+      if (q + 2 < KC / 32) load_a(S0{}, buf, q + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S1{});
+      __builtin_amdgcn_sched_barrier(0);
     }
     store_chunk(buf ^ 1);                       // the other buffer was last read in the previous iteration, before its barrier
     __syncthreads();
@@ -156,17 +174,16 @@ __global__ __launch_bounds__(512) void conv_chain_kernel(ConvP p) {
     if (acc[0][0][0] == 123.456f) p.out[0] = acc[3][3][3];
     return;
   }
-  // accumulator map: column = lane & 15, row = 4 (lane >> 4) + e
+  // accumulator map (swapped operands): row = lane & 15 of the 16-row tile, columns 4 (lane >> 4) .. + 3 of the 16-column tile
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < 4; ++t) {
+    const int m = row0 + t * 16 + li;
+    if (m < M) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int m = row0 + t * 16 + lg * 4 + e;
-      if (m < M) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) p.out[(size_t)m * NOUT + wave * 64 + c * 16 + li] = acc[t][c][e] * p.unscale;
-      }
+      for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<f32x4*>(p.out + (size_t)m * NOUT + wave * 64 + c * 16 + lg * 4) = acc[t][c] * p.unscale;
     }
+  }
 }
 
 // fp64 direct convolution of the same split operands: out[m][n] = sum_tap sum_c (hi + lo)(src) (whi + wlo)(k, n)
