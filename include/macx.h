@@ -500,7 +500,11 @@ int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, ui
  *          chain kernel, S_b of all steps in one launch at the end of the backward pass
  *   key 6  0 (default): every launch on the caller's stream; 1..3: the backward pass's dKB contraction runs per step on an internal
  *          queue (lowest / highest / middle priority), forked from and joined to the caller's stream by events (still
- *          stream-ordered for the caller) -- measured slower, kept for the A/B */
+ *          stream-ordered for the caller) -- measured slower, kept for the A/B; 4: the per-step dW2 contraction as a right-sized grid
+ *          beside the chain kernels (also slower)
+ *   key 7  K-loop variant of the chain kernels (-1 = default)      key 8  0: the 128 x 128 S_b kernel instead of the 128 x 256 one
+ *   key 9  0: the stem's 3 x 3 convolutions on kb_gemm3h_kernel; 1 (default): on kb_conv_chain_kernel where the shape allows
+ *          (512 output channels, input channels a multiple of 256) */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

@@ -2744,6 +2744,7 @@ int macx_debug_set(int key, int value) {
   if (key == 6 && value >= 0 && value <= 4) { overlap_mode() = value; return MACX_OK; }
   if (key == 7 && value >= -1 && value <= 63) { chain_kv() = value; return MACX_OK; }
   if (key == 8 && (value == 0 || value == 1)) { sb_wide_mode() = value; return MACX_OK; }
+  if (key == 9 && (value == 0 || value == 1)) { conv_chain_mode() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

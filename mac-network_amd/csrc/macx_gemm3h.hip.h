@@ -272,8 +272,192 @@ inline hipError_t kb_gemm3h_launch_rt(const GemmP& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The 3 x 3 convolution on the chain kernels' structure (round 4, measured first as tools/probes/conv_chain_probe.hip: 366 / 183 us
+// for the stem's two convolutions at B = 64 against kb_gemm3h_kernel's 440 / 214).  Same operands, same results' meaning and
+// the same epilogue code as kb_gemm3h_kernel<RT, A_PLAIN, B_PLAIN, EP, false> -- fp32 halo-padded A, one exponent per operand
+// tensor, format-3 weights, kb_epilogue_rows -- but
+//   * a workgroup owns 64 rows of the FLATTENED [B N] output x ALL 512 columns (wave w: columns 64 w .. 64 w + 63), so the fp16
+//     split of A is done once per element instead of once per 128-column block;
+//   * A goes through LDS in chunks of 256 channels of one tap (64 KB, two buffers): ONE barrier per 384 MFMAs of a wave;
+//   * the weights go from L2 straight into MFMA operand registers, one 32-wide slice ahead, and the order "request slice q + 1,
+//     multiply slice q" is pinned with sched_barrier (left alone the scheduler sinks the loads to their first use: 0.61 PF
+//     instead of 0.97 in the probe);
+//   * operands swapped (D^T = W^T A^T): a lane ends up with four consecutive columns of a row.
+// Shapes: conv_taps == 9, Nout == 512, conv_cin a multiple of 256.  macx_debug_set(9, 0) / MACX_STEM_CHAIN=0 keep kb_gemm3h_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CC_ROWS = 64, CC_NOUT = 512, CC_KC = 256, CC_KG = CC_KC / 8;
+constexpr int CC_BUF = 2 * CC_KG * CC_ROWS * 16;                 // [plane][k group][row] x 16 B
+constexpr int CC_LDT = 128 + 4;
+constexpr int CC_EPI = 4 * CC_ROWS * CC_LDT * 4;                // four 64 x 128 epilogue tiles
+constexpr int CC_LDS = 2 * CC_BUF > CC_EPI ? 2 * CC_BUF : CC_EPI;
+inline int& conv_chain_mode() { static int m = 1; return m; }
+
+template <int EP>
+__global__ __launch_bounds__(512) void kb_conv_chain_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int M = p.B * p.N;
+  const int row0 = blockIdx.x * CC_ROWS;
+  const int cpt = p.conv_cin / CC_KC;               // chunks per tap
+  const int nchunk = 9 * cpt;
+  const int nks = p.K >> 5;
+
+  const int eA = h2_exponent(*p.a_maxabs);
+  const int eW = *(reinterpret_cast<const int*>(p.Wp) + (size_t)p.K * p.Nout);
+  const float a_scale = h2_pow2(eA);
+  const float unscale = h2_unscale(eA, eW);
+
+  // ---- loader: slot s = tid + 512 i (i < 4) of a chunk = (16-row tile s >> 6 & 3, k quad s >> 8, lane = 16 g + row): 8 channels of
+  //      one row, fp32 in, split to both planes while it is stored
+  constexpr int A_IT = CC_ROWS * CC_KG / 512;       // 4
+  const float* a_src[A_IT];
+  int a_dst[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int s = tid + 512 * i;
+    const int blk = s >> 6;
+    const int rt = blk & 3, kq = blk >> 2;
+    const int row = rt * 16 + li, kg = kq * 4 + lg;
+    const int m = min(row0 + row, M - 1);           // rows past the end re-read the last row (the epilogue does not store them)
+    const int b = m / p.N, n = m - b * p.N;
+    const int srow = (n / p.conv_w + 1) * p.conv_wp + (n % p.conv_w) + 1;
+    a_src[i] = p.A + (size_t)b * p.a_qstride + (size_t)srow * p.lda + kg * 8;
+    a_dst[i] = (kg * CC_ROWS + row) * 16;
+  }
+  f32x4 ra[A_IT][2];
+  auto load_chunk = [&](int ch_raw) __attribute__((always_inline)) {
+    const int ch = min(ch_raw, nchunk - 1);
+    const int tap = ch / cpt, cc = ch - tap * cpt;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int shift = p.conv_sign * (dy * p.conv_wp + dx) * p.lda + cc * CC_KC;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      ra[i][0] = *reinterpret_cast<const f32x4*>(a_src[i] + shift);
+      ra[i][1] = *reinterpret_cast<const f32x4*>(a_src[i] + shift + 4);
+    }
+  };
+  auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ra[i][e >> 2][e & 3] * a_scale;
+      u32x4 s0, s1;
+      h2_split8(x, s0, s1);
+      char* d = lds + buf * CC_BUF + a_dst[i];
+      *reinterpret_cast<u32x4*>(d) = s0;
+      *reinterpret_cast<u32x4*>(d + CC_KG * CC_ROWS * 16) = s1;
+    }
+  };
+
+  // ---- weights (pack format 3: [32-wide slice][plane][k group][Nout] x 16 B): lane (i = li, g = lg) holds k = 8 g .. 8 g + 7 of
+  //      column i of each of the wave's four 16-column tiles, both planes
+  u32x4 wb[2][2][4], aq[2][2][4];          // [set][plane][tile]
+  auto load_w = [&](auto set_c, int ks_raw) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    const int ks = min(ks_raw, nks - 1);
+    const char* src = reinterpret_cast<const char*>(p.Wp) + ((((size_t)ks * 2) * 4 + lg) * CC_NOUT + wave * 64 + li) * 16;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wb[SET][pl][c] = *reinterpret_cast<const u32x4*>(src + ((size_t)pl * 4 * CC_NOUT + c * 16) * 16);
+  };
+  auto load_a = [&](auto set_c, int buf, int q) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    const char* sA = lds + buf * CC_BUF + ((q * 4 + lg) * CC_ROWS + li) * 16;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) aq[SET][pl][t] = *reinterpret_cast<const u32x4*>(sA + pl * (CC_KG * CC_ROWS * 16) + t * 256);
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mm = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[t][c] = mfma_f16(wb[SET][0][c], aq[SET][1][t], acc[t][c]);     // w_hi a_lo
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[t][c] = mfma_f16(wb[SET][1][c], aq[SET][0][t], acc[t][c]);     // w_lo a_hi
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[t][c] = mfma_f16(wb[SET][0][c], aq[SET][0][t], acc[t][c]);     // w_hi a_hi
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  load_chunk(0);
+  load_w(S0{}, 0);
+  store_chunk(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    load_chunk(ch + 1);                         // in flight under this chunk's 8 slices
+    load_a(S0{}, buf, 0);
+    const int ks0 = ch * (CC_KC / 32);
+#pragma unroll
+    for (int q = 0; q < CC_KC / 32; q += 2) {
+      load_w(S1{}, ks0 + q + 1);
+      load_a(S1{}, buf, q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S0{});
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(S0{}, ks0 + q + 2);                // (q + 2 == 8: slice 0 of the next chunk)
+      if (q + 2 < CC_KC / 32) load_a(S0{}, buf, q + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S1{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    store_chunk(buf ^ 1);                       // the other buffer was last read in the previous iteration, before its barrier
+    __syncthreads();
+  }
+
+  // ---- epilogue: the four 64 x 128 column blocks as row-major LDS tiles (the loop's buffers are idle), then the epilogue code of the
+  //      other GEMM kernels on each, with the batch seen as ONE image of B N rows (orow = n)
+  //      accumulator map (swapped operands): row = 16 t + (lane & 15), columns 16 c + 4 (lane >> 4) .. + 3 of the wave's 64
+  float* T = smem + (wave >> 1) * (CC_ROWS * CC_LDT);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<f32x4*>(T + (t * 16 + li) * CC_LDT + (wave & 1) * 64 + c * 16 + lg * 4) = acc[t][c] * unscale;
+  __syncthreads();
+  GemmP q = p;
+  q.N = M; q.B = 1;
+  const int row_end = min(M, row0 + CC_ROWS);
+#pragma unroll 1
+  for (int cb = 0; cb < 4; ++cb)
+    kb_epilogue_rows<4, 8, EP, false>(q, smem + cb * (CC_ROWS * CC_LDT), 0, cb, 0, 1, row0, row_end);
+}
+
+template <int EP>
+inline hipError_t kb_conv_chain_launch(const GemmP& p, hipStream_t st) {
+  auto kern = kb_conv_chain_kernel<EP>;
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), (size_t)CC_LDS);
+    if (e != hipSuccess) return e;
+  }
+  GemmP q = p;
+  q.dbg = kb_gemm_dbg();
+  hipLaunchKernelGGL(kern, dim3((p.B * p.N + CC_ROWS - 1) / CC_ROWS), dim3(512), CC_LDS, st, q);
+  return hipGetLastError();
+}
+
 template <int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm3h_launch(const GemmP& p, hipStream_t st) {
+  if constexpr (AP == A_PLAIN && BP == B_PLAIN && !COLSUM && (EP == E_BIAS_ACT || EP == E_MUL_DACT)) {
+    if (conv_chain_mode() && p.conv_taps == 9 && p.Nout == CC_NOUT && p.conv_cin % CC_KC == 0 && p.K == 9 * p.conv_cin)
+      return kb_conv_chain_launch<EP>(p, st);
+  }
   switch (kb_gemm_pick_rt(p.N, p.B, p.Nout / 128)) {
     case 1: return kb_gemm3h_launch_rt<1, AP, BP, EP, COLSUM>(p, st);
     case 2: return kb_gemm3h_launch_rt<2, AP, BP, EP, COLSUM>(p, st);

@@ -30,6 +30,8 @@ def macx():
         m._lib.lib().macx_debug_set(4, int(os.environ["MACX_CHAIN"]))
     if os.environ.get("MACX_SB_DEFER"):     # 0: the S_b contraction once per step
         m._lib.lib().macx_debug_set(5, int(os.environ["MACX_SB_DEFER"]))
+    if os.environ.get("MACX_STEM_CHAIN"):   # 0: the stem's convolutions on kb_gemm3h_kernel instead of kb_conv_chain_kernel
+        m._lib.lib().macx_debug_set(9, int(os.environ["MACX_STEM_CHAIN"]))
     if os.environ.get("MACX_CHAIN_KV"):     # K-loop variant of the chain kernels (macx_chain_h2.hip.h: ChainCtx::kloop)
         m._lib.lib().macx_debug_set(7, int(os.environ["MACX_CHAIN_KV"]))
     if os.environ.get("MACX_SB_WIDE"):      # 0: the deferred S_b contraction on the 128 x 128 kernel
