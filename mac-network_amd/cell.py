@@ -409,10 +409,13 @@ class _PaddedParams:
 class PaddedMACCell:
     """MACCell for memDim == ctrlDim == attDim == d with d % 128 != 0 (d % 8 == 0): the cell runs dp = ceil(d / 128) * 128 wide
     on zero-padded weights, biases and inputs (macx_shapes.d_logical = d).  Padded columns stay exact zeros through every
-    linear layer (zero weights, zero bias), activation (act(0) = 0; the gate's sigmoid(0) = 0.5 mixes two zeros), attention
-    logit (zero terms of a dot product) and gradient, and the kernels take the dropout element index at the LOGICAL width, so
-    states, attentions and gradients are those of the unpadded cell with the unpadded cell's masks.  Same interface as MACCell;
-    states and histories come back d wide."""
+    linear layer (zero weights, zero bias), every unit activation config.py offers (NON / RELU in its --relu variants / TANH:
+    act(0) = 0; the gate's sigmoid(0) = 0.5 mixes two zeros), attention logit (zero terms of a dot product) and gradient, and
+    the kernels take the dropout element index at the LOGICAL width, so states, attentions and gradients are those of the
+    unpadded cell with the unpadded cell's masks.  A unit activation of SIGMOID (ops.activations has it, config.py's choices do
+    not) would put 0.5 into the padded columns of H1 / the memory -- harmless after slicing, but no longer 'exact zeros' and a
+    different H2 row exponent than the unpadded cell's: refused here (UnsupportedOptions) rather than run untested.  Same
+    interface as MACCell; states and histories come back d wide."""
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
@@ -424,6 +427,9 @@ class PaddedMACCell:
         if gemm not in (None, "h2"):
             raise UnsupportedOptions("gemm=%r: a cell whose width is not a multiple of 128 runs zero-padded on the H2 kernel family only" % (gemm,))
         gemm = "h2"
+        for o in ("controlInputAct", "controlContAct", "readMemAct", "readCtrlAct", "writeMemAct"):
+            if str(get(config, o)).upper() == "SIGMOID":
+                raise UnsupportedOptions("%s=SIGMOID on a zero-padded width: sigmoid(0) = 0.5 would fill the padded columns" % o)
         self.config = config
         d = self.d = int(get(config, "memDim"))
         dp = self.dp = (d + 127) // 128 * 128

@@ -236,10 +236,9 @@ class TowerBuckets:
             return                                    # this backward pass got a buffer of its own: everything goes late
         if any(t.grad is None for t in self._tensors[:self.n_out]):
             return                                    # the classifier's gradients are not there yet (unusual graph): all late
-        self._gather(0, self.n_out)
         if not self._active():
-            self._early_started = True
-            return
+            return                                    # single process: allreduce_ gathers and scales the WHOLE buffer (like OverlappedBuckets)
+        self._gather(0, self.n_out)
         part = self.flat[:self.early]
         cur = torch.cuda.current_stream(self.flat.device) if self.side is not None else None
         if self.side is not None:

@@ -50,11 +50,16 @@ class FlatAdamEMA:
         """flat_grad: an already flat gradient in THIS layout -- the parameters in order, each segment padded to a multiple of
         4 floats: dp.GradBucket.flat / TowerBuckets.flat after the all-reduce, or MACCellParams.grad_buffer() for a cell-only
         optimizer built with grad_owner= (without a registered consumer the backward pass does not write into that buffer: a
-        stale or zero gradient would be stepped on -- refused below).  A buffer of any other size is rejected.  Without
+        stale or zero gradient would be stepped on -- refused below; a dp bucket over the parameters is such a consumer).  A buffer of any other size is rejected.  Without
         flat_grad the .grad of every parameter is gathered."""
         if flat_grad is not None and self.grad_owner is None and getattr(flat_grad, "_macx_cell_grad_buffer", False):
-            raise ValueError("this is a MACCellParams.grad_buffer(): build the optimizer with grad_owner=params so that the backward "
-                             "pass writes into it")
+            # the buffer is only ever written for a REGISTERED consumer: a dp bucket built over it (GradBucket(params=...),
+            # OverlappedBuckets) is one, and hands its `flat` -- this very tensor -- over after the exchange
+            owner = getattr(flat_grad, "_macx_cell_grad_owner", None)
+            owner = owner() if owner is not None else None
+            if owner is None or not getattr(owner, "_grad_flat_registered", False):
+                raise ValueError("this is a MACCellParams.grad_buffer() nobody is registered for: build the optimizer with "
+                                 "grad_owner=params (or a dp bucket over the parameters) so that the backward pass writes into it")
         if flat_grad is None:
             for p, k, off in zip(self.params, self.sizes, self.offsets):
                 if p.grad is None:

@@ -1,6 +1,7 @@
 """Parameters of the MAC cell, stored in the layouts the kernels read and exposed under the
 reference's TF variable names for checkpoint import/export."""
 import math
+import weakref
 
 import torch
 
@@ -126,7 +127,8 @@ class MACCellParams(torch.nn.Module):
         buf = getattr(self, "_grad_flat", None)
         if buf is None or buf.numel() != n or buf.device != dev:
             buf = torch.zeros(n, dtype=torch.float32, device=dev)
-            buf._macx_cell_grad_buffer = True          # optim.FlatAdamEMA.step refuses it from an optimizer that is not its consumer
+            buf._macx_cell_grad_buffer = True          # optim.FlatAdamEMA.step refuses it while NOBODY is registered as its consumer
+            buf._macx_cell_grad_owner = weakref.ref(self)
             object.__setattr__(self, "_grad_flat", buf)
         return buf
 

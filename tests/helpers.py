@@ -63,7 +63,7 @@ class relu_boundary:
 
 
 # ---- observed parity errors: every GPU parity test reports (key, error) here; the session writes them to
-# gpurun_out/parity_margins.json (copied to profiles/r03_parity_margins.json), and a key that has a committed record must stay
+# gpurun_out/parity_margins.json (copied to profiles/rNN_parity_margins.json; the newest one is the record), and a key that has a committed record must stay
 # within 3x of it (floor 2e-6: below that run-to-run differences of the box, not of the code, decide)
 _MARGINS = {}
 _BASELINE = None
@@ -72,10 +72,11 @@ _BASELINE = None
 def _baseline():
     global _BASELINE
     if _BASELINE is None:
-        import json, os
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_parity_margins.json")
+        import glob, json, os
+        # the NEWEST committed record (profiles/rNN_parity_margins.json, highest NN)
+        paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r[0-9][0-9]_parity_margins.json")))
         try:
-            _BASELINE = json.load(open(path))["errors"]
+            _BASELINE = json.load(open(paths[-1]))["errors"]
         except Exception:
             _BASELINE = {}
     return _BASELINE

@@ -164,6 +164,56 @@ def test_flat_optimizer_on_the_cells_gradient_buffer(macx, dev):
     a, _ = train(False)
     b, prm = train(True)
     assert torch.equal(a, b)
-    other = macx.optim.FlatAdamEMA(macx.MACCellParams(cfg, p).to(dev).tensors())
+    # a grad_buffer() NOBODY registered for is refused (the backward pass would not have written into it)
+    orphan = macx.MACCellParams(cfg, p).to(dev)
+    other = macx.optim.FlatAdamEMA(orphan.tensors())
     with pytest.raises(ValueError):
-        other.step(flat_grad=prm.grad_buffer())
+        other.step(flat_grad=orphan.grad_buffer())
+
+
+@pytest.mark.parametrize("kind", ["bucket", "overlapped"])
+def test_flat_optimizer_takes_a_cell_buckets_flat_buffer(macx, dev, kind):
+    """The documented cell-only data-parallel flow: bucket = GradBucket(params=prm) / OverlappedBuckets(prm) is the registered
+    consumer of prm.grad_buffer(), bucket.flat IS that buffer, and FlatAdamEMA(prm.tensors()).step(flat_grad=bucket.flat) steps on
+    it (round 4's guard refused the tagged tensor).  Two steps == the gather path."""
+    B, S, N, d, p = 4, 6, 33, 128, 2
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=d, ctrlDim=d, attDim=d)
+    vq, words, lengths, kb = [t.to(dev) for t in macx.configs.synthetic_inputs(B, S, N, d, seed=3)]
+
+    def train(flat):
+        params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(7)).to(dev)
+        bucket = None
+        if flat:
+            bucket = macx.dp.GradBucket(params.tensors(), params=params) if kind == "bucket" else macx.dp.OverlappedBuckets(params)
+            assert bucket.flat.data_ptr() == params.grad_buffer().data_ptr()
+        opt = macx.optim.FlatAdamEMA(params.tensors(), lr=1e-2)
+        for i in range(2):
+            for t in params.tensors():
+                t.grad = None
+            cell = macx.MACCell(vq, words, words, lengths, kb, cfg.memoryDropout, cfg.readDropout, cfg.writeDropout, B, True,
+                                config=cfg, params=params, seed=5 + i)
+            if bucket is not None and kind == "overlapped":
+                bucket.begin_step(B, B)
+            cell.run().memory.square().sum().backward()
+            if bucket is not None:
+                bucket.allreduce_(B, B)
+                assert bucket.zero_copy_steps == i + 1
+            opt.step(flat_grad=bucket.flat if flat else None)
+        torch.cuda.synchronize()
+        return opt.flat.clone()
+
+    assert torch.equal(train(False), train(True))
+
+
+def test_tower_buckets_single_process_shard_weight(macx, dev):
+    """One process, shard != global (shard emulation): TowerBuckets must scale EVERY gradient by shard / global -- the classifier's
+    and the cell's early fields too (round 4 marked them 'already exchanged' in the phase-1 hook and left them unscaled)."""
+    net, data, Bg = _tower(macx, dev)
+    lo, hi = 1, 4
+    plain = _tower_step(net, data, dev, lo, hi, Bg)
+    bucket = macx.dp.TowerBuckets(net)
+    got = _tower_step(net, data, dev, lo, hi, Bg, bucket)
+    w = float(hi - lo) / float(Bg)
+    for a, b in zip(got, plain):
+        assert torch.allclose(a, b * w, rtol=1e-6, atol=1e-9)
+    assert all(t.grad.data_ptr() == bucket.flat.data_ptr() + 4 * o for t, o in zip(bucket.tensors(), bucket.offsets))

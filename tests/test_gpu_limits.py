@@ -56,6 +56,14 @@ def test_padded_cell_runs_on_the_h2_family_whatever_the_default(macx, dev):
         L.macx_gemm_mode(before)
 
 
+def test_padded_cell_refuses_a_sigmoid_unit_activation(macx, dev):
+    """sigmoid(0) = 0.5 would fill the padded columns (PaddedMACCell's 'exact zeros' argument does not hold): refused"""
+    cfg, vq, words, lengths, kb = make_case("args", 2, 5, 20, 144, 2, readMemAct="SIGMOID")
+    vqd, wd, kbd = [t.to(dev) for t in (vq, words, kb)]
+    with pytest.raises(macx.UnsupportedOptions):
+        macx.MACCell(vqd, wd, wd, lengths.to(dev), kbd, 0.85, 0.85, 1.0, 2, True, config=cfg, seed=3)
+
+
 @pytest.mark.parametrize("over", [dict(S=257), dict(N=1025), dict(p=33), dict(d=1152), dict(d=192), dict(B=0), dict(d=256, d_logical=100),
                                   dict(d=256, d_logical=132)])
 def test_first_size_past_each_limit_is_rejected(macx, over):

@@ -279,3 +279,27 @@ def test_bench_settle_and_best_block_logic(monkeypatch):
     def one(i):
         clock["t"] += next(seq)
     assert abs(bench.best_block(one, 4) - 3e-3) < 1e-12
+
+
+def test_bench_metric_blocks_report_the_median_and_the_spread(monkeypatch):
+    """bench.time_blocks / block_summary: the metric is METRIC_BLOCKS blocks of exactly K steps; value is the MEDIAN block, with
+    min / max / spread beside it; step indices run on across the blocks (fresh dropout masks per step)"""
+    import bench
+    clock = {"t": 0.0}
+    monkeypatch.setattr(bench.time, "perf_counter", lambda: clock["t"])
+    monkeypatch.setattr(bench.torch.cuda, "synchronize", lambda *a, **k: None)
+    per_block = [5e-3, 4e-3, 4.2e-3, 9e-3, 4.1e-3]
+    seen = []
+
+    def step(i):
+        seen.append(i)
+        n_timed = len(seen) - 6                      # 2 priming + 3 warmup steps come first
+        clock["t"] += per_block[max(n_timed, 0) // 10]
+
+    dts = bench.time_blocks(step, 10, 3, 2, lambda: None, 1, None, None, blocks=5)
+    assert seen == list(range(55))
+    assert [round(d / 10, 6) for d in dts] == per_block
+    med, info = bench.block_summary(dts, 10, 64)
+    assert abs(med / 10 - 4.2e-3) < 1e-12
+    assert info["ms_per_step_min"] == 4.0 and info["ms_per_step_max"] == 9.0 and info["blocks"] == 5
+    assert abs(info["spread"] - (9.0 - 4.0) / 4.2) < 1e-3
