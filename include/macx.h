@@ -367,6 +367,24 @@ int macx_h2_gemm(const float* A, int B, int N, int K, const float* W, int n_out,
  * family does not run on that kernel. */
 int macx_read_chain_time(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*, const macx_inputs*,
                          float* saved, size_t saved_floats, int step, int reps, float* ms_out, void* stream);
+/* One of the read unit's kept [B*N, d] activations of step `step`, as fp32 row-major, from the `saved` buffer of a forward pass with
+ * keep = 1: which = 0 dropout(KB) (ops.py:678), 1 X = dropout(KB) Wx + bx (ops.py:688), 2 H1 (ops.py:718, mac_cell.py:237), 3 I2
+ * (ops.py:326) -- whatever format the kernel family keeps them in (H2 planes in the default family).  Inspection and tests: the chain
+ * kernel's intermediate products are checked against fp64 through this.  out: [B*N][d] floats, 16-byte aligned. */
+int macx_saved_activation(const macx_opts*, const macx_shapes*, int which, int step, const float* saved, size_t saved_floats,
+                          float* out, void* stream);
+/* The control unit's question projections on their own (mac_cell.py:442-448; SURVEY 8b's `ctrl_inputs` unit):
+ *   fwd:  ctrl_t[B,d] = controlInputAct(vecQuestions Wq + bq);  ctrl_inputs[p,B,d]: step i = ctrl_t WqU_i + bqU_i (one matrix per
+ *         step with controlInputUnshared, else the shared one) -- the two launches macx_cell_begin issues for them;
+ *   bwd:  d_ctrl_inputs[p,B,d] -> d_vecQuestions[B,d] and the non-NULL ones of GP->qInput_W / qInput_b / qInputU_W / qInputU_b.
+ * Only the qInput / qInputU fields of macx_params / macx_param_grads are touched.  ws >= macx_ctrl_inputs_ws_floats() floats
+ * (packed weights and [B,d] temporaries; nothing survives from fwd to bwd in it -- pass ctrl_t back in). */
+size_t macx_ctrl_inputs_ws_floats(const macx_opts*, const macx_shapes*);
+int macx_ctrl_inputs_fwd(const macx_opts*, const macx_shapes*, const macx_params*, const float* vecQuestions, float* ctrl_t,
+                         float* ctrl_inputs, float* ws, size_t ws_floats, void* stream);
+int macx_ctrl_inputs_bwd(const macx_opts*, const macx_shapes*, const macx_params*, const float* vecQuestions, const float* ctrl_t,
+                         const float* d_ctrl_inputs, const macx_param_grads*, float* d_vecQuestions, float* ws, size_t ws_floats,
+                         void* stream);
 /* X = dropout(KB) @ Wx + bx: the projX half of ops.mul (ops.py:678,688) on the knowledge-base GEMM.
  * `W_packed` from macx_pack_weight(Wx, d, d, macx_gemm_mode(-1) ? MACX_PACK_BF16X3 : MACX_PACK_F32MFMA);
  * `drop_ws` >= B*N*d + B*N*d/32 floats of scratch for the dropped KB and its keep bits (may be NULL when keep_read == 1). */
@@ -487,7 +505,12 @@ int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint
 int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
                       const uint32_t* mask_word, float* out, void* stream);
 
-/* tuning hook for A/B measurements (never needed for correct results):
+/* tuning hook for A/B measurements (never needed for correct results).  PROCESS-GLOBAL DEBUG STATE, not part of the per-call
+ * contract: keys 4 - 10 are plain process-wide integers inside the library (read when a call is enqueued, not thread-safe against a
+ * concurrent macx_debug_set); the kernel FAMILY, the one selector a product caller may want per cell, travels per call in
+ * macx_opts.gemm_family.  No product code path writes them: mac-network_amd/ never calls macx_debug_set (asserted by
+ * tests/test_host.py::test_product_code_never_touches_the_debug_knobs); bench.py / tests / tools set them from MACX_* environment
+ * variables for A/B runs only.
  *   key 0  waves per workgroup of the NATIVE knowledge-base GEMM (4 | 8)
  *   key 1  bit mask of timing experiments / kernel selection:
  *            1 skip the GEMM epilogue, 2 skip the in-loop staging, 4 write-through output stores (unsafe: stale cross-XCD
@@ -504,7 +527,10 @@ int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, ui
  *          beside the chain kernels (also slower)
  *   key 7  K-loop variant of the chain kernels (-1 = default)      key 8  0: the 128 x 128 S_b kernel instead of the 128 x 256 one
  *   key 9  0: the stem's 3 x 3 convolutions on kb_gemm3h_kernel; 1 (default): on kb_conv_chain_kernel where the shape allows
- *          (512 output channels, input channels a multiple of 256) */
+ *          (512 output channels, input channels a multiple of 256)
+ *   key 10 the all-steps weight-gradient contractions (wgrad_h2_kernel<2,2>): 0 round 4's loop (a stage is requested one iteration
+ *          ahead); 1 a buffer's G / A halves are re-requested inside the iteration as soon as every wave has read them (two stages
+ *          in flight); 2 (default) = 1 + dW2 and dWx as ONE launch (grid.y = 2) */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

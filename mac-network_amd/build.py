@@ -52,9 +52,16 @@ def build(force=False, verbose=False):
            "-Wno-pass-failed", "-Wno-inline-asm", "-I", os.path.join(ROOT, "include")]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH]
+    # the register / spill / occupancy remarks of every kernel ride along (tools/kernel_resources.py --from-build reads them)
+    cmd += ["-Rpass-analysis=kernel-resource-usage"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    with open(os.path.join(LIB_DIR, "kernel_resources.raw"), "w") as fh:
+        fh.write(res.stderr)
+    if res.returncode != 0:
+        sys.stderr.write("\n".join(l for l in res.stderr.splitlines() if "remark:" not in l) + "\n")
+        raise subprocess.CalledProcessError(res.returncode, cmd)
     with open(STAMP, "w") as fh:
         fh.write(dig)
     return LIB_PATH

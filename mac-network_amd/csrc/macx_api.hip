@@ -312,7 +312,7 @@ struct BwdLayout {
   size_t tmp_dd;    // [d,d] scratch
   size_t act_floats;                 // floats of one [B,N,d] activation (H2 size in h2 mode)
   size_t ecom;                       // h2: [4][EMIN_NB][8] ints, partial minima of the row exponents of H1 / dI2 / KBd / dX over all steps
-  size_t wg_ftab;                    // h2: [d/128][d/128][Mpad] fp16 row factors of the deferred weight-gradient contractions
+  size_t wg_ftab, wg_ftab2;          // h2: [d/128][d/128][Mpad] fp16 row factors of the two deferred weight-gradient contractions
   // per-step dW2 on the side queue (overlap mode 4): exponent minima [p][2][EMIN_NB][8], row factors [p][d/128][d/128][Mpad(B N)], splits
   size_t ecom_s, ftab_s, ftab_s_stride, side_ns;
   size_t total;
@@ -385,6 +385,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.tmp_dd = take(d * d);
   L.ecom = take(4 * EMIN_NB * 8);
   L.wg_ftab = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
+  L.wg_ftab2 = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
   L.ecom_s = take(p * 2 * EMIN_NB * 8);
   L.ftab_s_stride = h2_mode() ? al4((d / 128) * (d / 128) * wgrad_h2_mpad(B * N) / 2 + 4) : 4;
   L.ftab_s = take(p * L.ftab_s_stride);
@@ -1691,13 +1692,15 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     t.ftab = reinterpret_cast<uint16_t*>(ws + W.wg_ftab);
     t.dbg = kb_gemm_dbg();
     t.part = ws + W.slab_w2;
-    if (!w2_side) CK(wgrad_h2_launch(t, st));
+    const TnH2P t_w2 = t;
     t.A = reinterpret_cast<const char*>(saved + L.KBd);
     t.a_mod = rdrop ? 0 : B * N;                              // no dropout: the same (converted) KB every step
     t.G = reinterpret_cast<const char*>(ws + W.dX);
     t.ecomA = ecom + 2 * ES; t.ecomG = ecom + 3 * ES;
     t.part = ws + W.slab_wx;
-    CK(wgrad_h2_launch(t, st));
+    t.ftab = reinterpret_cast<uint16_t*>(ws + W.wg_ftab2);    // (a table of its own: the pair form builds both before either is read)
+    if (w2_side) CK(wgrad_h2_launch(t, st));
+    else CK(wgrad_h2_launch_pair(t_w2, t, st));
   } else {
     TnP t;
     memset(&t, 0, sizeof(t));
@@ -2736,6 +2739,122 @@ int macx_read_chain_time(const macx_opts* o, const macx_shapes* s, const macx_dr
   return MACX_OK;
 }
 
+// ---- the control unit's question projections (mac_cell.py:442-448) behind a contract of their own -----------------
+//   t = act(vecQ Wq + bq)  [B,d]  (controlInputAct);   cI_i = t WqU_i + bqU_i  [p,B,d]  (one matrix per step with
+//   controlInputUnshared, else the same one p times) -- the two launches macx_cell_begin issues for them.
+size_t macx_ctrl_inputs_ws_floats(const macx_opts* o, const macx_shapes* s) {
+  if (!o || !s || s->d < 1 || s->B < 1 || s->p < 1) return 0;
+  const size_t dd = (size_t)s->d * s->d, Bd = (size_t)s->B * s->d, nU = o->control_input_unshared ? s->p : 1;
+  return (1 + nU) * dd + 3 * Bd + (size_t)wgrad_splits(s->B, s->d, s->d) * dd + 64;
+}
+
+int macx_ctrl_inputs_fwd(const macx_opts* o, const macx_shapes* s, const macx_params* P, const float* vecQuestions, float* ctrl_t,
+                         float* ctrl_inputs, float* ws, size_t ws_floats, void* stream) {
+  ModeScope ms(o);
+  CKI(check_impl(o, s));
+  if (!P || !vecQuestions || !ctrl_t || !ctrl_inputs || !ws || !P->qInput_W || !P->qInputU_W) return MACX_EINVAL;
+  if (misaligned(vecQuestions) || misaligned(ctrl_t) || misaligned(ctrl_inputs) || misaligned(ws)) return MACX_EINVAL;
+  if (ws_floats < macx_ctrl_inputs_ws_floats(o, s)) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, d = s->d, p = s->p;
+  const size_t dd = (size_t)d * d;
+  const int nU = o->control_input_unshared ? p : 1;
+  float* wq_p = ws;
+  float* wqU_p = ws + dd;
+  Packer pk;
+  pk.add(P->qInput_W, d, 1, d, d, wq_p);
+  for (int i = 0; i < nU; ++i) {
+    if (pk.n == PACK_MAX) CK(pk.run(st));
+    pk.add(P->qInputU_W + (size_t)i * dd, d, 1, d, d, wqU_p + (size_t)i * dd);
+  }
+  CK(pk.run(st));
+  LinP l = lin_basic(vecQuestions, d, d, B, wq_p, P->qInput_b, d, o->control_input_act, ctrl_t, d);
+  CK(small_linear_launch(l, 1, st));
+  LinP u = lin_basic(ctrl_t, d, d, B, wqU_p, P->qInputU_b, d, MACX_ACT_NON, ctrl_inputs, d);
+  if (o->control_input_unshared) { u.zW = dd; u.zb = d; }
+  u.zout = (size_t)B * d;
+  CK(small_linear_launch(u, p, st));
+  return MACX_OK;
+}
+
+// backward of the above: d_ctrl_inputs [p,B,d] -> d_vecQuestions [B,d] and the gradients of qInput / qInputU (the non-NULL fields of
+// `GP`: qInput_W [d,d], qInput_b [d], qInputU_W [nU,d,d], qInputU_b [nU,d]) -- the arithmetic of the cell's backward pass for this
+// unit (SURVEY appendix A rows "qInput", "qInput{i}"): dt = sum_i dcI_i WqU_i^T, du = dt * act'(t), dvecQ = du Wq^T.
+int macx_ctrl_inputs_bwd(const macx_opts* o, const macx_shapes* s, const macx_params* P, const float* vecQuestions, const float* ctrl_t,
+                         const float* d_ctrl_inputs, const macx_param_grads* GP, float* d_vecQuestions, float* ws, size_t ws_floats,
+                         void* stream) {
+  ModeScope ms(o);
+  CKI(check_impl(o, s));
+  if (!P || !vecQuestions || !ctrl_t || !d_ctrl_inputs || !GP || !d_vecQuestions || !ws || !P->qInput_W || !P->qInputU_W) return MACX_EINVAL;
+  if (misaligned(vecQuestions) || misaligned(ctrl_t) || misaligned(d_ctrl_inputs) || misaligned(d_vecQuestions) || misaligned(ws)) return MACX_EINVAL;
+  if (ws_floats < macx_ctrl_inputs_ws_floats(o, s)) return MACX_ESMALL;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, d = s->d, p = s->p;
+  const size_t dd = (size_t)d * d, Bd = (size_t)B * d;
+  const int nU = o->control_input_unshared ? p : 1;
+  float* wqT = ws;
+  float* wqUT = wqT + dd;
+  float* dt = wqUT + (size_t)nU * dd;
+  float* du = dt + Bd;
+  float* dsum = du + Bd;
+  float* slab = dsum + Bd;
+  Packer pk;
+  pk.add(P->qInput_W, 1, d, d, d, wqT);
+  for (int i = 0; i < nU; ++i) {
+    if (pk.n == PACK_MAX) CK(pk.run(st));
+    pk.add(P->qInputU_W + (size_t)i * dd, 1, d, d, d, wqUT + (size_t)i * dd);
+  }
+  CK(pk.run(st));
+  if (o->control_input_unshared) {
+    LinP li = lin_basic(d_ctrl_inputs, d, d, B, wqUT, nullptr, d, MACX_ACT_NON, dt, d);
+    li.Ktot = p * d;
+    li.rep_stride = Bd;
+    CK(small_linear_launch(li, 1, st));
+    if (GP->qInputU_W)
+      for (int i = 0; i < p; ++i)
+        CKI(wgrad_impl(ctrl_t, d, d_ctrl_inputs + (size_t)i * Bd, d, B, d, d, GP->qInputU_W + (size_t)i * dd, slab, st));
+    CK(rowsum(d_ctrl_inputs, B, d, d, GP->qInputU_b, st, p, Bd, d));
+  } else {
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(256), dim3(256), 0, st, d_ctrl_inputs, p, Bd, dsum);
+    CK(hipGetLastError());
+    LinP ls = lin_basic(dsum, d, d, B, wqUT, nullptr, d, MACX_ACT_NON, dt, d);
+    CK(small_linear_launch(ls, 1, st));
+    if (GP->qInputU_W) CKI(wgrad_impl(ctrl_t, d, dsum, d, B, d, d, GP->qInputU_W, slab, st));
+    CK(rowsum(dsum, B, d, d, GP->qInputU_b, st));
+  }
+  hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, (const float*)dt, ctrl_t, o->control_input_act, Bd, du);
+  CK(hipGetLastError());
+  LinP l = lin_basic(du, d, d, B, wqT, nullptr, d, MACX_ACT_NON, d_vecQuestions, d);
+  CK(small_linear_launch(l, 1, st));
+  if (GP->qInput_W) CKI(wgrad_impl(vecQuestions, d, du, d, B, d, d, GP->qInput_W, slab, st));
+  CK(rowsum(du, B, d, d, GP->qInput_b, st));
+  return MACX_OK;
+}
+
+// One of the read unit's kept [B*N, d] activations of step `step` as fp32 row-major: which = 0 dropout(KB) (ops.py:678), 1 X
+// (ops.py:688), 2 H1 (ops.py:718), 3 I2 (ops.py:326) -- what the forward pass left in `saved` (keep = 1) for the backward pass,
+// whatever format the kernel family keeps it in (H2 planes in the default family).  Inspection / tests: the chain kernel's
+// intermediate products are checked against fp64 through this (tests/test_gpu_h2.py).
+int macx_saved_activation(const macx_opts* o, const macx_shapes* s, int which, int step, const float* saved, size_t saved_floats,
+                          float* out, void* stream) {
+  ModeScope ms(o);
+  CKI(check_impl(o, s));
+  if (!saved || !out || which < 0 || which > 3 || step < 0 || step >= s->p || misaligned(out)) return MACX_EINVAL;
+  const SavedLayout L = make_saved(o, s, 1);
+  if (saved_floats < L.total) return MACX_ESMALL;
+  const size_t base = which == 0 ? L.KBd : (which == 1 ? L.X : (which == 2 ? L.H1 : L.I2));
+  const float* src = saved + base + (size_t)step * L.act_stride;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t R = (size_t)s->B * s->N;
+  if (h2_mode()) {
+    hipLaunchKernelGGL(h2_to_f32_kernel, dim3(1024), dim3(256), 0, st, h2_view(src, (int)R, s->d), out);
+    CK(hipGetLastError());
+  } else {
+    CK(dev_copy(out, src, R * s->d * sizeof(float), st));
+  }
+  return MACX_OK;
+}
+
 int macx_debug_set(int key, int value) {
   if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }
   if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
@@ -2745,6 +2864,7 @@ int macx_debug_set(int key, int value) {
   if (key == 7 && value >= -1 && value <= 63) { chain_kv() = value; return MACX_OK; }
   if (key == 8 && (value == 0 || value == 1)) { sb_wide_mode() = value; return MACX_OK; }
   if (key == 9 && (value == 0 || value == 1)) { conv_chain_mode() = value; return MACX_OK; }
+  if (key == 10 && value >= 0 && value <= 2) { wgrad_pipe_mode() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

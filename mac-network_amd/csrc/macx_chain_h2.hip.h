@@ -76,8 +76,24 @@ __device__ __forceinline__ float row8_sum(float v) {
 // ELU inside the chain kernels: exp(x) - 1 on the negative side, without the cancellation-free polynomial of elu_f.  The
 // absolute error near zero (1 ulp of 1.0) is below what the value loses when it is stored as an H2 slot (2^-22 of the row
 // maximum) or summed into a logit, and the epilogues apply it to 64 values per lane.
+// tanh inside the chain kernels: libm's tanhf brought 100 spilled registers into stage B0 (64 values per lane at the 256-register
+// cap).  |x| < 0.3: the odd Taylor polynomial through x^9 (truncation 5e-8 relative); else 1 - 2 / (exp(2|x|) + 1) with the
+// hardware exponential and reciprocal (result >= 0.29: absolute error ~1 ulp of 1.0 -> <= 3e-7 relative).
+__device__ __forceinline__ float chain_tanh(float x) {
+  const float a = fabsf(x), x2 = x * x;
+  float r = 62.0f / 2835.0f;
+  r = fmaf(r, x2, -17.0f / 315.0f);
+  r = fmaf(r, x2, 2.0f / 15.0f);
+  r = fmaf(r, x2, -1.0f / 3.0f);
+  r = fmaf(r, x2, 1.0f);
+  r *= x;
+  const float e = __expf(2.0f * fminf(a, 20.0f));
+  const float t = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+  return a < 0.3f ? r : copysignf(t, x);
+}
 __device__ __forceinline__ float chain_act(int act, float x) {
   if (act == ACT_ELU) return x > 0.0f ? x : __expf(x) - 1.0f;
+  if (act == ACT_TANH) return chain_tanh(x);
   return act_apply(act, x);
 }
 
@@ -926,8 +942,8 @@ struct ChainBwdP {
   float* dy_part;           // [tiles][3][d] per question segment, like dc_part; null: not computed
 };
 
-// A2: readCtrlAct as a compile-time constant (ACT_ELU, what "RELU" means in the published configurations) or -1 = decided per
-// value at run time.  Two kernels rather than two arms in one: the arms met in one register allocation (86 spilled registers).
+// A2: readCtrlAct as a compile-time constant -- one kernel per activation (chain_bwd_launch_t); several arms in one kernel met in one
+// register allocation (two arms: 86 spilled registers; a per-value run-time switch: 102-104).
 template <int D_, int KV = 0, int A2 = -1, int R_ = 64>
 __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   using C = ChainCtx<D_, R_, (KV >> 4) & 1>;
@@ -1049,14 +1065,17 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
     };
     auto pass = [&](auto act_c) __attribute__((always_inline)) {
       constexpr int SBc = C::SB;                       // 8-row blocks of the tile: 8, 4 or 2
+      // row blocks requested ahead of their use: three.  (Two for the identity activation, whose allocation is 8 - 13 registers over
+      // the cap, was tried: 45 spilled registers -- the shorter body lets the scheduler hoist more of the next blocks' arithmetic.)
+      constexpr int PFD = 3;
       fetch(std::integral_constant<int, 0>{});
       if constexpr (SBc > 1) fetch(std::integral_constant<int, 1>{});
-      if constexpr (SBc > 2) fetch(std::integral_constant<int, 2>{});
+      if constexpr (SBc > 2 && PFD > 2) fetch(std::integral_constant<int, 2>{});
       __builtin_amdgcn_sched_barrier(0);
       auto step = [&](auto sb_c) __attribute__((always_inline)) {
         constexpr int sb = decltype(sb_c)::value;
         if constexpr (sb < SBc) {
-          if constexpr (sb + 3 < SBc) fetch(std::integral_constant<int, sb + 3>{});
+          if constexpr (sb + PFD < SBc) fetch(std::integral_constant<int, sb + PFD>{});
           block(act_c, sb_c);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -1252,9 +1271,18 @@ inline hipError_t chain_bwd_launch_a(const ChainBwdP& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+// One kernel per readCtrlAct (round 5).  The run-time variant (A2 = -1: a per-value switch inside stage B0's 64-value body) met
+// every activation's code in one register allocation and spilled 102-104 VGPRs at every width -- `--relu STD`, TANH and NON
+// option sets ran a quarter of their step through scratch.  It is no longer instantiated.
 template <int D_, int KV = 0, int R_ = 64>
 inline hipError_t chain_bwd_launch_t(const ChainBwdP& p, hipStream_t st) {
-  return p.act2 == ACT_ELU ? chain_bwd_launch_a<D_, KV, ACT_ELU, R_>(p, st) : chain_bwd_launch_a<D_, KV, -1, R_>(p, st);
+  switch (p.act2) {
+    case ACT_ELU: return chain_bwd_launch_a<D_, KV, ACT_ELU, R_>(p, st);
+    case ACT_RELU: return chain_bwd_launch_a<D_, KV, ACT_RELU, R_>(p, st);
+    case ACT_TANH: return chain_bwd_launch_a<D_, KV, ACT_TANH, R_>(p, st);
+    case ACT_SIGMOID: return chain_bwd_launch_a<D_, KV, ACT_SIGMOID, R_>(p, st);
+    default: return chain_bwd_launch_a<D_, KV, ACT_NON, R_>(p, st);
+  }
 }
 
 inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
@@ -1268,16 +1296,17 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
         case 32: return chain_bwd_launch_t<512, 0, 32>(p, st);
         default: break;
       }
+      // the measurement variants of the K loop exist for the published configurations' activation (ELU) only
+      if (p.act2 != ACT_ELU) return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
       switch (p.dbg >> 3) {
-        case 1: return chain_bwd_launch_t<512, 1>(p, st);
-        case 3: return chain_bwd_launch_t<512, 3>(p, st);
+        case 1: return chain_bwd_launch_a<512, 1, ACT_ELU>(p, st);
+        case 3: return chain_bwd_launch_a<512, 3, ACT_ELU>(p, st);
         default: break;
       }
       switch (chain_kv()) {
-        case 0: return chain_bwd_launch_t<512, 0>(p, st);
-        case 4: return chain_bwd_launch_t<512, 4>(p, st);
-        case 20: return chain_bwd_launch_t<512, 20>(p, st);
-        default: return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
+        case 0: return chain_bwd_launch_a<512, 0, ACT_ELU>(p, st);
+        case 20: return chain_bwd_launch_a<512, 20, ACT_ELU>(p, st);
+        default: return chain_bwd_launch_a<512, CHAIN_KV_DEFAULT, ACT_ELU>(p, st);
       }
     default: return hipErrorInvalidValue;
   }

@@ -256,7 +256,8 @@ template <int KW, int JW> constexpr int wh_stage_bytes() { return 2 * (KW + JW) 
 template <int KW, int JW> constexpr int wh_ring() { return KW + JW == 4 ? 2 : (KW + JW == 3 ? 3 : 4); }
 
 // one thread per reduction row: the fp16 factor of every (A block, G block) pair
-__global__ __launch_bounds__(256) void wgrad_h2_factors_kernel(TnH2P p) {
+__global__ __launch_bounds__(256) void wgrad_h2_factors_kernel(TnH2P p0, TnH2P p1) {
+  const TnH2P& p = blockIdx.y ? p1 : p0;             // grid.y = 2: the tables of two contractions in one launch
   __shared__ int sE[2][8];
   if (threadIdx.x < 16) {
     const int w = threadIdx.x >> 3, k = threadIdx.x & 7;
@@ -289,8 +290,23 @@ __device__ __forceinline__ void dma4b(const char* g, char* lds_wave_base) {     
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l) : "memory", "m0");
 }
 
-template <int KW, int JW>
-__global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
+// PIPE = 1 (KW = JW = 2 only, round 5): the same two-buffer ring, but a buffer's halves are re-requested as soon as the waves are
+// done with them instead of one iteration later.  compute() reads ALL of a stage's G fragments into registers first and the A planes
+// one after the other, so inside iteration s the G half of buffer s % 2 is free after the first few LDS reads and its A half after
+// a third of the products: the DMA of stage s + 2's G half is issued behind a barrier right there, the A half behind a second one.
+// Two stages (up to 128 KB per CU) are in flight instead of one, and a request has 1.7 - 2.0 iterations to land instead of one --
+// with RING = 2 the old loop had `vmcnt(0)` at the end of every iteration, i.e. every stage's full latency + transfer on the
+// critical path whenever it exceeded one iteration of products (round 4: 248 us against 134 compute-only / 146 DMA-only).
+// Same products in the same order: results are bit-identical to PIPE = 0.
+// 2 (default): PIPE = 1 and the two all-steps contractions of the backward pass as ONE launch (grid.y = 2); 1: PIPE = 1, one launch
+// each; 0: round 4's loop.  macx_debug_set(10, v): A/B in one process
+inline int& wgrad_pipe_mode() { static int m = 2; return m; }
+
+template <int KW, int JW, int PIPE = 0>
+__global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
+  // grid.y = 2: two contractions of the same shape in ONE launch (dW2 and dWx of the cell's backward pass): the second one's
+  // workgroups take the CUs the first one's free -- one ramp and one tail instead of two, one launch boundary less
+  const TnH2P& p = blockIdx.y ? p1 : p0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
   constexpr int KT = KW * T_TILE;
@@ -365,6 +381,38 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
     }
     if (wave == 0) dma4b(reinterpret_cast<const char*>(ft_src + m0), st + DATA);
   };
+  // PIPE: one half of a stage -- part 0 = the G planes + the factors (waves 4 - 7 and wave 0), part 1 = the A planes (waves 0 - 3)
+  auto issue_part = [&](int s_raw, int part) __attribute__((always_inline)) {
+    static_assert(!PIPE || (KW == 2 && JW == 2), "the split issue assumes waves 0-3 stage A and waves 4-7 stage G");
+    const int ch = min(s_raw, nchunk - 1);
+    const int m0 = m_begin + ch * 32;
+    const int mc = min(m0 + sl_m, p.M - 1);
+    const int ti = mc / p.R, rr = mc - ti * p.R;
+    char* st = lds + (s_raw % RING) * STAGE;
+    if (part == 1) {
+      if (wave < 4) {
+        const int ar = p.a_mod ? (mc % p.a_mod) : rr;
+        const char* ab = p.A + (p.a_mod ? 0 : (size_t)ti * p.a_stride);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int u = wave * NI + j;
+          const int pl = u / (8 * KW), ct = u - pl * 8 * KW;
+          dma16b(ab + pl * apb + ((size_t)(tk * 16 * KW + 2 * ct + sl_kg) * Rp + ar) * 16, st + pl * APL + ct * 1024);
+        }
+      }
+    } else {
+      if (wave >= 4) {
+        const char* gb = p.G + (size_t)ti * p.g_stride;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int ug = wave * NI + j - 16 * KW;
+          const int pl = ug / (8 * JW), ct = ug - pl * 8 * JW;
+          dma16b(gb + pl * gpb + ((size_t)(tj * 16 * JW + 2 * ct + sl_kg) * Rp + rr) * 16, st + 2 * APL + pl * GPL + ct * 1024);
+        }
+      }
+      if (wave == 0) dma4b(reinterpret_cast<const char*>(ft_src + m0), st + DATA);
+    }
+  };
   auto frag = [&](const char* tile) __attribute__((always_inline)) {       // the two row halves of one column tile
     const u32x2 lo = tr_read(tile + lane * 8), hi = tr_read(tile + 512 + lane * 8);
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -400,6 +448,59 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p) {
     }
   };
 
+  if constexpr (PIPE) {
+    if (nchunk > 0) {
+      const int my_n = NI + (wave == 0 ? 1 : 0);            // this wave's DMA instructions of ONE stage (its half + wave 0's factors)
+      issue(0);
+      issue(1);
+      wait_vmcnt_n(my_n);                                   // stage 0 has landed
+      __syncthreads();
+#pragma unroll 1
+      for (int s = 0; s < nchunk; ++s) {
+        const int buf = s & 1;
+        const char* sa = lds + buf * STAGE + (wr * NR) * 1024;
+        const char* sg = lds + buf * STAGE + 2 * APL + (wc * NC) * 1024;
+        const uint16_t* ft = reinterpret_cast<const uint16_t*>(lds + buf * STAGE + DATA) + (aq * JW + gq) * 32 + (lane >> 4) * 4;
+        const u32x2 f0 = *reinterpret_cast<const u32x2*>(ft), f1 = *reinterpret_cast<const u32x2*>(ft + 16);
+        u32x4 gf[2][NC];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            u32x4 w = frag(sg + pl * GPL + c * 1024);
+            w[0] = pk_mul_f16(w[0], f0[0]); w[1] = pk_mul_f16(w[1], f0[1]);
+            w[2] = pk_mul_f16(w[2], f1[0]); w[3] = pk_mul_f16(w[3], f1[1]);
+            gf[pl][c] = w;
+          }
+        __syncthreads();                                    // every wave holds its G fragments and factors: the G half is free
+        if (!(p.dbg & 2048)) issue_part(s + 2, 0);
+        u32x4 af[NR];
+#pragma unroll
+        for (int t = 0; t < NR; ++t) af[t] = frag(sa + APL + t * 1024);          // A lo
+        if (!(p.dbg & 1024)) {
+#pragma unroll
+          for (int t = 0; t < NR; ++t)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[t][c] = mfma_f16(af[t], gf[0][c], acc[t][c]);   // A_lo x G_hi
+        }
+#pragma unroll
+        for (int t = 0; t < NR; ++t) af[t] = frag(sa + t * 1024);                // A hi
+        __syncthreads();                                    // every wave holds its last A fragments: the A half is free
+        if (!(p.dbg & 2048)) issue_part(s + 2, 1);
+        if (!(p.dbg & 1024)) {
+#pragma unroll
+          for (int bp = 1; bp >= 0; --bp)
+#pragma unroll
+            for (int t = 0; t < NR; ++t)
+#pragma unroll
+              for (int c = 0; c < NC; ++c) acc[t][c] = mfma_f16(af[t], gf[bp][c], acc[t][c]);   // A_hi x G_lo, A_hi x G_hi
+        }
+        if (p.dbg & 2048) wait_vmcnt<0>(); else wait_vmcnt_n(my_n);              // stage s + 1 has landed (s + 2 may fly)
+        __syncthreads();
+      }
+      wait_vmcnt<0>();                                      // the speculative stages past the end
+    }
+  } else
   if (nchunk > 0) {
     const int my_n = (NI + (wave == 0 ? 1 : 0)) * (RING - 2);     // this wave's DMA instructions of the stages that may stay in flight
 #pragma unroll
@@ -448,24 +549,46 @@ inline int wgrad_h2_jw(int Jd) { return (Jd % 256 == 0) ? 2 : 1; }
 inline int wgrad_h2_kw(int Kd) { return (Kd % 256 == 0) ? 2 : 1; }
 inline int wgrad_h2_tiles(int Kd, int Jd) { return (Kd / (wgrad_h2_kw(Kd) * T_TILE)) * (Jd / (wgrad_h2_jw(Jd) * T_TILE)); }
 
-template <int KW, int JW>
+template <int KW, int JW, int PIPE = 0>
 inline hipError_t wgrad_h2_launch_t(const TnH2P& p, hipStream_t st) {
-  auto kern = wgrad_h2_kernel<KW, JW>;
+  auto kern = wgrad_h2_kernel<KW, JW, PIPE>;
   constexpr size_t lds = (size_t)wh_ring<KW, JW>() * wh_stage_bytes<KW, JW>();
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   const int grid = wgrad_h2_tiles(p.Kd, p.Jd) * p.nsplit;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, p);
+  return hipGetLastError();
+}
+// two contractions with the same M, Kd, Jd and split (own operands, tables and slabs) as one launch each of the factor and the
+// contraction kernel; wgrad_pipe_mode() < 2 or another tile shape: two launches each
+inline hipError_t wgrad_h2_launch(const TnH2P& p, hipStream_t st);
+inline hipError_t wgrad_h2_launch_pair(const TnH2P& a, const TnH2P& b, hipStream_t st) {
+  const bool same = a.M == b.M && a.Kd == b.Kd && a.Jd == b.Jd && a.nsplit == b.nsplit && a.rows_per_split == b.rows_per_split && a.R == b.R;
+  if (!(same && wgrad_pipe_mode() >= 2 && wgrad_h2_kw(a.Kd) == 2 && wgrad_h2_jw(a.Jd) == 2 && a.ftab != b.ftab && a.part != b.part)) {
+    hipError_t e = wgrad_h2_launch(a, st);
+    return e != hipSuccess ? e : wgrad_h2_launch(b, st);
+  }
+  if (a.rows_per_split % 32 != 0 || !a.ftab || !b.ftab) return hipErrorInvalidValue;
+  const size_t mpad = wgrad_h2_mpad((size_t)a.M);
+  hipLaunchKernelGGL(wgrad_h2_factors_kernel, dim3((unsigned)((mpad + 255) / 256), 2), dim3(256), 0, st, a, b);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  auto kern = wgrad_h2_kernel<2, 2, 1>;
+  constexpr size_t lds = (size_t)wh_ring<2, 2>() * wh_stage_bytes<2, 2>();
+  e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(wgrad_h2_tiles(a.Kd, a.Jd) * a.nsplit, 2), dim3(512), lds, st, a, b);
   return hipGetLastError();
 }
 inline hipError_t wgrad_h2_launch(const TnH2P& p, hipStream_t st) {
   if (p.rows_per_split % 32 != 0 || !p.ftab) return hipErrorInvalidValue;
   const size_t mpad = wgrad_h2_mpad((size_t)p.M);
-  hipLaunchKernelGGL(wgrad_h2_factors_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(wgrad_h2_factors_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, st, p, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int kw = wgrad_h2_kw(p.Kd), jw = wgrad_h2_jw(p.Jd);
-  if (kw == 2) return jw == 2 ? wgrad_h2_launch_t<2, 2>(p, st) : wgrad_h2_launch_t<2, 1>(p, st);
+  if (kw == 2 && jw == 2) return wgrad_pipe_mode() ? wgrad_h2_launch_t<2, 2, 1>(p, st) : wgrad_h2_launch_t<2, 2, 0>(p, st);
+  if (kw == 2) return wgrad_h2_launch_t<2, 1>(p, st);
   return jw == 2 ? wgrad_h2_launch_t<1, 2>(p, st) : wgrad_h2_launch_t<1, 1>(p, st);
 }
 

@@ -107,3 +107,69 @@ def test_h2_gemm_activation_and_determinism(macx, dev):
     ref = torch.nn.functional.elu(A.double().reshape(-1, K) @ W.double() + b.double())
     assert rel_err(outs[0], ref) < 2e-6
     assert torch.equal(outs[0], outs[1])
+
+
+def _wide(shape, g, span=12.0):
+    """N(0,1) entries times 2^u, u uniform in [-span, span], independently per ELEMENT: every exponent block (a row, a matrix, a
+    whole tensor) holds entries 2^(2 span) apart"""
+    return torch.randn(shape, generator=g) * torch.exp2((torch.rand(shape, generator=g) * 2 - 1) * span)
+
+
+@pytest.mark.parametrize("B,N,d", [(3, 196, 512), (2, 49, 256)])
+def test_chain_kernel_products_on_wide_dynamic_range(macx, dev, B, N, d):
+    """The chain kernels' coarser exponent granularities -- ONE exponent per ROW of d columns for the LDS-resident activation
+    tile, ONE per MATRIX for the packed weights (pack format 3) -- on data whose entries span 2^+-12 inside every such block
+    (they had only ever seen N(0,1)-scale data).  Stage 1 (X = KB Wx + bx) and stage 3 (I2 = H1 W2 + b2, with
+    the kept H1 as the operand the kernel multiplied) against fp64: error per unit of the row's largest sum |a w| + |b| below 1e-6
+    and at most 1.5x the native v_mfma_f32_16x16x4_f32 kernel's on the same data (+ 2^-22 for the H2 rounding of the stored result)."""
+    L = macx._lib.lib()
+    p = 1
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=d, ctrlDim=d, attDim=d)
+    g = torch.Generator().manual_seed(31)
+    vq, words, lengths, _ = macx.configs.synthetic_inputs(B, 5, N, d, seed=3)
+    kb = _wide((B, N, d), g)
+    params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        params.projX_W.copy_(_wide((d, d), g) / 22)
+        params.memKbProj2_W.copy_(_wide((d, d), g) / 22)
+        params.projX_b.copy_(torch.randn(d, generator=g))
+        params.memKbProj2_b.copy_(torch.randn(d, generator=g))
+    vqd, wd, kbd, ld = vq.to(dev), words.to(dev), kb.to(dev), lengths.to(dev)
+    cell = macx.MACCell(vqd, wd, wd, ld, kbd, 1.0, 1.0, 1.0, B, True, config=cfg, params=params, seed=1, gemm="h2")
+    run = macx.cell._Run(cell, True)
+    run.begin()
+    run.step(0)
+    outs = []
+    for which in (1, 2, 3):
+        o = torch.empty(B * N, d, device=dev)
+        macx._lib.check(L.macx_saved_activation(C.byref(run.opts), C.byref(run.shapes), which, 0, _p(run.saved), run.saved_floats, _p(o),
+                                                run.stream), "macx_saved_activation")
+        outs.append(o)
+    torch.cuda.synchronize()
+    X, H1, I2 = [o.cpu().double() for o in outs]
+    Wx, bx = params.projX_W.detach().cpu().double(), params.projX_b.detach().cpu().double()
+    W2, b2 = params.memKbProj2_W.detach().cpu().double(), params.memKbProj2_b.detach().cpu().double()
+    A1 = kb.double().reshape(-1, d)
+    cases = [("X", X, A1, Wx, bx, kb.reshape(-1, d), params.projX_W, params.projX_b),
+             ("I2", I2, H1, W2, b2, outs[1].cpu(), params.memKbProj2_W, params.memKbProj2_b)]
+    for name, got, A, W, b, A32, Wt, bt in cases:
+        ref = A @ W + b
+        scale = (A.abs() @ W.abs() + b.abs()).amax(dim=1, keepdim=True) + 1e-300
+        e = ((got - ref).abs() / scale)
+        emax, emean = float(e.max()), float(e.mean())
+        assert emax < 1e-6, (name, emax)
+        # the native f32-MFMA kernel on the same operands
+        try:
+            L.macx_gemm_mode(0)
+            sh = macx._lib.MacxShapes(B=B, S=1, N=N, d=d, p=1, b0=0)
+            dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=1)
+            wp = torch.zeros(2 * d * d, device=dev)
+            o2 = torch.empty(B, N, d, device=dev)
+            Ad = A32.to(dev).contiguous()
+            macx._lib.check(L.macx_pack_weight(_p(Wt.detach()), d, d, macx._lib.kb_pack_flags(), _p(wp), None), "pack")
+            macx._lib.check(L.macx_kb_project(C.byref(sh), C.byref(dp), 0, _p(Ad), _p(wp), _p(bt.detach()), _p(o2), None, None), "proj")
+            torch.cuda.synchronize()
+            e0 = (o2.cpu().double().reshape(-1, d) - ref).abs() / scale
+        finally:
+            L.macx_gemm_mode(default_gemm_mode())
+        assert emax <= 1.5 * float(e0.max()) + 2.0 ** -22 and emean <= 1.5 * float(e0.mean()) + 2.0 ** -24, (name, emax, emean, float(e0.max()), float(e0.mean()))

@@ -40,3 +40,20 @@ def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
         # (the logits bias shifts every logit of a softmax alike: its gradient is round-off around zero)
         floor = 0.2 if k.endswith("Logits_b") else 1e-6
         assert rel_err(got[k], ref[k], floor=floor) < 2e-5, k
+
+
+@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 3, 7, 196, 512, 2), ("args1", 4, 9, 49, 256, 3), ("args", 2, 5, 33, 512, 5)])
+def test_wgrad_pipeline_variants_are_bit_identical(macx, dev, name, B, S, N, d, p):
+    """key 10: the all-steps weight-gradient contractions with round 4's loop (0), with a buffer's halves re-requested inside the
+    iteration (1) and with dW2 / dWx as one launch on top (2, the default) multiply the same fragments in the same order: every
+    gradient bit for bit."""
+    lib = macx._lib.lib()
+    ref = run(macx, dev, name, B, S, N, d, p)
+    try:
+        for v in (0, 1):
+            assert lib.macx_debug_set(10, v) == 0
+            got = run(macx, dev, name, B, S, N, d, p)
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (v, k)
+    finally:
+        assert lib.macx_debug_set(10, 2) == 0

@@ -44,12 +44,63 @@ def test_stem_matches_conv2d_oracle(macx, dev, B, H, W, Cin, Cmid, Cout, train):
         assert rel_err(getattr(stem, f).grad, prm[name].grad) < 2e-4, f
 
 
-def test_stem_clevr_shape_fp32(macx, dev):
-    """config.imageDims = 14 x 14 x 1024 -> 512 -> 512 at B = 8 against the fp32 conv2d restatement."""
-    stem, kb, ref, prm = run_case(macx, dev, 8, 14, 14, 1024, 512, 512, True, dtype=torch.float32)
-    assert rel_err(kb, ref) < 1e-4
+def test_stem_clevr_shape(macx, dev):
+    """config.imageDims = 14 x 14 x 1024 -> 512 -> 512 (north_star's shape; both convolutions on kb_conv_chain_kernel, forward and
+    backward-data) at B = 8 against the fp64 conv2d restatement: forward 2e-5, every gradient 2e-4 -- the bounds of the GQA-shape
+    case (round 4 compared with an fp32 oracle at 1e-3)."""
+    stem, kb, ref, prm = run_case(macx, dev, 8, 14, 14, 1024, 512, 512, True, dtype=torch.float64)
+    assert rel_err(kb, ref) < 2e-5
     for f, name in macx.stem.REF_NAMES.items():
-        assert rel_err(getattr(stem, f).grad, prm[name].grad) < 1e-3, f
+        assert rel_err(getattr(stem, f).grad, prm[name].grad) < 2e-4, f
+
+
+@pytest.mark.parametrize("H,W,Cin", [(14, 14, 1024), (7, 7, 512)])
+def test_stem_on_wide_dynamic_range(macx, dev, H, W, Cin):
+    """The stem's products carry ONE exponent per operand TENSOR (macx_gemm3h.hip.h: image, hidden layer, both kernels).  Entries
+    spanning 2^+-12 inside each of those tensors (independently per element): the output against fp64 per unit of
+    conv(|a|, |w|) + |b| of the LAST layer, at most 1.5x what the native f32-MFMA kernels (macx_gemm_mode 0) leave on the same data.
+    What the format does NOT promise is stated in DESIGN 11: a pixel whose channels all sit 2^-k below the tensor's largest entry
+    keeps 22 - k bits -- the per-element spread of this test is not that case."""
+    L = macx._lib.lib()
+    B, Cmid, Cout = 4, 512, 512
+    cfg = mo.flag_file_config("args", memDim=Cout, ctrlDim=Cout, attDim=Cout)
+    cfg.stemDim = Cmid
+    g = torch.Generator().manual_seed(8)
+    wide = lambda shape, span: torch.randn(shape, generator=g) * torch.exp2((torch.rand(shape, generator=g) * 2 - 1) * span)
+    stem = macx.Stem(cfg, H=H, W=W, inDim=Cin, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        stem.kernel0.copy_(wide(stem.kernel0.shape, 12.0) * (2.0 / (9 * Cin)) ** 0.5 / 64)
+        stem.kernel1.copy_(wide(stem.kernel1.shape, 12.0) * (2.0 / (9 * Cmid)) ** 0.5 / 64)
+        stem.bias0.copy_(torch.rand(Cmid, generator=g) - 0.5)
+        stem.bias1.copy_(torch.rand(Cout, generator=g) - 0.5)
+    img = torch.relu(wide((B, H * W, Cin), 12.0))
+    imgd = img.to(dev)
+
+    def fwd():
+        with torch.no_grad():
+            out = stem(imgd, train=False)
+        torch.cuda.synchronize()
+        return out.cpu().double()
+
+    got = fwd()
+    try:
+        L.macx_gemm_mode(0)
+        native = fwd()
+    finally:
+        from helpers import default_gemm_mode
+        L.macx_gemm_mode(default_gemm_mode())
+    # fp64 reference and the last layer's sum |a| |w| + |b|
+    k0, k1 = stem.kernel0.detach().cpu().double(), stem.kernel1.detach().cpu().double()
+    b0_, b1_ = stem.bias0.detach().cpu().double(), stem.bias1.detach().cpu().double()
+    conv = lambda x, k: torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), k.permute(3, 2, 0, 1).contiguous(), padding=1).permute(0, 2, 3, 1)
+    x0 = img.double().reshape(B, H, W, Cin)
+    h = torch.nn.functional.elu(conv(x0, k0) + b0_)
+    ref = torch.nn.functional.elu(conv(h, k1) + b1_).reshape(B, H * W, Cout)
+    scale = (conv(h.abs(), k1.abs()) + b1_.abs()).reshape(B, H * W, Cout) + 1e-300
+    e, e0 = (got - ref).abs() / scale, (native - ref).abs() / scale
+    assert float(e.max()) < 2e-6, float(e.max())
+    assert float(e.max()) <= 1.5 * float(e0.max()) + 1e-9 and float(e.mean()) <= 1.5 * float(e0.mean()) + 1e-10, \
+        (float(e.max()), float(e0.max()), float(e.mean()), float(e0.mean()))
 
 
 def test_stem_gqa_shape(macx, dev):

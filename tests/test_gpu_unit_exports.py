@@ -161,3 +161,55 @@ def test_unit_exports_reject_what_they_cannot_do(macx, dev):
     assert u.L.macx_read_fwd(*u.head(), P(kb), P(x), P(x), P(u.saved), u.saved_floats, P(x), P(att), u.stream) == -1
     u.shapes.p = 1
     assert u.L.macx_read_fwd(*u.head(), P(kb), P(x), P(x), P(u.saved), 16, P(x), P(att), u.stream) == -4      # MACX_ESMALL
+
+
+@pytest.mark.parametrize("unshared,act,B,d,p", [(True, "TANH", 5, 128, 3), (False, "TANH", 3, 256, 2), (True, "NON", 64, 512, 12),
+                                                (True, "RELU", 4, 128, 2)])
+def test_ctrl_inputs_exports(macx, dev, unshared, act, B, d, p):
+    """SURVEY 8b's `ctrl_inputs` unit (mac_cell.py:442-448) through macx_ctrl_inputs_fwd / _bwd against the closed form in fp64:
+    t = act(vecQ Wq + bq), cI_i = t WqU_i + bqU_i; d_vecQ and the four parameter gradients from a random d_cI."""
+    lib = macx._lib
+    L = lib.lib()
+    cfg = mo.flag_file_config("args", netLength=p, memDim=d, ctrlDim=d, attDim=d, controlInputUnshared=unshared, controlInputAct=act)
+    opts = macx.options.freeze(cfg)
+    shapes = lib.MacxShapes(B=B, S=4, N=16, d=d, p=p, b0=0)
+    nU = p if unshared else 1
+    g = torch.Generator().manual_seed(3)
+    vq = torch.randn(B, d, generator=g)
+    Wq, bq = torch.randn(d, d, generator=g) / d ** 0.5, torch.randn(d, generator=g) * 0.1
+    WqU, bqU = torch.randn(nU, d, d, generator=g) / d ** 0.5, torch.randn(nU, d, generator=g) * 0.1
+    dcI = torch.randn(p, B, d, generator=g)
+    dv = [t.to(dev).contiguous() for t in (vq, Wq, bq, WqU, bqU, dcI)]
+    vqd, Wqd, bqd, WqUd, bqUd, dcId = dv
+    ps, gs = lib.MacxParams(), lib.MacxParamGrads()
+    ps.qInput_W, ps.qInput_b, ps.qInputU_W, ps.qInputU_b = Wqd.data_ptr(), bqd.data_ptr(), WqUd.data_ptr(), bqUd.data_ptr()
+    grads = {k: torch.full_like(t, float("nan")) for k, t in (("qInput_W", Wqd), ("qInput_b", bqd), ("qInputU_W", WqUd), ("qInputU_b", bqUd))}
+    for k, t in grads.items():
+        setattr(gs, k, t.data_ptr())
+    n = L.macx_ctrl_inputs_ws_floats(C.byref(opts), C.byref(shapes))
+    assert n > 0
+    ws = torch.empty(n, device=dev)
+    t_out, cI = torch.empty(B, d, device=dev), torch.empty(p, B, d, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    lib.check(L.macx_ctrl_inputs_fwd(C.byref(opts), C.byref(shapes), C.byref(ps), P(vqd), P(t_out), P(cI), P(ws), n, st), "ctrl_inputs_fwd")
+    dvq = torch.empty(B, d, device=dev)
+    lib.check(L.macx_ctrl_inputs_bwd(C.byref(opts), C.byref(shapes), C.byref(ps), P(vqd), P(t_out), P(dcId), C.byref(gs), P(dvq), P(ws), n, st),
+              "ctrl_inputs_bwd")
+    torch.cuda.synchronize()
+    # fp64 closed form through autograd
+    vq64, Wq64, bq64, WqU64, bqU64 = [t.double().requires_grad_(True) for t in (vq, Wq, bq, WqU, bqU)]
+    assert cfg.relu == "ELU"                  # configs/args.txt: "RELU" resolves to ELU (ops.py:161-179)
+    pre = vq64 @ Wq64 + bq64
+    t64 = {"TANH": torch.tanh, "NON": lambda x: x, "RELU": torch.nn.functional.elu}[act](pre)
+    c64 = torch.stack([t64 @ WqU64[i if unshared else 0] + bqU64[i if unshared else 0] for i in range(p)])
+    (c64 * dcI.double()).sum().backward()
+    assert rel_err(t_out, t64.detach()) < 1e-5
+    assert rel_err(cI, c64.detach()) < 1e-5
+    for name, got, ref in (("d_vecQ", dvq, vq64.grad), ("qInput_W", grads["qInput_W"], Wq64.grad), ("qInput_b", grads["qInput_b"], bq64.grad),
+                           ("qInputU_W", grads["qInputU_W"], WqU64.grad), ("qInputU_b", grads["qInputU_b"], bqU64.grad)):
+        assert torch.isfinite(got).all(), name
+        assert rel_err(got, ref) < 2e-4, (name, rel_err(got, ref))
+    # too small a workspace, a missing field
+    assert L.macx_ctrl_inputs_fwd(C.byref(opts), C.byref(shapes), C.byref(ps), P(vqd), P(t_out), P(cI), P(ws), n - 1, st) != 0
+    ps.qInputU_W = None
+    assert L.macx_ctrl_inputs_fwd(C.byref(opts), C.byref(shapes), C.byref(ps), P(vqd), P(t_out), P(cI), P(ws), n, st) != 0

@@ -37,7 +37,7 @@ def fb():
 
 
 res = {(v, k): [] for v in (0, 1) for k in ("fwd", "fwd+bwd")}
-for rnd in range(5):
+for rnd in range(int(os.environ.get("ROUNDS", "9"))):
     for v in (0, 1):
         L.macx_debug_set(9, v)
         res[(v, "fwd")].append(timeit(fwd))
