@@ -525,12 +525,18 @@ int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, ui
  *          queue (lowest / highest / middle priority), forked from and joined to the caller's stream by events (still
  *          stream-ordered for the caller) -- measured slower, kept for the A/B; 4: the per-step dW2 contraction as a right-sized grid
  *          beside the chain kernels (also slower)
- *   key 7  K-loop variant of the chain kernels (-1 = default)      key 8  0: the 128 x 128 S_b kernel instead of the 128 x 256 one
+ *   key 7  K-loop variant of the chain kernels (-1 = default)      key 8  the read unit's interaction weight gradients dW1a / dW1b: 0 the 128 x 128 per-question S_b kernel, 1 the 128 x 256 one,
+ *          2 (default) no per-question kernel -- the forward pass keeps X * y and both are one contraction over all rows with two
+ *          A operands (where the chain kernels run and d % 256 == 0; else as 1).  Read when the FORWARD pass is enqueued as well
+ *          (it decides whether X * y is kept): set it between whole steps only
  *   key 9  0: the stem's 3 x 3 convolutions on kb_gemm3h_kernel; 1 (default): on kb_conv_chain_kernel where the shape allows
  *          (512 output channels, input channels a multiple of 256)
  *   key 10 the all-steps weight-gradient contractions (wgrad_h2_kernel<2,2>): 0 round 4's loop (a stage is requested one iteration
  *          ahead); 1 a buffer's G / A halves are re-requested inside the iteration as soon as every wave has read them (two stages
- *          in flight); 2 (default) = 1 + dW2 and dWx as ONE launch (grid.y = 2) */
+ *          in flight); 2 (default) = 1 + dW2 and dWx as ONE launch (grid.y = 2)
+ *   key 11 workgroups of a pair launch (two dependent [B,d] linears in one launch with a device-scope barrier between them:
+ *          write-unit linear of step i + projY linear of step i + 1; dy linear of step i + write-unit backward linear of step i - 1);
+ *          0: every linear its own launch; 16 .. 256 (default 128) */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

@@ -59,7 +59,10 @@ inline bool use_chain(int d, int N) { return h2_mode() && chain_mode() && chain_
 // dy from the chain kernel and S_b of all steps as one deferred launch; macx_debug_set(5, 0): sb_h2 once per step, as before
 inline int& sb_defer_mode() { static int m = 1; return m; }
 // the deferred S_b contraction on 128 x 256 tiles with summation by parts (sb_h2w_kernel); macx_debug_set(8, 0): the 128 x 128 kernel
-inline int& sb_wide_mode() { static int m = 1; return m; }
+// ... 2 (default, round 5): not a per-question kernel at all -- the forward chain kernel keeps X * y, and dW1a = (X * y)^T dI1,
+// dW1b = X^T dI1 are ONE plain contraction over all p B N rows with two A families (wgrad_h2_kernel's dual form) where the
+// shape allows (chain kernels, d % 256 == 0); else as 1
+inline int& sb_wide_mode() { static int m = 2; return m; }
 // A second queue for the backward pass's contractions that nothing in the recurrence waits for (dKB of a step: 27 us of
 // full-chip matrix work).  Between two chain kernels the caller's stream runs ~100 us of [B,d]-sized launches that leave the
 // chip almost idle; the side queue was meant to fill exactly that.  Fork and join are events on the caller's stream, so for the
@@ -90,6 +93,19 @@ inline SideQueue* side_queue() {
     state[dev] = ok ? 1 : -1;
   }
   return state[dev] == 1 ? &q[dev] : nullptr;
+}
+// the read unit's interaction weight gradients as a dual-A contraction (sb_wide_mode() == 2): forward keeps X * y per step
+inline bool sb_dual_ok(const macx_shapes* s) {
+  return h2_mode() && use_chain(s->d, s->N) && s->N >= 32 && sb_defer_mode() && sb_wide_mode() == 2 && s->d % 256 == 0;
+}
+// write-unit linear of step i + projY linear of step i + 1 as one launch (forward), dy-linear of step i + write-unit backward
+// linear of step i - 1 as one launch (backward): small_linear_pair_kernel.  Whole cell only, writeInputs = BOTH without gate
+// (the gate's mix sits between the two products), B <= 128
+inline bool pair_fwd_ok(const macx_opts* o, const macx_shapes* s, int units) {
+  return lin_pair_grid() > 0 && units == 7 /* U_ALL */ && !o->write_gate && s->B <= 128;
+}
+inline bool pair_bwd_ok(const macx_opts* o, const macx_shapes* s, int units) {
+  return lin_pair_grid() > 0 && units == 7 /* U_ALL */ && !o->write_gate && !o->write_self_att && o->write_mem_act == MACX_ACT_NON && s->B <= 128;
 }
 inline int wfmt_plain() { return h2_mode() ? 3 : (gemm_split_mode() ? 1 : 0); }
 inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
@@ -163,10 +179,12 @@ struct SavedLayout {
   size_t self_smry;                 // [p,B,d]
   size_t logit_part;                // [d/128][B*N]
   size_t X, H1, I2;                 // [pk][B,N,d], pk = p (keep) or 1
+  size_t XY;                        // [p][B,N,d] X * y (H2) when the backward pass contracts it (sb_dual_ok, keep); else unused
   size_t KBd;                       // [pk][B,N,d] dropped knowledge base (ops.py:678)
   size_t act_stride;                // floats per kept step of X / H1 / I2 / KBd if keep else 0
   size_t act_floats;                // floats of one such tensor (B*N*d, or the H2 size in h2 mode)
   size_t wmax;                      // h2: max |W| of projX, memKbProj2, W1a, W1b (4 floats)
+  size_t pair_sync;                 // 4 words: arrival counter + fail flag of the forward pass's pair launches (macx_small.hip.h)
   size_t total;
 };
 
@@ -223,11 +241,13 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.H1 = take(pk * L.act_floats);
   L.I2 = take(pk * L.act_floats);
   L.KBd = take(pk * L.act_floats);
+  L.XY = (keep && sb_dual_ok(s)) ? take(p * L.act_floats) : 0;
   const size_t bits_floats = h2_mode() ? al4(((B * N + H2_PAD_ROWS) * (d / 8) + 3) / 4) : B * N * d / 32;
   L.bits_stride = keep ? bits_floats : 0;
   L.kb_bits = take(pk * bits_floats);
   L.att_bits = take(pk * bits_floats);
   L.wmax = take(8 + 4 * 64);          // the four maxima (+ 4 spare), then absmax4's per-workgroup partials
+  L.pair_sync = take(4);
   L.total = off;
   return L;
 }
@@ -302,6 +322,7 @@ struct BwdLayout {
   size_t dI1_stride;          // floats between the steps' dI1 (0: one buffer)
   size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part, ctrl_dl;
   size_t tmpBd[4];  // [B,d] scratch
+  size_t pair_sync; // 4 words: arrival counter + fail flag of the backward pass's pair launches
   size_t dccx;      // [p+1,B,d] gradient reaching cc_i from the NEXT step's contControl input (feedPrevAtt off)
   size_t dlin1;     // [p,B,d] gradient wrt the first contControl layer's pre-activation
   size_t dxc;       // [B,2d]  gradient wrt the contControl input of the current step
@@ -312,6 +333,9 @@ struct BwdLayout {
   size_t tmp_dd;    // [d,d] scratch
   size_t act_floats;                 // floats of one [B,N,d] activation (H2 size in h2 mode)
   size_t ecom;                       // h2: [4][EMIN_NB][8] ints, partial minima of the row exponents of H1 / dI2 / KBd / dX over all steps
+  bool sb_dual;                      // dW1a / dW1b from the dual-A contraction (sb_dual_ok)
+  size_t ftab_dual;                  // its 2 (d/128) (d/128) row-factor tables
+  size_t ns_dual;                    // its reduction splits
   size_t wg_ftab, wg_ftab2;          // h2: [d/128][d/128][Mpad] fp16 row factors of the two deferred weight-gradient contractions
   // per-step dW2 on the side queue (overlap mode 4): exponent minima [p][2][EMIN_NB][8], row factors [p][d/128][d/128][Mpad(B N)], splits
   size_t ecom_s, ftab_s, ftab_s_stride, side_ns;
@@ -339,6 +363,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dI2 = take(p * L.act_floats); L.dI1 = take((L.sb_deferred ? p : 1) * L.act_floats); L.dX = take(p * L.act_floats); L.da = take(B * N);   // dI2, dX (dI1) kept per step
   L.DM = take((p + 1) * B * d);
   L.DC = take((p + 1) * B * d);
+  L.pair_sync = take(4);              // (right behind DC: bwd_init_kernel zeroes it with them)
   L.dcI = take(p * B * d);
   L.dcc = o->control_feed_prev ? take(p * B * d) : L.dcI;
   L.dwlin = take(p * B * d);
@@ -349,13 +374,15 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dmd = take(B * d);
   L.dt = take(B * d); L.du = take(B * d);
   L.ns_big = wgrad_big_splits((int)(p * B * N), (int)d, (int)d);
+  L.sb_dual = sb_dual_ok(s);
+  L.ns_dual = L.sb_dual ? std::max<size_t>(1, 256 / (size_t)wgrad_h2_dual_tiles((int)d, (int)d)) : 0;
   L.sb_wide = L.sb_deferred && h2_mode() && sb_wide_mode() && sb_h2_wide_ok((int)B, (int)N, (int)d);
   L.sb_qpg = L.sb_wide ? sb_h2_wide_qpg((int)B, (int)N, (int)d) : sb_qpg((int)B, (int)N);
   L.ngroup = (B + L.sb_qpg - 1) / L.sb_qpg;
   L.slab_w2 = take(L.ns_big * d * d);
   L.slab_wx = take(L.ns_big * d * d);
-  L.slab_w1a = take((L.sb_deferred ? 1 : p) * L.ngroup * d * d);
-  L.slab_w1b = take((L.sb_deferred ? 1 : p) * L.ngroup * d * d);
+  L.slab_w1a = take(std::max((L.sb_deferred ? 1 : p) * L.ngroup, L.ns_dual) * d * d);
+  L.slab_w1b = take(std::max((L.sb_deferred ? 1 : p) * L.ngroup, L.ns_dual) * d * d);
   // column-sum partials of dI1 / dX: one row per GEMM workgroup row block, or per 64-row tile of the chain kernel
   const size_t nrb = use_chain((int)d, (int)N) ? chain_tiles((int)d, B * N) : B * nrb_of((int)N, (int)B, (int)d);
   L.db_rows = nrb;
@@ -383,7 +410,8 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.small_slab_stride = al4(small);
   L.small_slab = take(8 * L.small_slab_stride);        // SmallWgradBatch: one slab set per batched contraction
   L.tmp_dd = take(d * d);
-  L.ecom = take(4 * EMIN_NB * 8);
+  L.ecom = take(7 * EMIN_NB * 8);
+  L.ftab_dual = take(L.sb_dual ? 2 * (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
   L.wg_ftab = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
   L.wg_ftab2 = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
   L.ecom_s = take(p * 2 * EMIN_NB * 8);
@@ -462,6 +490,7 @@ ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dr
   c.wk = P->kbLogits_w;
   c.X = h2_view(saved + L.X + (size_t)ob * L.act_stride, R, d);
   if (keep) {
+    if (L.XY) c.XY = h2_view(saved + L.XY + (size_t)ob * L.act_stride, R, d);
     c.H1 = h2_view(saved + L.H1 + (size_t)ob * L.act_stride, R, d);
     c.I2 = h2_view(saved + L.I2 + (size_t)ob * L.act_stride, R, d);
   }
@@ -783,11 +812,11 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
 
   CKI(pack_forward_weights(o, s, P, saved, L, keep, U_ALL, st));
 
-  // initial state (mac_cell.py:546-553)
+  // initial state (mac_cell.py:546-553), both tensors and the pair launches' arrival counter in one launch
   float* controls = saved + L.seg[MACX_SEG_CONTROLS];
   float* memories = saved + L.seg[MACX_SEG_MEMORIES];
-  hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, st, o->init_ctrl, P->initCtrl, in->vecQuestions, B, d, controls);
-  hipLaunchKernelGGL(init_state_kernel, dim3(64), dim3(256), 0, st, o->init_mem, P->initMem, in->vecQuestions, B, d, memories);
+  hipLaunchKernelGGL(init_states_kernel, dim3(64), dim3(256), 0, st, o->init_ctrl, P->initCtrl, controls, o->init_mem, P->initMem, memories,
+                     in->vecQuestions, B, d, reinterpret_cast<uint32_t*>(saved + L.pair_sync));
   CK(hipGetLastError());
 
   // control inputs (mac_cell.py:442-448).  qInput is step-invariant; qInput{i} is batched over steps.
@@ -877,7 +906,8 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md, dlog_of(s));
     CK(hipGetLastError());
   }
-  {
+  const bool pair_fwd = md_fused && pair_fwd_ok(o, s, units);
+  if (!(pair_fwd && i > 0)) {        // (from step 1 on, the previous step's pair launch also left y behind)
     LinP l = lin_basic(md, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON, y, d);
     CK(small_linear_launch(l, 1, st));
   }
@@ -1024,7 +1054,15 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
       l.drop_row0 = (uint32_t)s->b0;
       l.out_drop = saved + L.md + (size_t)(i + 1) * Bd; l.ld_od = d;
     }
-    CK(small_linear_launch(l, 1, st));
+    if (md_fused && i + 1 < s->p && pair_fwd_ok(o, s, units)) {
+      // ... and the next step's y = md Wy + by (ops.py:679,688) behind a device-scope barrier in the same launch
+      LinP ly = lin_basic(saved + L.md + (size_t)(i + 1) * Bd, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON,
+                          saved + L.y + (size_t)(i + 1) * Bd, d);
+      uint32_t* sync = reinterpret_cast<uint32_t*>(saved + L.pair_sync);
+      CK(small_linear_pair_launch(l, ly, false, LinPairSync{sync, sync + 1}, st));
+    } else {
+      CK(small_linear_launch(l, 1, st));
+    }
     if (o->write_gate) {
       // z = sigmoid(control Wg + bg + gateBias); m = newMemory * z + memory * (1 - z)   (mac_cell.py:358-367)
       float* z = saved + L.seg[MACX_SEG_ATT_GATE] + (size_t)i * Bd;
@@ -1136,14 +1174,18 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   float* DC = ws + W.DC;
   // dL/d(newMemory linear output) for all steps; with writeMemAct = NON it IS dL/dm_{1..p}
   float* dwlin_all = (o->write_mem_act == MACX_ACT_NON && !o->write_gate) ? DM + Bd : ws + W.dwlin;
-  if (DC == DM + (size_t)(p + 1) * Bd) {                 // (adjacent in the workspace: one fill)
-    CK(dev_zero(DM, 2 * (size_t)(p + 1) * Bd * sizeof(float), st));
+  const bool pair_bwd = pair_bwd_ok(o, s, units);
+  if (DC == DM + (size_t)(p + 1) * Bd && ws + W.pair_sync == DC + (size_t)(p + 1) * Bd && !misaligned(d_memory) && !misaligned(d_control)) {
+    // (adjacent in the workspace: zeros, the incoming gradients in the last slabs and the pair launches' counter in ONE launch)
+    hipLaunchKernelGGL(bwd_init_kernel, dim3(fill_grid(2 * (size_t)(p + 1) * Bd)), dim3(256), 0, st, DM, Bd, p, d_memory, d_control, 4);
+    CK(hipGetLastError());
   } else {
     CK(dev_zero(DM, (size_t)(p + 1) * Bd * sizeof(float), st));
     CK(dev_zero(DC, (size_t)(p + 1) * Bd * sizeof(float), st));
+    CK(dev_zero(ws + W.pair_sync, 16, st));
+    if (d_memory) CK(dev_copy(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), st));
+    if (d_control) CK(dev_copy(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), st));
   }
-  if (d_memory) CK(dev_copy(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), st));
-  if (d_control) CK(dev_copy(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), st));
   if ((units & U_CONTROL) && o->control_feed_prev) {
     CK(dev_zero(GI->words, (size_t)B * S * d * sizeof(float), st));
     CK(dev_zero(ws + W.dwc_part, Bd * sizeof(float), st));
@@ -1196,7 +1238,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, dmnew, mnew_out, o->write_mem_act, Bd, dwlin);
       CK(hipGetLastError());
     }
-    {
+    if (!(pair_bwd && i < p - 1)) {      // (below step p - 1 the dy-linear launch of step i + 1 already did it: pair launch)
       LinP l = lin_basic(dwlin, d, d, B, ws + W.wmT, nullptr, win, MACX_ACT_NON, dwin, win);
       CK(small_linear_launch(l, 1, st));
     }
@@ -1441,8 +1483,16 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       l.d2 = make_drop(dp->keep_read, dp, SITE_READ_MEM, i);
       l.drop_row0 = (uint32_t)s->b0;
       if (units & U_WRITE) { l.addend = dwin; l.ld_add = win; }
-      if (h2_mode() && W.dy_in_linear) {
-        l.part = ws + W.dyc_part; l.part_N = N; l.part_sum = DYi; l.part_shift = chain_tile_shift(d, (size_t)B * N);
+      const bool part_form = h2_mode() && W.dy_in_linear;
+      if (part_form) { l.part = ws + W.dyc_part; l.part_N = N; l.part_sum = DYi; l.part_shift = chain_tile_shift(d, (size_t)B * N); }
+      if (pair_bwd && i > 0 && !acc_prev) {
+        // dL/dm_{i-1} (this launch's output) is the input of step i - 1's write-unit backward linear
+        // [dm part | dinfo] = dwlin Wm^T (writeMemAct = NON, no gate: dwlin_{i-1} IS dL/dm_{i-1}): both in one launch
+        LinP lw = lin_basic(dwlin_all + (size_t)(i - 1) * Bd, d, d, B, ws + W.wmT, nullptr, win, MACX_ACT_NON,
+                            ws + W.dwin + (size_t)(i - 1) * B * win, win);
+        uint32_t* sync = reinterpret_cast<uint32_t*>(ws + W.pair_sync);
+        CK(small_linear_pair_launch(l, lw, part_form, LinPairSync{sync, sync + 1}, st));
+      } else if (part_form) {
         CK(small_linear_part_launch(l, st));
       } else {
         CK(small_linear_launch(l, 1, st));
@@ -1680,7 +1730,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       el.base[1] = reinterpret_cast<const char*>(ws + W.dI2); el.stride[1] = W.act_floats * sizeof(float); el.nt[1] = p;
       el.base[2] = reinterpret_cast<const char*>(saved + L.KBd); el.stride[2] = L.act_stride * sizeof(float); el.nt[2] = rdrop ? p : 1;
       el.base[3] = reinterpret_cast<const char*>(ws + W.dX); el.stride[3] = W.act_floats * sizeof(float); el.nt[3] = p;
-      CK(emin_list(el, 4, st));
+      if (W.sb_dual && L.XY) {
+        el.base[4] = reinterpret_cast<const char*>(saved + L.XY); el.stride[4] = L.act_stride * sizeof(float); el.nt[4] = p;
+        el.base[5] = reinterpret_cast<const char*>(saved + L.X); el.stride[5] = L.act_stride * sizeof(float); el.nt[5] = p;
+        el.base[6] = reinterpret_cast<const char*>(ws + W.dI1); el.stride[6] = W.dI1_stride * sizeof(float); el.nt[6] = p;
+        CK(emin_list(el, 7, st));
+      } else {
+        CK(emin_list(el, 4, st));
+      }
     }
     TnH2P t;
     memset(&t, 0, sizeof(t));
@@ -1715,6 +1772,25 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     CK(wgrad_any(t, st));
   }
 
+  const bool dual_run = h2_mode() && W.sb_deferred && W.sb_dual && L.XY;
+  if (dual_run) {
+    // dW1a = sum over all p B N rows of (X * y)^T dI1, dW1b = ... X^T dI1 (ops.py:703,718): one contraction with two A families,
+    // the dI1 half of every stage staged once for both (wgrad_h2_kernel, dual form)
+    int* ecom = reinterpret_cast<int*>(ws + W.ecom);
+    constexpr int ES = EMIN_NB * 8;
+    TnH2P t;
+    memset(&t, 0, sizeof(t));
+    t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_dual; t.rows_per_split = rows_per_split(t.M, t.nsplit);
+    t.R = B * N;
+    t.A = reinterpret_cast<const char*>(saved + L.XY); t.a_stride = L.act_stride * sizeof(float); t.a_mod = 0;
+    t.A2 = reinterpret_cast<const char*>(saved + L.X); t.a2_stride = L.act_stride * sizeof(float);
+    t.G = reinterpret_cast<const char*>(ws + W.dI1); t.g_stride = W.dI1_stride * sizeof(float);
+    t.ecomA = ecom + 4 * ES; t.ecomA2 = ecom + 5 * ES; t.ecomG = ecom + 6 * ES; t.ecom_nb = EMIN_NB;
+    t.ftab = reinterpret_cast<uint16_t*>(ws + W.ftab_dual);
+    t.dbg = kb_gemm_dbg();
+    t.part = ws + W.slab_w1a; t.part2 = ws + W.slab_w1b;
+    CK(wgrad_h2_dual_launch(t, st));
+  } else
   if (h2_mode() && W.sb_deferred) {
     // dW1a = sum_i sum_b diag(y_ib) S_ib, dW1b = sum_i sum_b S_ib, S_ib = X_ib^T dI1_ib: every step in one launch, the two
     // accumulators of a workgroup run through all of them (macx_wgrad_h2.hip.h)
@@ -1731,7 +1807,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     q.qpg = W.sb_qpg;
     CK(W.sb_wide ? sb_h2w_launch(q, st) : sb_h2_launch(q, st));
   }
-  const int nslab1 = (int)((h2_mode() && W.sb_deferred ? 1 : p) * W.ngroup);
+  const int nslab1 = dual_run ? (int)W.ns_dual : (int)((h2_mode() && W.sb_deferred ? 1 : p) * W.ngroup);
   {
     SlabList sl;
     sl.d[0] = SlabDesc{ws + W.slab_w2, (int)((h2_mode() && w2_side) ? W.side_ns : W.ns_big), dd / 4, GP->memKbProj2_W, 0};
@@ -2862,9 +2938,10 @@ int macx_debug_set(int key, int value) {
   if (key == 5 && (value == 0 || value == 1)) { sb_defer_mode() = value; return MACX_OK; }
   if (key == 6 && value >= 0 && value <= 4) { overlap_mode() = value; return MACX_OK; }
   if (key == 7 && value >= -1 && value <= 63) { chain_kv() = value; return MACX_OK; }
-  if (key == 8 && (value == 0 || value == 1)) { sb_wide_mode() = value; return MACX_OK; }
+  if (key == 8 && value >= 0 && value <= 2) { sb_wide_mode() = value; return MACX_OK; }
   if (key == 9 && (value == 0 || value == 1)) { conv_chain_mode() = value; return MACX_OK; }
   if (key == 10 && value >= 0 && value <= 2) { wgrad_pipe_mode() = value; return MACX_OK; }
+  if (key == 11 && (value == 0 || (value >= 16 && value <= 256))) { lin_pair_grid() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

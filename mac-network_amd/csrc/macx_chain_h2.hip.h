@@ -651,6 +651,8 @@ struct ChainFwdP {
   const float* c;           // [B][d]
   const float* wk;          // [d]
   H2View X;                 // written in mode 0, read in mode 1
+  H2View XY;                // base null: not written.  X * y as stage 2 multiplies it (ops.py:703), kept for the backward pass's
+                            // dW1a = (X * y)^T dI1 contraction (wgrad_h2_kernel's dual form)
   H2View H1;                // base null: not written (inference)
   H2View I2;                // base null: not written
   float* logits;            // [M] (without the bias b_k, which kb_attend adds)
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
         m = fmaxf(m, fabsf(v[j][q]));
       }
     }
-    x.convert_finish(v, m, x.sE2, H2View{nullptr, M, D});
+    x.convert_finish(v, m, x.sE2, p.XY.base ? p.XY : H2View{nullptr, M, D});
   }
   {
     // accumulators: units 2^-(eX + e1b)  ->  2^-(eXy + e1a), exactly

@@ -301,7 +301,7 @@ __global__ void h2_to_f32_kernel(H2View in, float* out) {
 // (h2_emin_final).  The rounds before ran these minima as an atomicMin into an array preset by a memset; under HIP-graph replay
 // that pair was seen to run out of order, so no kernel of this library orders itself against a memset any more.
 constexpr int EMIN_NB = 64;
-struct EminList { const char* base[4]; size_t stride[4]; int nt[4]; int R, C; int* part; };
+struct EminList { const char* base[8]; size_t stride[8]; int nt[8]; int R, C; int* part; };
 __global__ __launch_bounds__(256) void h2_emin_list_kernel(EminList L) {
   __shared__ int red[8][4];
   const int f = blockIdx.y;

@@ -193,15 +193,15 @@ constexpr int LIN_PART_TILES = 6;     // tiles a question may touch in the PART 
 
 // RTL row tiles of 16 per workgroup: 4 for tall inputs; 1 for the [B,d] chain (B <= 128 rows), where 64-row workgroups
 // would leave a 32-workgroup grid on a 256-CU chip and the launch is pure latency.
+// one (16 RTL rows) x (16 columns) output tile of a LinP: tile (bx, by) of matrix z.  `red`: [4][16 RTL][20] floats of LDS.
+// Every thread of the workgroup must call it (barrier inside); callable more than once per kernel (a barrier guards `red`).
 template <int RTL, bool PART = false>
-__global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
+__device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by, int z, float (*red)[16 * RTL][20]) {
   constexpr int L_ROWS = 16 * RTL;
-  __shared__ float red[4][L_ROWS][20];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c0 = blockIdx.x * 16;
-  const int r0 = blockIdx.y * L_ROWS;
-  const int z = blockIdx.z;
+  const int c0 = bx * 16;
+  const int r0 = by * L_ROWS;
   const int li = lane & 15, lg = lane >> 4;
 
   f32x4 acc[RTL];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
         for (int j = 1; j < LIN_PART_TILES; ++j) sum += pvalid[j] ? pv[u][j] : f32x4{0.f, 0.f, 0.f, 0.f};
         af[u][0] = sum;
         const int Q = Q0 + 4 * u;
-        if (blockIdx.x == 0 && Q < nQ && r0 + li < p.rows)
+        if (bx == 0 && Q < nQ && r0 + li < p.rows)
           *reinterpret_cast<f32x4*>(p.part_sum + (size_t)(r0 + li) * p.Ktot + Q * 16 + lg * 4) = sum;
       }
     } else {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
   __syncthreads();
   const int r = tid >> 2, cq = (tid & 3) * 4;
   const int row = r0 + r;
-  if (r >= L_ROWS || row >= p.rows) return;
+  if (r < L_ROWS && row < p.rows) {
   f32x4 val, vald = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 4; ++e) val[e] = ((red[0][r][cq + e] + red[1][r][cq + e]) + red[2][r][cq + e]) + red[3][r][cq + e];
@@ -314,12 +314,86 @@ __global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
   }
   *reinterpret_cast<f32x4*>(p.out + (size_t)z * p.zout + (size_t)row * p.ldo + col) = val;
   if (p.use_drop == 2) *reinterpret_cast<f32x4*>(p.out_drop + (size_t)row * p.ld_od + col) = vald;
+  }
+}
+
+template <int RTL, bool PART = false>
+__global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
+  __shared__ float red[4][16 * RTL][20];
+  small_linear_tile<RTL, PART>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TWO dependent [B,d] linears in ONE launch (round 5): every output of `a` is an input of `b` (the write unit's new memory ->
+// the next step's projected memory, mac_cell.py:305-375 -> ops.py:679,688; backward: dL/dm_i -> the write unit's input gradients),
+// so the workgroups of the launch meet at a device-scope barrier between the two: a monotonic arrival counter in device memory
+// (zeroed on the caller's stream when the pass begins; every pair launch on it uses the same grid), one thread per workgroup:
+// release fence, agent-scope add, spin on an agent-scope load, acquire fence (L2 write-back / invalidate across XCDs -- what
+// cooperative-groups grid.sync() is made of).  Every workgroup of the grid must be resident at once: the
+// launcher refuses grids above 256 workgroups (one per CU; they hold 5 KB of LDS and 256 threads each).  The spin is BOUNDED: a
+// lost participant must not hang the device -- after ~2^22 polls the workgroup sets *fail (a word next to the counter, for a
+// debugger) and goes on with whatever it finds.
+//   tools/probes/grid_barrier_probe.hip measures the barrier against the launch boundary it replaces (profiles/r05_grid_barrier_probe.txt).
+// ---------------------------------------------------------------------------------------------------------------
+struct LinPairSync { uint32_t* counter; uint32_t* fail; };
+
+__device__ __forceinline__ void lin_pair_barrier(const LinPairSync& y) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    // the counter only ever grows, by gridDim.x per pair launch (launches on it are stream-ordered, so it is a multiple of
+    // gridDim.x whenever one starts): this workgroup's target is the next multiple above the value it found
+    const uint32_t old = __hip_atomic_fetch_add(y.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t target = (old / gridDim.x + 1u) * gridDim.x;
+    uint32_t spins = 0;
+    while (__hip_atomic_load(y.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22)) { __hip_atomic_store(y.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+// grid = nblk workgroups (1-D); tiles of `a` then of `b` are dealt round-robin: tile t -> (bx = t % ncol, by = t / ncol)
+template <bool PART_A>
+__global__ __launch_bounds__(256) void small_linear_pair_kernel(LinP a, LinP b, LinPairSync y) {
+  __shared__ float red[4][16][20];
+  const int nblk = gridDim.x;
+  {
+    const int ncol = a.n_out / 16, ntile = ncol * ((a.rows + 15) / 16);
+    for (int t = blockIdx.x; t < ntile; t += nblk) {
+      small_linear_tile<1, PART_A>(a, t % ncol, t / ncol, 0, red);
+      __syncthreads();
+    }
+  }
+  lin_pair_barrier(y);
+  {
+    const int ncol = b.n_out / 16, ntile = ncol * ((b.rows + 15) / 16);
+    for (int t = blockIdx.x; t < ntile; t += nblk) {
+      small_linear_tile<1, false>(b, t % ncol, t / ncol, 0, red);
+      __syncthreads();
+    }
+  }
 }
 
 inline hipError_t small_linear_part_launch(const LinP& p, hipStream_t st) {
   if (!p.part || !p.part_sum || p.rows > 128 || p.part_shift < 4 || p.part_shift > 6 ||
       ((p.part_N - 2) >> p.part_shift) + 2 > LIN_PART_TILES) return hipErrorInvalidValue;
   hipLaunchKernelGGL((small_linear_kernel<1, true>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+// a then b in one launch (see small_linear_pair_kernel); both with rows <= 128; `part_a`: a is in the PART form
+inline int& lin_pair_grid() { static int g = 128; return g; }      // workgroups of a pair launch (macx_debug_set(11, 0 | 32 .. 256); 0 = no pairs)
+inline hipError_t small_linear_pair_launch(const LinP& a, const LinP& b, bool part_a, const LinPairSync& y, hipStream_t st) {
+  const int g = lin_pair_grid();
+  if (a.rows > 128 || b.rows > 128 || g < 1 || g > 256 || !y.counter || !y.fail) return hipErrorInvalidValue;
+  if (part_a) {
+    if (!a.part || !a.part_sum || a.part_shift < 4 || a.part_shift > 6 || ((a.part_N - 2) >> a.part_shift) + 2 > LIN_PART_TILES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(small_linear_pair_kernel<true>, dim3(g), dim3(256), 0, st, a, b, y);
+  } else {
+    hipLaunchKernelGGL(small_linear_pair_kernel<false>, dim3(g), dim3(256), 0, st, a, b, y);
+  }
   return hipGetLastError();
 }
 inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
@@ -352,13 +426,33 @@ __global__ void drop2_kernel(const float* __restrict__ x, int rows, int d, uint3
 }
 
 // initial state (mac_cell.py:496-505): PRM -> tile the [d] variable, ZERO, Q -> copy vecQuestions
-__global__ void init_state_kernel(int mode, const float* __restrict__ prm, const float* __restrict__ vecQ, int rows, int d, float* out) {
+// ... both states of a run in one launch, plus the forward pass's pair-launch arrival counter (4 words, zeroed; may be null)
+__global__ void init_states_kernel(int mode_c, const float* __restrict__ prm_c, float* out_c, int mode_m, const float* __restrict__ prm_m,
+                                   float* out_m, const float* __restrict__ vecQ, int rows, int d, uint32_t* sync) {
   const int n = rows * d;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float q = (mode_c == 2 || mode_m == 2) ? vecQ[i] : 0.f;
+    out_c[i] = mode_c == 0 ? prm_c[i % d] : (mode_c == 2 ? q : 0.f);
+    out_m[i] = mode_m == 0 ? prm_m[i % d] : (mode_m == 2 ? q : 0.f);
+  }
+  if (sync && blockIdx.x == 0 && threadIdx.x < 4) sync[threadIdx.x] = 0u;
+}
+
+// start of a backward pass: the running gradients DM / DC [p + 1][rows * d] are zero except their last slab, which takes the
+// incoming dL/dm_p / dL/dc_p (null: zero); the words behind DC (pair-launch arrival counter) are zeroed.  One launch instead of a
+// fill and two copies.  DM and DC adjacent (DC == DM + (p + 1) n), `tail` words after DC.
+__global__ void bwd_init_kernel(float* DM, size_t slab, int p, const float* __restrict__ d_memory, const float* __restrict__ d_control, int tail) {
+  const size_t per = (size_t)(p + 1) * slab, total = 2 * per + (size_t)tail;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     float v = 0.f;
-    if (mode == 0) v = prm[i % d];
-    else if (mode == 2) v = vecQ[i];
-    out[i] = v;
+    if (i < 2 * per) {
+      const size_t w = i >= per ? i - per : i;
+      if (w >= (size_t)p * slab) {
+        const float* src = i >= per ? d_control : d_memory;
+        if (src) v = src[w - (size_t)p * slab];
+      }
+    }
+    DM[i] = v;
   }
 }
 

@@ -2,7 +2,9 @@
 gradients of the default one (summation orders differ, so not bit-for-bit):
   key 4 = 0   the read unit as per-product launches instead of the chain kernels
   key 5 = 0   S_b = X_b^T dI1_b once per step (delivering dy) instead of dy from the chain kernel + one deferred launch
-  key 6 = 1   the per-step dKB contraction on the internal side queue (fork / join by events) with accumulation in HBM"""
+  key 6 = 1   the per-step dKB contraction on the internal side queue (fork / join by events) with accumulation in HBM
+  key 8 = 1 / 0  dW1a / dW1b from the per-question S_b kernels (128 x 256 / 128 x 128 tiles) instead of the dual-A contraction over
+              the kept X * y (d % 256 == 0: the d = 256 and d = 512 cases)"""
 import pytest
 import torch
 
@@ -25,11 +27,11 @@ def run(macx, dev, name, B, S, N, d, p):
     return out
 
 
-@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1)])
-@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 5, 9, 196, 128, 3), ("args1", 4, 9, 49, 256, 4)])
+@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1), (8, 1), (8, 0)])
+@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 5, 9, 196, 128, 3), ("args1", 4, 9, 49, 256, 4), ("args", 3, 7, 196, 512, 3)])
 def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
     lib = macx._lib.lib()
-    defaults = {4: 1, 5: 1, 6: 0}
+    defaults = {4: 1, 5: 1, 6: 0, 8: 2}
     ref = run(macx, dev, name, B, S, N, d, p)
     assert lib.macx_debug_set(key, value) == 0
     try:
@@ -42,18 +44,21 @@ def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
         assert rel_err(got[k], ref[k], floor=floor) < 2e-5, k
 
 
-@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 3, 7, 196, 512, 2), ("args1", 4, 9, 49, 256, 3), ("args", 2, 5, 33, 512, 5)])
-def test_wgrad_pipeline_variants_are_bit_identical(macx, dev, name, B, S, N, d, p):
+@pytest.mark.parametrize("key,values,default", [(10, (0, 1), 2), (11, (0, 32, 256), 128)])
+@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 3, 7, 196, 512, 2), ("args1", 4, 9, 49, 256, 3), ("args", 2, 5, 33, 512, 5),
+                                            ("args3", 3, 6, 49, 128, 4), ("args", 64, 7, 20, 128, 3)])
+def test_launch_shape_knobs_are_bit_identical(macx, dev, key, values, default, name, B, S, N, d, p):
     """key 10: the all-steps weight-gradient contractions with round 4's loop (0), with a buffer's halves re-requested inside the
-    iteration (1) and with dW2 / dWx as one launch on top (2, the default) multiply the same fragments in the same order: every
-    gradient bit for bit."""
+    iteration (1) and with dW2 / dWx as one launch on top (2, the default) multiply the same fragments in the same order.
+    key 11: two dependent [B,d] linears as one launch with a device-scope barrier between them (32 / 128 / 256 workgroups) or as two
+    launches (0) compute the same tiles with the same code.  Final memory and every gradient bit for bit."""
     lib = macx._lib.lib()
     ref = run(macx, dev, name, B, S, N, d, p)
     try:
-        for v in (0, 1):
-            assert lib.macx_debug_set(10, v) == 0
+        for v in values:
+            assert lib.macx_debug_set(key, v) == 0
             got = run(macx, dev, name, B, S, N, d, p)
             for k in ref:
                 assert torch.equal(got[k], ref[k]), (v, k)
     finally:
-        assert lib.macx_debug_set(10, 2) == 0
+        assert lib.macx_debug_set(key, default) == 0
