@@ -536,7 +536,7 @@ int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, ui
  *          in flight); 2 (default) = 1 + dW2 and dWx as ONE launch (grid.y = 2)
  *   key 11 workgroups of a pair launch (two dependent [B,d] linears in one launch with a device-scope barrier between them:
  *          write-unit linear of step i + projY linear of step i + 1; dy linear of step i + write-unit backward linear of step i - 1);
- *          0: every linear its own launch; 16 .. 256 (default 128) */
+ *          0 (default): every linear its own launch -- pairs measured 2 - 13 % slower per step; 16 .. 256 */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

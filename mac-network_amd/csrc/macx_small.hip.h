@@ -384,7 +384,11 @@ inline hipError_t small_linear_part_launch(const LinP& p, hipStream_t st) {
   return hipGetLastError();
 }
 // a then b in one launch (see small_linear_pair_kernel); both with rows <= 128; `part_a`: a is in the PART form
-inline int& lin_pair_grid() { static int g = 128; return g; }      // workgroups of a pair launch (macx_debug_set(11, 0 | 32 .. 256); 0 = no pairs)
+// workgroups of a pair launch (macx_debug_set(11, 0 | 16 .. 256)); 0 = no pairs, the DEFAULT: measured (round 5, one box,
+// profiles/r05_pair_launch_ab.txt): the step is 2 % (128 workgroups) to 13 % (32) SLOWER with pairs than with one launch per linear
+// -- the barrier costs 1.6 us among 16 workgroups and 6.8 us among 128 (profiles/r05_grid_barrier_probe.txt: two device-scope
+// atomic round trips plus contention), a kernel boundary inside a replayed graph 1.56 us.  Kept behind the knob, bit-identical.
+inline int& lin_pair_grid() { static int g = 0; return g; }
 inline hipError_t small_linear_pair_launch(const LinP& a, const LinP& b, bool part_a, const LinPairSync& y, hipStream_t st) {
   const int g = lin_pair_grid();
   if (a.rows > 128 || b.rows > 128 || g < 1 || g > 256 || !y.counter || !y.fail) return hipErrorInvalidValue;

@@ -330,7 +330,10 @@ template <int KW, int JW, int PIPE = 0, bool DUAL = false>
 __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
   // grid.y = 2: two contractions of the same shape in ONE launch (dW2 and dWx of the cell's backward pass): the second one's
   // workgroups take the CUs the first one's free -- one ramp and one tail instead of two, one launch boundary less
-  const TnH2P& p = blockIdx.y ? p1 : p0;
+  // (dual launches are never paired: selecting between the two argument structs made the compiler copy BOTH to scratch in the dual
+  // variant -- 296 bytes per lane, every p.field a scratch load, and scratch loads count in vmcnt: each one drained the DMA queue.
+  // 1252 us per launch instead of ~200, gpurun_out/r5c2_kv8_kernel_stats.txt)
+  const TnH2P& p = DUAL ? p0 : (blockIdx.y ? p1 : p0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
   constexpr int KT = KW * T_TILE;

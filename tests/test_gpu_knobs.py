@@ -44,14 +44,14 @@ def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
         assert rel_err(got[k], ref[k], floor=floor) < 2e-5, k
 
 
-@pytest.mark.parametrize("key,values,default", [(10, (0, 1), 2), (11, (0, 32, 256), 128)])
+@pytest.mark.parametrize("key,values,default", [(10, (0, 1), 2), (11, (32, 128, 256), 0)])
 @pytest.mark.parametrize("name,B,S,N,d,p", [("args", 3, 7, 196, 512, 2), ("args1", 4, 9, 49, 256, 3), ("args", 2, 5, 33, 512, 5),
                                             ("args3", 3, 6, 49, 128, 4), ("args", 64, 7, 20, 128, 3)])
 def test_launch_shape_knobs_are_bit_identical(macx, dev, key, values, default, name, B, S, N, d, p):
     """key 10: the all-steps weight-gradient contractions with round 4's loop (0), with a buffer's halves re-requested inside the
     iteration (1) and with dW2 / dWx as one launch on top (2, the default) multiply the same fragments in the same order.
     key 11: two dependent [B,d] linears as one launch with a device-scope barrier between them (32 / 128 / 256 workgroups) or as two
-    launches (0) compute the same tiles with the same code.  Final memory and every gradient bit for bit."""
+    launches (0, the default: the pairs measured slower) compute the same tiles with the same code.  Final memory and every gradient bit for bit."""
     lib = macx._lib.lib()
     ref = run(macx, dev, name, B, S, N, d, p)
     try:
