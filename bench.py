@@ -768,9 +768,8 @@ def main():
                     # (tools/probes/mfma_probe.hip, profiles/r04_mfma_probe.txt): the matrix pipe's rate is data-dependent -- the chip
                     # clocks to its power budget -- 2440 TF on zero operands, 1880 TF on random ones; `peak` stays the guide's dense figure
                     "pipe_rate_random_operands_tflops": 1880.0 if mode == 2 else None,
-                    # chain kernel: the fp32 knowledge base in; dropout(KB), X, X * y (round 5: kept for the dW1a contraction), H1, I2
-                    # out as H2 (4 B per element) + keep bits; 4 weights
-                    "algorithmic_bytes_per_launch": ((1 + 5) * Bp * N * D * 4 + 2 * Bp * N * D // 8 + 4 * D * D * 4) if chain_ms is not None
+                    # chain kernel: the fp32 knowledge base in; dropout(KB), X, H1, I2 out as H2 (4 B per element) + keep bits; 4 weights
+                    "algorithmic_bytes_per_launch": ((1 + 4) * Bp * N * D * 4 + 2 * Bp * N * D // 8 + 4 * D * D * 4) if chain_ms is not None
                                                     else 2 * Bp * N * D * 4 + D * D * 4,
                     "in_step_kernel_ms": prof.get("in_step_kernel_ms"),
                     # the whole step priced by the REFERENCE's op count (3 p F per question) against the f32-input MFMA

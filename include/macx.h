@@ -526,9 +526,9 @@ int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, ui
  *          stream-ordered for the caller) -- measured slower, kept for the A/B; 4: the per-step dW2 contraction as a right-sized grid
  *          beside the chain kernels (also slower)
  *   key 7  K-loop variant of the chain kernels (-1 = default)      key 8  the read unit's interaction weight gradients dW1a / dW1b: 0 the 128 x 128 per-question S_b kernel, 1 the 128 x 256 one,
- *          2 (default) no per-question kernel -- the forward pass keeps X * y and both are one contraction over all rows with two
- *          A operands (where the chain kernels run and d % 256 == 0; else as 1).  Read when the FORWARD pass is enqueued as well
- *          (it decides whether X * y is kept): set it between whole steps only
+ *          (default); 2 no per-question kernel -- the forward pass keeps X * y and both are one contraction over all rows with two
+ *          A operands (where the chain kernels run and d % 256 == 0; else as 1): measured slower (twice the matrix work), kept for
+ *          the A/B.  Read when the FORWARD pass is enqueued as well (it decides whether X * y is kept): set it between whole steps
  *   key 9  0: the stem's 3 x 3 convolutions on kb_gemm3h_kernel; 1 (default): on kb_conv_chain_kernel where the shape allows
  *          (512 output channels, input channels a multiple of 256)
  *   key 10 the all-steps weight-gradient contractions (wgrad_h2_kernel<2,2>): 0 round 4's loop (a stage is requested one iteration
@@ -536,7 +536,9 @@ int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, ui
  *          in flight); 2 (default) = 1 + dW2 and dWx as ONE launch (grid.y = 2)
  *   key 11 workgroups of a pair launch (two dependent [B,d] linears in one launch with a device-scope barrier between them:
  *          write-unit linear of step i + projY linear of step i + 1; dy linear of step i + write-unit backward linear of step i - 1);
- *          0 (default): every linear its own launch -- pairs measured 2 - 13 % slower per step; 16 .. 256 */
+ *          0 (default): every linear its own launch -- pairs measured 2 - 13 % slower per step; 16 .. 256
+ *   key 12 1 (default): the [B,d] linears with a long reduction (K >= 1024, and the form that sums the chain kernel's dy partials
+ *          in its operand load) run 8 waves per workgroup (one batch of operand loads per wave instead of two); 0: 4 waves */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

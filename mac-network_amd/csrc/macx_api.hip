@@ -59,10 +59,14 @@ inline bool use_chain(int d, int N) { return h2_mode() && chain_mode() && chain_
 // dy from the chain kernel and S_b of all steps as one deferred launch; macx_debug_set(5, 0): sb_h2 once per step, as before
 inline int& sb_defer_mode() { static int m = 1; return m; }
 // the deferred S_b contraction on 128 x 256 tiles with summation by parts (sb_h2w_kernel); macx_debug_set(8, 0): the 128 x 128 kernel
-// ... 2 (default, round 5): not a per-question kernel at all -- the forward chain kernel keeps X * y, and dW1a = (X * y)^T dI1,
+// ... 2 (round 5): not a per-question kernel at all -- the forward chain kernel keeps X * y, and dW1a = (X * y)^T dI1,
 // dW1b = X^T dI1 are ONE plain contraction over all p B N rows with two A families (wgrad_h2_kernel's dual form) where the
 // shape allows (chain kernels, d % 256 == 0); else as 1
-inline int& sb_wide_mode() { static int m = 2; return m; }
+// MEASURED (round 5, profiles/r05_dual_contraction_ab.txt): the dual form is SLOWER -- 392 us against sb_h2w's 345 on the same box,
+// plus 2.4 us per chain_fwd launch for the X * y stores, 4.19 against 4.08 ms per step.  It executes the two outputs as two
+// contractions (474 GFLOP on the pipe, the rate of wgrad_h2: 2 x 200 us) where the per-question kernel gets both from ONE
+// (S_b, DESIGN 1 rewrite 2: 237 GFLOP).  Default stays 1; 2 is kept behind the knob, parity-tested.
+inline int& sb_wide_mode() { static int m = 1; return m; }
 // A second queue for the backward pass's contractions that nothing in the recurrence waits for (dKB of a step: 27 us of
 // full-chip matrix work).  Between two chain kernels the caller's stream runs ~100 us of [B,d]-sized launches that leave the
 // chip almost idle; the side queue was meant to fill exactly that.  Fork and join are events on the caller's stream, so for the
@@ -2942,6 +2946,7 @@ int macx_debug_set(int key, int value) {
   if (key == 9 && (value == 0 || value == 1)) { conv_chain_mode() = value; return MACX_OK; }
   if (key == 10 && value >= 0 && value <= 2) { wgrad_pipe_mode() = value; return MACX_OK; }
   if (key == 11 && (value == 0 || (value >= 16 && value <= 256))) { lin_pair_grid() = value; return MACX_OK; }
+  if (key == 12 && (value == 0 || value == 1)) { lin_wide_waves() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

@@ -195,7 +195,9 @@ constexpr int LIN_PART_TILES = 6;     // tiles a question may touch in the PART 
 // would leave a 32-workgroup grid on a 256-CU chip and the launch is pure latency.
 // one (16 RTL rows) x (16 columns) output tile of a LinP: tile (bx, by) of matrix z.  `red`: [4][16 RTL][20] floats of LDS.
 // Every thread of the workgroup must call it (barrier inside); callable more than once per kernel (a barrier guards `red`).
-template <int RTL, bool PART = false>
+// NWV: waves that share the tile's reduction dimension (4, or 8 for the inputs whose k-groups would otherwise take a wave two
+// dependent load batches: K >= 1024 and the PART form).
+template <int RTL, bool PART = false, int NWV = 4>
 __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by, int z, float (*red)[16 * RTL][20]) {
   constexpr int L_ROWS = 16 * RTL;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -230,13 +232,13 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
       pvalid[j] = t0 + j <= t1;
     }
   }
-  for (int Q0 = wave; Q0 < nQ; Q0 += 4 * PF) {
+  for (int Q0 = wave; Q0 < nQ; Q0 += NWV * PF) {
     f32x4 bf[PF], af[PF][RTL];
     if (PART) {
       f32x4 pv[PF][LIN_PART_TILES];
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
-        const int Q = min(Q0 + 4 * u, nQ - 1);
+        const int Q = min(Q0 + NWV * u, nQ - 1);
         bf[u] = *reinterpret_cast<const f32x4*>(Wz + (size_t)Q * 4 * p.n_out * 4);
 #pragma unroll
         for (int j = 0; j < LIN_PART_TILES; ++j) pv[u][j] = *reinterpret_cast<const f32x4*>(pbase[j] + Q * 16);
@@ -247,14 +249,14 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
 #pragma unroll
         for (int j = 1; j < LIN_PART_TILES; ++j) sum += pvalid[j] ? pv[u][j] : f32x4{0.f, 0.f, 0.f, 0.f};
         af[u][0] = sum;
-        const int Q = Q0 + 4 * u;
+        const int Q = Q0 + NWV * u;
         if (bx == 0 && Q < nQ && r0 + li < p.rows)
           *reinterpret_cast<f32x4*>(p.part_sum + (size_t)(r0 + li) * p.Ktot + Q * 16 + lg * 4) = sum;
       }
     } else {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int Q = min(Q0 + 4 * u, nQ - 1);
+      const int Q = min(Q0 + NWV * u, nQ - 1);
       int s = 0, koff = Q * 16;
       size_t rep_off = 0;
       if (p.rep_stride) {
@@ -273,7 +275,7 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      if (Q0 + 4 * u < nQ) {
+      if (Q0 + NWV * u < nQ) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -292,7 +294,11 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
   if (r < L_ROWS && row < p.rows) {
   f32x4 val, vald = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) val[e] = ((red[0][r][cq + e] + red[1][r][cq + e]) + red[2][r][cq + e]) + red[3][r][cq + e];
+  for (int e = 0; e < 4; ++e) {
+    float t = ((red[0][r][cq + e] + red[1][r][cq + e]) + red[2][r][cq + e]) + red[3][r][cq + e];
+    if constexpr (NWV == 8) t += ((red[4][r][cq + e] + red[5][r][cq + e]) + red[6][r][cq + e]) + red[7][r][cq + e];      // fixed order
+    val[e] = t;
+  }
   const int col = c0 + cq;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -317,10 +323,11 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
   }
 }
 
-template <int RTL, bool PART = false>
-__global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
-  __shared__ float red[4][16 * RTL][20];
-  small_linear_tile<RTL, PART>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
+template <int RTL, bool PART = false, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void small_linear_kernel(LinP p) {
+  static_assert(NWV == 4 || NWV == 8, "the cross-wave sum is written out for 4 and 8 waves");
+  __shared__ float red[NWV][16 * RTL][20];
+  small_linear_tile<RTL, PART, NWV>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -377,10 +384,15 @@ __global__ __launch_bounds__(256) void small_linear_pair_kernel(LinP a, LinP b, 
   }
 }
 
+// macx_debug_set(12, 0 | 1): 8-wave workgroups for the [B,d] linears whose reduction is long (K >= 1024, the PART form); A/B knob
+inline int& lin_wide_waves() { static int m = 1; return m; }
 inline hipError_t small_linear_part_launch(const LinP& p, hipStream_t st) {
   if (!p.part || !p.part_sum || p.rows > 128 || p.part_shift < 4 || p.part_shift > 6 ||
       ((p.part_N - 2) >> p.part_shift) + 2 > LIN_PART_TILES) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((small_linear_kernel<1, true>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(256), 0, st, p);
+  // 8 waves: a wave's 4 k-groups (of d / 16 = 32) are ONE batch of loads (6 partial rows + the weights per group) instead of two
+  // dependent ones
+  if (lin_wide_waves()) hipLaunchKernelGGL((small_linear_kernel<1, true, 8>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((small_linear_kernel<1, true>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(256), 0, st, p);
   return hipGetLastError();
 }
 // a then b in one launch (see small_linear_pair_kernel); both with rows <= 128; `part_a`: a is in the PART form
@@ -401,7 +413,9 @@ inline hipError_t small_linear_pair_launch(const LinP& a, const LinP& b, bool pa
   return hipGetLastError();
 }
 inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
-  if (p.rows <= 128) {
+  if (p.rows <= 128 && p.Ktot >= 1024 && lin_wide_waves()) {
+    hipLaunchKernelGGL((small_linear_kernel<1, false, 8>), dim3(p.n_out / 16, (p.rows + 15) / 16, nz), dim3(512), 0, st, p);
+  } else if (p.rows <= 128) {
     hipLaunchKernelGGL(small_linear_kernel<1>, dim3(p.n_out / 16, (p.rows + 15) / 16, nz), dim3(256), 0, st, p);
   } else {
     hipLaunchKernelGGL(small_linear_kernel<4>, dim3(p.n_out / 16, (p.rows + 63) / 64, nz), dim3(256), 0, st, p);

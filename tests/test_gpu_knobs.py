@@ -3,8 +3,9 @@ gradients of the default one (summation orders differ, so not bit-for-bit):
   key 4 = 0   the read unit as per-product launches instead of the chain kernels
   key 5 = 0   S_b = X_b^T dI1_b once per step (delivering dy) instead of dy from the chain kernel + one deferred launch
   key 6 = 1   the per-step dKB contraction on the internal side queue (fork / join by events) with accumulation in HBM
-  key 8 = 1 / 0  dW1a / dW1b from the per-question S_b kernels (128 x 256 / 128 x 128 tiles) instead of the dual-A contraction over
-              the kept X * y (d % 256 == 0: the d = 256 and d = 512 cases)"""
+  key 8 = 2 / 0  dW1a / dW1b from the dual-A contraction over the kept X * y (d % 256 == 0: the d = 256 and d = 512 cases) / from the
+              128 x 128 per-question S_b kernel instead of the 128 x 256 one
+  key 12 = 0  the long-reduction [B,d] linears on 4 waves per workgroup instead of 8 (the cross-wave sum has a different order)"""
 import pytest
 import torch
 
@@ -27,11 +28,11 @@ def run(macx, dev, name, B, S, N, d, p):
     return out
 
 
-@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1), (8, 1), (8, 0)])
+@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1), (8, 2), (8, 0), (12, 0)])
 @pytest.mark.parametrize("name,B,S,N,d,p", [("args", 5, 9, 196, 128, 3), ("args1", 4, 9, 49, 256, 4), ("args", 3, 7, 196, 512, 3)])
 def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
     lib = macx._lib.lib()
-    defaults = {4: 1, 5: 1, 6: 0, 8: 2}
+    defaults = {4: 1, 5: 1, 6: 0, 8: 1, 12: 1}
     ref = run(macx, dev, name, B, S, N, d, p)
     assert lib.macx_debug_set(key, value) == 0
     try:

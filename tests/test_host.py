@@ -54,8 +54,7 @@ def test_check_and_sizing_without_gpu(macx):
     nokeep = L.macx_saved_floats(C.byref(o), C.byref(s), 0)
     h2 = L.macx_h2_floats(64 * 196, 512)
     assert 64 * 196 * 512 < h2 < 1.01 * 64 * 196 * 512
-    # (+ round 5: X * y of all 12 steps, kept only by a run that will be differentiated -- the dW1a contraction's operand)
-    assert (11 * 4 + 12) * h2 < keep - nokeep < (11 * 4 + 12) * h2 + 11 * 2 * (64 * 196 + 64) * 64 // 4 + 64
+    assert 11 * 4 * h2 < keep - nokeep < 11 * 4 * h2 + 11 * 2 * (64 * 196 + 64) * 64 // 4 + 64
     off, cnt = C.c_size_t(), C.c_size_t()
     assert L.macx_saved_segment(C.byref(o), C.byref(s), 1, macx._lib.SEG["att_kb"], C.byref(off), C.byref(cnt)) == 0
     assert cnt.value == 12 * 64 * 196
