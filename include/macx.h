@@ -537,8 +537,11 @@ int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, ui
  *   key 11 workgroups of a pair launch (two dependent [B,d] linears in one launch with a device-scope barrier between them:
  *          write-unit linear of step i + projY linear of step i + 1; dy linear of step i + write-unit backward linear of step i - 1);
  *          0 (default): every linear its own launch -- pairs measured 2 - 13 % slower per step; 16 .. 256
- *   key 12 1 (default): the [B,d] linears with a long reduction (K >= 1024, and the form that sums the chain kernel's dy partials
- *          in its operand load) run 8 waves per workgroup (one batch of operand loads per wave instead of two); 0: 4 waves */
+ *   key 12 1: the [B,d] linears with a long reduction (K >= 1024, and the form that sums the chain kernel's dy partials in its
+ *          operand load) run 8 waves per workgroup (one batch of operand loads per wave instead of two) -- no measurable gain;
+ *          0 (default): 4 waves
+ *   key 13 sb_h2w_kernel (key 8 = 1): 1 (default) one stage stream over all steps, the next step's tables built inside the loop;
+ *          0 the pipeline drained and re-primed per step */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

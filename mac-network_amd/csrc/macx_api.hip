@@ -2947,6 +2947,7 @@ int macx_debug_set(int key, int value) {
   if (key == 10 && value >= 0 && value <= 2) { wgrad_pipe_mode() = value; return MACX_OK; }
   if (key == 11 && (value == 0 || (value >= 16 && value <= 256))) { lin_pair_grid() = value; return MACX_OK; }
   if (key == 12 && (value == 0 || value == 1)) { lin_wide_waves() = value; return MACX_OK; }
+  if (key == 13 && (value == 0 || value == 1)) { sb_cont_mode() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

@@ -385,7 +385,9 @@ __global__ __launch_bounds__(256) void small_linear_pair_kernel(LinP a, LinP b, 
 }
 
 // macx_debug_set(12, 0 | 1): 8-wave workgroups for the [B,d] linears whose reduction is long (K >= 1024, the PART form); A/B knob
-inline int& lin_wide_waves() { static int m = 1; return m; }
+// MEASURED (round 5, profiles/r05_wide_linear_ab.txt): the dy-summing form 11.5 -> 10.9 us, the step unchanged within 0.1 % --
+// the default stays 4 waves (the summation order the committed parity margins were taken on)
+inline int& lin_wide_waves() { static int m = 0; return m; }
 inline hipError_t small_linear_part_launch(const LinP& p, hipStream_t st) {
   if (!p.part || !p.part_sum || p.rows > 128 || p.part_shift < 4 || p.part_shift > 6 ||
       ((p.part_N - 2) >> p.part_shift) + 2 > LIN_PART_TILES) return hipErrorInvalidValue;

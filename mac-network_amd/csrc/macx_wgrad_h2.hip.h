@@ -955,13 +955,26 @@ constexpr int SBW_RING = 3;
 constexpr int SBW_MAXQ = 4;                            // questions per workgroup
 constexpr int SBW_MAXROWS = 1024;                      // factor-table rows (SBW_MAXQ questions of <= 256 rows)
 
+// CONT (round 5): ONE stage stream over all steps instead of a pipeline that is drained, re-primed and given fresh tables at every
+// step.  The phase knobs priced the per-step restart at ~100 of the kernel's 350 us (profiles/r05_phase_knobs.txt: 99 us with both
+// the products and the in-loop DMA skipped): per step two clamped stage re-reads past the end, a full drain, and tables() -- two
+// rounds of global loads and three barriers -- in front of the first product.  Here stage g + 2 is requested while stage g is
+// multiplied across step boundaries (nothing is requested twice, nothing drains), and the tables of step i + 1 (a second table
+// set in LDS) are built INSIDE step i's loop, spread over its first three iterations behind their barriers: iteration 0 presets the
+// minima, iteration 1 requests every row's exponent bytes and the y values (inline assembly, so that the explicit vmcnt(6) that
+// already ends the iteration covers them -- a load the compiler knows about would be waited for with vmcnt(0) and drain the two
+// stages in flight) and folds them into the questions' minima, iteration 2 writes the row factors.  Same products, folds and
+// order as the per-step form: bit-identical results.
+constexpr int SBW_TABLES = SBW_MAXROWS * 2 + SBW_MAXQ * T_TILE * 4 + 4 * SBW_MAXQ * 4;      // one table set: ftab | ytab | qmn (16-byte multiple)
+template <bool CONT>
 __global__ __launch_bounds__(512) void sb_h2w_kernel(SbH2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
-  uint16_t* ftab = reinterpret_cast<uint16_t*>(lds + SBW_RING * SBW_STAGE);                  // [questions][nchunk * 32]
-  float* ytab = reinterpret_cast<float*>(lds + SBW_RING * SBW_STAGE + SBW_MAXROWS * 2);      // [questions][128]
+  char* tab0 = lds + SBW_RING * SBW_STAGE;
+  uint16_t* ftab = reinterpret_cast<uint16_t*>(tab0);                                        // [questions][nchunk * 32]
+  float* ytab = reinterpret_cast<float*>(tab0 + SBW_MAXROWS * 2);                            // [questions][128]
   int* qmn = reinterpret_cast<int*>(ytab + SBW_MAXQ * T_TILE);                               // [2][questions] EX | EG of the step's questions
-  float* yold = reinterpret_cast<float*>(qmn + 3 * SBW_MAXQ);                                // [2][128] y of the question before (ytab is rebuilt per step)
+  float* yold = reinterpret_cast<float*>(tab0 + (CONT ? 2 : 1) * SBW_TABLES);                // [2][128] y of the question before (ytab is rebuilt per step)
 
   const int ntk = p.d / T_TILE, ntj = p.d / (2 * T_TILE);
   const int ntile = ntk * ntj;
@@ -1014,6 +1027,10 @@ __global__ __launch_bounds__(512) void sb_h2w_kernel(SbH2P p) {
   };
   // per step: the questions' common exponents (integer minima through LDS), the combined row factors (one table per dI1
   // column block of the tile: the chain kernels give a row ONE exponent, other producers one per 128 columns), y, units
+  // (the table set in use: CONT alternates between two sets by step parity, the per-step form only ever uses set 0)
+  uint16_t* ftab_c = ftab;
+  float* ytab_c = ytab;
+  int* qmn_c = qmn;
   auto tables = [&]() __attribute__((always_inline)) {
     if (tid < 3 * SBW_MAXQ) qmn[tid] = 127;
     __syncthreads();
@@ -1065,7 +1082,7 @@ __global__ __launch_bounds__(512) void sb_h2w_kernel(SbH2P p) {
   auto compute = [&](int buf, int qi, int ch) __attribute__((always_inline)) {
     const char* sa = lds + buf * SBW_STAGE + (wr * 4) * 1024;
     const char* sg = lds + buf * SBW_STAGE + 2 * WH_APL + (wc * 4) * 1024;
-    const uint16_t* ft = ftab + gq * (SBW_MAXROWS / 2) + qi * rows_q + ch * 32 + (lane >> 4) * 4;
+    const uint16_t* ft = ftab_c + gq * (SBW_MAXROWS / 2) + qi * rows_q + ch * 32 + (lane >> 4) * 4;
     const u32x2 f0 = *reinterpret_cast<const u32x2*>(ft), f1 = *reinterpret_cast<const u32x2*>(ft + 16);
     u32x4 gf[2][4];
 #pragma unroll
@@ -1124,6 +1141,113 @@ __global__ __launch_bounds__(512) void sb_h2w_kernel(SbH2P p) {
     ex_prev = ex_next; eg_prev = eg_next;
   };
 
+  if constexpr (CONT) {
+    const int G = p.nsteps * total;
+    auto issue_g = [&](int g_raw) __attribute__((always_inline)) {
+      const int g = min(g_raw, G - 1);
+      const int ist = g / total, sg = g - ist * total;
+      const int qi = sg / nchunk, ch = sg - qi * nchunk;
+      const int n = min(ch * 32 + sl_m, p.N - 1);
+      const uint32_t voff = (uint32_t)(((size_t)sl_kg * Rp + (size_t)(b_begin + qi) * p.N + n) * 16);
+      const uint32_t st = lds0 + (uint32_t)((g_raw % SBW_RING) * SBW_STAGE);
+      const char* xb = p.X.base + (size_t)ist * p.x_step;
+      const char* gb = p.dI1.base + (size_t)ist * p.g_step;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int u = wave * 2 + j, pl = u >> 3, ct = u & 7;
+        dma16b_s(xb + pl * xpb + (size_t)(tk * 16 + 2 * ct) * Rp * 16, voff, st + pl * WH_APL + ct * 1024);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int u = wave * 4 + j, pl = u >> 4, ct = u & 15;
+        dma16b_s(gb + pl * gpb + (size_t)(tj * 32 + 2 * ct) * Rp * 16, voff, st + 2 * WH_APL + pl * 2 * WH_APL + ct * 1024);
+      }
+    };
+    issue_g(0);
+    issue_g(1);
+    tables();                                               // step 0's, into set 0 (vX, vG, yS are step 0's)
+    wait_vmcnt<6>();                                        // stage 0 has landed (stage 1 may be in flight)
+    __syncthreads();
+    // this thread's share of the NEXT step's tables: one row of the workgroup's questions (nq * rows_q <= 512), one y value
+    const int nrows = nq * rows_q;
+    const int t_q = min(tid, nrows - 1) / rows_q, t_n = min(tid, nrows - 1) - t_q * rows_q;
+    const bool t_row = tid < nrows && t_n < p.N;
+    const size_t t_grow = (size_t)(b_begin + t_q) * p.N + min(t_n, p.N - 1);
+    const bool t_yv = tid < nq * T_TILE;
+    const size_t t_yoff = (size_t)(b_begin + (t_yv ? (tid >> 7) : 0)) * p.d + tk * T_TILE + (tid & 127);
+    int t_ex = 127, t_g0 = 127, t_g1 = 127;
+    float t_y = 0.f;
+    int step = 0, sg = 0, qi = 0, qch = 0;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+      const bool more = step + 1 < p.nsteps;
+      char* nset = tab0 + ((step + 1) & 1) * SBW_TABLES;
+      uint16_t* ftab_n = reinterpret_cast<uint16_t*>(nset);
+      float* ytab_n = reinterpret_cast<float*>(nset + SBW_MAXROWS * 2);
+      int* qmn_n = reinterpret_cast<int*>(ytab_n + SBW_MAXQ * T_TILE);
+      if (more && sg == 1) {
+        // the next step's exponent bytes of this thread's row and its y value: requested in front of this iteration's DMA, waited
+        // for by the vmcnt(6) that ends it
+        const H2View nX{const_cast<char*>(p.X.base) + (size_t)(step + 1) * p.x_step, p.X.R, p.X.C};
+        const H2View nG{const_cast<char*>(p.dI1.base) + (size_t)(step + 1) * p.g_step, p.dI1.R, p.dI1.C};
+        const int8_t* ax = nX.exps() + t_grow * xcb + tk;
+        const int8_t* ag = nG.exps() + t_grow * gcb + 2 * tj;
+        const float* ay = p.y + (size_t)(step + 1) * p.y_step + t_yoff;
+        asm volatile("global_load_sbyte %0, %1, off" : "=v"(t_ex) : "v"(ax) : "memory");
+        asm volatile("global_load_sbyte %0, %1, off" : "=v"(t_g0) : "v"(ag) : "memory");
+        asm volatile("global_load_sbyte %0, %1, off offset:1" : "=v"(t_g1) : "v"(ag) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(t_y) : "v"(ay) : "memory");
+      }
+      if (!(p.dbg & 2048)) issue_g(g + 2);                  // ring slot (g + 2) % 3 was last read in iteration g - 1
+      if (qch == 0) {
+        const float* yn = ytab_c + qi * T_TILE;
+        const int exn = min(qmn_c[qi], 126), egn = min(qmn_c[SBW_MAXQ + qi], 126);
+        if (pending) {
+          if (!(p.dbg & 512)) fold(yn, exn, egn);
+        } else {
+          keep_y(yn);
+          ex_prev = exn; eg_prev = egn;
+          pending = true;
+        }
+      }
+      if (!(p.dbg & 1024)) compute(g % SBW_RING, qi, qch);
+      if (p.dbg & 2048) wait_vmcnt<0>(); else wait_vmcnt<6>();      // stage g + 1 has landed (and this iteration's table loads); g + 2 stays in flight
+      if (more) {
+        if (sg == 0) {
+          if (tid < 3 * SBW_MAXQ) qmn_n[tid] = 127;
+        } else if (sg == 1) {
+          asm volatile("" : "+v"(t_ex), "+v"(t_g0), "+v"(t_g1), "+v"(t_y));
+          if (!t_row) { t_ex = 127; t_g0 = 127; t_g1 = 127; }
+          // the questions' minimum exponents (integer minima through LDS, as tables() does for step 0)
+          const int q_lo = min(tid & ~63, nrows - 1) / rows_q, q_hi = min(tid | 63, nrows - 1) / rows_q;
+          for (int q = q_lo; q <= q_hi; ++q) {
+            int mx = t_q == q ? t_ex : 127, mg = t_q == q ? min(t_g0, t_g1) : 127;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { mx = min(mx, __shfl_xor(mx, o, 64)); mg = min(mg, __shfl_xor(mg, o, 64)); }
+            if (lane == 0) { atomicMin(qmn_n + q, mx); atomicMin(qmn_n + SBW_MAXQ + q, mg); }
+          }
+        } else if (sg == 2) {
+          if (tid < nrows) {
+            const int bx = min(qmn_n[t_q], 126), bg = min(qmn_n[SBW_MAXQ + t_q], 126);
+            ftab_n[tid] = t_row ? (uint16_t)(pk_pow2_f16((bx - t_ex) + (bg - t_g0)) & 0xFFFFu) : (uint16_t)0;
+            ftab_n[(SBW_MAXROWS / 2) + tid] = t_row ? (uint16_t)(pk_pow2_f16((bx - t_ex) + (bg - t_g1)) & 0xFFFFu) : (uint16_t)0;
+          }
+          if (t_yv) ytab_n[tid] = t_y;
+        }
+      }
+      if (++qch == nchunk) { qch = 0; ++qi; }
+      if (++sg == total) {
+        sg = 0; qi = 0; ++step;
+        char* cset = tab0 + (step & 1) * SBW_TABLES;
+        ftab_c = reinterpret_cast<uint16_t*>(cset);
+        ytab_c = reinterpret_cast<float*>(cset + SBW_MAXROWS * 2);
+        qmn_c = reinterpret_cast<int*>(ytab_c + SBW_MAXQ * T_TILE);
+      }
+      __syncthreads();
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+  } else {
 #pragma unroll 1
   for (int step = 0; step < p.nsteps; ++step) {
     vX.base = p.X.base + (size_t)step * p.x_step; vG.base = p.dI1.base + (size_t)step * p.g_step;
@@ -1157,6 +1281,7 @@ __global__ __launch_bounds__(512) void sb_h2w_kernel(SbH2P p) {
       wait_vmcnt<0>();
     }
     __syncthreads();                                        // the ring and the tables are about to be reused
+  }
   }
   if (pending && !(p.dbg & 512)) fold(nullptr, ex_prev, eg_prev);     // y_{K+1} = 0; T stays in its unit
   const float scT = h2_unscale(ex_prev, eg_prev);
@@ -1196,14 +1321,26 @@ inline int sb_h2_wide_qpg(int B, int N, int d) {
   if (qpg > cap) qpg = cap;
   return qpg < 1 ? 1 : qpg;
 }
+inline int& sb_cont_mode() { static int m = 1; return m; }       // macx_debug_set(13, 0 | 1): sb_h2w_kernel per step / as one stage stream
 inline hipError_t sb_h2w_launch(const SbH2P& p, hipStream_t st) {
   const int nchunk = (p.N + 31) >> 5;
   if (p.qpg < 1 || p.qpg > SBW_MAXQ || p.qpg * nchunk * 32 > SBW_MAXROWS / 2 || p.d % 256 || p.dy_part || p.nsteps < 1) return hipErrorInvalidValue;
-  constexpr size_t lds = (size_t)SBW_RING * SBW_STAGE + SBW_MAXROWS * 2 + SBW_MAXQ * T_TILE * 4 + 3 * SBW_MAXQ * 4 + 2 * T_TILE * 4;
-  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2w_kernel), lds);
-  if (e != hipSuccess) return e;
   const int ngroup = (p.B + p.qpg - 1) / p.qpg;
-  hipLaunchKernelGGL(sb_h2w_kernel, dim3((p.d / 128) * (p.d / 256) * ngroup), dim3(512), lds, st, p);
+  // the continuous stage stream builds the next step's tables in iterations 0 - 2 of a step: at least three stages per step, and
+  // one table row per thread
+  const bool cont = sb_cont_mode() && p.nsteps > 1 && nchunk >= 3 && p.qpg * nchunk * 32 <= 512;
+  if (cont) {
+    constexpr size_t lds = (size_t)SBW_RING * SBW_STAGE + 2 * SBW_TABLES + 2 * T_TILE * 4;
+    static_assert(lds <= 160 * 1024, "two table sets fit beside the ring");
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2w_kernel<true>), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sb_h2w_kernel<true>, dim3((p.d / 128) * (p.d / 256) * ngroup), dim3(512), lds, st, p);
+    return hipGetLastError();
+  }
+  constexpr size_t lds = (size_t)SBW_RING * SBW_STAGE + SBW_TABLES + 2 * T_TILE * 4;
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(sb_h2w_kernel<false>), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(sb_h2w_kernel<false>, dim3((p.d / 128) * (p.d / 256) * ngroup), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 

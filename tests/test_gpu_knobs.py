@@ -5,7 +5,7 @@ gradients of the default one (summation orders differ, so not bit-for-bit):
   key 6 = 1   the per-step dKB contraction on the internal side queue (fork / join by events) with accumulation in HBM
   key 8 = 2 / 0  dW1a / dW1b from the dual-A contraction over the kept X * y (d % 256 == 0: the d = 256 and d = 512 cases) / from the
               128 x 128 per-question S_b kernel instead of the 128 x 256 one
-  key 12 = 0  the long-reduction [B,d] linears on 4 waves per workgroup instead of 8 (the cross-wave sum has a different order)"""
+  key 12 = 1  the long-reduction [B,d] linears on 8 waves per workgroup instead of 4 (the cross-wave sum has a different order)"""
 import pytest
 import torch
 
@@ -28,11 +28,11 @@ def run(macx, dev, name, B, S, N, d, p):
     return out
 
 
-@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1), (8, 2), (8, 0), (12, 0)])
+@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1), (8, 2), (8, 0), (12, 1)])
 @pytest.mark.parametrize("name,B,S,N,d,p", [("args", 5, 9, 196, 128, 3), ("args1", 4, 9, 49, 256, 4), ("args", 3, 7, 196, 512, 3)])
 def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
     lib = macx._lib.lib()
-    defaults = {4: 1, 5: 1, 6: 0, 8: 1, 12: 1}
+    defaults = {4: 1, 5: 1, 6: 0, 8: 1, 12: 0}
     ref = run(macx, dev, name, B, S, N, d, p)
     assert lib.macx_debug_set(key, value) == 0
     try:
@@ -45,14 +45,16 @@ def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
         assert rel_err(got[k], ref[k], floor=floor) < 2e-5, k
 
 
-@pytest.mark.parametrize("key,values,default", [(10, (0, 1), 2), (11, (32, 128, 256), 0)])
+@pytest.mark.parametrize("key,values,default", [(10, (0, 1), 2), (11, (32, 128, 256), 0), (13, (0,), 1)])
 @pytest.mark.parametrize("name,B,S,N,d,p", [("args", 3, 7, 196, 512, 2), ("args1", 4, 9, 49, 256, 3), ("args", 2, 5, 33, 512, 5),
                                             ("args3", 3, 6, 49, 128, 4), ("args", 64, 7, 20, 128, 3)])
 def test_launch_shape_knobs_are_bit_identical(macx, dev, key, values, default, name, B, S, N, d, p):
     """key 10: the all-steps weight-gradient contractions with round 4's loop (0), with a buffer's halves re-requested inside the
     iteration (1) and with dW2 / dWx as one launch on top (2, the default) multiply the same fragments in the same order.
     key 11: two dependent [B,d] linears as one launch with a device-scope barrier between them (32 / 128 / 256 workgroups) or as two
-    launches (0, the default: the pairs measured slower) compute the same tiles with the same code.  Final memory and every gradient bit for bit."""
+    launches (0, the default: the pairs measured slower) compute the same tiles with the same code.
+    key 13: sb_h2w_kernel as one stage stream over all steps (1) or drained and re-primed per step (0): same products, folds, order.
+    Final memory and every gradient bit for bit."""
     lib = macx._lib.lib()
     ref = run(macx, dev, name, B, S, N, d, p)
     try:
