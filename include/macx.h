@@ -533,7 +533,8 @@ int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, ui
  *          (512 output channels, input channels a multiple of 256)
  *   key 10 the all-steps weight-gradient contractions (wgrad_h2_kernel<2,2>): 0 round 4's loop (a stage is requested one iteration
  *          ahead); 1 a buffer's G / A halves are re-requested inside the iteration as soon as every wave has read them (two stages
- *          in flight); 2 (default) = 1 + dW2 and dWx as ONE launch (grid.y = 2)
+ *          in flight); 2 = 1 + dW2 and dWx as ONE launch (grid.y = 2); 3 (default) = 2 with half the reduction splits each (all of
+ *          the launch's workgroups resident at once; other split points: results differ from 0 - 2 in the last bits)
  *   key 11 workgroups of a pair launch (two dependent [B,d] linears in one launch with a device-scope barrier between them:
  *          write-unit linear of step i + projY linear of step i + 1; dy linear of step i + write-unit backward linear of step i - 1);
  *          0 (default): every linear its own launch -- pairs measured 2 - 13 % slower per step; 16 .. 256

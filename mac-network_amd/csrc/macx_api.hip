@@ -1719,6 +1719,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   CK(rs.run(st));
   if (phase == 1 || !(units & U_READ)) return MACX_OK;
 
+  int ns_w = (int)W.ns_big;          // reduction splits of the dW2 / dWx contractions (H2 family: decided below)
   // ---- read-unit weights: fixed-order reduction of the per-step slabs
   // dW2 = sum_i H1_i^T dI2_i and dWx = sum_i dropout_i(KB)^T dX_i: ONE contraction each over all
   // p*B*N rows (the per-step operands are kept; 288 GB of HBM makes that the cheap choice)
@@ -1745,7 +1746,11 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     }
     TnH2P t;
     memset(&t, 0, sizeof(t));
-    t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_big; t.rows_per_split = rows_per_split(t.M, t.nsplit);
+    // mode 3: the two contractions share ONE launch AND the chip -- half the reduction splits each, so that the 2 x 128 workgroups
+    // are all resident at once (one per CU) instead of 2 x 256 in two rounds: a workgroup's prologue, its 256 KB slab and the slab
+    // reduction's input are paid for once per CU instead of twice
+    ns_w = (!w2_side && wgrad_pipe_mode() >= 3 && wgrad_h2_kw(d) == 2 && wgrad_h2_jw(d) == 2 && W.ns_big >= 2) ? (int)W.ns_big / 2 : (int)W.ns_big;
+    t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = ns_w; t.rows_per_split = rows_per_split(t.M, t.nsplit);
     t.R = B * N;
     t.A = reinterpret_cast<const char*>(saved + L.H1); t.a_stride = L.act_stride * sizeof(float); t.a_mod = 0;
     t.G = reinterpret_cast<const char*>(ws + W.dI2); t.g_stride = W.act_floats * sizeof(float);
@@ -1814,8 +1819,8 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const int nslab1 = dual_run ? (int)W.ns_dual : (int)((h2_mode() && W.sb_deferred ? 1 : p) * W.ngroup);
   {
     SlabList sl;
-    sl.d[0] = SlabDesc{ws + W.slab_w2, (int)((h2_mode() && w2_side) ? W.side_ns : W.ns_big), dd / 4, GP->memKbProj2_W, 0};
-    sl.d[1] = SlabDesc{ws + W.slab_wx, (int)W.ns_big, dd / 4, GP->projX_W, 0};
+    sl.d[0] = SlabDesc{ws + W.slab_w2, (int)((h2_mode() && w2_side) ? W.side_ns : ns_w), dd / 4, GP->memKbProj2_W, 0};
+    sl.d[1] = SlabDesc{ws + W.slab_wx, ns_w, dd / 4, GP->projX_W, 0};
     sl.d[2] = SlabDesc{ws + W.slab_w1a, nslab1, dd / 4, GP->memKbProj_W, 0};
     sl.d[3] = SlabDesc{ws + W.slab_w1b, nslab1, dd / 4, GP->memKbProj_W + dd, 0};
     CK(slab_reduce_list_launch(sl, 4, dd, st));
@@ -2944,7 +2949,7 @@ int macx_debug_set(int key, int value) {
   if (key == 7 && value >= -1 && value <= 63) { chain_kv() = value; return MACX_OK; }
   if (key == 8 && value >= 0 && value <= 2) { sb_wide_mode() = value; return MACX_OK; }
   if (key == 9 && (value == 0 || value == 1)) { conv_chain_mode() = value; return MACX_OK; }
-  if (key == 10 && value >= 0 && value <= 2) { wgrad_pipe_mode() = value; return MACX_OK; }
+  if (key == 10 && value >= 0 && value <= 3) { wgrad_pipe_mode() = value; return MACX_OK; }
   if (key == 11 && (value == 0 || (value >= 16 && value <= 256))) { lin_pair_grid() = value; return MACX_OK; }
   if (key == 12 && (value == 0 || value == 1)) { lin_wide_waves() = value; return MACX_OK; }
   if (key == 13 && (value == 0 || value == 1)) { sb_cont_mode() = value; return MACX_OK; }

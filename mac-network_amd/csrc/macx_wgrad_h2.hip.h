@@ -322,9 +322,10 @@ __device__ __forceinline__ void dma4b(const char* g, char* lds_wave_base) {     
 // with RING = 2 the old loop had `vmcnt(0)` at the end of every iteration, i.e. every stage's full latency + transfer on the
 // critical path whenever it exceeded one iteration of products (round 4: 248 us against 134 compute-only / 146 DMA-only).
 // Same products in the same order: results are bit-identical to PIPE = 0.
-// 2 (default): PIPE = 1 and the two all-steps contractions of the backward pass as ONE launch (grid.y = 2); 1: PIPE = 1, one launch
-// each; 0: round 4's loop.  macx_debug_set(10, v): A/B in one process
-inline int& wgrad_pipe_mode() { static int m = 2; return m; }
+// 3 (default): as 2 with HALF the reduction splits per contraction (the caller's choice, macx_api.hip), so that both contractions'
+// workgroups are resident at once; 2: PIPE = 1 and the two all-steps contractions of the backward pass as ONE launch (grid.y = 2);
+// 1: PIPE = 1, one launch each; 0: round 4's loop.  macx_debug_set(10, v): A/B in one process
+inline int& wgrad_pipe_mode() { static int m = 3; return m; }
 
 template <int KW, int JW, int PIPE = 0, bool DUAL = false>
 __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {

@@ -28,11 +28,11 @@ def run(macx, dev, name, B, S, N, d, p):
     return out
 
 
-@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1), (8, 2), (8, 0), (12, 1)])
+@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1), (8, 2), (8, 0), (10, 2), (12, 1)])
 @pytest.mark.parametrize("name,B,S,N,d,p", [("args", 5, 9, 196, 128, 3), ("args1", 4, 9, 49, 256, 4), ("args", 3, 7, 196, 512, 3)])
 def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
     lib = macx._lib.lib()
-    defaults = {4: 1, 5: 1, 6: 0, 8: 1, 12: 0}
+    defaults = {4: 1, 5: 1, 6: 0, 8: 1, 10: 3, 12: 0}
     ref = run(macx, dev, name, B, S, N, d, p)
     assert lib.macx_debug_set(key, value) == 0
     try:
@@ -56,6 +56,8 @@ def test_launch_shape_knobs_are_bit_identical(macx, dev, key, values, default, n
     key 13: sb_h2w_kernel as one stage stream over all steps (1) or drained and re-primed per step (0): same products, folds, order.
     Final memory and every gradient bit for bit."""
     lib = macx._lib.lib()
+    if key == 10:
+        assert lib.macx_debug_set(10, 2) == 0       # (the default, 3, halves the reduction splits: another summation order)
     ref = run(macx, dev, name, B, S, N, d, p)
     try:
         for v in values:
@@ -64,4 +66,4 @@ def test_launch_shape_knobs_are_bit_identical(macx, dev, key, values, default, n
             for k in ref:
                 assert torch.equal(got[k], ref[k]), (v, k)
     finally:
-        assert lib.macx_debug_set(key, default) == 0
+        assert lib.macx_debug_set(key, 3 if key == 10 else default) == 0
