@@ -1404,6 +1404,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         g.A = h2_view(ws + W.dX + (size_t)i0 * W.act_floats, B * N, d); g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
         g.Wh = reinterpret_cast<const char*>(ws + W.wxT_p); g.w_exp = reinterpret_cast<const int*>(ws + W.wxT_p) + dd;
         g.nsteps = sq ? 1 : p; g.a_step_bytes = W.act_floats * sizeof(float);
+        g.a_row_exp = chain ? 1 : 0;          // chain_bwd_kernel gives a row of dX ONE exponent: the merged launch may fold once per step
         g.out_f32 = GI->knowledgeBase; g.ldo = d;
         const bool wd = dp->keep_write < 1.0f;
         g.dr = wd ? ws + W.dinfo : ws + W.dwin + d; g.ld_dr = wd ? d : win; g.dr_step = wd ? Bd : (size_t)B * win;
@@ -2953,6 +2954,7 @@ int macx_debug_set(int key, int value) {
   if (key == 11 && (value == 0 || (value >= 16 && value <= 256))) { lin_pair_grid() = value; return MACX_OK; }
   if (key == 12 && (value == 0 || value == 1)) { lin_wide_waves() = value; return MACX_OK; }
   if (key == 13 && (value == 0 || value == 1)) { sb_cont_mode() = value; return MACX_OK; }
+  if (key == 14 && (value == 0 || value == 1)) { dkb_uni_mode() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

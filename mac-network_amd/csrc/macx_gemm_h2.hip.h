@@ -52,6 +52,7 @@ struct GemmH2P {
   int nsteps; size_t a_step_bytes;
   size_t bits_step_words;   // uint32 words between the keep bits of consecutive steps
   size_t att_step, dr_step; // floats between att_i / dinfo_i of consecutive steps
+  int a_row_exp;            // E_DKB: every A tensor has ONE exponent per row (chain_bwd_kernel wrote it): the UNI kernel may fold per step
   int dbg;                  // measurement knobs (macx_debug_set(1, mask)): 1 skip the epilogue, 32 skip the in-loop staging,
                             // 64 skip the fragment reads + MFMAs, 256 return at once, 512 return in front of the K loop
 };
@@ -65,7 +66,11 @@ constexpr int kb_gemm_h2_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
-template <int RT, int BP, int EP, bool COLSUM>
+// UNI (E_DKB, K = 512 only; round 5): the A tensors carry ONE exponent per row -- what the chain kernels write (macx_chain_h2.hip.h)
+// -- so the four 128-wide K blocks of a step share their fold factor: the block accumulator runs through the whole step and is
+// folded (keep bits, row factor) ONCE per step instead of four times.  The phase knobs priced the loop's skeleton -- folds,
+// barriers, epilogue -- at 135 of the merged dKB launch's 335 us (profiles/r05_phase_knobs.txt); 36 of its 48 folds go away.
+template <int RT, int BP, int EP, bool COLSUM, bool UNI = false>
 __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
@@ -380,6 +385,38 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
       if (kt + 2 < nkt) wait_vmcnt_n(my_n); else wait_vmcnt<0>();    // slice kt + 1 has landed; slice kt + 2 may fly
       __syncthreads();
     };
+    if constexpr (UNI) {
+      // nk == 16: one fold per step, after its last slice; the 16 slices are written out (the zero-C variant of slice 0 and the
+      // accumulating variant of the other fifteen must not meet in a control-flow join, see below)
+      auto step_u = [&](auto first_c, int kt, bool last) __attribute__((always_inline)) {
+        if (kt + 2 < nkt && do_stage) issue(kt + 2);
+        if (do_compute) compute(kt % 3, first_c);
+        if (last) fold(kt >> 2);                          // (fold() takes a 128-wide block index: step = blk / nkb, table kb = 3 -- same factor as 0..2)
+        if (kt + 2 < nkt) wait_vmcnt_n(my_n); else wait_vmcnt<0>();
+        __syncthreads();
+      };
+      for (int kt = 0; kt < nkt; kt += 16) {
+        const int stp = kt >> 4;
+        step_u(FirstT{}, kt, false);
+        step_u(FirstF{}, kt + 1, false);
+        step_u(FirstF{}, kt + 2, false);
+        step_u(FirstF{}, kt + 3, false);
+        if (nsteps > 1 && stp + 1 < nsteps) issue_tables(stp + 1);       // older than the next slice DMA: landed by its wait
+        step_u(FirstF{}, kt + 4, false);
+        step_u(FirstF{}, kt + 5, false);
+        step_u(FirstF{}, kt + 6, false);
+        step_u(FirstF{}, kt + 7, false);
+        if (nsteps > 1 && stp + 1 < nsteps) convert_tables(stp + 1);
+        step_u(FirstF{}, kt + 8, false);
+        step_u(FirstF{}, kt + 9, false);
+        step_u(FirstF{}, kt + 10, false);
+        step_u(FirstF{}, kt + 11, false);
+        step_u(FirstF{}, kt + 12, false);
+        step_u(FirstF{}, kt + 13, false);
+        step_u(FirstF{}, kt + 14, false);
+        step_u(FirstF{}, kt + 15, true);
+      }
+    } else
     for (int kt = 0; kt < nkt; kt += 4) {
       if (EP == E_DKB && nsteps > 1) {
         // half-way through a step the fold factors of the next one are built (the other table; its global loads make
@@ -633,8 +670,21 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   }
 }
 
+inline int& dkb_uni_mode() { static int m = 1; return m; }        // macx_debug_set(14, 0 | 1): one fold per step in the merged dKB launch
 template <int RT, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_h2_launch_rt(const GemmH2P& p, hipStream_t st) {
+  if constexpr (EP == E_DKB && RT == 13 && BP == B_PLAIN && !COLSUM) {
+    if (p.a_row_exp && p.K == 512 && p.nsteps >= 1 && dkb_uni_mode()) {
+      auto kern = kb_gemm_h2_kernel<RT, BP, EP, COLSUM, true>;
+      constexpr size_t lds = (size_t)kb_gemm_h2_lds_bytes<RT>();
+      hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
+      if (e != hipSuccess) return e;
+      const int ncb = p.Nout / 128;
+      const int nrb = (p.N + RT * 16 - 1) / (RT * 16);
+      hipLaunchKernelGGL(kern, dim3(p.B * nrb * ncb), dim3(512), lds, st, p);
+      return hipGetLastError();
+    }
+  }
   auto kern = kb_gemm_h2_kernel<RT, BP, EP, COLSUM>;
   constexpr size_t lds = (size_t)kb_gemm_h2_lds_bytes<RT>();
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
