@@ -269,7 +269,7 @@ class MACCell:
         self.seed = fresh_seed(seed, bool(train))
         self.b0 = int(b0)
         self.params = params if params is not None else MACCellParams(self.config, self.netLength, device=self.knowledgeBase.device)
-        self.none = torch.zeros((self.batchSize, 1), dtype=torch.float32, device=self.knowledgeBase.device)
+        self._none = None           # the dummy cell input / output (mac_cell.py:75): allocated when first asked for (run() never does)
         self.iteration = 0
         self._run = None
 
@@ -300,6 +300,13 @@ class MACCell:
         self._att_gate = run.segment("att_gate", (s.p, s.B, s.d)) if self.opts.write_gate else None
 
     # ---- zero_state (mac_cell.py:539-592)
+    @property
+    def none(self):
+        """tf.zeros((batchSize, 1)): the cell's dummy input and output (mac_cell.py:75, :480)"""
+        if self._none is None:
+            self._none = torch.zeros((self.batchSize, 1), dtype=torch.float32, device=self.knowledgeBase.device)
+        return self._none
+
     def zero_state(self, batchSize=None, dtype=torch.float32):
         self._run = _Run(self, keep_activations=self._needs_grad())
         self._run.begin()
@@ -446,9 +453,9 @@ class PaddedMACCell:
         self.inner = MACCell(pad(vecQuestions), words_p, cntx_p, questionLengths, pad(knowledgeBase), memoryDropout, readDropout,
                              writeDropout, batchSize, train, reuse, config=wide, params=_PaddedParams(self.params, d, dp),
                              netLength=self.netLength, seed=seed, b0=b0, gemm=gemm, d_logical=d, mask_word=mask_word)
-        self.none = self.inner.none
         self.batchSize, self.train, self.seed, self.b0 = self.inner.batchSize, self.inner.train, self.inner.seed, self.inner.b0
 
+    none = property(lambda self: self.inner.none)
     iteration = property(lambda self: self.inner.iteration, lambda self, v: setattr(self.inner, "iteration", v))
     attentions = property(lambda self: self.inner.attentions)
 
