@@ -967,6 +967,52 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
     float* sDot = x.sPart + 64;         // [nq <= QS]
     for (int i = x.tid; i < D; i += 512) x.sW[i] = p.wk[i];
     for (int i = x.tid; i < nq * D; i += 512) x.sC[i] = p.c[(size_t)q0 * D + i];        // nq <= QS: the caller guarantees N >= 16
+    // row-block mapping (ChainCtx::convert_finish_blk): this lane's slot column and its eight rows
+    const int r8 = x.lane & 7, kq = x.lane >> 3;
+    const bool active = x.wave < KG / 8;
+    const int kg = active ? 8 * x.wave + kq : 0;
+    const size_t Rp = p.I2.Rp();
+    const size_t ipb = p.I2.plane_bytes();
+    const size_t tile = blockIdx.x;
+    const bool sums = p.dc_part != nullptr;
+    // (no keep bytes: any readable bytes stand in and are overridden -- a branch around a load costs a full wait per load)
+    const uint8_t* bytes_src = p.bytes2 ? p.bytes2 : reinterpret_cast<const uint8_t*>(p.I2.base);
+    const uint32_t bits_or = p.bytes2 ? 0u : 0xFFu;
+    float mx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the kept I2 slots, the keep bytes and the rows' scalars are requested three row blocks ahead of their use (all eight at
+    // once would hold 100 registers more than the kernel has).  Rows past the end lie in the tensors' pad rows
+    // (H2_PAD_ROWS = 64 = one tile): readable, never used
+    u32x4 raw[8][2];
+    uint32_t bits[8];
+    float dlr[8], inv[8];
+    int seg[8];
+    const char* src0 = p.I2.base + ((size_t)kg * Rp + x.grow0 + r8) * 16;
+    const uint8_t* b0 = bytes_src + (size_t)kg * Rp + x.grow0 + r8;
+    const int8_t* e0 = p.I2.exps() + (x.grow0 + r8) * CB + (kg >> 4);
+    const uint32_t g0 = (uint32_t)x.grow0 + r8, last = (uint32_t)M - 1, un = (uint32_t)p.N;
+    const uint32_t qb1 = (uint32_t)(q0 + 1) * un, qb2 = qb1 + un;       // first rows of the next two questions
+    // (round 5) the first three row blocks' loads -- I2 slots, keep bytes, exponent bytes, the rows' att / da -- are requested HERE, in
+    // front of the softmax-backward scalars below (two barriers and a round of global loads of their own), so that the tile's HBM
+    // burst runs under them; what needs the scalars (dl) is finished in fetch_b.  Only where all eight waves take part (d = 512): a
+    // load under `if (active)` would be drained at the join.
+    constexpr bool EARLY = (KV & 64) != 0 && (KG / 8) >= 8 && C::SB >= 3;       // KV & 64: A/B against the late form (macx_debug_set(7, 4))
+    int eraw[3];
+    float a_r[3], d_r[3];
+    auto fetch_a = [&](auto sb_c) __attribute__((always_inline)) {
+      constexpr int sb = decltype(sb_c)::value;
+      raw[sb][0] = *reinterpret_cast<const u32x4*>(src0 + sb * 128);
+      raw[sb][1] = *reinterpret_cast<const u32x4*>(src0 + ipb + sb * 128);
+      bits[sb] = (uint32_t)b0[sb * 8];
+      eraw[sb] = (int)e0[sb * 8 * CB];
+      const uint32_t gr = min(g0 + 8 * sb, last);
+      a_r[sb] = p.att[gr];
+      d_r[sb] = p.da[gr];
+    };
+    if constexpr (EARLY) {
+      fetch_a(std::integral_constant<int, 0>{});
+      fetch_a(std::integral_constant<int, 1>{});
+      fetch_a(std::integral_constant<int, 2>{});
+    }
     {
       // sum_j a_j da_j of each question the tile touches (every tile of a question: same order, same value).  All questions in
       // one pass: their loads are in flight together and the workgroup meets twice, not twice per question
@@ -995,30 +1041,6 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       }
       __syncthreads();
     }
-    // row-block mapping (ChainCtx::convert_finish_blk): this lane's slot column and its eight rows
-    const int r8 = x.lane & 7, kq = x.lane >> 3;
-    const bool active = x.wave < KG / 8;
-    const int kg = active ? 8 * x.wave + kq : 0;
-    const size_t Rp = p.I2.Rp();
-    const size_t ipb = p.I2.plane_bytes();
-    const size_t tile = blockIdx.x;
-    const bool sums = p.dc_part != nullptr;
-    // (no keep bytes: any readable bytes stand in and are overridden -- a branch around a load costs a full wait per load)
-    const uint8_t* bytes_src = p.bytes2 ? p.bytes2 : reinterpret_cast<const uint8_t*>(p.I2.base);
-    const uint32_t bits_or = p.bytes2 ? 0u : 0xFFu;
-    float mx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // the kept I2 slots, the keep bytes and the rows' scalars are requested three row blocks ahead of their use (all eight at
-    // once would hold 100 registers more than the kernel has).  Rows past the end lie in the tensors' pad rows
-    // (H2_PAD_ROWS = 64 = one tile): readable, never used
-    u32x4 raw[8][2];
-    uint32_t bits[8];
-    float dlr[8], inv[8];
-    int seg[8];
-    const char* src0 = p.I2.base + ((size_t)kg * Rp + x.grow0 + r8) * 16;
-    const uint8_t* b0 = bytes_src + (size_t)kg * Rp + x.grow0 + r8;
-    const int8_t* e0 = p.I2.exps() + (x.grow0 + r8) * CB + (kg >> 4);
-    const uint32_t g0 = (uint32_t)x.grow0 + r8, last = (uint32_t)M - 1, un = (uint32_t)p.N;
-    const uint32_t qb1 = (uint32_t)(q0 + 1) * un, qb2 = qb1 + un;       // first rows of the next two questions
     auto fetch = [&](auto sb_c) __attribute__((always_inline)) {
       constexpr int sb = decltype(sb_c)::value;
       raw[sb][0] = *reinterpret_cast<const u32x4*>(src0 + sb * 128);
@@ -1029,6 +1051,15 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       seg[sb] = nq <= 3 ? (int)(gr >= qb1) + (int)(gr >= qb2) : (int)(gr / un) - q0;
       const float dl_row = p.att[gr] * (p.da[gr] - sDot[seg[sb]]);
       dlr[sb] = 8 * sb + r8 < x.nvalid ? dl_row : 0.f;
+    };
+    auto fetch_b = [&](auto sb_c) __attribute__((always_inline)) {       // the rest of an early block: what needed the scalars
+      constexpr int sb = decltype(sb_c)::value;
+      if constexpr (sb < 3) {
+        inv[sb] = h2_pow2(-eraw[sb]);
+        const uint32_t gr = min(g0 + 8 * sb, last);
+        seg[sb] = nq <= 3 ? (int)(gr >= qb1) + (int)(gr >= qb2) : (int)(gr / un) - q0;
+        dlr[sb] = 8 * sb + r8 < x.nvalid ? a_r[sb] * (d_r[sb] - sDot[seg[sb]]) : 0.f;
+      }
     };
     float a_dw[8], a_db[8], a_dc[3][8];
 #pragma unroll
@@ -1070,9 +1101,15 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       // row blocks requested ahead of their use: three.  (Two for the identity activation, whose allocation is 8 - 13 registers over
       // the cap, was tried: 45 spilled registers -- the shorter body lets the scheduler hoist more of the next blocks' arithmetic.)
       constexpr int PFD = 3;
-      fetch(std::integral_constant<int, 0>{});
-      if constexpr (SBc > 1) fetch(std::integral_constant<int, 1>{});
-      if constexpr (SBc > 2 && PFD > 2) fetch(std::integral_constant<int, 2>{});
+      if constexpr (EARLY) {
+        fetch_b(std::integral_constant<int, 0>{});
+        fetch_b(std::integral_constant<int, 1>{});
+        fetch_b(std::integral_constant<int, 2>{});
+      } else {
+        fetch(std::integral_constant<int, 0>{});
+        if constexpr (SBc > 1) fetch(std::integral_constant<int, 1>{});
+        if constexpr (SBc > 2 && PFD > 2) fetch(std::integral_constant<int, 2>{});
+      }
       __builtin_amdgcn_sched_barrier(0);
       auto step = [&](auto sb_c) __attribute__((always_inline)) {
         constexpr int sb = decltype(sb_c)::value;
@@ -1299,7 +1336,7 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
         default: break;
       }
       // the measurement variants of the K loop exist for the published configurations' activation (ELU) only
-      if (p.act2 != ACT_ELU) return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
+      if (p.act2 != ACT_ELU) return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT | 64>(p, st);
       switch (p.dbg >> 3) {
         case 1: return chain_bwd_launch_a<512, 1, ACT_ELU>(p, st);
         case 3: return chain_bwd_launch_a<512, 3, ACT_ELU>(p, st);
@@ -1307,8 +1344,9 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
       }
       switch (chain_kv()) {
         case 0: return chain_bwd_launch_a<512, 0, ACT_ELU>(p, st);
+        case 4: return chain_bwd_launch_a<512, 4, ACT_ELU>(p, st);
         case 20: return chain_bwd_launch_a<512, 20, ACT_ELU>(p, st);
-        default: return chain_bwd_launch_a<512, CHAIN_KV_DEFAULT, ACT_ELU>(p, st);
+        default: return chain_bwd_launch_a<512, CHAIN_KV_DEFAULT | 64, ACT_ELU>(p, st);      // | 64: stage B0's first loads ahead of its scalars
       }
     default: return hipErrorInvalidValue;
   }

@@ -965,7 +965,10 @@ constexpr int SBW_MAXROWS = 1024;                      // factor-table rows (SBW
 // minima, iteration 1 requests every row's exponent bytes and the y values (inline assembly, so that the explicit vmcnt(6) that
 // already ends the iteration covers them -- a load the compiler knows about would be waited for with vmcnt(0) and drain the two
 // stages in flight) and folds them into the questions' minima, iteration 2 writes the row factors.  Same products, folds and
-// order as the per-step form: bit-identical results.
+// order as the per-step form: bit-identical results.  (Tried on top, not kept: a stage's G fragments read one iteration ahead,
+// behind the previous iteration's barrier and under its last products -- one loop-carried fragment set more, 5 spilled registers,
+// and a scratch reload inside this loop is a vmcnt(0): it drains both stages in flight every iteration.  The LDS-read exposure it
+// would hide is ~0.1 us of a 1.9 us stage.)
 constexpr int SBW_TABLES = SBW_MAXROWS * 2 + SBW_MAXQ * T_TILE * 4 + 4 * SBW_MAXQ * 4;      // one table set: ftab | ytab | qmn (16-byte multiple)
 template <bool CONT>
 __global__ __launch_bounds__(512) void sb_h2w_kernel(SbH2P p) {
