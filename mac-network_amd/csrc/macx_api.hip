@@ -2947,7 +2947,7 @@ int macx_debug_set(int key, int value) {
   if (key == 4 && (value == 0 || value == 1)) { chain_mode() = value; return MACX_OK; }
   if (key == 5 && (value == 0 || value == 1)) { sb_defer_mode() = value; return MACX_OK; }
   if (key == 6 && value >= 0 && value <= 4) { overlap_mode() = value; return MACX_OK; }
-  if (key == 7 && value >= -1 && value <= 127) { chain_kv() = value; return MACX_OK; }
+  if (key == 7 && value >= -1 && value <= 255) { chain_kv() = value; return MACX_OK; }
   if (key == 8 && value >= 0 && value <= 2) { sb_wide_mode() = value; return MACX_OK; }
   if (key == 9 && (value == 0 || value == 1)) { conv_chain_mode() = value; return MACX_OK; }
   if (key == 10 && value >= 0 && value <= 3) { wgrad_pipe_mode() = value; return MACX_OK; }
