@@ -324,38 +324,22 @@ struct ChainCtx {
   // lgkmcnt(0) then finds them long complete; requested in front, the wait sits between the request and the first
   // product).  KV & 8: static priority for the second-dispatched half of the workgroup (chain kernels set it once, at entry).
   // KV & 16: the 32 x 32 x 16 instruction (MF, a property of the context).
-  // KV & 128 (round 5): the weight fragments of a product's FIRST slice are requested by the caller ahead of the elementwise work
-  // that precedes the product (prefetch_w0, into 2 x CT registers of its own) instead of at the top of the K loop, where the
-  // L2 -> register round trip (~0.7 us, both waves of a SIMD in the same phase) sat in front of the first MFMA of every product.
-  typedef u32x4 WPre[2][CT];
-  __device__ __forceinline__ void prefetch_w0(WPre& pre, const char* W) const {
-    const char* wb = W + ((size_t)lg * D + colbase + li) * 16;
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int c = 0; c < CT; ++c) pre[pl][c] = *reinterpret_cast<const u32x4*>(wb + ((size_t)pl * 4 * D) * 16 + c * 256);
-  }
   template <int KV>
   __device__ __forceinline__ void kloop(f32x4 (&acc)[RT][CT], const char* W) const {
-    WPre none;
     if constexpr (MF) kloop32<KV>(acc, W);
-    else kloop16<KV, false>(acc, W, none);
+    else kloop16<KV>(acc, W);
   }
-  // ... with the first slice's weight fragments already requested into `pre` (by reference and a compile-time flag: handed over as
-  // a pointer the array went to scratch)
   template <int KV>
-  __device__ __forceinline__ void kloop_pre(f32x4 (&acc)[RT][CT], const char* W, const WPre& pre) const {
-    if constexpr (MF) kloop32<KV>(acc, W);
-    else kloop16<KV, (KV & 128) != 0>(acc, W, pre);
-  }
-  template <int KV, bool PRE>
-  __device__ __forceinline__ void kloop16(f32x4 (&acc)[RT][CT], const char* W, const WPre& pre) const {
+  __device__ __forceinline__ void kloop16(f32x4 (&acc)[RT][CT], const char* W) const {
     constexpr int KM = KV & 3;
     constexpr bool MID = (KV & 4) != 0 && RT >= 2;
     const char* wb = W + ((size_t)lg * D + colbase + li) * 16;
     const char* pa = P + ((size_t)lg * R + rowbase + li) * 16;
     // both operands of slice kt + 1 are requested before slice kt is multiplied: the weight slots from L2 (about one slice of
-    // matrix work away), the activation slots from LDS
+    // matrix work away), the activation slots from LDS.  (Round 5 tried requesting a product's FIRST weight slice ahead of the
+    // elementwise work in front of the product -- 2 x CT registers carried through the epilogues -- instead of here, where its L2
+    // round trip sits in front of the first MFMA: chain_fwd 93.6 -> 93.2 us, chain_bwd 88.1 -> 88.7, the step unchanged
+    // (gpurun call 9); two waves per SIMD already cover it.  Not kept.)
     u32x4 bq[2][2][CT], aq[2][2][RT];        // [set][plane][tile]
     auto load_b = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
       constexpr int S = decltype(set_c)::value;
@@ -418,15 +402,7 @@ struct ChainCtx {
     using S1 = std::integral_constant<int, 1>;
     // the scheduler would sink a slice's loads to the end of the previous slice's products (shortest live range), i.e. to where
     // they are needed: the order "request slice kt + 1, multiply slice kt" is pinned
-    if constexpr (PRE) {
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) bq[0][pl][c] = pre[pl][c];
-    } else {
-      load_b(S0{}, 0, false);
-    }
-    load_a(S0{}, 0, false);
+    load_b(S0{}, 0, false); load_a(S0{}, 0, false);
     if (KM >= 2) { load_b(S1{}, 1, false); load_a(S1{}, 1, false); }
     auto half_step = [&](auto cur, auto nxt, int kn) __attribute__((always_inline)) {
       load_b(nxt, kn, true);
@@ -695,11 +671,8 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   const int M = p.M;
   if ((KV & 8) && x.wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched wave of each SIMD loses every arbitration otherwise
 
-  constexpr bool WPF = (KV & 128) != 0 && ((KV >> 4) & 1) == 0;
-  typename C::WPre wpre;
   // =====================================================================================================================
   // stage 0: the operand of the first product
-  if constexpr (WPF) x.prefetch_w0(wpre, p.mode == 0 ? p.Wx.planes : p.W1b.planes);       // lands under stage 0
   if (p.mode == 0) {
     float v[IT][8];
     float m = 0.f;
@@ -773,8 +746,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   // stage 1: X = KBd Wx + bx
   if (p.mode == 0) {
     x.zero_acc(acc);
-    if constexpr (WPF) x.template kloop_pre<KV>(acc, p.Wx.planes, wpre); else x.template kloop<KV>(acc, p.Wx.planes);
-    if constexpr (WPF) x.prefetch_w0(wpre, p.W1b.planes);                  // the next product's first slice: lands under this epilogue
+    x.template kloop<KV>(acc, p.Wx.planes);
     bias_act(std::integral_constant<int, ACT_NON>{}, x.sE, *p.Wx.exp, p.bx);
     x.rowmax(acc);
     __syncthreads();                       // every wave is done reading P; sMax is complete
@@ -787,8 +759,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   // =====================================================================================================================
   // stage 2: H1 = act(X W1b + (X * y) W1a + b1)
   x.zero_acc(acc);
-  if constexpr (WPF) x.template kloop_pre<KV>(acc, p.W1b.planes, wpre); else x.template kloop<KV>(acc, p.W1b.planes);
-  if constexpr (WPF) x.prefetch_w0(wpre, p.W1a.planes);                    // lands under the X * y conversion pass
+  x.template kloop<KV>(acc, p.W1b.planes);
   __syncthreads();                         // every wave is done reading X
   {
     float v[IT][8];
@@ -823,8 +794,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
         for (int q = 0; q < 4; ++q) acc[t][c][q] = ldexpf(acc[t][c][q], k);
     }
   }
-  if constexpr (WPF) x.template kloop_pre<KV>(acc, p.W1a.planes, wpre); else x.template kloop<KV>(acc, p.W1a.planes);
-  if constexpr (WPF) x.prefetch_w0(wpre, p.W2.planes);
+  x.template kloop<KV>(acc, p.W1a.planes);
   bias_act_any(p.act1, x.sE2, *p.W1a.exp, p.b1);
   x.rowmax(acc);
   __syncthreads();
@@ -836,7 +806,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   // =====================================================================================================================
   // stage 3: I2 = H1 W2 + b2 ; logits = dropout(act(I2 * c)) . w_k
   x.zero_acc(acc);
-  if constexpr (WPF) x.template kloop_pre<KV>(acc, p.W2.planes, wpre); else x.template kloop<KV>(acc, p.W2.planes);
+  x.template kloop<KV>(acc, p.W2.planes);
   bias_act(std::integral_constant<int, ACT_NON>{}, x.sE, *p.W2.exp, p.b2);
   x.rowmax(acc);
   {
@@ -928,9 +898,9 @@ inline hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
       }
       switch (chain_kv()) {
         case 0: return chain_fwd_launch_t<512, 0>(p, st);
-        case 4: case 68: return chain_fwd_launch_t<512, 4>(p, st);
+        case 4: return chain_fwd_launch_t<512, 4>(p, st);
         case 20: return chain_fwd_launch_t<512, 20>(p, st);
-        default: return chain_fwd_launch_t<512, CHAIN_KV_DEFAULT | 128>(p, st);        // | 128: first weight slices requested ahead (prefetch_w0)
+        default: return chain_fwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
       }
     default: return hipErrorInvalidValue;
   }
@@ -1201,11 +1171,8 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   const size_t tile = blockIdx.x;
   // =====================================================================================================================
   // stage B1: dI1 = (dI2 W2^T) * act'(H1), act' from the kept activation OUTPUT
-  constexpr bool WPF = (KV & 128) != 0 && ((KV >> 4) & 1) == 0;
-  typename C::WPre wpre;
   x.zero_acc(acc);
   x.template kloop<KV>(acc, p.W2T.planes);
-  if constexpr (WPF) x.prefetch_w0(wpre, p.W1aT.planes);                   // lands under stage B1's epilogue (act' from the kept H1)
   {
     const int eW = *p.W2T.exp;
     const size_t Rp = p.H1.Rp();
@@ -1249,8 +1216,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   // =====================================================================================================================
   // stage B2: dX = (dI1 W1a^T) * y + dI1 W1b^T   (ops.py:703: d(x*y)/dx = y per column, per question)
   x.zero_acc(acc);
-  if constexpr (WPF) x.template kloop_pre<KV>(acc, p.W1aT.planes, wpre); else x.template kloop<KV>(acc, p.W1aT.planes);
-  if constexpr (WPF) x.prefetch_w0(wpre, p.W1bT.planes);                   // lands under the dy sums and the * y pass
+  x.template kloop<KV>(acc, p.W1aT.planes);
   if (p.dy_part) {
     const int q0 = (int)((uint32_t)x.grow0 / (uint32_t)p.N), q1 = (int)(((uint32_t)x.grow0 + x.nvalid - 1) / (uint32_t)p.N);
     const int nq = q1 - q0 + 1;                          // <= 3: the caller asks for this only when N >= 32
@@ -1315,7 +1281,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       }
     }
   }
-  if constexpr (WPF) x.template kloop_pre<KV>(acc, p.W1bT.planes, wpre); else x.template kloop<KV>(acc, p.W1bT.planes);
+  x.template kloop<KV>(acc, p.W1bT.planes);
   {
     const int eW = *p.W1bT.exp;
 #pragma unroll
@@ -1373,7 +1339,7 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
         default: break;
       }
       // the measurement variants of the K loop exist for the published configurations' activation (ELU) only
-      if (p.act2 != ACT_ELU) return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT | 64 | 128>(p, st);
+      if (p.act2 != ACT_ELU) return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT | 64>(p, st);
       switch (p.dbg >> 3) {
         case 1: return chain_bwd_launch_a<512, 1, ACT_ELU>(p, st);
         case 3: return chain_bwd_launch_a<512, 3, ACT_ELU>(p, st);
@@ -1382,9 +1348,8 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
       switch (chain_kv()) {
         case 0: return chain_bwd_launch_a<512, 0, ACT_ELU>(p, st);
         case 4: return chain_bwd_launch_a<512, 4, ACT_ELU>(p, st);
-        case 68: return chain_bwd_launch_a<512, 68, ACT_ELU>(p, st);
         case 20: return chain_bwd_launch_a<512, 20, ACT_ELU>(p, st);
-        default: return chain_bwd_launch_a<512, CHAIN_KV_DEFAULT | 64 | 128, ACT_ELU>(p, st);      // | 64: stage B0's first loads ahead of its scalars; | 128: prefetch_w0
+        default: return chain_bwd_launch_a<512, CHAIN_KV_DEFAULT | 64, ACT_ELU>(p, st);      // | 64: stage B0's first loads ahead of its scalars
       }
     default: return hipErrorInvalidValue;
   }
