@@ -161,6 +161,15 @@ inline int write_in_dim(const macx_opts* o, int d) {
 }
 
 // ---- layout of `saved` ------------------------------------------------------------------------
+// The backward pass reads its weights in layouts of its own (transposes; H2 planes for the chain kernels): [wxT | w1aT | w1bT | w2T |
+// wyT | wmT | wqT | wqUT | wccT | wcc2T | wscT | wgT], the first region of the backward workspace layout (make_bwd).  A run that keeps
+// its activations packs them in the FORWARD pass's pack launch, into `saved` (round 5: one launch and its boundary less per step).
+inline size_t bwd_packs_floats(const macx_opts* o, const macx_shapes* s) {
+  const size_t d = s->d, p = s->p, win = write_in_dim(o, s->d);
+  return 4 * al4(wsize(d, d)) + al4(d * d) + al4(win * d) + al4(d * d) + al4((o->control_input_unshared ? p : 1) * d * d) +
+         al4(2 * d * d) + 3 * al4(d * d);
+}
+
 struct SavedLayout {
   size_t seg[MACX_SEG_COUNT];
   size_t seg_count[MACX_SEG_COUNT];
@@ -189,6 +198,7 @@ struct SavedLayout {
   size_t act_floats;                // floats of one such tensor (B*N*d, or the H2 size in h2 mode)
   size_t wmax;                      // h2: max |W| of projX, memKbProj2, W1a, W1b (4 floats)
   size_t pair_sync;                 // 4 words: arrival counter + fail flag of the forward pass's pair launches (macx_small.hip.h)
+  size_t bwd_packs;                 // keep: the backward pass's weight packs (bwd_packs_floats), written by the forward pack launch; else 0
   size_t total;
 };
 
@@ -252,6 +262,7 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.att_bits = take(pk * bits_floats);
   L.wmax = take(8 + 4 * 64);          // the four maxima (+ 4 spare), then absmax4's per-workgroup partials
   L.pair_sync = take(4);
+  L.bwd_packs = keep ? take(bwd_packs_floats(o, s)) : 0;
   L.total = off;
   return L;
 }
@@ -300,6 +311,7 @@ inline int sb_qpg(int B, int N = 0) {   // questions per workgroup group in the 
 struct BwdLayout {
   size_t wxT_p, w1aT_p, w1bT_p, w2T_p;
   size_t wyT, wmT, wqT, wqUT, wccT, wcc2T, wscT, wgT;
+  size_t packs_end;
   size_t dI2, dI1, dX, da;
   size_t DM;        // [p+1,B,d]  dL/d memories
   size_t DC;        // [p+1,B,d]  dL/d controls
@@ -359,6 +371,7 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.wqT = take(d * d);
   L.wqUT = take((o->control_input_unshared ? p : 1) * d * d);
   L.wccT = take(2 * d * d); L.wcc2T = take(d * d); L.wscT = take(d * d); L.wgT = take(d * d);
+  L.packs_end = off;                  // == bwd_packs_floats(o, s): the same region lives in `saved` when the forward pass packed it
   L.act_floats = h2_mode() ? al4(h2_floats(B * N, d)) : B * N * d;
   L.chain_sums = use_chain((int)d, (int)N) && N >= 32;
   L.sb_deferred = L.chain_sums && sb_defer_mode();
@@ -756,6 +769,9 @@ namespace {
 enum { U_CONTROL = 1, U_READ = 2, U_WRITE = 4, U_ALL = 7 };   // which units of a step an entry point runs
 
 // weights -> MFMA operand layout  (memKbProj rows [0,d) multiply x*y, rows [d,2d) multiply x: ops.py:718)
+struct Packer;
+int add_bwd_packs(Packer& pk, const macx_opts* o, const macx_shapes* s, const macx_params* P, float* wT, const BwdLayout& W,
+                  const float* saved, const SavedLayout& L, int units, hipStream_t st);
 int pack_forward_weights(const macx_opts* o, const macx_shapes* s, const macx_params* P, float* saved, const SavedLayout& L,
                          int keep, int units, hipStream_t st) {
   const int B = s->B, d = s->d, p = s->p;
@@ -784,6 +800,8 @@ int pack_forward_weights(const macx_opts* o, const macx_shapes* s, const macx_pa
       if (o->write_gate) pk.add(P->gate_W, d, 1, d, d, saved + L.wg_p);
       if (o->write_self_att) pk.add(P->selfCtrl_W, d, 1, d, d, saved + L.ws_p);
     }
+    // a run that keeps its activations will be differentiated: the backward pass's transposed packs ride this launch
+    if (keep && L.bwd_packs) CKI(add_bwd_packs(pk, o, s, P, saved + L.bwd_packs, make_bwd(o, s), saved, L, units, st));
     if (!(units & U_CONTROL)) return pk.n ? pk.run(st) : hipSuccess;
     pk.add(P->qInput_W, d, 1, d, d, saved + L.wq_p);
     if (o->control_feed_prev) {
@@ -1110,6 +1128,43 @@ struct UnitGrads {
   float* d_info_out = nullptr;          // write: dL/d(info) (before the write dropout)
 };
 
+// the backward pass's weight packs into `wT` (offsets: BwdLayout's first region), appended to the caller's pack list
+int add_bwd_packs(Packer& pk, const macx_opts* o, const macx_shapes* s, const macx_params* P, float* wT, const BwdLayout& W,
+                  const float* saved, const SavedLayout& L, int units, hipStream_t st) {
+  const int d = s->d, p = s->p;
+  const size_t dd = (size_t)d * d;
+  const int win = write_in_dim(o, d);
+  const int nU = o->control_input_unshared ? p : 1;
+
+    if (units & U_READ) {
+      pk.add(P->projX_W, 1, d, d, d, wT + W.wxT_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);            // Wx^T
+      if (use_chain(d, s->N)) {      // the chain kernel applies y to the accumulators: plain H2 weights
+        pk.add(P->memKbProj_W, 1, d, d, d, wT + W.w1aT_p, -1, -1, 3, saved + L.wmax + 2);       // W1a^T
+        pk.add(P->memKbProj_W + dd, 1, d, d, d, wT + W.w1bT_p, -1, -1, 3, saved + L.wmax + 3);  // W1b^T
+      } else {
+        pk.add(P->memKbProj_W, 1, d, d, d, wT + W.w1aT_p, -1, -1, wfmt_ymix());       // W1a^T
+        pk.add(P->memKbProj_W + dd, 1, d, d, d, wT + W.w1bT_p, -1, -1, wfmt_ymix());  // W1b^T
+      }
+      pk.add(P->memKbProj2_W, 1, d, d, d, wT + W.w2T_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);       // W2^T
+      pk.add(P->projY_W, 1, d, d, d, wT + W.wyT);              // Wy^T
+    }
+    if (units & U_WRITE) {
+      pk.add(P->newMemory_W, 1, d, d, win, wT + W.wmT);        // Wm^T: [d] -> [win]
+      if (o->write_gate) pk.add(P->gate_W, 1, d, d, d, wT + W.wgT);
+      if (o->write_self_att) pk.add(P->selfCtrl_W, 1, d, d, d, wT + W.wscT);
+    }
+    if (units & U_CONTROL) pk.add(P->qInput_W, 1, d, d, d, wT + W.wqT);
+    if ((units & U_CONTROL) && o->control_feed_prev) {
+      pk.add(P->contControl_W, 1, d, d, o->control_feed_inputs ? 2 * d : d, wT + W.wccT);   // Wc^T: [d] -> [d or 2d]
+      if (o->control_cont_act != MACX_ACT_NON) pk.add(P->contControl2_W, 1, d, d, d, wT + W.wcc2T);
+    }
+    for (int i = 0; i < ((units & U_CONTROL) ? nU : 0); ++i) {
+      if (pk.n == PACK_MAX) CK(pk.run(st));
+      pk.add(P->qInputU_W + (size_t)i * dd, 1, d, d, d, wT + W.wqUT + (size_t)i * dd);
+    }
+  return MACX_OK;
+}
+
 int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
                        const macx_inputs* in, const float* saved, size_t saved_floats, float* ws, size_t ws_floats,
                        const float* d_memory, const float* d_control, const macx_param_grads* GP,
@@ -1141,36 +1196,13 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   SideQueue* sq_w2 = (w2_side && phase != 2) ? sq_any : nullptr;
 
   if (phase != 2) {
-  // ---- weights in the layouts the backward kernels read
-  const int nU = o->control_input_unshared ? p : 1;
-  {
+  // ---- weights in the layouts the backward kernels read: packed by the forward pass's pack launch into `saved` when it kept its
+  //      activations (SavedLayout::bwd_packs), else here into the workspace
+  const bool packs_fwd = L.bwd_packs != 0;
+  const float* wT = packs_fwd ? saved + L.bwd_packs : ws;
+  if (!packs_fwd) {
     Packer pk;
-    if (units & U_READ) {
-      pk.add(P->projX_W, 1, d, d, d, ws + W.wxT_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);            // Wx^T
-      if (use_chain(d, s->N)) {      // the chain kernel applies y to the accumulators: plain H2 weights
-        pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, -1, -1, 3, saved + L.wmax + 2);       // W1a^T
-        pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, -1, -1, 3, saved + L.wmax + 3);  // W1b^T
-      } else {
-        pk.add(P->memKbProj_W, 1, d, d, d, ws + W.w1aT_p, -1, -1, wfmt_ymix());       // W1a^T
-        pk.add(P->memKbProj_W + dd, 1, d, d, d, ws + W.w1bT_p, -1, -1, wfmt_ymix());  // W1b^T
-      }
-      pk.add(P->memKbProj2_W, 1, d, d, d, ws + W.w2T_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);       // W2^T
-      pk.add(P->projY_W, 1, d, d, d, ws + W.wyT);              // Wy^T
-    }
-    if (units & U_WRITE) {
-      pk.add(P->newMemory_W, 1, d, d, win, ws + W.wmT);        // Wm^T: [d] -> [win]
-      if (o->write_gate) pk.add(P->gate_W, 1, d, d, d, ws + W.wgT);
-      if (o->write_self_att) pk.add(P->selfCtrl_W, 1, d, d, d, ws + W.wscT);
-    }
-    if (units & U_CONTROL) pk.add(P->qInput_W, 1, d, d, d, ws + W.wqT);
-    if ((units & U_CONTROL) && o->control_feed_prev) {
-      pk.add(P->contControl_W, 1, d, d, o->control_feed_inputs ? 2 * d : d, ws + W.wccT);   // Wc^T: [d] -> [d or 2d]
-      if (o->control_cont_act != MACX_ACT_NON) pk.add(P->contControl2_W, 1, d, d, d, ws + W.wcc2T);
-    }
-    for (int i = 0; i < ((units & U_CONTROL) ? nU : 0); ++i) {
-      if (pk.n == PACK_MAX) CK(pk.run(st));
-      pk.add(P->qInputU_W + (size_t)i * dd, 1, d, d, d, ws + W.wqUT + (size_t)i * dd);
-    }
+    CKI(add_bwd_packs(pk, o, s, P, ws, W, saved, L, units, st));
     CK(pk.run(st));
   }
 
@@ -1233,7 +1265,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       CK(hipGetLastError());
       dmnew = ws + W.tmpBd[2];
       // dL/dc_i += dzpre Wg^T
-      LinP gl = lin_basic(dzpre, d, d, B, ws + W.wgT, nullptr, d, MACX_ACT_NON, DC + (size_t)(i + 1) * Bd, d);
+      LinP gl = lin_basic(dzpre, d, d, B, wT + W.wgT, nullptr, d, MACX_ACT_NON, DC + (size_t)(i + 1) * Bd, d);
       gl.addend = DC + (size_t)(i + 1) * Bd; gl.ld_add = d;
       CK(small_linear_launch(gl, 1, st));
     }
@@ -1243,7 +1275,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       CK(hipGetLastError());
     }
     if (!(pair_bwd && i < p - 1)) {      // (below step p - 1 the dy-linear launch of step i + 1 already did it: pair launch)
-      LinP l = lin_basic(dwlin, d, d, B, ws + W.wmT, nullptr, win, MACX_ACT_NON, dwin, win);
+      LinP l = lin_basic(dwlin, d, d, B, wT + W.wmT, nullptr, win, MACX_ACT_NON, dwin, win);
       CK(small_linear_launch(l, 1, st));
     }
     // d(info) through the write dropout (mac_cell.py:463); without write dropout it is a column view of dwin
@@ -1372,13 +1404,13 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       } else {
       // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
       g.A = hdI2;
-      g.Wh = reinterpret_cast<const char*>(ws + W.w2T_p); g.w_exp = reinterpret_cast<const int*>(ws + W.w2T_p) + dd;
+      g.Wh = reinterpret_cast<const char*>(wT + W.w2T_p); g.w_exp = reinterpret_cast<const int*>(wT + W.w2T_p) + dd;
       g.out = hdI1; g.aux = hH1; g.act = o->read_mem_act;
       g.colsum_part = ws + W.db1_part + (size_t)i * B * nrb * d;
       CK((kb_gemm_h2_launch<B_PLAIN, E_MUL_DACT, true>(g, st)));
       // dX = dI1 (diag(y) W1a + W1b)^T ; dbx partials
       g.A = hdI1; g.Wh = nullptr; g.w_exp = nullptr;
-      g.Wt = ws + W.w1aT_p; g.Wt2 = ws + W.w1bT_p; g.w_max = saved + L.wmax + 2; g.y = y; g.ldy = d;
+      g.Wt = wT + W.w1aT_p; g.Wt2 = wT + W.w1bT_p; g.w_max = saved + L.wmax + 2; g.y = y; g.ldy = d;
       g.out = hdX;
       g.colsum_part = ws + W.dbx_part + (size_t)i * B * nrb * d;
       CK((kb_gemm_h2_launch<B_YMIX_COL, E_PLAIN, true>(g, st)));
@@ -1402,7 +1434,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       if (sq || i == 0) {
         const int i0 = sq ? i : 0;
         g.A = h2_view(ws + W.dX + (size_t)i0 * W.act_floats, B * N, d); g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
-        g.Wh = reinterpret_cast<const char*>(ws + W.wxT_p); g.w_exp = reinterpret_cast<const int*>(ws + W.wxT_p) + dd;
+        g.Wh = reinterpret_cast<const char*>(wT + W.wxT_p); g.w_exp = reinterpret_cast<const int*>(wT + W.wxT_p) + dd;
         g.nsteps = sq ? 1 : p; g.a_step_bytes = W.act_floats * sizeof(float);
         g.a_row_exp = chain ? 1 : 0;          // chain_bwd_kernel gives a row of dX ONE exponent: the merged launch may fold once per step
         g.out_f32 = GI->knowledgeBase; g.ldo = d;
@@ -1445,12 +1477,12 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
     const uint32_t* kb_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits + (size_t)i * L.bits_stride) : nullptr;
     // dI1 = (dI2 W2^T) * act'(H1) ; db1 partials
-    g.A = dI2_i; g.lda = d; g.Wp = ws + W.w2T_p;
+    g.A = dI2_i; g.lda = d; g.Wp = wT + W.w2T_p;
     g.out = ws + W.dI1; g.ldo = d; g.aux = H1; g.act = o->read_mem_act;
     g.colsum_part = ws + W.db1_part + (size_t)i * B * nrb * d;
     CK((kb_gemm<A_PLAIN, B_PLAIN, E_MUL_DACT, true>(g, st)));
     // dX = dI1 (diag(y) W1a + W1b)^T ; dbx partials
-    g.A = ws + W.dI1; g.Wp = ws + W.w1aT_p; g.Wp2 = ws + W.w1bT_p; g.y = y; g.ldy = d;
+    g.A = ws + W.dI1; g.Wp = wT + W.w1aT_p; g.Wp2 = wT + W.w1bT_p; g.y = y; g.ldy = d;
     g.out = dX_i; g.aux = nullptr;
     g.colsum_part = ws + W.dbx_part + (size_t)i * B * nrb * d;
     CK((kb_gemm<A_PLAIN, B_YMIX_COL, E_PLAIN, true>(g, st)));
@@ -1465,7 +1497,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       CK((gemm_split_mode() && !(kb_gemm_dbg() & 256)) ? sb6_wgrad_launch(q, st) : sb_wgrad_launch(q, st));   // dbg 256: f32 kernel
     }
     // dKB (+)= (dX Wx^T) * kbmask + att * dinfo
-    g.A = dX_i; g.Wp = ws + W.wxT_p; g.Wp2 = nullptr; g.y = nullptr;
+    g.A = dX_i; g.Wp = wT + W.wxT_p; g.Wp2 = nullptr; g.y = nullptr;
     g.out = GI->knowledgeBase; g.aux = dinfo; g.ld_aux = ld_dinfo; g.att = att_kb + (size_t)i * B * N;
     g.e_bits = kb_bits;
     g.accumulate = (i != p - 1);
@@ -1481,7 +1513,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     {
       // with self attention DM[i] already holds the parts later steps sent to this memory: accumulate
       const bool acc_prev = (units & U_WRITE) && (o->write_self_att || o->write_gate);
-      LinP l = lin_basic(DYi, d, d, B, ws + W.wyT, nullptr, d, MACX_ACT_NON, acc_prev ? ws + W.tmpBd[0] : dm_prev, d);
+      LinP l = lin_basic(DYi, d, d, B, wT + W.wyT, nullptr, d, MACX_ACT_NON, acc_prev ? ws + W.tmpBd[0] : dm_prev, d);
       l.use_drop = 1; l.drop_ld = dlog_of(s);
       l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp, SITE_MEM_VAR, 0)
                                            : make_drop(dp->keep_memory, dp, SITE_MEM, i);
@@ -1493,7 +1525,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       if (pair_bwd && i > 0 && !acc_prev) {
         // dL/dm_{i-1} (this launch's output) is the input of step i - 1's write-unit backward linear
         // [dm part | dinfo] = dwlin Wm^T (writeMemAct = NON, no gate: dwlin_{i-1} IS dL/dm_{i-1}): both in one launch
-        LinP lw = lin_basic(dwlin_all + (size_t)(i - 1) * Bd, d, d, B, ws + W.wmT, nullptr, win, MACX_ACT_NON,
+        LinP lw = lin_basic(dwlin_all + (size_t)(i - 1) * Bd, d, d, B, wT + W.wmT, nullptr, win, MACX_ACT_NON,
                             ws + W.dwin + (size_t)(i - 1) * B * win, win);
         uint32_t* sync = reinterpret_cast<uint32_t*>(ws + W.pair_sync);
         CK(small_linear_pair_launch(l, lw, part_form, LinPairSync{sync, sync + 1}, st));
@@ -1512,7 +1544,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       const int cin = o->control_feed_inputs ? 2 * d : d;
       const bool two = o->control_cont_act != MACX_ACT_NON;
       if (o->write_self_att && !o->write_self_att_cont) {
-        LinP l = lin_basic(ws + W.dsc + (size_t)i * Bd, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, DC + (size_t)(i + 1) * Bd, d);
+        LinP l = lin_basic(ws + W.dsc + (size_t)i * Bd, d, d, B, wT + W.wscT, nullptr, d, MACX_ACT_NON, DC + (size_t)(i + 1) * Bd, d);
         l.addend = DC + (size_t)(i + 1) * Bd; l.ld_add = d;
         CK(small_linear_launch(l, 1, st));
       }
@@ -1533,21 +1565,21 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       // parts of dL/dcc_i that did not come through the word attention
       if (!o->control_feed_prev_att) CK(axpy(ws + W.dccx + (size_t)(i + 1) * Bd, Bd, dcc_i, st));
       if (o->write_self_att && o->write_self_att_cont) {
-        LinP l = lin_basic(ws + W.dsc + (size_t)i * Bd, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, dcc_i, d);
+        LinP l = lin_basic(ws + W.dsc + (size_t)i * Bd, d, d, B, wT + W.wscT, nullptr, d, MACX_ACT_NON, dcc_i, d);
         l.addend = dcc_i; l.ld_add = d;
         CK(small_linear_launch(l, 1, st));
       }
       // through contControl(_2): dlin1 = (dcc Wc2^T) * act'(h)  or  dcc
       float* dlin1 = ws + W.dlin1 + (size_t)i * Bd;
       if (two) {
-        LinP l2 = lin_basic(dcc_i, d, d, B, ws + W.wcc2T, nullptr, d, MACX_ACT_NON, dlin1, d);
+        LinP l2 = lin_basic(dcc_i, d, d, B, wT + W.wcc2T, nullptr, d, MACX_ACT_NON, dlin1, d);
         l2.actgrad_src = saved + L.cc_h + (size_t)i * Bd; l2.actgrad_act = o->control_cont_act; l2.ld_ag = d;
         CK(small_linear_launch(l2, 1, st));
       } else {
         CK(dev_copy(dlin1, dcc_i, Bd * sizeof(float), st));
       }
       // dx = dlin1 Wc^T = [d prev | d cI_i]
-      LinP lx = lin_basic(dlin1, d, d, B, ws + W.wccT, nullptr, cin, MACX_ACT_NON, ws + W.dxc, cin);
+      LinP lx = lin_basic(dlin1, d, d, B, wT + W.wccT, nullptr, cin, MACX_ACT_NON, ws + W.dxc, cin);
       CK(small_linear_launch(lx, 1, st));
       float* dprev_dst = o->control_feed_prev_att ? DC + (size_t)i * Bd : (i == 0 ? DC : ws + W.dccx + (size_t)i * Bd);
       hipLaunchKernelGGL(copy_cols_drop_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dxc), cin, 0, B, d, 0u, no_drop(),
@@ -1580,7 +1612,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   if (units == U_ALL) {
   if (o->write_self_att && !o->write_self_att_cont && !o->control_feed_prev) {
     // selfControl = the NEW control: dL/dc_i += dsc_i Ws^T before the word attention is differentiated
-    LinP l = lin_basic(ws + W.dsc, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, DC + Bd, d);
+    LinP l = lin_basic(ws + W.dsc, d, d, B, wT + W.wscT, nullptr, d, MACX_ACT_NON, DC + Bd, d);
     l.seg[0].zstride = Bd; l.zout = Bd; l.addend = DC + Bd; l.ld_add = d; l.zadd = Bd;
     CK(small_linear_launch(l, p, st));
   }
@@ -1632,7 +1664,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     // the self-attention control projection reads contControl (== controlInput here) or the control:
     // d(source)_i += dsc_i Ws^T, in place, all steps in one launch
     float* dst = o->write_self_att_cont ? ws + W.dcc : DC + Bd;
-    LinP l = lin_basic(ws + W.dsc, d, d, B, ws + W.wscT, nullptr, d, MACX_ACT_NON, dst, d);
+    LinP l = lin_basic(ws + W.dsc, d, d, B, wT + W.wscT, nullptr, d, MACX_ACT_NON, dst, d);
     l.seg[0].zstride = Bd; l.zout = Bd; l.addend = dst; l.ld_add = d; l.zadd = Bd;
     if (o->write_self_att_cont && !o->control_feed_prev) CK(small_linear_launch(l, p, st));
     const float* src = o->write_self_att_cont ? saved + L.cc : controls + Bd;
@@ -1654,7 +1686,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     // dt = sum_i dcI_i WqU_i^T: one linear over K = p d (the per-step inputs read as one [B, p d] operand, the per-step
     // packed transposes are contiguous = one packed [p d, d] matrix)
     {
-      LinP li = lin_basic(ws + W.dcI, d, d, B, ws + W.wqUT, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
+      LinP li = lin_basic(ws + W.dcI, d, d, B, wT + W.wqUT, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
       li.Ktot = p * d;
       li.rep_stride = Bd;
       CK(small_linear_launch(li, 1, st));
@@ -1675,7 +1707,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   } else {
     hipLaunchKernelGGL(sum_parts_kernel, dim3(256), dim3(256), 0, st, (const float*)(ws + W.dcI), p, Bd, dcI_sum);
     CK(hipGetLastError());
-    LinP ls = lin_basic(dcI_sum, d, d, B, ws + W.wqUT, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
+    LinP ls = lin_basic(dcI_sum, d, d, B, wT + W.wqUT, nullptr, d, MACX_ACT_NON, ws + W.dt, d);
     CK(small_linear_launch(ls, 1, st));
     CKI(wgrad_impl(ctrl_t, d, dcI_sum, d, B, d, d, GP->qInputU_W, ws + W.small_slab, st));
     CK(rs.add(dcI_sum, B, d, d, GP->qInputU_b, st));
@@ -1684,7 +1716,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
                      ws + W.du);
   CK(hipGetLastError());
   {
-    LinP l = lin_basic(ws + W.du, d, d, B, ws + W.wqT, nullptr, d, MACX_ACT_NON, GI->vecQuestions, d);
+    LinP l = lin_basic(ws + W.du, d, d, B, wT + W.wqT, nullptr, d, MACX_ACT_NON, GI->vecQuestions, d);
     CK(small_linear_launch(l, 1, st));
   }
   CKI(wb.add(in->vecQuestions, d, ws + W.du, d, B, d, d, GP->qInput_W, st));

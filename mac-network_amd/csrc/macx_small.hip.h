@@ -32,7 +32,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int 
 //   fmt 2: dst[kt][j][32] fp32 k-major tiles (macx_gemm6.hip.h, B_YMIX_*: mixed in fp32, split while staging)
 //   fmt 3: H2 weight planes dst[kt][plane][g][Nout] x 16 B fp16 + the matrix exponent (macx_h2.hip.h, macx_gemm_h2.hip.h)
 struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; int fmt; const float* maxabs; float* exp_dst; };   // zero fill for k >= k_src or j >= n_src; exp_dst: where format 3 leaves its exponent (null: behind the planes)
-constexpr int PACK_MAX = 40;
+constexpr int PACK_MAX = 56;       // 56 x 64 B of kernel arguments
 struct PackList { PackDesc d[PACK_MAX]; };
 __global__ void pack_weights_kernel(PackList L) {
   const PackDesc q = L.d[blockIdx.y];
