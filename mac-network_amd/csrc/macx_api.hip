@@ -1345,7 +1345,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       g.e_inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
       if (chain) {
         // dl -> dI2 -> dI1 -> dX in one launch (macx_chain_h2.hip.h)
-        auto wref = [&](size_t off) { return ChainW{reinterpret_cast<const char*>(ws + off), reinterpret_cast<const int*>(ws + off) + dd}; };
+        auto wref = [&](size_t off) { return ChainW{reinterpret_cast<const char*>(wT + off), reinterpret_cast<const int*>(wT + off) + dd}; };
         ChainBwdP c;
         memset(&c, 0, sizeof(c));
         c.M = R; c.N = N; c.d = d;
