@@ -339,7 +339,9 @@ struct ChainCtx {
     // matrix work away), the activation slots from LDS.  (Round 5 tried requesting a product's FIRST weight slice ahead of the
     // elementwise work in front of the product -- 2 x CT registers carried through the epilogues -- instead of here, where its L2
     // round trip sits in front of the first MFMA: chain_fwd 93.6 -> 93.2 us, chain_bwd 88.1 -> 88.7, the step unchanged
-    // (gpurun call 9); two waves per SIMD already cover it.  Not kept.)
+    // (gpurun call 9); two waves per SIMD already cover it.  Not kept.  Neither was sending the LAST stage's stores (I2 forward, dX
+    // backward) out ahead of its final vector pass -- the logits pass, the column sums -- so that the pass runs while they drain:
+    // chain_fwd 96.1 -> 97.3 us, chain_bwd 91.7 -> 92.1 (call 11): the extra barrier costs what the overlap returns.)
     u32x4 bq[2][2][CT], aq[2][2][RT];        // [set][plane][tile]
     auto load_b = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
       constexpr int S = decltype(set_c)::value;
@@ -805,19 +807,10 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
 
   // =====================================================================================================================
   // stage 3: I2 = H1 W2 + b2 ; logits = dropout(act(I2 * c)) . w_k
-  // KV & 128 (round 5): the kernel's LAST stores -- I2, 128 KB per workgroup -- leave BEFORE the logits pass instead of after it, so that
-  // the pass (exp, keep bits, a dot product per row: ~2 us of vector work) runs while they drain; nothing follows this stage to
-  // hide them behind.  One barrier more, same arithmetic.
-  constexpr bool LATE = (KV & 128) != 0;
   x.zero_acc(acc);
   x.template kloop<KV>(acc, p.W2.planes);
   bias_act(std::integral_constant<int, ACT_NON>{}, x.sE, *p.W2.exp, p.b2);
   x.rowmax(acc);
-  if constexpr (LATE) {
-    __syncthreads();
-    x.emit(acc, false, p.I2);
-    x.publish_rows(x.sE2, C::PASS_EPI, p.I2);
-  }
   {
     const bool drop2 = p.thr2 < (1u << 24);
     auto logit_pass = [&](auto act_c) __attribute__((always_inline)) {
@@ -853,10 +846,8 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
     }
   }
   __syncthreads();
-  if constexpr (!LATE) {
-    x.emit(acc, false, p.I2);
-    x.publish_rows(x.sE2, C::PASS_EPI, p.I2);
-  }
+  x.emit(acc, false, p.I2);
+  x.publish_rows(x.sE2, C::PASS_EPI, p.I2);
   if (x.tid < x.nvalid) {
     const int w0 = (x.tid / C::RPW) * C::NWC;
     float s = x.sPart[w0 * R + x.tid];
@@ -911,8 +902,7 @@ inline hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
         case 0: return chain_fwd_launch_t<512, 0>(p, st);
         case 4: return chain_fwd_launch_t<512, 4>(p, st);
         case 20: return chain_fwd_launch_t<512, 20>(p, st);
-        case 68: return chain_fwd_launch_t<512, 4>(p, st);
-        default: return chain_fwd_launch_t<512, CHAIN_KV_DEFAULT | 128>(p, st);        // | 128: the last stores ahead of the logits pass
+        default: return chain_fwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
       }
     default: return hipErrorInvalidValue;
   }
@@ -1303,13 +1293,11 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       for (int c = 0; c < CT; ++c) acc[t][c] *= s;
     }
   }
-  constexpr bool LATE = (KV & 128) != 0 && C::NWR == 1;       // dX's stores leave before the column sums are taken (see chain_fwd stage 3)
-  if constexpr (!LATE) x.colsum(acc, p.dbx_part + tile * D);
+  x.colsum(acc, p.dbx_part + tile * D);
   x.rowmax(acc);
   __syncthreads();
   x.emit(acc, false, p.dX);
   x.publish_rows(x.sE2, C::PASS_EPI, p.dX);
-  if constexpr (LATE) x.colsum(acc, p.dbx_part + tile * D);
   x.colsum_finish(p.dbx_part + tile * D);
   if (C::NWR == 2 && p.dy_part) {                       // the two row halves of the dy partials (staged before the last product)
     const int nq = (int)(((uint32_t)x.grow0 + x.nvalid - 1) / (uint32_t)p.N) - (int)((uint32_t)x.grow0 / (uint32_t)p.N) + 1;
@@ -1353,7 +1341,7 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
         default: break;
       }
       // the measurement variants of the K loop exist for the published configurations' activation (ELU) only
-      if (p.act2 != ACT_ELU) return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT | 64 | 128>(p, st);
+      if (p.act2 != ACT_ELU) return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT | 64>(p, st);
       switch (p.dbg >> 3) {
         case 1: return chain_bwd_launch_a<512, 1, ACT_ELU>(p, st);
         case 3: return chain_bwd_launch_a<512, 3, ACT_ELU>(p, st);
@@ -1362,9 +1350,8 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
       switch (chain_kv()) {
         case 0: return chain_bwd_launch_a<512, 0, ACT_ELU>(p, st);
         case 4: return chain_bwd_launch_a<512, 4, ACT_ELU>(p, st);
-        case 68: return chain_bwd_launch_a<512, 68, ACT_ELU>(p, st);
         case 20: return chain_bwd_launch_a<512, 20, ACT_ELU>(p, st);
-        default: return chain_bwd_launch_a<512, CHAIN_KV_DEFAULT | 64 | 128, ACT_ELU>(p, st);      // | 64: stage B0's first loads ahead of its scalars; | 128: dX's stores ahead of the column sums
+        default: return chain_bwd_launch_a<512, CHAIN_KV_DEFAULT | 64, ACT_ELU>(p, st);      // | 64: stage B0's first loads ahead of its scalars
       }
     default: return hipErrorInvalidValue;
   }
