@@ -893,6 +893,12 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   const bool wdrop = dp->keep_write < 1.0f;
   float* info_raw = wdrop ? saved + L.info_raw + (size_t)i * Bd : info;
 
+  const bool pair_fwd = md_fused && pair_fwd_ok(o, s, units);
+  // (see the read unit below: the write unit's linear split into its memory half, computed beside projY, and its info half)
+  const bool split_w = units == U_ALL && !pair_fwd && lin_split_mode() && !o->write_gate && !o->write_self_att && write_in_dim(o, d) == 2 * d &&
+                       B <= 128;
+  float* t_half = saved + L.wlin + (size_t)i * Bd;       // (the pre-activation slot of this step: unused by this option set otherwise)
+
   // ---- control unit when it is recurrent (mac_cell.py:141-151, configs/args1.txt)
   if ((units & U_CONTROL) && o->control_feed_prev) {
     const float* prev = o->control_feed_prev_att ? controls + (size_t)i * Bd
@@ -928,13 +934,9 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md, dlog_of(s));
     CK(hipGetLastError());
   }
-  const bool pair_fwd = md_fused && pair_fwd_ok(o, s, units);
   // split write linear (round 5): m_{i+1} = act([m_i, info_i] Wm + bm) = act((m_i Wm_top + bm) + info_i Wm_bot).  The first half needs
   // m_i only -- like y_i -- so it is computed HERE, in the projY launch (a dual launch: twice the tiles, the same duration), and the
   // launch on the critical path behind the attention contracts over d instead of 2 d.  BOTH + proj without gate / self-attention.
-  const bool split_w = units == U_ALL && !pair_fwd && lin_split_mode() && !o->write_gate && !o->write_self_att && write_in_dim(o, d) == 2 * d &&
-                       B <= 128;
-  float* t_half = saved + L.wlin + (size_t)i * Bd;       // (the pre-activation slot of this step: unused by this option set otherwise)
   if (!(pair_fwd && i > 0)) {        // (from step 1 on, the previous step's pair launch also left y behind)
     LinP l = lin_basic(md, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON, y, d);
     if (split_w) {
