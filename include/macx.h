@@ -544,9 +544,7 @@ int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, ui
  *   key 13 sb_h2w_kernel (key 8 = 1): 1 (default) one stage stream over all steps, the next step's tables built inside the loop;
  *          0 the pipeline drained and re-primed per step
  *   key 14 the merged dKB launch (all steps' (dX_i Wx^T) * mask_i in one kernel): 1 (default) ONE fold of the block accumulator per
- *          step where the chain kernels produced dX (one exponent per row, d = 512); 0 a fold per 128-wide K block
- *   key 15 the write unit's linear (writeInputs = BOTH, no gate / self-attention): 1 (default) split -- its memory half is computed in
- *          the projY launch of the same step (both need m_i only), the launch behind the attention contracts over d; 0 one K = 2 d launch */
+ *          step where the chain kernels produced dX (one exponent per row, d = 512); 0 a fold per 128-wide K block */
 int macx_debug_set(int key, int value);
 
 const char* macx_strerror(int code);

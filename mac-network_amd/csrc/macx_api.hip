@@ -893,12 +893,6 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   const bool wdrop = dp->keep_write < 1.0f;
   float* info_raw = wdrop ? saved + L.info_raw + (size_t)i * Bd : info;
 
-  const bool pair_fwd = md_fused && pair_fwd_ok(o, s, units);
-  // (see the read unit below: the write unit's linear split into its memory half, computed beside projY, and its info half)
-  const bool split_w = units == U_ALL && !pair_fwd && lin_split_mode() && !o->write_gate && !o->write_self_att && write_in_dim(o, d) == 2 * d &&
-                       B <= 128;
-  float* t_half = saved + L.wlin + (size_t)i * Bd;       // (the pre-activation slot of this step: unused by this option set otherwise)
-
   // ---- control unit when it is recurrent (mac_cell.py:141-151, configs/args1.txt)
   if ((units & U_CONTROL) && o->control_feed_prev) {
     const float* prev = o->control_feed_prev_att ? controls + (size_t)i * Bd
@@ -934,17 +928,10 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md, dlog_of(s));
     CK(hipGetLastError());
   }
-  // split write linear (round 5): m_{i+1} = act([m_i, info_i] Wm + bm) = act((m_i Wm_top + bm) + info_i Wm_bot).  The first half needs
-  // m_i only -- like y_i -- so it is computed HERE, in the projY launch (a dual launch: twice the tiles, the same duration), and the
-  // launch on the critical path behind the attention contracts over d instead of 2 d.  BOTH + proj without gate / self-attention.
+  const bool pair_fwd = md_fused && pair_fwd_ok(o, s, units);
   if (!(pair_fwd && i > 0)) {        // (from step 1 on, the previous step's pair launch also left y behind)
     LinP l = lin_basic(md, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON, y, d);
-    if (split_w) {
-      LinP lt = lin_basic(m_prev, d, d, B, saved + L.wm_p, P->newMemory_b, d, MACX_ACT_NON, t_half, d);
-      CK(small_linear_dual_launch(l, lt, st));
-    } else {
-      CK(small_linear_launch(l, 1, st));
-    }
+    CK(small_linear_launch(l, 1, st));
   }
   // keep bits of the two [B,N,d] read-dropout sites of this step (ops.py:678 and ops.py:312 via :142)
   const bool rdrop = dp->keep_read < 1.0f;
@@ -1080,11 +1067,6 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     l.seg[1] = LinSeg{info, d, d, 0};
     l.Ktot = 2 * d;
     if (self_smry) { l.seg[2] = LinSeg{self_smry, d, d, 0}; l.Ktot = 3 * d; }
-    if (split_w) {
-      // the memory half (+ bias) is in t_half already: info_i Wm_bot on top of it (the packed rows k >= d of Wm follow the first d: k-major)
-      l = lin_basic(info, d, d, B, saved + L.wm_p + (size_t)d * d, nullptr, d, o->write_mem_act, wout, d);
-      l.pre_add = t_half; l.ld_pre = d;
-    }
     if (md_fused && i + 1 < s->p) {
       // the new memory is the next step's read-unit input: its two dropouts (mac_cell.py:214-217, ops.py:679) ride this epilogue
       l.use_drop = 2; l.drop_ld = dlog_of(s);
@@ -3005,7 +2987,6 @@ int macx_debug_set(int key, int value) {
   if (key == 12 && (value == 0 || value == 1)) { lin_wide_waves() = value; return MACX_OK; }
   if (key == 13 && (value == 0 || value == 1)) { sb_cont_mode() = value; return MACX_OK; }
   if (key == 14 && (value == 0 || value == 1)) { dkb_uni_mode() = value; return MACX_OK; }
-  if (key == 15 && (value == 0 || value == 1)) { lin_split_mode() = value; return MACX_OK; }
   if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
   if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
   return MACX_EINVAL;

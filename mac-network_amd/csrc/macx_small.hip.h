@@ -183,8 +183,6 @@ struct LinP {
   int drop_ld;                      // row stride of the dropout index: the logical width of a zero-padded cell; 0 = n_out
   float* out_drop; int ld_od;       // use_drop == 2: `out` keeps val, out_drop receives val*f1*f2 (the next consumer's dropped copy)
   const float* addend; int ld_add; size_t zadd;                      // val += addend
-  const float* pre_add; int ld_pre;                                  // val += pre_add BEFORE the activation and the dropout copy (a partial sum of the
-                                                                     // same pre-activation computed by another launch); not strided over z
   size_t rep_stride;
   // PART form (small_linear_part_launch): the input row of question b is the sum of the chain kernel's per-tile partials
   // part[tile][3][Ktot] over the 64-row tiles the question's `part_N` rows touch (macx_chain_h2.hip.h, dy_part) -- the reduction
@@ -307,7 +305,6 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
     float v = val[e];
     if (p.bias) v += p.bias[(size_t)z * p.zb + col + e];
     v += p.bias_const;
-    if (p.pre_add) v += p.pre_add[(size_t)row * p.ld_pre + col + e];
     v = act_apply(p.act, v);
     if (p.actgrad_src) v *= act_grad_from_out(p.actgrad_act, p.actgrad_src[(size_t)z * p.zag + (size_t)row * p.ld_ag + col + e]);
     if (p.use_drop) {
@@ -400,28 +397,6 @@ inline hipError_t small_linear_part_launch(const LinP& p, hipStream_t st) {
   else hipLaunchKernelGGL((small_linear_kernel<1, true>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(256), 0, st, p);
   return hipGetLastError();
 }
-// two INDEPENDENT [B,d] linears in one launch (no barrier: tiles of `a` then of `b` over the grid) -- the projY linear of a step and
-// the memory half of the same step's write-unit linear both read m_i only (round 5, lin_split_mode)
-__global__ __launch_bounds__(256) void small_linear_dual_kernel(LinP a, LinP b) {
-  __shared__ float red[4][16][20];
-  const int ncol_a = a.n_out / 16, ntile_a = ncol_a * ((a.rows + 15) / 16);
-  const int t = blockIdx.x;
-  if (t < ntile_a) {
-    small_linear_tile<1, false>(a, t % ncol_a, t / ncol_a, 0, red);
-  } else {
-    const int ncol_b = b.n_out / 16, u = t - ntile_a;
-    small_linear_tile<1, false>(b, u % ncol_b, u / ncol_b, 0, red);
-  }
-}
-inline hipError_t small_linear_dual_launch(const LinP& a, const LinP& b, hipStream_t st) {
-  if (a.rows > 128 || b.rows > 128) return hipErrorInvalidValue;
-  const int nt = (a.n_out / 16) * ((a.rows + 15) / 16) + (b.n_out / 16) * ((b.rows + 15) / 16);
-  hipLaunchKernelGGL(small_linear_dual_kernel, dim3(nt), dim3(256), 0, st, a, b);
-  return hipGetLastError();
-}
-// macx_debug_set(15, 0 | 1): the write unit's linear split into its memory half (computed beside projY, off the critical path)
-// and its info half (K = d instead of 2 d on the critical path)
-inline int& lin_split_mode() { static int m = 1; return m; }
 // a then b in one launch (see small_linear_pair_kernel); both with rows <= 128; `part_a`: a is in the PART form
 // workgroups of a pair launch (macx_debug_set(11, 0 | 16 .. 256)); 0 = no pairs, the DEFAULT: measured (round 5, one box,
 // profiles/r05_pair_launch_ab.txt): the step is 2 % (128 workgroups) to 13 % (32) SLOWER with pairs than with one launch per linear

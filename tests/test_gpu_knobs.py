@@ -6,7 +6,6 @@ gradients of the default one (summation orders differ, so not bit-for-bit):
   key 8 = 2 / 0  dW1a / dW1b from the dual-A contraction over the kept X * y (d % 256 == 0: the d = 256 and d = 512 cases) / from the
               128 x 128 per-question S_b kernel instead of the 128 x 256 one
   key 14 = 0  the merged dKB launch folding its block accumulator per 128-wide K block instead of once per step (d = 512)
-  key 15 = 0  the write unit's linear as one K = 2 d launch instead of split (memory half beside projY, info half behind the attention)
   key 12 = 1  the long-reduction [B,d] linears on 8 waves per workgroup instead of 4 (the cross-wave sum has a different order)"""
 import pytest
 import torch
@@ -30,11 +29,11 @@ def run(macx, dev, name, B, S, N, d, p):
     return out
 
 
-@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1), (8, 2), (8, 0), (10, 2), (12, 1), (14, 0), (15, 0)])
+@pytest.mark.parametrize("key,value", [(4, 0), (5, 0), (6, 1), (8, 2), (8, 0), (10, 2), (12, 1), (14, 0)])
 @pytest.mark.parametrize("name,B,S,N,d,p", [("args", 5, 9, 196, 128, 3), ("args1", 4, 9, 49, 256, 4), ("args", 3, 7, 196, 512, 3)])
 def test_knob_routes_agree(macx, dev, key, value, name, B, S, N, d, p):
     lib = macx._lib.lib()
-    defaults = {4: 1, 5: 1, 6: 0, 8: 1, 10: 3, 12: 0, 14: 1, 15: 1}
+    defaults = {4: 1, 5: 1, 6: 0, 8: 1, 10: 3, 12: 0, 14: 1}
     ref = run(macx, dev, name, B, S, N, d, p)
     assert lib.macx_debug_set(key, value) == 0
     try:
