@@ -15,7 +15,7 @@
 #include "macx_gemm3h.hip.h"
 #include "macx_h2.hip.h"
 #include "macx_gemm_h2.hip.h"
-#include "macx_chain_h2.hip.h"
+#include "macx_chain_api.hip.h"
 #include "macx_wgrad_h2.hip.h"
 #include "macx_small.hip.h"
 #include "macx_ops.hip.h"

@@ -42,14 +42,10 @@
 //     per-question weight mixing.  Backward: dI1 W1a^T is multiplied by y per output column on the accumulators, then
 //     dI1 W1b^T is added.
 #pragma once
-#include "macx_h2.hip.h"
+#include "macx_chain_api.hip.h"
 
 namespace macx {
 
-struct ChainW {          // a weight matrix in pack format 3 (macx_h2.hip.h: pack_h2_weight)
-  const char* planes;    // [K/32][2][4][Nout] x 16 B
-  const int* exp;        // device int: the stored fp16 are W * 2^exp
-};
 
 // sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15); every lane of the row receives the same value (rotations
 // by 8, 4, 2, 1: the pairing is the same tree in every lane, and addition commutes)
@@ -635,33 +631,6 @@ struct ChainCtx {
 };
 
 // =========================================================================================================================
-struct ChainFwdP {
-  int M, N, d;              // rows (B*N), rows per question, width
-  int mode;                 // 0: KB -> X -> H1 -> I2 ; 1: X is read back (no read dropout: the projected KB is step-invariant)
-  int dbg;                  // timing knobs: 1 stop after stage 0, 2 after stage 1, 4 after stage 2; dbg >> 3 = K-loop variant
-  // stage 0
-  const float* kb;          // [M][d] fp32, row-major
-  uint32_t first;           // flat dropout index of element (0, 0): b0 * N * dlog
-  int dlog;                 // row stride of the dropout index: the logical width of a zero-padded cell (macx_shapes.d_logical), else d
-  uint32_t key1, thr1; float inv1;      // ops.py:678 site (thr = 1 << 24: keep everything)
-  uint8_t* bits1;           // its keep bits, row-major, one byte per 8 columns [M][d/8] (= uint32 words [M][d/32]); may be null
-  uint32_t key2, thr2; float inv2;      // ops.py:312 site on act(I2 * c)
-  const uint32_t* word;                 // macx_dropout.mask_word (device, may be null): XORed into both keys when the kernel runs
-  uint8_t* bytes2;          // its keep bits in slot order [d/8][M + pad]; may be null
-  H2View KBd;               // base null: not written
-  ChainW Wx, W1a, W1b, W2;
-  const float *bx, *b1, *b2;
-  int act1, act2;           // readMemAct (on H1), readCtrlAct (on I2 * c)
-  const float* y;           // [B][d]
-  const float* c;           // [B][d]
-  const float* wk;          // [d]
-  H2View X;                 // written in mode 0, read in mode 1
-  H2View XY;                // base null: not written.  X * y as stage 2 multiplies it (ops.py:703), kept for the backward pass's
-                            // dW1a = (X * y)^T dI1 contraction (wgrad_h2_kernel's dual form)
-  H2View H1;                // base null: not written (inference)
-  H2View I2;                // base null: not written
-  float* logits;            // [M] (without the bias b_k, which kb_attend adds)
-};
 
 template <int D_, int KV = 0, int R_ = 64>
 __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
@@ -867,21 +836,9 @@ inline hipError_t chain_fwd_launch_t(const ChainFwdP& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-// K-loop variant of the d = 512, 64-row chain kernels (ChainCtx::kloop: 4 = activation reads in mid-slice, 8 = static priority,
-// 16 = the 32 x 32 x 16 instruction, and their sums); -1 = the default.  macx_debug_set(7, v): A/B measurements in one process
-constexpr int CHAIN_KV_DEFAULT = 4;
-inline int& chain_kv() { static int v = -1; return v; }
-inline bool chain_supported(int d, int N) { return d % 128 == 0 && d >= 128 && d <= 512 && N >= 16; }
-// rows per tile: the tallest tile that still leaves the chip one tile per CU (short tiles exist for d = 512 only)
-inline int chain_tile_rows(int d, size_t M) {
-  if (d != 512) return 64;
-  if ((M + 31) / 32 > 256) return 64;
-  return (M + 15) / 16 > 256 ? 32 : 16;
-}
-inline int chain_tile_shift(int d, size_t M) { const int r = chain_tile_rows(d, M); return r == 64 ? 6 : (r == 32 ? 5 : 4); }
-inline size_t chain_tiles(int d, size_t M) { const size_t r = (size_t)chain_tile_rows(d, M); return (M + r - 1) / r; }
 
-inline hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
+#ifdef MACX_CHAIN_FWD_TU      // macx_chain_fwd.hip: the one translation unit that instantiates the forward kernels
+hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
   switch (p.d / 128) {
     case 1: return chain_fwd_launch_t<128>(p, st);
     case 2: return chain_fwd_launch_t<256>(p, st);
@@ -907,47 +864,10 @@ inline hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
     default: return hipErrorInvalidValue;
   }
 }
+#endif
 
 
 // =========================================================================================================================
-struct ChainBwdP {
-  int M, N, d;
-  int dbg;                  // timing knobs: 1 stop after stage B0, 2 after B1; dbg >> 3 = K-loop variant
-                            // (tried: pulling the kept H1 rows toward L2 by DMA from inside the K loop of stage B1, whose
-                            // epilogue reads them -- no change, 4.399 vs 4.400 ms per step)
-  // stage B0: dI2 from the kept I2
-  const float* att;         // [B][N] knowledge-base attention of the step
-  const float* da;          // [B][N] dinfo . KB[n] (kb_att_da_kernel)
-  H2View I2;
-  const float* c;           // [B][d]
-  const float* wk;          // [d]
-  int act2;                 // readCtrlAct
-  const uint8_t* bytes2;    // keep bits of the attention dropout in slot order [d/8][M + pad]; null = keep all
-  float inv2;
-  H2View dI2;
-  // column sums of stage B0 per 64-row tile, summed over tiles by the caller in a fixed order; a tile may touch up to three
-  // questions (N >= 32), so what is per question has three segments.  All four null: not computed here
-  // (read_att_bwd_h2_kernel in its sums-only mode does it).
-  float* dwk_part;          // [tiles][d]     sum_rows dl * dropped(act(I2 * c))
-  float* db2_part;          // [tiles][d]     sum_rows dI2
-  float* dc_part;           // [tiles][3][d]  sum_rows dZ * I2, per question segment
-  float* dls_part;          // [tiles][3]     sum_rows dl, per question segment
-  // stage B1: dI1 = (dI2 W2^T) * act'(H1)
-  ChainW W2T;
-  H2View H1; int act1;      // readMemAct
-  H2View dI1;
-  float* db1_part;          // [tiles][d] column sums of dI1
-  // stage B2: dX = (dI1 W1a^T) * y + dI1 W1b^T
-  ChainW W1aT, W1bT;
-  const float* y;           // [B][d]
-  H2View dX;
-  float* dbx_part;          // [tiles][d] column sums of dX
-  // dy[q][k] = sum over the question's rows of (dI1 W1a^T)[r][k] * X[r][k]  (ops.py:703: d(x * y)/dy = x): the first product of
-  // stage B2 is exactly the left factor, so dy costs one read of the kept X tile -- and the per-question contraction
-  // S_b = X_b^T dI1_b that used to deliver it (sb_h2_kernel) leaves the recurrence and runs once, over all steps, at the end
-  H2View X;                 // the step's kept X
-  float* dy_part;           // [tiles][3][d] per question segment, like dc_part; null: not computed
-};
 
 // A2: readCtrlAct as a compile-time constant -- one kernel per activation (chain_bwd_launch_t); several arms in one kernel met in one
 // register allocation (two arms: 86 spilled registers; a per-value run-time switch: 102-104).
@@ -1329,7 +1249,8 @@ inline hipError_t chain_bwd_launch_t(const ChainBwdP& p, hipStream_t st) {
   }
 }
 
-inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
+#ifdef MACX_CHAIN_BWD_TU      // macx_chain_bwd.hip: the one translation unit that instantiates the backward kernels
+hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
   switch (p.d / 128) {
     case 1: return chain_bwd_launch_t<128>(p, st);
     case 2: return chain_bwd_launch_t<256>(p, st);
@@ -1356,47 +1277,7 @@ inline hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
     default: return hipErrorInvalidValue;
   }
 }
+#endif
 
-// the per-question ends of stage B0's column sums: dc[q] += sum over the segments of the question's tiles, db_k partial
-struct DcReduceP {
-  int B, N, d;
-  const float* dc_part;     // [tiles][3][d]
-  const float* dls_part;    // [tiles][3]
-  float* dc;                // [B][d] accumulated in place
-  float* dbk_part;          // [B]
-  size_t part_step, dls_step, dc_step, dbk_step;      // blockIdx.y = step: floats between the steps' buffers
-  const float* dy_part;     // [tiles][3][d] (chain_bwd_kernel stage B2) or null
-  float* dy;                // [B][d] written
-  int tile_shift;           // log2 of the rows per tile (chain_tile_shift)
-};
-__global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
-  const int q = blockIdx.x;
-  p.dc_part += blockIdx.y * p.part_step; p.dls_part += blockIdx.y * p.dls_step;
-  p.dc += blockIdx.y * p.dc_step; p.dbk_part += blockIdx.y * p.dbk_step;
-  const uint32_t r0 = (uint32_t)q * (uint32_t)p.N, r1 = r0 + (uint32_t)p.N - 1;      // (rows < 2^31: 32-bit divisions, no 64-bit software routine)
-  const int ts = p.tile_shift;
-  const int t0 = (int)(r0 >> ts), t1 = (int)(r1 >> ts);
-  auto seg_of = [&](int t) { return q - (int)(((uint32_t)t << ts) / (uint32_t)p.N); };   // 0: the question that owns the tile's first row
-  for (int c4 = threadIdx.x * 4; c4 < p.d; c4 += 512) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int t = t0; t <= t1; ++t)                          // fixed order
-      s += *reinterpret_cast<const f32x4*>(p.dc_part + ((size_t)t * 3 + seg_of(t)) * p.d + c4);
-    f32x4* dst = reinterpret_cast<f32x4*>(p.dc + (size_t)q * p.d + c4);
-    *dst = *dst + s;
-    if (p.dy_part) {
-      f32x4 sy = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int t = t0; t <= t1; ++t)                        // fixed order
-        sy += *reinterpret_cast<const f32x4*>(p.dy_part + ((size_t)t * 3 + seg_of(t)) * p.d + c4);
-      *reinterpret_cast<f32x4*>(p.dy + (size_t)q * p.d + c4) = sy;
-    }
-  }
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int k = t0; k <= t1; ++k) t += p.dls_part[(size_t)k * 3 + seg_of(k)];
-    p.dbk_part[q] = t;
-  }
-}
 
 }  // namespace macx

@@ -203,6 +203,7 @@ __device__ __forceinline__ void h2_store_tile(const float* T, int ldt, int rows,
 }
 
 
+#ifndef MACX_H2_NO_KERNELS     // (the chain kernels' translation units take the format above, not the kernels below)
 // ---------------------------------------------------------------------------------------------------------------
 // fp32 [B][N][C] row-major -> H2 (the caller's knowledge base enters the format here), optionally through a dropout
 // site (ops.py:678: out = kb * mask / keep) whose keep bits are kept row-major for the dKB epilogue, and optionally
@@ -430,5 +431,7 @@ __device__ __forceinline__ void pack_h2_weight(const float* src, int ld_k, int l
   // weights -- share one exponent behind the last of them)
   if (tid_global == 0) *reinterpret_cast<int*>(exp_dst ? exp_dst : dst + (size_t)K * Nout) = e;
 }
+
+#endif  // MACX_H2_NO_KERNELS
 
 }  // namespace macx

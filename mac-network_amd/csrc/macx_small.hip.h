@@ -1519,4 +1519,46 @@ __global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, siz
   }
 }
 
+// the per-question ends of stage B0's column sums: dc[q] += sum over the segments of the question's tiles, db_k partial
+struct DcReduceP {
+  int B, N, d;
+  const float* dc_part;     // [tiles][3][d]
+  const float* dls_part;    // [tiles][3]
+  float* dc;                // [B][d] accumulated in place
+  float* dbk_part;          // [B]
+  size_t part_step, dls_step, dc_step, dbk_step;      // blockIdx.y = step: floats between the steps' buffers
+  const float* dy_part;     // [tiles][3][d] (chain_bwd_kernel stage B2) or null
+  float* dy;                // [B][d] written
+  int tile_shift;           // log2 of the rows per tile (chain_tile_shift)
+};
+__global__ __launch_bounds__(128) void dc_reduce_kernel(DcReduceP p) {
+  const int q = blockIdx.x;
+  p.dc_part += blockIdx.y * p.part_step; p.dls_part += blockIdx.y * p.dls_step;
+  p.dc += blockIdx.y * p.dc_step; p.dbk_part += blockIdx.y * p.dbk_step;
+  const uint32_t r0 = (uint32_t)q * (uint32_t)p.N, r1 = r0 + (uint32_t)p.N - 1;      // (rows < 2^31: 32-bit divisions, no 64-bit software routine)
+  const int ts = p.tile_shift;
+  const int t0 = (int)(r0 >> ts), t1 = (int)(r1 >> ts);
+  auto seg_of = [&](int t) { return q - (int)(((uint32_t)t << ts) / (uint32_t)p.N); };   // 0: the question that owns the tile's first row
+  for (int c4 = threadIdx.x * 4; c4 < p.d; c4 += 512) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = t0; t <= t1; ++t)                          // fixed order
+      s += *reinterpret_cast<const f32x4*>(p.dc_part + ((size_t)t * 3 + seg_of(t)) * p.d + c4);
+    f32x4* dst = reinterpret_cast<f32x4*>(p.dc + (size_t)q * p.d + c4);
+    *dst = *dst + s;
+    if (p.dy_part) {
+      f32x4 sy = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int t = t0; t <= t1; ++t)                        // fixed order
+        sy += *reinterpret_cast<const f32x4*>(p.dy_part + ((size_t)t * 3 + seg_of(t)) * p.d + c4);
+      *reinterpret_cast<f32x4*>(p.dy + (size_t)q * p.d + c4) = sy;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = t0; k <= t1; ++k) t += p.dls_part[(size_t)k * 3 + seg_of(k)];
+    p.dbk_part[q] = t;
+  }
+}
+
 }  // namespace macx

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 6, call 2: one step's launch timeline, eager and replayed graph
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out
+B="python bench.py --no-cpu-baseline --no-model-level --no-native --no-extra-legs --no-probe"
+rocprofv3 --kernel-trace -d $O/c1e -o r -- $B --eager --steps 5 --warmup 2 > $O/c1e.log 2>&1
+python tools/step_timeline.py $O/c1e/r_results.db > $O/r06_start_timeline_eager.txt
+rocprofv3 --kernel-trace -d $O/c1g -o r -- $B --steps 5 --warmup 2 > $O/c1g.log 2>&1
+python tools/step_timeline.py $O/c1g/r_results.db > $O/r06_start_timeline_graph.txt
+rm -rf $O/c1e $O/c1g
+tail -45 $O/r06_start_timeline_graph.txt
