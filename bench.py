@@ -559,20 +559,13 @@ def main():
 
     import macx
     L = macx._lib.lib()
-    if os.environ.get("MACX_DBG"):          # tuning only: kb GEMM debug bits
-        L.macx_debug_set(1, int(os.environ["MACX_DBG"]))
     if os.environ.get("MACX_GEMM"):         # native | split | h2 (default): kernel family of the read unit
         L.macx_gemm_mode({"native": 0, "split": 1, "h2": 2}[os.environ["MACX_GEMM"]])
-    if os.environ.get("MACX_CHAIN"):        # A/B only: 0 = the read unit's forward products as four launches
-        L.macx_debug_set(4, int(os.environ["MACX_CHAIN"]))
-    if os.environ.get("MACX_CHAIN_KV"):     # A/B only: K-loop variant of the chain kernels
-        L.macx_debug_set(7, int(os.environ["MACX_CHAIN_KV"]))
-    if os.environ.get("MACX_SB_DEFER"):     # A/B only: 0 = sb_h2 once per step
-        L.macx_debug_set(5, int(os.environ["MACX_SB_DEFER"]))
-    if os.environ.get("MACX_OVERLAP"):      # A/B only: 0 = no side queue
-        L.macx_debug_set(6, int(os.environ["MACX_OVERLAP"]))
-    if os.environ.get("MACX_FORCE_RT"):     # tuning only: row tiles per GEMM workgroup
-        L.macx_debug_set(2, int(os.environ["MACX_FORCE_RT"]))
+    # A/B only: the per-call tuning table (macx_opts.tune) of every cell this run freezes
+    for env, key in (("MACX_DBG", "phase_mask"), ("MACX_CHAIN", "chain"), ("MACX_CHAIN_KV", "chain_kv"), ("MACX_SB_DEFER", "sb_defer"),
+                     ("MACX_FORCE_RT", "row_tiles")):
+        if os.environ.get(env):
+            macx.options.SESSION_TUNE[key] = int(os.environ[env])
     p = args.p
     seed = 1234
     global_batch = args.per_gpu_batch * world if args.per_gpu_batch else B      # the metric: 64 questions in all

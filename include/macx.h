@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MACX_ABI_VERSION 4
+#define MACX_ABI_VERSION 5
 
 enum {
   MACX_OK = 0,
@@ -69,7 +69,36 @@ typedef struct macx_opts {
                                        (sizing, begin, step, backward): 0 = the process default (macx_gemm_mode),
                                        1 + MACX_GEMM_NATIVE / _SPLIT / _H2 = that family.  Per call and per thread: two
                                        cells of one process can run on different families side by side               */
+  int32_t tune[16];                 /* PER-CALL tuning table (ABI 5; replaces the process-global `macx_debug_set` of ABI <= 4): the A/B
+                                       hook of each live kernel-selection decision and the phase masks of the profiling tools.
+                                       All zero = the shipped configuration.  tune[k] = 0: the default of key k; else the value
+                                       v is passed as v + 1 (MACX_TUNE(v)).  Read when a call is enqueued, from the opts of THAT
+                                       call (forward and backward of one run must see the same table): no state lives in the
+                                       library, calls on different threads or with different opts never see each other's table.
+                                       Keys: MACX_TUNE_* below.  Never needed for correct results. */
 } macx_opts;
+#define MACX_TUNE(v) ((v) + 1)
+enum {
+  MACX_TUNE_NATIVE_WAVES = 0, /* waves per workgroup of the NATIVE knowledge-base GEMM: 4 | 8 (default)                        */
+  MACX_TUNE_PHASE_MASK = 1,   /* bit mask of TIMING experiments (results are wrong under a non-zero mask; tools/mask_steps.py):
+                                 1 skip the GEMM epilogue, 2 skip the in-loop staging, 8 epilogue without its global stores,
+                                 32 / 64 re-read K-slice 0 of A / of the weights (cache-hot), 128 weight-gradient contractions on
+                                 the f32 TN kernel, 256 S_b kernel on the f32 kernel, 512 / 1024 / 2048 the deferred contractions
+                                 without their folds / products / in-loop DMA, bits 12-16 stop chain_fwd after a stage, bits
+                                 17-21 chain_bwd                                                                              */
+  MACX_TUNE_ROW_TILES = 2,    /* forced row tiles per GEMM workgroup (0 = automatic | 1 | 2 | 4 | 7 | 13)                      */
+  MACX_TUNE_CHAIN = 4,        /* 0: the read unit's products as separate launches (what also runs for d > 512 or N < 16);
+                                 1 (default): the chain kernels of macx_chain_h2.hip.h                                        */
+  MACX_TUNE_SB_DEFER = 5,     /* 0: the per-question contraction S_b = X_b^T dI1_b once per step (it then also delivers dy; what
+                                 also runs for N < 32); 1 (default): dy from the chain kernel, S_b of all steps in one launch   */
+  MACX_TUNE_CHAIN_KV = 7,     /* K loop of the d = 512 chain kernels: 0 activation fragments requested in front of a slice's
+                                 products; -1 (default): in mid-slice                                                         */
+  MACX_TUNE_SB_WIDE = 8,      /* dW1a / dW1b: 0 the 128 x 128 per-question S_b kernel; 1 (default) the 128 x 256 one            */
+  MACX_TUNE_WGRAD_PIPE = 10,  /* wgrad_h2_kernel<2,2>: 0 a stage requested one iteration ahead; 1 a buffer's halves re-requested
+                                 inside the iteration; 2 = 1 + dW2 and dWx as ONE launch; 3 (default) = 2 with half the splits  */
+  MACX_TUNE_SB_CONT = 13,     /* sb_h2w_kernel: 1 (default) one stage stream over all steps; 0 drained and re-primed per step    */
+  MACX_TUNE_DKB_UNI = 14      /* merged dKB launch: 1 (default) one fold of the block accumulator per step; 0 per 128-wide K block */
+};
 
 typedef struct macx_shapes {
   int32_t B;     /* questions in this (shard of the) batch                                     */
@@ -207,7 +236,10 @@ int macx_cell_forward(const macx_opts*, const macx_shapes*, const macx_dropout*,
 
 /* Gradient of the whole p-step run (what tf.gradients builds for model.py:453-458).
  * d_memory / d_control: [B,d] gradients of the final state (either may be NULL = zero).
- * Requires `saved` from a forward run with keep_activations = 1 and the same dropout struct. */
+ * Requires `saved` from a forward run with keep_activations = 1, the same dropout struct, the same macx_opts (kernel family and
+ * tuning table included) and the SAME PARAMETER VALUES: the weight matrices are read from the transposed / H2 packs the forward
+ * call's pack launch left in `saved`, only biases and the attention vectors are read live from macx_params -- a run whose
+ * parameters change between its forward and its backward call mixes old and new weights. */
 int macx_cell_backward(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*,
                        const macx_inputs*, const float* saved, size_t saved_floats,
                        float* ws, size_t ws_floats,
@@ -505,47 +537,11 @@ int macx_op_dropout(const float* x, size_t n, uint32_t seed, uint32_t site, uint
 int macx_op_dropout_w(const float* x, size_t n, uint32_t seed, uint32_t site, uint32_t step, float keep, uint32_t first,
                       const uint32_t* mask_word, float* out, void* stream);
 
-/* tuning hook for A/B measurements (never needed for correct results).  PROCESS-GLOBAL DEBUG STATE, not part of the per-call
- * contract: keys 4 - 10 are plain process-wide integers inside the library (read when a call is enqueued, not thread-safe against a
- * concurrent macx_debug_set); the kernel FAMILY, the one selector a product caller may want per cell, travels per call in
- * macx_opts.gemm_family.  No product code path writes them: mac-network_amd/ never calls macx_debug_set (asserted by
- * tests/test_host.py::test_product_code_never_touches_the_debug_knobs); bench.py / tests / tools set them from MACX_* environment
- * variables for A/B runs only.
- *   key 0  waves per workgroup of the NATIVE knowledge-base GEMM (4 | 8)
- *   key 1  bit mask of timing experiments / kernel selection:
- *            1 skip the GEMM epilogue, 2 skip the in-loop staging, 4 write-through output stores (unsafe: stale cross-XCD
- *            reads were observed), 8 epilogue without its global stores, 32 / 64 re-read K-slice 0 of A / of the weights
- *            (cache-hot), 128 weight-gradient contractions on the f32 TN kernel, 256 S_b kernel on the f32 kernel
- *   key 2  forced row tiles per GEMM workgroup (0 = automatic | 1 | 2 | 4 | 7 | 13)
- *   key 3  = macx_gemm_mode
- *   key 4  0: the read unit's products as separate launches (A/B against the chain kernels of macx_chain_h2.hip.h); 1: default
- *   key 5  0: the per-question contraction S_b = X_b^T dI1_b once per step (it then also delivers dy); 1 (default): dy from the
- *          chain kernel, S_b of all steps in one launch at the end of the backward pass
- *   key 6  0 (default): every launch on the caller's stream; 1..3: the backward pass's dKB contraction runs per step on an internal
- *          queue (lowest / highest / middle priority), forked from and joined to the caller's stream by events (still
- *          stream-ordered for the caller) -- measured slower, kept for the A/B; 4: the per-step dW2 contraction as a right-sized grid
- *          beside the chain kernels (also slower)
- *   key 7  K-loop variant of the chain kernels (-1 = default)      key 8  the read unit's interaction weight gradients dW1a / dW1b: 0 the 128 x 128 per-question S_b kernel, 1 the 128 x 256 one,
- *          (default); 2 no per-question kernel -- the forward pass keeps X * y and both are one contraction over all rows with two
- *          A operands (where the chain kernels run and d % 256 == 0; else as 1): measured slower (twice the matrix work), kept for
- *          the A/B.  Read when the FORWARD pass is enqueued as well (it decides whether X * y is kept): set it between whole steps
- *   key 9  0: the stem's 3 x 3 convolutions on kb_gemm3h_kernel; 1 (default): on kb_conv_chain_kernel where the shape allows
- *          (512 output channels, input channels a multiple of 256)
- *   key 10 the all-steps weight-gradient contractions (wgrad_h2_kernel<2,2>): 0 round 4's loop (a stage is requested one iteration
- *          ahead); 1 a buffer's G / A halves are re-requested inside the iteration as soon as every wave has read them (two stages
- *          in flight); 2 = 1 + dW2 and dWx as ONE launch (grid.y = 2); 3 (default) = 2 with half the reduction splits each (all of
- *          the launch's workgroups resident at once; other split points: results differ from 0 - 2 in the last bits)
- *   key 11 workgroups of a pair launch (two dependent [B,d] linears in one launch with a device-scope barrier between them:
- *          write-unit linear of step i + projY linear of step i + 1; dy linear of step i + write-unit backward linear of step i - 1);
- *          0 (default): every linear its own launch -- pairs measured 2 - 13 % slower per step; 16 .. 256
- *   key 12 1: the [B,d] linears with a long reduction (K >= 1024, and the form that sums the chain kernel's dy partials in its
- *          operand load) run 8 waves per workgroup (one batch of operand loads per wave instead of two) -- no measurable gain;
- *          0 (default): 4 waves
- *   key 13 sb_h2w_kernel (key 8 = 1): 1 (default) one stage stream over all steps, the next step's tables built inside the loop;
- *          0 the pipeline drained and re-primed per step
- *   key 14 the merged dKB launch (all steps' (dX_i Wx^T) * mask_i in one kernel): 1 (default) ONE fold of the block accumulator per
- *          step where the chain kernels produced dX (one exponent per row, d = 512); 0 a fold per 128-wide K block */
-int macx_debug_set(int key, int value);
+/* (ABI <= 4 had a `macx_debug_set` entry point here: fifteen process-global integers.  ABI 5 removed it -- the live A/B hooks travel per
+ * call in macx_opts.tune, the variants that were measured slower in rounds 4-5 (side-queue modes, pair launches, the dual-A
+ * contraction, 8-wave linears, the 32 x 32 x 16 K loop, write-through stores) and the kernels only they instantiated are gone.
+ * What is left of process-wide state is macx_gemm_mode's default kernel FAMILY for the entry points that carry no macx_opts;
+ * no product module sets it: tests/test_host.py::test_product_code_never_touches_the_debug_knobs.) */
 
 const char* macx_strerror(int code);
 int macx_abi_version(void);

@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MACX_OK, MACX_EINVAL, MACX_EUNSUPPORTED, MACX_EREJECTED, MACX_ESMALL = 0, -1, -2, -3, -4
 ACT = {"NON": 0, "TANH": 1, "SIGMOID": 2, "ELU": 3, "RELU": 4}
@@ -22,7 +22,22 @@ class MacxOpts(C.Structure):
         "abi_version", "init_ctrl", "init_mem", "control_input_unshared", "control_input_act", "control_feed_prev",
         "control_feed_prev_att", "control_feed_inputs", "control_cont_act", "read_mem_act", "read_ctrl_act",
         "write_inputs", "write_self_att", "write_self_att_cont", "write_mem_act", "write_gate", "write_gate_shared")]
-    _fields_ += [("write_gate_bias", C.c_float), ("memory_variational_dropout", C.c_int32), ("gemm_family", C.c_int32)]
+    _fields_ += [("write_gate_bias", C.c_float), ("memory_variational_dropout", C.c_int32), ("gemm_family", C.c_int32),
+                 ("tune", C.c_int32 * 16)]
+
+
+# macx_opts.tune keys (include/macx.h MACX_TUNE_*): the per-call A/B hooks and the profiling tools' phase mask.  A value v travels
+# as v + 1; 0 = the shipped default of that key.
+TUNE = {"native_waves": 0, "phase_mask": 1, "row_tiles": 2, "chain": 4, "sb_defer": 5, "chain_kv": 7, "sb_wide": 8,
+        "wgrad_pipe": 10, "sb_cont": 13, "dkb_uni": 14}
+
+
+def set_tune(opts, key, value):
+    """opts.tune[key] = value (None: back to the default).  key: a name of TUNE or its number."""
+    k = TUNE[key] if isinstance(key, str) else int(key)
+    if k not in TUNE.values():
+        raise KeyError("no tuning key %r (have %s)" % (key, sorted(TUNE)))
+    opts.tune[k] = 0 if value is None else int(value) + 1
 
 
 class MacxShapes(C.Structure):
@@ -107,7 +122,7 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_saved_segment", "macx_cell_begin", "macx_cell_step", "macx_cell_forward", "macx_cell_backward",
            "macx_cell_backward_phase",
            "macx_linear", "macx_pack_weight", "macx_kb_project", "macx_control_attend", "macx_dropout_mask", "macx_dropout_mask_w", "macx_wgrad_splits",
-           "macx_wgrad", "macx_debug_set", "macx_output_saved_floats", "macx_output_ws_floats",
+           "macx_wgrad", "macx_output_saved_floats", "macx_output_ws_floats",
            "macx_output_forward", "macx_output_backward", "macx_adam_ema_step",
            "macx_stem_saved_floats", "macx_stem_ws_floats", "macx_stem_forward", "macx_stem_backward",
            "macx_encoder_saved_floats", "macx_encoder_ws_floats", "macx_encoder_forward", "macx_encoder_backward",
@@ -170,7 +185,6 @@ def lib():
                                     C.c_void_p]
     L.macx_dropout_mask_w.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
-    L.macx_debug_set.argtypes = [C.c_int, C.c_int]
     L.macx_read_chain_time.argtypes = [P(MacxOpts), P(MacxShapes), P(MacxDropout), P(MacxParams), P(MacxInputs), C.c_void_p, C.c_size_t,
                                        C.c_int, C.c_int, P(C.c_float), C.c_void_p]
     L.macx_saved_activation.argtypes = [P(MacxOpts), P(MacxShapes), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -203,6 +203,7 @@ class MACCell:
              (macx.h, macx_dropout.mask_word).  The seed is baked into a captured HIP graph, this word is not: write a new
              value between replays and one capture draws fresh masks per step (graph.CapturedTrainStep).  None == word 0.
     gemm     kernel family of the knowledge-base GEMMs of THIS cell: "h2" | "split" | "native" (None: the process default)
+    tune     {key: value} for macx_opts.tune, the per-call A/B hooks (_lib.TUNE; measurement only, never needed for results)
     """
 
     def __new__(cls, *args, config=None, gemm=None, **kw):
@@ -234,12 +235,12 @@ class MACCell:
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
-                 netLength=None, seed=None, b0=0, gemm=None, d_logical=0, mask_word=None):
+                 netLength=None, seed=None, b0=0, gemm=None, d_logical=0, mask_word=None, tune=None):
         from types import SimpleNamespace
         self.mask_word = _mask_word(mask_word, knowledgeBase)
         self.d_logical = int(d_logical)        # > 0: this is the zero-padded image of a d_logical-wide cell (PaddedMACCell)
         self.config = config if config is not None else SimpleNamespace()
-        self.opts = freeze(self.config, gemm)     # raises for rejected / unsupported option sets
+        self.opts = freeze(self.config, gemm, tune)     # raises for rejected / unsupported option sets
         self.netLength = int(netLength if netLength is not None else get(self.config, "netLength"))
         self.vecQuestions = _f32c(vecQuestions, "vecQuestions")
         self.questionWords = questionWords
@@ -429,7 +430,7 @@ class PaddedMACCell:
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
-                 netLength=None, seed=None, b0=0, gemm=None, mask_word=None):
+                 netLength=None, seed=None, b0=0, gemm=None, mask_word=None, tune=None):
         import copy
         from .options import UnsupportedOptions
         # the dropout index at the logical width (macx_shapes.d_logical) is implemented by the H2 kernel family: the padded cell runs
@@ -452,7 +453,7 @@ class PaddedMACCell:
         cntx_p = words_p if questionCntxWords is questionWords else pad(questionCntxWords)
         self.inner = MACCell(pad(vecQuestions), words_p, cntx_p, questionLengths, pad(knowledgeBase), memoryDropout, readDropout,
                              writeDropout, batchSize, train, reuse, config=wide, params=_PaddedParams(self.params, d, dp),
-                             netLength=self.netLength, seed=seed, b0=b0, gemm=gemm, d_logical=d, mask_word=mask_word)
+                             netLength=self.netLength, seed=seed, b0=b0, gemm=gemm, d_logical=d, mask_word=mask_word, tune=tune)
         self.batchSize, self.train, self.seed, self.b0 = self.inner.batchSize, self.inner.train, self.inner.seed, self.inner.b0
 
     none = property(lambda self: self.inner.none)

@@ -37,80 +37,35 @@ namespace {
 
 inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
 
-// The knowledge-base GEMM family runs on one of two kernels (macx_debug_set(3, mode), default split):
+// The knowledge-base GEMM family runs on one of two kernels (macx_gemm_mode / macx_opts.gemm_family):
 //   split (1): macx_gemm6.hip.h, fp32 operands as three exact bf16 pieces on the bf16 matrix pipe, fp32 accumulate;
 //   native (0): macx_gemm.hip.h, v_mfma_f32_16x16x4_f32.
 // They take different weight packings: plain weights -> format 1 (bf16 planes, 1.5x the floats) / 0, weights mixed
 // with a per-question vector (B_YMIX_*) -> format 2 (fp32 k-major tiles) / 0.  Buffers are sized for the larger one.
 //   h2 (2, the default): macx_gemm_h2.hip.h -- every [B,N,d] activation lives in HBM as two fp16 planes + per-row-block
 //     exponents (macx_h2.hip.h), three fp16 MFMA terms per product; plain weights -> format 3 (H2 planes + exponent).
-// the kernel family an ABI call runs on: macx_opts.gemm_family (when set) for the duration of the call, on this thread
+// the kernel family an ABI call runs on (macx_opts.gemm_family, when set) and the call's tuning table (macx_opts.tune): installed for
+// the duration of the call, on this thread
 struct ModeScope {
   int saved;
-  explicit ModeScope(const macx_opts* o) : saved(gemm_call_override()) {
+  TuneScope ts;
+  explicit ModeScope(const macx_opts* o) : saved(gemm_call_override()), ts(o ? o->tune : nullptr) {
     if (o && o->gemm_family >= 1 && o->gemm_family <= 3) gemm_call_override() = o->gemm_family - 1;
   }
   ~ModeScope() { gemm_call_override() = saved; }
 };
 inline bool h2_mode() { return gemm_split_mode() == 2; }
-// the read unit's forward products as one kernel (macx_chain_h2.hip.h); macx_debug_set(4, 0) falls back to the four launches
-inline int& chain_mode() { static int m = 1; return m; }
+// the read unit's products as one kernel per direction (macx_chain_h2.hip.h); MACX_TUNE_CHAIN = 0 falls back to the per-product
+// launches that also serve d > 512 and N < 16
+inline int chain_mode() { return tune_get(MACX_TUNE_CHAIN, 1); }
 inline bool use_chain(int d, int N) { return h2_mode() && chain_mode() && chain_supported(d, N); }
-// dy from the chain kernel and S_b of all steps as one deferred launch; macx_debug_set(5, 0): sb_h2 once per step, as before
-inline int& sb_defer_mode() { static int m = 1; return m; }
-// the deferred S_b contraction on 128 x 256 tiles with summation by parts (sb_h2w_kernel); macx_debug_set(8, 0): the 128 x 128 kernel
-// ... 2 (round 5): not a per-question kernel at all -- the forward chain kernel keeps X * y, and dW1a = (X * y)^T dI1,
-// dW1b = X^T dI1 are ONE plain contraction over all p B N rows with two A families (wgrad_h2_kernel's dual form) where the
-// shape allows (chain kernels, d % 256 == 0); else as 1
-// MEASURED (round 5, profiles/r05_dual_contraction_ab.txt): the dual form is SLOWER -- 392 us against sb_h2w's 345 on the same box,
-// plus 2.4 us per chain_fwd launch for the X * y stores, 4.19 against 4.08 ms per step.  It executes the two outputs as two
-// contractions (474 GFLOP on the pipe, the rate of wgrad_h2: 2 x 200 us) where the per-question kernel gets both from ONE
-// (S_b, DESIGN 1 rewrite 2: 237 GFLOP).  Default stays 1; 2 is kept behind the knob, parity-tested.
-inline int& sb_wide_mode() { static int m = 1; return m; }
-// A second queue for the backward pass's contractions that nothing in the recurrence waits for (dKB of a step: 27 us of
-// full-chip matrix work).  Between two chain kernels the caller's stream runs ~100 us of [B,d]-sized launches that leave the
-// chip almost idle; the side queue was meant to fill exactly that.  Fork and join are events on the caller's stream, so for the
-// caller everything is still ordered on `stream`.  MEASURED, same box: 4.44-4.47 ms per step with the side queue (lowest,
-// middle or highest priority alike) against 4.11 ms without -- the per-step dKB launches (read-modify-write of the gradient,
-// twelve ramps) cost more than the all-steps launch and hide nothing.  Off by default; macx_debug_set(6, 1..3) turns it on.
-// Mode 4 (round 4) is a different use of the same queue: the chain kernels occupy 196 of the chip's 256 CUs (one 64-row tile
-// per workgroup, one workgroup per CU), so a RIGHT-SIZED grid -- 56 workgroups, seven per XCD next to the chain kernel's 24-25 --
-// runs beside them on CUs that would idle: the dW2 = sum_i H1_i^T dI2_i contraction of step i (its operands are complete when
-// chain_bwd of step i ends) is launched there while the caller's stream goes on with step i - 1, accumulating into one set of
-// slabs; phase 2 then has one all-steps weight-gradient launch less.  (Modes 1-3 failed because a 244-workgroup launch does
-// not run BESIDE a chain kernel but in front of it: every CU holds one workgroup of either.)
-inline int& overlap_mode() { static int m = 0; return m; }
-struct SideQueue { hipStream_t s; hipEvent_t fork, join; };
-inline SideQueue* side_queue() {
-  constexpr int MAXDEV = 64;
-  static SideQueue q[MAXDEV];
-  static int state[MAXDEV];           // 0 untried, 1 ready, -1 failed
-  if (!overlap_mode()) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
-  if (state[dev] == 0) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo: least priority
-    const bool ok = hipStreamCreateWithPriority(&q[dev].s, hipStreamNonBlocking, overlap_mode() == 2 ? hi : (overlap_mode() == 3 ? (lo + hi) / 2 : lo)) == hipSuccess &&
-                    hipEventCreateWithFlags(&q[dev].fork, hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&q[dev].join, hipEventDisableTiming) == hipSuccess;
-    state[dev] = ok ? 1 : -1;
-  }
-  return state[dev] == 1 ? &q[dev] : nullptr;
-}
-// the read unit's interaction weight gradients as a dual-A contraction (sb_wide_mode() == 2): forward keeps X * y per step
-inline bool sb_dual_ok(const macx_shapes* s) {
-  return h2_mode() && use_chain(s->d, s->N) && s->N >= 32 && sb_defer_mode() && sb_wide_mode() == 2 && s->d % 256 == 0;
-}
-// write-unit linear of step i + projY linear of step i + 1 as one launch (forward), dy-linear of step i + write-unit backward
-// linear of step i - 1 as one launch (backward): small_linear_pair_kernel.  Whole cell only, writeInputs = BOTH without gate
-// (the gate's mix sits between the two products), B <= 128
-inline bool pair_fwd_ok(const macx_opts* o, const macx_shapes* s, int units) {
-  return lin_pair_grid() > 0 && units == 7 /* U_ALL */ && !o->write_gate && s->B <= 128;
-}
-inline bool pair_bwd_ok(const macx_opts* o, const macx_shapes* s, int units) {
-  return lin_pair_grid() > 0 && units == 7 /* U_ALL */ && !o->write_gate && !o->write_self_att && o->write_mem_act == MACX_ACT_NON && s->B <= 128;
-}
+// dy from the chain kernel and S_b of all steps as one deferred launch; MACX_TUNE_SB_DEFER = 0: sb_h2 once per step (what N < 32 runs)
+inline int sb_defer_mode() { return tune_get(MACX_TUNE_SB_DEFER, 1); }
+// the deferred S_b contraction on 128 x 256 tiles with summation by parts (sb_h2w_kernel); MACX_TUNE_SB_WIDE = 0: the 128 x 128 kernel.
+// (Measured and removed: dW1a / dW1b as ONE dual-A contraction over X * y and X -- twice the matrix work, 392 against 345 us,
+// profiles/r05_dual_contraction_ab.txt; a side queue for the per-step dKB / dW2 contractions -- +8 % / +130 us per step,
+// profiles/r04_side_queue_ab.txt.)
+inline int sb_wide_mode() { return tune_get(MACX_TUNE_SB_WIDE, 1) ? 1 : 0; }
 inline int wfmt_plain() { return h2_mode() ? 3 : (gemm_split_mode() ? 1 : 0); }
 inline int wfmt_ymix() { return gemm_split_mode() ? 2 : 0; }
 inline size_t wsize(size_t K, size_t n) { return K * n * 3 / 2; }     // covers format 1 (3/2) and format 3 (1 + the exponent)
@@ -192,12 +147,10 @@ struct SavedLayout {
   size_t self_smry;                 // [p,B,d]
   size_t logit_part;                // [d/128][B*N]
   size_t X, H1, I2;                 // [pk][B,N,d], pk = p (keep) or 1
-  size_t XY;                        // [p][B,N,d] X * y (H2) when the backward pass contracts it (sb_dual_ok, keep); else unused
   size_t KBd;                       // [pk][B,N,d] dropped knowledge base (ops.py:678)
   size_t act_stride;                // floats per kept step of X / H1 / I2 / KBd if keep else 0
   size_t act_floats;                // floats of one such tensor (B*N*d, or the H2 size in h2 mode)
   size_t wmax;                      // h2: max |W| of projX, memKbProj2, W1a, W1b (4 floats)
-  size_t pair_sync;                 // 4 words: arrival counter + fail flag of the forward pass's pair launches (macx_small.hip.h)
   size_t bwd_packs;                 // keep: the backward pass's weight packs (bwd_packs_floats), written by the forward pack launch; else 0
   size_t total;
 };
@@ -255,13 +208,11 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.H1 = take(pk * L.act_floats);
   L.I2 = take(pk * L.act_floats);
   L.KBd = take(pk * L.act_floats);
-  L.XY = (keep && sb_dual_ok(s)) ? take(p * L.act_floats) : 0;
   const size_t bits_floats = h2_mode() ? al4(((B * N + H2_PAD_ROWS) * (d / 8) + 3) / 4) : B * N * d / 32;
   L.bits_stride = keep ? bits_floats : 0;
   L.kb_bits = take(pk * bits_floats);
   L.att_bits = take(pk * bits_floats);
   L.wmax = take(8 + 4 * 64);          // the four maxima (+ 4 spare), then absmax4's per-workgroup partials
-  L.pair_sync = take(4);
   L.bwd_packs = keep ? take(bwd_packs_floats(o, s)) : 0;
   L.total = off;
   return L;
@@ -338,7 +289,6 @@ struct BwdLayout {
   size_t dI1_stride;          // floats between the steps' dI1 (0: one buffer)
   size_t db2_part, db1_part, dbx_part, dwk_part, dbk_part, dwc_part, dbc_part, ctrl_dl;
   size_t tmpBd[4];  // [B,d] scratch
-  size_t pair_sync; // 4 words: arrival counter + fail flag of the backward pass's pair launches
   size_t dccx;      // [p+1,B,d] gradient reaching cc_i from the NEXT step's contControl input (feedPrevAtt off)
   size_t dlin1;     // [p,B,d] gradient wrt the first contControl layer's pre-activation
   size_t dxc;       // [B,2d]  gradient wrt the contControl input of the current step
@@ -349,12 +299,7 @@ struct BwdLayout {
   size_t tmp_dd;    // [d,d] scratch
   size_t act_floats;                 // floats of one [B,N,d] activation (H2 size in h2 mode)
   size_t ecom;                       // h2: [4][EMIN_NB][8] ints, partial minima of the row exponents of H1 / dI2 / KBd / dX over all steps
-  bool sb_dual;                      // dW1a / dW1b from the dual-A contraction (sb_dual_ok)
-  size_t ftab_dual;                  // its 2 (d/128) (d/128) row-factor tables
-  size_t ns_dual;                    // its reduction splits
   size_t wg_ftab, wg_ftab2;          // h2: [d/128][d/128][Mpad] fp16 row factors of the two deferred weight-gradient contractions
-  // per-step dW2 on the side queue (overlap mode 4): exponent minima [p][2][EMIN_NB][8], row factors [p][d/128][d/128][Mpad(B N)], splits
-  size_t ecom_s, ftab_s, ftab_s_stride, side_ns;
   size_t total;
 };
 
@@ -371,7 +316,8 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.wqT = take(d * d);
   L.wqUT = take((o->control_input_unshared ? p : 1) * d * d);
   L.wccT = take(2 * d * d); L.wcc2T = take(d * d); L.wscT = take(d * d); L.wgT = take(d * d);
-  L.packs_end = off;                  // == bwd_packs_floats(o, s): the same region lives in `saved` when the forward pass packed it
+  L.packs_end = off;                  // == bwd_packs_floats(o, s).  These are offsets into SavedLayout::bwd_packs: the forward pass's pack
+  off = 0;                            // launch writes the backward pass's packs into `saved`; the workspace proper starts here
   L.act_floats = h2_mode() ? al4(h2_floats(B * N, d)) : B * N * d;
   L.chain_sums = use_chain((int)d, (int)N) && N >= 32;
   L.sb_deferred = L.chain_sums && sb_defer_mode();
@@ -380,7 +326,6 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dI2 = take(p * L.act_floats); L.dI1 = take((L.sb_deferred ? p : 1) * L.act_floats); L.dX = take(p * L.act_floats); L.da = take(B * N);   // dI2, dX (dI1) kept per step
   L.DM = take((p + 1) * B * d);
   L.DC = take((p + 1) * B * d);
-  L.pair_sync = take(4);              // (right behind DC: bwd_init_kernel zeroes it with them)
   L.dcI = take(p * B * d);
   L.dcc = o->control_feed_prev ? take(p * B * d) : L.dcI;
   L.dwlin = take(p * B * d);
@@ -391,15 +336,13 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.dmd = take(B * d);
   L.dt = take(B * d); L.du = take(B * d);
   L.ns_big = wgrad_big_splits((int)(p * B * N), (int)d, (int)d);
-  L.sb_dual = sb_dual_ok(s);
-  L.ns_dual = L.sb_dual ? std::max<size_t>(1, 256 / (size_t)wgrad_h2_dual_tiles((int)d, (int)d)) : 0;
   L.sb_wide = L.sb_deferred && h2_mode() && sb_wide_mode() && sb_h2_wide_ok((int)B, (int)N, (int)d);
   L.sb_qpg = L.sb_wide ? sb_h2_wide_qpg((int)B, (int)N, (int)d) : sb_qpg((int)B, (int)N);
   L.ngroup = (B + L.sb_qpg - 1) / L.sb_qpg;
   L.slab_w2 = take(L.ns_big * d * d);
   L.slab_wx = take(L.ns_big * d * d);
-  L.slab_w1a = take(std::max((L.sb_deferred ? 1 : p) * L.ngroup, L.ns_dual) * d * d);
-  L.slab_w1b = take(std::max((L.sb_deferred ? 1 : p) * L.ngroup, L.ns_dual) * d * d);
+  L.slab_w1a = take((L.sb_deferred ? 1 : p) * L.ngroup * d * d);
+  L.slab_w1b = take((L.sb_deferred ? 1 : p) * L.ngroup * d * d);
   // column-sum partials of dI1 / dX: one row per GEMM workgroup row block, or per 64-row tile of the chain kernel
   const size_t nrb = use_chain((int)d, (int)N) ? chain_tiles((int)d, B * N) : B * nrb_of((int)N, (int)B, (int)d);
   L.db_rows = nrb;
@@ -427,20 +370,9 @@ BwdLayout make_bwd(const macx_opts* o, const macx_shapes* s) {
   L.small_slab_stride = al4(small);
   L.small_slab = take(8 * L.small_slab_stride);        // SmallWgradBatch: one slab set per batched contraction
   L.tmp_dd = take(d * d);
-  L.ecom = take(7 * EMIN_NB * 8);
-  L.ftab_dual = take(L.sb_dual ? 2 * (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
+  L.ecom = take(4 * EMIN_NB * 8);
   L.wg_ftab = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
   L.wg_ftab2 = take(h2_mode() ? (d / 128) * (d / 128) * wgrad_h2_mpad(p * B * N) / 2 + 4 : 4);
-  L.ecom_s = take(p * 2 * EMIN_NB * 8);
-  L.ftab_s_stride = h2_mode() ? al4((d / 128) * (d / 128) * wgrad_h2_mpad(B * N) / 2 + 4) : 4;
-  L.ftab_s = take(p * L.ftab_s_stride);
-  {
-    // workgroups the chain kernel leaves free, a multiple of 8 (one XCD takes block b % 8): splits = free / output tiles
-    const size_t tiles = chain_supported((int)d, (int)N) ? chain_tiles((int)d, B * N) : 256;
-    const size_t free_wg = tiles < 256 ? ((256 - tiles) / 8) * 8 : 0;
-    L.side_ns = h2_mode() ? free_wg / wgrad_h2_tiles((int)d, (int)d) : 0;
-    if (L.side_ns > L.ns_big) L.side_ns = L.ns_big;
-  }
   L.total = off;
   return L;
 }
@@ -507,7 +439,6 @@ ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dr
   c.wk = P->kbLogits_w;
   c.X = h2_view(saved + L.X + (size_t)ob * L.act_stride, R, d);
   if (keep) {
-    if (L.XY) c.XY = h2_view(saved + L.XY + (size_t)ob * L.act_stride, R, d);
     c.H1 = h2_view(saved + L.H1 + (size_t)ob * L.act_stride, R, d);
     c.I2 = h2_view(saved + L.I2 + (size_t)ob * L.act_stride, R, d);
   }
@@ -834,11 +765,11 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
 
   CKI(pack_forward_weights(o, s, P, saved, L, keep, U_ALL, st));
 
-  // initial state (mac_cell.py:546-553), both tensors and the pair launches' arrival counter in one launch
+  // initial state (mac_cell.py:546-553), both tensors in one launch
   float* controls = saved + L.seg[MACX_SEG_CONTROLS];
   float* memories = saved + L.seg[MACX_SEG_MEMORIES];
   hipLaunchKernelGGL(init_states_kernel, dim3(64), dim3(256), 0, st, o->init_ctrl, P->initCtrl, controls, o->init_mem, P->initMem, memories,
-                     in->vecQuestions, B, d, reinterpret_cast<uint32_t*>(saved + L.pair_sync));
+                     in->vecQuestions, B, d);
   CK(hipGetLastError());
 
   // control inputs (mac_cell.py:442-448).  qInput is step-invariant; qInput{i} is batched over steps.
@@ -928,8 +859,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md, dlog_of(s));
     CK(hipGetLastError());
   }
-  const bool pair_fwd = md_fused && pair_fwd_ok(o, s, units);
-  if (!(pair_fwd && i > 0)) {        // (from step 1 on, the previous step's pair launch also left y behind)
+  {
     LinP l = lin_basic(md, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON, y, d);
     CK(small_linear_launch(l, 1, st));
   }
@@ -1076,14 +1006,8 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
       l.drop_row0 = (uint32_t)s->b0;
       l.out_drop = saved + L.md + (size_t)(i + 1) * Bd; l.ld_od = d;
     }
-    if (md_fused && i + 1 < s->p && pair_fwd_ok(o, s, units)) {
-      // ... and the next step's y = md Wy + by (ops.py:679,688) behind a device-scope barrier in the same launch
-      LinP ly = lin_basic(saved + L.md + (size_t)(i + 1) * Bd, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON,
-                          saved + L.y + (size_t)(i + 1) * Bd, d);
-      uint32_t* sync = reinterpret_cast<uint32_t*>(saved + L.pair_sync);
-      CK(small_linear_pair_launch(l, ly, false, LinPairSync{sync, sync + 1}, st));
-    } else {
-      CK(small_linear_launch(l, 1, st));
+    CK(small_linear_launch(l, 1, st));
+    if (o->write_gate) {      CK(small_linear_launch(l, 1, st));
     }
     if (o->write_gate) {
       // z = sigmoid(control Wg + bg + gateBias); m = newMemory * z + memory * (1 - z)   (mac_cell.py:358-367)
@@ -1189,36 +1113,23 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   const int nrb = nrb_of(N, B, d);
   const bool rdrop = dp->keep_read < 1.0f;
 
-  SideQueue* sq_any = ((units & U_READ) && h2_mode()) ? side_queue() : nullptr;
-  SideQueue* sq = (sq_any && overlap_mode() != 4) ? sq_any : nullptr;                     // modes 1-3: dKB of a step
-  // mode 4: dW2 of a step beside the chain kernels (only where there is room beside them and every step is kept)
-  const bool w2_side = sq_any && overlap_mode() == 4 && units == U_ALL && use_chain(d, N) && W.side_ns >= 1;
-  SideQueue* sq_w2 = (w2_side && phase != 2) ? sq_any : nullptr;
-
   if (phase != 2) {
-  // ---- weights in the layouts the backward kernels read: packed by the forward pass's pack launch into `saved` when it kept its
-  //      activations (SavedLayout::bwd_packs), else here into the workspace
-  const bool packs_fwd = L.bwd_packs != 0;
-  const float* wT = packs_fwd ? saved + L.bwd_packs : ws;
-  if (!packs_fwd) {
-    Packer pk;
-    CKI(add_bwd_packs(pk, o, s, P, ws, W, saved, L, units, st));
-    CK(pk.run(st));
-  }
+  // ---- weights in the layouts the backward kernels read: packed by the forward pass's pack launch into `saved`
+  //      (SavedLayout::bwd_packs; a run is differentiated only if it kept its activations, and then it packed these too)
+  if (!L.bwd_packs) return MACX_EINVAL;
+  const float* wT = saved + L.bwd_packs;
 
   float* DM = ws + W.DM;
   float* DC = ws + W.DC;
   // dL/d(newMemory linear output) for all steps; with writeMemAct = NON it IS dL/dm_{1..p}
   float* dwlin_all = (o->write_mem_act == MACX_ACT_NON && !o->write_gate) ? DM + Bd : ws + W.dwlin;
-  const bool pair_bwd = pair_bwd_ok(o, s, units);
-  if (DC == DM + (size_t)(p + 1) * Bd && ws + W.pair_sync == DC + (size_t)(p + 1) * Bd && !misaligned(d_memory) && !misaligned(d_control)) {
-    // (adjacent in the workspace: zeros, the incoming gradients in the last slabs and the pair launches' counter in ONE launch)
-    hipLaunchKernelGGL(bwd_init_kernel, dim3(fill_grid(2 * (size_t)(p + 1) * Bd)), dim3(256), 0, st, DM, Bd, p, d_memory, d_control, 4);
+  if (DC == DM + (size_t)(p + 1) * Bd && !misaligned(d_memory) && !misaligned(d_control)) {
+    // (adjacent in the workspace: zeros and the incoming gradients in the last slabs in ONE launch)
+    hipLaunchKernelGGL(bwd_init_kernel, dim3(fill_grid(2 * (size_t)(p + 1) * Bd)), dim3(256), 0, st, DM, Bd, p, d_memory, d_control, 0);
     CK(hipGetLastError());
   } else {
     CK(dev_zero(DM, (size_t)(p + 1) * Bd * sizeof(float), st));
     CK(dev_zero(DC, (size_t)(p + 1) * Bd * sizeof(float), st));
-    CK(dev_zero(ws + W.pair_sync, 16, st));
     if (d_memory) CK(dev_copy(DM + (size_t)p * Bd, d_memory, Bd * sizeof(float), st));
     if (d_control) CK(dev_copy(DC + (size_t)p * Bd, d_control, Bd * sizeof(float), st));
   }
@@ -1274,7 +1185,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, dmnew, mnew_out, o->write_mem_act, Bd, dwlin);
       CK(hipGetLastError());
     }
-    if (!(pair_bwd && i < p - 1)) {      // (below step p - 1 the dy-linear launch of step i + 1 already did it: pair launch)
+    {
       LinP l = lin_basic(dwlin, d, d, B, wT + W.wmT, nullptr, win, MACX_ACT_NON, dwin, win);
       CK(small_linear_launch(l, 1, st));
     }
@@ -1366,29 +1277,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         c.dX = hdX; c.dbx_part = ws + W.dbx_part + (size_t)i * W.db_rows * d;
         if (W.sb_deferred) { c.X = hX; c.dy_part = ws + W.dyc_part; }
         CK(chain_bwd_launch(c, st));
-        if (sq_w2) {
-          // dW2 += H1_i^T dI2_i on the side queue (macx_wgrad_h2.hip.h), its own common exponents and row factors per step
-          hipStream_t s2 = sq_w2->s;
-          CK(hipEventRecord(sq_w2->fork, st));
-          CK(hipStreamWaitEvent(s2, sq_w2->fork, 0));
-          int* ecs = reinterpret_cast<int*>(ws + W.ecom_s) + (size_t)i * 2 * EMIN_NB * 8;
-          EminList el;
-          memset(&el, 0, sizeof(el));
-          el.R = R; el.C = d; el.part = ecs;
-          el.base[0] = reinterpret_cast<const char*>(H1); el.nt[0] = 1;
-          el.base[1] = reinterpret_cast<const char*>(dI2_i); el.nt[1] = 1;
-          CK(emin_list(el, 2, s2));
-          TnH2P t;
-          memset(&t, 0, sizeof(t));
-          t.M = R; t.Kd = d; t.Jd = d; t.nsplit = (int)W.side_ns; t.rows_per_split = rows_per_split(t.M, t.nsplit);
-          t.R = R;
-          t.A = reinterpret_cast<const char*>(H1); t.G = reinterpret_cast<const char*>(dI2_i);
-          t.ecomA = ecs; t.ecomG = ecs + EMIN_NB * 8; t.ecom_nb = EMIN_NB;
-          t.ftab = reinterpret_cast<uint16_t*>(ws + W.ftab_s + (size_t)i * W.ftab_s_stride);
-          t.part = ws + W.slab_w2;
-          t.accumulate = (i != p - 1);
-          CK(wgrad_h2_launch(t, s2));
-        }
         if (W.chain_sums && (dc_in_loop || (W.sb_deferred && !W.dy_in_linear))) {
           // the per-tile partials of this step: dL/dc_i += read-unit part, db_k partials, dy_i (the next launch needs dy_i)
           DcReduceP q;
@@ -1429,13 +1317,12 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         q.dbg = kb_gemm_dbg();
         CK(sb_h2_launch(q, st));
       }
-      // dKB = sum_i (dX_i Wx^T) * kbmask_i + att_i (x) dinfo_i: a launch per step on the side queue (it runs under the [B,d]
-      // launches that follow on the caller's stream), or ONE launch over all steps after step 0
-      if (sq || i == 0) {
-        const int i0 = sq ? i : 0;
+      // dKB = sum_i (dX_i Wx^T) * kbmask_i + att_i (x) dinfo_i: ONE launch over all steps after step 0
+      if (i == 0) {
+        const int i0 = 0;
         g.A = h2_view(ws + W.dX + (size_t)i0 * W.act_floats, B * N, d); g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
         g.Wh = reinterpret_cast<const char*>(wT + W.wxT_p); g.w_exp = reinterpret_cast<const int*>(wT + W.wxT_p) + dd;
-        g.nsteps = sq ? 1 : p; g.a_step_bytes = W.act_floats * sizeof(float);
+        g.nsteps = p; g.a_step_bytes = W.act_floats * sizeof(float);
         g.a_row_exp = chain ? 1 : 0;          // chain_bwd_kernel gives a row of dX ONE exponent: the merged launch may fold once per step
         g.out_f32 = GI->knowledgeBase; g.ldo = d;
         const bool wd = dp->keep_write < 1.0f;
@@ -1445,15 +1332,9 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         g.att = att_kb + (size_t)i0 * B * N; g.att_step = (size_t)B * N;
         g.e_bits = rdrop ? reinterpret_cast<const uint32_t*>(saved + L.kb_bits + (size_t)i0 * L.bits_stride) : nullptr;
         g.bits_step_words = L.bits_stride;
-        g.accumulate = sq ? (i != p - 1) : 0;
+        g.accumulate = 0;
         g.colsum_part = nullptr; g.aux = H2View{nullptr, 0, 0};
-        if (sq) {
-          CK(hipEventRecord(sq->fork, st));
-          CK(hipStreamWaitEvent(sq->s, sq->fork, 0));
-          CK((kb_gemm_h2_launch<B_PLAIN, E_DKB, false>(g, sq->s)));
-        } else {
-          CK((kb_gemm_h2_launch<B_PLAIN, E_DKB, false>(g, st)));
-        }
+        CK((kb_gemm_h2_launch<B_PLAIN, E_DKB, false>(g, st)));
       }
     } else {
     {
@@ -1522,14 +1403,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       if (units & U_WRITE) { l.addend = dwin; l.ld_add = win; }
       const bool part_form = h2_mode() && W.dy_in_linear;
       if (part_form) { l.part = ws + W.dyc_part; l.part_N = N; l.part_sum = DYi; l.part_shift = chain_tile_shift(d, (size_t)B * N); }
-      if (pair_bwd && i > 0 && !acc_prev) {
-        // dL/dm_{i-1} (this launch's output) is the input of step i - 1's write-unit backward linear
-        // [dm part | dinfo] = dwlin Wm^T (writeMemAct = NON, no gate: dwlin_{i-1} IS dL/dm_{i-1}): both in one launch
-        LinP lw = lin_basic(dwlin_all + (size_t)(i - 1) * Bd, d, d, B, wT + W.wmT, nullptr, win, MACX_ACT_NON,
-                            ws + W.dwin + (size_t)(i - 1) * B * win, win);
-        uint32_t* sync = reinterpret_cast<uint32_t*>(ws + W.pair_sync);
-        CK(small_linear_pair_launch(l, lw, part_form, LinPairSync{sync, sync + 1}, st));
-      } else if (part_form) {
+      if (part_form) {
         CK(small_linear_part_launch(l, st));
       } else {
         CK(small_linear_launch(l, 1, st));
@@ -1604,10 +1478,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     q.tile_shift = chain_tile_shift(d, (size_t)B * N);
     hipLaunchKernelGGL(dc_reduce_kernel, dim3(B, p), dim3(128), 0, st, q);
     CK(hipGetLastError());
-  }
-  if (sq || sq_w2) {               // join: everything the side queue was given is ordered before what follows on `stream`
-    CK(hipEventRecord(sq_any->join, sq_any->s));
-    CK(hipStreamWaitEvent(st, sq_any->join, 0));
   }
   if (units == U_ALL) {
   if (o->write_self_att && !o->write_self_att_cont && !o->control_feed_prev) {
@@ -1768,21 +1638,14 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       el.base[1] = reinterpret_cast<const char*>(ws + W.dI2); el.stride[1] = W.act_floats * sizeof(float); el.nt[1] = p;
       el.base[2] = reinterpret_cast<const char*>(saved + L.KBd); el.stride[2] = L.act_stride * sizeof(float); el.nt[2] = rdrop ? p : 1;
       el.base[3] = reinterpret_cast<const char*>(ws + W.dX); el.stride[3] = W.act_floats * sizeof(float); el.nt[3] = p;
-      if (W.sb_dual && L.XY) {
-        el.base[4] = reinterpret_cast<const char*>(saved + L.XY); el.stride[4] = L.act_stride * sizeof(float); el.nt[4] = p;
-        el.base[5] = reinterpret_cast<const char*>(saved + L.X); el.stride[5] = L.act_stride * sizeof(float); el.nt[5] = p;
-        el.base[6] = reinterpret_cast<const char*>(ws + W.dI1); el.stride[6] = W.dI1_stride * sizeof(float); el.nt[6] = p;
-        CK(emin_list(el, 7, st));
-      } else {
-        CK(emin_list(el, 4, st));
-      }
+      CK(emin_list(el, 4, st));
     }
     TnH2P t;
     memset(&t, 0, sizeof(t));
     // mode 3: the two contractions share ONE launch AND the chip -- half the reduction splits each, so that the 2 x 128 workgroups
     // are all resident at once (one per CU) instead of 2 x 256 in two rounds: a workgroup's prologue, its 256 KB slab and the slab
     // reduction's input are paid for once per CU instead of twice
-    ns_w = (!w2_side && wgrad_pipe_mode() >= 3 && wgrad_h2_kw(d) == 2 && wgrad_h2_jw(d) == 2 && W.ns_big >= 2) ? (int)W.ns_big / 2 : (int)W.ns_big;
+    ns_w = (wgrad_pipe_mode() >= 3 && wgrad_h2_kw(d) == 2 && wgrad_h2_jw(d) == 2 && W.ns_big >= 2) ? (int)W.ns_big / 2 : (int)W.ns_big;
     t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = ns_w; t.rows_per_split = rows_per_split(t.M, t.nsplit);
     t.R = B * N;
     t.A = reinterpret_cast<const char*>(saved + L.H1); t.a_stride = L.act_stride * sizeof(float); t.a_mod = 0;
@@ -1798,8 +1661,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     t.ecomA = ecom + 2 * ES; t.ecomG = ecom + 3 * ES;
     t.part = ws + W.slab_wx;
     t.ftab = reinterpret_cast<uint16_t*>(ws + W.wg_ftab2);    // (a table of its own: the pair form builds both before either is read)
-    if (w2_side) CK(wgrad_h2_launch(t, st));
-    else CK(wgrad_h2_launch_pair(t_w2, t, st));
+    CK(wgrad_h2_launch_pair(t_w2, t, st));
   } else {
     TnP t;
     memset(&t, 0, sizeof(t));
@@ -1814,25 +1676,6 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     CK(wgrad_any(t, st));
   }
 
-  const bool dual_run = h2_mode() && W.sb_deferred && W.sb_dual && L.XY;
-  if (dual_run) {
-    // dW1a = sum over all p B N rows of (X * y)^T dI1, dW1b = ... X^T dI1 (ops.py:703,718): one contraction with two A families,
-    // the dI1 half of every stage staged once for both (wgrad_h2_kernel, dual form)
-    int* ecom = reinterpret_cast<int*>(ws + W.ecom);
-    constexpr int ES = EMIN_NB * 8;
-    TnH2P t;
-    memset(&t, 0, sizeof(t));
-    t.M = p * B * N; t.Kd = d; t.Jd = d; t.nsplit = (int)W.ns_dual; t.rows_per_split = rows_per_split(t.M, t.nsplit);
-    t.R = B * N;
-    t.A = reinterpret_cast<const char*>(saved + L.XY); t.a_stride = L.act_stride * sizeof(float); t.a_mod = 0;
-    t.A2 = reinterpret_cast<const char*>(saved + L.X); t.a2_stride = L.act_stride * sizeof(float);
-    t.G = reinterpret_cast<const char*>(ws + W.dI1); t.g_stride = W.dI1_stride * sizeof(float);
-    t.ecomA = ecom + 4 * ES; t.ecomA2 = ecom + 5 * ES; t.ecomG = ecom + 6 * ES; t.ecom_nb = EMIN_NB;
-    t.ftab = reinterpret_cast<uint16_t*>(ws + W.ftab_dual);
-    t.dbg = kb_gemm_dbg();
-    t.part = ws + W.slab_w1a; t.part2 = ws + W.slab_w1b;
-    CK(wgrad_h2_dual_launch(t, st));
-  } else
   if (h2_mode() && W.sb_deferred) {
     // dW1a = sum_i sum_b diag(y_ib) S_ib, dW1b = sum_i sum_b S_ib, S_ib = X_ib^T dI1_ib: every step in one launch, the two
     // accumulators of a workgroup run through all of them (macx_wgrad_h2.hip.h)
@@ -1849,10 +1692,10 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     q.qpg = W.sb_qpg;
     CK(W.sb_wide ? sb_h2w_launch(q, st) : sb_h2_launch(q, st));
   }
-  const int nslab1 = dual_run ? (int)W.ns_dual : (int)((h2_mode() && W.sb_deferred ? 1 : p) * W.ngroup);
+  const int nslab1 = (int)((h2_mode() && W.sb_deferred ? 1 : p) * W.ngroup);
   {
     SlabList sl;
-    sl.d[0] = SlabDesc{ws + W.slab_w2, (int)((h2_mode() && w2_side) ? W.side_ns : ns_w), dd / 4, GP->memKbProj2_W, 0};
+    sl.d[0] = SlabDesc{ws + W.slab_w2, ns_w, dd / 4, GP->memKbProj2_W, 0};
     sl.d[1] = SlabDesc{ws + W.slab_wx, ns_w, dd / 4, GP->projX_W, 0};
     sl.d[2] = SlabDesc{ws + W.slab_w1a, nslab1, dd / 4, GP->memKbProj_W, 0};
     sl.d[3] = SlabDesc{ws + W.slab_w1b, nslab1, dd / 4, GP->memKbProj_W + dd, 0};
@@ -2971,25 +2814,6 @@ int macx_saved_activation(const macx_opts* o, const macx_shapes* s, int which, i
     CK(dev_copy(out, src, R * s->d * sizeof(float), st));
   }
   return MACX_OK;
-}
-
-int macx_debug_set(int key, int value) {
-  if (key == 0 && (value == 4 || value == 8)) { kb_gemm_nw() = value; return MACX_OK; }
-  if (key == 1) { kb_gemm_dbg() = value; return MACX_OK; }
-  if (key == 4 && (value == 0 || value == 1)) { chain_mode() = value; return MACX_OK; }
-  if (key == 5 && (value == 0 || value == 1)) { sb_defer_mode() = value; return MACX_OK; }
-  if (key == 6 && value >= 0 && value <= 4) { overlap_mode() = value; return MACX_OK; }
-  if (key == 7 && value >= -1 && value <= 255) { chain_kv() = value; return MACX_OK; }
-  if (key == 8 && value >= 0 && value <= 2) { sb_wide_mode() = value; return MACX_OK; }
-  if (key == 9 && (value == 0 || value == 1)) { conv_chain_mode() = value; return MACX_OK; }
-  if (key == 10 && value >= 0 && value <= 3) { wgrad_pipe_mode() = value; return MACX_OK; }
-  if (key == 11 && (value == 0 || (value >= 16 && value <= 256))) { lin_pair_grid() = value; return MACX_OK; }
-  if (key == 12 && (value == 0 || value == 1)) { lin_wide_waves() = value; return MACX_OK; }
-  if (key == 13 && (value == 0 || value == 1)) { sb_cont_mode() = value; return MACX_OK; }
-  if (key == 14 && (value == 0 || value == 1)) { dkb_uni_mode() = value; return MACX_OK; }
-  if (key == 3 && (value == 0 || value == 1 || value == 2)) { gemm_default_mode() = value; return MACX_OK; }
-  if (key == 2 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7 || value == 13)) { kb_gemm_force_rt() = value; return MACX_OK; }
-  return MACX_EINVAL;
 }
 
 int macx_wgrad_splits(int M, int Kd, int Jd) {

@@ -32,8 +32,6 @@ struct ChainFwdP {
   const float* c;           // [B][d]
   const float* wk;          // [d]
   H2View X;                 // written in mode 0, read in mode 1
-  H2View XY;                // base null: not written.  X * y as stage 2 multiplies it (ops.py:703), kept for the backward pass's
-                            // dW1a = (X * y)^T dI1 contraction (wgrad_h2_kernel's dual form)
   H2View H1;                // base null: not written (inference)
   H2View I2;                // base null: not written
   float* logits;            // [M] (without the bias b_k, which kb_attend adds)
@@ -78,10 +76,10 @@ struct ChainBwdP {
   float* dy_part;           // [tiles][3][d] per question segment, like dc_part; null: not computed
 };
 
-// K-loop variant of the d = 512, 64-row chain kernels (ChainCtx::kloop: 4 = activation reads in mid-slice, 8 = static priority,
-// 16 = the 32 x 32 x 16 instruction, and their sums); -1 = the default.  macx_debug_set(7, v): A/B measurements in one process
+// K-loop variant of the d = 512, 64-row chain kernels (ChainCtx::kloop: 4 = activation reads in mid-slice); -1 = the default,
+// 0 = reads in front of the slice.  macx_opts.tune[MACX_TUNE_CHAIN_KV]: the A/B hook of that decision
 constexpr int CHAIN_KV_DEFAULT = 4;
-inline int& chain_kv() { static int v = -1; return v; }
+inline int chain_kv() { return tune_get(MACX_TUNE_CHAIN_KV, -1); }
 inline bool chain_supported(int d, int N) { return d % 128 == 0 && d >= 128 && d <= 512 && N >= 16; }
 // rows per tile: the tallest tile that still leaves the chip one tile per CU (short tiles exist for d = 512 only)
 inline int chain_tile_rows(int d, size_t M) {

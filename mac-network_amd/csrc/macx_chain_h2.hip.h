@@ -97,28 +97,25 @@ __device__ __forceinline__ float chain_act(int act, float x) {
 // metric's 64 questions): a launch lasts as long as ONE tile takes, so with 25 tiles of 64 rows on 256 CUs the kernel ran as
 // long as with 196 -- shorter tiles put the rows on more CUs (the weights then stream from L2 once per 16 or 32 rows instead
 // of once per 64: the K loop turns L2-bound, at about half its time).
-template <int D_, int R_ = 64, int MF_ = 0>
+template <int D_, int R_ = 64>
 struct ChainGeo {
   static constexpr int D = D_, R = R_, KG = D / 8, CB = D / 128, KS = D / 32;
-  // MF: the matrix instruction.  0: v_mfma_f32_16x16x32_f16 (16 accumulator tiles of 16 x 16 per wave at d = 512); 1:
-  // v_mfma_f32_32x32x16_f16 (4 tiles of 32 x 32, two instructions per 32-wide K slice) -- the 32 x 32 form issues at the
-  // pipe's full rate (MI355X_MICROARCH.md: 32 cycles per 32768 FLOP against ~19.5 per 16384 measured for 16x16x32).
-  static constexpr int MF = MF_;
-  static constexpr int TM = MF ? 32 : 16;            // edge of the instruction's output tile
+  // the matrix instruction is v_mfma_f32_16x16x32_f16: 16 accumulator tiles of 16 x 16 per wave at d = 512.  (v_mfma_f32_32x32x16_f16
+  // -- 4 tiles of 32 x 32 -- was built, parity-green and measured 13-24 us per launch SLOWER in round 4: on random fp16 operands the
+  // 32 x 32 form issues at 48.5 cycles against 2 x 21.4, profiles/r04_mfma_probe.txt, r04_kloop_variants.txt.  Removed in round 6.)
+  static constexpr int TM = 16;                      // edge of the instruction's output tile
   static constexpr int NWC = D >= 512 ? 8 : 4;       // waves along the columns
   static constexpr int NWR = 8 / NWC;                // waves along the rows
   static constexpr int CW = D / NWC;                 // columns per wave
   static constexpr int RPW = R / NWR;                // rows per wave
   static constexpr int RT = RPW / TM;                // row tiles per wave
-  // accumulators are addressed as f32x4 acc[RT][CT]: four consecutive columns of one row per entry.  16 x 16: one entry per
-  // 16-column tile; 32 x 32: the instruction leaves a lane four such groups per tile (columns 8 b + 4 (lane >> 5) .. + 3)
-  static constexpr int CT = MF ? CW / 8 : CW / 16;
+  // accumulators are addressed as f32x4 acc[RT][CT]: four consecutive columns of one row per entry, one entry per 16-column tile
+  static constexpr int CT = CW / 16;
   static constexpr int NRG = R / 16;                 // 16-row groups of the tile
   static constexpr int WPG = 8 / NRG;                // conversion passes: waves that share a row group
   static constexpr int IT = KG / (4 * WPG);          // ... slot columns per lane (16 rows x 4 slot columns per wave step)
   static constexpr int SB = R / 8;                   // backward stage B0: 8-row blocks per lane
   static_assert(R == 64 || ((R == 32 || R == 16) && NWR == 1), "short tiles: every wave holds all rows (d = 512)");
-  static_assert(!MF || (RPW % 32 == 0 && CW % 32 == 0 && RT * (CW / 32) >= 4), "32 x 32 tiles: at least four independent accumulators per wave");
   static constexpr size_t P_BYTES = (size_t)4 * R * D;
   static constexpr int QS = 5;                       // backward: questions a tile can touch (N >= 16) -- their control vectors are staged in LDS
   static constexpr int BITS_LD = KG + 4;             // bytes per row of sBits (+4: rows 4 apart would share a bank)
@@ -129,11 +126,11 @@ struct ChainGeo {
 };
 
 // what both kernels share: the tile in LDS, who owns what, the K loop, the row-exponent bookkeeping, the H2 emitters
-template <int D_, int R_ = 64, int MF_ = 0>
+template <int D_, int R_ = 64>
 struct ChainCtx {
-  using G = ChainGeo<D_, R_, MF_>;
+  using G = ChainGeo<D_, R_>;
   static constexpr int D = G::D, R = G::R, KG = G::KG, CB = G::CB, KS = G::KS, NWC = G::NWC, NWR = G::NWR, CT = G::CT, RT = G::RT, IT = G::IT,
-                       WPG = G::WPG, SB = G::SB, MF = G::MF, TM = G::TM, CW = G::CW, RPW = G::RPW;
+                       WPG = G::WPG, SB = G::SB, TM = G::TM, CW = G::CW, RPW = G::RPW;
   char* P;          // [2 planes][KG][R] x 16 B: the stage's activation operand
   float* sMax;      // [8][R] partial row maxima
   float* sPart;     // [8][R] partial row sums (attention logits)
@@ -163,7 +160,7 @@ struct ChainCtx {
     tid = threadIdx.x; lane = tid & 63;
     wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     li = lane & 15; lg = lane >> 4;
-    ar = MF ? (lane & 31) : li; ah = MF ? (lane >> 5) : lg;
+    ar = li; ah = lg;
     wr = wave / NWC; wc = wave % NWC;
     colbase = wc * CW; rowbase = wr * RPW;
     M = M_; N = N_;
@@ -314,19 +311,15 @@ struct ChainCtx {
   }
 
   // ---- the K loop of one product: acc[T][c] += W^T-slot x A-slot over all d (three fp16 terms, smallest first).
-  // KV is a bit mask.  KV & 3: measurement variants (0 = the product): 1 no MFMA (the loads stay), 2 no weight loads inside the
-  // loop, 3 no loads at all inside the loop -- timing only, results are wrong.  KV & 4: the activation fragments of the next
-  // slice are requested in the MIDDLE of the current slice's products instead of in front of them (their s_waitcnt
-  // lgkmcnt(0) then finds them long complete; requested in front, the wait sits between the request and the first
-  // product).  KV & 8: static priority for the second-dispatched half of the workgroup (chain kernels set it once, at entry).
-  // KV & 16: the 32 x 32 x 16 instruction (MF, a property of the context).
+  // KV is a bit mask.  KV & 4 (the default, CHAIN_KV_DEFAULT): the activation fragments of the next slice are requested in the MIDDLE
+  // of the current slice's products instead of in front of them (their s_waitcnt lgkmcnt(0) then finds them long complete;
+  // requested in front, the wait sits between the request and the first product) -- macx_opts.tune[MACX_TUNE_CHAIN_KV] = MACX_TUNE(0) is the A/B hook.
+  // KV & 3 (only in a build with -DMACX_PROFILE_VARIANTS): measurement variants -- 1 no MFMA (the loads stay), 2 no weight loads
+  // inside the loop, 3 no loads at all inside the loop; timing only, results are wrong.
+  // (Measured and removed: static s_setprio for the second-dispatched waves, a term-major product order, the 32 x 32 x 16
+  // instruction -- profiles/r04_kloop_variants.txt.)
   template <int KV>
   __device__ __forceinline__ void kloop(f32x4 (&acc)[RT][CT], const char* W) const {
-    if constexpr (MF) kloop32<KV>(acc, W);
-    else kloop16<KV>(acc, W);
-  }
-  template <int KV>
-  __device__ __forceinline__ void kloop16(f32x4 (&acc)[RT][CT], const char* W) const {
     constexpr int KM = KV & 3;
     constexpr bool MID = (KV & 4) != 0 && RT >= 2;
     const char* wb = W + ((size_t)lg * D + colbase + li) * 16;
@@ -371,21 +364,6 @@ struct ChainCtx {
         }
         return;
       }
-      if (KV & 32) {      // term-major: every accumulator of the range once per term (16 instead of 4 instructions between two on the same one)
-#pragma unroll
-        for (int t = t0; t < t1; ++t)
-#pragma unroll
-          for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][0][c], aq[S][1][t], acc[t][c]);
-#pragma unroll
-        for (int t = t0; t < t1; ++t)
-#pragma unroll
-          for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][1][c], aq[S][0][t], acc[t][c]);
-#pragma unroll
-        for (int t = t0; t < t1; ++t)
-#pragma unroll
-          for (int c = 0; c < CT; ++c) acc[t][c] = mfma_f16(bq[S][0][c], aq[S][0][t], acc[t][c]);
-        return;
-      }
 #pragma unroll
       for (int t = t0; t < t1; ++t) {
 #pragma unroll
@@ -423,112 +401,6 @@ struct ChainCtx {
       half_step(S1{}, S0{}, min(kt + 2, KS - 2));   // (unconditional: behind a branch the wait-count pass drains every load at the join)
     }
   }
-  // the same product on v_mfma_f32_32x32x16_f16: a wave's RPW x CW block is RT x CW/32 tiles of 32 x 32, a 32-wide K slice is
-  // two instructions per tile and term (k groups 0-1 and 2-3 of the slice; lane = (row or column l & 31, k group l >> 5)).
-  // Same operand swap as the 16 x 16 form (D^T = W^T A^T): lane l ends up with row l & 31 of the tile and the columns
-  // 8 b + 4 (l >> 5) + q, b = 0..3 -- four groups of four consecutive columns, i.e. half a slot each -- which is exactly what
-  // acc[t][4 c32 + b][q] names, so every epilogue is shared with the 16 x 16 form through arow / acol / akg / ahalf.
-  // Every tile is visited once per term and k half: the same accumulator is four instructions (128 cycles) apart.
-  template <int KV>
-  __device__ __forceinline__ void kloop32(f32x4 (&acc)[RT][CT], const char* W) const {
-    constexpr int KM = KV & 3;
-    constexpr bool MID = (KV & 4) != 0;
-    constexpr int C32 = CW / 32;
-    const char* wb = W + ((size_t)ah * D + colbase + ar) * 16;
-    const char* pa = P + ((size_t)ah * R + rowbase + ar) * 16;
-    // (whole-vector shuffles: element-wise inserts into an array of 16-wide vectors are not promoted to registers)
-    typedef float f32x8 __attribute__((ext_vector_type(8)));
-    f32x16 A[RT][C32];
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int c = 0; c < C32; ++c) {
-        const f32x8 lo = __builtin_shufflevector(acc[t][4 * c], acc[t][4 * c + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-        const f32x8 hi = __builtin_shufflevector(acc[t][4 * c + 2], acc[t][4 * c + 3], 0, 1, 2, 3, 4, 5, 6, 7);
-        A[t][c] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-      }
-    u32x4 bq[2][2][C32][2], aq[2][2][RT][2];        // [set][plane][tile][k half]
-    auto load_b = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
-      constexpr int S = decltype(set_c)::value;
-      if (!(KM >= 2 && in_loop)) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int c = 0; c < C32; ++c)
-              bq[S][pl][c][kk] = *reinterpret_cast<const u32x4*>(wb + ((size_t)((kt * 2 + pl) * 4 + 2 * kk) * D) * 16 + c * 512);
-      }
-    };
-    auto load_a = [&](auto set_c, int kt, bool in_loop) __attribute__((always_inline)) {
-      constexpr int S = decltype(set_c)::value;
-      if (!(KM >= 3 && in_loop)) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-              aq[S][pl][t][kk] = *reinterpret_cast<const u32x4*>(pa + ((size_t)(pl * KG + 4 * kt + 2 * kk) * R + 32 * t) * 16);
-      }
-    };
-    auto mm = [&](auto set_c, int kk) __attribute__((always_inline)) {
-      constexpr int S = decltype(set_c)::value;
-      if (KM == 1) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-          for (int c = 0; c < C32; ++c) asm volatile("" ::"v"(bq[S][pl][c][kk]));
-#pragma unroll
-          for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(aq[S][pl][t][kk]));
-        }
-        return;
-      }
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int c = 0; c < C32; ++c) A[t][c] = mfma32_f16(bq[S][0][c][kk], aq[S][1][t][kk], A[t][c]);     // w_hi a_lo
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int c = 0; c < C32; ++c) A[t][c] = mfma32_f16(bq[S][1][c][kk], aq[S][0][t][kk], A[t][c]);     // w_lo a_hi
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int c = 0; c < C32; ++c) A[t][c] = mfma32_f16(bq[S][0][c][kk], aq[S][0][t][kk], A[t][c]);     // w_hi a_hi
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    load_b(S0{}, 0, false); load_a(S0{}, 0, false);
-    if (KM >= 2) { load_b(S1{}, 1, false); load_a(S1{}, 1, false); }
-    auto half_step = [&](auto cur, auto nxt, int kn) __attribute__((always_inline)) {
-      load_b(nxt, kn, true);
-      if (!MID) load_a(nxt, kn, true);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(cur, 0);
-      if (MID) {
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(nxt, kn, true);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      mm(cur, 1);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-#pragma unroll 1
-    for (int kt = 0; kt < KS; kt += 2) {
-      half_step(S0{}, S1{}, kt + 1);
-      half_step(S1{}, S0{}, min(kt + 2, KS - 2));
-    }
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int c = 0; c < C32; ++c) {
-        acc[t][4 * c + 0] = __builtin_shufflevector(A[t][c], A[t][c], 0, 1, 2, 3);
-        acc[t][4 * c + 1] = __builtin_shufflevector(A[t][c], A[t][c], 4, 5, 6, 7);
-        acc[t][4 * c + 2] = __builtin_shufflevector(A[t][c], A[t][c], 8, 9, 10, 11);
-        acc[t][4 * c + 3] = __builtin_shufflevector(A[t][c], A[t][c], 12, 13, 14, 15);
-      }
-  }
   __device__ __forceinline__ void zero_acc(f32x4 (&acc)[RT][CT]) const {
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -536,26 +408,23 @@ struct ChainCtx {
       for (int c = 0; c < CT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- accumulator geometry: lane (ar, ah) holds, for row tile t and column group c, row rowbase + TM t + ar and the four
-  //      columns acol(c) .. + 3 in acc[t][c][0..3] (16 x 16: ar = lane & 15, ah = lane >> 4, one group per 16-column tile;
-  //      32 x 32: ar = lane & 31, ah = lane >> 5, four groups per 32-column tile).  A group is half of the slot akg(c).
+  // ---- accumulator geometry: lane (ar = lane & 15, ah = lane >> 4) holds, for row tile t and 16-column tile c, row rowbase + 16 t + ar
+  //      and the four columns acol(c) .. + 3 in acc[t][c][0..3].  A group is half of the slot akg(c).
   __device__ __forceinline__ int arow(int t) const { return rowbase + TM * t + ar; }
-  __device__ __forceinline__ int acol(int c) const { return colbase + (MF ? 8 * c + 4 * ah : 16 * c + 4 * ah); }
-  __device__ __forceinline__ int akg(int c) const { return (colbase >> 3) + (MF ? c : 2 * c + (ah >> 1)); }
-  __device__ __forceinline__ int ahalf() const { return (MF ? ah : (ah & 1)) * 8; }
+  __device__ __forceinline__ int acol(int c) const { return colbase + 16 * c + 4 * ah; }
+  __device__ __forceinline__ int akg(int c) const { return (colbase >> 3) + 2 * c + (ah >> 1); }
+  __device__ __forceinline__ int ahalf() const { return (ah & 1) * 8; }
   // reductions over the lanes that hold the same row (different column groups) / the same columns (different rows)
   __device__ __forceinline__ float rowred_max(float m) const {
-    if (!MF) m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
     return fmaxf(m, __shfl_xor(m, 32, 64));
   }
   __device__ __forceinline__ float rowred_sum(float v) const {
-    if (!MF) v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 16, 64);
     return v + __shfl_xor(v, 32, 64);
   }
   __device__ __forceinline__ float colred_sum(float v) const {
-    v = row16_sum(v);
-    if (MF) v += __shfl_xor(v, 16, 64);
-    return v;
+    return row16_sum(v);
   }
   __device__ __forceinline__ bool row_writer() const { return ah == 0; }     // one lane per row
   __device__ __forceinline__ bool col_writer() const { return ar == 0; }     // one lane per column group
@@ -634,13 +503,12 @@ struct ChainCtx {
 
 template <int D_, int KV = 0, int R_ = 64>
 __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
-  using C = ChainCtx<D_, R_, (KV >> 4) & 1>;
+  using C = ChainCtx<D_, R_>;
   constexpr int D = C::D, R = C::R, KG = C::KG, CT = C::CT, RT = C::RT, IT = C::IT;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   C x;
   x.init(lds, p.M, p.N);
   const int M = p.M;
-  if ((KV & 8) && x.wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched wave of each SIMD loses every arbitration otherwise
 
   // =====================================================================================================================
   // stage 0: the operand of the first product
@@ -751,7 +619,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
         m = fmaxf(m, fabsf(v[j][q]));
       }
     }
-    x.convert_finish(v, m, x.sE2, p.XY.base ? p.XY : H2View{nullptr, M, D});
+    x.convert_finish(v, m, x.sE2, H2View{nullptr, M, D});
   }
   {
     // accumulators: units 2^-(eX + e1b)  ->  2^-(eXy + e1a), exactly
@@ -829,7 +697,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
 template <int D_, int KV = 0, int R_ = 64>
 inline hipError_t chain_fwd_launch_t(const ChainFwdP& p, hipStream_t st) {
   auto kern = chain_fwd_kernel<D_, KV, R_>;
-  constexpr size_t lds = ChainGeo<D_, R_>::LDS;      // (the same for both matrix instructions)
+  constexpr size_t lds = ChainGeo<D_, R_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
@@ -849,18 +717,15 @@ hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
         case 32: return chain_fwd_launch_t<512, 0, 32>(p, st);
         default: break;
       }
+#ifdef MACX_PROFILE_VARIANTS
       switch (p.dbg >> 3) {
         case 1: return chain_fwd_launch_t<512, 1>(p, st);
         case 2: return chain_fwd_launch_t<512, 2>(p, st);
         case 3: return chain_fwd_launch_t<512, 3>(p, st);
         default: break;
       }
-      switch (chain_kv()) {
-        case 0: return chain_fwd_launch_t<512, 0>(p, st);
-        case 4: return chain_fwd_launch_t<512, 4>(p, st);
-        case 20: return chain_fwd_launch_t<512, 20>(p, st);
-        default: return chain_fwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
-      }
+#endif
+      return chain_kv() == 0 ? chain_fwd_launch_t<512, 0>(p, st) : chain_fwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
     default: return hipErrorInvalidValue;
   }
 }
@@ -873,13 +738,12 @@ hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
 // register allocation (two arms: 86 spilled registers; a per-value run-time switch: 102-104).
 template <int D_, int KV = 0, int A2 = -1, int R_ = 64>
 __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
-  using C = ChainCtx<D_, R_, (KV >> 4) & 1>;
+  using C = ChainCtx<D_, R_>;
   constexpr int D = C::D, R = C::R, KG = C::KG, CB = C::CB, CT = C::CT, RT = C::RT, IT = C::IT;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   C x;
   x.init(lds, p.M, p.N);
   const int M = p.M;
-  if ((KV & 8) && x.wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   // =====================================================================================================================
   // stage B0 (SURVEY appendix A rows "softmax", "logit", "ctrl-mul"):
@@ -920,7 +784,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
     // front of the softmax-backward scalars below (two barriers and a round of global loads of their own), so that the tile's HBM
     // burst runs under them; what needs the scalars (dl) is finished in fetch_b.  Only where all eight waves take part (d = 512): a
     // load under `if (active)` would be drained at the join.
-    constexpr bool EARLY = (KV & 64) != 0 && (KG / 8) >= 8 && C::SB >= 3;       // KV & 64: A/B against the late form (macx_debug_set(7, 4))
+    constexpr bool EARLY = (KG / 8) >= 8 && C::SB >= 3;
     int eraw[3];
     float a_r[3], d_r[3];
     auto fetch_a = [&](auto sb_c) __attribute__((always_inline)) {
@@ -1228,7 +1092,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
 template <int D_, int KV, int A2, int R_ = 64>
 inline hipError_t chain_bwd_launch_a(const ChainBwdP& p, hipStream_t st) {
   auto kern = chain_bwd_kernel<D_, KV, A2, R_>;
-  constexpr size_t lds = ChainGeo<D_, R_>::LDS;      // (the same for both matrix instructions)
+  constexpr size_t lds = ChainGeo<D_, R_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
@@ -1261,19 +1125,16 @@ hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
         case 32: return chain_bwd_launch_t<512, 0, 32>(p, st);
         default: break;
       }
-      // the measurement variants of the K loop exist for the published configurations' activation (ELU) only
-      if (p.act2 != ACT_ELU) return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT | 64>(p, st);
+      // the A/B and measurement variants of the K loop exist for the published configurations' activation (ELU) only
+      if (p.act2 != ACT_ELU) return chain_bwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
+#ifdef MACX_PROFILE_VARIANTS
       switch (p.dbg >> 3) {
         case 1: return chain_bwd_launch_a<512, 1, ACT_ELU>(p, st);
         case 3: return chain_bwd_launch_a<512, 3, ACT_ELU>(p, st);
         default: break;
       }
-      switch (chain_kv()) {
-        case 0: return chain_bwd_launch_a<512, 0, ACT_ELU>(p, st);
-        case 4: return chain_bwd_launch_a<512, 4, ACT_ELU>(p, st);
-        case 20: return chain_bwd_launch_a<512, 20, ACT_ELU>(p, st);
-        default: return chain_bwd_launch_a<512, CHAIN_KV_DEFAULT | 64, ACT_ELU>(p, st);      // | 64: stage B0's first loads ahead of its scalars
-      }
+#endif
+      return chain_kv() == 0 ? chain_bwd_launch_a<512, 0, ACT_ELU>(p, st) : chain_bwd_launch_a<512, CHAIN_KV_DEFAULT, ACT_ELU>(p, st);
     default: return hipErrorInvalidValue;
   }
 }

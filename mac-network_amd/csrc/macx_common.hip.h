@@ -7,6 +7,7 @@
 #include <mutex>
 #include <set>
 #include <utility>
+#include "../../include/macx.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -28,6 +29,22 @@ inline hipError_t lds_attr_once(const void* fn, size_t bytes) {
   if (e == hipSuccess) done.insert({fn, dev});
   return e;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The per-call tuning table (macx_opts.tune, include/macx.h: MACX_TUNE_*).  An entry point that takes macx_opts installs the
+// caller's table for the duration of the call ON THE CALLING THREAD (TuneScope, via ModeScope in macx_api.hip); launchers read it
+// through tune_get().  Entry points without macx_opts run the defaults.  Nothing outlives the call: no process-wide state.
+// ---------------------------------------------------------------------------------------------
+inline const int32_t*& tune_current() { static thread_local const int32_t* t = nullptr; return t; }
+inline int tune_get(int key, int dflt) {
+  const int32_t* t = tune_current();
+  return (t && t[key]) ? (int)t[key] - 1 : dflt;
+}
+struct TuneScope {
+  const int32_t* saved;
+  explicit TuneScope(const int32_t* t) : saved(tune_current()) { tune_current() = t; }
+  ~TuneScope() { tune_current() = saved; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based dropout stream.

@@ -82,7 +82,7 @@ struct GemmP {
   const uint32_t* e_bits; // E_I2_LOGIT: keep bits of act(I2*c) [B*N][Nout/32]; E_DKB: keep bits of KB; null = keep all
   float e_inv_keep;
   int accumulate;         // E_DKB: 1 -> out += , 0 -> out =
-  int dbg;                // measurement knobs (macx_debug_set(1, mask)): 1 skip epilogue, 2 skip in-loop staging, 4 write-through stores (unsafe, see epilogue), 8 no epilogue stores
+  int dbg;                // measurement knobs (macx_opts.tune[MACX_TUNE_PHASE_MASK]): 1 skip epilogue, 2 skip in-loop staging, 8 no epilogue stores
   const float* a_maxabs;  // kb_gemm3h_kernel: largest magnitude of A (device float)
 };
 
@@ -100,10 +100,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // per-lane global addresses into LDS at wave_base + lane*16.  No VGPR round trip, no ds_write.
 // 16-byte global store, plain or write-through (sc0 sc1: the bytes leave the XCD's L2 as they are issued instead of in
 // the end-of-kernel write-back burst; MI355X_MICROARCH "publish-large").  Timing experiment only.
-__device__ __forceinline__ void store16(float* g, f32x4 v, bool wt) {
-  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g), "v"(v) : "memory");
-  else *reinterpret_cast<f32x4*>(g) = v;
-}
+__device__ __forceinline__ void store16(float* g, f32x4 v) { *reinterpret_cast<f32x4*>(g) = v; }
 
 __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -166,9 +163,6 @@ __device__ __forceinline__ void kb_epilogue_rows(const GemmP& p, float* smem, in
   }
   if (EP == E_DKB) drj = *reinterpret_cast<const f32x4*>(p.aux + (size_t)b * p.ld_aux + col);
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-  // dbg 4: write-through (sc0 sc1) output stores.  Measured -3.7 us per launch, but a following kernel on another XCD was
-  // observed reading stale lines (tests/test_gpu_stem.py, intermittent) -> experiment only, never the default.
-  const bool wt = (p.dbg & 4) != 0;
   const int wpr = p.Nout >> 5;   // mask words per output row
   // every global operand the epilogue needs (activation outputs for act', the running dKB, mask words,
   // attention weights) is requested for ALL of this thread's rows before the first one is used: RT
@@ -204,10 +198,10 @@ __device__ __forceinline__ void kb_epilogue_rows(const GemmP& p, float* smem, in
     if (EP == E_BIAS_ACT) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = act_apply(p.act, val[e] + bias4[e]);
-      if (ok) store16(optr, val, wt);
+      if (ok) store16(optr, val);
     } else if (EP == E_I2_LOGIT) {
       val += bias4;
-      if (ok) store16(optr, val, wt);
+      if (ok) store16(optr, val);
       // mac_cell.py:248,262,266: act(I2 * c) -> dropout -> . w   (bias b_k added in kb_attend)
       const uint32_t bits = bitv[it];
       float part = 0.f;
@@ -227,16 +221,16 @@ __device__ __forceinline__ void kb_epilogue_rows(const GemmP& p, float* smem, in
       const float ik = p.e_bits ? p.e_inv_keep : 1.0f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] *= ((bits >> e) & 1u) ? act_grad_from_out(p.act, h[e]) * ik : 0.f;
-      if (ok) store16(optr, val, wt);
+      if (ok) store16(optr, val);
     } else if (EP == E_PLAIN) {
-      if (ok) store16(optr, val, wt);
+      if (ok) store16(optr, val);
     } else if (EP == E_DKB) {
       const uint32_t bits = bitv[it];
       const float a = attv[it];
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = (((bits >> e) & 1u) ? val[e] * p.e_inv_keep : 0.f) + a * drj[e];
       val += auxv[it];
-      if (ok) store16(optr, val, wt);
+      if (ok) store16(optr, val);
     }
     if (COLSUM && ok) csum += val;
   }
@@ -430,13 +424,13 @@ __global__ __launch_bounds__(64 * NW) void kb_gemm_kernel(GemmP p) {
 }
 
 // ---- host-side launcher ---------------------------------------------------------------------
-// runtime knob (macx_debug_set(0, NW)): waves per workgroup of the kb GEMM, 4 or 8
-inline int& kb_gemm_nw() { static int nw = 8; return nw; }
-inline int& kb_gemm_dbg() { static int m = 0; return m; }
+// per-call knob (MACX_TUNE_NATIVE_WAVES): waves per workgroup of the kb GEMM, 4 or 8
+inline int kb_gemm_nw() { const int v = tune_get(MACX_TUNE_NATIVE_WAVES, 8); return v == 4 ? 4 : 8; }
+inline int kb_gemm_dbg() { return tune_get(MACX_TUNE_PHASE_MASK, 0); }      // timing experiments of the profiling tools
 inline int& gemm_default_mode() { static int m = 2; return m; }     // process default (macx_gemm_mode)
 inline int& gemm_call_override() { static thread_local int m = -1; return m; }   // set for the duration of one ABI call (macx_opts.gemm_family)
 inline int gemm_split_mode() { return gemm_call_override() >= 0 ? gemm_call_override() : gemm_default_mode(); }   // kernel family of the read unit: 0 native f32 MFMA, 1 split-bf16 (macx_gemm6.hip.h), 2 H2 fp16 planes (macx_gemm_h2.hip.h)
-inline int& kb_gemm_force_rt() { static int rt = 0; return rt; }   // tuning override (macx_debug_set key 2)
+inline int kb_gemm_force_rt() { const int v = tune_get(MACX_TUNE_ROW_TILES, 0); return (v == 1 || v == 2 || v == 4 || v == 7 || v == 13) ? v : 0; }   // tuning override (macx_debug_set key 2)
 
 template <int RT, int NW, int AP, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_launch_rt(const GemmP& p, hipStream_t st) {

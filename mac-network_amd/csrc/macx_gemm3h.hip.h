@@ -284,14 +284,14 @@ inline hipError_t kb_gemm3h_launch_rt(const GemmP& p, hipStream_t st) {
 //     multiply slice q" is pinned with sched_barrier (left alone the scheduler sinks the loads to their first use: 0.61 PF
 //     instead of 0.97 in the probe);
 //   * operands swapped (D^T = W^T A^T): a lane ends up with four consecutive columns of a row.
-// Shapes: conv_taps == 9, Nout == 512, conv_cin a multiple of 256.  macx_debug_set(9, 0) / MACX_STEM_CHAIN=0 keep kb_gemm3h_kernel.
+// Shapes: conv_taps == 9, Nout == 512, conv_cin a multiple of 256.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CC_ROWS = 64, CC_NOUT = 512, CC_KC = 256, CC_KG = CC_KC / 8;
 constexpr int CC_BUF = 2 * CC_KG * CC_ROWS * 16;                 // [plane][k group][row] x 16 B
 constexpr int CC_LDT = 128 + 4;
 constexpr int CC_EPI = 4 * CC_ROWS * CC_LDT * 4;                // four 64 x 128 epilogue tiles
 constexpr int CC_LDS = 2 * CC_BUF > CC_EPI ? 2 * CC_BUF : CC_EPI;
-inline int& conv_chain_mode() { static int m = 1; return m; }
+constexpr bool conv_chain_mode() { return true; }      // (A/B against kb_gemm3h_kernel closed in round 5: profiles/r05_stem_conv_chain_ab.txt; that kernel remains the fallback by shape)
 
 template <int EP>
 __global__ __launch_bounds__(512) void kb_conv_chain_kernel(GemmP p) {

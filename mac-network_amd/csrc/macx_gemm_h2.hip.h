@@ -53,7 +53,7 @@ struct GemmH2P {
   size_t bits_step_words;   // uint32 words between the keep bits of consecutive steps
   size_t att_step, dr_step; // floats between att_i / dinfo_i of consecutive steps
   int a_row_exp;            // E_DKB: every A tensor has ONE exponent per row (chain_bwd_kernel wrote it): the UNI kernel may fold per step
-  int dbg;                  // measurement knobs (macx_debug_set(1, mask)): 1 skip the epilogue, 32 skip the in-loop staging,
+  int dbg;                  // measurement knobs (macx_opts.tune[MACX_TUNE_PHASE_MASK]): 1 skip the epilogue, 32 skip the in-loop staging,
                             // 64 skip the fragment reads + MFMAs, 256 return at once, 512 return in front of the K loop
 };
 
@@ -656,10 +656,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
       h2_split8(xs, hi, lo);
       char* d = o0 + ((size_t)(cb * 16 + kgl) * oRp + grow0 + lrow) * 16;
       if (p.dbg & 8) continue;                       // timing experiment: no output stores
-      if (p.dbg & 4) {                               // timing experiment: write-through stores
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d), "v"(hi) : "memory");
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d + opb), "v"(lo) : "memory");
-      } else if (p.dbg & 16) {                       // timing experiment: non-temporal stores
+      if (p.dbg & 16) {                       // timing experiment: non-temporal stores
         asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(d), "v"(hi) : "memory");
         asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(d + opb), "v"(lo) : "memory");
       } else {
@@ -670,7 +667,7 @@ __global__ __launch_bounds__(512) void kb_gemm_h2_kernel(GemmH2P p) {
   }
 }
 
-inline int& dkb_uni_mode() { static int m = 1; return m; }        // macx_debug_set(14, 0 | 1): one fold per step in the merged dKB launch
+inline int dkb_uni_mode() { return tune_get(MACX_TUNE_DKB_UNI, 1); }        // MACX_TUNE_DKB_UNI = 0 | 1: one fold per step in the merged dKB launch
 template <int RT, int BP, int EP, bool COLSUM>
 inline hipError_t kb_gemm_h2_launch_rt(const GemmH2P& p, hipStream_t st) {
   if constexpr (EP == E_DKB && RT == 13 && BP == B_PLAIN && !COLSUM) {

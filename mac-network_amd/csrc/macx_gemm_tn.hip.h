@@ -31,7 +31,7 @@ struct TnP {
   int conv_taps, conv_w, conv_wp, conv_cin, conv_n, conv_np;
   uint32_t magic_n, magic_w;   // ceil(2^32 / conv_n), ceil(2^32 / conv_w)
   int nz; size_t zG, zpart;   // nz > 1: blockIdx.y selects one of nz independent contractions sharing A (G += z*zG, part += z*zpart); split kernel only
-  int dbg;               // timing experiments (macx_debug_set(1, mask)): 16 no MFMAs, 32 no in-loop loads, 64 no in-loop split/store
+  int dbg;               // timing experiments (macx_opts.tune[MACX_TUNE_PHASE_MASK]): 16 no MFMAs, 32 no in-loop loads, 64 no in-loop split/store
   const float* a_maxabs; const float* g_maxabs;   // wgrad3h_kernel: largest magnitude of A / of G (device floats)
 };
 

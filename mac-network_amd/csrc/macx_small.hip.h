@@ -195,11 +195,10 @@ constexpr int LIN_PART_TILES = 6;     // tiles a question may touch in the PART 
 // would leave a 32-workgroup grid on a 256-CU chip and the launch is pure latency.
 // one (16 RTL rows) x (16 columns) output tile of a LinP: tile (bx, by) of matrix z.  `red`: [4][16 RTL][20] floats of LDS.
 // Every thread of the workgroup must call it (barrier inside); callable more than once per kernel (a barrier guards `red`).
-// NWV: waves that share the tile's reduction dimension (4, or 8 for the inputs whose k-groups would otherwise take a wave two
-// dependent load batches: K >= 1024 and the PART form).
-template <int RTL, bool PART = false, int NWV = 4>
+template <int RTL, bool PART = false>
 __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by, int z, float (*red)[16 * RTL][20]) {
   constexpr int L_ROWS = 16 * RTL;
+  constexpr int NWV = 4;               // waves that share the tile's reduction dimension
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c0 = bx * 16;
@@ -295,8 +294,7 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
   f32x4 val, vald = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float t = ((red[0][r][cq + e] + red[1][r][cq + e]) + red[2][r][cq + e]) + red[3][r][cq + e];
-    if constexpr (NWV == 8) t += ((red[4][r][cq + e] + red[5][r][cq + e]) + red[6][r][cq + e]) + red[7][r][cq + e];      // fixed order
+    float t = ((red[0][r][cq + e] + red[1][r][cq + e]) + red[2][r][cq + e]) + red[3][r][cq + e];      // fixed order
     val[e] = t;
   }
   const int col = c0 + cq;
@@ -323,101 +321,23 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
   }
 }
 
-template <int RTL, bool PART = false, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV) void small_linear_kernel(LinP p) {
-  static_assert(NWV == 4 || NWV == 8, "the cross-wave sum is written out for 4 and 8 waves");
-  __shared__ float red[NWV][16 * RTL][20];
-  small_linear_tile<RTL, PART, NWV>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
+template <int RTL, bool PART = false>
+__global__ __launch_bounds__(256) void small_linear_kernel(LinP p) {
+  __shared__ float red[4][16 * RTL][20];
+  small_linear_tile<RTL, PART>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// TWO dependent [B,d] linears in ONE launch (round 5): every output of `a` is an input of `b` (the write unit's new memory ->
-// the next step's projected memory, mac_cell.py:305-375 -> ops.py:679,688; backward: dL/dm_i -> the write unit's input gradients),
-// so the workgroups of the launch meet at a device-scope barrier between the two: a monotonic arrival counter in device memory
-// (zeroed on the caller's stream when the pass begins; every pair launch on it uses the same grid), one thread per workgroup:
-// release fence, agent-scope add, spin on an agent-scope load, acquire fence (L2 write-back / invalidate across XCDs -- what
-// cooperative-groups grid.sync() is made of).  Every workgroup of the grid must be resident at once: the
-// launcher refuses grids above 256 workgroups (one per CU; they hold 5 KB of LDS and 256 threads each).  The spin is BOUNDED: a
-// lost participant must not hang the device -- after ~2^22 polls the workgroup sets *fail (a word next to the counter, for a
-// debugger) and goes on with whatever it finds.
-//   tools/probes/grid_barrier_probe.hip measures the barrier against the launch boundary it replaces (profiles/r05_grid_barrier_probe.txt).
-// ---------------------------------------------------------------------------------------------------------------
-struct LinPairSync { uint32_t* counter; uint32_t* fail; };
-
-__device__ __forceinline__ void lin_pair_barrier(const LinPairSync& y) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    // the counter only ever grows, by gridDim.x per pair launch (launches on it are stream-ordered, so it is a multiple of
-    // gridDim.x whenever one starts): this workgroup's target is the next multiple above the value it found
-    const uint32_t old = __hip_atomic_fetch_add(y.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t target = (old / gridDim.x + 1u) * gridDim.x;
-    uint32_t spins = 0;
-    while (__hip_atomic_load(y.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 22)) { __hip_atomic_store(y.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-    }
-    __threadfence();
-  }
-  __syncthreads();
-}
-
-// grid = nblk workgroups (1-D); tiles of `a` then of `b` are dealt round-robin: tile t -> (bx = t % ncol, by = t / ncol)
-template <bool PART_A>
-__global__ __launch_bounds__(256) void small_linear_pair_kernel(LinP a, LinP b, LinPairSync y) {
-  __shared__ float red[4][16][20];
-  const int nblk = gridDim.x;
-  {
-    const int ncol = a.n_out / 16, ntile = ncol * ((a.rows + 15) / 16);
-    for (int t = blockIdx.x; t < ntile; t += nblk) {
-      small_linear_tile<1, PART_A>(a, t % ncol, t / ncol, 0, red);
-      __syncthreads();
-    }
-  }
-  lin_pair_barrier(y);
-  {
-    const int ncol = b.n_out / 16, ntile = ncol * ((b.rows + 15) / 16);
-    for (int t = blockIdx.x; t < ntile; t += nblk) {
-      small_linear_tile<1, false>(b, t % ncol, t / ncol, 0, red);
-      __syncthreads();
-    }
-  }
-}
-
-// macx_debug_set(12, 0 | 1): 8-wave workgroups for the [B,d] linears whose reduction is long (K >= 1024, the PART form); A/B knob
-// MEASURED (round 5, profiles/r05_wide_linear_ab.txt): the dy-summing form 11.5 -> 10.9 us, the step unchanged within 0.1 % --
-// the default stays 4 waves (the summation order the committed parity margins were taken on)
-inline int& lin_wide_waves() { static int m = 0; return m; }
+// the PART form (LinP::part): the dy-linear of the backward recurrence.  (Measured and removed in rounds 5-6: two dependent linears
+// in one launch with a device-scope barrier between them -- 2-13 % slower per step, profiles/r05_pair_launch_ab.txt,
+// r05_grid_barrier_probe.txt -- and 8-wave workgroups for the long reductions -- no gain, profiles/r05_wide_linear_ab.txt.)
 inline hipError_t small_linear_part_launch(const LinP& p, hipStream_t st) {
   if (!p.part || !p.part_sum || p.rows > 128 || p.part_shift < 4 || p.part_shift > 6 ||
       ((p.part_N - 2) >> p.part_shift) + 2 > LIN_PART_TILES) return hipErrorInvalidValue;
-  // 8 waves: a wave's 4 k-groups (of d / 16 = 32) are ONE batch of loads (6 partial rows + the weights per group) instead of two
-  // dependent ones
-  if (lin_wide_waves()) hipLaunchKernelGGL((small_linear_kernel<1, true, 8>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL((small_linear_kernel<1, true>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(256), 0, st, p);
-  return hipGetLastError();
-}
-// a then b in one launch (see small_linear_pair_kernel); both with rows <= 128; `part_a`: a is in the PART form
-// workgroups of a pair launch (macx_debug_set(11, 0 | 16 .. 256)); 0 = no pairs, the DEFAULT: measured (round 5, one box,
-// profiles/r05_pair_launch_ab.txt): the step is 2 % (128 workgroups) to 13 % (32) SLOWER with pairs than with one launch per linear
-// -- the barrier costs 1.6 us among 16 workgroups and 6.8 us among 128 (profiles/r05_grid_barrier_probe.txt: two device-scope
-// atomic round trips plus contention), a kernel boundary inside a replayed graph 1.56 us.  Kept behind the knob, bit-identical.
-inline int& lin_pair_grid() { static int g = 0; return g; }
-inline hipError_t small_linear_pair_launch(const LinP& a, const LinP& b, bool part_a, const LinPairSync& y, hipStream_t st) {
-  const int g = lin_pair_grid();
-  if (a.rows > 128 || b.rows > 128 || g < 1 || g > 256 || !y.counter || !y.fail) return hipErrorInvalidValue;
-  if (part_a) {
-    if (!a.part || !a.part_sum || a.part_shift < 4 || a.part_shift > 6 || ((a.part_N - 2) >> a.part_shift) + 2 > LIN_PART_TILES) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(small_linear_pair_kernel<true>, dim3(g), dim3(256), 0, st, a, b, y);
-  } else {
-    hipLaunchKernelGGL(small_linear_pair_kernel<false>, dim3(g), dim3(256), 0, st, a, b, y);
-  }
+  hipLaunchKernelGGL((small_linear_kernel<1, true>), dim3(p.n_out / 16, (p.rows + 15) / 16, 1), dim3(256), 0, st, p);
   return hipGetLastError();
 }
 inline hipError_t small_linear_launch(const LinP& p, int nz, hipStream_t st) {
-  if (p.rows <= 128 && p.Ktot >= 1024 && lin_wide_waves()) {
-    hipLaunchKernelGGL((small_linear_kernel<1, false, 8>), dim3(p.n_out / 16, (p.rows + 15) / 16, nz), dim3(512), 0, st, p);
-  } else if (p.rows <= 128) {
+  if (p.rows <= 128) {
     hipLaunchKernelGGL(small_linear_kernel<1>, dim3(p.n_out / 16, (p.rows + 15) / 16, nz), dim3(256), 0, st, p);
   } else {
     hipLaunchKernelGGL(small_linear_kernel<4>, dim3(p.n_out / 16, (p.rows + 63) / 64, nz), dim3(256), 0, st, p);
@@ -446,21 +366,20 @@ __global__ void drop2_kernel(const float* __restrict__ x, int rows, int d, uint3
 }
 
 // initial state (mac_cell.py:496-505): PRM -> tile the [d] variable, ZERO, Q -> copy vecQuestions
-// ... both states of a run in one launch, plus the forward pass's pair-launch arrival counter (4 words, zeroed; may be null)
+// ... both states of a run in one launch
 __global__ void init_states_kernel(int mode_c, const float* __restrict__ prm_c, float* out_c, int mode_m, const float* __restrict__ prm_m,
-                                   float* out_m, const float* __restrict__ vecQ, int rows, int d, uint32_t* sync) {
+                                   float* out_m, const float* __restrict__ vecQ, int rows, int d) {
   const int n = rows * d;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float q = (mode_c == 2 || mode_m == 2) ? vecQ[i] : 0.f;
     out_c[i] = mode_c == 0 ? prm_c[i % d] : (mode_c == 2 ? q : 0.f);
     out_m[i] = mode_m == 0 ? prm_m[i % d] : (mode_m == 2 ? q : 0.f);
   }
-  if (sync && blockIdx.x == 0 && threadIdx.x < 4) sync[threadIdx.x] = 0u;
 }
 
 // start of a backward pass: the running gradients DM / DC [p + 1][rows * d] are zero except their last slab, which takes the
-// incoming dL/dm_p / dL/dc_p (null: zero); the words behind DC (pair-launch arrival counter) are zeroed.  One launch instead of a
-// fill and two copies.  DM and DC adjacent (DC == DM + (p + 1) n), `tail` words after DC.
+// incoming dL/dm_p / dL/dc_p (null: zero).  One launch instead of a fill and two copies.  DM and DC adjacent
+// (DC == DM + (p + 1) n); `tail` more words after DC are zeroed too.
 __global__ void bwd_init_kernel(float* DM, size_t slab, int p, const float* __restrict__ d_memory, const float* __restrict__ d_control, int tail) {
   const size_t per = (size_t)(p + 1) * slab, total = 2 * per + (size_t)tail;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {

@@ -235,16 +235,9 @@ struct TnH2P {
   int ecom_nb;
   uint16_t* ftab;        // [Kd/128][Jd/128][Mpad] combined row factors, Mpad = wgrad_h2_mpad(M)
   float* part;           // [nsplit][Kd][Jd]
-  int dbg;               // measurement knobs (macx_debug_set(1, mask)): 1024 skip fragments + MFMAs, 2048 skip the in-loop DMA
-  int accumulate;        // 1: part += (a launch per step into one set of slabs, launches ordered on one stream)
-  // DUAL form (KW = JW = 2 only; A2 != null): TWO A families of Kd columns each against ONE G.  A 256 x 256 output tile is
-  // 128 rows of C1 = A^T G on top of 128 rows of C2 = A2^T G for the same 128-column block tk of both families: the G operand
-  // -- half of a stage -- is staged once for both.  Used for the read unit's interaction weights (round 5):
-  //   dW1a = sum_rows (X * y)^T dI1,  dW1b = sum_rows X^T dI1   (ops.py:703,718: the gradient of [X*y, X] W1 with respect to W1)
-  // with X * y kept by the forward chain kernel -- a plain contraction over all p B N rows instead of the per-question kernel.
-  const char* A2; size_t a2_stride;
-  const int* ecomA2;
-  float* part2;          // [nsplit][Kd][Jd] slabs of C2
+  int dbg;               // measurement knobs (macx_opts.tune[MACX_TUNE_PHASE_MASK]): 1024 skip fragments + MFMAs, 2048 skip the in-loop DMA
+  // (Round 5 also had a DUAL form here -- two A families against one G, for dW1a / dW1b as one contraction over X * y and X kept by the
+  // forward chain kernel: twice the per-question kernel's matrix work, 392 against 345 us, profiles/r05_dual_contraction_ab.txt.  Removed.)
 };
 __host__ __device__ inline size_t wgrad_h2_mpad(size_t M) { return (M + 63) & ~(size_t)31; }       // a stage starting below M stays inside
 
@@ -267,12 +260,9 @@ template <int KW, int JW> constexpr int wh_ring() { return KW + JW == 4 ? 2 : (K
 __global__ __launch_bounds__(256) void wgrad_h2_factors_kernel(TnH2P p0, TnH2P p1) {
   const TnH2P& p = blockIdx.y ? p1 : p0;             // grid.y = 2: the tables of two contractions in one launch
   __shared__ int sE[2][8];
-  __shared__ int sE2[8];
   if (threadIdx.x < 16) {
     const int w = threadIdx.x >> 3, k = threadIdx.x & 7;
     sE[w][k] = h2_emin_final(w ? p.ecomG : p.ecomA, p.ecom_nb, k);
-  } else if (threadIdx.x < 24 && p.A2) {
-    sE2[threadIdx.x - 16] = h2_emin_final(p.ecomA2, p.ecom_nb, threadIdx.x - 16);
   }
   __syncthreads();
   const size_t mpad = wgrad_h2_mpad((size_t)p.M);
@@ -281,26 +271,13 @@ __global__ __launch_bounds__(256) void wgrad_h2_factors_kernel(TnH2P p0, TnH2P p
   const int acb = p.Kd >> 7, gcb = p.Jd >> 7;
   const H2View a0{const_cast<char*>(p.A), p.R, p.Kd}, g0{const_cast<char*>(p.G), p.R, p.Jd};
   if (m >= (size_t)p.M) {
-    for (int i = 0; i < (p.A2 ? 2 : 1) * acb * gcb; ++i) p.ftab[(size_t)i * mpad + m] = 0;
+    for (int i = 0; i < acb * gcb; ++i) p.ftab[(size_t)i * mpad + m] = 0;
     return;
   }
   const int ti = (int)(m / p.R), rr = (int)(m - (size_t)ti * p.R);
   const int ar = p.a_mod ? (int)(m % p.a_mod) : rr;
   const int8_t* ea = reinterpret_cast<const int8_t*>(p.A + (p.a_mod ? 0 : (size_t)ti * p.a_stride) + 2 * a0.plane_bytes()) + (size_t)ar * acb;
   const int8_t* eg = reinterpret_cast<const int8_t*>(p.G + (size_t)ti * p.g_stride + 2 * g0.plane_bytes()) + (size_t)rr * gcb;
-  if (p.A2) {
-    // dual: table (2 k + which) belongs to column block k of family `which` (what a tile's wave rows 0-1 read)
-    const int8_t* ea2 = reinterpret_cast<const int8_t*>(p.A2 + (size_t)ti * p.a2_stride + 2 * a0.plane_bytes()) + (size_t)rr * acb;
-    for (int k = 0; k < acb; ++k) {
-      const int da = sE[0][k] - (int)ea[k], da2 = sE2[k] - (int)ea2[k];
-      for (int j = 0; j < gcb; ++j) {
-        const int dg = sE[1][j] - (int)eg[j];
-        p.ftab[((size_t)(2 * k) * gcb + j) * mpad + m] = (uint16_t)(pk_pow2_f16(da + dg) & 0xFFFFu);
-        p.ftab[((size_t)(2 * k + 1) * gcb + j) * mpad + m] = (uint16_t)(pk_pow2_f16(da2 + dg) & 0xFFFFu);
-      }
-    }
-    return;
-  }
   for (int k = 0; k < acb; ++k) {
     const int da = sE[0][k] - (int)ea[k];
     for (int j = 0; j < gcb; ++j)
@@ -324,17 +301,14 @@ __device__ __forceinline__ void dma4b(const char* g, char* lds_wave_base) {     
 // Same products in the same order: results are bit-identical to PIPE = 0.
 // 3 (default): as 2 with HALF the reduction splits per contraction (the caller's choice, macx_api.hip), so that both contractions'
 // workgroups are resident at once; 2: PIPE = 1 and the two all-steps contractions of the backward pass as ONE launch (grid.y = 2);
-// 1: PIPE = 1, one launch each; 0: round 4's loop.  macx_debug_set(10, v): A/B in one process
-inline int& wgrad_pipe_mode() { static int m = 3; return m; }
+// 1: PIPE = 1, one launch each; 0: round 4's loop.  macx_opts.tune[MACX_TUNE_WGRAD_PIPE]: the A/B hook
+inline int wgrad_pipe_mode() { const int v = tune_get(MACX_TUNE_WGRAD_PIPE, 3); return (v >= 0 && v <= 3) ? v : 3; }
 
-template <int KW, int JW, int PIPE = 0, bool DUAL = false>
+template <int KW, int JW, int PIPE = 0>
 __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
   // grid.y = 2: two contractions of the same shape in ONE launch (dW2 and dWx of the cell's backward pass): the second one's
   // workgroups take the CUs the first one's free -- one ramp and one tail instead of two, one launch boundary less
-  // (dual launches are never paired: selecting between the two argument structs made the compiler copy BOTH to scratch in the dual
-  // variant -- 296 bytes per lane, every p.field a scratch load, and scratch loads count in vmcnt: each one drained the DMA queue.
-  // 1252 us per launch instead of ~200, gpurun_out/r5c2_kv8_kernel_stats.txt)
-  const TnH2P& p = DUAL ? p0 : (blockIdx.y ? p1 : p0);
+  const TnH2P& p = blockIdx.y ? p1 : p0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
   constexpr int KT = KW * T_TILE;
@@ -348,10 +322,8 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
   constexpr int NR = 4 * KW;                  // 16-row tiles of a wave
   constexpr int NC = 2 * JW;                  // 16-column tiles of a wave
 
-  static_assert(!DUAL || (KW == 2 && JW == 2), "the dual form is a 256 x 256 tile: 128 rows per A family");
-  constexpr bool dual = DUAL;               // (a template parameter: as a run-time flag it cost the plain kernel 38 spilled registers)
   const int ntj = p.Jd / JT;
-  const int ntk = dual ? p.Kd / T_TILE : p.Kd / KT;       // dual: a tile is column block tk of BOTH A families
+  const int ntk = p.Kd / KT;
   const int ntile = ntj * ntk;
   const int nblk = gridDim.x;
   int v = blockIdx.x;
@@ -363,7 +335,7 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;    // 64 KW rows (k) x 32 JW columns (j) of the tile
-  const int aq = KW == 2 ? wr : 0;            // the 128-column block of A this wave's rows lie in (dual: the family)
+  const int aq = KW == 2 ? wr : 0;            // the 128-column block of A this wave's rows lie in
   const int gq = JW == 2 ? (wc >> 1) : 0;     // the 128-column block of G this wave's columns lie in
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
@@ -402,11 +374,6 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
       const int u = wave * NI + j;
       if (u < 16 * KW) {
         const int pl = u / (8 * KW), ct = u - pl * 8 * KW;
-        if (dual) {
-          // (NI = 8: wave w < 4 stages plane w >> 1 of family w & 1 -- one base per wave, not a select per instruction)
-          const char* src = ((wave & 1) ? p.A2 + (size_t)ti * p.a2_stride : p.A + (size_t)ti * p.a_stride) + (wave >> 1) * apb;
-          dma16b(src + ((size_t)(tk * 16 + 2 * j + sl_kg) * Rp + rr) * 16, st + pl * APL + ct * 1024);
-        } else
         dma16b(ab + pl * apb + ((size_t)(tk * 16 * KW + 2 * ct + sl_kg) * Rp + ar) * 16, st + pl * APL + ct * 1024);
       } else {
         const int ug = u - 16 * KW;
@@ -432,10 +399,6 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
         for (int j = 0; j < NI; ++j) {
           const int u = wave * NI + j;
           const int pl = u / (8 * KW), ct = u - pl * 8 * KW;
-          if (dual) {
-            const char* src = ((wave & 1) ? p.A2 + (size_t)ti * p.a2_stride : p.A + (size_t)ti * p.a_stride) + (wave >> 1) * apb;
-            dma16b(src + ((size_t)(tk * 16 + 2 * j + sl_kg) * Rp + rr) * 16, st + pl * APL + ct * 1024);
-          } else
           dma16b(ab + pl * apb + ((size_t)(tk * 16 * KW + 2 * ct + sl_kg) * Rp + ar) * 16, st + pl * APL + ct * 1024);
         }
       }
@@ -560,10 +523,8 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
 
   // ---- the slab leaves through LDS, 32 rows of the wave's share at a time (row-major in the wave's own corner of the idle
   //      ring, read back as float4): a store instruction writes whole 128 / 256-byte row segments instead of 64-byte pieces
-  const float sc = dual ? h2_unscale(h2_emin_final(aq ? p.ecomA2 : p.ecomA, p.ecom_nb, tk), h2_emin_final(p.ecomG, p.ecom_nb, tj * JW + gq))
-                        : h2_unscale(h2_emin_final(p.ecomA, p.ecom_nb, tk * KW + aq), h2_emin_final(p.ecomG, p.ecom_nb, tj * JW + gq));
-  float* out = dual ? (wr ? p.part2 : p.part) + (size_t)split * p.Kd * p.Jd + (size_t)(tk * T_TILE) * p.Jd + tj * JT + wc * 32 * JW
-                    : p.part + (size_t)split * p.Kd * p.Jd + (size_t)(tk * KT + wr * 16 * NR) * p.Jd + tj * JT + wc * 32 * JW;
+  const float sc = h2_unscale(h2_emin_final(p.ecomA, p.ecom_nb, tk * KW + aq), h2_emin_final(p.ecomG, p.ecom_nb, tj * JW + gq));
+  float* out = p.part + (size_t)split * p.Kd * p.Jd + (size_t)(tk * KT + wr * 16 * NR) * p.Jd + tj * JT + wc * 32 * JW;
   constexpr int CW = 32 * JW, LDW = CW + 4;
   constexpr int LPR = CW / 4, RPI = 64 / LPR;             // lanes per row, rows per store instruction
   float* tw = reinterpret_cast<float*>(lds) + wave * (32 * LDW);
@@ -580,7 +541,6 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
       const int r = i * RPI + lane / LPR, c4 = (lane % LPR) * 4;
       f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)(tp * 16 + r) * p.Jd + c4);
       f32x4 val = *reinterpret_cast<const f32x4*>(tw + r * LDW + c4);
-      if (p.accumulate) val += *dst;
       *dst = val;
     }
   }
@@ -589,8 +549,6 @@ __global__ __launch_bounds__(512) void wgrad_h2_kernel(TnH2P p0, TnH2P p1) {
 inline int wgrad_h2_jw(int Jd) { return (Jd % 256 == 0) ? 2 : 1; }
 inline int wgrad_h2_kw(int Kd) { return (Kd % 256 == 0) ? 2 : 1; }
 inline int wgrad_h2_tiles(int Kd, int Jd) { return (Kd / (wgrad_h2_kw(Kd) * T_TILE)) * (Jd / (wgrad_h2_jw(Jd) * T_TILE)); }
-inline bool wgrad_h2_dual_ok(int Kd, int Jd) { return Kd % 128 == 0 && Jd % 256 == 0; }
-inline int wgrad_h2_dual_tiles(int Kd, int Jd) { return (Kd / T_TILE) * (Jd / (2 * T_TILE)); }
 
 template <int KW, int JW, int PIPE = 0>
 inline hipError_t wgrad_h2_launch_t(const TnH2P& p, hipStream_t st) {
@@ -621,28 +579,6 @@ inline hipError_t wgrad_h2_launch_pair(const TnH2P& a, const TnH2P& b, hipStream
   e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(wgrad_h2_tiles(a.Kd, a.Jd) * a.nsplit, 2), dim3(512), lds, st, a, b);
-  return hipGetLastError();
-}
-// the dual form (TnH2P::A2): [A^T G ; A2^T G] -> part / part2; ftab holds 2 (Kd / 128) (Jd / 128) tables
-inline hipError_t wgrad_h2_dual_launch(const TnH2P& p, hipStream_t st) {
-  if (p.rows_per_split % 32 != 0 || !p.ftab || !p.A2 || !p.ecomA2 || !p.part2 || p.a_mod || !wgrad_h2_dual_ok(p.Kd, p.Jd)) return hipErrorInvalidValue;
-  const size_t mpad = wgrad_h2_mpad((size_t)p.M);
-  hipLaunchKernelGGL(wgrad_h2_factors_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, st, p, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  constexpr size_t lds = (size_t)wh_ring<2, 2>() * wh_stage_bytes<2, 2>();
-  const int grid = wgrad_h2_dual_tiles(p.Kd, p.Jd) * p.nsplit;
-  if (wgrad_pipe_mode()) {
-    auto kern = wgrad_h2_kernel<2, 2, 1, true>;
-    e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, p);
-  } else {
-    auto kern = wgrad_h2_kernel<2, 2, 0, true>;
-    e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, p);
-  }
   return hipGetLastError();
 }
 inline hipError_t wgrad_h2_launch(const TnH2P& p, hipStream_t st) {
@@ -688,7 +624,7 @@ struct SbH2P {
   // are written once
   int nsteps;
   size_t x_step, g_step, y_step;
-  int dbg;                 // measurement knobs (macx_debug_set(1, mask)): 512 skip the per-question fold, 1024 skip fragments + MFMAs,
+  int dbg;                 // measurement knobs (macx_opts.tune[MACX_TUNE_PHASE_MASK]): 512 skip the per-question fold, 1024 skip fragments + MFMAs,
                            // 2048 skip the DMA issue
 };
 
@@ -1325,7 +1261,7 @@ inline int sb_h2_wide_qpg(int B, int N, int d) {
   if (qpg > cap) qpg = cap;
   return qpg < 1 ? 1 : qpg;
 }
-inline int& sb_cont_mode() { static int m = 1; return m; }       // macx_debug_set(13, 0 | 1): sb_h2w_kernel per step / as one stage stream
+inline int sb_cont_mode() { return tune_get(MACX_TUNE_SB_CONT, 1); }       // MACX_TUNE_SB_CONT = 0 | 1: sb_h2w_kernel per step / as one stage stream
 inline hipError_t sb_h2w_launch(const SbH2P& p, hipStream_t st) {
   const int nchunk = (p.N + 31) >> 5;
   if (p.qpg < 1 || p.qpg > SBW_MAXQ || p.qpg * nchunk * 32 > SBW_MAXROWS / 2 || p.d % 256 || p.dy_part || p.nsteps < 1) return hipErrorInvalidValue;

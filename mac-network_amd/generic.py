@@ -514,8 +514,9 @@ class GenericMACCell:
 
     def __init__(self, vecQuestions, questionWords, questionCntxWords, questionLengths, knowledgeBase,
                  memoryDropout, readDropout, writeDropout, batchSize, train, reuse=None, *, config=None, params=None,
-                 netLength=None, seed=None, b0=0, mask_word=None):
+                 netLength=None, seed=None, b0=0, mask_word=None, tune=None):
         from .cell import _mask_word
+        del tune            # (the A/B hooks of macx_opts.tune select among FUSED kernels; this path has one kernel per op)
         self.mask_word = _mask_word(mask_word, knowledgeBase)
         self.config = config if config is not None else SimpleNamespace()
         reject_like_reference(self.config)

@@ -188,10 +188,17 @@ def reject_like_reference(config):
 
 GEMM_FAMILIES = {None: 0, "default": 0, "native": 1, "split": 2, "h2": 3}
 
+# Tuning values every MacxOpts frozen from now on starts with ({key name or number: value}; _lib.TUNE): the switchboard of the A/B
+# tools and of the test session's MACX_* environment variables (tests/conftest.py, bench.py, tools/kv_sweep.py).  Empty in
+# production -- no module of this package writes it -- and it is HOST state of the Python layer: what reaches the library is the
+# per-call table macx_opts.tune.
+SESSION_TUNE = {}
 
-def freeze(config, gemm=None):
+
+def freeze(config, gemm=None, tune=None):
     """config -> MacxOpts.  gemm: kernel family of the knowledge-base GEMMs for every call made with these options
-    ("native" | "split" | "h2"; None = the process default, macx_gemm_mode) -- macx_opts.gemm_family."""
+    ("native" | "split" | "h2"; None = the process default, macx_gemm_mode) -- macx_opts.gemm_family.  tune: {key: value} for
+    macx_opts.tune (A/B hooks, _lib.TUNE), on top of SESSION_TUNE."""
     g = lambda n: get(config, n)
     if gemm not in GEMM_FAMILIES:
         raise ValueError("gemm=%r: one of %s" % (gemm, sorted(k for k in GEMM_FAMILIES if k)))
@@ -237,6 +244,8 @@ def freeze(config, gemm=None):
     o.write_gate_bias = float(g("writeGateBias"))
     o.memory_variational_dropout = int(bool(g("memoryVariationalDropout")))
     o.gemm_family = GEMM_FAMILIES[gemm]
+    for k, v in list(SESSION_TUNE.items()) + list((tune or {}).items()):
+        _lib.set_tune(o, k, v)
     if o.read_mem_act == _lib.ACT["NON"]:
         unsupported.append("readMemAct=NON (no memKbProj_2 layer, ops.py:325)")
     if unsupported:

@@ -24,20 +24,14 @@ def macx():
     import macx as m
     if os.environ.get("MACX_GEMM"):         # run the whole suite on one kernel family: native | split | h2 (default)
         m._lib.lib().macx_gemm_mode(GEMM_MODES[os.environ["MACX_GEMM"]])
-    if os.environ.get("MACX_DBG"):          # debugging aid: kernel-selection / timing bits of macx_debug_set(1, .)
-        m._lib.lib().macx_debug_set(1, int(os.environ["MACX_DBG"]))
-    if os.environ.get("MACX_CHAIN"):        # 0: the read unit's forward products as four launches instead of the fused chain kernel
-        m._lib.lib().macx_debug_set(4, int(os.environ["MACX_CHAIN"]))
-    if os.environ.get("MACX_SB_DEFER"):     # 0: the S_b contraction once per step
-        m._lib.lib().macx_debug_set(5, int(os.environ["MACX_SB_DEFER"]))
-    if os.environ.get("MACX_STEM_CHAIN"):   # 0: the stem's convolutions on kb_gemm3h_kernel instead of kb_conv_chain_kernel
-        m._lib.lib().macx_debug_set(9, int(os.environ["MACX_STEM_CHAIN"]))
-    if os.environ.get("MACX_CHAIN_KV"):     # K-loop variant of the chain kernels (macx_chain_h2.hip.h: ChainCtx::kloop)
-        m._lib.lib().macx_debug_set(7, int(os.environ["MACX_CHAIN_KV"]))
-    if os.environ.get("MACX_SB_WIDE"):      # 0: the deferred S_b contraction on the 128 x 128 kernel
-        m._lib.lib().macx_debug_set(8, int(os.environ["MACX_SB_WIDE"]))
-    if os.environ.get("MACX_OVERLAP"):      # 0: no side queue in the backward pass
-        m._lib.lib().macx_debug_set(6, int(os.environ["MACX_OVERLAP"]))
+    # A/B routes for a whole session: the per-call tuning table (macx_opts.tune) of every cell frozen from here on
+    for env, key in (("MACX_DBG", "phase_mask"),        # debugging aid: timing bits (results are wrong under a non-zero mask)
+                     ("MACX_CHAIN", "chain"),           # 0: the read unit's products as separate launches instead of the chain kernels
+                     ("MACX_SB_DEFER", "sb_defer"),     # 0: the S_b contraction once per step
+                     ("MACX_CHAIN_KV", "chain_kv"),     # 0: the chain kernels' K loop with fragment requests in front of a slice
+                     ("MACX_SB_WIDE", "sb_wide")):      # 0: the deferred S_b contraction on the 128 x 128 kernel
+        if os.environ.get(env):
+            m.options.SESSION_TUNE[key] = int(os.environ[env])
     return m
 
 

@@ -89,7 +89,7 @@ def check_margin(key, err, tol):
     base = _baseline().get(key)
     # the record was taken on the default kernel family (H2) with the default knobs: a run on another family or under an A/B knob
     # (MACX_GEMM=split|native, MACX_CHAIN=0, ...) rounds differently and is held to the tolerance alone
-    other = os.environ.get("MACX_GEMM", "h2") != "h2" or any(os.environ.get(k) for k in ("MACX_CHAIN", "MACX_SB_DEFER", "MACX_OVERLAP",
+    other = os.environ.get("MACX_GEMM", "h2") != "h2" or any(os.environ.get(k) for k in ("MACX_CHAIN", "MACX_SB_DEFER",
                                                                                         "MACX_CHAIN_KV", "MACX_SB_WIDE"))
     bound = tol if (base is None or other) else min(tol, max(3.0 * base, 2e-6))
     return float(err) < bound, bound

@@ -12,7 +12,7 @@ FWD_TOL = 2e-5     # relative, per state tensor (fp32 kernels vs fp64 oracle)
 GRAD_TOL = 2e-4    # relative to the largest entry of each gradient tensor
 
 
-def build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=0, b0=0, requires_grad=False, gen_seed=5):
+def build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=0, b0=0, requires_grad=False, gen_seed=5, tune=None):
     p = cfg.netLength
     params = macx.MACCellParams(cfg, p, generator=torch.Generator().manual_seed(gen_seed)).to(dev)
     # non-zero biases so that bias paths are exercised
@@ -26,7 +26,7 @@ def build_cell(macx, dev, cfg, vq, words, lengths, kb, train, seed=0, b0=0, requ
     cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=lengths.to(dev),
                         knowledgeBase=kbd, memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout,
                         writeDropout=cfg.writeDropout, batchSize=vq.shape[0], train=train, config=cfg, params=params,
-                        seed=seed, b0=b0)
+                        seed=seed, b0=b0, tune=tune)
     return cell, params, (vqd, wd, kbd)
 
 

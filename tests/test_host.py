@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_builds_loads_and_exports_the_header(macx):
     L = macx._lib.lib()
-    assert L.macx_abi_version() == 4
+    assert L.macx_abi_version() == 5
     header = open(os.path.join(ROOT, "include", "macx.h")).read()
     declared = set(re.findall(r"\b(macx_[a-z_0-9]+)\s*\(", header))
     declared -= {"macx_opts", "macx_shapes"}
@@ -25,7 +25,7 @@ def test_library_builds_loads_and_exports_the_header(macx):
 
 
 def test_struct_layouts_match_header(macx):
-    assert C.sizeof(macx._lib.MacxOpts) == 20 * 4
+    assert C.sizeof(macx._lib.MacxOpts) == (20 + 16) * 4          # + the per-call tuning table (ABI 5)
     assert C.sizeof(macx._lib.MacxShapes) == 7 * 4
     assert C.sizeof(macx._lib.MacxDropout) == 4 * 4 + 8         # + mask_word (device pointer)
     assert C.sizeof(macx._lib.MacxParams) == 30 * 8 == C.sizeof(macx._lib.MacxParamGrads)
@@ -311,18 +311,27 @@ def test_bench_metric_blocks_report_the_median_and_the_spread(monkeypatch):
 
 
 def test_product_code_never_touches_the_debug_knobs():
-    """include/macx.h documents macx_debug_set's keys as PROCESS-GLOBAL debug state outside the per-call contract (VERDICT r04 weak
-    10): no module of the product package calls it or macx_gemm_mode (the per-call selector is macx_opts.gemm_family); only
-    bench.py, tests/ and tools/ do, from MACX_* environment variables."""
+    """The A/B hooks travel per call in macx_opts.tune (ABI 5; the process-global macx_debug_set of ABI <= 4 is gone from the library),
+    and what is left of process-wide state -- macx_gemm_mode's default kernel family, options.SESSION_TUNE on the Python side -- is
+    never written by a module of the product package: only bench.py, tests/ and tools/ do, from MACX_* environment variables."""
     import glob
     import re
-    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mac-network_amd")
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "mac-network_amd")
     offenders = []
     for path in sorted(glob.glob(os.path.join(pkg, "*.py"))):
         src = open(path).read()
         for m in re.finditer(r"\.(macx_debug_set|macx_gemm_mode)\s*\((?!\s*-1\s*\))", src):      # (macx_gemm_mode(-1) only reads the mode)
-            line = src[:m.start()].count("\n") + 1
-            offenders.append("%s:%d %s" % (os.path.basename(path), line, m.group(1)))
+            offenders.append("%s:%d %s" % (os.path.basename(path), src[:m.start()].count("\n") + 1, m.group(1)))
+        for m in re.finditer(r"SESSION_TUNE\s*(\[[^\]]*\]\s*=|\.(update|setdefault|pop|clear)\()", src):
+            offenders.append("%s:%d writes SESSION_TUNE" % (os.path.basename(path), src[:m.start()].count("\n") + 1))
     assert not offenders, offenders
-    hdr = open(os.path.join(os.path.dirname(pkg), "include", "macx.h")).read()
-    assert "PROCESS-GLOBAL DEBUG STATE" in hdr
+    hdr = open(os.path.join(root, "include", "macx.h")).read()
+    assert "macx_debug_set(" not in hdr and "int32_t tune[16]" in hdr
+    # no `static int` knob is left in the library's sources: every accessor reads the call's table
+    for path in sorted(glob.glob(os.path.join(pkg, "csrc", "*"))):
+        src = open(path).read()
+        assert not re.search(r"inline int&\s+\w+\(\)\s*\{\s*static int", src.replace("gemm_default_mode", "")), path
+
+

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/knob_profile.sh "<mask> <mask> ..." [kernel-name regex]  (GPU box): per-kernel durations of the bench step under the
-# measurement knobs of macx_debug_set(1, mask) -- results are WRONG under a non-zero mask, only the timing means something.
+# measurement knobs of macx_opts.tune[MACX_TUNE_PHASE_MASK] (MACX_DBG) -- results are WRONG under a non-zero mask, only the timing means something.
 export TMPDIR=/tmp
 F="--steps 6 --warmup 2 --no-cpu-baseline --no-model-level --no-native --no-extra-legs"
 for m in $1; do

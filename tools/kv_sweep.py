@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""K-loop variants of the chain kernels (macx_debug_set(7, kv); ChainCtx::kloop in macx_chain_h2.hip.h) in ONE process:
-for every kv, (1) one training step compared with the kv = 0 step on the same seed (final memory, dKB, three weight
+"""Same-process A/B of one key of the per-call tuning table (macx_opts.tune, _lib.TUNE; default: chain_kv, the K-loop variant of the
+chain kernels) on the bench step: for every value, (1) one training step compared with the kv = 0 step on the same seed (final memory, dKB, three weight
 gradients: the variants reorder fp32 sums, so the comparison is relative to the tensor's largest entry), (2) ms per bench
 step, (3) the forward chain kernel alone (macx_read_chain_time).
-    python tools/kv_sweep.py 0 4 8 12 16 20 24 28 [--steps 20] [--batch 64]"""
+    python tools/kv_sweep.py --key wgrad_pipe 3 0 1 2 [--steps 20] [--batch 64] [--rounds 2]
+The first value is the parity reference.  (Every step freezes a new cell, which picks options.SESSION_TUNE up.)"""
 import argparse, ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +17,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--p", type=int, default=12)
 ap.add_argument("--rounds", type=int, default=2)
-ap.add_argument("--key", type=int, default=7, help="macx_debug_set key the values belong to (7: K-loop variant, 6: side-queue mode)")
+ap.add_argument("--key", default="chain_kv", help="name of the tuning key (macx._lib.TUNE)")
 ap.add_argument("--zero", action="store_true", help="all-zero knowledge base and weights: the matrix pipe's data-dependent power "
                 "draw (tools/probes/mfma_probe.hip) taken out of the kernel times -- timing only")
 a = ap.parse_args()
@@ -35,18 +36,18 @@ def snapshot():
     return out
 
 
-L.macx_debug_set(a.key, 0 if a.key != 7 else 0)
+macx.options.SESSION_TUNE[a.key] = a.kvs[0]
 for i in range(4):
     step(i)
 ref = snapshot()
 for k, v in ref.items():
     print("ref %-14s max %.3e" % (k, float(v.abs().max())), flush=True)
 for kv in a.kvs:
-    L.macx_debug_set(a.key, kv)
+    macx.options.SESSION_TUNE[a.key] = kv
     got = snapshot()
     worst = max(float((got[k] - ref[k]).abs().max() / ref[k].abs().max()) for k in ref)
     bad = any(not torch.isfinite(v).all() for v in got.values())
-    print("kv %2d  parity vs kv 0: worst rel-to-max %.2e%s" % (kv, worst, "  NON-FINITE" if bad else ""), flush=True)
+    print("kv %2d  parity vs the first value: worst rel-to-max %.2e%s" % (kv, worst, "  NON-FINITE" if bad else ""), flush=True)
 if a.zero:
     with torch.no_grad():
         kbd.zero_()
@@ -54,7 +55,7 @@ if a.zero:
             t.zero_()
 for r in range(a.rounds):
     for kv in a.kvs:
-        L.macx_debug_set(a.key, kv)
+        macx.options.SESSION_TUNE[a.key] = kv
         for i in range(3):
             step(i)
         torch.cuda.synchronize()
@@ -63,4 +64,4 @@ for r in range(a.rounds):
             step(i)
         torch.cuda.synchronize()
         print("round %d kv %2d  %.3f ms/step" % (r, kv, (time.perf_counter() - t0) / a.steps * 1e3), flush=True)
-L.macx_debug_set(a.key, -1 if a.key == 7 else 0)
+macx.options.SESSION_TUNE.pop(a.key, None)

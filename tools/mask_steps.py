@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A few eager training steps of the metric's shape under a phase-knob mask of macx_debug_set(1, mask) -- for a kernel trace per mask
+"""A few eager training steps of the metric's shape under a phase-knob mask of macx_opts.tune[MACX_TUNE_PHASE_MASK] -- for a kernel trace per mask
 (results are WRONG under a non-zero mask; only kernel durations mean something):
     rocprofv3 --kernel-trace --stats -d out -o r -- python tools/mask_steps.py 1024
 masks: 512 sb: skip the per-question fold, 1024 sb / wgrad: skip fragments + MFMAs, 2048 sb / wgrad: skip the in-loop DMA,
@@ -18,9 +18,9 @@ step, params, kbd, bl = bench.make_step(macx, dev, None, 1, 0, 64, 12, 1234)
 for i in range(3):
     step(i)
 torch.cuda.synchronize()
-L.macx_debug_set(1, mask)
+L.macx_opts.tune[MACX_TUNE_PHASE_MASK]
 for i in range(steps):
     step(3 + i)
 torch.cuda.synchronize()
-L.macx_debug_set(1, 0)
+macx.options.SESSION_TUNE.pop("phase_mask", None)
 print("mask", mask, "done")

@@ -24,19 +24,10 @@ def main():
     L.macx_pack_weight(p(W), d, d, macx._lib.kb_pack_flags(), p(wp), None)
     sh = macx._lib.MacxShapes(B=B, S=50, N=N, d=d, p=12, b0=0)
     flops = 2.0 * B * N * d * d
-    for nw in (4, 8):
-        L.macx_debug_set(0, nw)
-        for keep in (1.0, 0.85):
-            dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=keep, keep_write=1.0, seed=1)
-            us = timeit(lambda: L.macx_kb_project(C.byref(sh), C.byref(dp), 0, p(kb), p(wp), p(b), p(out), p(bits), None))
-            print("kb_project NW=%d keep=%.2f: %8.1f us  %6.1f TF" % (nw, keep, us, flops / us / 1e6))
-    L.macx_debug_set(0, 8)
-    dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=1.0, keep_write=1.0, seed=1)
-    for dbg in (0, 1, 2, 3, 4, 8):
-        L.macx_debug_set(1, dbg)
+    for keep in (1.0, 0.85):
+        dp = macx._lib.MacxDropout(keep_memory=1.0, keep_read=keep, keep_write=1.0, seed=1)
         us = timeit(lambda: L.macx_kb_project(C.byref(sh), C.byref(dp), 0, p(kb), p(wp), p(b), p(out), p(bits), None))
-        print("kb_project NW=8 dbg=%d (1 no epilogue, 2 no staging, 4 write-through stores, 8 no epilogue stores): %8.1f us  %6.1f TF" % (dbg, us, flops / us / 1e6))
-    L.macx_debug_set(1, 0)
+        print("kb_project keep=%.2f: %8.1f us  %6.1f TF" % (keep, us, flops / us / 1e6))
     M = B * N
     A = torch.randn(M, d, device=dev); G = torch.randn(M, d, device=dev)
     ns = L.macx_wgrad_splits(M, d, d); ws = torch.empty(ns * d * d, device=dev); o = torch.empty(d, d, device=dev)
