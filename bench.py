@@ -59,39 +59,44 @@ def physical_cores():
         return None
 
 
-def cpu_baseline(seed, iters, sample_b, budget_s=25.0):
-    """The op-for-op torch-CPU restatement of the reference graph (oracle/, kind = "port") timed on
-    this host's cores over a bounded sample of the same workload."""
+def cpu_baseline(seed, iters, sample_b):
+    """The op-for-op torch-CPU restatement of the reference graph (oracle/, kind = "port") timed on this host's cores on the metric's
+    own configuration (B = 64, p = 12, train mode, fwd + bwd): a thread-count sweep (8 / 32 / the physical cores; one
+    warm + one timed pass each), then `iters` timed passes at the best count, median.  About 30 s of CPU work."""
     from oracle import mac_oracle as mo
-    # all host cores up to 32: beyond that torch-CPU's intra-op pool loses throughput on these shapes
-    # (256 threads on the GPU box's host ran the same sample 14x slower than 8 threads on a Xeon)
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     cfg = mo.flag_file_config("args", netLength=P, memDim=D, ctrlDim=D, attDim=D)
     vq, words, lengths, kb = mo.synthetic_inputs(sample_b, S, N, D, seed=seed)
     vs = mo.VarStore(generator=torch.Generator().manual_seed(seed), requires_grad=True)
     keeps = (cfg.memoryDropout, cfg.readDropout, cfg.writeDropout)
     mask_fn = mo.hash_mask_fn(seed, keeps)
     gm = torch.randn(sample_b, D, generator=torch.Generator().manual_seed(1)) / sample_b
-    times = []
-    t_start = time.perf_counter()
-    for it in range(iters + 1):
-        if it > 1 and time.perf_counter() - t_start > budget_s:
-            break
+
+    def one():
         kbr = kb.clone().requires_grad_(True)
         t0 = time.perf_counter()
         c, m, _ = mo.mac_network(cfg, vs, vq, words, words, lengths, kbr, train=True, mask_fn=mask_fn, keeps=keeps)
         (m * gm).sum().backward()
         dt = time.perf_counter() - t0
-        if it > 0:                      # first pass creates the variables / warms the allocator
-            times.append(dt)
         for v in vs.params.values():
             v.grad = None
-    times.sort()
+        return dt
+
+    ncpu = os.cpu_count() or 1
+    sweep = sorted({min(8, ncpu), min(32, ncpu), min(physical_cores() or ncpu, ncpu)})
+    per_threads = {}
+    for t in sweep:
+        torch.set_num_threads(t)
+        one()                                # (the first pass creates the variables / warms the allocator and the thread pool)
+        per_threads[t] = one()
+    best = min(per_threads, key=per_threads.get)
+    torch.set_num_threads(best)
+    times = sorted(one() for _ in range(max(iters, 5)))
     med = times[len(times) // 2]
-    return {"value": round(sample_b / med, 3), "unit": "questions/s", "cores": torch.get_num_threads(),
-            "host_logical_cpus": os.cpu_count(), "host_physical_cores": physical_cores(), "kind": "port",
+    return {"value": round(sample_b / med, 3), "unit": "questions/s", "cores": best,
+            "thread_sweep_questions_per_s": {str(t): round(sample_b / dt, 2) for t, dt in per_threads.items()},
+            "host_logical_cpus": ncpu, "host_physical_cores": physical_cores(), "kind": "port",
             "sample": "%d x (B=%d, S=%d, N=%d, d=%d, p=%d) fwd+bwd, torch-CPU fp32 op-for-op restatement of the TF1 graph "
-                      "(oracle/mac_oracle.py), median" % (len(times), sample_b, S, N, D, P)}
+                      "(oracle/mac_oracle.py), median; thread count = the best of the sweep" % (len(times), sample_b, S, N, D, P)}
 
 
 def model_level(macx, dev, seed, steps=6):
@@ -510,8 +515,8 @@ def main():
     ap.add_argument("--no-extra-dp", action="store_true", help="N > 1: only the metric's (strong-scaling) configuration")
     ap.add_argument("--eager", action="store_true", default=bool(os.environ.get("MACX_BENCH_EAGER")),
                     help="N = 1: time the eager step instead of the captured one")
-    ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--cpu-batch", type=int, default=B)
     ap.add_argument("--p", type=int, default=P, help=argparse.SUPPRESS)
     ap.add_argument("--per-gpu-batch", type=int, default=0, help=argparse.SUPPRESS)   # exploration only; the metric is global B=64
     args = ap.parse_args()
@@ -674,12 +679,24 @@ def main():
                                   readDropout=cfg_r.readDropout, writeDropout=cfg_r.writeDropout, batchSize=Bp, train=True,
                                   config=cfg_r, params=params, seed=seed)
             run = macx.cell._Run(cell_r, True)
+            # (1) IN A RUNNING FORWARD PASS: the library records a HIP event pair around each of a pass's p chain launches on this
+            # stream (macx_cell_forward_chain_time) -- the step's [B,d] linear in front of a launch, the attention kernel behind it, as
+            # in the timed step.  Median of five passes = roofline.kernel_ms.
+            ms = C.c_float(0.0)
+            in_step = []
+            for _ in range(6):
+                rc = L.macx_cell_forward_chain_time(*run._common(), C.byref(ms), run.stream)
+                if rc != 0:
+                    break
+                in_step.append(float(ms.value))
+            chain_in_step_ms = sorted(in_step[1:])[len(in_step[1:]) // 2] if len(in_step) > 1 else None
+            # (2) back to back: 48 launches between ONE event pair (macx_read_chain_time); the next launch starts while the previous
+            # one's 100 MB of stores still drain -- a side figure
             run.begin()
             run.step(0)
-            ms = C.c_float(0.0)
             rc = L.macx_read_chain_time(*run._common()[:7], 0, 48, C.byref(ms), run.stream)
-            if rc == 0:
-                chain_ms = float(ms.value)
+            chain_b2b_ms = float(ms.value) if rc == 0 else None
+            chain_ms = chain_in_step_ms if chain_in_step_ms is not None else chain_b2b_ms
             del run, cell_r
         if chain_ms is not None:
             k_ms = chain_ms
@@ -746,17 +763,21 @@ def main():
         peak = PEAK_BF16_MFMA if mode else PEAK_FP32_MFMA
         # per-launch HBM bytes (PMC) and in-step kernel averages (rocprofv3 --kernel-trace), written by tools/profile_round.sh
         prof = latest_roofline_inputs()
+        # SURVEY 8d's convention: `achieved` = ALGORITHMIC flops of the launch (one fp32 product counted once, the reference's op count of
+        # what the launch computes) / its in-step duration; `frac` = achieved / the dense peak of the pipe the products execute on.
+        # What the pipe EXECUTES for it (3 fp16 terms per product) is the side field executed_*.
         roofline = {"bound": "mfma", "kernel": kname,
-                    # achieved = the FLOPs the matrix pipe EXECUTES for this launch (terms x the algorithmic 2 (B N) d^2) per second,
-                    # priced against the dense peak of the pipe they execute on
-                    "achieved": round(terms * alg / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-                    "frac": round(terms * alg / peak, 4), "pipe": pipe, "mfma_terms_per_product": terms,
-                    # the same launch on SURVEY 8d's ALGORITHMIC flops (one fp32 product counted once, not the 3 fp16 terms it
-                    # executes as) against the same pipe peak
-                    "algorithmic_frac": round(alg / peak, 4),
-                    "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": k_flops,
-                    "algorithmic_tflops": round(alg / 1e12, 2),
+                    "achieved": round(alg / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
+                    "kernel_ms": round(k_ms, 4),
+                    "kernel_ms_how": ("HIP event pair around each chain launch of a running forward pass on the launch stream "
+                                      "(macx_cell_forward_chain_time), median of 5 passes x %d launches" % p) if chain_ms is not None
+                                     else "HIP events around %d back-to-back launches" % nrep,
+                    "algorithmic_flops_per_launch": k_flops,
                     "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("source"), "profile_file": prof.get("file"),
+                    "pipe": pipe, "mfma_terms_per_product": terms,
+                    "executed_tflops": round(terms * alg / 1e12, 2), "executed_frac": round(terms * alg / peak, 4),
+                    "back_to_back_kernel_ms": None if chain_ms is None or chain_b2b_ms is None else round(chain_b2b_ms, 4),
+                    "profile_in_step_kernel_ms": prof.get("in_step_kernel_ms"),
                     # what the pipe sustains on THIS instruction with random fp16 operands, all 256 CUs, nothing else in the loop
                     # (tools/probes/mfma_probe.hip, profiles/r04_mfma_probe.txt): the matrix pipe's rate is data-dependent -- the chip
                     # clocks to its power budget -- 2440 TF on zero operands, 1880 TF on random ones; `peak` stays the guide's dense figure
@@ -764,7 +785,6 @@ def main():
                     # chain kernel: the fp32 knowledge base in; dropout(KB), X, H1, I2 out as H2 (4 B per element) + keep bits; 4 weights
                     "algorithmic_bytes_per_launch": ((1 + 4) * Bp * N * D * 4 + 2 * Bp * N * D // 8 + 4 * D * D * 4) if chain_ms is not None
                                                     else 2 * Bp * N * D * 4 + D * D * 4,
-                    "in_step_kernel_ms": prof.get("in_step_kernel_ms"),
                     # the whole step priced by the REFERENCE's op count (3 p F per question) against the f32-input MFMA
                     # peak (157.3 TF), the arithmetic the metric is stated in.  A RATIO, not a roofline fraction: the step does not run
                     # under that roof (its products execute on the fp16 pipe), so values above 1 are expected
@@ -785,7 +805,7 @@ def main():
                "value": round(qps, 2), "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "timing": timing, "higher_is_better": True,
                "scaling": "weak" if args.per_gpu_batch else "strong", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32 (3xfp16-split emulation)" if mode == 2 else ("f32 (6xbf16-split emulation)" if mode == 1 else "f32"), "data": "synthetic",
                "dtype_note": ("fp32 in, fp32 accumulate, fp32-class results; the large contractions multiply on the fp16 matrix pipe: every "
                               "operand is stored once as x 2^e = hi + lo (two fp16, |error| <= 2^-24) with one exponent per (row, 128 "
                               "columns), a product is the 3 leading terms (dropped: lo*lo <= 2^-24 |ab|); measured error vs fp64 <= the "

@@ -131,7 +131,7 @@ EXPORTS = ("macx_abi_version", "macx_strerror", "macx_check", "macx_saved_floats
            "macx_op_softmax", "macx_op_softmax_bwd", "macx_op_dropout", "macx_op_dropout_w", "macx_kb_attend_fwd", "macx_kb_attend_bwd",
            "macx_kb_attend_bwd_ws_floats", "macx_answer_loss", "macx_workspace_bytes", "macx_embed_lookup", "macx_embed_lookup_bwd", "macx_control_attend_bwd",
            "macx_control_attend_bwd_ws_floats", "macx_read_fwd", "macx_read_bwd",
-           "macx_write_fwd", "macx_write_bwd", "macx_read_chain_time", "macx_saved_activation", "macx_ctrl_inputs_ws_floats",
+           "macx_write_fwd", "macx_write_bwd", "macx_read_chain_time", "macx_cell_forward_chain_time", "macx_saved_activation", "macx_ctrl_inputs_ws_floats",
            "macx_ctrl_inputs_fwd", "macx_ctrl_inputs_bwd")
 
 _lib = None
@@ -187,6 +187,7 @@ def lib():
                                       C.c_void_p]
     L.macx_read_chain_time.argtypes = [P(MacxOpts), P(MacxShapes), P(MacxDropout), P(MacxParams), P(MacxInputs), C.c_void_p, C.c_size_t,
                                        C.c_int, C.c_int, P(C.c_float), C.c_void_p]
+    L.macx_cell_forward_chain_time.argtypes = common + [P(C.c_float), C.c_void_p]
     L.macx_saved_activation.argtypes = [P(MacxOpts), P(MacxShapes), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.macx_ctrl_inputs_ws_floats.restype = C.c_size_t
     L.macx_ctrl_inputs_ws_floats.argtypes = [P(MacxOpts), P(MacxShapes)]

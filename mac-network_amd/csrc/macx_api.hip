@@ -797,6 +797,10 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
 }
 
 namespace {
+// macx_cell_forward_chain_time: an event pair around every forward chain launch of the passes this thread runs while `on`
+struct ChainProbe { hipEvent_t ev[2 * 64]; int n; bool on; };
+inline ChainProbe& chain_probe() { static thread_local ChainProbe p = {}; return p; }
+
 int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
                    const macx_inputs* in, float* saved, size_t saved_floats, int keep, int step, int units, void* stream) {
   CKI(check_impl(o, s));
@@ -879,7 +883,11 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     if (use_chain(d, s->N)) {
       // KB -> X -> H1 -> I2 -> logits in one launch (macx_chain_h2.hip.h)
       const ChainFwdP c = make_chain_fwd(o, s, dp, P, in, saved, L, keep, i, i);
+      ChainProbe& cp = chain_probe();
+      const bool timed = cp.on && cp.n < 64;
+      if (timed) CK(hipEventRecord(cp.ev[2 * cp.n], st));
       CK(chain_fwd_launch(c, st));
+      if (timed) { CK(hipEventRecord(cp.ev[2 * cp.n + 1], st)); ++cp.n; }
     } else {
     if (rdrop || i == 0) {
       H2FromP f;
@@ -2697,6 +2705,38 @@ int macx_read_chain_time(const macx_opts* o, const macx_shapes* s, const macx_dr
   *ms_out = t / reps;
   CK(hipEventDestroy(e0));
   CK(hipEventDestroy(e1));
+  return MACX_OK;
+}
+
+/* The same kernel timed IN A RUNNING FORWARD PASS: one macx_cell_forward (keep = 1) on `stream` with a HIP event pair around each of
+   its p chain launches -- in front of a launch sits the step's [B,d] linear, behind it the attention kernel, as in a training step;
+   *ms_out = average milliseconds per launch (synchronises `stream`).  What bench.py's roofline.kernel_ms reports. */
+int macx_cell_forward_chain_time(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
+                                 const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats, float* ms_out,
+                                 void* stream) {
+  ModeScope ms(o);
+  CKI(check_impl(o, s));
+  if (!ms_out) return MACX_EINVAL;
+  if (!use_chain(s->d, s->N)) return MACX_EUNSUPPORTED;
+  ChainProbe& cp = chain_probe();
+  if (cp.on) return MACX_EINVAL;
+  const int ne = 2 * (s->p < 64 ? s->p : 64);
+  for (int i = 0; i < ne; ++i) CK(hipEventCreate(&cp.ev[i]));
+  cp.n = 0; cp.on = true;
+  const int rc = macx_cell_forward(o, s, dp, P, in, saved, saved_floats, ws, ws_floats, 1, stream);
+  cp.on = false;
+  int err = rc;
+  if (rc == MACX_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) err = MACX_EINVAL;
+  double total = 0.0;
+  for (int k = 0; err == MACX_OK && k < cp.n; ++k) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, cp.ev[2 * k], cp.ev[2 * k + 1]) != hipSuccess) err = MACX_EINVAL;
+    total += t;
+  }
+  for (int i = 0; i < ne; ++i) (void)hipEventDestroy(cp.ev[i]);
+  if (err != MACX_OK) return err;
+  if (cp.n < 1) return MACX_EUNSUPPORTED;
+  *ms_out = (float)(total / cp.n);
   return MACX_OK;
 }
 

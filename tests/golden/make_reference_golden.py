@@ -152,9 +152,18 @@ def hip_case(name, p, B=2, S=6, N=20, D=128, HID=64, ANS=28, seed=31, compact=Fa
     np.savez_compressed(os.path.join(OUT, "hip_%s_p%d.npz" % (tag or name, p)), **z)
 
 
+def metric_depth_case():
+    """The metric's depth and geometry (p = 12, d = 512, N = 196, S = 50; 16 questions = 49 tiles of 64 rows) in training mode: the
+    reference executed over twelve steps of the chain kernels' products, compact form."""
+    hip_case("args", 12, B=16, S=50, N=196, D=512, HID=64, seed=41, compact=True, tag="args_d512")
+
+
 def main():
     assert rx.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
+    if "--metric-depth-only" in sys.argv:
+        metric_depth_case()
+        return
     for f in os.listdir(OUT):
         if f.endswith(".npz") and (f.startswith("oracle_") or f.startswith("hip_")):      # (training_steps.npz: make_training_golden.py)
             os.remove(os.path.join(OUT, f))
@@ -168,6 +177,7 @@ def main():
     hip_case("args", 12)
     # the chain kernels' d = 512 geometry (64-row tiles over 8 x 196 rows = 24.5 tiles) against the executed reference directly
     hip_case("args", 4, B=8, S=9, N=196, D=512, HID=64, seed=37, compact=True, tag="args_d512")
+    metric_depth_case()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote %d files, %.1f KB" % (len(os.listdir(OUT)), total / 1024))
 

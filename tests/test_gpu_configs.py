@@ -1,8 +1,9 @@
 """-m gpu: the configurations BASELINE.json names, at full size, against the fp64 oracle: final state, attentions and EVERY
 gradient (all parameters, knowledge base, words, question vectors).  Questions are independent inside the cell, so the oracle
 runs the batch in chunks of questions (same global question indices -> same dropout masks) and adds the parameter gradients
-up.  Every tensor's observed error is recorded (helpers.check_margin -> profiles/r03_parity_margins.json) and bounded by
-min(tolerance, 3 x the committed observation)."""
+up.  Every tensor's observed error is recorded (helpers.check_margin -> gpurun_out/parity_margins.json, committed as
+profiles/rNN_parity_margins.json) and bounded by min(tolerance, 3 x the smallest committed observation of that tensor over all
+rounds); a tensor no record knows fails."""
 import pytest
 import torch
 
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 FWD_TOL = 2e-5      # final memory / control, relative to the largest entry
 ATT_TOL = 2e-6      # attention weights, absolute
-GRAD_TOL = 1e-4     # every gradient, relative to the tensor's largest entry
+GRAD_TOL = 3e-5     # every gradient, relative to the tensor's largest entry (observed worst: 1.12e-5, the bias of projX at B = 128, p = 16)
 
 
 def oracle_chunked_grads(cfg, ref_params, vq, words, lengths, kb, train, seed, d_memory, chunk=8, dtype=torch.float64, b0=0):
@@ -72,7 +73,7 @@ def check_full(macx, dev, tag, name, B, S, N, d, p, seed, b0=0):
             errs["d_" + refname] = (rel_err(got.reshape(rg.shape), rg, floor=floor), GRAD_TOL)
     bad = {}
     for k, (e, tol) in errs.items():
-        ok, bound = check_margin("%s/%s" % (tag, k), e, tol)
+        ok, bound = check_margin("%s/%s" % (tag, k), e, tol, require_record=True)
         if not ok:
             bad[k] = (e, bound)
     assert not bad, bad

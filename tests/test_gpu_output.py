@@ -67,6 +67,33 @@ def test_end_to_end_logits_and_argmax_p12(macx, dev):
         assert torch.equal(logits.argmax(-1).cpu(), rl.argmax(-1))
 
 
+def test_end_to_end_logits_and_argmax_p12_train_mode(macx, dev):
+    """The same bar in TRAINING mode at the metric's size: dropout .85/.85/1.0 in the cell (memory, read sites)
+    and the classifier's output dropout, masks from the stateless stream handed identically to the fp64 oracle (chunks of 8
+    questions: same global question indices, same masks).  Logits within 1e-4, argmax identical."""
+    B, S, N, d, p, A = 64, 50, 196, 512, 12, 28
+    cfg, vq, words, lengths, kb = make_case("args", B, S, N, d, p)
+    cfg.answerWordsNum = A
+    seed = 77
+    cell, params, (vqd, wd, kbd) = build_cell(macx, dev, cfg, vq, words, lengths, kb, True, seed=seed)
+    out = macx.OutputClassifier(cfg, generator=torch.Generator().manual_seed(3)).to(dev)
+    with torch.no_grad():
+        state = cell.run()
+        logits = out(state.memory, vqd, train=True, seed=seed)
+    torch.cuda.synchronize()
+    mems = []
+    for lo in range(0, B, 8):
+        sl = slice(lo, lo + 8)
+        r = oracle_run(cfg, params.to_reference_dict(), vq[sl], words[sl], lengths[sl], kb[sl], train=True, seed=seed, b0=lo,
+                       dtype=torch.float64)
+        mems.append(r["memory"].detach())
+    mem = torch.cat(mems)
+    assert rel_err(state.memory, mem) < 2e-5
+    rl, _ = oracle_logits(cfg, out.to_reference_dict(), mem, vq.double(), cfg.outputDropout, seed, dtype=torch.float64)
+    assert max_abs(logits, rl) < 1e-4, max_abs(logits, rl)
+    assert torch.equal(logits.argmax(-1).cpu(), rl.argmax(-1))
+
+
 @pytest.mark.parametrize("clip", [8.0, 0.0])
 def test_adam_ema_step_matches_oracle(macx, dev, clip):
     """model.py:639-669 over a flat buffer: 4 steps, clip active (large grads) and inactive."""
