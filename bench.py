@@ -679,9 +679,9 @@ def main():
                                   readDropout=cfg_r.readDropout, writeDropout=cfg_r.writeDropout, batchSize=Bp, train=True,
                                   config=cfg_r, params=params, seed=seed)
             run = macx.cell._Run(cell_r, True)
-            # (1) IN A RUNNING FORWARD PASS: the library records a HIP event pair around each of a pass's p chain launches on this
-            # stream (macx_cell_forward_chain_time) -- the step's [B,d] linear in front of a launch, the attention kernel behind it, as
-            # in the timed step.  Median of five passes = roofline.kernel_ms.
+            # (1) IN A RUNNING FORWARD PASS: the library launches each of a pass's p chain kernels with a start and a stop HIP event on
+            # this stream (macx_cell_forward_chain_time: the kernel's own timestamps) -- the step's [B,d] linear in front of a launch,
+            # the attention kernel behind it, as in the timed step.  Median of five passes = roofline.kernel_ms.
             ms = C.c_float(0.0)
             in_step = []
             for _ in range(6):
@@ -769,8 +769,9 @@ def main():
         roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(alg / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
                     "kernel_ms": round(k_ms, 4),
-                    "kernel_ms_how": ("HIP event pair around each chain launch of a running forward pass on the launch stream "
-                                      "(macx_cell_forward_chain_time), median of 5 passes x %d launches" % p) if chain_ms is not None
+                    "kernel_ms_how": ("start / stop HIP events of each chain launch of a running forward pass on the launch stream "
+                                      "(hipExtLaunchKernelGGL: the kernel's own timestamps; macx_cell_forward_chain_time), median of 5 "
+                                      "passes x %d launches" % p) if chain_ms is not None
                                      else "HIP events around %d back-to-back launches" % nrep,
                     "algorithmic_flops_per_launch": k_flops,
                     "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("source"), "profile_file": prof.get("file"),

@@ -399,9 +399,11 @@ int macx_h2_gemm(const float* A, int B, int N, int K, const float* W, int n_out,
  * family does not run on that kernel. */
 int macx_read_chain_time(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*, const macx_inputs*,
                          float* saved, size_t saved_floats, int step, int reps, float* ms_out, void* stream);
-/* ... and IN A RUNNING FORWARD PASS: one macx_cell_forward (keep = 1) on `stream` with a HIP event pair around each of its p chain
- * launches (the step's [B,d] linear in front, the attention kernel behind, as in a training step); *ms_out = average milliseconds
- * per launch.  Synchronises `stream`.  bench.py's roofline.kernel_ms. */
+/* ... and IN A RUNNING FORWARD PASS: one macx_cell_forward (keep = 1) on `stream`, each of its p chain launches issued with a start
+ * and a stop HIP event that receive the kernel's own dispatch timestamps (the step's [B,d] linear in front of a launch, the
+ * attention kernel behind it, as in a training step), behind three untimed passes so that the chip is as busy as inside a training
+ * loop; *ms_out = average milliseconds per launch of the timed pass.  Synchronises `stream`.
+ * bench.py's roofline.kernel_ms. */
 int macx_cell_forward_chain_time(const macx_opts*, const macx_shapes*, const macx_dropout*, const macx_params*, const macx_inputs*,
                                  float* saved, size_t saved_floats, float* ws, size_t ws_floats, float* ms_out, void* stream);
 /* One of the read unit's kept [B*N, d] activations of step `step`, as fp32 row-major, from the `saved` buffer of a forward pass with

@@ -177,7 +177,8 @@ class _CellFunction(torch.autograd.Function):
         p = run.shapes.p
         controls = run.segment("controls", (p + 1, run.shapes.B, run.shapes.d))
         memories = run.segment("memories", (p + 1, run.shapes.B, run.shapes.d))
-        return controls[p].clone(), memories[p].clone()
+        # views of the run's own `saved` buffer (nothing writes it after the forward pass): no copy launches
+        return controls[p], memories[p]
 
     @staticmethod
     def backward(ctx, d_control, d_memory):

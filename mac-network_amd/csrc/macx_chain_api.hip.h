@@ -91,7 +91,7 @@ inline int chain_tile_shift(int d, size_t M) { const int r = chain_tile_rows(d, 
 inline size_t chain_tiles(int d, size_t M) { const size_t r = (size_t)chain_tile_rows(d, M); return (M + r - 1) / r; }
 
 // defined in macx_chain_fwd.hip / macx_chain_bwd.hip
-hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st);
+hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // e0 / e1: the kernel's own start / stop timestamps
 hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st);
 
 }  // namespace macx

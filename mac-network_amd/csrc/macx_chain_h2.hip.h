@@ -42,6 +42,7 @@
 //     per-question weight mixing.  Backward: dI1 W1a^T is multiplied by y per output column on the accumulators, then
 //     dI1 W1b^T is added.
 #pragma once
+#include <hip/hip_ext.h>
 #include "macx_chain_api.hip.h"
 
 namespace macx {
@@ -694,38 +695,41 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   }
 }
 
+// e0 / e1 (both or neither): HIP events that receive the KERNEL's own start and stop timestamps (hipExtLaunchKernelGGL: the dispatch
+// packet's signal times, what a kernel trace reports) -- macx_cell_forward_chain_time
 template <int D_, int KV = 0, int R_ = 64>
-inline hipError_t chain_fwd_launch_t(const ChainFwdP& p, hipStream_t st) {
+inline hipError_t chain_fwd_launch_t(const ChainFwdP& p, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   auto kern = chain_fwd_kernel<D_, KV, R_>;
   constexpr size_t lds = ChainGeo<D_, R_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
+  if (e0 && e1) hipExtLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, e0, e1, 0, p);
+  else hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
 
 #ifdef MACX_CHAIN_FWD_TU      // macx_chain_fwd.hip: the one translation unit that instantiates the forward kernels
-hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st) {
+hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   switch (p.d / 128) {
-    case 1: return chain_fwd_launch_t<128>(p, st);
-    case 2: return chain_fwd_launch_t<256>(p, st);
-    case 3: return chain_fwd_launch_t<384>(p, st);
+    case 1: return chain_fwd_launch_t<128>(p, st, e0, e1);
+    case 2: return chain_fwd_launch_t<256>(p, st, e0, e1);
+    case 3: return chain_fwd_launch_t<384>(p, st, e0, e1);
     case 4:
       switch (chain_tile_rows(p.d, (size_t)p.M)) {
-        case 16: return chain_fwd_launch_t<512, 0, 16>(p, st);
-        case 32: return chain_fwd_launch_t<512, 0, 32>(p, st);
+        case 16: return chain_fwd_launch_t<512, 0, 16>(p, st, e0, e1);
+        case 32: return chain_fwd_launch_t<512, 0, 32>(p, st, e0, e1);
         default: break;
       }
 #ifdef MACX_PROFILE_VARIANTS
       switch (p.dbg >> 3) {
-        case 1: return chain_fwd_launch_t<512, 1>(p, st);
-        case 2: return chain_fwd_launch_t<512, 2>(p, st);
-        case 3: return chain_fwd_launch_t<512, 3>(p, st);
+        case 1: return chain_fwd_launch_t<512, 1>(p, st, e0, e1);
+        case 2: return chain_fwd_launch_t<512, 2>(p, st, e0, e1);
+        case 3: return chain_fwd_launch_t<512, 3>(p, st, e0, e1);
         default: break;
       }
 #endif
-      return chain_kv() == 0 ? chain_fwd_launch_t<512, 0>(p, st) : chain_fwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st);
+      return chain_kv() == 0 ? chain_fwd_launch_t<512, 0>(p, st, e0, e1) : chain_fwd_launch_t<512, CHAIN_KV_DEFAULT>(p, st, e0, e1);
     default: return hipErrorInvalidValue;
   }
 }

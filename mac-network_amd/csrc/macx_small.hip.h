@@ -214,6 +214,21 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
 
   const float* Wz = p.W + (size_t)z * p.zW + ((size_t)lg * p.n_out + c0 + li) * 4;
   const int nQ = p.Ktot >> 4;
+  // the epilogue's global operands (bias, addend, the activation output act' is taken from) do not depend on the product: they are
+  // requested HERE, in front of the K loop, so that their L2 / HBM round trip runs under the loop's instead of behind the
+  // cross-wave combine (round 6: one dependent round trip less in a launch that is a chain of three)
+  const int er = tid >> 2, ecq = (tid & 3) * 4;
+  const int erow = min(r0 + er, p.rows - 1), ecol = c0 + ecq;
+  f32x4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_add = {0.f, 0.f, 0.f, 0.f}, e_ag = {0.f, 0.f, 0.f, 0.f};
+  auto ld4 = [](const float* q) __attribute__((always_inline)) {       // 16-byte load where the caller's pointer allows it
+    if ((reinterpret_cast<uintptr_t>(q) & 15) == 0) return *reinterpret_cast<const f32x4*>(q);
+    return f32x4{q[0], q[1], q[2], q[3]};
+  };
+  if (er < L_ROWS) {
+    if (p.bias) e_bias = ld4(p.bias + (size_t)z * p.zb + ecol);
+    if (p.addend) e_add = ld4(p.addend + (size_t)z * p.zadd + (size_t)erow * p.ld_add + ecol);
+    if (p.actgrad_src) e_ag = ld4(p.actgrad_src + (size_t)z * p.zag + (size_t)erow * p.ld_ag + ecol);
+  }
   // Operands are L2-resident and the chain is latency-bound: fetch the fragments of 8 k-groups
   // (40 x 16 B per lane in flight) before touching the matrix pipe.
   constexpr int PF = PART ? 4 : 8;
@@ -301,10 +316,10 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float v = val[e];
-    if (p.bias) v += p.bias[(size_t)z * p.zb + col + e];
+    v += e_bias[e];
     v += p.bias_const;
     v = act_apply(p.act, v);
-    if (p.actgrad_src) v *= act_grad_from_out(p.actgrad_act, p.actgrad_src[(size_t)z * p.zag + (size_t)row * p.ld_ag + col + e]);
+    if (p.actgrad_src) v *= act_grad_from_out(p.actgrad_act, e_ag[e]);
     if (p.use_drop) {
       const uint32_t idx = (p.drop_row0 + row) * (uint32_t)(p.drop_ld > 0 ? p.drop_ld : p.n_out) + col + e;
       float f = 1.f;
@@ -313,7 +328,7 @@ __device__ __forceinline__ void small_linear_tile(const LinP& p, int bx, int by,
       if (p.use_drop == 2) vald[e] = v * f;
       else v *= f;
     }
-    if (p.addend) v += p.addend[(size_t)z * p.zadd + (size_t)row * p.ld_add + col + e];
+    v += e_add[e];
     val[e] = v;
   }
   *reinterpret_cast<f32x4*>(p.out + (size_t)z * p.zout + (size_t)row * p.ldo + col) = val;
@@ -501,6 +516,7 @@ struct CtrlP {
 };
 
 constexpr int C_MAXS = 256;   // max padded question length held in LDS
+constexpr int CA_U = 8;       // words a wave requests together in the logit / da passes of the word-attention kernels
 
 __global__ __launch_bounds__(256) void control_attend_kernel(CtrlP p) {
   __shared__ float s_logit[C_MAXS];
@@ -511,20 +527,33 @@ __global__ __launch_bounds__(256) void control_attend_kernel(CtrlP p) {
   const float* words = p.words + (size_t)b * p.S * p.d;
   const int L = p.lengths[b];
 
-  for (int s = wave; s < p.S; s += 4) {
-    float part = 0.f;
+  // a wave takes the words s = wave, wave + 4, ..; CA_U of them are requested together (rows past the end re-read the last one):
+  // the launch is a chain of dependent L2 round trips, one per batch instead of one per word (round 6: 23.8 -> ~12 us at S = 50)
+  const float bias0 = p.bias[0];
+  for (int s0 = wave; s0 < p.S; s0 += 4 * CA_U) {
+    float part[CA_U];
+#pragma unroll
+    for (int u = 0; u < CA_U; ++u) part[u] = 0.f;
     for (int k = lane * 4; k < p.d; k += 256) {
-      const f32x4 wd = *reinterpret_cast<const f32x4*>(words + (size_t)s * p.d + k);
+      f32x4 wd[CA_U];
+#pragma unroll
+      for (int u = 0; u < CA_U; ++u) wd[u] = *reinterpret_cast<const f32x4*>(words + (size_t)min(s0 + 4 * u, p.S - 1) * p.d + k);
       const f32x4 c4 = *reinterpret_cast<const f32x4*>(cc + k);
       const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.w + k);
       // (cc * words) * w, the order of mac_cell.py:155 then ops.py:317
-      part += (c4[0] * wd[0]) * w4[0] + (c4[1] * wd[1]) * w4[1] + (c4[2] * wd[2]) * w4[2] + (c4[3] * wd[3]) * w4[3];
+#pragma unroll
+      for (int u = 0; u < CA_U; ++u)
+        part[u] += (c4[0] * wd[u][0]) * w4[0] + (c4[1] * wd[u][1]) * w4[1] + (c4[2] * wd[u][2]) * w4[2] + (c4[3] * wd[u][3]) * w4[3];
     }
-    part = wave_sum(part);
-    if (lane == 0) {
-      const float logit = part + p.bias[0];
-      // ops.expMask (ops.py:243-247): seq + (1 - mask) * (-1e30)
-      s_logit[s] = logit + (s < L ? 0.f : 1.0f) * (-1e30f);
+#pragma unroll
+    for (int u = 0; u < CA_U; ++u) {
+      const int s = s0 + 4 * u;
+      const float t = wave_sum(part[u]);
+      if (lane == 0 && s < p.S) {
+        const float logit = t + bias0;
+        // ops.expMask (ops.py:243-247): seq + (1 - mask) * (-1e30)
+        s_logit[s] = logit + (s < L ? 0.f : 1.0f) * (-1e30f);
+      }
     }
   }
   __syncthreads();
@@ -590,15 +619,24 @@ __global__ __launch_bounds__(256) void control_bwd_dl_kernel(CtrlBwdP p) {
   const float* words = p.words + (size_t)b * p.S * p.d;
   const float* dc = p.dcontrol + (size_t)z * p.z_dc + (size_t)b * p.d;
   const float* att = p.att + (size_t)z * p.z_att + (size_t)b * p.S;
-  for (int s = wave; s < p.S; s += 4) {
-    float part = 0.f;
+  for (int s0 = wave; s0 < p.S; s0 += 4 * CA_U) {       // (CA_U words per batch of loads, as in control_attend_kernel)
+    float part[CA_U];
+#pragma unroll
+    for (int u = 0; u < CA_U; ++u) part[u] = 0.f;
     for (int k = lane * 4; k < p.d; k += 256) {
-      const f32x4 wd = *reinterpret_cast<const f32x4*>(words + (size_t)s * p.d + k);
+      f32x4 wd[CA_U];
+#pragma unroll
+      for (int u = 0; u < CA_U; ++u) wd[u] = *reinterpret_cast<const f32x4*>(words + (size_t)min(s0 + 4 * u, p.S - 1) * p.d + k);
       const f32x4 g = *reinterpret_cast<const f32x4*>(dc + k);
-      part += g[0] * wd[0] + g[1] * wd[1] + g[2] * wd[2] + g[3] * wd[3];
+#pragma unroll
+      for (int u = 0; u < CA_U; ++u) part[u] += g[0] * wd[u][0] + g[1] * wd[u][1] + g[2] * wd[u][2] + g[3] * wd[u][3];
     }
-    part = wave_sum(part);
-    if (lane == 0) s_da[s] = part;
+#pragma unroll
+    for (int u = 0; u < CA_U; ++u) {
+      const int s = s0 + 4 * u;
+      const float t = wave_sum(part[u]);
+      if (lane == 0 && s < p.S) s_da[s] = t;
+    }
   }
   __syncthreads();
   float dot = 0.f;
