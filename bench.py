@@ -482,7 +482,49 @@ def make_step(macx, dev, dist, world, rank, global_batch, p, seed):
         if world > 1:
             bucket.allreduce_(bl, global_batch)
 
+    step.bucket, step.slice = bucket, (lo, hi)
     return step, params, kbd, bl
+
+
+def make_dp_graph_step(macx, dev, dist, params, bucket, kbd, lo, hi, global_batch, p, seed):
+    """The data-parallel step as TWO graph replays (forward + backward phase 1 | backward phase 2) with the early bucket's all-reduce
+    between them on the side stream and the late bucket behind them (macx.CapturedDPTrainStep): 2 replays + 2 collectives per rank
+    and step instead of ~125 host-issued launches.  Checked here, on every rank, against one eager data-parallel step on the same
+    inputs, seed and mask word: the all-reduced flat gradient buffer must be bit-identical.  Returns (step, ok_on_all_ranks)."""
+    bl = hi - lo
+    cfg = macx.configs.flag_file_config("args", netLength=p, memDim=D, ctrlDim=D, attDim=D)
+    vq, words, lengths, _ = macx.configs.synthetic_inputs(bl, S, N, D, seed=seed + dist.get_rank())
+    gm = (torch.randn(bl, D, generator=torch.Generator().manual_seed(1)) / global_batch).to(dev)
+    vqd, wd, ld = vq.to(dev), words.to(dev), lengths.to(dev)
+    # the eager reference step (the cell's autograd node drives the bucket), mask word 0
+    for t in params.tensors():
+        t.grad = None
+    cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=ld, knowledgeBase=kbd.detach(),
+                        memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout, writeDropout=cfg.writeDropout, batchSize=bl,
+                        train=True, config=cfg, params=params, seed=seed, b0=lo)
+    state = cell.run()
+    bucket.begin_step(bl, global_batch)
+    torch.autograd.backward([state.memory], [gm])
+    bucket.allreduce_(bl, global_batch)
+    torch.cuda.synchronize()
+    want = bucket.flat.detach().clone()
+    for t in params.tensors():
+        t.grad = None
+    del cell, state
+    cap = macx.CapturedDPTrainStep(cfg, params, bucket, B=bl, S=S, N=N, global_batch=global_batch, seed=seed, b0=lo)
+    cap.load(vqd, wd, ld, kbd.detach(), gm)
+    ok = True
+    for _ in range(2):
+        cap.step()
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.equal(bucket.flat, want))
+    flag = torch.tensor([1.0 if (ok and cap.captured) else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+
+    def step(i):
+        cap.step(iteration=i)
+
+    return step, bool(flag.item() > 0.5), cap
 
 
 def make_graph_step(macx, dev, params, kbd, bl, p, seed):
@@ -626,6 +668,27 @@ def main():
             launch_mode = ("one captured HIP graph per step (macx.CapturedTrainStep: forward + full backward, self-checked bit for bit against "
                            "the eager step incl. every gradient; the run's mask word is rewritten before each replay: fresh dropout masks per step)")
         del gstep, cap
+    dp_graph_note = None
+    if world > 1 and not args.eager and mode_is_h2(L):
+        # N > 1: the captured data-parallel step -- two graph replays with the exchange between and behind them -- is what a rank runs
+        # when its replays reproduce the eager data-parallel step bit for bit on EVERY rank; the eager step timed above stays in the
+        # line as `eager_step`.  Anything else (a failed self-check on some rank, an exception while capturing) keeps the eager timing.
+        try:
+            lo, hi = step.slice
+            cstep, ok, cap_dp = make_dp_graph_step(macx, dev, dist, params, step.bucket, kbd, lo, hi, global_batch, p, seed)
+        except Exception as e:          # (every rank runs the same code on the same shapes: an exception here is an exception everywhere)
+            ok, dp_graph_note = False, "capture failed: %s: %s" % (type(e).__name__, str(e)[:200])
+        if ok:
+            emed, _ = block_summary(dts, args.steps, global_batch)
+            eager_leg = {"ms_per_step": round(emed / args.steps * 1e3, 3), "value": round(global_batch * args.steps / emed, 2), "unit": "questions/s",
+                         "ms_per_step_blocks": [round(d / args.steps * 1e3, 3) for d in dts],
+                         "what": "the same data-parallel step as eager launches (autograd node + phase-1 hook), same processes"}
+            dts = time_blocks(cstep, args.steps, args.warmup, 4, barrier, world, dev, dist, blocks=METRIC_BLOCKS)
+            launch_mode = ("two captured HIP graphs per rank and step (macx.CapturedDPTrainStep: forward + backward phase 1 | backward phase 2), "
+                           "the early bucket's all-reduce between them on a side stream, the late bucket behind them; self-checked bit for "
+                           "bit against the eager data-parallel step on every rank; fresh dropout masks per step through the mask word")
+        elif dp_graph_note is None:
+            dp_graph_note = "the replayed step did not reproduce the eager data-parallel step on every rank: eager launches timed"
     if world == 1 and len(dts) == 1:          # the eager step IS the metric here (--eager, another kernel family, no capture): time the remaining blocks
         dts = dts + time_blocks(step, args.steps, 0, 0, barrier, world, dev, dist, blocks=METRIC_BLOCKS - 1)
     dt, timing = block_summary(dts, args.steps, global_batch)
@@ -824,6 +887,8 @@ def main():
                "roofline": roofline}
         out.update(extra)
         out["launch"] = launch_mode
+        if dp_graph_note:
+            out["launch_note"] = dp_graph_note
         out["side_legs_timing"] = ("every leg below the metric (other_families, fwd_only_p4, train_b128_p12_adam_ema, gqa_shape_*, model_level) reports "
                                    "the fastest of 3 timed blocks of its `steps` steps; the metric itself is the MEDIAN of %d blocks of K steps (`timing`)" % METRIC_BLOCKS)
         if eager_leg is not None:

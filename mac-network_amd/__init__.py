@@ -11,6 +11,6 @@ from .output import GenericOutputClassifier, OutputClassifier   # noqa: F401
 from .stem import Stem                              # noqa: F401
 from .encoder import GenericQuestionEncoder, QuestionEncoder   # noqa: F401
 from .model import MACNet, MACNetCore               # noqa: F401
-from .graph import CapturedForward, CapturedTrainStep  # noqa: F401
+from .graph import CapturedForward, CapturedTrainStep, CapturedDPTrainStep  # noqa: F401
 
 __all__ = ["MACCell", "MACCellTuple", "MACCellParams", "OutputClassifier", "GenericOutputClassifier", "UnsupportedOptions", "freeze"]

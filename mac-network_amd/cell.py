@@ -110,7 +110,9 @@ class _Run:
             raise ValueError("segment %s holds %d floats, view wants %d" % (name, cnt.value, n))
         return self.saved[off.value: off.value + n].view(*shape)
 
-    def backward(self, d_control, d_memory):
+    def backward_begin(self, d_control, d_memory):
+        """Buffers and argument block of this run's backward pass: (args of macx_cell_backward[_phase] without the trailing phase /
+        stream, {field: gradient view}, (d vecQuestions, d words, d knowledgeBase), the flat gradient buffer, keep-alive list)."""
         if not self.keep:
             raise RuntimeError("this run did not keep its activations (train=False / no_grad)")
         dev = self.saved.device
@@ -147,16 +149,25 @@ class _Run:
                                        knowledgeBase=gi_kb.data_ptr())
         dm = _f32c(d_memory, "d_memory") if d_memory is not None else None
         dc = _f32c(d_control, "d_control") if d_control is not None else None
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         args = (C.byref(self.opts), C.byref(self.shapes), C.byref(self.drop), C.byref(self.pstruct), C.byref(self.inputs),
                 _ptr(self.saved), C.c_size_t(self.saved_floats), _ptr(ws), C.c_size_t(ws_floats), _ptr(dm), _ptr(dc),
                 C.byref(gstruct), C.byref(gistruct))
+        return args, grads, (gi_vq, gi_words, gi_kb), flat, (ws, gstruct, gistruct, dm, dc)
+
+    def backward_phase(self, args, phase):
+        """macx_cell_backward_phase on torch's CURRENT stream (1: everything but the read unit's deferred contractions, 2: those)"""
+        stream = C.c_void_p(torch.cuda.current_stream(self.saved.device).cuda_stream)
+        _lib.check(self.L.macx_cell_backward_phase(*args, int(phase), stream), "macx_cell_backward_phase(%d)" % phase)
+
+    def backward(self, d_control, d_memory):
+        args, grads, (gi_vq, gi_words, gi_kb), flat, _keep = self.backward_begin(d_control, d_memory)
+        stream = C.c_void_p(torch.cuda.current_stream(self.saved.device).cuda_stream)
         hook = getattr(self.params, "after_backward_phase1", None)
         if hook is not None and flat is getattr(self.params, "_grad_flat", None):
             # every gradient except the read unit's big contractions is final: let the data-parallel layer start on it
-            _lib.check(self.L.macx_cell_backward_phase(*args, 1, stream), "macx_cell_backward_phase(1)")
+            self.backward_phase(args, 1)
             hook(flat)
-            _lib.check(self.L.macx_cell_backward_phase(*args, 2, stream), "macx_cell_backward_phase(2)")
+            self.backward_phase(args, 2)
         else:
             _lib.check(self.L.macx_cell_backward(*args, stream), "macx_cell_backward")
         return grads, gi_vq, gi_words, gi_kb

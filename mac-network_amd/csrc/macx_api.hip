@@ -483,12 +483,21 @@ inline hipError_t dev_copy2d(void* dst, size_t dpitch, const void* src, size_t s
 }
 inline hipError_t dev_copy(void* dst, const void* src, size_t bytes, hipStream_t st) { return dev_copy2d(dst, bytes, src, bytes, bytes, 1, st); }
 
+// the maximum |W| behind a format-3 pack's exponent: matrix k of absmax4's four (projX, memKbProj_2, W1a, W1b).  Where the chain
+// kernels run every consumer of the maxima is a pack of this run's ONE pack launch, which combines absmax_kernel's per-workgroup
+// partials itself (fold: no absmax_finish launch); elsewhere the y-mixing GEMM kernels read the finished values.
+struct WMaxRef { const float* src; int n; float* out; };
+inline WMaxRef wmax_ref(const float* saved, size_t wmax, int k, bool fold) {
+  float* base = const_cast<float*>(saved) + wmax;
+  return fold ? WMaxRef{base + 8 + (size_t)k * 64, 64, base + k} : WMaxRef{base + k, 0, nullptr};
+}
+
 struct Packer {
   PackList L;
   int n = 0;
   void add(const float* src, int ld_k, int ld_j, int K, int Nout, float* dst, int k_src = -1, int n_src = -1, int fmt = 0,
-           const float* maxabs = nullptr, float* exp_dst = nullptr) {
-    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout, k_src < 0 ? K : k_src, n_src < 0 ? Nout : n_src, fmt, maxabs, exp_dst};
+           const float* maxabs = nullptr, float* exp_dst = nullptr, int maxabs_n = 0, float* maxabs_out = nullptr) {
+    L.d[n++] = PackDesc{src, dst, ld_k, ld_j, K, Nout, k_src < 0 ? K : k_src, n_src < 0 ? Nout : n_src, fmt, maxabs_n, maxabs, exp_dst, maxabs_out};
   }
   hipError_t run(hipStream_t st) {
     if (n == 0) return hipSuccess;
@@ -520,14 +529,14 @@ hipError_t h2_from_f32(const H2FromP& f, hipStream_t st) {
 // out[0..3] = max |.| of four tensors; part: 4 * ABSMAX_BLOCKS floats of scratch, or null (one workgroup per tensor: slower)
 constexpr int ABSMAX_BLOCKS = 64;
 hipError_t absmax4(const float* a, size_t na, const float* b, size_t nb, const float* c, size_t nc, const float* d_, size_t nd,
-                   float* out, float* part, hipStream_t st) {
+                   float* out, float* part, hipStream_t st, bool finish = true) {
   AbsMaxList L;
   memset(&L, 0, sizeof(L));
   L.src[0] = a; L.n[0] = na; L.src[1] = b; L.n[1] = nb; L.src[2] = c; L.n[2] = nc; L.src[3] = d_; L.n[3] = nd;
   L.out = out; L.part = part;
   hipLaunchKernelGGL(absmax_kernel, dim3(part ? ABSMAX_BLOCKS : 1, 4), dim3(256), 0, st, L);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || !part) return e;
+  if (e != hipSuccess || !part || !finish) return e;        // !finish: the consumer (pack_h2_weight) combines the partials itself
   hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)part, ABSMAX_BLOCKS, out);
   return hipGetLastError();
 }
@@ -713,19 +722,22 @@ int pack_forward_weights(const macx_opts* o, const macx_shapes* s, const macx_pa
     if (h2_mode() && (units & U_READ)) {
       // per-matrix maxima -> weight exponents (plain weights) and the bound of the question-mixed tile (W1a, W1b)
       const size_t dd_ = (size_t)d * d;
+      static_assert(ABSMAX_BLOCKS == 64, "wmax_ref's partial layout");
       CK(absmax4(P->projX_W, dd_, P->memKbProj2_W, dd_, P->memKbProj_W, dd_, P->memKbProj_W + dd_, dd_, saved + L.wmax,
-                 saved + L.wmax + 8, st));
+                 saved + L.wmax + 8, st, !use_chain(d, s->N)));
     }
+    const bool fold = h2_mode() && use_chain(d, s->N);
+    auto mx = [&](int k) { return wmax_ref(saved, L.wmax, k, fold); };
     if (units & U_READ) {
-      pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);
+      pk.add(P->projX_W, d, 1, d, d, saved + L.wx_p, -1, -1, wfmt_plain(), mx(0).src, nullptr, mx(0).n, mx(0).out);
       if (use_chain(d, s->N)) {      // the chain kernel scales the A side by y: W1a and W1b are plain H2 weights there
-        pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, 3, saved + L.wmax + 2);
-        pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, 3, saved + L.wmax + 3);
+        pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, 3, mx(2).src, nullptr, mx(2).n, mx(2).out);
+        pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, 3, mx(3).src, nullptr, mx(3).n, mx(3).out);
       } else {
         pk.add(P->memKbProj_W, d, 1, d, d, saved + L.w1a_p, -1, -1, wfmt_ymix());
         pk.add(P->memKbProj_W + (size_t)d * d, d, 1, d, d, saved + L.w1b_p, -1, -1, wfmt_ymix());
       }
-      pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);
+      pk.add(P->memKbProj2_W, d, 1, d, d, saved + L.w2_p, -1, -1, wfmt_plain(), mx(1).src, nullptr, mx(1).n, mx(1).out);
       pk.add(P->projY_W, d, 1, d, d, saved + L.wy_p);
     }
     if (units & U_WRITE) {
@@ -770,9 +782,16 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
   // initial state (mac_cell.py:546-553), both tensors in one launch
   float* controls = saved + L.seg[MACX_SEG_CONTROLS];
   float* memories = saved + L.seg[MACX_SEG_MEMORIES];
-  hipLaunchKernelGGL(init_states_kernel, dim3(64), dim3(256), 0, st, o->init_ctrl, P->initCtrl, controls, o->init_mem, P->initMem, memories,
-                     in->vecQuestions, B, d);
-  CK(hipGetLastError());
+  // ... and step 0's dropped memory (mac_cell.py:214-217, ops.py:679) where macx_cell_step would otherwise launch drop2 for it
+  // (md_fused there: the whole cell without a gate; later steps get theirs from the write unit's linear)
+  {
+    const bool md0 = !o->write_gate;
+    const DropSpec dm = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp, SITE_MEM_VAR, 0) : make_drop(dp->keep_memory, dp, SITE_MEM, 0);
+    const DropSpec dry = make_drop(dp->keep_read, dp, SITE_READ_MEM, 0);
+    hipLaunchKernelGGL(init_states_kernel, dim3(64), dim3(256), 0, st, o->init_ctrl, P->initCtrl, controls, o->init_mem, P->initMem, memories,
+                       in->vecQuestions, B, d, md0 ? saved + L.md : nullptr, (uint32_t)s->b0, dm, dry, dlog_of(s));
+    CK(hipGetLastError());
+  }
 
   // control inputs (mac_cell.py:442-448).  qInput is step-invariant; qInput{i} is batched over steps.
   {
@@ -861,8 +880,8 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   const DropSpec dm = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp, SITE_MEM_VAR, 0)
                                                     : make_drop(dp->keep_memory, dp, SITE_MEM, i);
   const DropSpec dry = make_drop(dp->keep_read, dp, SITE_READ_MEM, i);
-  // (from step 1 on, the previous step's write unit left this step's dropped memory behind: md_fused below)
-  if (!(md_fused && i > 0)) {
+  // (md_fused: macx_cell_begin left step 0's dropped memory behind, the previous step's write unit every later one's)
+  if (!md_fused) {
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md, dlog_of(s));
     CK(hipGetLastError());
   }
@@ -1073,16 +1092,18 @@ int add_bwd_packs(Packer& pk, const macx_opts* o, const macx_shapes* s, const ma
   const int win = write_in_dim(o, d);
   const int nU = o->control_input_unshared ? p : 1;
 
+    const bool fold = h2_mode() && use_chain(d, s->N);        // (these packs ride the forward pass's pack launch: same rule as there)
+    auto mx = [&](int k) { return wmax_ref(saved, L.wmax, k, fold); };
     if (units & U_READ) {
-      pk.add(P->projX_W, 1, d, d, d, wT + W.wxT_p, -1, -1, wfmt_plain(), saved + L.wmax + 0);            // Wx^T
+      pk.add(P->projX_W, 1, d, d, d, wT + W.wxT_p, -1, -1, wfmt_plain(), mx(0).src, nullptr, mx(0).n, mx(0).out);            // Wx^T
       if (use_chain(d, s->N)) {      // the chain kernel applies y to the accumulators: plain H2 weights
-        pk.add(P->memKbProj_W, 1, d, d, d, wT + W.w1aT_p, -1, -1, 3, saved + L.wmax + 2);       // W1a^T
-        pk.add(P->memKbProj_W + dd, 1, d, d, d, wT + W.w1bT_p, -1, -1, 3, saved + L.wmax + 3);  // W1b^T
+        pk.add(P->memKbProj_W, 1, d, d, d, wT + W.w1aT_p, -1, -1, 3, mx(2).src, nullptr, mx(2).n, mx(2).out);       // W1a^T
+        pk.add(P->memKbProj_W + dd, 1, d, d, d, wT + W.w1bT_p, -1, -1, 3, mx(3).src, nullptr, mx(3).n, mx(3).out);  // W1b^T
       } else {
         pk.add(P->memKbProj_W, 1, d, d, d, wT + W.w1aT_p, -1, -1, wfmt_ymix());       // W1a^T
         pk.add(P->memKbProj_W + dd, 1, d, d, d, wT + W.w1bT_p, -1, -1, wfmt_ymix());  // W1b^T
       }
-      pk.add(P->memKbProj2_W, 1, d, d, d, wT + W.w2T_p, -1, -1, wfmt_plain(), saved + L.wmax + 1);       // W2^T
+      pk.add(P->memKbProj2_W, 1, d, d, d, wT + W.w2T_p, -1, -1, wfmt_plain(), mx(1).src, nullptr, mx(1).n, mx(1).out);       // W2^T
       pk.add(P->projY_W, 1, d, d, d, wT + W.wyT);              // Wy^T
     }
     if (units & U_WRITE) {
@@ -1575,7 +1596,9 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
       LinP li = lin_basic(ws + W.dcI, d, d, B, wT + W.wqUT, nullptr, d, MACX_ACT_NON, ws + W.dt_part, d);
       li.seg[0].zstride = Bd; li.zW = dd; li.zout = Bd;
       CK(small_linear_launch(li, p, st));
-      hipLaunchKernelGGL(sum_parts_kernel, dim3(256), dim3(256), 0, st, (const float*)(ws + W.dt_part), p, Bd, ws + W.dt);
+      // ... which also leaves du = dt * act'(t) (the mul_actgrad launch of the shared-weights path below)
+      hipLaunchKernelGGL(sum_parts_kernel, dim3(256), dim3(256), 0, st, (const float*)(ws + W.dt_part), p, Bd, ws + W.dt, ctrl_t,
+                         (int)o->control_input_act, ws + W.du);
       CK(hipGetLastError());
     }
     // the p weight gradients ctrl_t^T dcI_i share A: one batched launch (B rows -> a single split, no slabs)
@@ -1599,11 +1622,17 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     CKI(wgrad_impl(ctrl_t, d, dcI_sum, d, B, d, d, GP->qInputU_W, ws + W.small_slab, st));
     CK(rs.add(dcI_sum, B, d, d, GP->qInputU_b, st));
   }
-  hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dt), ctrl_t, o->control_input_act, Bd,
-                     ws + W.du);
-  CK(hipGetLastError());
+  if (!o->control_input_unshared) {
+    hipLaunchKernelGGL(mul_actgrad_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + W.dt), ctrl_t, o->control_input_act, Bd,
+                       ws + W.du);
+    CK(hipGetLastError());
+  }
+  // dvecQ = du Wq^T (+ dL/d(initial state) where a state is initialised from the question vector, mac_cell.py:496-505: the first of
+  // them rides this launch's epilogue instead of an axpy of its own)
+  const float* q_add = o->init_ctrl == MACX_INIT_Q ? DC : (o->init_mem == MACX_INIT_Q ? DM : nullptr);
   {
     LinP l = lin_basic(ws + W.du, d, d, B, wT + W.wqT, nullptr, d, MACX_ACT_NON, GI->vecQuestions, d);
+    if (q_add) { l.addend = q_add; l.ld_add = d; }
     CK(small_linear_launch(l, 1, st));
   }
   CKI(wb.add(in->vecQuestions, d, ws + W.du, d, B, d, d, GP->qInput_W, st));
@@ -1611,9 +1640,8 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
 
   // ---- initial state (mac_cell.py:496-505)
   if (o->init_mem == MACX_INIT_PRM) CK(rs.add(DM, B, d, d, GP->initMem, st));
-  else if (o->init_mem == MACX_INIT_Q) CK(axpy(DM, Bd, GI->vecQuestions, st));
+  else if (o->init_mem == MACX_INIT_Q && q_add != DM) CK(axpy(DM, Bd, GI->vecQuestions, st));
   if (o->init_ctrl == MACX_INIT_PRM) CK(rs.add(DC, B, d, d, GP->initCtrl, st));
-  else if (o->init_ctrl == MACX_INIT_Q) CK(axpy(DC, Bd, GI->vecQuestions, st));
 
   }   // U_ALL
   // ---- weight gradients of the [B,d] linears, one contraction over all p*B rows each

@@ -31,15 +31,16 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int ld_k, int 
 //   fmt 1: dst[kt][plane][j][32] bf16 -- the exact 3-way bf16 split of W (macx_gemm6.hip.h, B_PLAIN); K*Nout*3/2 floats
 //   fmt 2: dst[kt][j][32] fp32 k-major tiles (macx_gemm6.hip.h, B_YMIX_*: mixed in fp32, split while staging)
 //   fmt 3: H2 weight planes dst[kt][plane][g][Nout] x 16 B fp16 + the matrix exponent (macx_h2.hip.h, macx_gemm_h2.hip.h)
-struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; int fmt; const float* maxabs; float* exp_dst; };   // zero fill for k >= k_src or j >= n_src; exp_dst: where format 3 leaves its exponent (null: behind the planes)
-constexpr int PACK_MAX = 56;       // 56 x 64 B of kernel arguments
+struct PackDesc { const float* src; float* dst; int ld_k, ld_j, K, Nout; int k_src, n_src; int fmt; int maxabs_n; const float* maxabs; float* exp_dst; float* maxabs_out; };      // 72 bytes   // zero fill for k >= k_src or j >= n_src; exp_dst: where format 3 leaves its exponent (null: behind the planes)
+constexpr int PACK_MAX = 56;       // 56 x 72 B of kernel arguments (the limit is 4 KB)
+static_assert(sizeof(PackDesc) * PACK_MAX <= 4096, "PackList travels by value as a kernel argument");
 struct PackList { PackDesc d[PACK_MAX]; };
 __global__ void pack_weights_kernel(PackList L) {
   const PackDesc q = L.d[blockIdx.y];
   const size_t total = (size_t)q.K * q.Nout;
   if (q.fmt == 3) {
     pack_h2_weight(q.src, q.ld_k, q.ld_j, q.K, q.Nout, q.k_src, q.n_src, q.maxabs, q.dst,
-                   (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, q.exp_dst);
+                   (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, q.exp_dst, q.maxabs_n, q.maxabs_out);
     return;
   }
   if (q.fmt == 0) {
@@ -382,13 +383,24 @@ __global__ void drop2_kernel(const float* __restrict__ x, int rows, int d, uint3
 
 // initial state (mac_cell.py:496-505): PRM -> tile the [d] variable, ZERO, Q -> copy vecQuestions
 // ... both states of a run in one launch
+// ... and, with md != null, step 0's dropped memory md = m_0 * f1 * f2 (mac_cell.py:214-217 then ops.py:679: what drop2_kernel would
+// write in a launch of its own in front of the first projY linear); dl: the logical width of a zero-padded cell, 0 = d
 __global__ void init_states_kernel(int mode_c, const float* __restrict__ prm_c, float* out_c, int mode_m, const float* __restrict__ prm_m,
-                                   float* out_m, const float* __restrict__ vecQ, int rows, int d) {
+                                   float* out_m, const float* __restrict__ vecQ, int rows, int d, float* md = nullptr, uint32_t row0 = 0,
+                                   DropSpec d1 = DropSpec{}, DropSpec d2 = DropSpec{}, int dl = 0) {
   const int n = rows * d;
+  if (md) { d1 = drop_resolve(d1); d2 = drop_resolve(d2); }
+  if (dl <= 0) dl = d;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float q = (mode_c == 2 || mode_m == 2) ? vecQ[i] : 0.f;
     out_c[i] = mode_c == 0 ? prm_c[i % d] : (mode_c == 2 ? q : 0.f);
-    out_m[i] = mode_m == 0 ? prm_m[i % d] : (mode_m == 2 ? q : 0.f);
+    const float m = mode_m == 0 ? prm_m[i % d] : (mode_m == 2 ? q : 0.f);
+    out_m[i] = m;
+    if (md) {
+      const int r = i / d, j = i - r * d;
+      const uint32_t idx = (row0 + (uint32_t)r) * (uint32_t)dl + (uint32_t)j;
+      md[i] = drop_apply(drop_apply(m, idx, d1), idx, d2);
+    }
   }
 }
 
@@ -1468,11 +1480,14 @@ __global__ __launch_bounds__(256) void opt_apply_kernel(OptP q) {
 }
 
 // dy[b][k] = sum over parts   (S_b kernel leaves 2*d/128 partials)
-__global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, size_t n, float* dst) {
+// ... optionally also dst2 = sum * act'(o) (o: the activation's OUTPUT): the mul_actgrad launch that would follow
+__global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, size_t n, float* dst, const float* __restrict__ o = nullptr,
+                                 int act = 0, float* dst2 = nullptr) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float s = part[i];
     for (int q = 1; q < nparts; ++q) s += part[(size_t)q * n + i];
     dst[i] = s;
+    if (dst2) dst2[i] = s * act_grad_from_out(act, o[i]);
   }
 }
 

@@ -161,6 +161,38 @@ class OverlappedBuckets(GradBucket):
         return self.flat
 
 
+class TwoPhaseStep:
+    """The host side of a data-parallel step whose backward pass is cut at the phase-1 seam (macx_cell_backward_phase): run part A
+    (forward + backward phase 1), hand the finished front of the flat gradient buffer to the bucket -- the early all-reduce starts on the
+    side stream -- run part B (backward phase 2) under it, then the late bucket and the join.  What the parts ARE is the subclass's
+    business: graph.CapturedDPTrainStep replays two captured HIP graphs (2 replays + 2 collectives per step instead of ~125 launches);
+    tests/test_dp_gloo.py drives this class with stand-in parts on CPU.  The bucket is driven exactly as the cell's autograd node
+    drives it in the eager step (begin_step -> phase-1 hook -> allreduce_), so both give the same bits."""
+
+    def __init__(self, params, bucket, shard, global_batch):
+        self.params, self.bucket = params, bucket
+        self.shard, self.global_batch = int(shard), int(global_batch)
+
+    def run_part_a(self):          # forward + backward phase 1; returns {field: gradient view of the flat buffer}
+        raise NotImplementedError
+
+    def run_part_b(self):          # backward phase 2
+        raise NotImplementedError
+
+    def exchange_step(self):
+        b = self.bucket
+        if hasattr(b, "begin_step"):
+            b.begin_step(self.shard, self.global_batch)
+        grads = self.run_part_a()
+        for f, g in grads.items():                       # (views of the flat buffer at the bucket's offsets: its zero-copy path)
+            getattr(self.params, f).grad = g
+        hook = getattr(self.params, "after_backward_phase1", None)
+        if hook is not None:
+            hook(b.flat)                                 # early bucket: scale + all-reduce (side stream on the GPU)
+        self.run_part_b()
+        return b.allreduce_(self.shard, self.global_batch)      # late bucket (or the one bucket), join; releases the flat buffer
+
+
 class TowerBuckets:
     """Data parallelism for the WHOLE tower the reference builds per GPU (model.py:775-826: embeddings, question encoder, stem,
     MAC cell, output unit + classifier -- 57 MB of fp32 gradients at p = 12), two buckets over ONE flat buffer:

@@ -34,6 +34,7 @@ import warnings
 import torch
 
 from .cell import MACCell
+from .dp import TwoPhaseStep
 from .options import get
 
 
@@ -247,4 +248,129 @@ class CapturedTrainStep:
             self.graph.replay()
         else:
             self.memory = self._eager()
+        return self.memory
+
+
+class CapturedDPTrainStep(TwoPhaseStep):
+    """One DATA-PARALLEL training step of the cell as TWO graph replays with the gradient exchange between and behind them.
+
+    The eager data-parallel step is ~125 host-issued launches per rank; at 8 questions per GPU that is more host work than GPU work
+    and inherits the host's launch rate (DESIGN: boxes differ 7x).  The exchange itself cannot sit inside a graph (RCCL calls are
+    issued by torch.distributed), but the backward pass has exactly one seam where it is needed: after phase 1
+    (macx_cell_backward_phase) every gradient except the read unit's deferred contractions is final.  So:
+
+        graph A = forward + backward phase 1            replay
+        early bucket: scale + all-reduce                side stream, in flight under graph B     (bucket._phase1)
+        graph B = backward phase 2                      replay
+        late bucket: scale + all-reduce, join           (bucket.allreduce_)
+
+    -- 2 replays + 2 collectives per step instead of ~125 launches.  `bucket` is a macx.dp.OverlappedBuckets (two buckets; RCCL) or a
+    macx.dp.GradBucket built over params (one all-reduce behind graph B); the step drives it exactly as the cell's autograd node
+    drives it in the eager step, so both produce the same bits (tests/test_gpu_dp.py, two ranks sharing the GPU).  No autograd is
+    involved: the two phases are the C-ABI calls themselves, captured on static buffers; parameters' .grad are views of the flat
+    gradient buffer.  Fresh dropout masks per step through the mask word, as CapturedTrainStep.
+
+        bucket = macx.dp.OverlappedBuckets(params)
+        step = macx.CapturedDPTrainStep(cfg, params, bucket, B=shard, S=50, N=196, global_batch=64, seed=1234, b0=lo)
+        step.load(vecQ[lo:hi], words[lo:hi], lengths[lo:hi], kb[lo:hi], d_memory[lo:hi])
+        step.step(iteration=it)              # params' .grad = the all-reduced full-batch gradient; step.memory: [shard, d]
+    """
+
+    def __init__(self, config, params, bucket, B, S, N, global_batch, seed=0, b0=0, device=None, netLength=None, warmup=2, capture=True):
+        dev = torch.device(device) if device is not None else params.tensors()[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("CapturedDPTrainStep needs the HIP device: the MAC cell has no CPU path")
+        if bucket.flat.data_ptr() != params.grad_buffer().data_ptr():
+            raise ValueError("the bucket must be built over params' own flat gradient buffer (OverlappedBuckets(params) / "
+                             "GradBucket(params.tensors(), params=params))")
+        d = int(get(config, "memDim"))
+        super().__init__(params, bucket, B, global_batch)
+        self.config = config
+        self.seed, self.b0 = int(seed), int(b0)
+        self.netLength = int(netLength if netLength is not None else get(config, "netLength"))
+        self.vecQuestions = torch.zeros(B, d, device=dev)
+        self.words = torch.zeros(B, S, d, device=dev)
+        self.lengths = torch.full((B,), S, dtype=torch.int32, device=dev)
+        self.knowledgeBase = torch.zeros(B, N, d, device=dev)
+        self.d_memory = torch.zeros(B, d, device=dev)
+        self.mask_word = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.captured = False
+        for t in params.tensors():
+            t.grad = None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # (warm-up outside capture: code objects, LDS attributes, allocator)
+            for _ in range(max(1, warmup)):
+                self._phase_a()
+                self._phase_b()
+                params.release_grad_buffer()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        if capture:
+            with torch.cuda.graph(self.graph_a):
+                self._phase_a()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                self._phase_b()
+            self.captured = True
+        params.release_grad_buffer()
+
+    def _phase_a(self):
+        """forward + backward phase 1 on the current stream; leaves self._run / self._args for phase 2"""
+        from .cell import _Run
+        with torch.no_grad():
+            cell = MACCell(vecQuestions=self.vecQuestions, questionWords=self.words, questionCntxWords=self.words,
+                           questionLengths=self.lengths, knowledgeBase=self.knowledgeBase,
+                           memoryDropout=float(get(self.config, "memoryDropout")), readDropout=float(get(self.config, "readDropout")),
+                           writeDropout=float(get(self.config, "writeDropout")), batchSize=self.shard, train=True,
+                           config=self.config, params=self.params, netLength=self.netLength, seed=self.seed, b0=self.b0,
+                           mask_word=self.mask_word)
+            run = _Run(cell, True)
+            run.forward()
+            args, grads, gi, flat, keep = run.backward_begin(None, self.d_memory)
+            if flat.data_ptr() != self.bucket.flat.data_ptr():
+                raise RuntimeError("the backward pass did not receive the parameters' flat gradient buffer (is a gradient still attached?)")
+            run.backward_phase(args, 1)
+        p = run.shapes.p
+        self.memory = run.segment("memories", (p + 1, run.shapes.B, run.shapes.d))[p]
+        self.d_vecQuestions, self.d_words, self.d_knowledgeBase = gi
+        self._grads = grads
+        self._run, self._args, self._keep = run, args, (keep, cell)
+
+    def _phase_b(self):
+        with torch.no_grad():
+            self._run.backward_phase(self._args, 2)
+
+    def set_mask_word(self, word):
+        word &= 0xFFFFFFFF
+        self.mask_word.fill_(word - (1 << 32) if word >= (1 << 31) else word)
+
+    def load(self, vecQuestions, words, lengths, knowledgeBase, d_memory):
+        with torch.no_grad():
+            self.vecQuestions.copy_(vecQuestions)
+            self.words.copy_(words)
+            self.lengths.copy_(lengths)
+            self.knowledgeBase.copy_(knowledgeBase)
+            self.d_memory.copy_(d_memory)
+
+    def run_part_a(self):
+        if self.captured:
+            self.graph_a.replay()
+        else:
+            for t in self.params.tensors():
+                t.grad = None
+            self._phase_a()
+        return self._grads
+
+    def run_part_b(self):
+        if self.captured:
+            self.graph_b.replay()
+        else:
+            self._phase_b()
+
+    def step(self, iteration=None):
+        """one data-parallel step; afterwards every parameter's .grad is its view of the all-reduced flat buffer"""
+        if iteration is not None:
+            self.set_mask_word(mix32(int(iteration)))
+        self.exchange_step()
         return self.memory

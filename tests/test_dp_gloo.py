@@ -111,3 +111,67 @@ def test_overlapped_buckets_two_ranks():
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_overlap_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["ok"] and ret["overlapped"] == 1
+
+
+def _two_phase_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import macx
+    from oracle import mac_oracle as mo
+    cfg = mo.flag_file_config("args", netLength=3, memDim=128, ctrlDim=128, attDim=128)
+    params = macx.MACCellParams(cfg, 3)
+    bucket = macx.dp.OverlappedBuckets(params)
+    flat = params.grad_buffer()
+    shard, glob = (2, 5) if rank == 0 else (3, 5)
+    g = torch.Generator().manual_seed(100 + rank)
+    values = torch.randn(flat.numel(), generator=g)               # this rank's "gradients"
+
+    def views():
+        out, off = {}, 0
+        for f, t in zip(params.fields, params.tensors()):
+            out[f] = flat[off: off + t.numel()].view_as(t)
+            off += (t.numel() + 3) & ~3
+        return out
+
+    # the eager data-parallel step, as the cell's autograd node drives the bucket: phase 1 fills the front, hook, phase 2 the rest
+    bucket.begin_step(shard, glob)
+    for f, v in views().items():
+        getattr(params, f).grad = v
+    flat.zero_()
+    flat[: bucket.early] = values[: bucket.early]
+    params.after_backward_phase1(flat)
+    flat[bucket.early:] = values[bucket.early:]
+    want = bucket.allreduce_(shard, glob).clone()
+
+    class Parts(macx.dp.TwoPhaseStep):          # the two "graph replays" as stand-ins: they write what the phases would
+        def run_part_a(self):
+            flat.zero_()
+            flat[: bucket.early] = values[: bucket.early]
+            return views()
+
+        def run_part_b(self):
+            flat[bucket.early:] = values[bucket.early:]
+
+    for t in params.tensors():
+        t.grad = None
+    step = Parts(params, bucket, shard, glob)
+    same = []
+    for _ in range(3):
+        got = step.exchange_step()
+        same.append(bool(torch.equal(got, want)) and all(t.grad is not None and t.grad.data_ptr() >= flat.data_ptr() for t in params.tensors()))
+    if rank == 0:
+        ret["same"], ret["overlapped"] = same, bucket.overlapped_steps
+    dist.destroy_process_group()
+
+
+def test_two_phase_step_equals_the_eager_dp_step_bit_for_bit():
+    """macx.dp.TwoPhaseStep (the host side of graph.CapturedDPTrainStep: part A, early bucket from the phase-1 hook, part B, late
+    bucket) leaves the flat buffer bit for bit as the eager sequence does, step after step, with the early bucket in flight each time."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_two_phase_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert list(ret["same"]) == [True, True, True]
+    assert ret["overlapped"] == 4
