@@ -15,10 +15,10 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 dev = torch.device("cuda:0")
 L = macx._lib.lib()
 step, params, kbd, bl = bench.make_step(macx, dev, None, 1, 0, 64, 12, 1234)
-for i in range(3):
+macx.options.SESSION_TUNE["phase_mask"] = mask      # (every step freezes a new cell: it picks the table up) -- the warm-up steps too,
+for i in range(3):                                  # so that a per-kernel mean of the trace is the masked kernel's
     step(i)
 torch.cuda.synchronize()
-L.macx_opts.tune[MACX_TUNE_PHASE_MASK]
 for i in range(steps):
     step(3 + i)
 torch.cuda.synchronize()
