@@ -821,7 +821,7 @@ namespace {
 // macx_cell_forward_chain_time: an event pair that receives the start / stop timestamps of every forward chain launch of the passes
 // this thread runs while `on`
 struct ChainProbe { hipEvent_t ev[2 * 64]; int n; bool on; };
-inline ChainProbe& chain_probe() { static thread_local ChainProbe p = {}; return p; }
+inline ChainProbe* chain_probe() { static thread_local ChainProbe p = {}; return &p; }
 
 int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
                    const macx_inputs* in, float* saved, size_t saved_floats, int keep, int step, int units, void* stream) {
@@ -905,7 +905,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     if (use_chain(d, s->N)) {
       // KB -> X -> H1 -> I2 -> logits in one launch (macx_chain_h2.hip.h)
       const ChainFwdP c = make_chain_fwd(o, s, dp, P, in, saved, L, keep, i, i);
-      ChainProbe& cp = chain_probe();
+      ChainProbe& cp = *chain_probe();
       if (cp.on && cp.n < 64) {      // the kernel's own start / stop timestamps into the probe's event pair
         CK(chain_fwd_launch(c, st, cp.ev[2 * cp.n], cp.ev[2 * cp.n + 1]));
         ++cp.n;
@@ -2756,7 +2756,7 @@ int macx_cell_forward_chain_time(const macx_opts* o, const macx_shapes* s, const
   CKI(check_impl(o, s));
   if (!ms_out) return MACX_EINVAL;
   if (!use_chain(s->d, s->N)) return MACX_EUNSUPPORTED;
-  ChainProbe& cp = chain_probe();
+  ChainProbe& cp = *chain_probe();
   if (cp.on) return MACX_EINVAL;
   const int ne = 2 * (s->p < 64 ? s->p : 64);
   for (int i = 0; i < ne; ++i) CK(hipEventCreate(&cp.ev[i]));
