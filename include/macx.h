@@ -97,7 +97,11 @@ enum {
   MACX_TUNE_WGRAD_PIPE = 10,  /* wgrad_h2_kernel<2,2>: 0 a stage requested one iteration ahead; 1 a buffer's halves re-requested
                                  inside the iteration; 2 = 1 + dW2 and dWx as ONE launch; 3 (default) = 2 with half the splits  */
   MACX_TUNE_SB_CONT = 13,     /* sb_h2w_kernel: 1 (default) one stage stream over all steps; 0 drained and re-primed per step    */
-  MACX_TUNE_DKB_UNI = 14      /* merged dKB launch: 1 (default) one fold of the block accumulator per step; 0 per 128-wide K block */
+  MACX_TUNE_DKB_UNI = 14,     /* merged dKB launch: 1 (default) one fold of the block accumulator per step; 0 per 128-wide K block */
+  MACX_TUNE_PRE_FILL = 3,     /* stage 0 of the read unit's forward chain (dropout(KB) -> fp16 planes, keep bits) for step i + 1 on the CUs
+                                 chain_fwd's launch of step i leaves idle (training runs of macx_cell_forward, d = 512): 1 (default) | 0 */
+  MACX_TUNE_DKB_FILL = 15     /* dKB on the CUs a d = 512 chain_bwd launch leaves idle (196 tiles on 256 CUs at B = 64): jobs per
+                                 filler workgroup, default 3; 0: all of dKB in the merged launch after the last step            */
 };
 
 typedef struct macx_shapes {

@@ -28,8 +28,8 @@ class MacxOpts(C.Structure):
 
 # macx_opts.tune keys (include/macx.h MACX_TUNE_*): the per-call A/B hooks and the profiling tools' phase mask.  A value v travels
 # as v + 1; 0 = the shipped default of that key.
-TUNE = {"native_waves": 0, "phase_mask": 1, "row_tiles": 2, "chain": 4, "sb_defer": 5, "chain_kv": 7, "sb_wide": 8,
-        "wgrad_pipe": 10, "sb_cont": 13, "dkb_uni": 14}
+TUNE = {"native_waves": 0, "phase_mask": 1, "row_tiles": 2, "pre_fill": 3, "chain": 4, "sb_defer": 5, "chain_kv": 7, "sb_wide": 8,
+        "wgrad_pipe": 10, "sb_cont": 13, "dkb_uni": 14, "dkb_fill": 15}
 
 
 def set_tune(opts, key, value):

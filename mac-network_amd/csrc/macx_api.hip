@@ -403,8 +403,10 @@ int check_impl(const macx_opts* o, const macx_shapes* s) {
 
 // the parameter block of the read unit's forward chain kernel for step `i`; `ob`: the step whose X / H1 / I2 / KBd / keep-bit
 // buffers receive the outputs (= i in a run; the timing hook rotates it)
+// pre: bit 0 -- stage 0 of this step was done by the previous step's launch (ChainFwdP::mode 2); bit 1 -- this launch's fillers do
+// stage 0 of step i + 1 (ChainPreP).  Both only where macx_cell_forward sequences the steps itself.
 ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
-                         const macx_inputs* in, float* saved, const SavedLayout& L, int keep, int i, int ob) {
+                         const macx_inputs* in, float* saved, const SavedLayout& L, int keep, int i, int ob, int pre = 0) {
   const int B = s->B, N = s->N, d = s->d;
   const int R = B * N;
   const size_t Bd = (size_t)B * d, dd_ = (size_t)d * d;
@@ -445,6 +447,15 @@ ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dr
     c.I2 = h2_view(saved + L.I2 + (size_t)ob * L.act_stride, R, d);
   }
   c.logits = saved + L.logit_part;
+  if (rdrop && c.mode == 0 && (pre & 1)) c.mode = 2;
+  if (rdrop && (pre & 2)) {
+    c.pre.nfill = pre_fill_count(d, (size_t)R, device_cu_count());
+    c.pre.key1 = make_drop(dp->keep_read, dp, SITE_READ_KB, i + 1).key;
+    c.pre.key2 = make_drop(dp->keep_read, dp, SITE_READ_ATT, i + 1).key;
+    c.pre.bits1 = reinterpret_cast<uint8_t*>(saved + L.kb_bits + (size_t)(ob + 1) * L.bits_stride);
+    c.pre.bytes2 = reinterpret_cast<uint8_t*>(saved + L.att_bits + (size_t)(ob + 1) * L.bits_stride);
+    c.pre.KBd = h2_view(saved + L.KBd + (size_t)(ob + 1) * L.act_stride, R, d);
+  }
   return c;
 }
 
@@ -824,7 +835,7 @@ struct ChainProbe { hipEvent_t ev[2 * 64]; int n; bool on; };
 inline ChainProbe* chain_probe() { static thread_local ChainProbe p = {}; return &p; }
 
 int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
-                   const macx_inputs* in, float* saved, size_t saved_floats, int keep, int step, int units, void* stream) {
+                   const macx_inputs* in, float* saved, size_t saved_floats, int keep, int step, int units, void* stream, int pre = 0) {
   CKI(check_impl(o, s));
   if (!dp || !P || !in || !saved) return MACX_EINVAL;
   if (step < 0 || step >= s->p) return MACX_EINVAL;
@@ -904,7 +915,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     uint8_t* att_bytes = rdrop ? reinterpret_cast<uint8_t*>(att_bits) : nullptr;
     if (use_chain(d, s->N)) {
       // KB -> X -> H1 -> I2 -> logits in one launch (macx_chain_h2.hip.h)
-      const ChainFwdP c = make_chain_fwd(o, s, dp, P, in, saved, L, keep, i, i);
+      const ChainFwdP c = make_chain_fwd(o, s, dp, P, in, saved, L, keep, i, i, pre);
       ChainProbe& cp = *chain_probe();
       if (cp.on && cp.n < 64) {      // the kernel's own start / stop timestamps into the probe's event pair
         CK(chain_fwd_launch(c, st, cp.ev[2 * cp.n], cp.ev[2 * cp.n + 1]));
@@ -1039,8 +1050,6 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
       l.out_drop = saved + L.md + (size_t)(i + 1) * Bd; l.ld_od = d;
     }
     CK(small_linear_launch(l, 1, st));
-    if (o->write_gate) {      CK(small_linear_launch(l, 1, st));
-    }
     if (o->write_gate) {
       // z = sigmoid(control Wg + bg + gateBias); m = newMemory * z + memory * (1 - z)   (mac_cell.py:358-367)
       float* z = saved + L.seg[MACX_SEG_ATT_GATE] + (size_t)i * Bd;
@@ -1067,7 +1076,13 @@ int macx_cell_forward(const macx_opts* o, const macx_shapes* s, const macx_dropo
                       const macx_inputs* in, float* saved, size_t saved_floats, float* ws, size_t ws_floats,
                       int keep, void* stream) {
   CKI(macx_cell_begin(o, s, dp, P, in, saved, saved_floats, ws, ws_floats, keep, stream));
-  for (int i = 0; i < s->p; ++i) CKI(macx_cell_step(o, s, dp, P, in, saved, saved_floats, ws, ws_floats, keep, i, stream));
+  ModeScope ms(o);
+  // a training run's steps are sequenced here: stage 0 of the read unit's chain for step i + 1 (state-independent) rides the
+  // launch of step i on its idle CUs (ChainPreP).  The step-wise entry point makes no assumption about what ran before it.
+  const bool pre = keep && dp && dp->keep_read < 1.0f && h2_mode() && use_chain(s->d, s->N) &&
+                   pre_fill_count(s->d, (size_t)s->B * s->N, device_cu_count()) > 0;
+  for (int i = 0; i < s->p; ++i)
+    CKI(cell_step_impl(o, s, dp, P, in, saved, saved_floats, keep, i, U_ALL, stream, pre ? ((i > 0 ? 1 : 0) | (i + 1 < s->p ? 2 : 0)) : 0));
   return MACX_OK;
 }
 
@@ -1181,6 +1196,25 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   // the recurrent control unit differentiates through dL/dc_i inside iteration i; otherwise every step's dc / db_k partials are
   // reduced in one launch after the loop
   const bool dc_in_loop = (units & U_CONTROL) && o->control_feed_prev;
+  // dKB of step i + 1 rides chain_bwd's launch of step i on the CUs that launch leaves idle (ChainDkbP, macx_chain_api.hip.h); what
+  // the fillers leave out and step 0 run in chain_dkb_rest_launch after the last step.  Off (njobs = 0): the merged dKB launch.
+  const DkbFillPlan dkb_plan = (units == U_ALL && h2_mode() && use_chain(d, s->N))
+                                   ? dkb_fill_plan(d, (size_t)B * N, p, device_cu_count()) : DkbFillPlan{0, 0, 0};
+  ChainDkbP dkb_q;
+  memset(&dkb_q, 0, sizeof(dkb_q));
+  if (dkb_plan.njobs) {
+    const bool wd = dp->keep_write < 1.0f;
+    dkb_q.njobs = dkb_plan.njobs; dkb_q.nfill = dkb_plan.nfill; dkb_q.nskip = dkb_plan.nskip; dkb_q.p = p;
+    dkb_q.dX = reinterpret_cast<const char*>(ws + W.dX); dkb_q.dx_step = W.act_floats * sizeof(float);
+    dkb_q.WxT = ChainW{reinterpret_cast<const char*>(wT + W.wxT_p), reinterpret_cast<const int*>(wT + W.wxT_p) + dd};
+    dkb_q.bits = rdrop ? reinterpret_cast<const uint8_t*>(saved + L.kb_bits) : nullptr;
+    dkb_q.bits_step = L.bits_stride * sizeof(uint32_t);
+    dkb_q.inv_keep = rdrop ? 1.0f / dp->keep_read : 1.0f;
+    dkb_q.att = att_kb; dkb_q.att_step = (size_t)B * N;
+    dkb_q.dinfo = wd ? ws + W.dinfo : ws + W.dwin + d; dkb_q.ld_dinfo = wd ? d : win; dkb_q.dinfo_step = wd ? Bd : (size_t)B * win;
+    dkb_q.out = GI->knowledgeBase;
+    dkb_q.dbg = (kb_gemm_dbg() >> 22) & 31;
+  }
   for (int i = p - 1; i >= 0; --i) {
     const float* c_i = controls + (size_t)(i + 1) * Bd;
     const float* X = saved + L.X + (size_t)i * L.act_stride;
@@ -1310,6 +1344,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         c.W1aT = wref(W.w1aT_p); c.W1bT = wref(W.w1bT_p); c.y = y;
         c.dX = hdX; c.dbx_part = ws + W.dbx_part + (size_t)i * W.db_rows * d;
         if (W.sb_deferred) { c.X = hX; c.dy_part = ws + W.dyc_part; }
+        if (dkb_plan.njobs && i + 1 < p) { c.dkb = dkb_q; c.dkb.step = i + 1; }
         CK(chain_bwd_launch(c, st));
         if (W.chain_sums && (dc_in_loop || (W.sb_deferred && !W.dy_in_linear))) {
           // the per-tile partials of this step: dL/dc_i += read-unit part, db_k partials, dy_i (the next launch needs dy_i)
@@ -1351,8 +1386,11 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
         q.dbg = kb_gemm_dbg();
         CK(sb_h2_launch(q, st));
       }
-      // dKB = sum_i (dX_i Wx^T) * kbmask_i + att_i (x) dinfo_i: ONE launch over all steps after step 0
-      if (i == 0) {
+      // dKB = sum_i (dX_i Wx^T) * kbmask_i + att_i (x) dinfo_i: ONE launch over all steps after step 0 -- or, where chain_bwd's
+      // launches carried the products of steps p - 1 .. 1 on their idle CUs, the closing launch of that route
+      if (i == 0 && dkb_plan.njobs) {
+        CK(chain_dkb_rest_launch(dkb_q, B * N, N, d, st));
+      } else if (i == 0) {
         const int i0 = 0;
         g.A = h2_view(ws + W.dX + (size_t)i0 * W.act_floats, B * N, d); g.Wt = nullptr; g.Wt2 = nullptr; g.y = nullptr;
         g.Wh = reinterpret_cast<const char*>(wT + W.wxT_p); g.w_exp = reinterpret_cast<const int*>(wT + W.wxT_p) + dd;

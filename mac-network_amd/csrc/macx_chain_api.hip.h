@@ -11,9 +11,21 @@ struct ChainW {          // a weight matrix in pack format 3 (macx_h2.hip.h: pac
   const int* exp;        // device int: the stored fp16 are W * 2^exp
 };
 
+// Stage 0 (dropout(KB) -> H2, both keep-bit sites) of the NEXT step on the CUs a d = 512 chain_fwd launch leaves idle: it depends on
+// no state, only on the step's site keys.  The launch of step i carries `nfill` extra workgroups that walk the tiles of step i + 1
+// (tile f, f + nfill, ..); the launch of step i + 1 then starts from the finished planes (ChainFwdP::mode 2).
+struct ChainPreP {
+  int nfill;                // filler workgroups; 0: none
+  uint32_t key1, key2;      // the next step's site keys (thresholds and scales are the step's own: one keep probability per run)
+  uint8_t* bits1;           // its outputs, as ChainFwdP's
+  uint8_t* bytes2;
+  H2View KBd;
+};
+
 struct ChainFwdP {
   int M, N, d;              // rows (B*N), rows per question, width
-  int mode;                 // 0: KB -> X -> H1 -> I2 ; 1: X is read back (no read dropout: the projected KB is step-invariant)
+  int mode;                 // 0: KB -> X -> H1 -> I2 ; 1: X is read back (no read dropout: the projected KB is step-invariant);
+                            // 2: as 0 with stage 0 done by the previous launch's fillers (KBd and bytes2 are read)
   int dbg;                  // timing knobs: 1 stop after stage 0, 2 after stage 1, 4 after stage 2; dbg >> 3 = K-loop variant
   // stage 0
   const float* kb;          // [M][d] fp32, row-major
@@ -35,7 +47,38 @@ struct ChainFwdP {
   H2View H1;                // base null: not written (inference)
   H2View I2;                // base null: not written
   float* logits;            // [M] (without the bias b_k, which kb_attend adds)
+  ChainPreP pre;
 };
+
+// dKB = sum_i (dX_i Wx^T) * kbmask_i + att_i (x) dinfo_i on the CUs a chain_bwd launch leaves idle (d = 512, 64-row tiles: 196 tiles
+// on 256 CUs at B = 64).  The launch of step i carries `nfill` extra workgroups -- one per idle CU: a chain workgroup fills a CU's
+// LDS -- and each runs `njobs` JOBS: a job is one 64-row tile of step `step` = i + 1 (whose dX is complete): tile -> LDS, one K loop
+// against Wx^T, keep bits, + att (x) dinfo, read-modify-write of the caller's fp32 gradient.  nfill * njobs tiles are covered per
+// launch; the `nskip` tiles left out are a window that moves with the step (dkb_win0), so that what is left for the closing launch
+// (chain_dkb_rest_kernel: step 0 everywhere + the skipped (step, tile) pairs) is ~2 jobs per tile, spread over the whole chip.
+// Every (step, tile) pair is added exactly once, in a fixed order per tile (steps p - 1 .. 1 as launched, then the closing launch).
+struct ChainDkbP {
+  int njobs;                 // jobs per filler workgroup; 0: no fillers in this launch
+  int nfill;                 // filler workgroups
+  int step;                  // fillers: the step whose dX they multiply
+  int p;                     // steps of the run
+  int nskip;                 // tiles a filler launch leaves out
+  const char* dX; size_t dx_step;             // H2 tensor dX_0, bytes between steps
+  ChainW WxT;
+  const uint8_t* bits; size_t bits_step;      // keep bits of the knowledge-base dropout of step 0, row-major [M][d/8]; bytes between steps; null = keep all
+  float inv_keep;
+  const float* att; size_t att_step;          // [M] attention of step 0, floats between steps
+  const float* dinfo; int ld_dinfo; size_t dinfo_step;   // [B][ld_dinfo] of step 0
+  float* out;                // dKB [M][d] fp32
+  int dbg;                   // timing knobs (macx_opts.tune[MACX_TUNE_PHASE_MASK] bits 22-26; results are wrong except under 16): 1 no K loop,
+                             // 2 no read of the gradient (store only), 4 no tile load, 8 no row pass, 16 atomic adds instead of read-modify-write
+};
+// first tile of the window filler launches of step s leave out (s >= 1)
+__host__ __device__ inline int dkb_win0(int s, int nskip, int ntile) { return (int)(((uint32_t)(s - 1) * (uint32_t)nskip) % (uint32_t)(ntile - nskip + 1)); }
+__host__ __device__ inline bool dkb_skipped(int s, int t, int nskip, int ntile) {
+  const int w = dkb_win0(s, nskip, ntile);
+  return t >= w && t < w + nskip;
+}
 
 struct ChainBwdP {
   int M, N, d;
@@ -74,6 +117,7 @@ struct ChainBwdP {
   // S_b = X_b^T dI1_b that used to deliver it (sb_h2_kernel) leaves the recurrence and runs once, over all steps, at the end
   H2View X;                 // the step's kept X
   float* dy_part;           // [tiles][3][d] per question segment, like dc_part; null: not computed
+  ChainDkbP dkb;            // dKB jobs of the PREVIOUSLY differentiated step on the idle CUs (njobs = 0: none)
 };
 
 // K-loop variant of the d = 512, 64-row chain kernels (ChainCtx::kloop: 4 = activation reads in mid-slice); -1 = the default,
@@ -93,5 +137,28 @@ inline size_t chain_tiles(int d, size_t M) { const size_t r = (size_t)chain_tile
 // defined in macx_chain_fwd.hip / macx_chain_bwd.hip
 hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // e0 / e1: the kernel's own start / stop timestamps
 hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st);
+hipError_t chain_dkb_rest_launch(const ChainDkbP& q, int M, int N, int d, hipStream_t st);    // d = 512, 64-row tiles only
+// jobs per filler workgroup of a chain_bwd launch (0: the merged dKB launch instead) and what follows from it
+// MACX_TUNE_PRE_FILL: 1 (default) stage 0 of step i + 1 on the idle CUs of chain_fwd's launch of step i; 0 every launch its own
+inline int pre_fill_mode() { return tune_get(MACX_TUNE_PRE_FILL, 1); }
+inline int pre_fill_count(int d, size_t M, int ncu) {
+  if (!pre_fill_mode() || d != 512 || ncu <= 0 || chain_tile_rows(d, M) != 64) return 0;
+  const int ntile = (int)chain_tiles(d, M);
+  const int idle = (ncu - ntile % ncu) % ncu;
+  return idle * 6 >= ntile ? idle : 0;           // (a filler walks ntile / idle tiles at about a sixth of a chain tile's time each)
+}
+inline int dkb_fill_mode() { return tune_get(MACX_TUNE_DKB_FILL, 3); }
+struct DkbFillPlan { int njobs, nfill, nskip; };
+inline DkbFillPlan dkb_fill_plan(int d, size_t M, int p, int ncu) {
+  DkbFillPlan f{0, 0, 0};
+  const int nj = dkb_fill_mode();
+  if (nj <= 0 || d != 512 || p < 2 || ncu <= 0 || chain_tile_rows(d, M) != 64) return f;
+  const int ntile = (int)chain_tiles(d, M);
+  const int idle = (ncu - ntile % ncu) % ncu;       // CUs without a tile in the launch's last round
+  if (idle * nj * 4 < ntile) return f;              // too few to matter: the closing launch would carry most of the work
+  f.njobs = nj; f.nfill = idle;
+  f.nskip = ntile > idle * nj ? ntile - idle * nj : 0;
+  return f;
+}
 
 }  // namespace macx

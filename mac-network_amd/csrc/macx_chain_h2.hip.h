@@ -165,9 +165,12 @@ struct ChainCtx {
     wr = wave / NWC; wc = wave % NWC;
     colbase = wc * CW; rowbase = wr * RPW;
     M = M_; N = N_;
-    grow0 = (size_t)blockIdx.x * R;
-    nvalid = (int)min((size_t)R, (size_t)M - grow0);
     crow = (wave / WPG) * 16 + li;
+    set_tile(blockIdx.x);
+  }
+  __device__ __forceinline__ void set_tile(size_t t) {
+    grow0 = t * R;
+    nvalid = (int)min((size_t)R, (size_t)M - grow0);
     cgrow = grow0 + crow;
     cvalid = crow < nvalid;
   }
@@ -512,12 +515,13 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   const int M = p.M;
 
   // =====================================================================================================================
-  // stage 0: the operand of the first product
-  if (p.mode == 0) {
+  // stage 0: the operand of the first product.  dropout(KB) of the tile x stands on -> H2 planes in P (+ HBM), the keep bits of both
+  // read-dropout sites (the second site's also into sBits: stage 3 reads them there)
+  auto stage0 = [&](uint32_t k1, uint32_t k2, uint8_t* bits1, uint8_t* bytes2, const H2View& KBd) __attribute__((always_inline)) {
     float v[IT][8];
     float m = 0.f;
     const bool drop1 = p.thr1 < (1u << 24), drop2 = p.thr2 < (1u << 24);
-    const uint32_t key1 = run_key(p.key1, p.word), key2 = run_key(p.key2, p.word);
+    const uint32_t key1 = run_key(k1, p.word), key2 = run_key(k2, p.word);
     const size_t Rp2 = (size_t)M + H2_PAD_ROWS;
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
         for (int q = 0; q < 8; q += 2) byte |= keep_pair(e0 + q, key1, p.thr1) << q;
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[j][q] = ((byte >> q) & 1u) ? v[j][q] * p.inv1 : 0.f;
-        if (p.bits1 && x.cvalid) p.bits1[x.cgrow * KG + kg] = (uint8_t)byte;
+        if (bits1 && x.cvalid) bits1[x.cgrow * KG + kg] = (uint8_t)byte;
       }
       if (drop2) {
         // hashed once per element, here: the logits epilogue of stage 3 reads the bits back from LDS
@@ -546,12 +550,37 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
 #pragma unroll
         for (int q = 0; q < 8; q += 2) byte |= keep_pair(e0 + q, key2, p.thr2) << q;
         x.sBits[x.crow * C::G::BITS_LD + kg] = (uint8_t)byte;
-        if (p.bytes2 && x.cvalid) p.bytes2[(size_t)kg * Rp2 + x.cgrow] = (uint8_t)byte;
+        if (bytes2 && x.cvalid) bytes2[(size_t)kg * Rp2 + x.cgrow] = (uint8_t)byte;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[j][q]));
     }
-    x.convert_finish(v, m, x.sE, p.KBd);
+    x.convert_finish(v, m, x.sE, KBd);
+  };
+  if constexpr (D == 512 && R == 64) {
+    // workgroups past the tile grid: stage 0 of the NEXT step on the CUs this launch leaves idle (ChainPreP)
+    const int ntile = (M + R - 1) / R;
+    if ((int)blockIdx.x >= ntile) {
+#pragma unroll 1
+      for (int t = (int)blockIdx.x - ntile; t < ntile; t += p.pre.nfill) {
+        x.set_tile((size_t)t);
+        stage0(p.pre.key1, p.pre.key2, p.pre.bits1, p.pre.bytes2, p.pre.KBd);
+      }
+      return;
+    }
+  }
+  if (p.mode == 0) {
+    stage0(p.key1, p.key2, p.bits1, p.bytes2, p.KBd);
+  } else if (p.mode == 2) {
+    // the previous launch's fillers left the planes and the keep bytes behind
+    if (p.thr2 < (1u << 24)) {
+      const size_t Rp2 = (size_t)M + H2_PAD_ROWS;
+      const int r = x.tid & 63, k0 = x.tid >> 6;
+      const size_t gr = min(x.grow0 + r, (size_t)M - 1);
+#pragma unroll
+      for (int j = 0; j < KG / 8; ++j) x.sBits[r * C::G::BITS_LD + k0 + 8 * j] = p.bytes2[(size_t)(k0 + 8 * j) * Rp2 + gr];
+    }
+    x.load_tile(p.KBd, x.sE);
   } else {
     x.load_tile(p.X, x.sE);
   }
@@ -584,7 +613,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
 
   // =====================================================================================================================
   // stage 1: X = KBd Wx + bx
-  if (p.mode == 0) {
+  if (p.mode != 1) {
     x.zero_acc(acc);
     x.template kloop<KV>(acc, p.Wx.planes);
     bias_act(std::integral_constant<int, ACT_NON>{}, x.sE, *p.Wx.exp, p.bx);
@@ -703,8 +732,9 @@ inline hipError_t chain_fwd_launch_t(const ChainFwdP& p, hipStream_t st, hipEven
   constexpr size_t lds = ChainGeo<D_, R_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
-  if (e0 && e1) hipExtLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, e0, e1, 0, p);
-  else hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
+  const int grid = (p.M + R_ - 1) / R_ + ((D_ == 512 && R_ == 64) ? p.pre.nfill : 0);
+  if (e0 && e1) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, e0, e1, 0, p);
+  else hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
@@ -738,6 +768,168 @@ hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st, hipEvent_t e0, h
 
 // =========================================================================================================================
 
+
+// =========================================================================================================================
+// dKB jobs (ChainDkbP, macx_chain_api.hip.h): dKB[tile] (+)= (dX_s[tile] Wx^T) * kbmask_s / keep + att_s (x) dinfo_s for one 64-row
+// tile of one step; a workgroup runs a SEQUENCE of jobs (DkbSeq: the fillers of a chain_bwd launch, the closing launch).
+//   * the tile comes from HBM as it lies -- 16 slots per thread, a pure copy -- and the NEXT job's slots are requested before the
+//     current job's row pass and written to LDS after it: only a sequence's first tile load is exposed;
+//   * the K loop is the chain kernels' (ChainCtx::kloop);
+//   * the accumulators go through LDS as an fp32 row-major tile (row stride D + 4 floats: the 1 KB past P lands in sMax, idle here)
+//     so that the read-modify-write of the caller's gradient runs with lanes along a row (whole 2 KB rows per 128 lanes); the old
+//     values, the rows' attention and keep bits are requested in front of that staging.
+// Measured (profiles/r06_dkb_jobs.txt): K loop 14.6 us of a job, tile load 5-8, row pass 7-15 (the closing launch runs its 196
+// workgroups in lockstep: its memory phases share HBM).
+struct DkbJob { int s, t; bool write, valid; };
+
+template <int KV, class C, class NEXT>
+__device__ __forceinline__ void dkb_run(C& x, const ChainDkbP& q, DkbJob job, NEXT next) {
+  constexpr int D = C::D, R = C::R, KG = C::KG, CB = C::CB, CT = C::CT, RT = C::RT;
+  constexpr int LDW = D + 4;
+  constexpr int NS = 2 * KG * R / 512;           // tile slots per thread
+  constexpr int NR = R / 4;                      // row-pass rows per thread: thread (r0 = tid >> 7, c4 = tid & 127) takes rows r0 + 4 k
+  static_assert(R == 64 && D == 512, "dKB jobs: d = 512, 64-row tiles");
+  const size_t Rp = (size_t)x.M + H2_PAD_ROWS;
+  // tile copy: thread (lr = tid & 63, ls = tid >> 6) moves row lr of the slot columns (plane * KG + kg) ls + 8 k
+  float* T = reinterpret_cast<float*>(x.P);
+  u32x4 pf[NS];
+  int pe = 0;
+  // (the opaque zeros: addresses are rebuilt where they are used -- hoisted out of the job loop they would live through the K loop,
+  // whose registers are full: 175 spilled registers without them)
+  // real = false (behind the last job): the same sixteen loads, all of one slot column -- cache hits nobody waits long for
+  auto request = [&](const DkbJob& j, bool real) __attribute__((always_inline)) {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    const int lr = (x.tid & 63) + z, ls = (x.tid >> 6) + z;
+    const char* base = q.dX + (size_t)j.s * q.dx_step;
+    const size_t gr = min((size_t)j.t * R + lr, (size_t)x.M - 1);
+    const size_t cs = real ? Rp : 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) pf[k] = *reinterpret_cast<const u32x4*>(base + ((size_t)(ls + 8 * k) * cs + gr) * 16);
+    pe = (int)reinterpret_cast<const int8_t*>(base + 2 * (size_t)KG * Rp * 16)[gr * CB];       // (threads 0 .. R - 1 use theirs)
+  };
+  if (!job.valid) return;
+  request(job, true);
+#pragma unroll 1
+  while (true) {
+    x.set_tile((size_t)job.t);
+    // (opaque per job: the tile's addresses are rebuilt where they are used instead of living through the K loop)
+    asm volatile("" : "+s"(job.t), "+s"(job.s));
+    {
+      int z = 0;
+      asm volatile("" : "+v"(z));
+      const int lr = (x.tid & 63) + z, ls = (x.tid >> 6) + z;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) *reinterpret_cast<u32x4*>(x.P + ((size_t)(ls + 8 * k) * R + lr) * 16) = pf[k];
+    }
+    if (x.tid < R) x.sE[x.tid] = pe;
+    __syncthreads();
+    f32x4 acc[RT][CT];
+    x.zero_acc(acc);
+    if (!(q.dbg & 1)) x.template kloop<KV>(acc, q.WxT.planes);
+    // the row pass's operands, requested in front of the staging of the accumulators.  No load sits behind a branch (the wait-count
+    // pass drains every load at a join): a job that stores reads the old values all the same, missing keep bits are stood in for by
+    // any readable bytes, and after the last job the next tile's request repeats the current one
+    const bool write = job.write || (q.dbg & 2);
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    const int c4 = (x.tid & 127) + z, r0 = (x.tid >> 7) + z;
+    const uint8_t* bits = q.bits ? q.bits + (size_t)job.s * q.bits_step : reinterpret_cast<const uint8_t*>(q.out);
+    const uint32_t bits_or = q.bits ? 0u : 0xFu;
+    const float* att = q.att + (size_t)job.s * q.att_step;
+    const float* dinfo = q.dinfo + (size_t)job.s * q.dinfo_step + c4 * 4;
+    const uint32_t un = (uint32_t)x.N, q0 = (uint32_t)x.grow0 / un, qlast = ((uint32_t)x.M - 1) / un;
+    const uint32_t qb1 = (q0 + 1) * un;          // first row of the next question (a tile touches at most QS = 5: N >= 16)
+    f32x4 old[NR], di[C::G::QS];
+    float a[NR];
+    uint32_t kb[NR];
+#pragma unroll
+    for (int k = 0; k < C::G::QS; ++k) di[k] = *reinterpret_cast<const f32x4*>(dinfo + (size_t)min(q0 + k, qlast) * q.ld_dinfo);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const uint32_t gr = min((uint32_t)x.grow0 + r0 + 4 * k, (uint32_t)x.M - 1);
+      old[k] = *reinterpret_cast<const f32x4*>(q.out + (size_t)gr * D + c4 * 4);
+      a[k] = att[gr];
+      kb[k] = ((uint32_t)bits[(size_t)gr * KG + (c4 >> 1)] >> ((c4 & 1) * 4)) | bits_or;
+    }
+    __syncthreads();                             // every wave is done reading the tile
+    {
+      const int eW = *q.WxT.exp;
+#pragma unroll
+      for (int tt = 0; tt < RT; ++tt) {
+        const int row = x.arow(tt);
+        const float sc = h2_unscale(x.sE[row], eW);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4*>(T + row * LDW + x.acol(c)) = acc[tt][c] * sc;
+      }
+    }
+    __syncthreads();
+    const DkbJob nj = next(job);
+    request(nj.valid ? nj : job, nj.valid);      // lands while the row pass runs
+    if (!(q.dbg & 8)) {
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int row = r0 + 4 * k;
+        const uint32_t gr = min((uint32_t)x.grow0 + row, (uint32_t)x.M - 1);
+        f32x4 dv = di[0];
+#pragma unroll
+        for (int j = 1; j < C::G::QS; ++j) dv = gr >= qb1 + (uint32_t)(j - 1) * un ? di[j] : dv;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * LDW + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float m = ((kb[k] >> e) & 1u) ? v[e] * q.inv_keep : 0.f;
+          o[e] = fmaf(a[k], dv[e], m) + (write ? 0.f : old[k][e]);
+        }
+        if (row < x.nvalid) *reinterpret_cast<f32x4*>(q.out + (x.grow0 + row) * D + c4 * 4) = o;
+      }
+    }
+    if (!nj.valid) break;
+    job = nj;
+    __syncthreads();                             // the next tile overwrites T
+  }
+}
+
+// filler workgroup f of the chain_bwd launch that carries step q.step's jobs: tiles u = f, f + nfill, .. of the covered list
+template <int KV, class C>
+__device__ __forceinline__ void dkb_fill(C& x, const ChainDkbP& q, int f) {
+  const int ntile = (x.M + C::R - 1) / C::R;
+  const int s = q.step;
+  const int w0 = q.nskip ? dkb_win0(s, q.nskip, ntile) : 0;
+  auto job_of = [&](int j) {
+    DkbJob r;
+    const int u = f + q.nfill * j;
+    r.valid = j < q.njobs && u < ntile - q.nskip;
+    r.s = s;
+    r.t = u < w0 ? u : u + q.nskip;
+    r.write = true;                              // the first contribution a tile receives is stored, not added
+    for (int s2 = s + 1; s2 < q.p; ++s2) r.write = r.write && q.nskip && dkb_skipped(s2, r.t, q.nskip, ntile);
+    return r;
+  };
+  int j = 0;
+  dkb_run<KV>(x, q, job_of(0), [&](const DkbJob&) { return job_of(++j); });
+}
+
+// the closing launch: per tile, the (step, tile) pairs the filler launches left out (steps p - 1 .. 1), then step 0
+template <int D_, int KV>
+__global__ __launch_bounds__(512) void chain_dkb_rest_kernel(const ChainDkbP q, int M, int N) {
+  using C = ChainCtx<D_, 64>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  C x;
+  x.init(lds, M, N);
+  const int ntile = gridDim.x, t = blockIdx.x;
+  bool touched = false;
+  for (int s = 1; s < q.p; ++s) touched = touched || !(q.nskip && dkb_skipped(s, t, q.nskip, ntile));
+  auto below = [&](int s0, bool wr) {            // the first job among steps s0, s0 - 1, .. 0
+    DkbJob r;
+    int s = s0;
+    while (s > 0 && !(q.nskip && dkb_skipped(s, t, q.nskip, ntile))) --s;
+    r.s = s; r.t = t; r.write = wr; r.valid = s >= 0;
+    return r;
+  };
+  dkb_run<KV>(x, q, below(q.p - 1, !touched), [&](const DkbJob& cur) { return cur.s > 0 ? below(cur.s - 1, false) : DkbJob{0, 0, false, false}; });
+}
+
 // A2: readCtrlAct as a compile-time constant -- one kernel per activation (chain_bwd_launch_t); several arms in one kernel met in one
 // register allocation (two arms: 86 spilled registers; a per-value run-time switch: 102-104).
 template <int D_, int KV = 0, int A2 = -1, int R_ = 64>
@@ -748,6 +940,14 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   C x;
   x.init(lds, p.M, p.N);
   const int M = p.M;
+  if constexpr (D == 512 && R == 64) {
+    // workgroups past the tile grid: dKB jobs of the previously differentiated step on the CUs this launch leaves idle
+    const int ntile = (M + R - 1) / R;
+    if ((int)blockIdx.x >= ntile) {
+      dkb_fill<KV>(x, p.dkb, (int)blockIdx.x - ntile);
+      return;
+    }
+  }
 
   // =====================================================================================================================
   // stage B0 (SURVEY appendix A rows "softmax", "logit", "ctrl-mul"):
@@ -1099,7 +1299,8 @@ inline hipError_t chain_bwd_launch_a(const ChainBwdP& p, hipStream_t st) {
   constexpr size_t lds = ChainGeo<D_, R_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_), dim3(512), lds, st, p);
+  const int nfill = (D_ == 512 && R_ == 64 && p.dkb.njobs > 0) ? p.dkb.nfill : 0;
+  hipLaunchKernelGGL(kern, dim3((p.M + R_ - 1) / R_ + nfill), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
@@ -1118,6 +1319,16 @@ inline hipError_t chain_bwd_launch_t(const ChainBwdP& p, hipStream_t st) {
 }
 
 #ifdef MACX_CHAIN_BWD_TU      // macx_chain_bwd.hip: the one translation unit that instantiates the backward kernels
+hipError_t chain_dkb_rest_launch(const ChainDkbP& q, int M, int N, int d, hipStream_t st) {
+  if (d != 512 || chain_tile_rows(d, (size_t)M) != 64) return hipErrorInvalidValue;
+  auto kern = chain_dkb_rest_kernel<512, CHAIN_KV_DEFAULT>;
+  constexpr size_t lds = ChainGeo<512, 64>::LDS;
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((M + 63) / 64), dim3(512), lds, st, q, M, N);
+  return hipGetLastError();
+}
+
 hipError_t chain_bwd_launch(const ChainBwdP& p, hipStream_t st) {
   switch (p.d / 128) {
     case 1: return chain_bwd_launch_t<128>(p, st);

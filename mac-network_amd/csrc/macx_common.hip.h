@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
+#include <map>
 #include <set>
 #include <utility>
 #include "../../include/macx.h"
@@ -28,6 +29,21 @@ inline hipError_t lds_attr_once(const void* fn, size_t bytes) {
   e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e == hipSuccess) done.insert({fn, dev});
   return e;
+}
+
+// compute units of the current device (0 if it cannot be asked): a device fact, cached per device like the attribute above
+inline int device_cu_count() {
+  static std::mutex mu;
+  static std::map<int, int> known;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = known.find(dev);
+  if (it != known.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+  known[dev] = n;
+  return n;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -67,3 +67,31 @@ def test_tables_of_two_cells_do_not_leak(macx, dev):
     for k in ref:
         assert torch.equal(again[k], ref[k]), k
     assert any(not torch.equal(other[k], ref[k]) for k in ref)      # (the other route rounds differently: it really ran)
+
+
+@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 64, 7, 196, 512, 3), ("args", 43, 5, 196, 512, 4), ("args3", 64, 5, 196, 512, 2),
+                                            ("args", 50, 5, 170, 512, 5)])
+def test_dkb_on_idle_cus_agrees_with_merged_launch(macx, dev, name, B, S, N, d, p):
+    """dkb_fill: dKB of step i + 1 as jobs on the CUs chain_bwd's launch of step i leaves idle + a closing launch (default, 3 jobs per
+    filler workgroup) against ONE merged launch over all steps (0).  1 and 2 jobs per workgroup move the window of left-out tiles
+    (nskip) and with it which launch stores a tile first.  Only dKB may differ (one fp32 rounding per step instead of one per
+    launch); everything else bit for bit -- the fillers share a launch with the chain tiles and must not disturb them."""
+    ref = run(macx, dev, name, B, S, N, d, p, tune={"dkb_fill": 0})
+    for v in (3, 1, 2):
+        got = run(macx, dev, name, B, S, N, d, p, tune={"dkb_fill": v})
+        for k in ref:
+            if k == "d_kb":
+                assert rel_err(got[k], ref[k], floor=1e-6) < 2e-6, (v, k)
+            else:
+                assert torch.equal(got[k], ref[k]), (v, k)
+
+
+@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 64, 7, 196, 512, 3), ("args", 43, 5, 196, 512, 2), ("args3", 50, 5, 170, 512, 4)])
+def test_stage0_on_idle_cus_is_bit_identical(macx, dev, name, B, S, N, d, p):
+    """pre_fill: dropout(KB) -> fp16 planes and the keep bits of step i + 1 written by filler workgroups of chain_fwd's launch of step i
+    (default) against every launch converting its own tile (0): the same values reach the same products -- final memory and every
+    gradient bit for bit."""
+    ref = run(macx, dev, name, B, S, N, d, p, tune={"pre_fill": 0})
+    got = run(macx, dev, name, B, S, N, d, p)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
