@@ -98,8 +98,10 @@ enum {
                                  inside the iteration; 2 = 1 + dW2 and dWx as ONE launch; 3 (default) = 2 with half the splits  */
   MACX_TUNE_SB_CONT = 13,     /* sb_h2w_kernel: 1 (default) one stage stream over all steps; 0 drained and re-primed per step    */
   MACX_TUNE_DKB_UNI = 14,     /* merged dKB launch: 1 (default) one fold of the block accumulator per step; 0 per 128-wide K block */
-  MACX_TUNE_PRE_FILL = 3,     /* stage 0 of the read unit's forward chain (dropout(KB) -> fp16 planes, keep bits) for step i + 1 on the CUs
-                                 chain_fwd's launch of step i leaves idle (training runs of macx_cell_forward, d = 512): 1 (default) | 0 */
+  MACX_TUNE_PRE_FILL = 3,     /* what the filler workgroups of a d = 512 chain_fwd launch do on the CUs its tile grid leaves idle (runs
+                                 of macx_cell_forward; 196 tiles on 256 CUs at B = 64): 1 (default) the previous step's write-unit
+                                 linear, this step's y = md Wy + by, and stage 0 (dropout(KB) -> fp16 planes, keep bits) of the next
+                                 step; 2 the same without the write unit; 0 no fillers: every piece is a launch / a stage of its own */
   MACX_TUNE_DKB_FILL = 15     /* dKB on the CUs a d = 512 chain_bwd launch leaves idle (196 tiles on 256 CUs at B = 64): jobs per
                                  filler workgroup, default 3; 0: all of dKB in the merged launch after the last step            */
 };

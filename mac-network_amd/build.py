@@ -34,6 +34,7 @@ def _digest():
             h.update(os.path.basename(p).encode())
             with open(p, "rb") as fh:
                 h.update(fh.read())
+    h.update(os.environ.get("MACX_BUILD_DEFINES", "").encode())
     return h.hexdigest()
 
 
@@ -69,6 +70,8 @@ def _without_remarks(stderr_text):
 def _compile_one(src, obj, verbose):
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-fPIC", "-Wno-pass-failed", "-Wno-inline-asm",
            "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, src), "-o", obj]
+    for name in os.environ.get("MACX_BUILD_DEFINES", "").split():     # e.g. MACX_FILL_PROF, MACX_PROFILE_VARIANTS (measurement builds)
+        cmd += ["-D" + name]
     if os.environ.get("MACX_BUILD_REMARKS", "1") != "0":
         # the register / spill / occupancy remarks of every kernel ride along (tools/kernel_resources.py --from-build reads them)
         cmd += ["-Rpass-analysis=kernel-resource-usage"]

@@ -152,6 +152,8 @@ struct SavedLayout {
   size_t act_floats;                // floats of one such tensor (B*N*d, or the H2 size in h2 mode)
   size_t wmax;                      // h2: max |W| of projX, memKbProj2, W1a, W1b (4 floats)
   size_t bwd_packs;                 // keep: the backward pass's weight packs (bwd_packs_floats), written by the forward pack launch; else 0
+  size_t sync;                      // SYNC_WORDS uint32: [i] the y counter of step i's chain launch (ChainPreP::yflag, p <= 32), [63] the fail
+                                    // word, [64 + 16 i ..] step i's per-block counters (gflag); zeroed by macx_cell_begin's init_states launch
   size_t total;
 };
 
@@ -214,6 +216,7 @@ SavedLayout make_saved(const macx_opts* o, const macx_shapes* s, int keep) {
   L.att_bits = take(pk * bits_floats);
   L.wmax = take(8 + 4 * 64);          // the four maxima (+ 4 spare), then absmax4's per-workgroup partials
   L.bwd_packs = keep ? take(bwd_packs_floats(o, s)) : 0;
+  L.sync = take(SYNC_WORDS);
   L.total = off;
   return L;
 }
@@ -403,7 +406,28 @@ int check_impl(const macx_opts* o, const macx_shapes* s) {
 
 // the parameter block of the read unit's forward chain kernel for step `i`; `ob`: the step whose X / H1 / I2 / KBd / keep-bit
 // buffers receive the outputs (= i in a run; the timing hook rotates it)
-// pre: bit 0 -- stage 0 of this step was done by the previous step's launch (ChainFwdP::mode 2); bit 1 -- this launch's fillers do
+LinP lin_basic(const float* x, int ldx, int K, int rows, const float* Wp, const float* bias, int n_out, int act, float* out, int ldo);
+
+// the write unit's linear of step i without self attention and gate (mac_cell.py:305-375, writeInputs = BOTH): [m_i, info_i] Wm + bm
+// -> m_{i+1}; with md_next its epilogue also leaves the next step's dropped memory (mac_cell.py:214-217, ops.py:679)
+LinP make_write_lin(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P, float* saved,
+                    const SavedLayout& L, int i, const float* info, float* wout, bool md_next) {
+  const int B = s->B, d = s->d;
+  const size_t Bd = (size_t)B * d;
+  LinP l = lin_basic(saved + L.seg[MACX_SEG_MEMORIES] + (size_t)i * Bd, d, d, B, saved + L.wm_p, P->newMemory_b, d, o->write_mem_act, wout, d);
+  l.seg[1] = LinSeg{info, d, d, 0};
+  l.Ktot = 2 * d;
+  if (md_next) {
+    l.use_drop = 2; l.drop_ld = dlog_of(s);
+    l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp, SITE_MEM_VAR, 0) : make_drop(dp->keep_memory, dp, SITE_MEM, i + 1);
+    l.d2 = make_drop(dp->keep_read, dp, SITE_READ_MEM, i + 1);
+    l.drop_row0 = (uint32_t)s->b0;
+    l.out_drop = saved + L.md + (size_t)(i + 1) * Bd; l.ld_od = d;
+  }
+  return l;
+}
+
+// pre: bit 2 -- this launch's filler workgroups compute the step's y (ChainPreP::ylin); bit 0 -- stage 0 of this step was done by the previous step's launch (ChainFwdP::mode 2); bit 1 -- this launch's fillers do
 // stage 0 of step i + 1 (ChainPreP).  Both only where macx_cell_forward sequences the steps itself.
 ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dropout* dp, const macx_params* P,
                          const macx_inputs* in, float* saved, const SavedLayout& L, int keep, int i, int ob, int pre = 0) {
@@ -448,8 +472,21 @@ ChainFwdP make_chain_fwd(const macx_opts* o, const macx_shapes* s, const macx_dr
   }
   c.logits = saved + L.logit_part;
   if (rdrop && c.mode == 0 && (pre & 1)) c.mode = 2;
-  if (rdrop && (pre & 2)) {
-    c.pre.nfill = pre_fill_count(d, (size_t)R, device_cu_count());
+  if (pre & 6) c.pre.nfill = pre_fill_count(d, (size_t)R, device_cu_count());
+  if ((pre & 4) && c.pre.nfill) {
+    // this step's y = md Wy + by on the filler workgroups (cell_step_impl then launches no linear for it)
+    c.pre.ylin = lin_basic(saved + L.md + (size_t)i * Bd, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON, saved + L.y + (size_t)i * Bd, d);
+    c.pre.step = i;
+    c.pre.yflag = reinterpret_cast<uint32_t*>(saved + L.sync) + i;
+    c.pre.fail = reinterpret_cast<uint32_t*>(saved + L.sync) + 63;
+    if ((pre & 16) && i > 0) {
+      // ... after the previous step's write unit (cell_step_impl did not launch it)
+      c.pre.wlin = make_write_lin(o, s, dp, P, saved, L, i - 1, saved + L.seg[MACX_SEG_INFOS] + (size_t)(i - 1) * Bd,
+                                  saved + L.seg[MACX_SEG_MEMORIES] + (size_t)i * Bd, true);
+      c.pre.gflag = reinterpret_cast<uint32_t*>(saved + L.sync) + 64 + 16 * i;
+    }
+  }
+  if (rdrop && (pre & 2) && c.pre.nfill) {
     c.pre.key1 = make_drop(dp->keep_read, dp, SITE_READ_KB, i + 1).key;
     c.pre.key2 = make_drop(dp->keep_read, dp, SITE_READ_ATT, i + 1).key;
     c.pre.bits1 = reinterpret_cast<uint8_t*>(saved + L.kb_bits + (size_t)(ob + 1) * L.bits_stride);
@@ -800,7 +837,8 @@ int macx_cell_begin(const macx_opts* o, const macx_shapes* s, const macx_dropout
     const DropSpec dm = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp, SITE_MEM_VAR, 0) : make_drop(dp->keep_memory, dp, SITE_MEM, 0);
     const DropSpec dry = make_drop(dp->keep_read, dp, SITE_READ_MEM, 0);
     hipLaunchKernelGGL(init_states_kernel, dim3(64), dim3(256), 0, st, o->init_ctrl, P->initCtrl, controls, o->init_mem, P->initMem, memories,
-                       in->vecQuestions, B, d, md0 ? saved + L.md : nullptr, (uint32_t)s->b0, dm, dry, dlog_of(s));
+                       in->vecQuestions, B, d, md0 ? saved + L.md : nullptr, (uint32_t)s->b0, dm, dry, dlog_of(s),
+                       reinterpret_cast<uint32_t*>(saved + L.sync));
     CK(hipGetLastError());
   }
 
@@ -896,7 +934,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     hipLaunchKernelGGL(drop2_kernel, dim3(64), dim3(256), 0, st, m_prev, B, d, (uint32_t)s->b0, dm, dry, md, dlog_of(s));
     CK(hipGetLastError());
   }
-  {
+  if (!((pre & 4) && h2_mode() && use_chain(d, s->N))) {     // (pre & 4: the chain launch's filler workgroups compute y, ChainPreP)
     LinP l = lin_basic(md, d, d, B, saved + L.wy_p, P->projY_b, d, MACX_ACT_NON, y, d);
     CK(small_linear_launch(l, 1, st));
   }
@@ -1008,6 +1046,7 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
     hipLaunchKernelGGL(kb_attend_kernel, dim3(B, d / 128), dim3(KA_THREADS), 0, st, a);
     CK(hipGetLastError());
   }
+  if (pre & 8) return MACX_OK;      // the write unit: on the next chain launch's filler workgroups (ChainPreP::wlin)
   }   // U_READ
   if (!(units & U_WRITE)) return MACX_OK;
   // write dropout (mac_cell.py:461-463); self.infos keeps the dropped value (mac_cell.py:474)
@@ -1036,19 +1075,9 @@ int cell_step_impl(const macx_opts* o, const macx_shapes* s, const macx_dropout*
   }
   {
     float* wout = o->write_gate ? saved + L.mnew + (size_t)i * Bd : m_new;
-    LinP l = lin_basic(m_prev, d, d, B, saved + L.wm_p, P->newMemory_b, d, o->write_mem_act, wout, d);
-    l.seg[1] = LinSeg{info, d, d, 0};
-    l.Ktot = 2 * d;
+    // (md_fused: the new memory is the next step's read-unit input: its two dropouts, mac_cell.py:214-217 and ops.py:679, ride the epilogue)
+    LinP l = make_write_lin(o, s, dp, P, saved, L, i, info, wout, md_fused && i + 1 < s->p);
     if (self_smry) { l.seg[2] = LinSeg{self_smry, d, d, 0}; l.Ktot = 3 * d; }
-    if (md_fused && i + 1 < s->p) {
-      // the new memory is the next step's read-unit input: its two dropouts (mac_cell.py:214-217, ops.py:679) ride this epilogue
-      l.use_drop = 2; l.drop_ld = dlog_of(s);
-      l.d1 = o->memory_variational_dropout ? make_drop(dp->keep_memory, dp, SITE_MEM_VAR, 0)
-                                           : make_drop(dp->keep_memory, dp, SITE_MEM, i + 1);
-      l.d2 = make_drop(dp->keep_read, dp, SITE_READ_MEM, i + 1);
-      l.drop_row0 = (uint32_t)s->b0;
-      l.out_drop = saved + L.md + (size_t)(i + 1) * Bd; l.ld_od = d;
-    }
     CK(small_linear_launch(l, 1, st));
     if (o->write_gate) {
       // z = sigmoid(control Wg + bg + gateBias); m = newMemory * z + memory * (1 - z)   (mac_cell.py:358-367)
@@ -1079,10 +1108,18 @@ int macx_cell_forward(const macx_opts* o, const macx_shapes* s, const macx_dropo
   ModeScope ms(o);
   // a training run's steps are sequenced here: stage 0 of the read unit's chain for step i + 1 (state-independent) rides the
   // launch of step i on its idle CUs (ChainPreP).  The step-wise entry point makes no assumption about what ran before it.
-  const bool pre = keep && dp && dp->keep_read < 1.0f && h2_mode() && use_chain(s->d, s->N) &&
-                   pre_fill_count(s->d, (size_t)s->B * s->N, device_cu_count()) > 0;
-  for (int i = 0; i < s->p; ++i)
-    CKI(cell_step_impl(o, s, dp, P, in, saved, saved_floats, keep, i, U_ALL, stream, pre ? ((i > 0 ? 1 : 0) | (i + 1 < s->p ? 2 : 0)) : 0));
+  const bool fill = h2_mode() && use_chain(s->d, s->N) && s->p <= 32 && s->B <= 128 && pre_fill_count(s->d, (size_t)s->B * s->N, device_cu_count()) > 0;
+  const bool pre = fill && keep && dp && dp->keep_read < 1.0f;
+  // the write unit's linear too, where it is one launch: the plain write unit of the published flag files
+  const bool tail = fill && s->B <= 128 && !o->write_gate && !o->write_self_att && !o->control_feed_prev && dp && !(dp->keep_write < 1.0f) &&
+                    tune_get(MACX_TUNE_PRE_FILL, 1) >= 1 && tune_get(MACX_TUNE_PRE_FILL, 1) != 2;
+  for (int i = 0; i < s->p; ++i) {
+    // bit 0: stage 0 was done by the previous launch; 1: this launch does the next step's; 2: this launch's fillers compute y;
+    // 3: this step's write unit is left to the next launch; 4: this launch's fillers run the previous step's
+    const int flags = (pre && i > 0 ? 1 : 0) | (pre && i + 1 < s->p ? 2 : 0) | (fill ? 4 : 0) | (tail && i + 1 < s->p ? 8 : 0) |
+                      (tail && i > 0 ? 16 : 0);
+    CKI(cell_step_impl(o, s, dp, P, in, saved, saved_floats, keep, i, U_ALL, stream, flags));
+  }
   return MACX_OK;
 }
 

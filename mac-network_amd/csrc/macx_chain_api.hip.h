@@ -3,6 +3,7 @@
 // (macx_chain_fwd.hip, macx_chain_bwd.hip: two thirds of the library's compile time, built in parallel with the rest).
 #pragma once
 #include "macx_h2.hip.h"
+#include "macx_lin_tile.hip.h"
 
 namespace macx {
 
@@ -14,12 +15,30 @@ struct ChainW {          // a weight matrix in pack format 3 (macx_h2.hip.h: pac
 // Stage 0 (dropout(KB) -> H2, both keep-bit sites) of the NEXT step on the CUs a d = 512 chain_fwd launch leaves idle: it depends on
 // no state, only on the step's site keys.  The launch of step i carries `nfill` extra workgroups that walk the tiles of step i + 1
 // (tile f, f + nfill, ..); the launch of step i + 1 then starts from the finished planes (ChainFwdP::mode 2).
+// The same workgroups first compute THIS step's y = md Wy + by (the [B,d] linear that would otherwise be a launch of its own in front
+// of the chain launch): tiles of small_linear_kernel's arithmetic (macx_lin_tile.hip.h), outputs written through the L2 (agent-scope
+// stores), then one increment of `yflag` per filler workgroup.  The chain tiles need y only after their second product (~45 us
+// into the launch); they wait for yflag == nfill (bounded: `fail` is set if a tile gives up) and read y with agent-scope loads --
+// the per-XCD L2s are not coherent inside a launch.  Fillers carry the LOWEST workgroup ids: they are dispatched before any tile,
+// so a tile never waits for a workgroup that is not running.
 struct ChainPreP {
   int nfill;                // filler workgroups; 0: none
   uint32_t key1, key2;      // the next step's site keys (thresholds and scales are the step's own: one keep probability per run)
   uint8_t* bits1;           // its outputs, as ChainFwdP's
   uint8_t* bytes2;
-  H2View KBd;
+  H2View KBd;               // base null: no stage 0 to do (the last step)
+  LinP ylin;                // n_out = 0: y was computed by a launch
+  uint32_t* yflag;          // device word, zero when the launch starts
+  uint32_t* fail;           // device word, sticky
+  // ... and, in front of y, the PREVIOUS step's write unit (wlin.n_out = 0: a launch did it): the [B,d] linears between two chain
+  // launches then run beside the tiles' first two stages instead of between the launches.  Filler-to-filler order per block of 16
+  // questions: its write tiles -> its y tiles (which read the dropped new memory the write tiles leave); a filler finishes ALL its
+  // write tiles before it waits for anything, so the counters always complete.
+  // (Measured and not kept: the attention over the knowledge base -- kb_attend_kernel's units -- on the fillers too: 60 CUs take
+  // 30 us over the 25.7 MB the launch reads in 6.8, the tiles wait 39 us for y; profiles/r06_fillers.txt.)
+  LinP wlin;                // [m_prev, info] Wm + bm -> m_new, and the dropped copy this step's y reads
+  uint32_t* gflag;          // [8] device words, zero when the launch starts: write tiles finished per block of 16 questions
+  int step;                 // (-DMACX_FILL_PROF: step 5's filler 0 / tile 0 leave 100 MHz timestamps in sync[32..47], tools/fill_prof.py)
 };
 
 struct ChainFwdP {

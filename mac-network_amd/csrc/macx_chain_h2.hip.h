@@ -558,16 +558,80 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
     x.convert_finish(v, m, x.sE, KBd);
   };
   if constexpr (D == 512 && R == 64) {
-    // workgroups past the tile grid: stage 0 of the NEXT step on the CUs this launch leaves idle (ChainPreP)
-    const int ntile = (M + R - 1) / R;
-    if ((int)blockIdx.x >= ntile) {
+    // the first p.pre.nfill workgroups are fillers on the CUs the tile grid leaves idle (ChainPreP): this step's y, then stage 0 of
+    // the NEXT step
+#ifdef MACX_FILL_PROF
+#define MACX_STAMP(cond, k) do { if ((cond) && p.pre.step == 5 && p.pre.fail && x.tid == 0) p.pre.fail[-31 + (k)] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define MACX_STAMP(cond, k) do { } while (0)
+#endif
+    if ((int)blockIdx.x < p.pre.nfill) {
+      const int f = blockIdx.x, nf = p.pre.nfill;
+      MACX_STAMP(f == 0, 0);
+      float (*red)[16][20] = reinterpret_cast<float (*)[16][20]>(lds);       // two linear tiles side by side: [2 halves][2 x 4][16][20]
+      const int half = x.tid >> 8, tl = x.tid & 255;
+      // every wave's stores have left, then one increment
+      auto signal = [&](uint32_t* c0, uint32_t* c1) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (x.tid == 0 && c0) __hip_atomic_fetch_add(c0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x.tid == 64 && c1) __hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      auto wait_ge = [&](uint32_t* c, uint32_t v) __attribute__((always_inline)) {
+        if (x.tid == 0) {
+          uint32_t spins = 0;
+          while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) { __hip_atomic_store(p.pre.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          }
+        }
+        __syncthreads();
+      };
+      const bool tail = p.pre.wlin.n_out != 0;
+      if (tail) {
+        // the previous step's write tiles (16 rows x 32 columns: 64 tiles at B = 64, one round on the fillers' 2 x nf halves)
+        const LinP& wl = p.pre.wlin;
+        const int ntx = wl.n_out / 32, nun = ntx * ((wl.rows + 15) / 16);
 #pragma unroll 1
-      for (int t = (int)blockIdx.x - ntile; t < ntile; t += p.pre.nfill) {
-        x.set_tile((size_t)t);
-        stage0(p.pre.key1, p.pre.key2, p.pre.bits1, p.pre.bytes2, p.pre.KBd);
+        for (int u0 = 2 * f; u0 < nun; u0 += 2 * nf) {
+          const int ua = u0, ub = min(u0 + 1, nun - 1), bya = ua / ntx, byb = ub / ntx;
+          const int u = half ? ub : ua;
+          small_linear_tile<1, false, true, false, 2>(wl, u % ntx, u / ntx, 0, red + 8 * half, tl, u0 + half < nun);
+          signal(p.pre.gflag + bya, u0 + 1 < nun ? p.pre.gflag + byb : nullptr);
+        }
       }
+      MACX_STAMP(f == 0, 1);
+      if (p.pre.ylin.n_out) {
+        const LinP& yl = p.pre.ylin;
+        const int ntx = yl.n_out / 32, nunits = ntx * ((yl.rows + 15) / 16);
+        const uint32_t wtiles = (uint32_t)(p.pre.wlin.n_out / 32);
+#pragma unroll 1
+        for (int u0 = 2 * f; u0 < nunits; u0 += 2 * nf) {
+          const int ua = u0, ub = min(u0 + 1, nunits - 1), bya = ua / ntx, byb = ub / ntx;
+          if (tail) {
+            wait_ge(p.pre.gflag + bya, wtiles);
+            if (byb != bya) wait_ge(p.pre.gflag + byb, wtiles);
+          }
+          const int u = half ? ub : ua;
+          small_linear_tile<1, false, true, true, 2>(yl, u % ntx, u / ntx, 0, red + 8 * half, tl, u0 + half < nunits);
+          __syncthreads();
+        }
+        signal(p.pre.yflag, nullptr);
+      }
+      MACX_STAMP(f == 0, 2);
+      if (p.pre.KBd.base) {
+        const int ntile = (M + R - 1) / R;
+#pragma unroll 1
+        for (int t = f; t < ntile; t += p.pre.nfill) {
+          x.set_tile((size_t)t);
+          stage0(p.pre.key1, p.pre.key2, p.pre.bits1, p.pre.bytes2, p.pre.KBd);
+        }
+      }
+      MACX_STAMP(f == 0, 3);
       return;
     }
+    x.set_tile((size_t)blockIdx.x - p.pre.nfill);
+    MACX_STAMP((int)blockIdx.x == p.pre.nfill, 8);
   }
   if (p.mode == 0) {
     stage0(p.key1, p.key2, p.bits1, p.bytes2, p.KBd);
@@ -629,12 +693,35 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   // stage 2: H1 = act(X W1b + (X * y) W1a + b1)
   x.zero_acc(acc);
   x.template kloop<KV>(acc, p.W1b.planes);
-  __syncthreads();                         // every wave is done reading X
+  constexpr bool YCOH = D == 512 && R == 64;      // y may come from this launch's fillers (ChainPreP): agent-scope loads
+  if constexpr (YCOH) {
+    MACX_STAMP((int)blockIdx.x == p.pre.nfill, 9);
+    if (p.pre.ylin.n_out && x.tid == 0) {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(p.pre.yflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)p.pre.nfill) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) { __hip_atomic_store(p.pre.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+  }
+  if constexpr (YCOH) MACX_STAMP((int)blockIdx.x == p.pre.nfill, 10);
+  __syncthreads();                         // every wave is done reading X (and y is complete)
   {
     float v[IT][8];
     float m = 0.f;
     const float inv = h2_pow2(-x.sE[x.crow]);
     const float* yq = p.y + x.qrow(x.cgrow) * D;
+    auto ldy = [&](const float* q) __attribute__((always_inline)) {
+      if constexpr (YCOH) {
+        const uint64_t* q8 = reinterpret_cast<const uint64_t*>(q);
+        const uint64_t lo = __hip_atomic_load(q8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t hi = __hip_atomic_load(q8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return f32x4{__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+                     __uint_as_float((uint32_t)(hi >> 32))};
+      } else {
+        return *reinterpret_cast<const f32x4*>(q);
+      }
+    };
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
       const int kg = x.ckg(j);
@@ -642,7 +729,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
       const u32x4 hi = *reinterpret_cast<const u32x4*>(s), lo = *reinterpret_cast<const u32x4*>(s + (size_t)KG * R * 16);
       float xv[8];
       h2_join8(hi, lo, inv, xv);
-      const f32x4 y0 = *reinterpret_cast<const f32x4*>(yq + kg * 8), y1 = *reinterpret_cast<const f32x4*>(yq + kg * 8 + 4);
+      const f32x4 y0 = ldy(yq + kg * 8), y1 = ldy(yq + kg * 8 + 4);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         v[j][q] = xv[q] * (q < 4 ? y0[q & 3] : y1[q & 3]);      // ops.py:703: the product the reference rounds to fp32
@@ -715,6 +802,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   __syncthreads();
   x.emit(acc, false, p.I2);
   x.publish_rows(x.sE2, C::PASS_EPI, p.I2);
+  if constexpr (D == 512 && R == 64) MACX_STAMP((int)blockIdx.x == p.pre.nfill, 11);
   if (x.tid < x.nvalid) {
     const int w0 = (x.tid / C::RPW) * C::NWC;
     float s = x.sPart[w0 * R + x.tid];

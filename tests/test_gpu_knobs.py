@@ -87,11 +87,14 @@ def test_dkb_on_idle_cus_agrees_with_merged_launch(macx, dev, name, B, S, N, d, 
 
 
 @pytest.mark.parametrize("name,B,S,N,d,p", [("args", 64, 7, 196, 512, 3), ("args", 43, 5, 196, 512, 2), ("args3", 50, 5, 170, 512, 4)])
-def test_stage0_on_idle_cus_is_bit_identical(macx, dev, name, B, S, N, d, p):
-    """pre_fill: dropout(KB) -> fp16 planes and the keep bits of step i + 1 written by filler workgroups of chain_fwd's launch of step i
-    (default) against every launch converting its own tile (0): the same values reach the same products -- final memory and every
-    gradient bit for bit."""
+def test_fillers_of_chain_fwd_are_bit_identical(macx, dev, name, B, S, N, d, p):
+    """pre_fill: the filler workgroups of chain_fwd's launch of step i run step i - 1's write unit, step i's y = md Wy + by (results
+    handed to the tiles of the SAME launch through counters and agent-scope loads / stores) and stage 0 of step i + 1 (default 1;
+    2: without the write unit) against launches / stages of their own (0): the same
+    arithmetic in the same order -- final memory and every gradient bit for bit, several times over (a stale read would show)."""
     ref = run(macx, dev, name, B, S, N, d, p, tune={"pre_fill": 0})
-    got = run(macx, dev, name, B, S, N, d, p)
-    for k in ref:
-        assert torch.equal(got[k], ref[k]), k
+    for rep in range(2):
+        for v in (1, 2):
+            got = run(macx, dev, name, B, S, N, d, p, tune={"pre_fill": v})
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (rep, v, k)
