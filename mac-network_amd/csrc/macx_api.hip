@@ -1236,7 +1236,7 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
   // dKB of step i + 1 rides chain_bwd's launch of step i on the CUs that launch leaves idle (ChainDkbP, macx_chain_api.hip.h); what
   // the fillers leave out and step 0 run in chain_dkb_rest_launch after the last step.  Off (njobs = 0): the merged dKB launch.
   const DkbFillPlan dkb_plan = (units == U_ALL && h2_mode() && use_chain(d, s->N))
-                                   ? dkb_fill_plan(d, (size_t)B * N, p, device_cu_count()) : DkbFillPlan{0, 0, 0};
+                                   ? dkb_fill_plan(d, (size_t)B * N, N, p, device_cu_count()) : DkbFillPlan{0, 0, 0};
   ChainDkbP dkb_q;
   memset(&dkb_q, 0, sizeof(dkb_q));
   if (dkb_plan.njobs) {
@@ -1251,6 +1251,9 @@ int cell_backward_impl(const macx_opts* o, const macx_shapes* s, const macx_drop
     dkb_q.dinfo = wd ? ws + W.dinfo : ws + W.dwin + d; dkb_q.ld_dinfo = wd ? d : win; dkb_q.dinfo_step = wd ? Bd : (size_t)B * win;
     dkb_q.out = GI->knowledgeBase;
     dkb_q.dbg = (kb_gemm_dbg() >> 22) & 31;
+#ifdef MACX_FILL_PROF
+    dkb_q.prof = reinterpret_cast<uint32_t*>(const_cast<float*>(saved) + L.sync) + 48;
+#endif
   }
   for (int i = p - 1; i >= 0; --i) {
     const float* c_i = controls + (size_t)(i + 1) * Bd;

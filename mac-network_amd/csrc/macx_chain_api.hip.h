@@ -89,6 +89,7 @@ struct ChainDkbP {
   const float* att; size_t att_step;          // [M] attention of step 0, floats between steps
   const float* dinfo; int ld_dinfo; size_t dinfo_step;   // [B][ld_dinfo] of step 0
   float* out;                // dKB [M][d] fp32
+  uint32_t* prof;            // -DMACX_FILL_PROF: filler 0 of step 5's launch leaves shader-clock stamps here (sync words 48..62, tools/fill_prof.py)
   int dbg;                   // timing knobs (macx_opts.tune[MACX_TUNE_PHASE_MASK] bits 22-26; results are wrong except under 16): 1 no K loop,
                              // 2 no read of the gradient (store only), 4 no tile load, 8 no row pass, 16 atomic adds instead of read-modify-write
 };
@@ -168,10 +169,10 @@ inline int pre_fill_count(int d, size_t M, int ncu) {
 }
 inline int dkb_fill_mode() { return tune_get(MACX_TUNE_DKB_FILL, 3); }
 struct DkbFillPlan { int njobs, nfill, nskip; };
-inline DkbFillPlan dkb_fill_plan(int d, size_t M, int p, int ncu) {
+inline DkbFillPlan dkb_fill_plan(int d, size_t M, int N, int p, int ncu) {
   DkbFillPlan f{0, 0, 0};
   const int nj = dkb_fill_mode();
-  if (nj <= 0 || d != 512 || p < 2 || ncu <= 0 || chain_tile_rows(d, M) != 64) return f;
+  if (nj <= 0 || d != 512 || N < 64 || p < 2 || ncu <= 0 || chain_tile_rows(d, M) != 64) return f;      // (N >= 64: a tile touches <= 2 questions)
   const int ntile = (int)chain_tiles(d, M);
   const int idle = (ncu - ntile % ncu) % ncu;       // CUs without a tile in the launch's last round
   if (idle * nj * 4 < ntile) return f;              // too few to matter: the closing launch would carry most of the work

@@ -859,29 +859,28 @@ hipError_t chain_fwd_launch(const ChainFwdP& p, hipStream_t st, hipEvent_t e0, h
 
 // =========================================================================================================================
 // dKB jobs (ChainDkbP, macx_chain_api.hip.h): dKB[tile] (+)= (dX_s[tile] Wx^T) * kbmask_s / keep + att_s (x) dinfo_s for one 64-row
-// tile of one step; a workgroup runs a SEQUENCE of jobs (DkbSeq: the fillers of a chain_bwd launch, the closing launch).
-//   * the tile comes from HBM as it lies -- 16 slots per thread, a pure copy -- and the NEXT job's slots are requested before the
-//     current job's row pass and written to LDS after it: only a sequence's first tile load is exposed;
+// tile of one step; a workgroup runs a SEQUENCE of jobs (the fillers of a chain_bwd launch, the closing launch).
+//   * the tile comes from HBM as it lies -- 16 slots per thread, a pure copy -- and the NEXT job's slots are requested right behind
+//     the current job's K loop and written to LDS behind its epilogue: only a sequence's first tile load is exposed;
 //   * the K loop is the chain kernels' (ChainCtx::kloop);
-//   * the accumulators go through LDS as an fp32 row-major tile (row stride D + 4 floats: the 1 KB past P lands in sMax, idle here)
-//     so that the read-modify-write of the caller's gradient runs with lanes along a row (whole 2 KB rows per 128 lanes); the old
-//     values, the rows' attention and keep bits are requested in front of that staging.
-// Measured (profiles/r06_dkb_jobs.txt): K loop 14.6 us of a job, tile load 5-8, row pass 7-15 (the closing launch runs its 196
-// workgroups in lockstep: its memory phases share HBM).
+//   * the epilogue stays on the accumulators where they lie (lane (ar, ah): four consecutive columns of row 16 t + ar per 16-column
+//     tile): keep bits, + att (x) dinfo, then the read-modify-write of the caller's gradient as 16-byte pieces, four lanes per
+//     64-byte run.  (The first version staged the accumulators through LDS for a row-major pass over whole 2 KB rows: 5 us of
+//     staging + two barriers per job, profiles/r06_dkb_jobs.txt -- a job was 27 us of which the K loop 14.5.)
+// No load sits behind a branch (the wait-count pass drains every load at a join): a job that stores reads the old values all the same,
+// missing keep bits are stood in for by any readable bytes, and behind the last job the next tile's request degenerates to cache hits.
 struct DkbJob { int s, t; bool write, valid; };
 
 template <int KV, class C, class NEXT>
 __device__ __forceinline__ void dkb_run(C& x, const ChainDkbP& q, DkbJob job, NEXT next) {
   constexpr int D = C::D, R = C::R, KG = C::KG, CB = C::CB, CT = C::CT, RT = C::RT;
-  constexpr int LDW = D + 4;
   constexpr int NS = 2 * KG * R / 512;           // tile slots per thread
-  constexpr int NR = R / 4;                      // row-pass rows per thread: thread (r0 = tid >> 7, c4 = tid & 127) takes rows r0 + 4 k
-  static_assert(R == 64 && D == 512, "dKB jobs: d = 512, 64-row tiles");
+  static_assert(R == 64 && D == 512 && CT == 4 && RT == 4, "dKB jobs: d = 512, 64-row tiles");
   const size_t Rp = (size_t)x.M + H2_PAD_ROWS;
-  // tile copy: thread (lr = tid & 63, ls = tid >> 6) moves row lr of the slot columns (plane * KG + kg) ls + 8 k
-  float* T = reinterpret_cast<float*>(x.P);
   u32x4 pf[NS];
+  f32x4 dq = {0.f, 0.f, 0.f, 0.f};
   int pe = 0;
+  // tile copy: thread (lr = tid & 63, ls = tid >> 6) moves row lr of the slot columns (plane * KG + kg) ls + 8 k.
   // (the opaque zeros: addresses are rebuilt where they are used -- hoisted out of the job loop they would live through the K loop,
   // whose registers are full: 175 spilled registers without them)
   // real = false (behind the last job): the same sixteen loads, all of one slot column -- cache hits nobody waits long for
@@ -895,8 +894,19 @@ __device__ __forceinline__ void dkb_run(C& x, const ChainDkbP& q, DkbJob job, NE
 #pragma unroll
     for (int k = 0; k < NS; ++k) pf[k] = *reinterpret_cast<const u32x4*>(base + ((size_t)(ls + 8 * k) * cs + gr) * 16);
     pe = (int)reinterpret_cast<const int8_t*>(base + 2 * (size_t)KG * Rp * 16)[gr * CB];       // (threads 0 .. R - 1 use theirs)
+    // dinfo of the (at most two, N >= 64) questions the tile touches: 2 x D floats for sC, one float4 per thread of the first 256
+    const uint32_t un = (uint32_t)x.N, jq0 = (uint32_t)((size_t)j.t * R) / un, qlast = ((uint32_t)x.M - 1) / un;
+    const int dq_q = ((x.tid >> 7) & 1) + z, dq_c = (x.tid & 127) + z;
+    dq = *reinterpret_cast<const f32x4*>(q.dinfo + (size_t)j.s * q.dinfo_step + (size_t)min(jq0 + (uint32_t)dq_q, qlast) * q.ld_dinfo + dq_c * 4);
   };
+#ifdef MACX_FILL_PROF
+  int nstamp = 0;
+#define MACX_DSTAMP() do { if (q.prof && q.step == 5 && blockIdx.x == gridDim.x - q.nfill && x.tid == 0 && nstamp < 15) q.prof[nstamp++] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define MACX_DSTAMP() do { } while (0)
+#endif
   if (!job.valid) return;
+  MACX_DSTAMP();
   request(job, true);
 #pragma unroll 1
   while (true) {
@@ -911,70 +921,68 @@ __device__ __forceinline__ void dkb_run(C& x, const ChainDkbP& q, DkbJob job, NE
       for (int k = 0; k < NS; ++k) *reinterpret_cast<u32x4*>(x.P + ((size_t)(ls + 8 * k) * R + lr) * 16) = pf[k];
     }
     if (x.tid < R) x.sE[x.tid] = pe;
+    if (x.tid < 256) *reinterpret_cast<f32x4*>(x.sC + (x.tid >> 7) * D + (x.tid & 127) * 4) = dq;
     __syncthreads();
+    MACX_DSTAMP();                               // tile in LDS
     f32x4 acc[RT][CT];
     x.zero_acc(acc);
     if (!(q.dbg & 1)) x.template kloop<KV>(acc, q.WxT.planes);
-    // the row pass's operands, requested in front of the staging of the accumulators.  No load sits behind a branch (the wait-count
-    // pass drains every load at a join): a job that stores reads the old values all the same, missing keep bits are stood in for by
-    // any readable bytes, and after the last job the next tile's request repeats the current one
-    const bool write = job.write || (q.dbg & 2);
-    int z = 0;
-    asm volatile("" : "+v"(z));
-    const int c4 = (x.tid & 127) + z, r0 = (x.tid >> 7) + z;
-    const uint8_t* bits = q.bits ? q.bits + (size_t)job.s * q.bits_step : reinterpret_cast<const uint8_t*>(q.out);
-    const uint32_t bits_or = q.bits ? 0u : 0xFu;
-    const float* att = q.att + (size_t)job.s * q.att_step;
-    const float* dinfo = q.dinfo + (size_t)job.s * q.dinfo_step + c4 * 4;
-    const uint32_t un = (uint32_t)x.N, q0 = (uint32_t)x.grow0 / un, qlast = ((uint32_t)x.M - 1) / un;
-    const uint32_t qb1 = (q0 + 1) * un;          // first row of the next question (a tile touches at most QS = 5: N >= 16)
-    f32x4 old[NR], di[C::G::QS];
-    float a[NR];
-    uint32_t kb[NR];
-#pragma unroll
-    for (int k = 0; k < C::G::QS; ++k) di[k] = *reinterpret_cast<const f32x4*>(dinfo + (size_t)min(q0 + k, qlast) * q.ld_dinfo);
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const uint32_t gr = min((uint32_t)x.grow0 + r0 + 4 * k, (uint32_t)x.M - 1);
-      old[k] = *reinterpret_cast<const f32x4*>(q.out + (size_t)gr * D + c4 * 4);
-      a[k] = att[gr];
-      kb[k] = ((uint32_t)bits[(size_t)gr * KG + (c4 >> 1)] >> ((c4 & 1) * 4)) | bits_or;
-    }
-    __syncthreads();                             // every wave is done reading the tile
-    {
-      const int eW = *q.WxT.exp;
-#pragma unroll
-      for (int tt = 0; tt < RT; ++tt) {
-        const int row = x.arow(tt);
-        const float sc = h2_unscale(x.sE[row], eW);
-#pragma unroll
-        for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4*>(T + row * LDW + x.acol(c)) = acc[tt][c] * sc;
-      }
-    }
-    __syncthreads();
+    MACX_DSTAMP();                               // K loop done
     const DkbJob nj = next(job);
-    request(nj.valid ? nj : job, nj.valid);      // lands while the row pass runs
+    request(nj.valid ? nj : job, nj.valid);      // lands while the epilogue runs
     if (!(q.dbg & 8)) {
+      const bool write = job.write || (q.dbg & 2);
+      int z = 0;
+      asm volatile("" : "+v"(z));
+      const int ar = x.ar + z, ah = x.ah + z;
+      const uint32_t un = (uint32_t)x.N, q0 = (uint32_t)x.grow0 / un;
+      const uint32_t qb1 = (q0 + 1) * un;          // first row of the next question
+      // (N >= 64, dkb_fill_plan: a tile touches at most two questions)
+      const uint8_t* bits = q.bits ? q.bits + (size_t)job.s * q.bits_step : reinterpret_cast<const uint8_t*>(q.out);
+      const uint32_t bits_or = q.bits ? 0u : 0xFFu;
+      const float* att = q.att + (size_t)job.s * q.att_step;
+      const float* dinfo = x.sC + x.colbase + 4 * ah;      // [2][D] in LDS: the tile's first question and the one behind it
+      const int eW = *q.WxT.exp;
+      // the old values first (the longest round trip), then what the new contribution needs
+      f32x4 old[RT][CT];
+      uint32_t gr[RT];
 #pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        const int row = r0 + 4 * k;
-        const uint32_t gr = min((uint32_t)x.grow0 + row, (uint32_t)x.M - 1);
-        f32x4 dv = di[0];
+      for (int t = 0; t < RT; ++t) {
+        gr[t] = min((uint32_t)x.grow0 + x.rowbase + 16 * t + ar, (uint32_t)x.M - 1);
+        const float* o = q.out + (size_t)gr[t] * D + x.colbase + 4 * ah;
 #pragma unroll
-        for (int j = 1; j < C::G::QS; ++j) dv = gr >= qb1 + (uint32_t)(j - 1) * un ? di[j] : dv;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * LDW + c4 * 4);
-        f32x4 o;
+        for (int c = 0; c < CT; ++c) old[t][c] = *reinterpret_cast<const f32x4*>(o + 16 * c);
+      }
+      uint64_t kb8[RT];                            // the row's keep bytes of this wave's 64 columns
+      float a[RT], sc[RT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float m = ((kb[k] >> e) & 1u) ? v[e] * q.inv_keep : 0.f;
-          o[e] = fmaf(a[k], dv[e], m) + (write ? 0.f : old[k][e]);
+      for (int t = 0; t < RT; ++t) {
+        a[t] = att[gr[t]];
+        kb8[t] = *reinterpret_cast<const uint64_t*>(bits + (size_t)gr[t] * KG + (x.colbase >> 3));
+        sc[t] = h2_unscale(x.sE[x.rowbase + 16 * t + ar], eW);
+      }
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const int row = x.rowbase + 16 * t + ar;
+        const bool second = gr[t] >= qb1;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const f32x4 dv = *reinterpret_cast<const f32x4*>(dinfo + (second ? D : 0) + 16 * c);
+          const uint32_t nib = ((uint32_t)(kb8[t] >> (16 * c + 4 * ah)) | bits_or) & 0xFu;      // byte 2 c + (ah >> 1), its half ah & 1
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float m = ((nib >> e) & 1u) ? acc[t][c][e] * sc[t] * q.inv_keep : 0.f;
+            o[e] = fmaf(a[t], dv[e], m) + (write ? 0.f : old[t][c][e]);
+          }
+          if (row < x.nvalid) *reinterpret_cast<f32x4*>(q.out + ((size_t)x.grow0 + row) * D + x.colbase + 16 * c + 4 * ah) = o;
         }
-        if (row < x.nvalid) *reinterpret_cast<f32x4*>(q.out + (x.grow0 + row) * D + c4 * 4) = o;
       }
     }
+    MACX_DSTAMP();                               // epilogue issued
     if (!nj.valid) break;
     job = nj;
-    __syncthreads();                             // the next tile overwrites T
+    __syncthreads();                             // every wave is done with the tile and its exponents: the next one overwrites them
   }
 }
 

@@ -24,10 +24,11 @@ for i in range(4):
     cell = macx.MACCell(vecQuestions=vqd, questionWords=wd, questionCntxWords=wd, questionLengths=ld, knowledgeBase=kbd,
                         memoryDropout=cfg.memoryDropout, readDropout=cfg.readDropout, writeDropout=cfg.writeDropout, batchSize=B,
                         train=True, config=cfg, params=params, seed=1234 + i, b0=0)
-    run = RunCls(cell, True)
-    run.forward()
+    state = cell.run()
+    (state.memory.sum()).backward()
     torch.cuda.synchronize()
-saved = run.saved
+import gc
+saved = cell._run.saved if cell._run is not None else max((o for o in gc.get_objects() if isinstance(o, RunCls)), key=lambda o: o.saved.numel()).saved
 w = saved.view(torch.int32)[-576:].cpu().numpy().astype("uint32")
 t = w[32:48].astype("int64")
 print("pre_fill", v, "raw", t.tolist())
@@ -37,3 +38,6 @@ names = {0: "filler start", 1: "filler: write tiles done", 2: "filler: y signall
 base = min(f0, t0)
 for k in sorted(names):
     print("%-40s %10d ticks  (+%d)" % (names[k], t[k], (t[k] - base) & 0xFFFFFFFF))
+d = w[48:63].astype("int64")
+print("chain_bwd filler 0 of step 5 (dKB jobs): start | per job: tile in LDS, K loop done, staged, row pass issued -- ticks since start")
+print([int((v - d[0]) & 0xFFFFFFFF) if v else 0 for v in d])

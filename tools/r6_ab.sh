@@ -11,6 +11,6 @@ for r in 1 2; do
     (cd $D && rocprofv3 --kernel-trace -d $O/${TAG}_${T}_$r -o r -- $B > $O/${TAG}_${T}_$r.log 2>&1; python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $O/${TAG}_${T}_$r/r_results.db > $O/${TAG}_${T}_${r}_kernel_stats.txt; python $GRAFT_REPO_ROOT/tools/step_timeline.py $O/${TAG}_${T}_$r/r_results.db --brief | head -1 > $O/${TAG}_${T}_${r}_span.txt)
     rm -rf $O/${TAG}_${T}_$r
     echo "== $T round $r: $(cat $O/${TAG}_${T}_${r}_span.txt)"
-    grep -E "chain_fwd|chain_bwd|small_linear|TOTAL" $O/${TAG}_${T}_${r}_kernel_stats.txt | awk '{printf "   %-60s %6s %10s %9s %9s\n", substr($1,1,60), $2, $3, $4, $5}'
+    grep -E "chain_fwd|chain_bwd|chain_dkb|TOTAL" $O/${TAG}_${T}_${r}_kernel_stats.txt | awk '{printf "   %-60s %6s %10s %9s %9s\n", substr($1,1,60), $2, $3, $4, $5}'
   done
 done
