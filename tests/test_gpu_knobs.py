@@ -98,3 +98,21 @@ def test_fillers_of_chain_fwd_are_bit_identical(macx, dev, name, B, S, N, d, p):
             got = run(macx, dev, name, B, S, N, d, p, tune={"pre_fill": v})
             for k in ref:
                 assert torch.equal(got[k], ref[k]), (rep, v, k)
+
+
+@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 64, 7, 196, 512, 4), ("args", 128, 5, 196, 512, 2)])
+def test_fillers_of_chain_fwd_inference_and_two_rounds(macx, dev, name, B, S, N, d, p):
+    """Evaluation runs (nothing kept, no dropout: the fillers have no stage 0 to do, only the write linear and y) and B = 128 (392 tiles
+    = two rounds of the chip, 120 fillers dispatched in front of them): final state and attentions bit for bit against pre_fill = 0,
+    and the run's fail word (a tile or filler that gave up waiting) is zero."""
+    cfg, vq, words, lengths, kb = make_case(name, B, S, N, d, p)
+    out = {}
+    for v in (0, 1):
+        with torch.no_grad():
+            cell, params, _ = build_cell(macx, dev, cfg, vq, words, lengths, kb, False, seed=11, tune={"pre_fill": v})
+            state = cell.run()
+            torch.cuda.synchronize()
+            out[v] = [state.memory.clone(), state.control.clone()] + [a.clone() for a in cell.attentions["kb"]]
+            assert int(cell._run.saved.view(torch.int32)[-576 + 63]) == 0
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
