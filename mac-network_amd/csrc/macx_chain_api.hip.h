@@ -162,8 +162,14 @@ hipError_t chain_dkb_rest_launch(const ChainDkbP& q, int M, int N, int d, hipStr
 // MACX_TUNE_PRE_FILL: 1 (default) stage 0 of step i + 1 on the idle CUs of chain_fwd's launch of step i; 0 every launch its own
 inline int pre_fill_mode() { return tune_get(MACX_TUNE_PRE_FILL, 1); }
 inline int pre_fill_count(int d, size_t M, int ncu) {
-  if (!pre_fill_mode() || d != 512 || ncu <= 0 || chain_tile_rows(d, M) != 64) return 0;
+  if (!pre_fill_mode() || d != 512 || ncu <= 0) return 0;
   const int ntile = (int)chain_tiles(d, M);
+  if (chain_tile_rows(d, M) == 16) {
+    // 16-row tiles (small batches, data-parallel shards of 8 - 16 questions): at most one tile per CU and a third of a CU's LDS each,
+    // so fillers fit anywhere; a quarter of the chip takes the handful of linear tiles and 2 - 4 short stage-0 jobs each
+    return ncu >= 64 ? ncu / 4 : 0;
+  }
+  // 32- and 64-row tiles fill a CU's LDS: fillers are the CUs without a tile in the launch's last round
   const int idle = (ncu - ntile % ncu) % ncu;
   return idle * 6 >= ntile ? idle : 0;           // (a filler walks ntile / idle tiles at about a sixth of a chain tile's time each)
 }

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
     }
     x.convert_finish(v, m, x.sE, KBd);
   };
-  if constexpr (D == 512 && R == 64) {
+  if constexpr (D == 512) {
     // the first p.pre.nfill workgroups are fillers on the CUs the tile grid leaves idle (ChainPreP): this step's y, then stage 0 of
     // the NEXT step
 #ifdef MACX_FILL_PROF
@@ -641,8 +641,10 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
       const size_t Rp2 = (size_t)M + H2_PAD_ROWS;
       const int r = x.tid & 63, k0 = x.tid >> 6;
       const size_t gr = min(x.grow0 + r, (size_t)M - 1);
+      if (r < R) {
 #pragma unroll
-      for (int j = 0; j < KG / 8; ++j) x.sBits[r * C::G::BITS_LD + k0 + 8 * j] = p.bytes2[(size_t)(k0 + 8 * j) * Rp2 + gr];
+        for (int j = 0; j < KG / 8; ++j) x.sBits[r * C::G::BITS_LD + k0 + 8 * j] = p.bytes2[(size_t)(k0 + 8 * j) * Rp2 + gr];
+      }
     }
     x.load_tile(p.KBd, x.sE);
   } else {
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   // stage 2: H1 = act(X W1b + (X * y) W1a + b1)
   x.zero_acc(acc);
   x.template kloop<KV>(acc, p.W1b.planes);
-  constexpr bool YCOH = D == 512 && R == 64;      // y may come from this launch's fillers (ChainPreP): agent-scope loads
+  constexpr bool YCOH = D == 512;                 // y may come from this launch's fillers (ChainPreP): agent-scope loads
   if constexpr (YCOH) {
     MACX_STAMP((int)blockIdx.x == p.pre.nfill, 9);
     if (p.pre.ylin.n_out && x.tid == 0) {
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
   __syncthreads();
   x.emit(acc, false, p.I2);
   x.publish_rows(x.sE2, C::PASS_EPI, p.I2);
-  if constexpr (D == 512 && R == 64) MACX_STAMP((int)blockIdx.x == p.pre.nfill, 11);
+  if constexpr (D == 512) MACX_STAMP((int)blockIdx.x == p.pre.nfill, 11);
   if (x.tid < x.nvalid) {
     const int w0 = (x.tid / C::RPW) * C::NWC;
     float s = x.sPart[w0 * R + x.tid];
@@ -820,7 +822,7 @@ inline hipError_t chain_fwd_launch_t(const ChainFwdP& p, hipStream_t st, hipEven
   constexpr size_t lds = ChainGeo<D_, R_>::LDS;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
-  const int grid = (p.M + R_ - 1) / R_ + ((D_ == 512 && R_ == 64) ? p.pre.nfill : 0);
+  const int grid = (p.M + R_ - 1) / R_ + (D_ == 512 ? p.pre.nfill : 0);
   if (e0 && e1) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, e0, e1, 0, p);
   else hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
   return hipGetLastError();

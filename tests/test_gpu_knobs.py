@@ -86,7 +86,8 @@ def test_dkb_on_idle_cus_agrees_with_merged_launch(macx, dev, name, B, S, N, d, 
                 assert torch.equal(got[k], ref[k]), (v, k)
 
 
-@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 64, 7, 196, 512, 3), ("args", 43, 5, 196, 512, 2), ("args3", 50, 5, 170, 512, 4)])
+@pytest.mark.parametrize("name,B,S,N,d,p", [("args", 64, 7, 196, 512, 3), ("args", 43, 5, 196, 512, 2), ("args3", 50, 5, 170, 512, 4),
+                                            ("args", 8, 7, 196, 512, 3), ("args", 24, 5, 196, 512, 3), ("args", 5, 5, 49, 512, 4)])
 def test_fillers_of_chain_fwd_are_bit_identical(macx, dev, name, B, S, N, d, p):
     """pre_fill: the filler workgroups of chain_fwd's launch of step i run step i - 1's write unit, step i's y = md Wy + by (results
     handed to the tiles of the SAME launch through counters and agent-scope loads / stores) and stage 0 of step i + 1 (default 1;
