@@ -558,8 +558,8 @@ __global__ __launch_bounds__(512) void chain_fwd_kernel(const ChainFwdP p) {
     x.convert_finish(v, m, x.sE, KBd);
   };
   if constexpr (D == 512) {
-    // the first p.pre.nfill workgroups are fillers on the CUs the tile grid leaves idle (ChainPreP): this step's y, then stage 0 of
-    // the NEXT step
+    // the first p.pre.nfill workgroups are fillers on the CUs the tile grid leaves idle (ChainPreP): the previous step's write-unit
+    // linear, this step's y (both handed to the tiles of this launch through counters), then stage 0 of the NEXT step
 #ifdef MACX_FILL_PROF
 #define MACX_STAMP(cond, k) do { if ((cond) && p.pre.step == 5 && p.pre.fail && x.tid == 0) p.pre.fail[-31 + (k)] = (uint32_t)__builtin_readcyclecounter(); } while (0)
 #else
