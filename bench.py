@@ -843,7 +843,9 @@ def main():
                     "kernel_ms": round(k_ms, 4),
                     "kernel_ms_how": ("start / stop HIP events of each chain launch of a running forward pass on the launch stream "
                                       "(hipExtLaunchKernelGGL: the kernel's own timestamps; macx_cell_forward_chain_time), median of 5 "
-                                      "passes x %d launches" % p) if chain_ms is not None
+                                      "passes x %d launches.  Since round 6 a launch also carries the filler workgroups on the CUs its "
+                                      "tile grid leaves idle (the previous step's write linear, this step's y, the next step's stage 0: "
+                                      "DESIGN 3.0); the FLOPs counted are the tiles' four products only" % p) if chain_ms is not None
                                      else "HIP events around %d back-to-back launches" % nrep,
                     "algorithmic_flops_per_launch": k_flops,
                     "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("source"), "profile_file": prof.get("file"),
