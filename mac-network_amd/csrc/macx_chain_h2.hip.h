@@ -1046,6 +1046,12 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       return;
     }
   }
+#ifdef MACX_FILL_PROF
+#define MACX_BSTAMP(k) do { if (p.dkb.prof && p.dkb.step == 5 && blockIdx.x == 0 && x.tid == 0) p.dkb.prof[336 + (k)] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define MACX_BSTAMP(k) do { } while (0)
+#endif
+  MACX_BSTAMP(0);
 
   // =====================================================================================================================
   // stage B0 (SURVEY appendix A rows "softmax", "logit", "ctrl-mul"):
@@ -1253,6 +1259,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
     }
     x.convert_finish_blk(mx, p.dI2, x.sE);
   }
+  MACX_BSTAMP(1);                             // B0 done
   if (p.dbg & 1) return;
 
   f32x4 acc[RT][CT];
@@ -1261,6 +1268,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   // stage B1: dI1 = (dI2 W2^T) * act'(H1), act' from the kept activation OUTPUT
   x.zero_acc(acc);
   x.template kloop<KV>(acc, p.W2T.planes);
+  MACX_BSTAMP(2);                             // B1 product done
   {
     const int eW = *p.W2T.exp;
     const size_t Rp = p.H1.Rp();
@@ -1299,12 +1307,14 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   x.publish_rows(x.sE, C::PASS_EPI, p.dI1);
   x.colsum_finish(p.db1_part + tile * D);
   __syncthreads();
+  MACX_BSTAMP(3);                             // B1 epilogue done
   if (p.dbg & 2) return;
 
   // =====================================================================================================================
   // stage B2: dX = (dI1 W1a^T) * y + dI1 W1b^T   (ops.py:703: d(x*y)/dx = y per column, per question)
   x.zero_acc(acc);
   x.template kloop<KV>(acc, p.W1aT.planes);
+  MACX_BSTAMP(4);                             // B2 first product done
   if (p.dy_part) {
     const int q0 = (int)((uint32_t)x.grow0 / (uint32_t)p.N), q1 = (int)(((uint32_t)x.grow0 + x.nvalid - 1) / (uint32_t)p.N);
     const int nq = q1 - q0 + 1;                          // <= 3: the caller asks for this only when N >= 32
@@ -1369,7 +1379,9 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
       }
     }
   }
+  MACX_BSTAMP(5);                             // dy sums and the y scaling done
   x.template kloop<KV>(acc, p.W1bT.planes);
+  MACX_BSTAMP(6);                             // B2 second product done
   {
     const int eW = *p.W1bT.exp;
 #pragma unroll
@@ -1385,6 +1397,7 @@ __global__ __launch_bounds__(512) void chain_bwd_kernel(const ChainBwdP p) {
   x.emit(acc, false, p.dX);
   x.publish_rows(x.sE2, C::PASS_EPI, p.dX);
   x.colsum_finish(p.dbx_part + tile * D);
+  MACX_BSTAMP(7);                             // dX emitted
   if (C::NWR == 2 && p.dy_part) {                       // the two row halves of the dy partials (staged before the last product)
     const int nq = (int)(((uint32_t)x.grow0 + x.nvalid - 1) / (uint32_t)p.N) - (int)((uint32_t)x.grow0 / (uint32_t)p.N) + 1;
     for (int i = x.tid; i < nq * D; i += 512) p.dy_part[tile * 3 * D + i] = x.sW[i] + x.sW[3 * D + i];

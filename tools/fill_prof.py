@@ -41,3 +41,7 @@ for k in sorted(names):
 d = w[48:63].astype("int64")
 print("chain_bwd filler 0 of step 5 (dKB jobs): start | per job: tile in LDS, K loop done, staged, row pass issued -- ticks since start")
 print([int((v - d[0]) & 0xFFFFFFFF) if v else 0 for v in d])
+b = w[48 + 336:48 + 336 + 8].astype("int64")
+print("chain_bwd tile 0 of step 5: start, B0 done, B1 product, B1 epilogue, B2 product 1, dy + y scaling, B2 product 2, dX emitted -- ticks since start")
+print([int((v - b[0]) & 0xFFFFFFFF) if v else 0 for v in b])
+
