@@ -335,3 +335,12 @@ def test_product_code_never_touches_the_debug_knobs():
         assert not re.search(r"inline int&\s+\w+\(\)\s*\{\s*static int", src.replace("gemm_default_mode", "")), path
 
 
+
+
+def test_tune_keys_match_the_header():
+    """macx._lib.TUNE (names -> indices of macx_opts.tune) is the MACX_TUNE_* enumeration of include/macx.h, key for key."""
+    import macx
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "macx.h")).read()
+    enum = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"MACX_TUNE_([A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
+    assert enum == dict(macx._lib.TUNE)
+    assert len(set(enum.values())) == len(enum) and max(enum.values()) < 16
